@@ -1,0 +1,184 @@
+/*
+ * msk_physx.h — C ABI of the MI355X-native batched rigid-body backend.
+ *
+ * This is the drop-in boundary for the ManiSkill hot path `PhysxGpuSystem.step()`
+ * (reference: mani_skill/envs/scene.py:379-380) and the buffer / apply / fetch /
+ * contact-query contract around it (mani_skill/envs/scene.py:902-986, 741-801;
+ * mani_skill/utils/structs/base.py:103-144; structs/articulation.py:723-921).
+ *
+ * The reference reaches this functionality through the `sapien.physx` Python module
+ * (pybind11 over PhysX 5, not in the reference tree).  Every entry point below names
+ * the `sapien.physx` call it stands in for.  Signatures use only plain pointers and
+ * sizes; device pointers returned by msk_buffer() are wrapped zero-copy by the host
+ * language (torch.from_blob-style).
+ *
+ * One msk_ctx == one `PhysxGpuSystem` == all sub-scenes ("envs") of one process/GPU.
+ * All envs share ONE template (same bodies / shapes / joints); state differs per env.
+ * Thread model: single host thread (as in the reference); kernels are enqueued on the
+ * hipStream_t handed to each call (torch's current stream).
+ *
+ * Return convention: int functions return >= 0 on success (often an id) and a negative
+ * msk_status on failure; msk_last_error() gives the text.
+ */
+#ifndef MSK_PHYSX_H
+#define MSK_PHYSX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct msk_ctx msk_ctx;
+
+enum msk_status {
+  MSK_OK = 0,
+  MSK_ERR_INVALID = -1,   /* bad argument / wrong phase (e.g. add_* after finalize)   */
+  MSK_ERR_CAPACITY = -2,  /* template exceeds a compile-time capacity (MSK_MAX_*)     */
+  MSK_ERR_HIP = -3,       /* a HIP runtime call failed                                */
+  MSK_ERR_OVERFLOW = -4   /* per-env contact capacity exceeded during step()          */
+};
+
+enum msk_joint_type { MSK_JOINT_FIXED = 0, MSK_JOINT_REVOLUTE = 1, MSK_JOINT_PRISMATIC = 2 };
+enum msk_body_kind { MSK_BODY_KINEMATIC = 1, MSK_BODY_DYNAMIC = 2, MSK_BODY_LINK = 3 };
+enum msk_shape_type { MSK_SHAPE_PLANE = 0, MSK_SHAPE_BOX = 1, MSK_SHAPE_SPHERE = 2, MSK_SHAPE_CONVEX = 3 };
+
+/* Capacities of one env template (compile-time, shared by oracle and HIP library). */
+#define MSK_MAX_BODIES 48
+#define MSK_MAX_SHAPES 64
+#define MSK_MAX_DOF 16        /* articulation DoF per env (all articulations)         */
+#define MSK_MAX_NV 32         /* generalized velocity size: art DoF + 6 per free body */
+#define MSK_MAX_PAIRS 512     /* candidate shape pairs after static filtering         */
+#define MSK_MAX_CONTACTS 48   /* contact points per env per step                      */
+#define MSK_MAX_HULL_VERTS 64
+#define MSK_MAX_TENDONS 4
+
+/* Scene / solver configuration.  Mirrors what ManiSkill pushes through
+ * physx.set_scene_config / set_body_config / set_shape_config / PhysxGpuSystem.timestep
+ * (mani_skill/envs/sapien_env.py:1173-1180,1227; structs/types.py:35-90). */
+typedef struct msk_config {
+  float timestep;             /* 1 / sim_freq                                          */
+  float gravity[3];
+  int32_t solver_position_iterations;
+  int32_t solver_velocity_iterations;
+  float contact_offset;       /* per shape; a pair generates contacts below offA+offB  */
+  float rest_offset;
+  float bounce_threshold;     /* accepted; restitution is 0 in every scoped task       */
+  float sleep_threshold;      /* accepted; sleeping not modelled                       */
+  int32_t enable_tgs;         /* must be 1                                             */
+  int32_t enable_pcm;         /* accepted                                              */
+  int32_t reserved[6];
+} msk_config;
+
+/* ---- lifetime -------------------------------------------------------------------- */
+/* sapien.physx.PhysxGpuSystem(device)  (sapien_env.py:1187) */
+msk_ctx* msk_create(int hip_device, const msk_config* cfg);
+/* scene teardown (sapien_env.py:1232-1243) */
+void msk_destroy(msk_ctx* ctx);
+const char* msk_last_error(msk_ctx* ctx);
+
+/* ---- template build phase (host only; before msk_finalize) ------------------------ */
+/* PhysxArticulation creation via ArticulationBuilder.build (building/articulation_builder.py:114).
+ * root_pose = [px py pz qw qx qy qz]; fixed base.  Returns articulation index. */
+int msk_add_articulation(msk_ctx* ctx, const float root_pose[7]);
+/* PhysxArticulationLinkComponent(parent) + joint record (articulation_builder.py:65-112).
+ * parent_body = -1 for the root link.  Joint axis is +x of the joint frame (SAPIEN
+ * convention): child pose = parent pose * pose_in_parent * J_x(q) * inv(pose_in_child).
+ * inertia6 = [ixx iyy izz ixy ixz iyz] about the COM, in link axes.  Returns body id. */
+int msk_add_link(msk_ctx* ctx, int art, int parent_body, int joint_type,
+                 const float pose_in_parent[7], const float pose_in_child[7],
+                 float limit_lo, float limit_hi, float mass, const float com[3],
+                 const float inertia6[6], int disable_gravity, float armature,
+                 float joint_friction);
+/* PhysxArticulationJoint.set_drive_properties (agents/controllers/pd_joint_pos.py:38-52) */
+int msk_set_drive(msk_ctx* ctx, int link_body, float stiffness, float damping,
+                  float force_limit, int mode_acceleration);
+/* PhysxArticulation.create_fixed_tendon for URDF mimic joints
+ * (articulation_builder.py:161-200): soft constraint
+ * coef_a*q(link_a) + coef_b*q(link_b) = rest, with the given stiffness/damping. */
+int msk_add_tendon(msk_ctx* ctx, int link_a, int link_b, float coef_a, float coef_b,
+                   float rest, float stiffness, float damping);
+/* PhysxRigidDynamicComponent / kinematic actors (building/actor_builder.py:193-261).
+ * Returns body id. */
+int msk_add_actor(msk_ctx* ctx, int kind, const float pose[7], float mass,
+                  const float com[3], const float inertia6[6], float linear_damping,
+                  float angular_damping, int disable_gravity);
+/* PhysxCollisionShape* + body.attach(shape) (actor_builder.py:57-164).  body = -1
+ * attaches to the static world (PhysxRigidStaticComponent).  params: box half sizes /
+ * sphere radius / unused.  verts (convex only): nverts*3 floats in shape-local
+ * coordinates, scale already applied, nverts <= MSK_MAX_HULL_VERTS.  Plane normal is
+ * +x of the shape frame (SAPIEN convention, building/ground.py:38-40). */
+int msk_add_shape(msk_ctx* ctx, int body, int type, const float local_pose[7],
+                  const float params[3], const float* verts, int nverts,
+                  float static_friction, float dynamic_friction, float restitution,
+                  const uint32_t groups[4], float patch_radius, float min_patch_radius);
+/* SRDF <disable_collisions> (panda_v2.srdf) */
+int msk_disable_collision(msk_ctx* ctx, int body_a, int body_b);
+/* PhysxGpuSystem.gpu_init() (envs/scene.py:910): freeze the template, replicate it for
+ * num_envs sub-scenes, allocate and upload everything. */
+int msk_finalize(msk_ctx* ctx, int num_envs);
+/* PhysxGpuSystem.set_scene_offset (sapien_env.py:1202): offsets = num_envs*3 host floats,
+ * added to positions on fetch and subtracted on apply. */
+int msk_set_scene_offsets(msk_ctx* ctx, const float* offsets);
+
+/* ---- buffers (device pointers, valid until msk_destroy) --------------------------- */
+enum msk_buffer_id {
+  MSK_BUF_RIGID_BODY_DATA = 0, /* px.cuda_rigid_body_data: (num_envs*NB, 13) f32
+                                  [p(3) q(wxyz) v(3) w(3)], row = env*NB + body id       */
+  MSK_BUF_ART_QPOS = 1,        /* px.cuda_articulation_qpos: (num_envs*NA, max_dof) f32 */
+  MSK_BUF_ART_QVEL = 2,
+  MSK_BUF_ART_QACC = 3,
+  MSK_BUF_ART_QF = 4,
+  MSK_BUF_ART_TARGET_QPOS = 5, /* px.cuda_articulation_target_qpos                      */
+  MSK_BUF_ART_TARGET_QVEL = 6,
+  MSK_BUF_COUNT = 7
+};
+void* msk_buffer(msk_ctx* ctx, int buffer_id, int64_t shape[2]);
+
+/* ---- apply / fetch / step (async on `stream`; a hipStream_t passed as void*) ------- */
+enum msk_apply_mask {
+  MSK_APPLY_RIGID_DATA = 1 << 0,   /* gpu_apply_rigid_dynamic_data                       */
+  MSK_APPLY_ART_QPOS = 1 << 1,     /* gpu_apply_articulation_qpos                        */
+  MSK_APPLY_ART_QVEL = 1 << 2,     /* gpu_apply_articulation_qvel                        */
+  MSK_APPLY_ART_QF = 1 << 3,       /* gpu_apply_articulation_qf                          */
+  MSK_APPLY_ART_TARGET_QPOS = 1 << 4, /* gpu_apply_articulation_target_position          */
+  MSK_APPLY_ART_TARGET_QVEL = 1 << 5, /* gpu_apply_articulation_target_velocity          */
+  MSK_APPLY_ART_ROOT_POSE = 1 << 6    /* gpu_apply_articulation_root_pose (root link row) */
+};
+enum msk_fetch_mask {
+  MSK_FETCH_RIGID_DATA = 1 << 0,   /* gpu_fetch_rigid_dynamic_data + link_pose/velocity  */
+  MSK_FETCH_ART_QPOS = 1 << 1,
+  MSK_FETCH_ART_QVEL = 1 << 2,
+  MSK_FETCH_ART_QACC = 1 << 3,
+  MSK_FETCH_ART_TARGETS = 1 << 4
+};
+int msk_apply(msk_ctx* ctx, uint32_t mask, void* stream);
+int msk_fetch(msk_ctx* ctx, uint32_t mask, void* stream);
+/* PhysxGpuSystem.gpu_update_articulation_kinematics (sapien_env.py:959,1304) */
+int msk_update_kinematics(msk_ctx* ctx, void* stream);
+/* PhysxGpuSystem.step() (envs/scene.py:379-380): one substep of `timestep` for all envs. */
+int msk_step(msk_ctx* ctx, void* stream);
+
+/* ---- contact impulse queries (envs/scene.py:771-781) ------------------------------ */
+/* gpu_create_contact_pair_impulse_query(body_pairs): body ids are template body ids, the
+ * same pair is queried in every env.  Output buffer (num_envs*npairs, 3) f32, row =
+ * env*npairs + pair; value = sum of contact impulses of the last step() applied ON
+ * body_a BY body_b.  Returns query id. */
+int msk_query_create_pairs(msk_ctx* ctx, const int32_t* body_pairs, int npairs);
+void* msk_query_buffer(msk_ctx* ctx, int query, int64_t shape[2]);
+/* gpu_query_contact_pair_impulses(query) */
+int msk_query_run(msk_ctx* ctx, int query, void* stream);
+
+/* ---- inspection (parity tests; synchronous, host output) --------------------------- */
+/* Template sizes: out[0]=NB bodies, out[1]=NA articulations, out[2]=max_dof, out[3]=nv,
+ * out[4]=number of shapes, out[5]=number of candidate pairs, out[6]=num_envs. */
+int msk_get_sizes(msk_ctx* ctx, int32_t out[8]);
+/* Contacts generated by the last step() in env `env`: for each contact point
+ * ids[3*i..] = {shape_a, shape_b, body-pair slot}, vals[8*i..] = {pos(3), normal(3), separation,
+ * normal impulse}.  Returns the number of points (<= max_points written). */
+int msk_get_contacts(msk_ctx* ctx, int env, int32_t* ids, float* vals, int max_points);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSK_PHYSX_H */

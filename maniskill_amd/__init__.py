@@ -1,0 +1,12 @@
+"""maniskill_amd — MI355X-native batched rigid-body backend for ManiSkill's hot path.
+
+Scope: the physics substep behind ``PhysxGpuSystem.step()`` and the
+buffer/apply/fetch/contact-query contract around it, as hand-written HIP kernels behind a
+C ABI (include/msk_physx.h), plus the thin Python host that mirrors the reference's
+``sapien.physx`` / ``BaseEnv`` interfaces for that path.  No CPU fallback lives here.
+"""
+import os
+
+PACKAGE_DIR = os.path.dirname(os.path.abspath(__file__))
+PACKAGE_ASSET_DIR = os.path.join(PACKAGE_DIR, "assets")
+__version__ = "0.1.0"

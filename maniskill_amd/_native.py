@@ -1,0 +1,117 @@
+"""ctypes binding of the C ABI declared in include/msk_physx.h.
+
+The product path loads ``maniskill_amd/csrc/libmsk_physx.so`` (hand-written HIP kernels for
+gfx950) and FAILS LOUDLY when it is missing: there is no CPU fallback in this package.
+``NativeLib`` itself is prefix-generic so that the test-suite can bind the CPU oracle
+(``oracle/liborc.so``, prefix ``orc_``) behind the same Python classes; nothing under
+``maniskill_amd/`` ever does that.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "csrc", "libmsk_physx.so")
+
+# enums of include/msk_physx.h
+JOINT_FIXED, JOINT_REVOLUTE, JOINT_PRISMATIC = 0, 1, 2
+BODY_KINEMATIC, BODY_DYNAMIC, BODY_LINK = 1, 2, 3
+SHAPE_PLANE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_CONVEX = 0, 1, 2, 3
+(BUF_RIGID_BODY_DATA, BUF_ART_QPOS, BUF_ART_QVEL, BUF_ART_QACC, BUF_ART_QF, BUF_ART_TARGET_QPOS,
+ BUF_ART_TARGET_QVEL) = range(7)
+APPLY_RIGID_DATA, APPLY_ART_QPOS, APPLY_ART_QVEL, APPLY_ART_QF = 1, 2, 4, 8
+APPLY_ART_TARGET_QPOS, APPLY_ART_TARGET_QVEL, APPLY_ART_ROOT_POSE = 16, 32, 64
+FETCH_RIGID_DATA, FETCH_ART_QPOS, FETCH_ART_QVEL, FETCH_ART_QACC, FETCH_ART_TARGETS = 1, 2, 4, 8, 16
+
+EXPORTS = [
+    "create", "destroy", "last_error", "add_articulation", "add_link", "set_drive", "add_tendon",
+    "add_actor", "add_shape", "disable_collision", "finalize", "set_scene_offsets", "buffer", "apply",
+    "fetch", "update_kinematics", "step", "query_create_pairs", "query_buffer", "query_run",
+    "get_sizes", "get_contacts",
+]
+
+
+class MskConfig(C.Structure):
+    _fields_ = [
+        ("timestep", C.c_float),
+        ("gravity", C.c_float * 3),
+        ("solver_position_iterations", C.c_int32),
+        ("solver_velocity_iterations", C.c_int32),
+        ("contact_offset", C.c_float),
+        ("rest_offset", C.c_float),
+        ("bounce_threshold", C.c_float),
+        ("sleep_threshold", C.c_float),
+        ("enable_tgs", C.c_int32),
+        ("enable_pcm", C.c_int32),
+        ("reserved", C.c_int32 * 6),
+    ]
+
+
+def _fa(values, n=None):
+    vals = [float(v) for v in values]
+    if n is not None and len(vals) != n:
+        raise ValueError(f"expected {n} floats, got {len(vals)}")
+    return (C.c_float * len(vals))(*vals)
+
+
+class NativeLib:
+    """One loaded shared library exporting ``<prefix><name>`` for every name in EXPORTS."""
+
+    def __init__(self, path: str = DEFAULT_LIB, prefix: str = "msk_"):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"native backend library not found: {path}. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950); "
+                "maniskill_amd has no CPU fallback."
+            )
+        self.path, self.prefix = path, prefix
+        self.dll = C.CDLL(path)
+        f = lambda name: getattr(self.dll, prefix + name)  # noqa: E731
+        vp, i32, f32, u32 = C.c_void_p, C.c_int, C.c_float, C.c_uint32
+        fp = C.POINTER(C.c_float)
+        sig = {
+            "create": (vp, [i32, C.POINTER(MskConfig)]),
+            "destroy": (None, [vp]),
+            "last_error": (C.c_char_p, [vp]),
+            "add_articulation": (i32, [vp, fp]),
+            "add_link": (i32, [vp, i32, i32, i32, fp, fp, f32, f32, f32, fp, fp, i32, f32, f32]),
+            "set_drive": (i32, [vp, i32, f32, f32, f32, i32]),
+            "add_tendon": (i32, [vp, i32, i32, f32, f32, f32, f32, f32]),
+            "add_actor": (i32, [vp, i32, fp, f32, fp, fp, f32, f32, i32]),
+            "add_shape": (i32, [vp, i32, i32, fp, fp, fp, i32, f32, f32, f32, C.POINTER(u32), f32, f32]),
+            "disable_collision": (i32, [vp, i32, i32]),
+            "finalize": (i32, [vp, i32]),
+            "set_scene_offsets": (i32, [vp, fp]),
+            "buffer": (vp, [vp, i32, C.POINTER(C.c_int64)]),
+            "apply": (i32, [vp, u32, vp]),
+            "fetch": (i32, [vp, u32, vp]),
+            "update_kinematics": (i32, [vp, vp]),
+            "step": (i32, [vp, vp]),
+            "query_create_pairs": (i32, [vp, C.POINTER(C.c_int32), i32]),
+            "query_buffer": (vp, [vp, i32, C.POINTER(C.c_int64)]),
+            "query_run": (i32, [vp, i32, vp]),
+            "get_sizes": (i32, [vp, C.POINTER(C.c_int32)]),
+            "get_contacts": (i32, [vp, i32, C.POINTER(C.c_int32), fp, i32]),
+        }
+        for name, (res, args) in sig.items():
+            fn = f(name)
+            fn.restype, fn.argtypes = res, args
+            setattr(self, name, fn)
+
+    def check(self, ctx, code: int, what: str) -> int:
+        if code < 0:
+            msg = self.last_error(ctx)
+            raise RuntimeError(f"{self.prefix}{what} failed ({code}): {msg.decode() if msg else ''}")
+        return code
+
+
+_default = None
+
+
+def default_lib() -> NativeLib:
+    """The HIP backend.  Raises RuntimeError if the extension has not been built."""
+    global _default
+    if _default is None:
+        _default = NativeLib(DEFAULT_LIB, "msk_")
+    return _default

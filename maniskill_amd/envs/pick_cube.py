@@ -1,0 +1,361 @@
+"""PickCube-v1 on the MI355X-native backend: host-side mirror of the reference hot path.
+
+Mirrors, with the same names and semantics (rows A1-A8 of SURVEY.md §8a):
+  * BaseEnv.reset / step / _step_action / get_obs / get_state   mani_skill/envs/sapien_env.py:857-978,1042-1132,501-560,1272-1325
+  * TimeLimitWrapper (max_episode_steps=50)                     mani_skill/utils/registration.py:127-168
+  * PickCubeEnv                                                 mani_skill/envs/tasks/tabletop/pick_cube.py:35-195
+  * Panda.is_grasping / is_static / tcp_pose                    mani_skill/agents/robots/panda/panda.py:237-277
+  * pd_joint_delta_pos = PDJointPos(use_delta) arm + PDJointPosMimic gripper
+                                                                mani_skill/agents/controllers/pd_joint_pos.py:76-93,207-228
+  * TableSceneBuilder.initialize                                mani_skill/utils/scene_builder/table/scene_builder.py:67-103
+
+Everything here is torch indexing over the backend's zero-copy buffers; the physics is
+``self.px.step()`` (HIP kernels behind include/msk_physx.h).  Because rows are env-major,
+``rigid_body_data.view(N, 18, 13)[:, body]`` is a strided view, not a gather.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ..physx import PhysxGpuSystem, SimConfig
+from . import scene_builders as sb
+
+
+# --------------------------------------------------------------------------------------
+# counter-based RNG: partition-invariant episode randomness (seed 2022 + global env index,
+# reference: sapien_env.py:321,327 and envs/utils/randomization/batched_rng.py:13-70)
+# --------------------------------------------------------------------------------------
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+class BatchedRNG:
+    """One independent stream per env, keyed by (seed, episode counter, draw counter)."""
+
+    def __init__(self, seeds: np.ndarray):
+        self.seeds = np.asarray(seeds, dtype=np.uint64)
+        self.counter = np.zeros_like(self.seeds)
+
+    def reseed(self, idx: np.ndarray, seeds: np.ndarray):
+        self.seeds[idx] = np.asarray(seeds, dtype=np.uint64)
+        self.counter[idx] = 0
+
+    def _bits(self, idx: np.ndarray, n: int) -> np.ndarray:
+        with np.errstate(over="ignore"):
+            base = _splitmix64(self.seeds[idx] * np.uint64(0x2545F4914F6CDD1D) + self.counter[idx])
+            k = np.arange(1, n + 1, dtype=np.uint64)[None, :]
+            out = _splitmix64(base[:, None] + k * np.uint64(0xD1342543DE82EF95))
+        self.counter[idx] += np.uint64(n)
+        return out
+
+    def uniform(self, idx: np.ndarray, n: int) -> np.ndarray:
+        """(len(idx), n) float64 in [0, 1)."""
+        return (self._bits(idx, n) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+    def normal(self, idx: np.ndarray, n: int) -> np.ndarray:
+        u = self.uniform(idx, 2 * n)
+        u1, u2 = 1.0 - u[:, :n], u[:, n:]
+        return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def _quat_to_y_axis(q: torch.Tensor) -> torch.Tensor:
+    """Second column of the rotation matrix of wxyz quaternions (Pose.to_transformation_matrix()[..., :3, 1])."""
+    w, x, y, z = q.unbind(-1)
+    return torch.stack([2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x)], dim=-1)
+
+
+def compute_angle_between(x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """utils/common.py:300-304 (normalize_vector uses eps 1e-8)."""
+    n1 = x1 / torch.linalg.norm(x1, dim=1, keepdim=True).clamp_min(1e-8)
+    n2 = x2 / torch.linalg.norm(x2, dim=1, keepdim=True).clamp_min(1e-8)
+    return torch.arccos(torch.clip((n1 * n2).sum(1), -1, 1))
+
+
+class PickCubeEnv:
+    """PickCube-v1, state observations, ``pd_joint_delta_pos`` control, Panda.
+
+    ``num_envs`` sub-scenes live on one device in one ``PhysxGpuSystem``.  The constructor
+    argument ``px_factory`` exists for the test-suite (it injects the CPU oracle); the
+    product path always builds ``PhysxGpuSystem`` on a GPU and raises if the HIP library
+    is missing.
+    """
+
+    max_episode_steps = 50
+    goal_thresh = 0.025
+    cube_half_size = 0.02
+    cube_spawn_half_size = 0.1
+    cube_spawn_center = (0.0, 0.0)
+    max_goal_height = 0.3
+    arm_delta = 0.1                      # arm_pd_joint_delta_pos lower/upper (panda.py:90-98)
+    gripper_low, gripper_high = -0.01, 0.04  # gripper_pd_joint_pos (panda.py:177-185)
+    action_dim = 8
+    obs_dim = 42
+
+    def __init__(self, num_envs: int = 1, device: Optional[str] = None, sim_config: Optional[SimConfig] = None,
+                 robot_init_qpos_noise: float = 0.02, reward_mode: str = "normalized_dense",
+                 env_index_offset: int = 0, px_factory=None):
+        self.num_envs = int(num_envs)
+        self.sim_config = sim_config or SimConfig()
+        self.robot_init_qpos_noise = robot_init_qpos_noise
+        self.reward_mode = reward_mode
+        self.env_index_offset = int(env_index_offset)
+        assert self.sim_config.sim_freq % self.sim_config.control_freq == 0
+        self._sim_steps_per_control = self.sim_config.sim_freq // self.sim_config.control_freq
+        tpl, ids = sb.build_pick_cube_template(self.cube_half_size)
+        self.template, self.ids = tpl, ids
+        if px_factory is None:
+            if device is None:
+                device = "cuda"
+            dev = torch.device(device)
+            if dev.type != "cuda":
+                raise RuntimeError("maniskill_amd runs its physics on an AMD GPU (device 'cuda[:k]'); there is no CPU backend")
+            self.px = PhysxGpuSystem(dev, tpl, self.num_envs, self.sim_config)
+        else:
+            self.px = px_factory(tpl, self.num_envs, self.sim_config)
+        self.device = self.px.device
+        self.px.gpu_init()
+        # sub-scene grid offsets (sapien_env.py:1191-1202)
+        side = int(np.ceil(np.sqrt(self.num_envs)))
+        g = np.arange(self.num_envs)
+        offsets = np.stack([(g % side - side // 2) * self.sim_config.spacing,
+                            (g // side - side // 2) * self.sim_config.spacing, np.zeros(self.num_envs)], axis=1)
+        self.px.set_scene_offsets(offsets)
+        N, NB = self.num_envs, self.px.bodies_per_env
+        self._rbd = self.px.cuda_rigid_body_data.torch().view(N, NB, 13)
+        self._qpos = self.px.cuda_articulation_qpos.torch().view(N, -1)
+        self._qvel = self.px.cuda_articulation_qvel.torch().view(N, -1)
+        self._target_qpos_buf = self.px.cuda_articulation_target_qpos.torch().view(N, -1)
+        b = tpl.body_id
+        self._b_cube, self._b_goal, self._b_table = ids["cube"], ids["goal_site"], ids["table"]
+        self._b_root = b("panda_link0")
+        self._b_tcp = b("panda_hand_tcp")
+        self._b_f1, self._b_f2 = b("panda_leftfinger"), b("panda_rightfinger")
+        self._q_lgrasp = self.px.gpu_create_contact_pair_impulse_query([(self._b_f1, self._b_cube)])
+        self._q_rgrasp = self.px.gpu_create_contact_pair_impulse_query([(self._b_f2, self._b_cube)])
+        self._offsets = self.px.scene_offsets  # (N, 3)
+        dev = self.device
+        self._rest_qpos = torch.tensor(sb.PANDA_REST_QPOS, dtype=torch.float32, device=dev)
+        self._table_pose = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)],
+                                        dtype=torch.float32, device=dev)
+        self._root_pose = torch.tensor([-0.615, 0.0, 0.0, 1, 0, 0, 0], dtype=torch.float32, device=dev)
+        self._elapsed_steps = torch.zeros(N, dtype=torch.int32, device=dev)
+        self._target_qpos = torch.zeros(N, 9, dtype=torch.float32, device=dev)
+        self._main_seeds = 2022 + self.env_index_offset + np.arange(N)
+        self._rng = BatchedRNG(self._main_seeds)
+        self._episode_count = np.zeros(N, dtype=np.uint64)
+        self.action_low = -torch.ones(self.action_dim, device=dev)
+        self.action_high = torch.ones(self.action_dim, device=dev)
+        self.reset(seed=None)
+
+    # ---------------------------------------------------------------- struct-style views
+    def _pose(self, body):  # Actor.pose / Link.pose .raw_pose with the scene offset removed (actor.py:341-365)
+        raw = self._rbd[:, body, :7].clone()
+        raw[:, :3] -= self._offsets
+        return raw
+
+    @property
+    def cube_pose(self): return self._pose(self._b_cube)
+    @property
+    def goal_pos(self): return self._rbd[:, self._b_goal, :3] - self._offsets
+    @property
+    def tcp_pose(self): return self._pose(self._b_tcp)
+    @property
+    def qpos(self): return self._qpos[:, :9]
+    @property
+    def qvel(self): return self._qvel[:, :9]
+
+    # ---------------------------------------------------------------- reset
+    def reset(self, seed=None, options: Optional[dict] = None):
+        options = options or {}
+        dev = self.device
+        if "env_idx" in options:
+            env_idx = torch.as_tensor(options["env_idx"], device=dev, dtype=torch.long)
+        else:
+            env_idx = torch.arange(self.num_envs, device=dev)
+        idx_np = env_idx.cpu().numpy()
+        if seed is not None:
+            seeds = (np.asarray(seed).reshape(-1) if not np.isscalar(seed) else np.array([seed])).astype(np.int64)
+            if len(seeds) == 1:
+                seeds = seeds[0] + self.env_index_offset + idx_np
+            self._main_seeds[idx_np] = seeds
+            self._episode_count[idx_np] = 0
+        # episode seed = f(main seed, episode counter)
+        self._rng.reseed(idx_np, self._main_seeds[idx_np].astype(np.uint64) * np.uint64(1000003) + self._episode_count[idx_np])
+        self._episode_count[idx_np] += np.uint64(1)
+        self._elapsed_steps[env_idx] = 0
+        b = len(idx_np)
+        f32 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+        off = self._offsets[env_idx]
+        # _clear_sim_state (sapien_env.py:1023-1036)
+        self._rbd[env_idx, self._b_cube, 7:13] = 0.0
+        self._qvel[env_idx] = 0.0
+        if "reset_to_env_states" in options:
+            self.set_state(options["reset_to_env_states"]["env_states"], env_idx)
+        else:
+            # TableSceneBuilder.initialize
+            table = self._table_pose.repeat(b, 1)
+            table[:, :3] += off
+            self._rbd[env_idx, self._b_table, :7] = table
+            qpos = f32(self._rng.normal(idx_np, 9) * self.robot_init_qpos_noise) + self._rest_qpos
+            qpos[:, -2:] = 0.04
+            self._qpos[env_idx, :9] = qpos
+            root = self._root_pose.repeat(b, 1)
+            root[:, :3] += off
+            self._rbd[env_idx, self._b_root, :7] = root
+            # PickCubeEnv._initialize_episode
+            u = f32(self._rng.uniform(idx_np, 6))
+            xyz = torch.zeros(b, 3, device=dev)
+            xyz[:, :2] = u[:, 0:2] * self.cube_spawn_half_size * 2 - self.cube_spawn_half_size
+            xyz[:, 0] += self.cube_spawn_center[0]
+            xyz[:, 1] += self.cube_spawn_center[1]
+            xyz[:, 2] = self.cube_half_size
+            yaw = u[:, 2] * (2 * np.pi)  # random_quaternions(lock_x, lock_y): rotation about z
+            qs = torch.zeros(b, 4, device=dev)
+            qs[:, 0] = torch.cos(yaw / 2)
+            qs[:, 3] = torch.sin(yaw / 2)
+            self._rbd[env_idx, self._b_cube, :3] = xyz + off
+            self._rbd[env_idx, self._b_cube, 3:7] = qs
+            goal = torch.zeros(b, 3, device=dev)
+            goal[:, :2] = u[:, 3:5] * self.cube_spawn_half_size * 2 - self.cube_spawn_half_size
+            goal[:, 0] += self.cube_spawn_center[0]
+            goal[:, 1] += self.cube_spawn_center[1]
+            goal[:, 2] = u[:, 5] * self.max_goal_height + xyz[:, 2]
+            self._rbd[env_idx, self._b_goal, :3] = goal + off
+            self._rbd[env_idx, self._b_goal, 3:7] = torch.tensor([1.0, 0, 0, 0], device=dev)
+        # controller.reset(): targets = current qpos (pd_joint_pos.py:54-69)
+        self._target_qpos[env_idx] = self._qpos[env_idx, :9]
+        self._target_qpos_buf[env_idx, :9] = self._qpos[env_idx, :9]
+        self.px.gpu_apply_all()
+        self.px.gpu_update_articulation_kinematics()
+        self.px.gpu_fetch_all()
+        info = self.get_info()
+        obs = self.get_obs(info)
+        return obs, info
+
+    # ---------------------------------------------------------------- step
+    def _set_action(self, action: torch.Tensor):
+        """CombinedController.set_action -> arm PDJointPos(use_delta) + gripper PDJointPosMimic."""
+        a = torch.clip(action, -1.0, 1.0)
+        qpos = self.qpos
+        # _clip_and_scale_action: 0.5*(high+low) + 0.5*(high-low)*a  (utils/gym_utils.py:104-107)
+        self._target_qpos[:, :7] = qpos[:, :7] + self.arm_delta * a[:, :7]
+        g = 0.5 * (self.gripper_high + self.gripper_low) + 0.5 * (self.gripper_high - self.gripper_low) * a[:, 7:8]
+        self._target_qpos[:, 7:9] = g
+        self._target_qpos_buf[:, :9] = self._target_qpos
+
+    def _step_action(self, action):
+        if action is not None:
+            action = torch.as_tensor(action, dtype=torch.float32, device=self.device)
+            if action.ndim == 1:
+                action = action[None]
+            if action.shape != (self.num_envs, self.action_dim):
+                raise AssertionError(f"Received action of shape {tuple(action.shape)} but expected shape ({self.num_envs}, {self.action_dim})")
+            self._set_action(action)
+            self.px.gpu_apply_articulation_target_position()
+        for _ in range(self._sim_steps_per_control):
+            self.px.step()
+        self.px.gpu_fetch_all()
+        return action
+
+    def step(self, action):
+        action = self._step_action(action)
+        self._elapsed_steps += 1
+        info = self.get_info()
+        obs = self.get_obs(info)
+        reward = self.get_reward(obs, action, info)
+        terminated = info["success"].clone()
+        truncated = self._elapsed_steps >= self.max_episode_steps  # TimeLimitWrapper
+        return obs, reward, terminated, truncated, info
+
+    # ---------------------------------------------------------------- task
+    def get_pairwise_contact_forces(self, query):
+        self.px.gpu_query_contact_pair_impulses(query)
+        return query.cuda_impulses.torch().clone() / self.px.timestep
+
+    def is_grasping(self, min_force=0.5, max_angle=85):
+        lf = self.get_pairwise_contact_forces(self._q_lgrasp)
+        rf = self.get_pairwise_contact_forces(self._q_rgrasp)
+        lforce, rforce = torch.linalg.norm(lf, dim=1), torch.linalg.norm(rf, dim=1)
+        ldir = _quat_to_y_axis(self._rbd[:, self._b_f1, 3:7])
+        rdir = -_quat_to_y_axis(self._rbd[:, self._b_f2, 3:7])
+        langle = compute_angle_between(ldir, lf)
+        rangle = compute_angle_between(rdir, rf)
+        lflag = torch.logical_and(lforce >= min_force, torch.rad2deg(langle) <= max_angle)
+        rflag = torch.logical_and(rforce >= min_force, torch.rad2deg(rangle) <= max_angle)
+        return torch.logical_and(lflag, rflag)
+
+    def is_static(self, threshold=0.2):
+        return torch.max(torch.abs(self.qvel[:, :-2]), 1)[0] <= threshold
+
+    def evaluate(self):
+        is_obj_placed = torch.linalg.norm(self.goal_pos - self.cube_pose[:, :3], dim=1) <= self.goal_thresh
+        is_grasped = self.is_grasping()
+        is_robot_static = self.is_static(0.2)
+        return {"success": is_obj_placed & is_robot_static, "is_obj_placed": is_obj_placed,
+                "is_robot_static": is_robot_static, "is_grasped": is_grasped}
+
+    def get_info(self):
+        info = dict(elapsed_steps=self._elapsed_steps.clone())
+        info.update(self.evaluate())
+        return info
+
+    def get_obs(self, info):
+        """flatten_state_dict(dict(agent=dict(qpos, qvel), extra=dict(...))) -> (N, 42) (pick_cube.py:132-145)."""
+        cube, tcp, goal = self.cube_pose, self.tcp_pose, self.goal_pos
+        return torch.hstack([
+            self.qpos, self.qvel, info["is_grasped"][:, None].float(), tcp, goal, cube,
+            cube[:, :3] - tcp[:, :3], goal - cube[:, :3],
+        ])
+
+    def compute_dense_reward(self, obs, action, info):
+        cube_p, tcp_p, goal = self.cube_pose[:, :3], self.tcp_pose[:, :3], self.goal_pos
+        reaching_reward = 1 - torch.tanh(5 * torch.linalg.norm(cube_p - tcp_p, dim=1))
+        reward = reaching_reward
+        is_grasped = info["is_grasped"]
+        reward = reward + is_grasped
+        place_reward = 1 - torch.tanh(5 * torch.linalg.norm(goal - cube_p, dim=1))
+        reward = reward + place_reward * is_grasped
+        static_reward = 1 - torch.tanh(5 * torch.linalg.norm(self.qvel[:, :-2], dim=1))
+        reward = reward + static_reward * info["is_obj_placed"]
+        reward = torch.where(info["success"], torch.full_like(reward, 5.0), reward)
+        return reward
+
+    def get_reward(self, obs, action, info):
+        r = self.compute_dense_reward(obs, action, info)
+        return r / 5 if self.reward_mode == "normalized_dense" else r
+
+    # ---------------------------------------------------------------- state (sapien_env.py:1272-1325)
+    def get_state(self):
+        """(N, 13*3 + 13 + 9*2): actors [table, cube, goal] then articulation [root pose/vel, qpos, qvel]
+        (tests/test_sim_state.py:10-37)."""
+        def actor(bid):
+            s = self._rbd[:, bid, :].clone()
+            s[:, :3] -= self._offsets
+            return s
+        root = actor(self._b_root)
+        return torch.hstack([actor(self._b_table), actor(self._b_cube), actor(self._b_goal), root, self.qpos, self.qvel])
+
+    def set_state(self, state, env_idx=None):
+        if env_idx is None:
+            env_idx = torch.arange(self.num_envs, device=self.device)
+        state = torch.as_tensor(state, dtype=torch.float32, device=self.device)
+        off = self._offsets[env_idx]
+        for k, bid in enumerate([self._b_table, self._b_cube, self._b_goal, self._b_root]):
+            s = state[:, 13 * k: 13 * (k + 1)].clone()
+            s[:, :3] += off
+            self._rbd[env_idx, bid, :] = s
+        self._qpos[env_idx, :9] = state[:, 52:61]
+        self._qvel[env_idx, :9] = state[:, 61:70]
+        self.px.gpu_apply_all()
+        self.px.gpu_update_articulation_kinematics()
+        self.px.gpu_fetch_all()
+
+    def close(self):
+        self.px.close()

@@ -1,0 +1,83 @@
+"""Template-level scene builders (host only, cold path).
+
+Mirror of the pieces of the reference that populate a PickCube sub-scene:
+  * TableSceneBuilder.build      mani_skill/utils/scene_builder/table/scene_builder.py:20-66
+  * build_ground                 mani_skill/utils/building/ground.py:20-44
+  * actors.build_cube / build_sphere   mani_skill/utils/building/actors/common.py:70-91
+  * Panda agent (URDF, urdf_config, drives)   mani_skill/agents/robots/panda/panda.py:16-98
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _native as N
+from ..agents.urdf import add_urdf_articulation, load_model
+from ..physx import SceneTemplate
+
+TABLE_HEIGHT = 0.9196429
+# value of table_scene.table_height (aabb z extent, scene_builder.py:49-57)
+GROUND_ALTITUDE = -(3.5762787e-07 + 0.91964257)
+
+PANDA_URDF_CONFIG = dict(
+    _materials=dict(gripper=dict(static_friction=2.0, dynamic_friction=2.0, restitution=0.0)),
+    link=dict(
+        panda_leftfinger=dict(material="gripper", patch_radius=0.1, min_patch_radius=0.1),
+        panda_rightfinger=dict(material="gripper", patch_radius=0.1, min_patch_radius=0.1),
+    ),
+)
+PANDA_ARM_JOINTS = [f"panda_joint{i}" for i in range(1, 8)]
+PANDA_GRIPPER_JOINTS = ["panda_finger_joint1", "panda_finger_joint2"]
+PANDA_REST_QPOS = np.array([0.0, np.pi / 8, 0, -np.pi * 5 / 8, 0, np.pi * 3 / 4, np.pi / 4, 0.04, 0.04])
+
+
+def box_mass_properties(half_size, density=1000.0):
+    hx, hy, hz = [float(h) for h in half_size]
+    m = density * 8.0 * hx * hy * hz
+    I = (m / 3.0 * (hy * hy + hz * hz), m / 3.0 * (hx * hx + hz * hz), m / 3.0 * (hx * hx + hy * hy), 0.0, 0.0, 0.0)
+    return m, I
+
+
+def add_table_scene(tpl: SceneTemplate, material=(0.3, 0.3, 0.0)):
+    """Kinematic table box with its top at z = 0 and the ground plane below it."""
+    q = (float(np.cos(np.pi / 4)), 0.0, 0.0, float(np.sin(np.pi / 4)))  # euler2quat(0, 0, pi/2)
+    table = tpl.add_actor("table-workspace", N.BODY_KINEMATIC, p=(-0.12, 0.0, -TABLE_HEIGHT), q=q)
+    tpl.add_shape(table, N.SHAPE_BOX, p=(0, 0, TABLE_HEIGHT / 2), params=(2.418 / 2, 1.209 / 2, TABLE_HEIGHT / 2),
+                  static_friction=material[0], dynamic_friction=material[1], restitution=material[2])
+    # ground: static plane, normal = +x of the shape frame rotated onto +z (ground.py:38-40)
+    tpl.add_shape(-1, N.SHAPE_PLANE, p=(0, 0, GROUND_ALTITUDE), q=(0.7071068, 0, -0.7071068, 0),
+                  static_friction=material[0], dynamic_friction=material[1], restitution=material[2])
+    return table
+
+
+def add_cube(tpl: SceneTemplate, name, half_size, p, material=(0.3, 0.3, 0.0), density=1000.0):
+    m, I = box_mass_properties([half_size] * 3, density)
+    cube = tpl.add_actor(name, N.BODY_DYNAMIC, p=p, mass=m, inertia6=I)
+    tpl.add_shape(cube, N.SHAPE_BOX, params=(half_size,) * 3, static_friction=material[0],
+                  dynamic_friction=material[1], restitution=material[2])
+    return cube
+
+
+def add_site(tpl: SceneTemplate, name, p=(0, 0, 0)):
+    """Kinematic marker without collision (build_sphere(..., add_collision=False))."""
+    return tpl.add_actor(name, N.BODY_KINEMATIC, p=p)
+
+
+def add_panda(tpl: SceneTemplate, root_p=(-0.615, 0.0, 0.0), stiffness=1e3, damping=1e2, force_limit=100.0):
+    """Panda with the drive properties of its pd_joint_delta_pos controller (panda.py:68-98,177-190)."""
+    model = load_model("panda_v2.json")
+    art = add_urdf_articulation(tpl, model, "panda", root_p=root_p, urdf_config=PANDA_URDF_CONFIG,
+                                disable_gravity=True)  # balance_passive_force (base_agent.py:263-282)
+    for bid in tpl.art_active[art]:
+        tpl.set_drive(bid, stiffness, damping, force_limit, "force")
+    return art
+
+
+def build_pick_cube_template(cube_half_size=0.02):
+    """Body order: 15 panda links (ids 0..14), table-workspace, cube, goal_site = 18 rows per env
+    (_load_agent runs before _load_scene, sapien_env.py:725-759)."""
+    tpl = SceneTemplate()
+    art = add_panda(tpl)
+    table = add_table_scene(tpl)
+    cube = add_cube(tpl, "cube", cube_half_size, (0, 0, cube_half_size))
+    goal = add_site(tpl, "goal_site")
+    return tpl, dict(art=art, table=table, cube=cube, goal_site=goal)

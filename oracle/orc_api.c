@@ -1,0 +1,409 @@
+/*
+ * orc_api.c — the oracle behind the same entry points as include/msk_physx.h, with the
+ * prefix orc_ and host-memory buffers.  TEST INFRASTRUCTURE ONLY: loaded by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by maniskill_amd/.
+ */
+#include "orc_sim.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_EXPORT __attribute__((visibility("default")))
+
+static pose pose_from7(const float* p) {
+  pose r;
+  r.p = v3_make(p[0], p[1], p[2]);
+  r.q = quat_normalize(quat_make(p[3], p[4], p[5], p[6]));
+  return r;
+}
+
+static int fail(orc_ctx* c, int code, const char* msg) {
+  snprintf(c->err, sizeof(c->err), "%s", msg);
+  return code;
+}
+
+ORC_EXPORT orc_ctx* orc_create(int device, const msk_config* cfg) {
+  (void)device;
+  orc_ctx* c = (orc_ctx*)calloc(1, sizeof(orc_ctx));
+  c->cfg = *cfg;
+  return c;
+}
+
+ORC_EXPORT void orc_destroy(orc_ctx* c) {
+  if (!c) return;
+  free(c->envs);
+  free(c->offsets);
+  for (int i = 0; i < MSK_BUF_COUNT; ++i) free(c->buf[i]);
+  for (int i = 0; i < c->nqueries; ++i) { free(c->queries[i].pairs); free(c->queries[i].out); }
+  free(c);
+}
+
+ORC_EXPORT const char* orc_last_error(orc_ctx* c) { return c->err; }
+
+ORC_EXPORT int orc_add_articulation(orc_ctx* c, const float root_pose[7]) {
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "add_articulation after finalize");
+  if (c->na >= 8) return fail(c, MSK_ERR_CAPACITY, "too many articulations");
+  c->art_root[c->na] = -1;
+  c->art_dof0[c->na] = c->ndof;
+  c->art_ndof[c->na] = 0;
+  /* root pose is attached to the root link when it is added */
+  orc_body* tmp = &c->bodies[MSK_MAX_BODIES - 1];
+  tmp->init_pose = pose_from7(root_pose);
+  return c->na++;
+}
+
+ORC_EXPORT int orc_add_link(orc_ctx* c, int art, int parent_body, int joint_type, const float pose_in_parent[7],
+                            const float pose_in_child[7], float limit_lo, float limit_hi, float mass,
+                            const float com[3], const float inertia6[6], int disable_gravity, float armature,
+                            float joint_friction) {
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "add_link after finalize");
+  if (c->nb >= MSK_MAX_BODIES - 1) return fail(c, MSK_ERR_CAPACITY, "too many bodies");
+  if (art != c->na - 1) return fail(c, MSK_ERR_INVALID, "links must be added to the most recent articulation");
+  orc_body* b = &c->bodies[c->nb];
+  pose root = c->bodies[MSK_MAX_BODIES - 1].init_pose;
+  memset(b, 0, sizeof(*b));
+  b->kind = MSK_BODY_LINK;
+  b->art = art;
+  b->parent = parent_body;
+  b->jtype = (parent_body < 0) ? MSK_JOINT_FIXED : joint_type;
+  b->Xp = pose_from7(pose_in_parent);
+  b->XcInv = pose_inv(pose_from7(pose_in_child));
+  b->lim_lo = limit_lo; b->lim_hi = limit_hi;
+  b->mass = mass;
+  b->com = v3_make(com[0], com[1], com[2]);
+  memcpy(b->I6, inertia6, sizeof(b->I6));
+  b->nograv = disable_gravity;
+  b->armature = armature; b->jfriction = joint_friction;
+  b->dof = -1; b->vofs = -1;
+  if (parent_body < 0) {
+    b->init_pose = root;
+    c->art_root[art] = c->nb;
+  } else {
+    if (parent_body >= c->nb || c->bodies[parent_body].art != art) return fail(c, MSK_ERR_INVALID, "bad parent link");
+    if (b->jtype != MSK_JOINT_FIXED) {
+      if (c->ndof >= MSK_MAX_DOF) return fail(c, MSK_ERR_CAPACITY, "too many dofs");
+      b->dof = c->ndof++;
+      c->art_ndof[art]++;
+    }
+    b->movable = (b->dof >= 0) || c->bodies[parent_body].movable;
+  }
+  return c->nb++;
+}
+
+ORC_EXPORT int orc_set_drive(orc_ctx* c, int link_body, float K, float D, float force_limit, int mode_acc) {
+  if (link_body < 0 || link_body >= c->nb || c->bodies[link_body].dof < 0) return fail(c, MSK_ERR_INVALID, "set_drive: not an active joint");
+  orc_body* b = &c->bodies[link_body];
+  b->K = K; b->D = D; b->fmax = force_limit; b->drive_accel = mode_acc;
+  return MSK_OK;
+}
+
+ORC_EXPORT int orc_add_tendon(orc_ctx* c, int link_a, int link_b, float ca, float cb, float rest, float K, float D) {
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "add_tendon after finalize");
+  if (c->nt >= MSK_MAX_TENDONS) return fail(c, MSK_ERR_CAPACITY, "too many tendons");
+  if (link_a < 0 || link_b < 0 || link_a >= c->nb || link_b >= c->nb) return fail(c, MSK_ERR_INVALID, "bad tendon link");
+  if (c->bodies[link_a].dof < 0 || c->bodies[link_b].dof < 0) return fail(c, MSK_ERR_INVALID, "tendon on a fixed joint");
+  orc_tendon* t = &c->tendons[c->nt];
+  t->dof_a = c->bodies[link_a].dof; t->dof_b = c->bodies[link_b].dof;
+  t->ca = ca; t->cb = cb; t->rest = rest; t->K = K; t->D = D;
+  return c->nt++;
+}
+
+static void sym6_inverse(const float I[6], float out[6]) {
+  float a = I[0], b = I[3], cc = I[4], d = I[1], e = I[5], f = I[2];
+  float det = a * (d * f - e * e) - b * (b * f - e * cc) + cc * (b * e - d * cc);
+  float inv = 1.0f / det;
+  out[0] = (d * f - e * e) * inv;
+  out[1] = (a * f - cc * cc) * inv;
+  out[2] = (a * d - b * b) * inv;
+  out[3] = (cc * e - b * f) * inv;
+  out[4] = (b * e - cc * d) * inv;
+  out[5] = (b * cc - a * e) * inv;
+}
+
+ORC_EXPORT int orc_add_actor(orc_ctx* c, int kind, const float pose7[7], float mass, const float com[3],
+                             const float inertia6[6], float lin_damp, float ang_damp, int disable_gravity) {
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "add_actor after finalize");
+  if (c->nb >= MSK_MAX_BODIES - 1) return fail(c, MSK_ERR_CAPACITY, "too many bodies");
+  if (kind != MSK_BODY_KINEMATIC && kind != MSK_BODY_DYNAMIC) return fail(c, MSK_ERR_INVALID, "bad actor kind");
+  orc_body* b = &c->bodies[c->nb];
+  memset(b, 0, sizeof(*b));
+  b->kind = kind; b->art = -1; b->parent = -1; b->dof = -1; b->vofs = -1;
+  b->init_pose = pose_from7(pose7);
+  b->mass = mass;
+  b->com = v3_make(com[0], com[1], com[2]);
+  memcpy(b->I6, inertia6, sizeof(b->I6));
+  if (kind == MSK_BODY_DYNAMIC) {
+    if (!(mass > 0.0f)) return fail(c, MSK_ERR_INVALID, "dynamic actor needs positive mass");
+    sym6_inverse(b->I6, b->Iinv6);
+  }
+  b->lin_damp = lin_damp; b->ang_damp = ang_damp; b->nograv = disable_gravity;
+  b->movable = kind == MSK_BODY_DYNAMIC;
+  return c->nb++;
+}
+
+ORC_EXPORT int orc_add_shape(orc_ctx* c, int body, int type, const float local_pose[7], const float params[3],
+                             const float* verts, int nverts, float sf, float df, float rest, const uint32_t groups[4],
+                             float patch_radius, float min_patch_radius) {
+  (void)min_patch_radius;
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "add_shape after finalize");
+  if (c->ns >= MSK_MAX_SHAPES) return fail(c, MSK_ERR_CAPACITY, "too many shapes");
+  if (body >= c->nb) return fail(c, MSK_ERR_INVALID, "bad body");
+  orc_shape* s = &c->shapes[c->ns];
+  memset(s, 0, sizeof(*s));
+  s->body = body; s->type = type;
+  s->local = pose_from7(local_pose);
+  s->par[0] = params[0]; s->par[1] = params[1]; s->par[2] = params[2];
+  s->sf = sf; s->df = df; s->rest = rest;
+  memcpy(s->g, groups, sizeof(s->g));
+  s->patch_r = patch_radius;
+  if (type == MSK_SHAPE_CONVEX) {
+    if (nverts < 4 || nverts > MSK_MAX_HULL_VERTS) return fail(c, MSK_ERR_CAPACITY, "convex: 4..64 vertices");
+    s->nverts = nverts;
+    v3 lo = v3_make(3e38f, 3e38f, 3e38f), hi = v3_make(-3e38f, -3e38f, -3e38f);
+    for (int i = 0; i < nverts; ++i) {
+      s->verts[i] = v3_make(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
+      lo = v3_make(fminf(lo.x, s->verts[i].x), fminf(lo.y, s->verts[i].y), fminf(lo.z, s->verts[i].z));
+      hi = v3_make(fmaxf(hi.x, s->verts[i].x), fmaxf(hi.y, s->verts[i].y), fmaxf(hi.z, s->verts[i].z));
+    }
+    s->aabb_c = v3_scale(v3_add(lo, hi), 0.5f);
+    s->aabb_h = v3_scale(v3_sub(hi, lo), 0.5f);
+  } else if (type == MSK_SHAPE_BOX) {
+    s->aabb_c = v3_make(0, 0, 0);
+    s->aabb_h = v3_make(params[0], params[1], params[2]);
+  } else if (type == MSK_SHAPE_PLANE) {
+    if (body >= 0) return fail(c, MSK_ERR_INVALID, "planes must be static");
+  } else {
+    return fail(c, MSK_ERR_INVALID, "shape type not supported");
+  }
+  return c->ns++;
+}
+
+ORC_EXPORT int orc_disable_collision(orc_ctx* c, int a, int b) {
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "disable_collision after finalize");
+  if (c->ndisabled >= 256) return fail(c, MSK_ERR_CAPACITY, "too many disabled pairs");
+  c->disabled[c->ndisabled][0] = a; c->disabled[c->ndisabled][1] = b;
+  c->ndisabled++;
+  return MSK_OK;
+}
+
+static int body_movable(const orc_ctx* c, int b) { return b >= 0 && c->bodies[b].movable; }
+
+static int pair_enabled(const orc_ctx* c, const orc_shape* A, const orc_shape* B) {
+  if (A->body == B->body) return 0;
+  if (!body_movable(c, A->body) && !body_movable(c, B->body)) return 0;
+  if (A->g[2] & B->g[2]) return 0;
+  if (!((A->g[0] & B->g[1]) || (A->g[1] & B->g[0]))) return 0;
+  if (A->body >= 0 && B->body >= 0) {
+    const orc_body* ba = &c->bodies[A->body];
+    const orc_body* bb = &c->bodies[B->body];
+    if (ba->kind == MSK_BODY_LINK && bb->kind == MSK_BODY_LINK && ba->art == bb->art)
+      if (ba->parent == B->body || bb->parent == A->body) return 0;
+    for (int i = 0; i < c->ndisabled; ++i)
+      if ((c->disabled[i][0] == A->body && c->disabled[i][1] == B->body) ||
+          (c->disabled[i][0] == B->body && c->disabled[i][1] == A->body))
+        return 0;
+  }
+  return 1;
+}
+
+static void env_reset(const orc_ctx* c, orc_env* e) {
+  memset(e, 0, sizeof(*e));
+  for (int i = 0; i < c->nb; ++i) {
+    e->bpose[i] = c->bodies[i].init_pose;
+    if (c->bodies[i].kind == MSK_BODY_LINK && c->bodies[i].parent >= 0) e->bpose[i].q = quat_make(1, 0, 0, 0);
+  }
+  orc_forward_kinematics(c, e);
+}
+
+ORC_EXPORT int orc_finalize(orc_ctx* c, int num_envs) {
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "finalize twice");
+  if (!c->cfg.enable_tgs) return fail(c, MSK_ERR_INVALID, "only the TGS solver is implemented");
+  c->nv = c->ndof;
+  for (int i = 0; i < c->nb; ++i)
+    if (c->bodies[i].kind == MSK_BODY_DYNAMIC) { c->bodies[i].vofs = c->nv; c->nv += 6; }
+  if (c->nv > MSK_MAX_NV) return fail(c, MSK_ERR_CAPACITY, "generalized velocity too large");
+  c->max_dof = 0;
+  for (int a = 0; a < c->na; ++a) {
+    if (c->art_root[a] < 0) return fail(c, MSK_ERR_INVALID, "articulation without links");
+    if (c->art_ndof[a] > c->max_dof) c->max_dof = c->art_ndof[a];
+  }
+  c->npairs = 0;
+  for (int i = 0; i < c->ns; ++i)
+    for (int j = i + 1; j < c->ns; ++j)
+      if (pair_enabled(c, &c->shapes[i], &c->shapes[j])) {
+        if (c->npairs >= MSK_MAX_PAIRS) return fail(c, MSK_ERR_CAPACITY, "too many candidate pairs");
+        c->pairs[c->npairs].sa = i; c->pairs[c->npairs].sb = j;
+        c->npairs++;
+      }
+  c->num_envs = num_envs;
+  c->envs = (orc_env*)calloc((size_t)num_envs, sizeof(orc_env));
+  c->offsets = (float*)calloc((size_t)num_envs * 3, sizeof(float));
+  for (int e = 0; e < num_envs; ++e) env_reset(c, &c->envs[e]);
+  size_t nrb = (size_t)num_envs * c->nb * 13;
+  size_t nart = (size_t)num_envs * (c->na > 0 ? c->na : 1) * (c->max_dof > 0 ? c->max_dof : 1);
+  c->buf[MSK_BUF_RIGID_BODY_DATA] = (float*)calloc(nrb, sizeof(float));
+  for (int b = MSK_BUF_ART_QPOS; b < MSK_BUF_COUNT; ++b) c->buf[b] = (float*)calloc(nart, sizeof(float));
+  c->finalized = 1;
+  return MSK_OK;
+}
+
+ORC_EXPORT int orc_set_scene_offsets(orc_ctx* c, const float* offsets) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "set_scene_offsets before finalize");
+  memcpy(c->offsets, offsets, sizeof(float) * 3 * (size_t)c->num_envs);
+  return MSK_OK;
+}
+
+ORC_EXPORT void* orc_buffer(orc_ctx* c, int id, int64_t shape[2]) {
+  if (!c->finalized || id < 0 || id >= MSK_BUF_COUNT) return NULL;
+  if (id == MSK_BUF_RIGID_BODY_DATA) { shape[0] = (int64_t)c->num_envs * c->nb; shape[1] = 13; }
+  else { shape[0] = (int64_t)c->num_envs * c->na; shape[1] = c->max_dof; }
+  return c->buf[id];
+}
+
+static float* art_row(orc_ctx* c, int buf, int env, int art) {
+  return c->buf[buf] + ((size_t)env * c->na + art) * c->max_dof;
+}
+
+ORC_EXPORT int orc_apply(orc_ctx* c, uint32_t mask, void* stream) {
+  (void)stream;
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "apply before finalize");
+  for (int e = 0; e < c->num_envs; ++e) {
+    orc_env* env = &c->envs[e];
+    const float* off = c->offsets + 3 * e;
+    for (int i = 0; i < c->nb; ++i) {
+      const orc_body* b = &c->bodies[i];
+      const float* r = c->buf[MSK_BUF_RIGID_BODY_DATA] + ((size_t)e * c->nb + i) * 13;
+      int is_root = b->kind == MSK_BODY_LINK && b->parent < 0;
+      if ((b->kind != MSK_BODY_LINK && (mask & MSK_APPLY_RIGID_DATA)) || (is_root && (mask & MSK_APPLY_ART_ROOT_POSE))) {
+        env->bpose[i].p = v3_make(r[0] - off[0], r[1] - off[1], r[2] - off[2]);
+        env->bpose[i].q = quat_normalize(quat_make(r[3], r[4], r[5], r[6]));
+        if (b->kind == MSK_BODY_DYNAMIC) {
+          env->blin[i] = v3_make(r[7], r[8], r[9]);
+          env->bang[i] = v3_make(r[10], r[11], r[12]);
+        }
+      }
+    }
+    for (int a = 0; a < c->na; ++a)
+      for (int j = 0; j < c->art_ndof[a]; ++j) {
+        int d = c->art_dof0[a] + j;
+        if (mask & MSK_APPLY_ART_QPOS) env->q[d] = art_row(c, MSK_BUF_ART_QPOS, e, a)[j];
+        if (mask & MSK_APPLY_ART_QVEL) env->qd[d] = art_row(c, MSK_BUF_ART_QVEL, e, a)[j];
+        if (mask & MSK_APPLY_ART_QF) env->qf[d] = art_row(c, MSK_BUF_ART_QF, e, a)[j];
+        if (mask & MSK_APPLY_ART_TARGET_QPOS) env->qt[d] = art_row(c, MSK_BUF_ART_TARGET_QPOS, e, a)[j];
+        if (mask & MSK_APPLY_ART_TARGET_QVEL) env->qdt[d] = art_row(c, MSK_BUF_ART_TARGET_QVEL, e, a)[j];
+      }
+  }
+  return MSK_OK;
+}
+
+ORC_EXPORT int orc_update_kinematics(orc_ctx* c, void* stream) {
+  (void)stream;
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "update_kinematics before finalize");
+  for (int e = 0; e < c->num_envs; ++e) orc_forward_kinematics(c, &c->envs[e]);
+  return MSK_OK;
+}
+
+ORC_EXPORT int orc_fetch(orc_ctx* c, uint32_t mask, void* stream) {
+  (void)stream;
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "fetch before finalize");
+  for (int e = 0; e < c->num_envs; ++e) {
+    const orc_env* env = &c->envs[e];
+    const float* off = c->offsets + 3 * e;
+    if (mask & MSK_FETCH_RIGID_DATA)
+      for (int i = 0; i < c->nb; ++i) {
+        float* r = c->buf[MSK_BUF_RIGID_BODY_DATA] + ((size_t)e * c->nb + i) * 13;
+        r[0] = env->bpose[i].p.x + off[0]; r[1] = env->bpose[i].p.y + off[1]; r[2] = env->bpose[i].p.z + off[2];
+        r[3] = env->bpose[i].q.w; r[4] = env->bpose[i].q.x; r[5] = env->bpose[i].q.y; r[6] = env->bpose[i].q.z;
+        r[7] = env->blin[i].x; r[8] = env->blin[i].y; r[9] = env->blin[i].z;
+        r[10] = env->bang[i].x; r[11] = env->bang[i].y; r[12] = env->bang[i].z;
+      }
+    for (int a = 0; a < c->na; ++a)
+      for (int j = 0; j < c->art_ndof[a]; ++j) {
+        int d = c->art_dof0[a] + j;
+        if (mask & MSK_FETCH_ART_QPOS) art_row(c, MSK_BUF_ART_QPOS, e, a)[j] = env->q[d];
+        if (mask & MSK_FETCH_ART_QVEL) art_row(c, MSK_BUF_ART_QVEL, e, a)[j] = env->qd[d];
+        if (mask & MSK_FETCH_ART_QACC) art_row(c, MSK_BUF_ART_QACC, e, a)[j] = env->qacc[d];
+        if (mask & MSK_FETCH_ART_TARGETS) {
+          art_row(c, MSK_BUF_ART_TARGET_QPOS, e, a)[j] = env->qt[d];
+          art_row(c, MSK_BUF_ART_TARGET_QVEL, e, a)[j] = env->qdt[d];
+        }
+      }
+  }
+  return MSK_OK;
+}
+
+ORC_EXPORT int orc_step(orc_ctx* c, void* stream) {
+  (void)stream;
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "step before finalize");
+  int overflow = 0;
+#pragma omp parallel for schedule(static) reduction(| : overflow) if (c->num_envs >= 16)
+  for (int e = 0; e < c->num_envs; ++e) {
+    orc_step_env(c, &c->envs[e]);
+    overflow |= c->envs[e].overflow;
+  }
+  if (overflow) return fail(c, MSK_ERR_OVERFLOW, "per-env contact capacity exceeded");
+  return MSK_OK;
+}
+
+ORC_EXPORT int orc_query_create_pairs(orc_ctx* c, const int32_t* body_pairs, int npairs) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "query before finalize");
+  if (c->nqueries >= 16) return fail(c, MSK_ERR_CAPACITY, "too many queries");
+  int q = c->nqueries++;
+  c->queries[q].npairs = npairs;
+  c->queries[q].pairs = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)npairs);
+  memcpy(c->queries[q].pairs, body_pairs, sizeof(int32_t) * 2 * (size_t)npairs);
+  c->queries[q].out = (float*)calloc((size_t)c->num_envs * npairs * 3, sizeof(float));
+  return q;
+}
+
+ORC_EXPORT void* orc_query_buffer(orc_ctx* c, int q, int64_t shape[2]) {
+  if (q < 0 || q >= c->nqueries) return NULL;
+  shape[0] = (int64_t)c->num_envs * c->queries[q].npairs; shape[1] = 3;
+  return c->queries[q].out;
+}
+
+ORC_EXPORT int orc_query_run(orc_ctx* c, int q, void* stream) {
+  (void)stream;
+  if (q < 0 || q >= c->nqueries) return fail(c, MSK_ERR_INVALID, "bad query");
+  int np = c->queries[q].npairs;
+  for (int e = 0; e < c->num_envs; ++e) {
+    const orc_env* env = &c->envs[e];
+    for (int p = 0; p < np; ++p) {
+      int x = c->queries[q].pairs[2 * p], y = c->queries[q].pairs[2 * p + 1];
+      v3 sum = v3_make(0, 0, 0);
+      for (int k = 0; k < env->ncontacts; ++k) {
+        const orc_contact* ct = &env->contacts[k];
+        float sgn = 0.0f;
+        if (ct->ba == x && ct->bb == y) sgn = 1.0f;
+        else if (ct->ba == y && ct->bb == x) sgn = -1.0f;
+        else continue;
+        v3 imp = v3_madd(v3_madd(v3_scale(ct->n, ct->lam[0]), ct->t1, ct->lam[1]), ct->t2, ct->lam[2]);
+        sum = v3_madd(sum, imp, sgn);
+      }
+      float* o = c->queries[q].out + ((size_t)e * np + p) * 3;
+      o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
+    }
+  }
+  return MSK_OK;
+}
+
+ORC_EXPORT int orc_get_sizes(orc_ctx* c, int32_t out[8]) {
+  out[0] = c->nb; out[1] = c->na; out[2] = c->max_dof; out[3] = c->nv; out[4] = c->ns; out[5] = c->npairs;
+  out[6] = c->num_envs; out[7] = 0;
+  return MSK_OK;
+}
+
+ORC_EXPORT int orc_get_contacts(orc_ctx* c, int env, int32_t* ids, float* vals, int max_points) {
+  if (env < 0 || env >= c->num_envs) return fail(c, MSK_ERR_INVALID, "bad env");
+  const orc_env* e = &c->envs[env];
+  int n = e->ncontacts < max_points ? e->ncontacts : max_points;
+  for (int i = 0; i < n; ++i) {
+    const orc_contact* ct = &e->contacts[i];
+    ids[3 * i] = ct->sa; ids[3 * i + 1] = ct->sb; ids[3 * i + 2] = ct->ba * 256 + (ct->bb & 255);
+    float* v = vals + 8 * i;
+    v[0] = ct->pos.x; v[1] = ct->pos.y; v[2] = ct->pos.z;
+    v[3] = ct->n.x; v[4] = ct->n.y; v[5] = ct->n.z;
+    v[6] = ct->sep; v[7] = ct->lam[0];
+  }
+  return e->ncontacts;
+}

@@ -1,0 +1,452 @@
+/*
+ * orc_sim.c — one simulation substep of one env, scalar CPU oracle.
+ * TEST INFRASTRUCTURE ONLY: never linked into or called from the product path.
+ *
+ * Stands in for `PhysxGpuSystem.step()` (mani_skill/envs/scene.py:379-380) under the
+ * parameters of mani_skill/utils/structs/types.py:35-90 (TGS, 15 position + 1 velocity
+ * iterations, contact_offset 0.02, friction every iteration).  Pipeline:
+ *   1. kinematics      link frames from (root pose, q); joint axes; spatial velocities
+ *   2. dynamics        CRBA joint-space inertia M, RNEA bias forces; joint PD drives and
+ *                      tendon springs are integrated implicitly by folding them into the
+ *                      system matrix A = M + dt*D + dt^2*K (+ tendon terms), Cholesky,
+ *                      A^-1, unconstrained velocity v* = A^-1 (M v + dt*(tau - bias - K e + D vt));
+ *                      a drive whose predicted force exceeds its limit is re-solved as a
+ *                      constant force at the limit
+ *   3. collision       orc_collide.c over the static candidate pair table
+ *   4. rows            joint limits, contact normal + 2 friction rows per point, in
+ *                      generalized coordinates, with response Y = A^-1 J^T
+ *   5. TGS             position iterations = sub-steps of dt/Np: one Gauss-Seidel sweep
+ *                      each, errors re-linearised from the accumulated displacement dq;
+ *                      then velocity iterations without penetration bias
+ *   6. integrate       q += dq, free bodies x += dq_lin, R = exp(dq_ang) R; kinematics
+ */
+#include "orc_sim.h"
+#include <string.h>
+
+#define ORC_PEN_BETA 0.8f        /* penetration recovery rate: bias = beta * depth / dt   */
+#define ORC_MAX_DEPEN_VEL 3.0f   /* m/s cap on the penetration-recovery bias            */
+#define ORC_WARM_DIST 5.0e-3f    /* contact matching radius for warm starting             */
+#define ORC_WARM_FACTOR 0.9f     /* fraction of last step's impulses applied up front     */
+
+enum { ROW_LIMLO, ROW_LIMHI, ROW_CN, ROW_CT1, ROW_CT2 };
+
+typedef struct {
+  int kind, idx;
+  float J[MSK_MAX_NV], Y[MSK_MAX_NV];
+  float d;      /* J . Y */
+  float lam;    /* accumulated impulse */
+} orc_row;
+
+typedef struct {
+  sv6 S[MSK_MAX_BODIES];      /* joint motion subspace about the env origin (zero if fixed) */
+  sv6 V[MSK_MAX_BODIES];      /* spatial velocity of links */
+  v3 comw[MSK_MAX_BODIES];    /* world COM */
+  float Iw[MSK_MAX_BODIES][6];/* world inertia about the COM */
+  float Minv[MSK_MAX_DOF][MSK_MAX_DOF];
+  float Iwinv[MSK_MAX_BODIES][6];
+  float vfree[MSK_MAX_NV];
+} orc_scratch;
+
+/* ---- 1. kinematics ---------------------------------------------------------------- */
+static void kinematics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
+  for (int i = 0; i < c->nb; ++i) {
+    const orc_body* b = &c->bodies[i];
+    s->S[i] = sv6_zero();
+    s->V[i] = sv6_zero();
+    if (b->kind == MSK_BODY_LINK && b->parent >= 0) {
+      pose Tj = pose_mul(e->bpose[b->parent], b->Xp);
+      v3 axis = quat_rotate(Tj.q, v3_make(1, 0, 0));
+      pose Jq;
+      Jq.p = v3_make(0, 0, 0);
+      Jq.q = quat_make(1, 0, 0, 0);
+      if (b->jtype == MSK_JOINT_REVOLUTE) {
+        float sn, cs;
+        orc_sincos(0.5f * e->q[b->dof], &sn, &cs);
+        Jq.q = quat_make(cs, sn, 0, 0);
+        s->S[i].a = axis;
+        s->S[i].l = v3_cross(Tj.p, axis);
+      } else if (b->jtype == MSK_JOINT_PRISMATIC) {
+        Jq.p = v3_make(e->q[b->dof], 0, 0);
+        s->S[i].l = axis;
+      }
+      pose T = pose_mul(pose_mul(Tj, Jq), b->XcInv);
+      T.q = quat_normalize(T.q);
+      e->bpose[i] = T;
+      s->V[i] = s->V[b->parent];
+      if (b->dof >= 0) s->V[i] = sv6_madd(s->V[i], s->S[i], e->qd[b->dof]);
+    }
+    m33 R = quat_to_m33(e->bpose[i].q);
+    s->comw[i] = v3_add(e->bpose[i].p, m33_mulv(&R, b->com));
+    sym6_rotate(&R, b->I6, s->Iw[i]);
+    if (b->kind == MSK_BODY_LINK) {
+      /* published velocities: angular, and linear velocity of the COM */
+      e->bang[i] = s->V[i].a;
+      e->blin[i] = v3_add(s->V[i].l, v3_cross(s->V[i].a, s->comw[i]));
+    } else if (b->kind == MSK_BODY_DYNAMIC) {
+      sym6_rotate(&R, b->Iinv6, s->Iwinv[i]);
+    } else {
+      e->blin[i] = v3_make(0, 0, 0);
+      e->bang[i] = v3_make(0, 0, 0);
+    }
+  }
+}
+
+void orc_forward_kinematics(const orc_ctx* c, orc_env* e) {
+  orc_scratch s;
+  kinematics(c, e, &s);
+}
+
+/* ---- 2. dynamics ------------------------------------------------------------------ */
+static void dynamics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
+  const float dt = c->cfg.timestep;
+  const v3 g = v3_make(c->cfg.gravity[0], c->cfg.gravity[1], c->cfg.gravity[2]);
+  const int nd = c->ndof;
+  sinertia Isp[MSK_MAX_BODIES], Ic[MSK_MAX_BODIES];
+  sv6 f[MSK_MAX_BODIES];
+  sv6 acc[MSK_MAX_BODIES];
+  float M[MSK_MAX_DOF][MSK_MAX_DOF];
+  float bias[MSK_MAX_DOF];
+  memset(M, 0, sizeof(M));
+  /* spatial inertias about the env origin, RNEA forward pass with zero joint accelerations */
+  for (int i = 0; i < c->nb; ++i) {
+    const orc_body* b = &c->bodies[i];
+    if (b->kind != MSK_BODY_LINK) continue;
+    v3 cw = s->comw[i];
+    float m = b->mass;
+    Isp[i].m = m;
+    Isp[i].h = v3_scale(cw, m);
+    float cc = v3_dot(cw, cw);
+    Isp[i].I[0] = s->Iw[i][0] + m * (cc - cw.x * cw.x);
+    Isp[i].I[1] = s->Iw[i][1] + m * (cc - cw.y * cw.y);
+    Isp[i].I[2] = s->Iw[i][2] + m * (cc - cw.z * cw.z);
+    Isp[i].I[3] = s->Iw[i][3] - m * (cw.x * cw.y);
+    Isp[i].I[4] = s->Iw[i][4] - m * (cw.x * cw.z);
+    Isp[i].I[5] = s->Iw[i][5] - m * (cw.y * cw.z);
+    Ic[i] = Isp[i];
+    if (b->parent < 0) {
+      acc[i] = sv6_zero();
+    } else {
+      acc[i] = acc[b->parent];
+      if (b->dof >= 0) {
+        sv6 sq = {v3_scale(s->S[i].a, e->qd[b->dof]), v3_scale(s->S[i].l, e->qd[b->dof])};
+        acc[i] = sv6_add(acc[i], sv6_crossm(s->V[b->parent], sq));
+      }
+    }
+    sv6 Iv = sinertia_mul(&Isp[i], s->V[i]);
+    f[i] = sv6_add(sinertia_mul(&Isp[i], acc[i]), sv6_crossf(s->V[i], Iv));
+    if (!b->nograv) {
+      v3 mg = v3_scale(g, m);
+      f[i].a = v3_sub(f[i].a, v3_cross(cw, mg));
+      f[i].l = v3_sub(f[i].l, mg);
+    }
+  }
+  /* backward pass: bias torques, composite inertias */
+  for (int i = c->nb - 1; i >= 0; --i) {
+    const orc_body* b = &c->bodies[i];
+    if (b->kind != MSK_BODY_LINK) continue;
+    if (b->dof >= 0) bias[b->dof] = sv6_dot(s->S[i], f[i]);
+    if (b->parent >= 0) {
+      f[b->parent] = sv6_add(f[b->parent], f[i]);
+      sinertia_acc(&Ic[b->parent], &Ic[i]);
+    }
+  }
+  /* CRBA */
+  for (int i = 0; i < c->nb; ++i) {
+    const orc_body* b = &c->bodies[i];
+    if (b->kind != MSK_BODY_LINK || b->dof < 0) continue;
+    sv6 F = sinertia_mul(&Ic[i], s->S[i]);
+    M[b->dof][b->dof] = sv6_dot(s->S[i], F) + b->armature;
+    int j = b->parent;
+    while (j >= 0) {
+      const orc_body* bj = &c->bodies[j];
+      if (bj->dof >= 0) {
+        float v = sv6_dot(s->S[j], F);
+        M[b->dof][bj->dof] = v;
+        M[bj->dof][b->dof] = v;
+      }
+      j = bj->parent;
+    }
+  }
+  /* implicit PD drives / tendons: A = M + dt*D + dt^2*K; saturated drives become constant forces */
+  float Kd[MSK_MAX_DOF], Dd[MSK_MAX_DOF], fconst[MSK_MAX_DOF], fmaxd[MSK_MAX_DOF], err[MSK_MAX_DOF];
+  for (int i = 0; i < c->nb; ++i) {
+    const orc_body* b = &c->bodies[i];
+    if (b->kind != MSK_BODY_LINK || b->dof < 0) continue;
+    Kd[b->dof] = b->K; Dd[b->dof] = b->D; fmaxd[b->dof] = b->fmax; fconst[b->dof] = 0.0f;
+    err[b->dof] = e->q[b->dof] - e->qt[b->dof];
+  }
+  float A[MSK_MAX_DOF][MSK_MAX_DOF], L[MSK_MAX_DOF][MSK_MAX_DOF], rhs[MSK_MAX_DOF];
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = 0; i < nd; ++i) {
+      float mv = 0.0f;
+      for (int k = 0; k < nd; ++k) { A[i][k] = M[i][k]; mv = fmaf(M[i][k], e->qd[k], mv); }
+      A[i][i] += dt * fmaf(dt, Kd[i], Dd[i]);
+      float tau = e->qf[i] - bias[i] - Kd[i] * err[i] + Dd[i] * e->qdt[i] + fconst[i];
+      rhs[i] = fmaf(dt, tau, mv);
+    }
+    for (int t = 0; t < c->nt; ++t) {
+      const orc_tendon* tn = &c->tendons[t];
+      float g2 = dt * fmaf(dt, tn->K, tn->D);
+      float te = fmaf(tn->ca, e->q[tn->dof_a], tn->cb * e->q[tn->dof_b]) - tn->rest;
+      A[tn->dof_a][tn->dof_a] += g2 * tn->ca * tn->ca;
+      A[tn->dof_b][tn->dof_b] += g2 * tn->cb * tn->cb;
+      A[tn->dof_a][tn->dof_b] += g2 * tn->ca * tn->cb;
+      A[tn->dof_b][tn->dof_a] += g2 * tn->ca * tn->cb;
+      rhs[tn->dof_a] -= dt * tn->K * te * tn->ca;
+      rhs[tn->dof_b] -= dt * tn->K * te * tn->cb;
+    }
+    /* Cholesky A = L L^T (lower) */
+    memset(L, 0, sizeof(L));
+    for (int i = 0; i < nd; ++i) {
+      for (int j = 0; j <= i; ++j) {
+        float sum = A[i][j];
+        for (int k = 0; k < j; ++k) sum = fmaf(-L[i][k], L[j][k], sum);
+        if (i == j) L[i][i] = sqrtf(sum);
+        else L[i][j] = sum / L[j][j];
+      }
+    }
+    /* v* = A^-1 rhs */
+    float y[MSK_MAX_DOF];
+    for (int i = 0; i < nd; ++i) {
+      float sum = rhs[i];
+      for (int k = 0; k < i; ++k) sum = fmaf(-L[i][k], y[k], sum);
+      y[i] = sum / L[i][i];
+    }
+    for (int i = nd - 1; i >= 0; --i) {
+      float sum = y[i];
+      for (int k = i + 1; k < nd; ++k) sum = fmaf(-L[k][i], s->vfree[k], sum);
+      s->vfree[i] = sum / L[i][i];
+    }
+    if (pass == 1) break;
+    /* drive force limits: predict the PD force at v*, saturate where it exceeds the limit */
+    int nsat = 0;
+    for (int i = 0; i < nd; ++i) {
+      if (Kd[i] == 0.0f && Dd[i] == 0.0f) continue;
+      float F = -Kd[i] * fmaf(dt, s->vfree[i], err[i]) - Dd[i] * (s->vfree[i] - e->qdt[i]);
+      if (fabsf(F) > fmaxd[i]) {
+        fconst[i] = (F > 0.0f) ? fmaxd[i] : -fmaxd[i];
+        Kd[i] = 0.0f; Dd[i] = 0.0f; err[i] = 0.0f;
+        nsat++;
+      }
+    }
+    if (nsat == 0) break;
+  }
+  /* A^-1 column by column */
+  for (int col = 0; col < nd; ++col) {
+    float y[MSK_MAX_DOF];
+    for (int i = 0; i < nd; ++i) {
+      float sum = (i == col) ? 1.0f : 0.0f;
+      for (int k = 0; k < i; ++k) sum = fmaf(-L[i][k], y[k], sum);
+      y[i] = sum / L[i][i];
+    }
+    for (int i = nd - 1; i >= 0; --i) {
+      float sum = y[i];
+      for (int k = i + 1; k < nd; ++k) sum = fmaf(-L[k][i], s->Minv[k][col], sum);
+      s->Minv[i][col] = sum / L[i][i];
+    }
+  }
+  for (int i = 0; i < c->nb; ++i) {
+    const orc_body* b = &c->bodies[i];
+    if (b->kind != MSK_BODY_DYNAMIC) continue;
+    v3 v = e->blin[i], w = e->bang[i];
+    if (!b->nograv) v = v3_madd(v, g, dt);
+    float kl = fmaxf(0.0f, 1.0f - dt * b->lin_damp);
+    float ka = fmaxf(0.0f, 1.0f - dt * b->ang_damp);
+    v = v3_scale(v, kl);
+    w = v3_scale(w, ka);
+    s->vfree[b->vofs + 0] = v.x; s->vfree[b->vofs + 1] = v.y; s->vfree[b->vofs + 2] = v.z;
+    s->vfree[b->vofs + 3] = w.x; s->vfree[b->vofs + 4] = w.y; s->vfree[b->vofs + 5] = w.z;
+  }
+}
+
+/* ---- 3. collision ----------------------------------------------------------------- */
+static void collide(const orc_ctx* c, orc_env* e) {
+  /* previous step's contacts, for warm starting: a new point inherits the impulses of the nearest
+   * old point of the same shape pair if it lies within ORC_WARM_DIST */
+  orc_contact prev[MSK_MAX_CONTACTS];
+  const int nprev = e->ncontacts;
+  memcpy(prev, e->contacts, sizeof(orc_contact) * (size_t)nprev);
+  e->ncontacts = 0;
+  for (int p = 0; p < c->npairs; ++p) {
+    orc_contact tmp[4];
+    int n = orc_collide_pair(c, e, p, tmp);
+    for (int k = 0; k < n; ++k) {
+      if (e->ncontacts >= MSK_MAX_CONTACTS) { e->overflow = 1; break; }
+      orc_contact* ct = &tmp[k];
+      ct->lam[0] = ct->lam[1] = ct->lam[2] = 0.0f;
+      int best = -1;
+      float bd = ORC_WARM_DIST * ORC_WARM_DIST;
+      for (int j = 0; j < nprev; ++j) {
+        if (prev[j].sa != ct->sa || prev[j].sb != ct->sb) continue;
+        float d2 = v3_len2(v3_sub(prev[j].pos, ct->pos));
+        if (d2 < bd) { bd = d2; best = j; }
+      }
+      if (best >= 0)
+        for (int a = 0; a < 3; ++a) ct->lam[a] = ORC_WARM_FACTOR * prev[best].lam[a];
+      e->contacts[e->ncontacts++] = *ct;
+    }
+  }
+}
+
+/* ---- 4. rows ---------------------------------------------------------------------- */
+/* J += sgn * (generalized velocity -> velocity of the body-fixed point p along dir) */
+static void jac_point(const orc_ctx* c, const orc_scratch* s, int body, v3 p, v3 dir, float sgn, float* J) {
+  if (body < 0) return;
+  const orc_body* b = &c->bodies[body];
+  if (b->kind == MSK_BODY_LINK) {
+    sv6 F = {v3_cross(p, dir), dir};
+    int j = body;
+    while (j >= 0) {
+      const orc_body* bj = &c->bodies[j];
+      if (bj->dof >= 0) J[bj->dof] = fmaf(sgn, sv6_dot(s->S[j], F), J[bj->dof]);
+      j = bj->parent;
+    }
+  } else if (b->kind == MSK_BODY_DYNAMIC) {
+    v3 r = v3_cross(v3_sub(p, s->comw[body]), dir);
+    J[b->vofs + 0] += sgn * dir.x; J[b->vofs + 1] += sgn * dir.y; J[b->vofs + 2] += sgn * dir.z;
+    J[b->vofs + 3] += sgn * r.x; J[b->vofs + 4] += sgn * r.y; J[b->vofs + 5] += sgn * r.z;
+  }
+}
+
+static void apply_minv(const orc_ctx* c, const orc_scratch* s, orc_row* r) {
+  const int nd = c->ndof;
+  for (int i = 0; i < nd; ++i) {
+    float a = 0.0f;
+    for (int k = 0; k < nd; ++k) a = fmaf(s->Minv[i][k], r->J[k], a);
+    r->Y[i] = a;
+  }
+  for (int i = 0; i < c->nb; ++i) {
+    const orc_body* b = &c->bodies[i];
+    if (b->kind != MSK_BODY_DYNAMIC) continue;
+    float im = 1.0f / b->mass;
+    r->Y[b->vofs + 0] = r->J[b->vofs + 0] * im;
+    r->Y[b->vofs + 1] = r->J[b->vofs + 1] * im;
+    r->Y[b->vofs + 2] = r->J[b->vofs + 2] * im;
+    v3 ja = v3_make(r->J[b->vofs + 3], r->J[b->vofs + 4], r->J[b->vofs + 5]);
+    v3 ya = sym6_mulv(s->Iwinv[i], ja);
+    r->Y[b->vofs + 3] = ya.x; r->Y[b->vofs + 4] = ya.y; r->Y[b->vofs + 5] = ya.z;
+  }
+  float d = 0.0f;
+  for (int k = 0; k < c->nv; ++k) d = fmaf(r->J[k], r->Y[k], d);
+  r->d = d;
+}
+
+/* ---- 5./6. solve and integrate ----------------------------------------------------- */
+void orc_step_env(const orc_ctx* c, orc_env* e) {
+  static _Thread_local orc_row rows[2 * MSK_MAX_DOF + 3 * MSK_MAX_CONTACTS];
+  orc_scratch s;
+  const int nv = c->nv, nd = c->ndof;
+  const float dt = c->cfg.timestep;
+  const int Np = c->cfg.solver_position_iterations, Nv = c->cfg.solver_velocity_iterations;
+  const float h = dt / (float)Np;
+
+  kinematics(c, e, &s);
+  dynamics(c, e, &s);
+  collide(c, e);
+
+  int nr = 0;
+  for (int i = 0; i < c->nb; ++i) {
+    const orc_body* b = &c->bodies[i];
+    if (b->kind != MSK_BODY_LINK || b->dof < 0) continue;
+    if (b->lim_lo < -1e30f && b->lim_hi > 1e30f) continue;
+    for (int kind = ROW_LIMLO; kind <= ROW_LIMHI; ++kind) {
+      orc_row* r = &rows[nr++];
+      memset(r, 0, sizeof(*r));
+      r->kind = kind;
+      r->idx = i;
+      r->J[b->dof] = (kind == ROW_LIMHI) ? -1.0f : 1.0f;
+      apply_minv(c, &s, r);
+    }
+  }
+  for (int k = 0; k < e->ncontacts; ++k) {
+    orc_contact* ct = &e->contacts[k];
+    orc_tangents(ct->n, &ct->t1, &ct->t2);
+    v3 dirs[3] = {ct->n, ct->t1, ct->t2};
+    for (int a = 0; a < 3; ++a) {
+      orc_row* r = &rows[nr++];
+      memset(r, 0, sizeof(*r));
+      r->kind = ROW_CN + a;
+      r->idx = k;
+      jac_point(c, &s, ct->ba, ct->pos, dirs[a], 1.0f, r->J);
+      jac_point(c, &s, ct->bb, ct->pos, dirs[a], -1.0f, r->J);
+      apply_minv(c, &s, r);
+      r->lam = ct->lam[a];
+    }
+  }
+
+  float v[MSK_MAX_NV], dq[MSK_MAX_NV];
+  for (int k = 0; k < nv; ++k) { v[k] = s.vfree[k]; dq[k] = 0.0f; }
+  for (int ri = 0; ri < nr; ++ri)
+    if (rows[ri].lam != 0.0f)
+      for (int k = 0; k < nv; ++k) v[k] = fmaf(rows[ri].Y[k], rows[ri].lam, v[k]);
+
+  for (int it = 0; it < Np + Nv; ++it) {
+    const int posit = it < Np;
+    for (int ri = 0; ri < nr; ++ri) {
+      orc_row* r = &rows[ri];
+      float jv = 0.0f, jdq = 0.0f;
+      for (int k = 0; k < nv; ++k) { jv = fmaf(r->J[k], v[k], jv); jdq = fmaf(r->J[k], dq[k], jdq); }
+      float dl = 0.0f;
+      switch (r->kind) {
+        case ROW_LIMLO:
+        case ROW_LIMHI:
+        case ROW_CN: {
+          float c0;
+          if (r->kind == ROW_CN) c0 = e->contacts[r->idx].sep;
+          else {
+            const orc_body* b = &c->bodies[r->idx];
+            c0 = (r->kind == ROW_LIMLO) ? (e->q[b->dof] - b->lim_lo) : (b->lim_hi - e->q[b->dof]);
+          }
+          float cur = c0 + jdq;
+          float bias;
+          if (posit) bias = (cur > 0.0f) ? cur / h : fmaxf(cur * (ORC_PEN_BETA / dt), -ORC_MAX_DEPEN_VEL);
+          else bias = (cur > 0.0f) ? cur / dt : 0.0f;
+          dl = -(jv + bias) / r->d;
+          float nl = fmaxf(r->lam + dl, 0.0f);
+          dl = nl - r->lam;
+          r->lam = nl;
+          break;
+        }
+        default: { /* friction */
+          const orc_contact* ct = &e->contacts[r->idx];
+          const orc_row* rn = &rows[ri - (r->kind - ROW_CN)];
+          float bias = posit ? jdq / h : 0.0f;
+          dl = -(jv + bias) / r->d;
+          float lim = ct->mu * rn->lam;
+          float nl = fminf(fmaxf(r->lam + dl, -lim), lim);
+          dl = nl - r->lam;
+          r->lam = nl;
+          break;
+        }
+      }
+      if (dl != 0.0f)
+        for (int k = 0; k < nv; ++k) v[k] = fmaf(r->Y[k], dl, v[k]);
+    }
+    if (posit)
+      for (int k = 0; k < nv; ++k) dq[k] = fmaf(h, v[k], dq[k]);
+  }
+
+  /* contact impulses for the reports */
+  for (int ri = 0; ri < nr; ++ri)
+    if (rows[ri].kind >= ROW_CN) e->contacts[rows[ri].idx].lam[rows[ri].kind - ROW_CN] = rows[ri].lam;
+
+  /* integrate */
+  for (int i = 0; i < nd; ++i) {
+    e->qacc[i] = (v[i] - e->qd[i]) / dt;
+    e->q[i] += dq[i];
+    e->qd[i] = v[i];
+  }
+  for (int i = 0; i < c->nb; ++i) {
+    const orc_body* b = &c->bodies[i];
+    if (b->kind != MSK_BODY_DYNAMIC) continue;
+    v3 dx = v3_make(dq[b->vofs + 0], dq[b->vofs + 1], dq[b->vofs + 2]);
+    v3 dr = v3_make(dq[b->vofs + 3], dq[b->vofs + 4], dq[b->vofs + 5]);
+    v3 cw = v3_add(s.comw[i], dx);
+    quat qn = quat_normalize(quat_mul(quat_from_rotvec(dr), e->bpose[i].q));
+    e->bpose[i].q = qn;
+    e->bpose[i].p = v3_sub(cw, quat_rotate(qn, b->com));
+    e->blin[i] = v3_make(v[b->vofs + 0], v[b->vofs + 1], v[b->vofs + 2]);
+    e->bang[i] = v3_make(v[b->vofs + 3], v[b->vofs + 4], v[b->vofs + 5]);
+  }
+  kinematics(c, e, &s);
+}

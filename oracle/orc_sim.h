@@ -1,0 +1,115 @@
+/*
+ * orc_sim.h — data model of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+ *
+ * The oracle restates, in scalar readable C, the algorithm the HIP backend implements for
+ * `PhysxGpuSystem.step()` (reference call site mani_skill/envs/scene.py:379-380).  The
+ * arithmetic behind that call lives in the un-vendored `sapien>=3.0.0` wheel (PhysX 5,
+ * reference setup.py:50) and is NOT available: parity unpinned against PhysX.  What is
+ * restated here is the published pipeline — broadphase over per-env shape pairs, convex
+ * narrowphase (SAT for boxes, GJK/EPA for hulls) with one-shot face-clipping manifolds,
+ * reduced-coordinate articulation dynamics (Featherstone CRBA/RNEA), and a temporal
+ * Gauss-Seidel (TGS) row solver with implicit PD joint drives — anchored on the contract
+ * visible in the reference (buffer layouts, solver parameters, drive semantics;
+ * SURVEY.md §8).
+ */
+#ifndef ORC_SIM_H
+#define ORC_SIM_H
+
+#include "../include/msk_physx.h"
+#include "orc_math.h"
+
+typedef struct {
+  int kind;          /* msk_body_kind */
+  int art;           /* articulation index or -1 */
+  int parent;        /* parent body id (links) or -1 */
+  int jtype;         /* msk_joint_type */
+  pose Xp;           /* pose_in_parent */
+  pose XcInv;        /* inverse of pose_in_child */
+  float lim_lo, lim_hi;
+  float mass;
+  v3 com;            /* COM in body frame */
+  float I6[6];       /* inertia about COM in body axes */
+  float Iinv6[6];    /* inverse (free bodies) */
+  int nograv;
+  float armature, jfriction;
+  int dof;           /* index into q (articulation dof) or -1 */
+  int vofs;          /* offset into the generalized velocity vector (free bodies), or -1 */
+  float K, D, fmax;  /* drive */
+  int drive_accel;
+  float lin_damp, ang_damp;
+  pose init_pose;    /* actors: initial pose; root links: articulation root pose */
+  int movable;       /* 1 if the body can move (dynamic actor, or link below a moving joint) */
+} orc_body;
+
+typedef struct {
+  int body;          /* body id or -1 (static world) */
+  int type;          /* msk_shape_type */
+  pose local;
+  float par[3];
+  int nverts;
+  v3 verts[MSK_MAX_HULL_VERTS];
+  v3 aabb_c, aabb_h; /* local AABB */
+  float sf, df, rest;
+  uint32_t g[4];
+  float patch_r;
+} orc_shape;
+
+typedef struct { int dof_a, dof_b; float ca, cb, rest, K, D; } orc_tendon;
+typedef struct { int sa, sb; } orc_pair;
+
+typedef struct {
+  int sa, sb;        /* shape ids, sa < sb */
+  int ba, bb;        /* body ids (-1 static) */
+  v3 pos;            /* contact point (env frame) */
+  v3 n;              /* unit normal, from B towards A */
+  float sep;         /* signed separation along n (negative = penetration) */
+  float mu;
+  float lam[3];      /* accumulated impulses: normal, t1, t2 */
+  v3 t1, t2;
+} orc_contact;
+
+typedef struct {
+  /* articulation state */
+  float q[MSK_MAX_DOF], qd[MSK_MAX_DOF], qacc[MSK_MAX_DOF], qf[MSK_MAX_DOF];
+  float qt[MSK_MAX_DOF], qdt[MSK_MAX_DOF];
+  /* body state: world (env-frame) pose of the body frame, COM linear velocity, angular velocity */
+  pose bpose[MSK_MAX_BODIES];
+  v3 blin[MSK_MAX_BODIES], bang[MSK_MAX_BODIES];
+  /* contacts of the last step */
+  int ncontacts;
+  orc_contact contacts[MSK_MAX_CONTACTS];
+  int overflow;
+} orc_env;
+
+struct msk_ctx; /* opaque in the public header; the oracle's own definition follows */
+
+typedef struct orc_ctx {
+  msk_config cfg;
+  int finalized;
+  int nb, na, ndof, nv, ns, npairs, nt;
+  int art_root[8];
+  orc_body bodies[MSK_MAX_BODIES];
+  orc_shape shapes[MSK_MAX_SHAPES];
+  orc_tendon tendons[MSK_MAX_TENDONS];
+  orc_pair pairs[MSK_MAX_PAIRS];
+  int ndisabled;
+  int disabled[256][2];
+  int max_dof;       /* per-articulation max dof (buffer width) */
+  int art_dof0[8], art_ndof[8];
+  int num_envs;
+  orc_env* envs;
+  float* offsets;    /* num_envs*3 */
+  /* external buffers (host memory, same layout as the device buffers of the HIP library) */
+  float* buf[MSK_BUF_COUNT];
+  int nqueries;
+  struct { int npairs; int32_t* pairs; float* out; } queries[16];
+  char err[256];
+} orc_ctx;
+
+/* orc_collide.c */
+int orc_collide_pair(const orc_ctx* c, const orc_env* e, int pair_index, orc_contact* out /* up to 4 */);
+/* orc_sim.c */
+void orc_forward_kinematics(const orc_ctx* c, orc_env* e);
+void orc_step_env(const orc_ctx* c, orc_env* e);
+
+#endif

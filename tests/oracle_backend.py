@@ -1,0 +1,35 @@
+"""Test double: the CPU oracle (oracle/liborc.so) behind maniskill_amd's PhysxGpuSystem class.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import os
+import subprocess
+
+import torch
+
+from maniskill_amd import _native as N
+from maniskill_amd.physx import PhysxGpuSystem
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "liborc.so")
+
+_lib = None
+
+
+def oracle_lib() -> N.NativeLib:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_LIB):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "liborc.so"])
+        _lib = N.NativeLib(ORACLE_LIB, "orc_")
+    return _lib
+
+
+class OraclePhysxSystem(PhysxGpuSystem):
+    """Same Python surface, host memory, scalar C arithmetic (the parity checker)."""
+
+    host_memory = True
+
+    def __init__(self, template, num_envs, sim_config=None):
+        super().__init__(torch.device("cpu"), template, num_envs, sim_config, lib=oracle_lib())
