@@ -1,0 +1,629 @@
+/*
+ * msk_collide.h — per-pair narrowphase device functions (one HIP thread = one (pair, env)).
+ *
+ * box-box SAT, GJK distance + EPA penetration for hulls, plane-vs-vertices, and the one-shot
+ * support-feature clipping manifold (<= 4 points per pair).  The pair index is uniform over a
+ * wavefront (64 lanes = 64 envs of the same pair), so shape constants and hull vertices are
+ * fetched with scalar loads and all lanes follow the same shape-type branch; only iteration
+ * counts diverge.  Arithmetic is kept operation-for-operation identical to the CPU oracle.
+ */
+#ifndef MSK_COLLIDE_H
+#define MSK_COLLIDE_H
+
+#include "msk_model.h"
+
+#define ORC_FEAT_EPS 2.5e-3f
+#define ORC_GJK_ITERS 32
+#define ORC_EPA_ITERS 32
+#define ORC_EPA_MAXV 40
+#define ORC_EPA_MAXF 96
+
+struct DContactOut { v3 pos; v3 n; float sep; };
+
+MSK_DEV int shape_nverts(const DShape* sh) { return sh->type == MSK_SHAPE_BOX ? 8 : sh->nverts; }
+MSK_DEV v3 shape_vert(const DModel* m, const DShape* sh, int i) {
+  if (sh->type == MSK_SHAPE_BOX)
+    return v3_make((i & 1) ? sh->par[0] : -sh->par[0], (i & 2) ? sh->par[1] : -sh->par[1],
+                   (i & 4) ? sh->par[2] : -sh->par[2]);
+  return m->verts[sh->vbase + i];
+}
+
+/* support point (world) of a box / hull in world direction d */
+MSK_DEV v3 support(const DModel* m, const DShape* sh, const pose* T, v3 d) {
+  v3 dl = quat_rotate_inv(T->q, d);
+  v3 pl;
+  if (sh->type == MSK_SHAPE_BOX) {
+    pl = v3_make(dl.x >= 0.0f ? sh->par[0] : -sh->par[0], dl.y >= 0.0f ? sh->par[1] : -sh->par[1],
+                 dl.z >= 0.0f ? sh->par[2] : -sh->par[2]);
+  } else {
+    int best = 0;
+    float bd = v3_dot(m->verts[sh->vbase], dl);
+    for (int i = 1; i < sh->nverts; ++i) {
+      float di = v3_dot(m->verts[sh->vbase + i], dl);
+      if (di > bd) { bd = di; best = i; }
+    }
+    pl = m->verts[sh->vbase + best];
+  }
+  return pose_apply(*T, pl);
+}
+
+MSK_DEV void world_aabb(const DShape* sh, const pose* T, v3* c, v3* h) {
+  m33 R = quat_to_m33(T->q);
+  *c = v3_add(T->p, m33_mulv(&R, sh->aabb_c));
+  h->x = fmaf(fabsf(R.m[0][0]), sh->aabb_h.x, fmaf(fabsf(R.m[0][1]), sh->aabb_h.y, fabsf(R.m[0][2]) * sh->aabb_h.z));
+  h->y = fmaf(fabsf(R.m[1][0]), sh->aabb_h.x, fmaf(fabsf(R.m[1][1]), sh->aabb_h.y, fabsf(R.m[1][2]) * sh->aabb_h.z));
+  h->z = fmaf(fabsf(R.m[2][0]), sh->aabb_h.x, fmaf(fabsf(R.m[2][1]), sh->aabb_h.y, fabsf(R.m[2][2]) * sh->aabb_h.z));
+}
+
+/* ---- manifold ------------------------------------------------------------------------ */
+typedef struct { float u, v, h; } p3;   /* coordinates in the (t1, t2, n) contact frame */
+
+/* support feature of `sh` along sign*n: up to 8 extreme points, CCW about n */
+MSK_DEV int select_feature(const DModel* m, const DShape* sh, const pose* T, v3 n, v3 t1, v3 t2, float sign, p3* out) {
+  const float DX[8] = {1.0f, 0.70710678f, 0.0f, -0.70710678f, -1.0f, -0.70710678f, 0.0f, 0.70710678f};
+  const float DY[8] = {0.0f, 0.70710678f, 1.0f, 0.70710678f, 0.0f, -0.70710678f, -1.0f, -0.70710678f};
+  v3 nl = quat_rotate_inv(T->q, n), t1l = quat_rotate_inv(T->q, t1), t2l = quat_rotate_inv(T->q, t2);
+  float on = v3_dot(T->p, n), o1 = v3_dot(T->p, t1), o2 = v3_dot(T->p, t2);
+  int nv = shape_nverts(sh);
+  float hh[MSK_MAX_HULL_VERTS];
+  float hbest = -3.0e38f;
+  for (int i = 0; i < nv; ++i) {
+    hh[i] = v3_dot(shape_vert(m, sh, i), nl);
+    float s = sign * hh[i];
+    if (s > hbest) hbest = s;
+  }
+  int sel[8];
+  for (int k = 0; k < 8; ++k) {
+    int best = -1;
+    float bd = -3.0e38f;
+    for (int i = 0; i < nv; ++i) {
+      if (sign * hh[i] < hbest - ORC_FEAT_EPS) continue;
+      v3 p = shape_vert(m, sh, i);
+      float d = fmaf(v3_dot(p, t1l), DX[k], v3_dot(p, t2l) * DY[k]);
+      if (d > bd) { bd = d; best = i; }
+    }
+    sel[k] = best;
+  }
+  int cnt = 0;
+  int kept[8];
+  for (int k = 0; k < 8; ++k) {
+    if (cnt > 0 && sel[k] == kept[cnt - 1]) continue;
+    kept[cnt++] = sel[k];
+  }
+  if (cnt > 1 && kept[cnt - 1] == kept[0]) cnt--;
+  for (int k = 0; k < cnt; ++k) {
+    v3 p = shape_vert(m, sh, kept[k]);
+    out[k].u = v3_dot(p, t1l) + o1;
+    out[k].v = v3_dot(p, t2l) + o2;
+    out[k].h = hh[kept[k]] + on;
+  }
+  return cnt;
+}
+
+/* height (n coordinate) of a feature's surface above the in-plane point (u, v) */
+MSK_DEV float feature_height(const p3* f, int n, float u, float v) {
+  if (n == 1) return f[0].h;
+  if (n == 2) {
+    float du = f[1].u - f[0].u, dv = f[1].v - f[0].v;
+    float l2 = fmaf(du, du, dv * dv);
+    float t = (l2 > 1e-12f) ? fmaf(u - f[0].u, du, (v - f[0].v) * dv) / l2 : 0.0f;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    return fmaf(t, f[1].h - f[0].h, f[0].h);
+  }
+  /* Newell normal and centroid */
+  float mx = 0, my = 0, mz = 0, gu = 0, gv = 0, gh = 0;
+  for (int i = 0; i < n; ++i) {
+    const p3* a = &f[i];
+    const p3* b = &f[(i + 1) % n];
+    mx += (a->v - b->v) * (a->h + b->h);
+    my += (a->h - b->h) * (a->u + b->u);
+    mz += (a->u - b->u) * (a->v + b->v);
+    gu += a->u; gv += a->v; gh += a->h;
+  }
+  float inv = 1.0f / (float)n;
+  gu *= inv; gv *= inv; gh *= inv;
+  if (fabsf(mz) < 1e-12f) return gh;
+  return gh - (mx * (u - gu) + my * (v - gv)) / mz;
+}
+
+MSK_DEV float cross2(float ax, float ay, float bx, float by) { return fmaf(ax, by, -(ay * bx)); }
+
+/* clip the segment p0-p1 against the convex CCW polygon poly; returns number of points (0..2) */
+MSK_DEV int clip_segment_poly(const p3* seg, const p3* poly, int np, float out[][2]) {
+  float t0 = 0.0f, t1 = 1.0f;
+  float dx = seg[1].u - seg[0].u, dy = seg[1].v - seg[0].v;
+  for (int i = 0; i < np; ++i) {
+    const p3* a = &poly[i];
+    const p3* b = &poly[(i + 1) % np];
+    float ex = b->u - a->u, ey = b->v - a->v;
+    float c0 = cross2(ex, ey, seg[0].u - a->u, seg[0].v - a->v);
+    float cd = cross2(ex, ey, dx, dy);
+    if (fabsf(cd) < 1e-12f) {
+      if (c0 < -1e-7f) return 0;
+      continue;
+    }
+    float t = -c0 / cd;
+    if (cd > 0.0f) { if (t > t0) t0 = t; }
+    else { if (t < t1) t1 = t; }
+  }
+  if (t0 > t1 + 1e-6f) return 0;
+  out[0][0] = fmaf(t0, dx, seg[0].u); out[0][1] = fmaf(t0, dy, seg[0].v);
+  if (t1 - t0 < 1e-6f) return 1;
+  out[1][0] = fmaf(t1, dx, seg[0].u); out[1][1] = fmaf(t1, dy, seg[0].v);
+  return 2;
+}
+
+/* Sutherland-Hodgman: subject polygon (CCW) clipped by convex CCW polygon */
+MSK_DEV int clip_poly_poly(const p3* subj, int ns, const p3* clip, int nc, float out[][2]) {
+  float bufa[24][2], bufb[24][2];
+  int na = ns;
+  for (int i = 0; i < ns; ++i) { bufa[i][0] = subj[i].u; bufa[i][1] = subj[i].v; }
+  float(*in)[2] = bufa;
+  float(*ot)[2] = bufb;
+  for (int ci = 0; ci < nc && na > 0; ++ci) {
+    const p3* a = &clip[ci];
+    const p3* b = &clip[(ci + 1) % nc];
+    float ex = b->u - a->u, ey = b->v - a->v;
+    int no = 0;
+    for (int i = 0; i < na; ++i) {
+      const float* P = in[i];
+      const float* Q = in[(i + 1) % na];
+      float cp = cross2(ex, ey, P[0] - a->u, P[1] - a->v);
+      float cq = cross2(ex, ey, Q[0] - a->u, Q[1] - a->v);
+      int pin = cp >= -1e-9f, qin = cq >= -1e-9f;
+      if (pin && no < 24) { ot[no][0] = P[0]; ot[no][1] = P[1]; no++; }
+      if (pin != qin && no < 24) {
+        float t = cp / (cp - cq);
+        ot[no][0] = fmaf(t, Q[0] - P[0], P[0]);
+        ot[no][1] = fmaf(t, Q[1] - P[1], P[1]);
+        no++;
+      }
+    }
+    float(*tmp)[2] = in; in = ot; ot = tmp;
+    na = no;
+  }
+  for (int i = 0; i < na; ++i) { out[i][0] = in[i][0]; out[i][1] = in[i][1]; }
+  return na;
+}
+
+MSK_DEV int seg_seg(const p3* a, const p3* b, float out[][2]) {
+  float d1x = a[1].u - a[0].u, d1y = a[1].v - a[0].v;
+  float d2x = b[1].u - b[0].u, d2y = b[1].v - b[0].v;
+  float rx = b[0].u - a[0].u, ry = b[0].v - a[0].v;
+  float den = cross2(d1x, d1y, d2x, d2y);
+  float l1 = fmaf(d1x, d1x, d1y * d1y), l2 = fmaf(d2x, d2x, d2y * d2y);
+  if (den * den > 1e-6f * l1 * l2) {
+    float s = cross2(rx, ry, d2x, d2y) / den;
+    s = fminf(fmaxf(s, 0.0f), 1.0f);
+    out[0][0] = fmaf(s, d1x, a[0].u); out[0][1] = fmaf(s, d1y, a[0].v);
+    return 1;
+  }
+  /* parallel: overlap of b's endpoints projected on a */
+  if (l1 < 1e-12f) { out[0][0] = a[0].u; out[0][1] = a[0].v; return 1; }
+  float s0 = fmaf(rx, d1x, ry * d1y) / l1;
+  float s1 = fmaf(b[1].u - a[0].u, d1x, (b[1].v - a[0].v) * d1y) / l1;
+  float lo = fmaxf(fminf(s0, s1), 0.0f), hi = fminf(fmaxf(s0, s1), 1.0f);
+  if (lo > hi) { float m = fminf(fmaxf(0.5f * (s0 + s1), 0.0f), 1.0f); lo = hi = m; }
+  out[0][0] = fmaf(lo, d1x, a[0].u); out[0][1] = fmaf(lo, d1y, a[0].v);
+  if (hi - lo < 1e-6f) return 1;
+  out[1][0] = fmaf(hi, d1x, a[0].u); out[1][1] = fmaf(hi, d1y, a[0].v);
+  return 2;
+}
+
+typedef struct { float u, v, hm, sep; } cand;
+
+/* keep at most 4 candidates: deepest, farthest from it, and the extremes on both sides of that line */
+MSK_DEV int reduce4(cand* cs, int n) {
+  if (n <= 4) return n;
+  int i0 = 0;
+  for (int i = 1; i < n; ++i) if (cs[i].sep < cs[i0].sep) i0 = i;
+  int i1 = -1; float best = -1.0f;
+  for (int i = 0; i < n; ++i) {
+    if (i == i0) continue;
+    float du = cs[i].u - cs[i0].u, dv = cs[i].v - cs[i0].v;
+    float d = fmaf(du, du, dv * dv);
+    if (d > best) { best = d; i1 = i; }
+  }
+  float ex = cs[i1].u - cs[i0].u, ey = cs[i1].v - cs[i0].v;
+  int i2 = -1, i3 = -1; float bp = 0.0f, bn = 0.0f;
+  for (int i = 0; i < n; ++i) {
+    if (i == i0 || i == i1) continue;
+    float cr = cross2(ex, ey, cs[i].u - cs[i0].u, cs[i].v - cs[i0].v);
+    if (cr > bp) { bp = cr; i2 = i; }
+    if (cr < bn) { bn = cr; i3 = i; }
+  }
+  cand out[4];
+  int m = 0;
+  out[m++] = cs[i0]; out[m++] = cs[i1];
+  if (i2 >= 0) out[m++] = cs[i2];
+  if (i3 >= 0) out[m++] = cs[i3];
+  for (int i = 0; i < m; ++i) cs[i] = out[i];
+  return m;
+}
+
+MSK_DEV int build_manifold(const DModel* m, const DShape* A, const pose* TA, const DShape* B, const pose* TB, v3 n,
+                          float margin, v3 wa, v3 wb, float sep_hint, DContactOut* out) {
+  v3 t1, t2;
+  msk_tangents(n, &t1, &t2);
+  p3 fa[8], fb[8];
+  int ka = select_feature(m, A, TA, n, t1, t2, -1.0f, fa);
+  int kb = select_feature(m, B, TB, n, t1, t2, 1.0f, fb);
+  float pts[24][2];
+  int np = 0;
+  if (ka == 1) { pts[0][0] = fa[0].u; pts[0][1] = fa[0].v; np = 1; }
+  else if (kb == 1) { pts[0][0] = fb[0].u; pts[0][1] = fb[0].v; np = 1; }
+  else if (ka >= 3 && kb >= 3) np = clip_poly_poly(fa, ka, fb, kb, pts);
+  else if (ka == 2 && kb >= 3) np = clip_segment_poly(fa, fb, kb, pts);
+  else if (kb == 2 && ka >= 3) np = clip_segment_poly(fb, fa, ka, pts);
+  else np = seg_seg(fa, fb, pts);
+  cand cs[24];
+  int nc = 0;
+  for (int i = 0; i < np; ++i) {
+    float ha = feature_height(fa, ka, pts[i][0], pts[i][1]);
+    float hb = feature_height(fb, kb, pts[i][0], pts[i][1]);
+    float sep = ha - hb;
+    if (sep > margin) continue;
+    cs[nc].u = pts[i][0]; cs[nc].v = pts[i][1]; cs[nc].hm = 0.5f * (ha + hb); cs[nc].sep = sep;
+    nc++;
+  }
+  if (nc == 0) {
+    if (sep_hint > margin) return 0;
+    v3 mid = v3_scale(v3_add(wa, wb), 0.5f);
+    out[0].pos = mid; out[0].n = n; out[0].sep = sep_hint;
+    return 1;
+  }
+  nc = reduce4(cs, nc);
+  for (int i = 0; i < nc; ++i) {
+    out[i].pos = v3_madd(v3_madd(v3_scale(t1, cs[i].u), t2, cs[i].v), n, cs[i].hm);
+    out[i].n = n;
+    out[i].sep = cs[i].sep;
+  }
+  return nc;
+}
+
+/* ---- box-box SAT ---------------------------------------------------------------------- */
+MSK_DEV int sat_box_box(const DShape* A, const pose* TA, const DShape* B, const pose* TB, float margin,
+                       v3* n_out, float* sep_out) {
+  m33 Ra = quat_to_m33(TA->q), Rb = quat_to_m33(TB->q);
+  v3 au[3] = {m33_col(&Ra, 0), m33_col(&Ra, 1), m33_col(&Ra, 2)};
+  v3 bu[3] = {m33_col(&Rb, 0), m33_col(&Rb, 1), m33_col(&Rb, 2)};
+  const float* a = A->par;
+  const float* b = B->par;
+  v3 dc = v3_sub(TA->p, TB->p); /* from B to A */
+  float R[3][3], AR[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) { R[i][j] = v3_dot(au[i], bu[j]); AR[i][j] = fabsf(R[i][j]); }
+  float best_f = -3.0e38f; v3 nf = v3_make(0, 0, 1);
+  for (int i = 0; i < 3; ++i) {
+    float t = v3_dot(dc, au[i]);
+    float rb = fmaf(b[0], AR[i][0], fmaf(b[1], AR[i][1], b[2] * AR[i][2]));
+    float s = fabsf(t) - (a[i] + rb);
+    if (s > best_f) { best_f = s; nf = (t >= 0.0f) ? au[i] : v3_neg(au[i]); }
+  }
+  for (int j = 0; j < 3; ++j) {
+    float t = v3_dot(dc, bu[j]);
+    float ra = fmaf(a[0], AR[0][j], fmaf(a[1], AR[1][j], a[2] * AR[2][j]));
+    float s = fabsf(t) - (b[j] + ra);
+    if (s > best_f) { best_f = s; nf = (t >= 0.0f) ? bu[j] : v3_neg(bu[j]); }
+  }
+  if (best_f > margin) return 0;
+  float best_e = -3.0e38f; v3 ne = nf;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      v3 L = v3_cross(au[i], bu[j]);
+      float l2 = v3_len2(L);
+      if (l2 < 1e-6f) continue;
+      float inv = 1.0f / sqrtf(l2);
+      int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      float ra = fmaf(a[i1], AR[i2][j], a[i2] * AR[i1][j]);
+      float rb = fmaf(b[j1], AR[i][j2], b[j2] * AR[i][j1]);
+      float t = v3_dot(dc, L);
+      float s = (fabsf(t) - (ra + rb)) * inv;
+      if (s > best_e) { best_e = s; ne = v3_scale(L, (t >= 0.0f) ? inv : -inv); }
+    }
+  if (best_e > margin) return 0;
+  if (best_e > best_f + 5e-4f) { *n_out = ne; *sep_out = best_e; }
+  else { *n_out = nf; *sep_out = best_f; }
+  return 1;
+}
+
+/* ---- GJK / EPA ------------------------------------------------------------------------ */
+typedef struct { v3 w, a, b; } mvert;
+
+MSK_DEV mvert msupport(const DModel* m, const DShape* A, const pose* TA, const DShape* B, const pose* TB, v3 d) {
+  mvert r;
+  r.a = support(m, A, TA, d);
+  r.b = support(m, B, TB, v3_neg(d));
+  r.w = v3_sub(r.a, r.b);
+  return r;
+}
+
+/* closest point to the origin on triangle (p0,p1,p2); returns barycentrics and a mask of used vertices */
+MSK_DEV v3 closest_tri(v3 a, v3 b, v3 c, float* bary, int* mask) {
+  v3 ab = v3_sub(b, a), ac = v3_sub(c, a), ap = v3_neg(a);
+  float d1 = v3_dot(ab, ap), d2 = v3_dot(ac, ap);
+  if (d1 <= 0.0f && d2 <= 0.0f) { bary[0] = 1; bary[1] = 0; bary[2] = 0; *mask = 1; return a; }
+  v3 bp = v3_neg(b);
+  float d3 = v3_dot(ab, bp), d4 = v3_dot(ac, bp);
+  if (d3 >= 0.0f && d4 <= d3) { bary[0] = 0; bary[1] = 1; bary[2] = 0; *mask = 2; return b; }
+  float vc = fmaf(d1, d4, -(d3 * d2));
+  if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {
+    float v = d1 / (d1 - d3);
+    bary[0] = 1.0f - v; bary[1] = v; bary[2] = 0; *mask = 3;
+    return v3_madd(a, ab, v);
+  }
+  v3 cp = v3_neg(c);
+  float d5 = v3_dot(ab, cp), d6 = v3_dot(ac, cp);
+  if (d6 >= 0.0f && d5 <= d6) { bary[0] = 0; bary[1] = 0; bary[2] = 1; *mask = 4; return c; }
+  float vb = fmaf(d5, d2, -(d1 * d6));
+  if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {
+    float w = d2 / (d2 - d6);
+    bary[0] = 1.0f - w; bary[1] = 0; bary[2] = w; *mask = 5;
+    return v3_madd(a, ac, w);
+  }
+  float va = fmaf(d3, d6, -(d5 * d4));
+  if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {
+    float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    bary[0] = 0; bary[1] = 1.0f - w; bary[2] = w; *mask = 6;
+    return v3_madd(b, v3_sub(c, b), w);
+  }
+  float denom = 1.0f / (va + vb + vc);
+  float v = vb * denom, w = vc * denom;
+  bary[0] = 1.0f - v - w; bary[1] = v; bary[2] = w; *mask = 7;
+  return v3_madd(v3_madd(a, ab, v), ac, w);
+}
+
+/* reduce the simplex to the sub-simplex closest to the origin; returns 1 if the origin is enclosed */
+MSK_DEV int simplex_closest(mvert* s, int* n, v3* v, float* bary) {
+  if (*n == 1) { *v = s[0].w; bary[0] = 1; return 0; }
+  if (*n == 2) {
+    v3 ab = v3_sub(s[1].w, s[0].w);
+    float t = -v3_dot(s[0].w, ab);
+    float l2 = v3_len2(ab);
+    if (t <= 0.0f || l2 < 1e-20f) { *n = 1; *v = s[0].w; bary[0] = 1; return 0; }
+    if (t >= l2) { s[0] = s[1]; *n = 1; *v = s[0].w; bary[0] = 1; return 0; }
+    t /= l2;
+    bary[0] = 1.0f - t; bary[1] = t;
+    *v = v3_madd(s[0].w, ab, t);
+    return 0;
+  }
+  if (*n == 3) {
+    float bc[3]; int mask;
+    *v = closest_tri(s[0].w, s[1].w, s[2].w, bc, &mask);
+    int m = 0;
+    for (int i = 0; i < 3; ++i)
+      if (mask & (1 << i)) { s[m] = s[i]; bary[m] = bc[i]; m++; }
+    *n = m;
+    return 0;
+  }
+  /* tetrahedron: test the four faces */
+  const int F[4][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 3, 1}, {1, 2, 3, 0}};
+  float bestd = 3.0e38f;
+  int bestf = -1, bestmask = 0;
+  float bestb[3];
+  v3 bestv = v3_make(0, 0, 0);
+  for (int f = 0; f < 4; ++f) {
+    v3 a = s[F[f][0]].w, b = s[F[f][1]].w, c = s[F[f][2]].w, d = s[F[f][3]].w;
+    v3 nrm = v3_cross(v3_sub(b, a), v3_sub(c, a));
+    float sd = v3_dot(nrm, v3_sub(d, a));  /* side of the opposite vertex */
+    float so = v3_dot(nrm, v3_neg(a));     /* side of the origin */
+    int outside = (sd > 0.0f) ? (so < 0.0f) : (so > 0.0f);
+    if (fabsf(sd) < 1e-20f) outside = 1; /* degenerate tetrahedron: treat as a face */
+    if (!outside) continue;
+    float bc[3]; int mask;
+    v3 p = closest_tri(a, b, c, bc, &mask);
+    float d2 = v3_len2(p);
+    if (d2 < bestd) { bestd = d2; bestf = f; bestmask = mask; bestv = p; bestb[0] = bc[0]; bestb[1] = bc[1]; bestb[2] = bc[2]; }
+  }
+  if (bestf < 0) return 1;
+  mvert t[3] = {s[F[bestf][0]], s[F[bestf][1]], s[F[bestf][2]]};
+  int m = 0;
+  for (int i = 0; i < 3; ++i)
+    if (bestmask & (1 << i)) { s[m] = t[i]; bary[m] = bestb[i]; m++; }
+  *n = m;
+  *v = bestv;
+  return 0;
+}
+
+typedef struct { int i[3]; v3 n; float d; int alive; } epa_face;
+
+MSK_DEV int epa_make_face(const mvert* vs, epa_face* f, int a, int b, int c) {
+  f->i[0] = a; f->i[1] = b; f->i[2] = c;
+  v3 nrm = v3_cross(v3_sub(vs[b].w, vs[a].w), v3_sub(vs[c].w, vs[a].w));
+  float l = v3_len(nrm);
+  f->alive = 1;
+  if (l < 1e-12f) { f->n = v3_make(0, 0, 0); f->d = 3.0e38f; return 0; }
+  f->n = v3_scale(nrm, 1.0f / l);
+  f->d = v3_dot(f->n, vs[a].w);
+  return 1;
+}
+
+/* penetration of two overlapping convex shapes; starts from the GJK simplex */
+MSK_DEV int epa(const DModel* m, const DShape* A, const pose* TA, const DShape* B, const pose* TB, mvert* simplex, int ns,
+               v3* n_out, float* depth_out, v3* wa, v3* wb) {
+  mvert vs[ORC_EPA_MAXV];
+  epa_face fs[ORC_EPA_MAXF];
+  int nv = 0, nf = 0;
+  /* grow a degenerate simplex into a tetrahedron with axis-direction supports */
+  mvert cand_[10];
+  int ncand = 0;
+  for (int i = 0; i < ns; ++i) cand_[ncand++] = simplex[i];
+  if (ns < 4) {
+    const float D[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+    for (int k = 0; k < 6; ++k) cand_[ncand++] = msupport(m, A, TA, B, TB, v3_make(D[k][0], D[k][1], D[k][2]));
+  }
+  vs[0] = cand_[0];
+  {
+    int b1 = -1; float bd = 1e-12f;
+    for (int i = 1; i < ncand; ++i) { float d = v3_len2(v3_sub(cand_[i].w, vs[0].w)); if (d > bd) { bd = d; b1 = i; } }
+    if (b1 < 0) return 0;
+    vs[1] = cand_[b1];
+    int b2 = -1; bd = 1e-14f;
+    for (int i = 1; i < ncand; ++i) {
+      float d = v3_len2(v3_cross(v3_sub(vs[1].w, vs[0].w), v3_sub(cand_[i].w, vs[0].w)));
+      if (d > bd) { bd = d; b2 = i; }
+    }
+    if (b2 < 0) return 0;
+    vs[2] = cand_[b2];
+    v3 nrm = v3_cross(v3_sub(vs[1].w, vs[0].w), v3_sub(vs[2].w, vs[0].w));
+    int b3 = -1; float bv = 1e-16f;
+    for (int i = 1; i < ncand; ++i) {
+      float d = fabsf(v3_dot(nrm, v3_sub(cand_[i].w, vs[0].w)));
+      if (d > bv) { bv = d; b3 = i; }
+    }
+    if (b3 < 0) {
+      /* flat: try supports along +-normal */
+      mvert p = msupport(m, A, TA, B, TB, nrm), q = msupport(m, A, TA, B, TB, v3_neg(nrm));
+      float dp = fabsf(v3_dot(nrm, v3_sub(p.w, vs[0].w))), dq = fabsf(v3_dot(nrm, v3_sub(q.w, vs[0].w)));
+      if (fmaxf(dp, dq) < 1e-16f) return 0;
+      vs[3] = (dp > dq) ? p : q;
+    } else vs[3] = cand_[b3];
+    nv = 4;
+    /* orient so that face normals point away from the 4th vertex */
+    v3 n012 = v3_cross(v3_sub(vs[1].w, vs[0].w), v3_sub(vs[2].w, vs[0].w));
+    if (v3_dot(n012, v3_sub(vs[3].w, vs[0].w)) > 0.0f) { mvert t = vs[1]; vs[1] = vs[2]; vs[2] = t; }
+    epa_make_face(vs, &fs[0], 0, 1, 2);
+    epa_make_face(vs, &fs[1], 0, 3, 1);
+    epa_make_face(vs, &fs[2], 0, 2, 3);
+    epa_make_face(vs, &fs[3], 1, 3, 2);
+    nf = 4;
+  }
+  int bestf = 0;
+  for (int it = 0; it < ORC_EPA_ITERS; ++it) {
+    bestf = -1;
+    float bd = 3.0e38f;
+    for (int f = 0; f < nf; ++f)
+      if (fs[f].alive && fs[f].d < bd) { bd = fs[f].d; bestf = f; }
+    if (bestf < 0) return 0;
+    mvert w = msupport(m, A, TA, B, TB, fs[bestf].n);
+    float dist = v3_dot(w.w, fs[bestf].n);
+    if (dist - fs[bestf].d < 2e-5f || nv >= ORC_EPA_MAXV) break;
+    /* remove faces visible from w, collect the horizon */
+    int edges[ORC_EPA_MAXF][2];
+    int ne = 0;
+    for (int f = 0; f < nf; ++f) {
+      if (!fs[f].alive) continue;
+      if (v3_dot(fs[f].n, v3_sub(w.w, vs[fs[f].i[0]].w)) > 0.0f) {
+        fs[f].alive = 0;
+        for (int k = 0; k < 3; ++k) {
+          int a = fs[f].i[k], b = fs[f].i[(k + 1) % 3];
+          int found = -1;
+          for (int q = 0; q < ne; ++q) if (edges[q][0] == b && edges[q][1] == a) { found = q; break; }
+          if (found >= 0) { edges[found][0] = edges[ne - 1][0]; edges[found][1] = edges[ne - 1][1]; ne--; }
+          else if (ne < ORC_EPA_MAXF) { edges[ne][0] = a; edges[ne][1] = b; ne++; }
+        }
+      }
+    }
+    if (ne == 0) break;
+    vs[nv] = w;
+    int stop = 0;
+    for (int q = 0; q < ne; ++q) {
+      int slot = -1;
+      for (int f = 0; f < nf; ++f) if (!fs[f].alive) { slot = f; break; }
+      if (slot < 0) { if (nf >= ORC_EPA_MAXF) { stop = 1; break; } slot = nf++; }
+      epa_make_face(vs, &fs[slot], edges[q][0], edges[q][1], nv);
+    }
+    nv++;
+    if (stop) break;
+  }
+  if (bestf < 0) return 0;
+  /* witness points from the barycentrics of the origin's projection on the closest face */
+  const epa_face* f = &fs[bestf];
+  v3 p = v3_scale(f->n, f->d);
+  v3 a = vs[f->i[0]].w, b = vs[f->i[1]].w, cc = vs[f->i[2]].w;
+  v3 v0 = v3_sub(b, a), v1 = v3_sub(cc, a), v2 = v3_sub(p, a);
+  float d00 = v3_dot(v0, v0), d01 = v3_dot(v0, v1), d11 = v3_dot(v1, v1), d20 = v3_dot(v2, v0), d21 = v3_dot(v2, v1);
+  float den = fmaf(d00, d11, -(d01 * d01));
+  float bv = 1.0f / 3.0f, bw = 1.0f / 3.0f;
+  if (fabsf(den) > 1e-20f) { bv = fmaf(d11, d20, -(d01 * d21)) / den; bw = fmaf(d00, d21, -(d01 * d20)) / den; }
+  float bu = 1.0f - bv - bw;
+  *wa = v3_add(v3_add(v3_scale(vs[f->i[0]].a, bu), v3_scale(vs[f->i[1]].a, bv)), v3_scale(vs[f->i[2]].a, bw));
+  *wb = v3_add(v3_add(v3_scale(vs[f->i[0]].b, bu), v3_scale(vs[f->i[1]].b, bv)), v3_scale(vs[f->i[2]].b, bw));
+  *n_out = v3_neg(f->n);
+  *depth_out = fmaxf(f->d, 0.0f);
+  return 1;
+}
+
+/* GJK distance + EPA. Returns 0 if farther apart than margin. n from B to A. */
+MSK_DEV int gjk_epa(const DModel* m, const DShape* A, const pose* TA, const DShape* B, const pose* TB, v3 ca, v3 cb, float margin,
+                   v3* n_out, float* sep_out, v3* wa, v3* wb) {
+  mvert s[4];
+  float bary[4] = {1, 0, 0, 0};
+  int n = 0;
+  v3 d0 = v3_sub(ca, cb);
+  if (v3_len2(d0) < 1e-12f) d0 = v3_make(1, 0, 0);
+  s[0] = msupport(m, A, TA, B, TB, v3_neg(d0));
+  n = 1;
+  v3 v = s[0].w;
+  float vv = v3_len2(v);
+  int hit = 0;
+  for (int it = 0; it < ORC_GJK_ITERS; ++it) {
+    if (vv < 1e-10f) { hit = 1; break; }
+    mvert w = msupport(m, A, TA, B, TB, v3_neg(v));
+    float vw = v3_dot(v, w.w);
+    if (vw > 0.0f && vw * vw > margin * margin * vv) return 0; /* separated by more than margin */
+    if (vv - vw <= 1e-6f * vv) break;                          /* converged */
+    int dupl = 0;
+    for (int i = 0; i < n; ++i) if (v3_len2(v3_sub(s[i].w, w.w)) < 1e-14f) dupl = 1;
+    if (dupl) break;
+    s[n++] = w;
+    v3 nvv;
+    if (simplex_closest(s, &n, &nvv, bary)) { hit = 1; break; }
+    float nvl = v3_len2(nvv);
+    if (nvl >= vv) break; /* no progress (numerical) */
+    v = nvv;
+    vv = nvl;
+  }
+  if (!hit) {
+    float dist = sqrtf(vv);
+    if (dist > margin) return 0;
+    if (dist > 1e-5f) {
+      v3 pa = v3_make(0, 0, 0), pb = v3_make(0, 0, 0);
+      for (int i = 0; i < n; ++i) { pa = v3_madd(pa, s[i].a, bary[i]); pb = v3_madd(pb, s[i].b, bary[i]); }
+      *n_out = v3_scale(v, 1.0f / dist);
+      *sep_out = dist;
+      *wa = pa; *wb = pb;
+      return 1;
+    }
+  }
+  float depth;
+  if (!epa(m, A, TA, B, TB, s, n, n_out, &depth, wa, wb)) {
+    /* degenerate: fall back to the centre direction with zero separation */
+    *n_out = v3_normalize(d0);
+    *sep_out = 0.0f;
+    *wa = support(m, A, TA, v3_neg(*n_out));
+    *wb = support(m, B, TB, *n_out);
+    return 1;
+  }
+  *sep_out = -depth;
+  return 1;
+}
+
+/* ---- plane ----------------------------------------------------------------------------- */
+MSK_DEV int plane_convex(const DModel* m, const DShape* P, const pose* TP, const DShape* C, const pose* TC, float margin,
+                        int plane_is_a, DContactOut* out) {
+  v3 pn = quat_rotate(TP->q, v3_make(1, 0, 0));
+  float pd = v3_dot(pn, TP->p);
+  v3 t1, t2;
+  msk_tangents(pn, &t1, &t2);
+  cand cs[MSK_MAX_HULL_VERTS];
+  int nc = 0;
+  int nv = shape_nverts(C);
+  for (int i = 0; i < nv; ++i) {
+    v3 w = pose_apply(*TC, shape_vert(m, C, i));
+    float sep = v3_dot(pn, w) - pd;
+    if (sep > margin) continue;
+    cs[nc].u = v3_dot(w, t1); cs[nc].v = v3_dot(w, t2); cs[nc].hm = pd + 0.5f * sep; cs[nc].sep = sep;
+    nc++;
+  }
+  nc = reduce4(cs, nc);
+  for (int i = 0; i < nc; ++i) {
+    out[i].pos = v3_madd(v3_madd(v3_scale(t1, cs[i].u), t2, cs[i].v), pn, cs[i].hm);
+    out[i].n = plane_is_a ? v3_neg(pn) : pn;
+    out[i].sep = cs[i].sep;
+  }
+  return nc;
+}
+
+
+#endif

@@ -1,0 +1,201 @@
+/*
+ * msk_math.h — fp32 vector / quaternion / spatial-algebra helpers for the HIP kernels.
+ *
+ * Device-side counterpart of the formulas the CPU oracle uses (oracle/orc_math.h); the two
+ * are kept operation-for-operation identical ON PURPOSE: the kernels are compiled with
+ * -ffp-contract=off and use fmaf() explicitly, sqrt/div are correctly rounded on gfx950
+ * (hipcc default), and sin/cos come from the polynomial below instead of the device
+ * libm — so a HIP thread and the scalar oracle produce the same bits for the same env.
+ */
+#ifndef MSK_MATH_H
+#define MSK_MATH_H
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#define MSK_DEV static __device__ __forceinline__
+
+typedef struct { float x, y, z; } v3;
+typedef struct { float w, x, y, z; } quat;
+typedef struct { v3 p; quat q; } pose;
+typedef struct { float m[3][3]; } m33;
+/* spatial vectors about the env origin: motion [w; v] / force [n; f] */
+typedef struct { v3 a; v3 l; } sv6;
+/* spatial rigid-body inertia about the env origin: mass, h = m*c, and the symmetric
+ * rotational inertia about the origin stored as [xx yy zz xy xz yz] */
+typedef struct { float m; v3 h; float I[6]; } sinertia;
+
+MSK_DEV v3 v3_make(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+MSK_DEV v3 v3_add(v3 a, v3 b) { return v3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
+MSK_DEV v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
+MSK_DEV v3 v3_scale(v3 a, float s) { return v3_make(a.x * s, a.y * s, a.z * s); }
+MSK_DEV v3 v3_neg(v3 a) { return v3_make(-a.x, -a.y, -a.z); }
+/* a + b*s */
+MSK_DEV v3 v3_madd(v3 a, v3 b, float s) {
+  return v3_make(fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z));
+}
+MSK_DEV float v3_dot(v3 a, v3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+MSK_DEV v3 v3_cross(v3 a, v3 b) {
+  return v3_make(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)),
+                 fmaf(a.x, b.y, -(a.y * b.x)));
+}
+MSK_DEV float v3_len2(v3 a) { return v3_dot(a, a); }
+MSK_DEV float v3_len(v3 a) { return sqrtf(v3_dot(a, a)); }
+MSK_DEV v3 v3_normalize(v3 a) {
+  float l = v3_len(a);
+  float inv = 1.0f / l;
+  return v3_scale(a, inv);
+}
+MSK_DEV float v3_get(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+MSK_DEV quat quat_make(float w, float x, float y, float z) { quat r = {w, x, y, z}; return r; }
+MSK_DEV quat quat_mul(quat a, quat b) {
+  quat r;
+  r.w = fmaf(a.w, b.w, -fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)));
+  r.x = fmaf(a.w, b.x, fmaf(a.x, b.w, fmaf(a.y, b.z, -(a.z * b.y))));
+  r.y = fmaf(a.w, b.y, fmaf(a.y, b.w, fmaf(a.z, b.x, -(a.x * b.z))));
+  r.z = fmaf(a.w, b.z, fmaf(a.z, b.w, fmaf(a.x, b.y, -(a.y * b.x))));
+  return r;
+}
+MSK_DEV quat quat_conj(quat a) { return quat_make(a.w, -a.x, -a.y, -a.z); }
+MSK_DEV quat quat_normalize(quat a) {
+  float n2 = fmaf(a.w, a.w, fmaf(a.x, a.x, fmaf(a.y, a.y, a.z * a.z)));
+  float inv = 1.0f / sqrtf(n2);
+  return quat_make(a.w * inv, a.x * inv, a.y * inv, a.z * inv);
+}
+/* v' = v + 2w(u x v) + 2 u x (u x v) */
+MSK_DEV v3 quat_rotate(quat q, v3 v) {
+  v3 u = v3_make(q.x, q.y, q.z);
+  v3 t = v3_cross(u, v);
+  t = v3_add(t, t);
+  return v3_add(v3_madd(v, t, q.w), v3_cross(u, t));
+}
+MSK_DEV v3 quat_rotate_inv(quat q, v3 v) { return quat_rotate(quat_conj(q), v); }
+MSK_DEV m33 quat_to_m33(quat q) {
+  m33 R;
+  float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z;
+  float xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z;
+  float wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;
+  R.m[0][0] = 1.0f - 2.0f * (yy + zz); R.m[0][1] = 2.0f * (xy - wz); R.m[0][2] = 2.0f * (xz + wy);
+  R.m[1][0] = 2.0f * (xy + wz); R.m[1][1] = 1.0f - 2.0f * (xx + zz); R.m[1][2] = 2.0f * (yz - wx);
+  R.m[2][0] = 2.0f * (xz - wy); R.m[2][1] = 2.0f * (yz + wx); R.m[2][2] = 1.0f - 2.0f * (xx + yy);
+  return R;
+}
+MSK_DEV v3 m33_col(const m33* R, int j) { return v3_make(R->m[0][j], R->m[1][j], R->m[2][j]); }
+MSK_DEV v3 m33_mulv(const m33* R, v3 v) {
+  return v3_make(fmaf(R->m[0][0], v.x, fmaf(R->m[0][1], v.y, R->m[0][2] * v.z)),
+                 fmaf(R->m[1][0], v.x, fmaf(R->m[1][1], v.y, R->m[1][2] * v.z)),
+                 fmaf(R->m[2][0], v.x, fmaf(R->m[2][1], v.y, R->m[2][2] * v.z)));
+}
+MSK_DEV v3 m33_tmulv(const m33* R, v3 v) {
+  return v3_make(fmaf(R->m[0][0], v.x, fmaf(R->m[1][0], v.y, R->m[2][0] * v.z)),
+                 fmaf(R->m[0][1], v.x, fmaf(R->m[1][1], v.y, R->m[2][1] * v.z)),
+                 fmaf(R->m[0][2], v.x, fmaf(R->m[1][2], v.y, R->m[2][2] * v.z)));
+}
+
+MSK_DEV pose pose_mul(pose a, pose b) {
+  pose r;
+  r.p = v3_add(a.p, quat_rotate(a.q, b.p));
+  r.q = quat_mul(a.q, b.q);
+  return r;
+}
+MSK_DEV pose pose_inv(pose a) {
+  pose r;
+  r.q = quat_conj(a.q);
+  r.p = v3_neg(quat_rotate(r.q, a.p));
+  return r;
+}
+MSK_DEV v3 pose_apply(pose a, v3 v) { return v3_add(a.p, quat_rotate(a.q, v)); }
+
+/* sin and cos of x (|x| < ~1e4), Cephes single-precision kernels. */
+MSK_DEV void msk_sincos(float x, float* s, float* c) {
+  float fj = rintf(x * 0.63661977236758134f); /* x * 2/pi */
+  int j = (int)fj;
+  float y = fmaf(fj, -1.5703125f, x);
+  y = fmaf(fj, -4.837512969970703125e-4f, y);
+  y = fmaf(fj, -7.54978995489188216e-8f, y);
+  float z = y * y;
+  float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * y, y);
+  float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f),
+                  z * z, fmaf(-0.5f, z, 1.0f));
+  switch (j & 3) {
+    case 0: *s = sp; *c = cp; break;
+    case 1: *s = cp; *c = -sp; break;
+    case 2: *s = -sp; *c = -cp; break;
+    default: *s = -cp; *c = sp; break;
+  }
+}
+
+/* rotation by the rotation vector r (angle = |r|) */
+MSK_DEV quat quat_from_rotvec(v3 r) {
+  float a2 = v3_len2(r);
+  if (a2 < 1e-12f) return quat_normalize(quat_make(1.0f, 0.5f * r.x, 0.5f * r.y, 0.5f * r.z));
+  float a = sqrtf(a2);
+  float s, c;
+  msk_sincos(0.5f * a, &s, &c);
+  float k = s / a;
+  return quat_make(c, r.x * k, r.y * k, r.z * k);
+}
+
+/* two unit vectors orthogonal to the unit vector n, t1 x t2 = n */
+MSK_DEV void msk_tangents(v3 n, v3* t1, v3* t2) {
+  v3 a = (fabsf(n.x) < 0.57735f) ? v3_make(1, 0, 0) : ((fabsf(n.y) < 0.57735f) ? v3_make(0, 1, 0) : v3_make(0, 0, 1));
+  v3 t = v3_cross(n, a);
+  *t1 = v3_normalize(t);
+  *t2 = v3_cross(n, *t1);
+}
+
+/* ---- spatial algebra (Featherstone, Plücker coordinates about the env origin) ----- */
+MSK_DEV sv6 sv6_zero(void) { sv6 r = {{0, 0, 0}, {0, 0, 0}}; return r; }
+MSK_DEV sv6 sv6_add(sv6 a, sv6 b) { sv6 r = {v3_add(a.a, b.a), v3_add(a.l, b.l)}; return r; }
+MSK_DEV sv6 sv6_madd(sv6 a, sv6 b, float s) { sv6 r = {v3_madd(a.a, b.a, s), v3_madd(a.l, b.l, s)}; return r; }
+MSK_DEV float sv6_dot(sv6 a, sv6 b) { return v3_dot(a.a, b.a) + v3_dot(a.l, b.l); }
+/* motion x motion */
+MSK_DEV sv6 sv6_crossm(sv6 v, sv6 m) {
+  sv6 r;
+  r.a = v3_cross(v.a, m.a);
+  r.l = v3_add(v3_cross(v.a, m.l), v3_cross(v.l, m.a));
+  return r;
+}
+/* motion x* force */
+MSK_DEV sv6 sv6_crossf(sv6 v, sv6 f) {
+  sv6 r;
+  r.a = v3_add(v3_cross(v.a, f.a), v3_cross(v.l, f.l));
+  r.l = v3_cross(v.a, f.l);
+  return r;
+}
+MSK_DEV v3 sym6_mulv(const float I[6], v3 v) {
+  return v3_make(fmaf(I[0], v.x, fmaf(I[3], v.y, I[4] * v.z)),
+                 fmaf(I[3], v.x, fmaf(I[1], v.y, I[5] * v.z)),
+                 fmaf(I[4], v.x, fmaf(I[5], v.y, I[2] * v.z)));
+}
+/* I * [w; v] = [Ibar w + h x v ; m v - h x w] */
+MSK_DEV sv6 sinertia_mul(const sinertia* I, sv6 v) {
+  sv6 r;
+  r.a = v3_add(sym6_mulv(I->I, v.a), v3_cross(I->h, v.l));
+  r.l = v3_sub(v3_scale(v.l, I->m), v3_cross(I->h, v.a));
+  return r;
+}
+MSK_DEV void sinertia_acc(sinertia* a, const sinertia* b) {
+  a->m += b->m;
+  a->h = v3_add(a->h, b->h);
+  for (int i = 0; i < 6; ++i) a->I[i] += b->I[i];
+}
+/* R * sym(I6) * R^T as sym6 */
+MSK_DEV void sym6_rotate(const m33* R, const float I[6], float out[6]) {
+  /* T = R * I */
+  float T[3][3];
+  float Im[3][3] = {{I[0], I[3], I[4]}, {I[3], I[1], I[5]}, {I[4], I[5], I[2]}};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      T[i][j] = fmaf(R->m[i][0], Im[0][j], fmaf(R->m[i][1], Im[1][j], R->m[i][2] * Im[2][j]));
+  float O[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = i; j < 3; ++j)
+      O[i][j] = fmaf(T[i][0], R->m[j][0], fmaf(T[i][1], R->m[j][1], T[i][2] * R->m[j][2]));
+  out[0] = O[0][0]; out[1] = O[1][1]; out[2] = O[2][2]; out[3] = O[0][1]; out[4] = O[0][2]; out[5] = O[1][2];
+}
+
+
+#endif

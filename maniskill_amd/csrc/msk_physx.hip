@@ -1,0 +1,512 @@
+/*
+ * msk_physx.hip — C-ABI host side of the MI355X-native rigid-body backend (include/msk_physx.h).
+ *
+ * Host code only records the env template, uploads it once, owns the device arrays and
+ * enqueues the kernels of msk_kernels.h on the caller's HIP stream.  No CPU physics here:
+ * every entry point that computes anything launches a kernel.
+ */
+#include "msk_kernels.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#define MSK_API extern "C" __attribute__((visibility("default")))
+
+struct HostQuery { int npairs; int* d_pairs; float* d_out; };
+
+struct msk_ctx {
+  int device;
+  bool finalized;
+  DModel model;          /* host copy of the template */
+  DModel* d_model;
+  DState st;
+  DBuffers bufs;
+  int art_root[8], art_dof0[8], art_ndof[8];
+  int *d_art_dof0, *d_art_ndof;
+  int max_dof;
+  int ndisabled;
+  int disabled[256][2];
+  pose init_pose[MSK_MAX_BODIES];
+  pose pending_root;
+  int nverts_total;
+  int nv_pad;            /* generalized velocity size padded to the k_solve<NV> instantiation */
+  uint32_t groups[MSK_MAX_SHAPES][4]; /* collision groups: only the static pair filter needs them */
+  std::vector<void*> allocs;
+  std::vector<HostQuery> queries;
+  char err[256];
+};
+
+static int fail(msk_ctx* c, int code, const char* msg) {
+  snprintf(c->err, sizeof(c->err), "%s", msg);
+  return code;
+}
+static int hip_fail(msk_ctx* c, hipError_t e, const char* what) {
+  snprintf(c->err, sizeof(c->err), "%s: %s", what, hipGetErrorString(e));
+  return MSK_ERR_HIP;
+}
+#define HIP_TRY(call)                                        \
+  do {                                                       \
+    hipError_t _e = (call);                                  \
+    if (_e != hipSuccess) return hip_fail(c, _e, #call);     \
+  } while (0)
+
+static pose pose_from7(const float* p) {
+  pose r;
+  r.p.x = p[0]; r.p.y = p[1]; r.p.z = p[2];
+  float w = p[3], x = p[4], y = p[5], z = p[6];
+  float n2 = fmaf(w, w, fmaf(x, x, fmaf(y, y, z * z)));
+  float inv = 1.0f / sqrtf(n2);
+  r.q.w = w * inv; r.q.x = x * inv; r.q.y = y * inv; r.q.z = z * inv;
+  return r;
+}
+static v3 h_cross(v3 a, v3 b) {
+  v3 r = {fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
+  return r;
+}
+static v3 h_rotate(quat q, v3 v) {
+  v3 u = {q.x, q.y, q.z};
+  v3 t = h_cross(u, v);
+  t.x += t.x; t.y += t.y; t.z += t.z;
+  v3 c2 = h_cross(u, t);
+  v3 r = {fmaf(t.x, q.w, v.x) + c2.x, fmaf(t.y, q.w, v.y) + c2.y, fmaf(t.z, q.w, v.z) + c2.z};
+  return r;
+}
+static pose h_pose_inv(pose a) {
+  pose r;
+  r.q.w = a.q.w; r.q.x = -a.q.x; r.q.y = -a.q.y; r.q.z = -a.q.z;
+  v3 t = h_rotate(r.q, a.p);
+  r.p.x = -t.x; r.p.y = -t.y; r.p.z = -t.z;
+  return r;
+}
+
+MSK_API msk_ctx* msk_create(int hip_device, const msk_config* cfg) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= hip_device) {
+    fprintf(stderr, "msk_create: no HIP device %d (found %d); this backend has no CPU path\n", hip_device, count);
+    return nullptr;
+  }
+  msk_ctx* c = new msk_ctx();
+  memset(&c->model, 0, sizeof(c->model));
+  memset(&c->st, 0, sizeof(c->st));
+  memset(&c->bufs, 0, sizeof(c->bufs));
+  c->device = hip_device;
+  c->finalized = false;
+  c->model.cfg = *cfg;
+  c->d_model = nullptr;
+  c->ndisabled = 0;
+  c->nverts_total = 0;
+  c->max_dof = 0;
+  c->err[0] = 0;
+  return c;
+}
+
+MSK_API void msk_destroy(msk_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  for (void* p : c->allocs) hipFree(p);
+  delete c;
+}
+
+MSK_API const char* msk_last_error(msk_ctx* c) { return c ? c->err : "null context"; }
+
+MSK_API int msk_add_articulation(msk_ctx* c, const float root_pose[7]) {
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "add_articulation after finalize");
+  DModel& m = c->model;
+  if (m.na >= 8) return fail(c, MSK_ERR_CAPACITY, "too many articulations");
+  c->art_root[m.na] = -1;
+  c->art_dof0[m.na] = m.nd;
+  c->art_ndof[m.na] = 0;
+  c->pending_root = pose_from7(root_pose);
+  return m.na++;
+}
+
+MSK_API int msk_add_link(msk_ctx* c, int art, int parent_body, int joint_type, const float pose_in_parent[7],
+                         const float pose_in_child[7], float limit_lo, float limit_hi, float mass, const float com[3],
+                         const float inertia6[6], int disable_gravity, float armature, float joint_friction) {
+  (void)joint_friction;
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "add_link after finalize");
+  DModel& m = c->model;
+  if (m.nb >= MSK_MAX_BODIES - 1) return fail(c, MSK_ERR_CAPACITY, "too many bodies");
+  if (art != m.na - 1) return fail(c, MSK_ERR_INVALID, "links must be added to the most recent articulation");
+  DBody* b = &m.bodies[m.nb];
+  memset(b, 0, sizeof(*b));
+  b->kind = MSK_BODY_LINK;
+  b->art = art;
+  b->parent = parent_body;
+  b->jtype = (parent_body < 0) ? MSK_JOINT_FIXED : joint_type;
+  b->Xp = pose_from7(pose_in_parent);
+  b->XcInv = h_pose_inv(pose_from7(pose_in_child));
+  b->lim_lo = limit_lo; b->lim_hi = limit_hi;
+  b->mass = mass;
+  b->com.x = com[0]; b->com.y = com[1]; b->com.z = com[2];
+  memcpy(b->I6, inertia6, sizeof(b->I6));
+  b->nograv = disable_gravity;
+  b->armature = armature;
+  b->dof = -1; b->vofs = -1;
+  memset(&c->init_pose[m.nb], 0, sizeof(pose));
+  c->init_pose[m.nb].q.w = 1.0f;
+  if (parent_body < 0) {
+    c->init_pose[m.nb] = c->pending_root;
+    c->art_root[art] = m.nb;
+  } else {
+    if (parent_body >= m.nb || m.bodies[parent_body].art != art) return fail(c, MSK_ERR_INVALID, "bad parent link");
+    if (b->jtype != MSK_JOINT_FIXED) {
+      if (m.nd >= MSK_MAX_DOF) return fail(c, MSK_ERR_CAPACITY, "too many dofs");
+      b->dof = m.nd++;
+      c->art_ndof[art]++;
+    }
+    b->movable = (b->dof >= 0) || m.bodies[parent_body].movable;
+  }
+  return m.nb++;
+}
+
+MSK_API int msk_set_drive(msk_ctx* c, int link_body, float K, float D, float force_limit, int mode_acc) {
+  (void)mode_acc;
+  DModel& m = c->model;
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "set_drive after finalize");
+  if (link_body < 0 || link_body >= m.nb || m.bodies[link_body].dof < 0) return fail(c, MSK_ERR_INVALID, "set_drive: not an active joint");
+  DBody* b = &m.bodies[link_body];
+  b->K = K; b->D = D; b->fmax = force_limit;
+  return MSK_OK;
+}
+
+MSK_API int msk_add_tendon(msk_ctx* c, int link_a, int link_b, float ca, float cb, float rest, float K, float D) {
+  DModel& m = c->model;
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "add_tendon after finalize");
+  if (m.nt >= MSK_MAX_TENDONS) return fail(c, MSK_ERR_CAPACITY, "too many tendons");
+  if (link_a < 0 || link_b < 0 || link_a >= m.nb || link_b >= m.nb) return fail(c, MSK_ERR_INVALID, "bad tendon link");
+  if (m.bodies[link_a].dof < 0 || m.bodies[link_b].dof < 0) return fail(c, MSK_ERR_INVALID, "tendon on a fixed joint");
+  DTendon* t = &m.tendons[m.nt];
+  t->dof_a = m.bodies[link_a].dof; t->dof_b = m.bodies[link_b].dof;
+  t->ca = ca; t->cb = cb; t->rest = rest; t->K = K; t->D = D;
+  return m.nt++;
+}
+
+static void sym6_inverse(const float I[6], float out[6]) {
+  float a = I[0], b = I[3], cc = I[4], d = I[1], e = I[5], f = I[2];
+  float det = a * (d * f - e * e) - b * (b * f - e * cc) + cc * (b * e - d * cc);
+  float inv = 1.0f / det;
+  out[0] = (d * f - e * e) * inv;
+  out[1] = (a * f - cc * cc) * inv;
+  out[2] = (a * d - b * b) * inv;
+  out[3] = (cc * e - b * f) * inv;
+  out[4] = (b * e - cc * d) * inv;
+  out[5] = (b * cc - a * e) * inv;
+}
+
+MSK_API int msk_add_actor(msk_ctx* c, int kind, const float pose7[7], float mass, const float com[3],
+                          const float inertia6[6], float lin_damp, float ang_damp, int disable_gravity) {
+  DModel& m = c->model;
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "add_actor after finalize");
+  if (m.nb >= MSK_MAX_BODIES - 1) return fail(c, MSK_ERR_CAPACITY, "too many bodies");
+  if (kind != MSK_BODY_KINEMATIC && kind != MSK_BODY_DYNAMIC) return fail(c, MSK_ERR_INVALID, "bad actor kind");
+  DBody* b = &m.bodies[m.nb];
+  memset(b, 0, sizeof(*b));
+  b->kind = kind; b->art = -1; b->parent = -1; b->dof = -1; b->vofs = -1;
+  c->init_pose[m.nb] = pose_from7(pose7);
+  b->mass = mass;
+  b->com.x = com[0]; b->com.y = com[1]; b->com.z = com[2];
+  memcpy(b->I6, inertia6, sizeof(b->I6));
+  if (kind == MSK_BODY_DYNAMIC) {
+    if (!(mass > 0.0f)) return fail(c, MSK_ERR_INVALID, "dynamic actor needs positive mass");
+    sym6_inverse(b->I6, b->Iinv6);
+  }
+  b->lin_damp = lin_damp; b->ang_damp = ang_damp; b->nograv = disable_gravity;
+  b->movable = kind == MSK_BODY_DYNAMIC;
+  return m.nb++;
+}
+
+MSK_API int msk_add_shape(msk_ctx* c, int body, int type, const float local_pose[7], const float params[3],
+                          const float* verts, int nverts, float sf, float df, float rest, const uint32_t groups[4],
+                          float patch_radius, float min_patch_radius) {
+  (void)sf; (void)rest; (void)patch_radius; (void)min_patch_radius;
+  DModel& m = c->model;
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "add_shape after finalize");
+  if (m.ns >= MSK_MAX_SHAPES) return fail(c, MSK_ERR_CAPACITY, "too many shapes");
+  if (body >= m.nb) return fail(c, MSK_ERR_INVALID, "bad body");
+  DShape* s = &m.shapes[m.ns];
+  memset(s, 0, sizeof(*s));
+  s->body = body; s->type = type;
+  s->local = pose_from7(local_pose);
+  s->par[0] = params[0]; s->par[1] = params[1]; s->par[2] = params[2];
+  s->df = df;
+  if (type == MSK_SHAPE_CONVEX) {
+    if (nverts < 4 || nverts > MSK_MAX_HULL_VERTS) return fail(c, MSK_ERR_CAPACITY, "convex: 4..64 vertices");
+    if (c->nverts_total + nverts > MSK_MAX_SHAPES * 16) return fail(c, MSK_ERR_CAPACITY, "hull vertex pool exhausted");
+    s->nverts = nverts;
+    s->vbase = c->nverts_total;
+    v3 lo = {3e38f, 3e38f, 3e38f}, hi = {-3e38f, -3e38f, -3e38f};
+    for (int i = 0; i < nverts; ++i) {
+      v3 p = {verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]};
+      m.verts[s->vbase + i] = p;
+      lo.x = fminf(lo.x, p.x); lo.y = fminf(lo.y, p.y); lo.z = fminf(lo.z, p.z);
+      hi.x = fmaxf(hi.x, p.x); hi.y = fmaxf(hi.y, p.y); hi.z = fmaxf(hi.z, p.z);
+    }
+    c->nverts_total += nverts;
+    s->aabb_c.x = (lo.x + hi.x) * 0.5f; s->aabb_c.y = (lo.y + hi.y) * 0.5f; s->aabb_c.z = (lo.z + hi.z) * 0.5f;
+    s->aabb_h.x = (hi.x - lo.x) * 0.5f; s->aabb_h.y = (hi.y - lo.y) * 0.5f; s->aabb_h.z = (hi.z - lo.z) * 0.5f;
+  } else if (type == MSK_SHAPE_BOX) {
+    s->aabb_h.x = params[0]; s->aabb_h.y = params[1]; s->aabb_h.z = params[2];
+  } else if (type == MSK_SHAPE_PLANE) {
+    if (body >= 0) return fail(c, MSK_ERR_INVALID, "planes must be static");
+  } else {
+    return fail(c, MSK_ERR_INVALID, "shape type not supported");
+  }
+  memcpy(c->groups[m.ns], groups, 4 * sizeof(uint32_t));
+  return m.ns++;
+}
+
+MSK_API int msk_disable_collision(msk_ctx* c, int a, int b) {
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "disable_collision after finalize");
+  if (c->ndisabled >= 256) return fail(c, MSK_ERR_CAPACITY, "too many disabled pairs");
+  c->disabled[c->ndisabled][0] = a; c->disabled[c->ndisabled][1] = b;
+  c->ndisabled++;
+  return MSK_OK;
+}
+
+static bool pair_enabled(msk_ctx* c, int i, int j) {
+  const DModel& m = c->model;
+  const DShape* A = &m.shapes[i];
+  const DShape* B = &m.shapes[j];
+  const uint32_t* ga = c->groups[i];
+  const uint32_t* gb = c->groups[j];
+  auto movable = [&](int b) { return b >= 0 && m.bodies[b].movable; };
+  if (A->body == B->body) return false;
+  if (!movable(A->body) && !movable(B->body)) return false;
+  if (ga[2] & gb[2]) return false;
+  if (!((ga[0] & gb[1]) || (ga[1] & gb[0]))) return false;
+  if (A->body >= 0 && B->body >= 0) {
+    const DBody* ba = &m.bodies[A->body];
+    const DBody* bb = &m.bodies[B->body];
+    if (ba->kind == MSK_BODY_LINK && bb->kind == MSK_BODY_LINK && ba->art == bb->art)
+      if (ba->parent == B->body || bb->parent == A->body) return false;
+    for (int k = 0; k < c->ndisabled; ++k)
+      if ((c->disabled[k][0] == A->body && c->disabled[k][1] == B->body) ||
+          (c->disabled[k][0] == B->body && c->disabled[k][1] == A->body))
+        return false;
+  }
+  return true;
+}
+
+template <typename T>
+static int dev_alloc(msk_ctx* c, T** out, size_t count) {
+  void* p = nullptr;
+  size_t bytes = (count > 0 ? count : 1) * sizeof(T);
+  HIP_TRY(hipMalloc(&p, bytes));
+  HIP_TRY(hipMemset(p, 0, bytes));
+  c->allocs.push_back(p);
+  *out = (T*)p;
+  return MSK_OK;
+}
+#define ALLOC(ptr, count)                                   \
+  do {                                                      \
+    int _r = dev_alloc(c, &(ptr), (size_t)(count));         \
+    if (_r < 0) return _r;                                  \
+  } while (0)
+
+MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "finalize twice");
+  DModel& m = c->model;
+  if (!m.cfg.enable_tgs) return fail(c, MSK_ERR_INVALID, "only the TGS solver is implemented");
+  if (num_envs <= 0) return fail(c, MSK_ERR_INVALID, "num_envs must be positive");
+  HIP_TRY(hipSetDevice(c->device));
+  m.nv = m.nd;
+  for (int i = 0; i < m.nb; ++i)
+    if (m.bodies[i].kind == MSK_BODY_DYNAMIC) { m.bodies[i].vofs = m.nv; m.nv += 6; }
+  if (m.nv > MSK_MAX_NV) return fail(c, MSK_ERR_CAPACITY, "generalized velocity too large");
+  c->max_dof = 0;
+  for (int a = 0; a < m.na; ++a) {
+    if (c->art_root[a] < 0) return fail(c, MSK_ERR_INVALID, "articulation without links");
+    if (c->art_ndof[a] > c->max_dof) c->max_dof = c->art_ndof[a];
+  }
+  m.np = 0;
+  for (int i = 0; i < m.ns; ++i)
+    for (int j = i + 1; j < m.ns; ++j)
+      if (pair_enabled(c, i, j)) {
+        if (m.np >= MSK_MAX_PAIRS) return fail(c, MSK_ERR_CAPACITY, "too many candidate pairs");
+        m.pairs[m.np].sa = i; m.pairs[m.np].sb = j;
+        m.np++;
+      }
+  m.N = num_envs;
+  const size_t N = (size_t)num_envs;
+  ALLOC(c->d_model, 1);
+  HIP_TRY(hipMemcpy(c->d_model, &m, sizeof(DModel), hipMemcpyHostToDevice));
+  DState& st = c->st;
+  const size_t nd = m.nd > 0 ? m.nd : 1;
+  ALLOC(st.q, nd * N); ALLOC(st.qd, nd * N); ALLOC(st.qacc, nd * N); ALLOC(st.qf, nd * N);
+  ALLOC(st.qt, nd * N); ALLOC(st.qdt, nd * N);
+  ALLOC(st.bpose, (size_t)m.nb * 7 * N); ALLOC(st.blin, (size_t)m.nb * 3 * N); ALLOC(st.bang, (size_t)m.nb * 3 * N);
+  ALLOC(st.S, nd * 6 * N); ALLOC(st.comw, (size_t)m.nb * 3 * N); ALLOC(st.Minv, nd * nd * N);
+  ALLOC(st.Iwinv, (size_t)m.nb * 6 * N); ALLOC(st.vfree, (size_t)m.nv * N);
+  const size_t np = m.np > 0 ? m.np : 1;
+  ALLOC(st.ct_cnt, np * N); ALLOC(st.ct_pos, np * 12 * N); ALLOC(st.ct_n, np * 3 * N);
+  ALLOC(st.ct_sep, np * 4 * N); ALLOC(st.ct_lam, np * 12 * N);
+  c->nv_pad = (m.nv <= 8) ? 8 : (m.nv <= 16) ? 16 : (m.nv <= 24) ? 24 : 32;
+  ALLOC(st.rw_J, (size_t)MSK_MAX_ROWS * c->nv_pad * N); ALLOC(st.rw_Y, (size_t)MSK_MAX_ROWS * c->nv_pad * N);
+  ALLOC(st.rw_d, (size_t)MSK_MAX_ROWS * N);
+  ALLOC(st.env_ncontacts, N); ALLOC(st.env_overflow, 1);
+  ALLOC(st.offsets, 3 * N);
+  ALLOC(c->d_art_dof0, 8); ALLOC(c->d_art_ndof, 8);
+  HIP_TRY(hipMemcpy(c->d_art_dof0, c->art_dof0, sizeof(int) * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->d_art_ndof, c->art_ndof, sizeof(int) * 8, hipMemcpyHostToDevice));
+  /* external (torch-visible) AoS buffers */
+  const size_t nrb = N * (size_t)m.nb * 13;
+  const size_t nart = N * (size_t)(m.na > 0 ? m.na : 1) * (size_t)(c->max_dof > 0 ? c->max_dof : 1);
+  ALLOC(c->bufs.buf[MSK_BUF_RIGID_BODY_DATA], nrb);
+  for (int b = MSK_BUF_ART_QPOS; b < MSK_BUF_COUNT; ++b) ALLOC(c->bufs.buf[b], nart);
+  c->bufs.max_dof = c->max_dof;
+  /* initial poses (template replicated) */
+  std::vector<float> h((size_t)m.nb * 7 * N);
+  for (int i = 0; i < m.nb; ++i) {
+    const pose& p = c->init_pose[i];
+    const float vals[7] = {p.p.x, p.p.y, p.p.z, p.q.w, p.q.x, p.q.y, p.q.z};
+    for (int k = 0; k < 7; ++k)
+      for (size_t e = 0; e < N; ++e) h[((size_t)i * 7 + k) * N + e] = vals[k];
+  }
+  HIP_TRY(hipMemcpy(st.bpose, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  c->finalized = true;
+  hipLaunchKernelGGL(k_kinematics, dim3((num_envs + 63) / 64), dim3(64), 0, 0, c->d_model, c->st);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return MSK_OK;
+}
+
+MSK_API int msk_set_scene_offsets(msk_ctx* c, const float* offsets) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "set_scene_offsets before finalize");
+  const size_t N = (size_t)c->model.N;
+  std::vector<float> h(3 * N);
+  for (size_t e = 0; e < N; ++e)
+    for (int k = 0; k < 3; ++k) h[(size_t)k * N + e] = offsets[3 * e + k];
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpy(c->st.offsets, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  return MSK_OK;
+}
+
+MSK_API void* msk_buffer(msk_ctx* c, int id, int64_t shape[2]) {
+  if (!c->finalized || id < 0 || id >= MSK_BUF_COUNT) return nullptr;
+  if (id == MSK_BUF_RIGID_BODY_DATA) { shape[0] = (int64_t)c->model.N * c->model.nb; shape[1] = 13; }
+  else { shape[0] = (int64_t)c->model.N * c->model.na; shape[1] = c->max_dof; }
+  return c->bufs.buf[id];
+}
+
+MSK_API int msk_apply(msk_ctx* c, uint32_t mask, void* stream) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "apply before finalize");
+  const int N = c->model.N;
+  hipLaunchKernelGGL(k_apply, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->bufs, mask,
+                     c->d_art_dof0, c->d_art_ndof);
+  HIP_TRY(hipGetLastError());
+  return MSK_OK;
+}
+
+MSK_API int msk_fetch(msk_ctx* c, uint32_t mask, void* stream) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "fetch before finalize");
+  const int N = c->model.N;
+  hipLaunchKernelGGL(k_fetch, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->bufs, mask,
+                     c->d_art_dof0, c->d_art_ndof);
+  HIP_TRY(hipGetLastError());
+  return MSK_OK;
+}
+
+MSK_API int msk_update_kinematics(msk_ctx* c, void* stream) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "update_kinematics before finalize");
+  const int N = c->model.N;
+  hipLaunchKernelGGL(k_kinematics, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, c->d_model, c->st);
+  HIP_TRY(hipGetLastError());
+  return MSK_OK;
+}
+
+MSK_API int msk_step(msk_ctx* c, void* stream) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "step before finalize");
+  const int N = c->model.N;
+  const int nblk = (N + 63) / 64;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_dynamics, dim3(nblk), dim3(64), 0, s, c->d_model, c->st);
+  if (c->model.np > 0) hipLaunchKernelGGL(k_collide, dim3(nblk, c->model.np), dim3(64), 0, s, c->d_model, c->st);
+  switch (c->nv_pad) {
+    case 8: hipLaunchKernelGGL(k_solve<8>, dim3(nblk), dim3(64), 0, s, c->d_model, c->st); break;
+    case 16: hipLaunchKernelGGL(k_solve<16>, dim3(nblk), dim3(64), 0, s, c->d_model, c->st); break;
+    case 24: hipLaunchKernelGGL(k_solve<24>, dim3(nblk), dim3(64), 0, s, c->d_model, c->st); break;
+    default: hipLaunchKernelGGL(k_solve<32>, dim3(nblk), dim3(64), 0, s, c->d_model, c->st); break;
+  }
+  HIP_TRY(hipGetLastError());
+  return MSK_OK;
+}
+
+MSK_API int msk_query_create_pairs(msk_ctx* c, const int32_t* body_pairs, int npairs) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "query before finalize");
+  if (c->queries.size() >= 16) return fail(c, MSK_ERR_CAPACITY, "too many queries");
+  HIP_TRY(hipSetDevice(c->device));
+  HostQuery q;
+  q.npairs = npairs;
+  ALLOC(q.d_pairs, 2 * (size_t)npairs);
+  HIP_TRY(hipMemcpy(q.d_pairs, body_pairs, sizeof(int) * 2 * (size_t)npairs, hipMemcpyHostToDevice));
+  ALLOC(q.d_out, (size_t)c->model.N * npairs * 3);
+  c->queries.push_back(q);
+  return (int)c->queries.size() - 1;
+}
+
+MSK_API void* msk_query_buffer(msk_ctx* c, int q, int64_t shape[2]) {
+  if (q < 0 || q >= (int)c->queries.size()) return nullptr;
+  shape[0] = (int64_t)c->model.N * c->queries[q].npairs; shape[1] = 3;
+  return c->queries[q].d_out;
+}
+
+MSK_API int msk_query_run(msk_ctx* c, int q, void* stream) {
+  if (q < 0 || q >= (int)c->queries.size()) return fail(c, MSK_ERR_INVALID, "bad query");
+  const int N = c->model.N;
+  hipLaunchKernelGGL(k_query, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st,
+                     c->queries[q].d_pairs, c->queries[q].npairs, c->queries[q].d_out);
+  HIP_TRY(hipGetLastError());
+  return MSK_OK;
+}
+
+MSK_API int msk_get_sizes(msk_ctx* c, int32_t out[8]) {
+  const DModel& m = c->model;
+  out[0] = m.nb; out[1] = m.na; out[2] = c->max_dof; out[3] = m.nv; out[4] = m.ns; out[5] = m.np; out[6] = m.N;
+  out[7] = 0;
+  if (c->finalized) {
+    int flag = 0;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&flag, c->st.env_overflow, sizeof(int), hipMemcpyDeviceToHost));
+    out[7] = flag;
+  }
+  return MSK_OK;
+}
+
+MSK_API int msk_get_contacts(msk_ctx* c, int env, int32_t* ids, float* vals, int max_points) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "get_contacts before finalize");
+  const DModel& m = c->model;
+  if (env < 0 || env >= m.N) return fail(c, MSK_ERR_INVALID, "bad env");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t N = (size_t)m.N;
+  const int np = m.np;
+  std::vector<int> cnt(np > 0 ? np : 1);
+  std::vector<float> pos((size_t)np * 12 + 1), nrm((size_t)np * 3 + 1), sep((size_t)np * 4 + 1), lam((size_t)np * 12 + 1);
+  if (np == 0) return 0;
+  const size_t pitch = N * sizeof(float);
+  HIP_TRY(hipMemcpy2D(cnt.data(), sizeof(int), c->st.ct_cnt + env, pitch, sizeof(int), np, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy2D(pos.data(), sizeof(float), c->st.ct_pos + env, pitch, sizeof(float), (size_t)np * 12, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy2D(nrm.data(), sizeof(float), c->st.ct_n + env, pitch, sizeof(float), (size_t)np * 3, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy2D(sep.data(), sizeof(float), c->st.ct_sep + env, pitch, sizeof(float), (size_t)np * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy2D(lam.data(), sizeof(float), c->st.ct_lam + env, pitch, sizeof(float), (size_t)np * 12, hipMemcpyDeviceToHost));
+  int total = 0;
+  for (int p = 0; p < np; ++p)
+    for (int k = 0; k < cnt[p]; ++k) {
+      if (total < max_points) {
+        const int sa = m.pairs[p].sa, sb = m.pairs[p].sb;
+        ids[3 * total] = sa; ids[3 * total + 1] = sb;
+        ids[3 * total + 2] = m.shapes[sa].body * 256 + (m.shapes[sb].body & 255);
+        float* v = vals + 8 * total;
+        v[0] = pos[p * 12 + k * 3 + 0]; v[1] = pos[p * 12 + k * 3 + 1]; v[2] = pos[p * 12 + k * 3 + 2];
+        v[3] = nrm[p * 3 + 0]; v[4] = nrm[p * 3 + 1]; v[5] = nrm[p * 3 + 2];
+        v[6] = sep[p * 4 + k]; v[7] = lam[p * 12 + k * 3 + 0];
+      }
+      total++;
+    }
+  return total;
+}

@@ -203,31 +203,32 @@ class PickCubeEnv:
             table = self._table_pose.repeat(b, 1)
             table[:, :3] += off
             self._rbd[env_idx, self._b_table, :7] = table
-            qpos = f32(self._rng.normal(idx_np, 9) * self.robot_init_qpos_noise) + self._rest_qpos
+            qpos = self._rng.normal(idx_np, 9) * self.robot_init_qpos_noise + sb.PANDA_REST_QPOS
             qpos[:, -2:] = 0.04
-            self._qpos[env_idx, :9] = qpos
+            self._qpos[env_idx, :9] = f32(qpos)
             root = self._root_pose.repeat(b, 1)
             root[:, :3] += off
             self._rbd[env_idx, self._b_root, :7] = root
             # PickCubeEnv._initialize_episode
-            u = f32(self._rng.uniform(idx_np, 6))
-            xyz = torch.zeros(b, 3, device=dev)
-            xyz[:, :2] = u[:, 0:2] * self.cube_spawn_half_size * 2 - self.cube_spawn_half_size
-            xyz[:, 0] += self.cube_spawn_center[0]
-            xyz[:, 1] += self.cube_spawn_center[1]
+            # all episode randomness is evaluated on the host in float64 and rounded once, so that the
+            # initial state is bit-identical whatever device the env lives on
+            u = self._rng.uniform(idx_np, 6)
+            hs, cc = self.cube_spawn_half_size, self.cube_spawn_center
+            xyz = np.zeros((b, 3))
+            xyz[:, 0] = u[:, 0] * hs * 2 - hs + cc[0]
+            xyz[:, 1] = u[:, 1] * hs * 2 - hs + cc[1]
             xyz[:, 2] = self.cube_half_size
             yaw = u[:, 2] * (2 * np.pi)  # random_quaternions(lock_x, lock_y): rotation about z
-            qs = torch.zeros(b, 4, device=dev)
-            qs[:, 0] = torch.cos(yaw / 2)
-            qs[:, 3] = torch.sin(yaw / 2)
-            self._rbd[env_idx, self._b_cube, :3] = xyz + off
-            self._rbd[env_idx, self._b_cube, 3:7] = qs
-            goal = torch.zeros(b, 3, device=dev)
-            goal[:, :2] = u[:, 3:5] * self.cube_spawn_half_size * 2 - self.cube_spawn_half_size
-            goal[:, 0] += self.cube_spawn_center[0]
-            goal[:, 1] += self.cube_spawn_center[1]
+            qs = np.zeros((b, 4))
+            qs[:, 0] = np.cos(yaw / 2)
+            qs[:, 3] = np.sin(yaw / 2)
+            self._rbd[env_idx, self._b_cube, :3] = f32(xyz) + off
+            self._rbd[env_idx, self._b_cube, 3:7] = f32(qs)
+            goal = np.zeros((b, 3))
+            goal[:, 0] = u[:, 3] * hs * 2 - hs + cc[0]
+            goal[:, 1] = u[:, 4] * hs * 2 - hs + cc[1]
             goal[:, 2] = u[:, 5] * self.max_goal_height + xyz[:, 2]
-            self._rbd[env_idx, self._b_goal, :3] = goal + off
+            self._rbd[env_idx, self._b_goal, :3] = f32(goal) + off
             self._rbd[env_idx, self._b_goal, 3:7] = torch.tensor([1.0, 0, 0, 0], device=dev)
         # controller.reset(): targets = current qpos (pd_joint_pos.py:54-69)
         self._target_qpos[env_idx] = self._qpos[env_idx, :9]
