@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of 4096 parallel PickCube-v1 envs (state obs) on N MI355X.
+
+Harness = the reference's ``mani_skill/examples/benchmarking/gpu_sim.py:90-108``:
+``reset(seed=2022)``, warm-up steps, then K ``env.step`` calls with uniform random actions in
+[-1, 1] generated on the device inside the timed region; env-steps/s = total_envs * K / wall
+(``examples/benchmarking/profiling.py:96-113``), wall bracketed by barrier + device sync, max
+over ranks.  Task-default frequencies (sim 100 Hz / control 20 Hz => 5 physics substeps per step,
+15 position + 1 velocity TGS iterations).  The 4096 envs are split over the ranks (strong
+scaling, BASELINE.json: "4096 parallel PickCube-v1 envs at 1/2/4/8 MI355X"); the only
+collective is one all-gather of (obs | reward | terminated | truncated) per step (dist.py).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      dominant kernel of the substep, algorithmic bytes / HIP-event duration
+  cpu_baseline  the CPU oracle (oracle/liborc.so, OpenMP over envs) on a bounded sample, N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from maniskill_amd.dist import make_sharded_pick_cube  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+# algorithmic bytes of one physics substep of one PickCube env
+# (18 body rows r+w 1872 B + generalized state 288 B + ~8 contacts x 112 B = 896 B)
+ALG_BYTES_PER_ENV_SUBSTEP = 3056.0
+
+
+def cpu_baseline(sample_envs: int, sample_steps: int):
+    """Times the CPU oracle (test infrastructure, 'port' of the same algorithm) on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_backend import OraclePhysxSystem
+    from maniskill_amd.envs.pick_cube import PickCubeEnv
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(1)
+    env = PickCubeEnv(num_envs=sample_envs, px_factory=lambda tpl, n, cfg: OraclePhysxSystem(tpl, n, cfg))
+    env.reset(seed=2022)
+    gen = torch.Generator().manual_seed(0)
+    env.step(2 * torch.rand(sample_envs, 8, generator=gen) - 1)
+    t0 = time.perf_counter()
+    for _ in range(sample_steps):
+        env.step(2 * torch.rand(sample_envs, 8, generator=gen) - 1)
+    dt = time.perf_counter() - t0
+    env.close()
+    return {
+        "value": sample_envs * sample_steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "sample": f"{sample_envs} PickCube-v1 envs x {sample_steps} control steps (5 substeps each), "
+                  f"oracle/liborc.so scalar C, OpenMP over envs on {cores} host threads, {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--envs", type=int, default=4096, help="total env count over all ranks")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU (the product path has no CPU fallback)")
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    env, gather, rank, world = make_sharded_pick_cube(args.envs, device_type="cuda")
+    dev = env.device
+    n_local = env.num_envs
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.inference_mode():
+        torch.manual_seed(0 + rank)
+        env.reset(seed=2022)
+        for _ in range(args.warmup):
+            out = env.step(2 * torch.rand(n_local, env.action_dim, device=dev) - 1)
+            gather(*out[:4])
+        substeps = env._sim_steps_per_control
+        env.px.timing_enable(args.steps * substeps)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            actions = 2 * torch.rand(n_local, env.action_dim, device=dev) - 1
+            obs, rew, term, trunc, _ = env.step(actions)
+            gather(obs, rew, term, trunc)
+        sync()
+        dt = time.perf_counter() - t0
+        kernels = env.px.timing_read()
+        env.px.timing_enable(0)
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        tot_ms, launches = kernels[dom]
+        avg_s = tot_ms / max(launches, 1) * 1e-3
+        alg_bytes = ALG_BYTES_PER_ENV_SUBSTEP * n_local
+        achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        result = {
+            "metric": "env steps/sec (whole node), 4096 parallel PickCube-v1 envs",
+            "value": args.envs * args.steps / dt,
+            "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (uniform random actions in [-1,1], seed-2022 resets)",
+            "config": {"workload": f"PickCube-v1, num_envs={args.envs}, state obs, pd_joint_delta_pos, "
+                                   f"sim 100 Hz / control 20 Hz ({substeps} substeps, 15+1 TGS iterations)",
+                       "envs_per_gpu": n_local, "parallelism": f"env-shard x{world}"},
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_kernel_us": avg_s * 1e6, "launches": launches,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_us": {k: v[0] / max(v[1], 1) * 1e3 for k, v in kernels.items()},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(512, 100)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -178,6 +178,17 @@ int msk_get_sizes(msk_ctx* ctx, int32_t out[8]);
  * normal impulse}.  Returns the number of points (<= max_points written). */
 int msk_get_contacts(msk_ctx* ctx, int env, int32_t* ids, float* vals, int max_points);
 
+/* ---- measurement (bench.py: roofline.achieved) --------------------------------------- */
+/* Per-kernel HIP-event timing of msk_step(), on the stream the kernels are launched on.
+ * The reference's harness only has wall-clock (examples/benchmarking/profiling.py:96-113);
+ * this is the per-kernel counterpart.  msk_timing_enable(ctx, max_steps) arms the timer for
+ * the next max_steps calls of msk_step (0 disarms and drops the samples);
+ * msk_timing_read waits for the recorded events and returns, for kernel slot `slot`
+ * (enum msk_kernel_slot), the summed duration in milliseconds and the number of launches. */
+enum msk_kernel_slot { MSK_K_DYNAMICS = 0, MSK_K_COLLIDE = 1, MSK_K_SOLVE = 2, MSK_K_SLOTS = 3 };
+int msk_timing_enable(msk_ctx* ctx, int max_steps);
+int msk_timing_read(msk_ctx* ctx, int slot, double* total_ms, int32_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

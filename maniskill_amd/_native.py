@@ -2,9 +2,8 @@
 
 The product path loads ``maniskill_amd/csrc/libmsk_physx.so`` (hand-written HIP kernels for
 gfx950) and FAILS LOUDLY when it is missing: there is no CPU fallback in this package.
-``NativeLib`` itself is prefix-generic so that the test-suite can bind the CPU oracle
-(``oracle/liborc.so``, prefix ``orc_``) behind the same Python classes; nothing under
-``maniskill_amd/`` ever does that.
+``NativeLib`` itself is prefix-generic so that the test-suite can bind its CPU checker
+behind the same Python classes; nothing under ``maniskill_amd/`` ever does that.
 """
 from __future__ import annotations
 
@@ -28,8 +27,10 @@ EXPORTS = [
     "create", "destroy", "last_error", "add_articulation", "add_link", "set_drive", "add_tendon",
     "add_actor", "add_shape", "disable_collision", "finalize", "set_scene_offsets", "buffer", "apply",
     "fetch", "update_kinematics", "step", "query_create_pairs", "query_buffer", "query_run",
-    "get_sizes", "get_contacts",
+    "get_sizes", "get_contacts", "timing_enable", "timing_read",
 ]
+K_DYNAMICS, K_COLLIDE, K_SOLVE = 0, 1, 2
+KERNEL_SLOTS = {"k_dynamics": K_DYNAMICS, "k_collide": K_COLLIDE, "k_solve": K_SOLVE}
 
 
 class MskConfig(C.Structure):
@@ -93,6 +94,8 @@ class NativeLib:
             "query_run": (i32, [vp, i32, vp]),
             "get_sizes": (i32, [vp, C.POINTER(C.c_int32)]),
             "get_contacts": (i32, [vp, i32, C.POINTER(C.c_int32), fp, i32]),
+            "timing_enable": (i32, [vp, i32]),
+            "timing_read": (i32, [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
         }
         for name, (res, args) in sig.items():
             fn = f(name)

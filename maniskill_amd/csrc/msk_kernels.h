@@ -605,10 +605,17 @@ __global__ void __launch_bounds__(256) k_apply(const DModel* __restrict__ m, DSt
     const float* r = bf.buf[MSK_BUF_RIGID_BODY_DATA] + ((size_t)e * m->nb + i) * 13;
     const bool is_root = b->kind == MSK_BODY_LINK && b->parent < 0;
     if ((b->kind != MSK_BODY_LINK && (mask & MSK_APPLY_RIGID_DATA)) || (is_root && (mask & MSK_APPLY_ART_ROOT_POSE))) {
-      pose T;
-      T.p = v3_make(r[0] - ox, r[1] - oy, r[2] - oz);
-      T.q = quat_normalize(quat_make(r[3], r[4], r[5], r[6]));
-      store_pose(st.bpose, i, N, e, T);
+      /* rows the caller did not touch since the last fetch are left alone: (p + off) - off and
+       * re-normalisation are not exact in fp32, and apply must not perturb untouched envs */
+      const pose cur = load_pose(st.bpose, i, N, e);
+      const bool same = (r[0] == cur.p.x + ox) && (r[1] == cur.p.y + oy) && (r[2] == cur.p.z + oz) &&
+                        (r[3] == cur.q.w) && (r[4] == cur.q.x) && (r[5] == cur.q.y) && (r[6] == cur.q.z);
+      if (!same) {
+        pose T;
+        T.p = v3_make(r[0] - ox, r[1] - oy, r[2] - oz);
+        T.q = quat_normalize(quat_make(r[3], r[4], r[5], r[6]));
+        store_pose(st.bpose, i, N, e, T);
+      }
       if (b->kind == MSK_BODY_DYNAMIC) {
         store_v3(st.blin, i, N, e, v3_make(r[7], r[8], r[9]));
         store_v3(st.bang, i, N, e, v3_make(r[10], r[11], r[12]));

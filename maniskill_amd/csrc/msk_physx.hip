@@ -35,6 +35,9 @@ struct msk_ctx {
   uint32_t groups[MSK_MAX_SHAPES][4]; /* collision groups: only the static pair filter needs them */
   std::vector<void*> allocs;
   std::vector<HostQuery> queries;
+  /* per-kernel event timing (msk_timing_*): MSK_K_SLOTS + 1 events per armed step */
+  std::vector<hipEvent_t> tev;
+  int t_cap, t_n;
   char err[256];
 };
 
@@ -98,6 +101,7 @@ MSK_API msk_ctx* msk_create(int hip_device, const msk_config* cfg) {
   c->ndisabled = 0;
   c->nverts_total = 0;
   c->max_dof = 0;
+  c->t_cap = 0; c->t_n = 0;
   c->err[0] = 0;
   return c;
 }
@@ -107,6 +111,7 @@ MSK_API void msk_destroy(msk_ctx* c) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   for (void* p : c->allocs) hipFree(p);
+  for (hipEvent_t e : c->tev) hipEventDestroy(e);
   delete c;
 }
 
@@ -423,15 +428,50 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
   const int N = c->model.N;
   const int nblk = (N + 63) / 64;
   hipStream_t s = (hipStream_t)stream;
+  const bool timed = c->t_n < c->t_cap;
+  hipEvent_t* ev = timed ? &c->tev[(size_t)c->t_n * (MSK_K_SLOTS + 1)] : nullptr;
+  if (timed) hipEventRecord(ev[0], s);
   hipLaunchKernelGGL(k_dynamics, dim3(nblk), dim3(64), 0, s, c->d_model, c->st);
+  if (timed) hipEventRecord(ev[1], s);
   if (c->model.np > 0) hipLaunchKernelGGL(k_collide, dim3(nblk, c->model.np), dim3(64), 0, s, c->d_model, c->st);
+  if (timed) hipEventRecord(ev[2], s);
   switch (c->nv_pad) {
     case 8: hipLaunchKernelGGL(k_solve<8>, dim3(nblk), dim3(64), 0, s, c->d_model, c->st); break;
     case 16: hipLaunchKernelGGL(k_solve<16>, dim3(nblk), dim3(64), 0, s, c->d_model, c->st); break;
     case 24: hipLaunchKernelGGL(k_solve<24>, dim3(nblk), dim3(64), 0, s, c->d_model, c->st); break;
     default: hipLaunchKernelGGL(k_solve<32>, dim3(nblk), dim3(64), 0, s, c->d_model, c->st); break;
   }
+  if (timed) { hipEventRecord(ev[3], s); c->t_n++; }
   HIP_TRY(hipGetLastError());
+  return MSK_OK;
+}
+
+MSK_API int msk_timing_enable(msk_ctx* c, int max_steps) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "timing before finalize");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t need = (size_t)(max_steps > 0 ? max_steps : 0) * (MSK_K_SLOTS + 1);
+  while (c->tev.size() < need) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    c->tev.push_back(e);
+  }
+  c->t_cap = max_steps > 0 ? max_steps : 0;
+  c->t_n = 0;
+  return MSK_OK;
+}
+
+MSK_API int msk_timing_read(msk_ctx* c, int slot, double* total_ms, int32_t* launches) {
+  if (slot < 0 || slot >= MSK_K_SLOTS) return fail(c, MSK_ERR_INVALID, "bad kernel slot");
+  double sum = 0.0;
+  for (int i = 0; i < c->t_n; ++i) {
+    hipEvent_t* ev = &c->tev[(size_t)i * (MSK_K_SLOTS + 1)];
+    HIP_TRY(hipEventSynchronize(ev[slot + 1]));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev[slot], ev[slot + 1]));
+    sum += ms;
+  }
+  *total_ms = sum;
+  *launches = c->t_n;
   return MSK_OK;
 }
 

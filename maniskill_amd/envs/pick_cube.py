@@ -100,7 +100,7 @@ class PickCubeEnv:
 
     def __init__(self, num_envs: int = 1, device: Optional[str] = None, sim_config: Optional[SimConfig] = None,
                  robot_init_qpos_noise: float = 0.02, reward_mode: str = "normalized_dense",
-                 env_index_offset: int = 0, px_factory=None):
+                 env_index_offset: int = 0, total_envs: Optional[int] = None, px_factory=None):
         self.num_envs = int(num_envs)
         self.sim_config = sim_config or SimConfig()
         self.robot_init_qpos_noise = robot_init_qpos_noise
@@ -122,8 +122,10 @@ class PickCubeEnv:
         self.device = self.px.device
         self.px.gpu_init()
         # sub-scene grid offsets (sapien_env.py:1191-1202)
-        side = int(np.ceil(np.sqrt(self.num_envs)))
-        g = np.arange(self.num_envs)
+        # a shard of a larger job (dist.py) keeps the GLOBAL grid cell of each env, so that the
+        # published fp32 rows (env-frame pose + offset) do not depend on the partitioning
+        side = int(np.ceil(np.sqrt(total_envs if total_envs is not None else self.num_envs)))
+        g = np.arange(self.num_envs) + self.env_index_offset
         offsets = np.stack([(g % side - side // 2) * self.sim_config.spacing,
                             (g // side - side // 2) * self.sim_config.spacing, np.zeros(self.num_envs)], axis=1)
         self.px.set_scene_offsets(offsets)

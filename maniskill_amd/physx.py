@@ -347,6 +347,20 @@ class PhysxGpuSystem:
     def gpu_query_contact_pair_impulses(self, query: ContactPairImpulseQuery):
         self.lib.check(self.ctx, self.lib.query_run(self.ctx, query.id, self._stream()), "query_run")
 
+    # -- measurement -------------------------------------------------------------------------
+    def timing_enable(self, max_steps: int):
+        """Arm per-kernel HIP-event timing for the next ``max_steps`` calls of ``step()``."""
+        self.lib.check(self.ctx, self.lib.timing_enable(self.ctx, int(max_steps)), "timing_enable")
+
+    def timing_read(self):
+        """{kernel name: (total_ms, launches)} of the armed steps (waits for the events)."""
+        out = {}
+        for name, slot in N.KERNEL_SLOTS.items():
+            ms, n = C.c_double(), C.c_int32()
+            self.lib.check(self.ctx, self.lib.timing_read(self.ctx, slot, C.byref(ms), C.byref(n)), "timing_read")
+            out[name] = (ms.value, n.value)
+        return out
+
     # -- inspection (parity tests) -------------------------------------------------------
     def get_contacts(self, env: int, max_points: int = 64):
         ids = (C.c_int32 * (3 * max_points))()
@@ -355,6 +369,12 @@ class PhysxGpuSystem:
         n = min(n, max_points)
         return (np.array(ids[: 3 * n], dtype=np.int32).reshape(n, 3),
                 np.array(vals[: 8 * n], dtype=np.float32).reshape(n, 8))
+
+    def get_overflow(self) -> int:
+        """1 if any env exceeded its contact capacity since gpu_init (synchronises)."""
+        sizes = (C.c_int32 * 8)()
+        self.lib.check(self.ctx, self.lib.get_sizes(self.ctx, sizes), "get_sizes")
+        return int(sizes[7])
 
     def close(self):
         if getattr(self, "ctx", None):

@@ -275,8 +275,15 @@ ORC_EXPORT int orc_apply(orc_ctx* c, uint32_t mask, void* stream) {
       const float* r = c->buf[MSK_BUF_RIGID_BODY_DATA] + ((size_t)e * c->nb + i) * 13;
       int is_root = b->kind == MSK_BODY_LINK && b->parent < 0;
       if ((b->kind != MSK_BODY_LINK && (mask & MSK_APPLY_RIGID_DATA)) || (is_root && (mask & MSK_APPLY_ART_ROOT_POSE))) {
-        env->bpose[i].p = v3_make(r[0] - off[0], r[1] - off[1], r[2] - off[2]);
-        env->bpose[i].q = quat_normalize(quat_make(r[3], r[4], r[5], r[6]));
+        /* rows the caller did not touch since the last fetch are left alone: (p + off) - off and
+         * re-normalisation are not exact in fp32, and apply must not perturb untouched envs */
+        const pose cur = env->bpose[i];
+        int same = (r[0] == cur.p.x + off[0]) && (r[1] == cur.p.y + off[1]) && (r[2] == cur.p.z + off[2]) &&
+                   (r[3] == cur.q.w) && (r[4] == cur.q.x) && (r[5] == cur.q.y) && (r[6] == cur.q.z);
+        if (!same) {
+          env->bpose[i].p = v3_make(r[0] - off[0], r[1] - off[1], r[2] - off[2]);
+          env->bpose[i].q = quat_normalize(quat_make(r[3], r[4], r[5], r[6]));
+        }
         if (b->kind == MSK_BODY_DYNAMIC) {
           env->blin[i] = v3_make(r[7], r[8], r[9]);
           env->bang[i] = v3_make(r[10], r[11], r[12]);
@@ -406,4 +413,12 @@ ORC_EXPORT int orc_get_contacts(orc_ctx* c, int env, int32_t* ids, float* vals, 
     v[6] = ct->sep; v[7] = ct->lam[0];
   }
   return e->ncontacts;
+}
+
+/* msk_timing_*: the oracle has no kernels to time; kept so that both libraries export the same ABI */
+ORC_EXPORT int orc_timing_enable(orc_ctx* c, int max_steps) { (void)c; (void)max_steps; return MSK_OK; }
+ORC_EXPORT int orc_timing_read(orc_ctx* c, int slot, double* total_ms, int32_t* launches) {
+  (void)c; (void)slot;
+  *total_ms = 0.0; *launches = 0;
+  return MSK_OK;
 }

@@ -1,0 +1,60 @@
+"""The C-ABI libraries load and export every symbol include/msk_physx.h declares (no GPU needed)."""
+import ctypes
+import os
+import re
+
+from maniskill_amd import _native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "msk_physx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(msk_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    names = _declared()
+    assert len(names) >= 22
+    assert {"msk_" + n for n in N.EXPORTS} == set(names)
+
+
+def test_hip_library_exports_every_symbol(built):
+    dll = ctypes.CDLL(N.DEFAULT_LIB)
+    for name in _declared():
+        assert hasattr(dll, name), f"libmsk_physx.so does not export {name}"
+
+
+def test_oracle_exports_same_surface(built):
+    from oracle_backend import ORACLE_LIB
+
+    dll = ctypes.CDLL(ORACLE_LIB)
+    for name in _declared():
+        assert hasattr(dll, name.replace("msk_", "orc_", 1))
+
+
+def test_product_has_no_oracle_dependency():
+    """Nothing under maniskill_amd/ may reference oracle/ (the product has no CPU path)."""
+    pkg = os.path.join(ROOT, "maniskill_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")) or f == "Makefile":
+                src = open(os.path.join(dp, f), errors="ignore").read()
+                assert "liborc" not in src and "oracle_backend" not in src, os.path.join(dp, f)
+                assert not re.search(r'#include\s+"[^"]*orc_', src), os.path.join(dp, f)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    import pytest
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        N.NativeLib(str(tmp_path / "nope.so"), "msk_")
+
+
+def test_cpu_device_is_rejected():
+    import pytest
+    from maniskill_amd.envs.pick_cube import PickCubeEnv
+
+    with pytest.raises(RuntimeError, match="no CPU backend"):
+        PickCubeEnv(num_envs=1, device="cpu")

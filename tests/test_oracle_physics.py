@@ -1,0 +1,252 @@
+"""Known-answer tests of the CPU oracle (tier T2 of SURVEY.md §8c): physical facts derived from the
+reference's task definitions, since no PhysX trace exists to compare with (parity unpinned)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from maniskill_amd import _native as N
+from maniskill_amd.agents.urdf import load_model
+from maniskill_amd.envs import scene_builders as sb
+from maniskill_amd.physx import SceneTemplate
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _cube_scene(oracle_factory, n=2):
+    tpl = SceneTemplate()
+    table = sb.add_table_scene(tpl)
+    cube = sb.add_cube(tpl, "cube", 0.02, (0, 0, 0.02))
+    px = oracle_factory(tpl, n, None)
+    px.gpu_init()
+    return tpl, px, table, cube
+
+
+def test_cube_rests_on_table(oracle_factory):
+    """pick_cube.py:88-94,118: a cube placed at z = half_size stays there (Actor.is_static thresholds)."""
+    tpl, px, table, cube = _cube_scene(oracle_factory)
+    rbd = px.cuda_rigid_body_data.torch().view(2, -1, 13)
+    for _ in range(200):
+        px.step()
+    px.gpu_fetch_all()
+    assert abs(rbd[0, cube, 2].item() - 0.02) < 1e-3
+    assert rbd[0, cube, 7:10].norm().item() < 1e-2 and rbd[0, cube, 10:13].norm().item() < 0.1
+    ids, vals = px.get_contacts(0)
+    assert len(ids) == 4 and np.allclose(vals[:, 5], -1.0, atol=1e-5)  # table is shape A: normal from cube to table
+    m = 1000 * 0.04 ** 3
+    assert abs(vals[:, 7].sum() - m * 9.81 * px.timestep) < 2e-5  # sum of normal impulses = m g dt
+
+
+def test_dropped_tilted_cube_settles_flat(oracle_factory):
+    tpl, px, table, cube = _cube_scene(oracle_factory)
+    rbd = px.cuda_rigid_body_data.torch().view(2, -1, 13)
+    rbd[1, cube, 2] = 0.15
+    rbd[1, cube, 3:7] = torch.tensor([0.9659258, 0.2588190, 0.0, 0.0])  # 30 deg about x
+    px.gpu_apply_all()
+    for _ in range(300):
+        px.step()
+    px.gpu_fetch_all()
+    assert abs(rbd[1, cube, 2].item() - 0.02) < 1.5e-3
+    assert rbd[1, cube, 7:13].abs().max().item() < 5e-2
+    assert torch.isfinite(rbd).all()
+
+
+def test_cube_off_the_table_lands_on_ground_plane(oracle_factory):
+    tpl, px, table, cube = _cube_scene(oracle_factory)
+    rbd = px.cuda_rigid_body_data.torch().view(2, -1, 13)
+    rbd[0, cube, :3] = torch.tensor([3.0, 0.0, 0.5])
+    px.gpu_apply_all()
+    for _ in range(400):
+        px.step()
+    px.gpu_fetch_all()
+    assert abs(rbd[0, cube, 2].item() - (sb.GROUND_ALTITUDE + 0.02)) < 2e-3
+
+
+def _fk_numpy(model, q, root_p):
+    """Independent float64 forward kinematics straight from the cooked URDF data."""
+    def qmat(qt):
+        w, x, y, z = qt
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    T = []
+    dof = 0
+    for L in model["links"]:
+        J = L["joint"]
+        if L["parent"] < 0:
+            M = np.eye(4)
+            M[:3, 3] = root_p
+        else:
+            O = np.eye(4)
+            O[:3, :3] = qmat(J["q"])
+            O[:3, 3] = J["p"]
+            Jm = np.eye(4)
+            ax = np.asarray(J["axis"], dtype=float)
+            if J["type"] == "revolute":
+                a = q[dof]; dof += 1
+                K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+                Jm[:3, :3] = np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+            elif J["type"] == "prismatic":
+                Jm[:3, 3] = ax * q[dof]; dof += 1
+            M = T[L["parent"]] @ O @ Jm
+        T.append(M)
+    return T
+
+
+def test_forward_kinematics_matches_independent_fk(oracle_factory):
+    tpl, ids = sb.build_pick_cube_template()
+    px = oracle_factory(tpl, 4, None)
+    px.gpu_init()
+    model = load_model("panda_v2.json")
+    rng = np.random.RandomState(0)
+    qpos = px.cuda_articulation_qpos.torch()
+    qs = sb.PANDA_REST_QPOS[None] + rng.uniform(-0.5, 0.5, (4, 9))
+    qs[:, 7:] = rng.uniform(0, 0.04, (4, 2))
+    qpos[:] = torch.tensor(qs, dtype=torch.float32)
+    px.gpu_apply_articulation_qpos()
+    px.gpu_update_articulation_kinematics()
+    px.gpu_fetch_all()
+    rbd = px.cuda_rigid_body_data.torch().view(4, -1, 13).numpy()
+    for e in range(4):
+        T = _fk_numpy(model, qs[e], np.array([-0.615, 0, 0]))
+        for i, M in enumerate(T):
+            assert np.allclose(rbd[e, i, :3], M[:3, 3], atol=2e-6), (e, i)
+            w, x, y, z = rbd[e, i, 3:7]
+            R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                          [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                          [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+            assert np.allclose(R, M[:3, :3], atol=5e-6), (e, i)
+
+
+def test_arm_holds_rest_pose_and_tracks_targets(oracle_factory):
+    """pd_joint_pos drives (K=1e3, D=1e2) with gravity disabled on the links (base_agent.py:278-282)."""
+    tpl, ids = sb.build_pick_cube_template()
+    px = oracle_factory(tpl, 1, None)
+    px.gpu_init()
+    qpos, tq = px.cuda_articulation_qpos.torch(), px.cuda_articulation_target_qpos.torch()
+    qpos[0] = torch.tensor(sb.PANDA_REST_QPOS, dtype=torch.float32)
+    tq[0] = qpos[0]
+    px.gpu_apply_all()
+    for _ in range(100):
+        px.step()
+    px.gpu_fetch_all()
+    assert np.allclose(qpos[0].numpy(), sb.PANDA_REST_QPOS, atol=1e-5)
+    target = sb.PANDA_REST_QPOS.copy()
+    target[:7] += np.array([0.2, -0.15, 0.1, 0.2, -0.2, -0.3, 0.3])
+    tq[0] = torch.tensor(target, dtype=torch.float32)
+    px.gpu_apply_articulation_target_position()
+    for _ in range(300):
+        px.step()
+    px.gpu_fetch_all()
+    assert np.allclose(qpos[0].numpy(), target, atol=2e-3)
+    assert px.cuda_articulation_qvel.torch()[0].abs().max().item() < 1e-2
+
+
+def test_joint_limits_hold(oracle_factory):
+    tpl, ids = sb.build_pick_cube_template()
+    px = oracle_factory(tpl, 1, None)
+    px.gpu_init()
+    qpos, tq = px.cuda_articulation_qpos.torch(), px.cuda_articulation_target_qpos.torch()
+    qpos[0] = torch.tensor(sb.PANDA_REST_QPOS, dtype=torch.float32)
+    tq[0] = qpos[0]
+    tq[0, 3] = 1.0       # panda_joint4 upper limit is -0.0698
+    tq[0, 7:] = 0.2      # fingers: upper limit 0.04
+    px.gpu_apply_all()
+    for _ in range(400):
+        px.step()
+    px.gpu_fetch_all()
+    assert qpos[0, 3].item() < -0.0698 + 5e-3
+    assert qpos[0, 7].item() < 0.04 + 1e-3 and qpos[0, 8].item() < 0.04 + 1e-3
+
+
+def test_static_pair_filter(oracle_factory):
+    """Collision filtering: adjacent links, SRDF-disabled pairs and static-static pairs are removed."""
+    tpl, ids = sb.build_pick_cube_template()
+    px = oracle_factory(tpl, 1, None)
+    px.gpu_init()
+    assert (px.bodies_per_env, px.arts_per_env, px.max_dof, px.nv, px.nshapes) == (18, 1, 9, 15, 20)
+    assert px.npairs == 94
+
+
+def test_scripted_pick_and_lift_keeps_the_cube_grasped(oracle_factory):
+    """T2: closing the gripper on the cube gives is_grasping (>= 0.5 N, <= 85 deg: panda.py:237-265) and
+    the lifted cube follows the TCP (cf. franka_pick_cube.py:26-36 in the reference's benchmark)."""
+    from maniskill_amd.envs.pick_cube import PickCubeEnv
+
+    wp = json.load(open(os.path.join(HERE, "golden", "grasp_waypoints.json")))
+    env = PickCubeEnv(num_envs=1, px_factory=oracle_factory, robot_init_qpos_noise=0.0)
+    env.reset(seed=0)
+    # put the cube at the origin, unrotated
+    st = env.get_state()
+    st[0, 13:16] = torch.tensor([0.0, 0.0, 0.02]); st[0, 16:20] = torch.tensor([1.0, 0, 0, 0])
+    env.set_state(st)
+    tq = env._target_qpos_buf
+
+    def go(qa, qb, grip, steps):
+        for k in range(steps):
+            a = (k + 1) / steps
+            tq[0, :7] = torch.tensor(np.asarray(qa) * (1 - a) + np.asarray(qb) * a, dtype=torch.float32)
+            tq[0, 7:9] = grip
+            env.px.gpu_apply_articulation_target_position()
+            for _ in range(5):
+                env.px.step()
+        env.px.gpu_fetch_all()
+
+    go(wp["q_rest"], wp["q_pre"], 0.04, 20)
+    go(wp["q_pre"], wp["q_grasp"], 0.04, 20)
+    assert not env.is_grasping()[0]
+    go(wp["q_grasp"], wp["q_grasp"], -0.01, 20)
+    assert env.is_grasping()[0]
+    go(wp["q_grasp"], wp["q_lift"], -0.01, 40)
+    go(wp["q_lift"], wp["q_lift"], -0.01, 60)
+    assert env.is_grasping()[0]
+    cube, tcp = env.cube_pose[0], env.tcp_pose[0]
+    assert cube[2].item() > 0.2 and (cube[:3] - tcp[:3]).norm().item() < 0.01
+    lf = env.get_pairwise_contact_forces(env._q_lgrasp)[0]
+    assert 15.0 < lf.norm().item() < 60.0  # K*(q - target) = 1e3 * 0.03 = 30 N nominal
+
+
+def test_convex_vs_box_matches_box_vs_box(oracle_factory):
+    """GJK/EPA + manifold on a hull with a box's vertices must agree with the SAT box path."""
+    res = []
+    for as_hull in (False, True):
+        tpl = SceneTemplate()
+        base = tpl.add_actor("base", N.BODY_KINEMATIC, p=(0, 0, 0))
+        tpl.add_shape(base, N.SHAPE_BOX, params=(0.5, 0.5, 0.05))
+        m, I = sb.box_mass_properties((0.03, 0.02, 0.01))
+        b = tpl.add_actor("b", N.BODY_DYNAMIC, p=(0.1, 0.05, 0.0595), q=(0.9807853, 0, 0, 0.1950903), mass=m, inertia6=I)
+        if as_hull:
+            v = np.array([[sx * 0.03, sy * 0.02, sz * 0.01] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float32)
+            tpl.add_shape(b, N.SHAPE_CONVEX, verts=v)
+        else:
+            tpl.add_shape(b, N.SHAPE_BOX, params=(0.03, 0.02, 0.01))
+        px = oracle_factory(tpl, 1, None)
+        px.gpu_init()
+        px.step()
+        ids, vals = px.get_contacts(0)
+        res.append(vals)
+    a, b = res
+    assert a.shape == b.shape == (4, 8)
+    assert np.allclose(a[:, 3:6], b[:, 3:6], atol=1e-4)                       # normals
+    assert np.allclose(np.sort(a[:, 6]), np.sort(b[:, 6]), atol=2e-5)          # separations (-0.5 mm)
+    assert np.allclose(a[:, 6], -5e-4, atol=5e-5)
+    pa = a[np.lexsort((a[:, 1], a[:, 0]))][:, :3]
+    pb = b[np.lexsort((b[:, 1], b[:, 0]))][:, :3]
+    assert np.allclose(pa, pb, atol=1e-4)
+
+
+def test_oracle_matches_its_golden_rollout(oracle_factory):
+    """Drift detector: the committed fixture (tests/golden/make_golden.py) is reproduced."""
+    from maniskill_amd.envs.pick_cube import PickCubeEnv
+
+    g = np.load(os.path.join(HERE, "golden", "pickcube_oracle_rollout.npz"))
+    n = g["actions"].shape[1]
+    env = PickCubeEnv(num_envs=n, px_factory=oracle_factory)
+    obs, _ = env.reset(seed=2022)
+    assert np.allclose(obs.numpy(), g["obs"][0], atol=1e-6)
+    for t in range(g["actions"].shape[0]):
+        obs, r, *_ = env.step(torch.from_numpy(g["actions"][t]))
+        assert np.allclose(obs.numpy(), g["obs"][t + 1], rtol=1e-4, atol=1e-5), t
+    assert np.allclose(env.get_state().numpy(), g["state"], rtol=1e-4, atol=1e-5)
