@@ -178,6 +178,9 @@ int msk_get_sizes(msk_ctx* ctx, int32_t out[8]);
  * normal impulse}.  Returns the number of points (<= max_points written). */
 int msk_get_contacts(msk_ctx* ctx, int env, int32_t* ids, float* vals, int max_points);
 
+/* Number of contact points each env solved in the last step(): out[num_envs]. */
+int msk_get_env_contact_counts(msk_ctx* ctx, int32_t* out);
+
 /* ---- measurement (bench.py: roofline.achieved) --------------------------------------- */
 /* Per-kernel HIP-event timing of msk_step(), on the stream the kernels are launched on.
  * The reference's harness only has wall-clock (examples/benchmarking/profiling.py:96-113);

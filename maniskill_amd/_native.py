@@ -27,7 +27,7 @@ EXPORTS = [
     "create", "destroy", "last_error", "add_articulation", "add_link", "set_drive", "add_tendon",
     "add_actor", "add_shape", "disable_collision", "finalize", "set_scene_offsets", "buffer", "apply",
     "fetch", "update_kinematics", "step", "query_create_pairs", "query_buffer", "query_run",
-    "get_sizes", "get_contacts", "timing_enable", "timing_read",
+    "get_sizes", "get_contacts", "get_env_contact_counts", "timing_enable", "timing_read",
 ]
 K_DYNAMICS, K_COLLIDE, K_SOLVE = 0, 1, 2
 KERNEL_SLOTS = {"k_dynamics": K_DYNAMICS, "k_collide": K_COLLIDE, "k_solve": K_SOLVE}
@@ -94,6 +94,7 @@ class NativeLib:
             "query_run": (i32, [vp, i32, vp]),
             "get_sizes": (i32, [vp, C.POINTER(C.c_int32)]),
             "get_contacts": (i32, [vp, i32, C.POINTER(C.c_int32), fp, i32]),
+            "get_env_contact_counts": (i32, [vp, C.POINTER(C.c_int32)]),
             "timing_enable": (i32, [vp, i32]),
             "timing_read": (i32, [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
         }

@@ -5,8 +5,7 @@
  *   k_dynamics   <<<N/64, 64>>>          one lane per env: link frames, CRBA, RNEA, implicit-PD
  *                                         system matrix, Cholesky, A^-1, unconstrained velocity
  *   k_collide    <<<(N/64, P), 64>>>     one lane per (pair, env); the pair is wave-uniform
- *   k_solve      <<<N/64, 64>>>          one lane per env: row assembly, TGS sweeps, integration,
- *                                         final kinematics, impulse write-back
+ *   k_solve<G>   <<<N*G/64, 64>>>        G lanes per env (one per generalized coordinate): msk_solve.h
  *   k_apply / k_fetch / k_kinematics / k_query   memcpy-class layout converters (AoS rows <-> SoA)
  * All per-env data is SoA with env fastest (msk_model.h), so a wave's accesses coalesce.
  * Arithmetic order mirrors the CPU oracle statement for statement (bitwise parity target).
@@ -15,9 +14,8 @@
 #define MSK_KERNELS_H
 
 #include "msk_collide.h"
+#include "msk_solve.h"
 
-#define MSK_PEN_BETA 0.8f
-#define MSK_MAX_DEPEN_VEL 3.0f
 #define MSK_WARM_DIST 5.0e-3f
 #define MSK_WARM_FACTOR 0.9f
 
@@ -108,12 +106,16 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
   const int e = blockIdx.x * 64 + threadIdx.x;
   if (e >= N) return;
   const int nd = m->nd;
+  const int G = m->G;
   const float dt = m->cfg.timestep;
   const v3 g = v3_make(m->cfg.gravity[0], m->cfg.gravity[1], m->cfg.gravity[2]);
   float q[MSK_MAX_DOF], qd[MSK_MAX_DOF];
   for (int i = 0; i < nd; ++i) { q[i] = AT(st.q, i); qd[i] = AT(st.qd, i); }
   KinScratch s;
   kinematics(m, st, N, e, q, qd, &s, true);
+  /* W: block-diagonal inverse mass matrix, row k for lane k of the solver */
+  float* Wenv = st.W + (size_t)e * G * G;   /* entries outside the blocks stay zero from allocation */
+  float* vfenv = st.vfree + (size_t)e * G;
 
   sinertia Ic[MSK_MAX_BODIES];
   sv6 f[MSK_MAX_BODIES];
@@ -179,9 +181,9 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
       }
       j = bj->parent;
     }
-    /* publish the joint subspace for the row assembly */
-    AT(st.S, b->dof * 6 + 0) = s.S[i].a.x; AT(st.S, b->dof * 6 + 1) = s.S[i].a.y; AT(st.S, b->dof * 6 + 2) = s.S[i].a.z;
-    AT(st.S, b->dof * 6 + 3) = s.S[i].l.x; AT(st.S, b->dof * 6 + 4) = s.S[i].l.y; AT(st.S, b->dof * 6 + 5) = s.S[i].l.z;
+    /* motion subspace column of coordinate dof, for the row assembly */
+    float* sc = st.Scol + ((size_t)e * G + b->dof) * 8;
+    sc[0] = s.S[i].a.x; sc[1] = s.S[i].a.y; sc[2] = s.S[i].a.z; sc[3] = s.S[i].l.x; sc[4] = s.S[i].l.y; sc[5] = s.S[i].l.z;
   }
   /* implicit PD drives / tendons folded into A */
   float Kd[MSK_MAX_DOF], Dd[MSK_MAX_DOF], fconst[MSK_MAX_DOF], fmaxd[MSK_MAX_DOF], err[MSK_MAX_DOF];
@@ -247,8 +249,8 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
     }
     if (nsat == 0) break;
   }
-  for (int i = 0; i < nd; ++i) AT(st.vfree, i) = vfree[i];
-  /* A^-1 column by column (reuse A as the output buffer) */
+  for (int i = 0; i < nd; ++i) vfenv[i] = vfree[i];
+  /* A^-1 column by column */
   for (int col = 0; col < nd; ++col) {
     float y[MSK_MAX_DOF], x[MSK_MAX_DOF];
     for (int i = 0; i < nd; ++i) {
@@ -261,7 +263,7 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
       for (int k = i + 1; k < nd; ++k) sum = fmaf(-L[k][i], x[k], sum);
       x[i] = sum / L[i][i];
     }
-    for (int i = 0; i < nd; ++i) AT(st.Minv, i * nd + col) = x[i];
+    for (int i = 0; i < nd; ++i) Wenv[i * G + col] = x[i];
   }
   /* free bodies */
   for (int i = 0; i < m->nb; ++i) {
@@ -273,12 +275,24 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
     float ka = fmaxf(0.0f, 1.0f - dt * b->ang_damp);
     v = v3_scale(v, kl);
     w = v3_scale(w, ka);
-    AT(st.vfree, b->vofs + 0) = v.x; AT(st.vfree, b->vofs + 1) = v.y; AT(st.vfree, b->vofs + 2) = v.z;
-    AT(st.vfree, b->vofs + 3) = w.x; AT(st.vfree, b->vofs + 4) = w.y; AT(st.vfree, b->vofs + 5) = w.z;
+    const int o = b->vofs;
+    vfenv[o + 0] = v.x; vfenv[o + 1] = v.y; vfenv[o + 2] = v.z;
+    vfenv[o + 3] = w.x; vfenv[o + 4] = w.y; vfenv[o + 5] = w.z;
     m33 R = quat_to_m33(s.bpose[i].q);
-    float Iwi[6];
-    sym6_rotate(&R, b->Iinv6, Iwi);
-    for (int k = 0; k < 6; ++k) AT(st.Iwinv, i * 6 + k) = Iwi[k];
+    float Ii[6];
+    sym6_rotate(&R, b->Iinv6, Ii);
+    const float im = 1.0f / b->mass;
+    const float Im[3][3] = {{Ii[0], Ii[3], Ii[4]}, {Ii[3], Ii[1], Ii[5]}, {Ii[4], Ii[5], Ii[2]}};
+    const v3 ex[3] = {v3_make(1, 0, 0), v3_make(0, 1, 0), v3_make(0, 0, 1)};
+    for (int a = 0; a < 3; ++a) {
+      Wenv[(o + a) * G + o + a] = im;
+      for (int j = 0; j < 3; ++j) Wenv[(o + 3 + a) * G + o + 3 + j] = Im[a][j];
+      float* sl = st.Scol + ((size_t)e * G + o + a) * 8;       /* v_com */
+      sl[0] = 0.0f; sl[1] = 0.0f; sl[2] = 0.0f; sl[3] = ex[a].x; sl[4] = ex[a].y; sl[5] = ex[a].z;
+      float* sa = st.Scol + ((size_t)e * G + o + 3 + a) * 8;   /* omega: point velocity = w x (p - c) */
+      const v3 cl = v3_cross(s.comw[i], ex[a]);
+      sa[0] = ex[a].x; sa[1] = ex[a].y; sa[2] = ex[a].z; sa[3] = cl.x; sa[4] = cl.y; sa[5] = cl.z;
+    }
     store_v3(st.comw, i, N, e, s.comw[i]);
   }
 }
@@ -339,19 +353,20 @@ __global__ void __launch_bounds__(64) k_collide(const DModel* __restrict__ m, DS
     }
   }
   /* warm start from the previous contents of this pair's slot, then overwrite it */
-  const int nprev = AT(st.ct_cnt, pi);
+  int* cntp = st.ct_cnt + (size_t)e * m->npp + pi;
+  float* rec = st.ct_rec + ((size_t)e * m->npp + pi) * MSK_CT_REC;
+  const int nprev = *cntp;
   v3 ppos[4];
   float plam[4][3];
   for (int j = 0; j < 4; ++j) {
     if (j < nprev) {
-      ppos[j] = v3_make(AT(st.ct_pos, pi * 12 + j * 3 + 0), AT(st.ct_pos, pi * 12 + j * 3 + 1), AT(st.ct_pos, pi * 12 + j * 3 + 2));
-      for (int a = 0; a < 3; ++a) plam[j][a] = AT(st.ct_lam, pi * 12 + j * 3 + a);
+      ppos[j] = v3_make(rec[4 + j * 3 + 0], rec[4 + j * 3 + 1], rec[4 + j * 3 + 2]);
+      for (int a = 0; a < 3; ++a) plam[j][a] = rec[20 + j * 3 + a];
     }
   }
-  AT(st.ct_cnt, pi) = n;
-  if (n > 0) {
-    AT(st.ct_n, pi * 3 + 0) = out[0].n.x; AT(st.ct_n, pi * 3 + 1) = out[0].n.y; AT(st.ct_n, pi * 3 + 2) = out[0].n.z;
-  }
+  if (n == 0 && nprev == 0) return;
+  *cntp = n;
+  if (n > 0) { rec[0] = out[0].n.x; rec[1] = out[0].n.y; rec[2] = out[0].n.z; }
   for (int k = 0; k < n; ++k) {
     float lam[3] = {0.0f, 0.0f, 0.0f};
     int best = -1;
@@ -362,233 +377,12 @@ __global__ void __launch_bounds__(64) k_collide(const DModel* __restrict__ m, DS
     }
     if (best >= 0)
       for (int a = 0; a < 3; ++a) lam[a] = MSK_WARM_FACTOR * plam[best][a];
-    AT(st.ct_pos, pi * 12 + k * 3 + 0) = out[k].pos.x;
-    AT(st.ct_pos, pi * 12 + k * 3 + 1) = out[k].pos.y;
-    AT(st.ct_pos, pi * 12 + k * 3 + 2) = out[k].pos.z;
-    AT(st.ct_sep, pi * 4 + k) = out[k].sep - m->cfg.rest_offset * 2.0f;
-    for (int a = 0; a < 3; ++a) AT(st.ct_lam, pi * 12 + k * 3 + a) = lam[a];
+    rec[4 + k * 3 + 0] = out[k].pos.x;
+    rec[4 + k * 3 + 1] = out[k].pos.y;
+    rec[4 + k * 3 + 2] = out[k].pos.z;
+    rec[16 + k] = out[k].sep - m->cfg.rest_offset * 2.0f;
+    for (int a = 0; a < 3; ++a) rec[20 + k * 3 + a] = lam[a];
   }
-}
-
-/* ---- solver ------------------------------------------------------------------------------ */
-/* J += sgn * d(velocity of the body-fixed point p along dir)/d(generalized velocity) */
-MSK_DEV void jac_point(const DModel* m, const DState& st, int N, int e, int body, v3 p, v3 dir, float sgn, float* J) {
-  if (body < 0) return;
-  const DBody* b = &m->bodies[body];
-  if (b->kind == MSK_BODY_LINK) {
-    sv6 F = {v3_cross(p, dir), dir};
-    int j = body;
-    while (j >= 0) {
-      const DBody* bj = &m->bodies[j];
-      if (bj->dof >= 0) {
-        sv6 Sj;
-        Sj.a = v3_make(AT(st.S, bj->dof * 6 + 0), AT(st.S, bj->dof * 6 + 1), AT(st.S, bj->dof * 6 + 2));
-        Sj.l = v3_make(AT(st.S, bj->dof * 6 + 3), AT(st.S, bj->dof * 6 + 4), AT(st.S, bj->dof * 6 + 5));
-        J[bj->dof] = fmaf(sgn, sv6_dot(Sj, F), J[bj->dof]);
-      }
-      j = bj->parent;
-    }
-  } else if (b->kind == MSK_BODY_DYNAMIC) {
-    v3 r = v3_cross(v3_sub(p, load_v3(st.comw, body, N, e)), dir);
-    J[b->vofs + 0] += sgn * dir.x; J[b->vofs + 1] += sgn * dir.y; J[b->vofs + 2] += sgn * dir.z;
-    J[b->vofs + 3] += sgn * r.x; J[b->vofs + 4] += sgn * r.y; J[b->vofs + 5] += sgn * r.z;
-  }
-}
-
-/* Y = A^-1 J^T, d = J.Y ; writes the row to the workspace (row stride NV, zero padded) */
-template <int NV>
-MSK_DEV void finish_row(const DModel* m, const DState& st, int N, int e, int row, const float* J) {
-  const int nd = m->nd, nv = m->nv;
-  float Y[MSK_MAX_NV];
-  for (int i = 0; i < nd; ++i) {
-    float a = 0.0f;
-    for (int k = 0; k < nd; ++k) a = fmaf(AT(st.Minv, i * nd + k), J[k], a);
-    Y[i] = a;
-  }
-  for (int i = 0; i < m->nb; ++i) {
-    const DBody* b = &m->bodies[i];
-    if (b->kind != MSK_BODY_DYNAMIC) continue;
-    float im = 1.0f / b->mass;
-    Y[b->vofs + 0] = J[b->vofs + 0] * im;
-    Y[b->vofs + 1] = J[b->vofs + 1] * im;
-    Y[b->vofs + 2] = J[b->vofs + 2] * im;
-    v3 ja = v3_make(J[b->vofs + 3], J[b->vofs + 4], J[b->vofs + 5]);
-    float Iwi[6];
-    for (int k = 0; k < 6; ++k) Iwi[k] = AT(st.Iwinv, i * 6 + k);
-    v3 ya = sym6_mulv(Iwi, ja);
-    Y[b->vofs + 3] = ya.x; Y[b->vofs + 4] = ya.y; Y[b->vofs + 5] = ya.z;
-  }
-  float d = 0.0f;
-  for (int k = 0; k < nv; ++k) {
-    d = fmaf(J[k], Y[k], d);
-    AT(st.rw_J, row * NV + k) = J[k];
-    AT(st.rw_Y, row * NV + k) = Y[k];
-  }
-  for (int k = nv; k < NV; ++k) {
-    AT(st.rw_J, row * NV + k) = 0.0f;
-    AT(st.rw_Y, row * NV + k) = 0.0f;
-  }
-  AT(st.rw_d, row) = d;
-}
-
-enum { ROW_LIMLO = 0, ROW_LIMHI = 1, ROW_CN = 2, ROW_CT1 = 3, ROW_CT2 = 4 };
-
-/* NV = generalized-velocity size padded to a compile-time constant: v[] and dq[] then live in
- * registers (every k loop is fully unrolled) instead of scratch memory. */
-template <int NV>
-__global__ void __launch_bounds__(64) k_solve(const DModel* __restrict__ m, DState st) {
-  const int N = m->N;
-  const int e = blockIdx.x * 64 + threadIdx.x;
-  if (e >= N) return;
-  const int nv = m->nv, nd = m->nd;
-  const float dt = m->cfg.timestep;
-  const int Np = m->cfg.solver_position_iterations, Nv = m->cfg.solver_velocity_iterations;
-  const float h = dt / (float)Np;
-
-  float q[MSK_MAX_DOF], qd[MSK_MAX_DOF];
-  for (int i = 0; i < nd; ++i) { q[i] = AT(st.q, i); qd[i] = AT(st.qd, i); }
-
-  /* row table: kind/idx (idx = body for limits, contact slot code pair*4+k for contacts), mu, c0, lam */
-  unsigned short rkind[MSK_MAX_ROWS];
-  unsigned short ridx[MSK_MAX_ROWS];
-  float rc0[MSK_MAX_ROWS], rlam[MSK_MAX_ROWS], rmu[MSK_MAX_ROWS];
-  int nr = 0;
-  float J[MSK_MAX_NV];
-  for (int i = 0; i < m->nb; ++i) {
-    const DBody* b = &m->bodies[i];
-    if (b->kind != MSK_BODY_LINK || b->dof < 0) continue;
-    if (b->lim_lo < -1e30f && b->lim_hi > 1e30f) continue;
-    for (int kind = ROW_LIMLO; kind <= ROW_LIMHI; ++kind) {
-      for (int k = 0; k < nv; ++k) J[k] = 0.0f;
-      J[b->dof] = (kind == ROW_LIMHI) ? -1.0f : 1.0f;
-      finish_row<NV>(m, st, N, e, nr, J);
-      rkind[nr] = kind; ridx[nr] = i; rlam[nr] = 0.0f; rmu[nr] = 0.0f;
-      rc0[nr] = (kind == ROW_LIMLO) ? (q[b->dof] - b->lim_lo) : (b->lim_hi - q[b->dof]);
-      nr++;
-    }
-  }
-  int ncontacts = 0;
-  int overflow = 0;
-  for (int p = 0; p < m->np; ++p) {
-    const int cnt = AT(st.ct_cnt, p);
-    if (cnt == 0) continue;
-    const DShape* A = &m->shapes[m->pairs[p].sa];
-    const DShape* B = &m->shapes[m->pairs[p].sb];
-    v3 n = v3_make(AT(st.ct_n, p * 3 + 0), AT(st.ct_n, p * 3 + 1), AT(st.ct_n, p * 3 + 2));
-    v3 t1, t2;
-    msk_tangents(n, &t1, &t2);
-    const float mu = 0.5f * (A->df + B->df);
-    for (int k = 0; k < cnt; ++k) {
-      if (ncontacts >= MSK_MAX_CONTACTS) { overflow = 1; AT(st.ct_cnt, p) = k; break; }
-      v3 pos = v3_make(AT(st.ct_pos, p * 12 + k * 3 + 0), AT(st.ct_pos, p * 12 + k * 3 + 1), AT(st.ct_pos, p * 12 + k * 3 + 2));
-      v3 dirs[3] = {n, t1, t2};
-      for (int a = 0; a < 3; ++a) {
-        for (int kk = 0; kk < nv; ++kk) J[kk] = 0.0f;
-        jac_point(m, st, N, e, A->body, pos, dirs[a], 1.0f, J);
-        jac_point(m, st, N, e, B->body, pos, dirs[a], -1.0f, J);
-        finish_row<NV>(m, st, N, e, nr, J);
-        rkind[nr] = ROW_CN + a; ridx[nr] = (unsigned short)(p * 4 + k);
-        rlam[nr] = AT(st.ct_lam, p * 12 + k * 3 + a);
-        rmu[nr] = mu;
-        rc0[nr] = AT(st.ct_sep, p * 4 + k);
-        nr++;
-      }
-      ncontacts++;
-    }
-    if (overflow) {
-      for (int pp = p + 1; pp < m->np; ++pp) AT(st.ct_cnt, pp) = 0;
-      break;
-    }
-  }
-  st.env_ncontacts[e] = ncontacts;
-  if (overflow) atomicOr(st.env_overflow, 1);
-
-  float v[NV], dq[NV];
-#pragma unroll
-  for (int k = 0; k < NV; ++k) { v[k] = (k < nv) ? AT(st.vfree, k) : 0.0f; dq[k] = 0.0f; }
-  for (int ri = 0; ri < nr; ++ri)
-    if (rlam[ri] != 0.0f) {
-      const float l = rlam[ri];
-#pragma unroll
-      for (int k = 0; k < NV; ++k) v[k] = fmaf(AT(st.rw_Y, ri * NV + k), l, v[k]);
-    }
-
-  for (int it = 0; it < Np + Nv; ++it) {
-    const int posit = it < Np;
-    for (int ri = 0; ri < nr; ++ri) {
-      float jv = 0.0f, jdq = 0.0f;
-      float Jr[NV];
-#pragma unroll
-      for (int k = 0; k < NV; ++k) Jr[k] = AT(st.rw_J, ri * NV + k);
-#pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        jv = fmaf(Jr[k], v[k], jv);
-        jdq = fmaf(Jr[k], dq[k], jdq);
-      }
-      const float d = AT(st.rw_d, ri);
-      const int kind = rkind[ri];
-      const float lam0 = rlam[ri];
-      float dl, nl;
-      if (kind <= ROW_CN) {
-        float cur = rc0[ri] + jdq;
-        float bias;
-        if (posit) bias = (cur > 0.0f) ? cur / h : fmaxf(cur * (MSK_PEN_BETA / dt), -MSK_MAX_DEPEN_VEL);
-        else bias = (cur > 0.0f) ? cur / dt : 0.0f;
-        dl = -(jv + bias) / d;
-        nl = fmaxf(lam0 + dl, 0.0f);
-      } else {
-        float bias = posit ? jdq / h : 0.0f;
-        dl = -(jv + bias) / d;
-        float lim = rmu[ri] * rlam[ri - (kind - ROW_CN)];
-        nl = fminf(fmaxf(lam0 + dl, -lim), lim);
-      }
-      dl = nl - lam0;
-      rlam[ri] = nl;
-      if (dl != 0.0f) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) v[k] = fmaf(AT(st.rw_Y, ri * NV + k), dl, v[k]);
-      }
-    }
-    if (posit) {
-#pragma unroll
-      for (int k = 0; k < NV; ++k) dq[k] = fmaf(h, v[k], dq[k]);
-    }
-  }
-
-  /* impulse write-back (contact reports + next step's warm start) */
-  for (int ri = 0; ri < nr; ++ri)
-    if (rkind[ri] >= ROW_CN) {
-      int code = ridx[ri];
-      AT(st.ct_lam, (code >> 2) * 12 + (code & 3) * 3 + (rkind[ri] - ROW_CN)) = rlam[ri];
-    }
-
-  /* integrate (vs/dqs: dynamically indexed copies; v/dq themselves stay in registers) */
-  float vs[NV], dqs[NV];
-#pragma unroll
-  for (int k = 0; k < NV; ++k) { vs[k] = v[k]; dqs[k] = dq[k]; }
-  for (int i = 0; i < nd; ++i) {
-    AT(st.qacc, i) = (vs[i] - qd[i]) / dt;
-    q[i] += dqs[i];
-    qd[i] = vs[i];
-    AT(st.q, i) = q[i];
-    AT(st.qd, i) = qd[i];
-  }
-  for (int i = 0; i < m->nb; ++i) {
-    const DBody* b = &m->bodies[i];
-    if (b->kind != MSK_BODY_DYNAMIC) continue;
-    v3 dx = v3_make(dqs[b->vofs + 0], dqs[b->vofs + 1], dqs[b->vofs + 2]);
-    v3 dr = v3_make(dqs[b->vofs + 3], dqs[b->vofs + 4], dqs[b->vofs + 5]);
-    v3 cw = v3_add(load_v3(st.comw, i, N, e), dx);
-    pose T = load_pose(st.bpose, i, N, e);
-    quat qn = quat_normalize(quat_mul(quat_from_rotvec(dr), T.q));
-    T.q = qn;
-    T.p = v3_sub(cw, quat_rotate(qn, b->com));
-    store_pose(st.bpose, i, N, e, T);
-    store_v3(st.blin, i, N, e, v3_make(vs[b->vofs + 0], vs[b->vofs + 1], vs[b->vofs + 2]));
-    store_v3(st.bang, i, N, e, v3_make(vs[b->vofs + 3], vs[b->vofs + 4], vs[b->vofs + 5]));
-  }
-  KinScratch s;
-  kinematics(m, st, N, e, q, qd, &s, true);
 }
 
 /* ---- AoS <-> SoA converters ------------------------------------------------------------------ */
@@ -600,6 +394,7 @@ __global__ void __launch_bounds__(256) k_apply(const DModel* __restrict__ m, DSt
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= N) return;
   const float ox = AT(st.offsets, 0), oy = AT(st.offsets, 1), oz = AT(st.offsets, 2);
+  bool teleported = false; /* a pose or joint position was overwritten: the env's contact cache is stale */
   for (int i = 0; i < m->nb; ++i) {
     const DBody* b = &m->bodies[i];
     const float* r = bf.buf[MSK_BUF_RIGID_BODY_DATA] + ((size_t)e * m->nb + i) * 13;
@@ -615,6 +410,7 @@ __global__ void __launch_bounds__(256) k_apply(const DModel* __restrict__ m, DSt
         T.p = v3_make(r[0] - ox, r[1] - oy, r[2] - oz);
         T.q = quat_normalize(quat_make(r[3], r[4], r[5], r[6]));
         store_pose(st.bpose, i, N, e, T);
+        teleported = true;
       }
       if (b->kind == MSK_BODY_DYNAMIC) {
         store_v3(st.blin, i, N, e, v3_make(r[7], r[8], r[9]));
@@ -626,12 +422,20 @@ __global__ void __launch_bounds__(256) k_apply(const DModel* __restrict__ m, DSt
     for (int j = 0; j < art_ndof[a]; ++j) {
       const int d = art_dof0[a] + j;
       const size_t row = ((size_t)e * m->na + a) * bf.max_dof + j;
-      if (mask & MSK_APPLY_ART_QPOS) AT(st.q, d) = bf.buf[MSK_BUF_ART_QPOS][row];
+      if (mask & MSK_APPLY_ART_QPOS) {
+        const float nq = bf.buf[MSK_BUF_ART_QPOS][row];
+        if (nq != AT(st.q, d)) teleported = true;
+        AT(st.q, d) = nq;
+      }
       if (mask & MSK_APPLY_ART_QVEL) AT(st.qd, d) = bf.buf[MSK_BUF_ART_QVEL][row];
       if (mask & MSK_APPLY_ART_QF) AT(st.qf, d) = bf.buf[MSK_BUF_ART_QF][row];
       if (mask & MSK_APPLY_ART_TARGET_QPOS) AT(st.qt, d) = bf.buf[MSK_BUF_ART_TARGET_QPOS][row];
       if (mask & MSK_APPLY_ART_TARGET_QVEL) AT(st.qdt, d) = bf.buf[MSK_BUF_ART_TARGET_QVEL][row];
     }
+  if (teleported) { /* no warm start across a teleport: replays from a state are reproducible */
+    int* cnts = st.ct_cnt + (size_t)e * m->npp;
+    for (int p = 0; p < m->np; ++p) cnts[p] = 0;
+  }
 }
 
 __global__ void __launch_bounds__(256) k_fetch(const DModel* __restrict__ m, DState st, DBuffers bf, unsigned mask, const int* __restrict__ art_dof0,
@@ -668,22 +472,25 @@ __global__ void __launch_bounds__(256) k_query(const DModel* __restrict__ m, DSt
   const int N = m->N;
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= N) return;
+  const int* cnts = st.ct_cnt + (size_t)e * m->npp;
+  const float* recs = st.ct_rec + (size_t)e * m->npp * MSK_CT_REC;
   for (int qi = 0; qi < nq; ++qi) {
     const int x = qpairs[2 * qi], y = qpairs[2 * qi + 1];
     v3 sum = v3_make(0, 0, 0);
     for (int p = 0; p < m->np; ++p) {
-      const int ba = m->shapes[m->pairs[p].sa].body, bb = m->shapes[m->pairs[p].sb].body;
+      const int ba = m->pinfo[p].ba, bb = m->pinfo[p].bb;
       float sgn;
       if (ba == x && bb == y) sgn = 1.0f;
       else if (ba == y && bb == x) sgn = -1.0f;
       else continue;
-      const int cnt = AT(st.ct_cnt, p);
+      const int cnt = cnts[p];
       if (cnt == 0) continue;
-      v3 n = v3_make(AT(st.ct_n, p * 3 + 0), AT(st.ct_n, p * 3 + 1), AT(st.ct_n, p * 3 + 2));
+      const float* rec = recs + (size_t)p * MSK_CT_REC;
+      v3 n = v3_make(rec[0], rec[1], rec[2]);
       v3 t1, t2;
       msk_tangents(n, &t1, &t2);
       for (int k = 0; k < cnt; ++k) {
-        float l0 = AT(st.ct_lam, p * 12 + k * 3 + 0), l1 = AT(st.ct_lam, p * 12 + k * 3 + 1), l2 = AT(st.ct_lam, p * 12 + k * 3 + 2);
+        float l0 = rec[20 + k * 3 + 0], l1 = rec[20 + k * 3 + 1], l2 = rec[20 + k * 3 + 2];
         v3 imp = v3_madd(v3_madd(v3_scale(n, l0), t1, l1), t2, l2);
         sum = v3_madd(sum, imp, sgn);
       }

@@ -32,6 +32,7 @@ struct DShape {
 
 struct DTendon { int dof_a, dof_b; float ca, cb, rest, K, D; };
 struct DPair { int sa, sb; };
+struct DPairInfo { int ba, bb; float mu; int pad; }; /* bodies of the two shapes, friction of the pair */
 
 struct DModel {
   msk_config cfg;
@@ -41,9 +42,22 @@ struct DModel {
   DTendon tendons[MSK_MAX_TENDONS];
   DPair pairs[MSK_MAX_PAIRS];
   v3 verts[MSK_MAX_SHAPES * 16]; /* hull vertex pool (<= 1024 vertices per template) */
+  /* lane-group solver tables: one lane per generalized coordinate k (msk_solve.h) */
+  int G;                               /* lanes per env = nv padded to 16 or 32                  */
+  int npp;                             /* np padded to a multiple of G (contact slot stride)     */
+  unsigned long long coord_moves[MSK_MAX_NV]; /* bit b: coordinate k moves body b                */
+  int coord_body[MSK_MAX_NV];          /* free body whose first coordinate is k, else -1         */
+  float dof_lo[MSK_MAX_DOF], dof_hi[MSK_MAX_DOF];
+  DPairInfo pinfo[MSK_MAX_PAIRS];
 };
 
 #define MSK_MAX_ROWS (2 * MSK_MAX_DOF + 3 * MSK_MAX_CONTACTS)
+#define MSK_ROWS_LDS 64                        /* solver rows per env in the workgroup's LDS row pool
+                                                  (shared: one env may use its neighbours' share); rows
+                                                  that do not fit spill to HBM (st.ov_*)          */
+/* contact slot of one candidate pair of one env: 32 floats
+ *   [0..2] normal  [4+3k..] point k  [16+k] separation k  [20+3k+a] impulse k (normal, t1, t2) */
+#define MSK_CT_REC 32
 
 /* All device arrays of one context.  Sizes are in floats / ints per env times N. */
 struct DState {
@@ -52,20 +66,18 @@ struct DState {
   float *bpose;                                /* [nb*7][N]  px py pz qw qx qy qz */
   float *blin, *bang;                          /* [nb*3][N]  COM linear / angular velocity */
   /* per-step scratch */
-  float *S;                                    /* [nd*6][N]  joint motion subspaces */
   float *comw;                                 /* [nb*3][N] */
-  float *Minv;                                 /* [nd*nd][N] */
-  float *Iwinv;                                /* [nb*6][N]  (dynamic actors only) */
-  float *vfree;                                /* [nv][N] */
-  /* contacts, one slot of <= 4 points per candidate pair (persistent: warm starting) */
-  int *ct_cnt;                                 /* [np][N] */
-  float *ct_pos;                               /* [np*12][N] */
-  float *ct_n;                                 /* [np*3][N] */
-  float *ct_sep;                               /* [np*4][N] */
-  float *ct_lam;                               /* [np*12][N] */
-  /* solver rows */
-  float *rw_J, *rw_Y;                          /* [MSK_MAX_ROWS*nv][N] */
-  float *rw_d;                                 /* [MSK_MAX_ROWS][N] */
+  /* env-major tables for the lane-group solver (lane k of an env reads a contiguous row) */
+  float *Scol;                                 /* [N][G][8]  motion subspace column of coordinate k (a, l, pad) */
+  float *W;                                    /* [N][G][G]  block-diagonal inverse mass matrix, zero padded    */
+  float *vfree;                                /* [N][G]     unconstrained velocity                             */
+  /* contacts, env-major, one slot of <= 4 points per candidate pair (persistent: warm starting) */
+  int *ct_cnt;                                 /* [N][npp] */
+  float *ct_rec;                               /* [N][npp][MSK_CT_REC] */
+  /* solver rows that did not fit the LDS pool */
+  float2 *ov_jy;                               /* [N][MSK_MAX_ROWS][G] */
+  float4 *ov_rs;                               /* [N][MSK_MAX_ROWS] */
+  float *ov_lam;                               /* [N][MSK_MAX_ROWS] */
   int *env_ncontacts;                          /* [N] */
   int *env_overflow;                           /* [1] */
   float *offsets;                              /* [3][N] */

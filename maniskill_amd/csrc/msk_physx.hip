@@ -31,7 +31,7 @@ struct msk_ctx {
   pose init_pose[MSK_MAX_BODIES];
   pose pending_root;
   int nverts_total;
-  int nv_pad;            /* generalized velocity size padded to the k_solve<NV> instantiation */
+  bool kin_dirty;        /* link frames in st.bpose are older than (q, qd): run k_kinematics before reading them */
   uint32_t groups[MSK_MAX_SHAPES][4]; /* collision groups: only the static pair filter needs them */
   std::vector<void*> allocs;
   std::vector<HostQuery> queries;
@@ -336,6 +336,29 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
         m.np++;
       }
   m.N = num_envs;
+  /* lane-group solver tables */
+  m.G = (m.nv <= 16) ? 16 : 32;
+  m.npp = ((m.np + m.G - 1) / m.G) * m.G;
+  if (m.npp == 0) m.npp = m.G;
+  for (int k = 0; k < MSK_MAX_NV; ++k) { m.coord_moves[k] = 0; m.coord_body[k] = -1; }
+  for (int i = 0; i < m.nb; ++i) {
+    const DBody* b = &m.bodies[i];
+    if (b->kind == MSK_BODY_LINK) {
+      if (b->dof >= 0) { m.dof_lo[b->dof] = b->lim_lo; m.dof_hi[b->dof] = b->lim_hi; }
+      for (int j = i; j >= 0; j = m.bodies[j].parent)
+        if (m.bodies[j].dof >= 0) m.coord_moves[m.bodies[j].dof] |= 1ull << i;
+    } else if (b->kind == MSK_BODY_DYNAMIC) {
+      for (int a = 0; a < 6; ++a) m.coord_moves[b->vofs + a] = 1ull << i;
+      m.coord_body[b->vofs] = i;
+    }
+  }
+  for (int p = 0; p < m.np; ++p) {
+    const DShape* A = &m.shapes[m.pairs[p].sa];
+    const DShape* B = &m.shapes[m.pairs[p].sb];
+    m.pinfo[p].ba = A->body; m.pinfo[p].bb = B->body;
+    m.pinfo[p].mu = 0.5f * (A->df + B->df);
+    m.pinfo[p].pad = 0;
+  }
   const size_t N = (size_t)num_envs;
   ALLOC(c->d_model, 1);
   HIP_TRY(hipMemcpy(c->d_model, &m, sizeof(DModel), hipMemcpyHostToDevice));
@@ -344,14 +367,11 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   ALLOC(st.q, nd * N); ALLOC(st.qd, nd * N); ALLOC(st.qacc, nd * N); ALLOC(st.qf, nd * N);
   ALLOC(st.qt, nd * N); ALLOC(st.qdt, nd * N);
   ALLOC(st.bpose, (size_t)m.nb * 7 * N); ALLOC(st.blin, (size_t)m.nb * 3 * N); ALLOC(st.bang, (size_t)m.nb * 3 * N);
-  ALLOC(st.S, nd * 6 * N); ALLOC(st.comw, (size_t)m.nb * 3 * N); ALLOC(st.Minv, nd * nd * N);
-  ALLOC(st.Iwinv, (size_t)m.nb * 6 * N); ALLOC(st.vfree, (size_t)m.nv * N);
-  const size_t np = m.np > 0 ? m.np : 1;
-  ALLOC(st.ct_cnt, np * N); ALLOC(st.ct_pos, np * 12 * N); ALLOC(st.ct_n, np * 3 * N);
-  ALLOC(st.ct_sep, np * 4 * N); ALLOC(st.ct_lam, np * 12 * N);
-  c->nv_pad = (m.nv <= 8) ? 8 : (m.nv <= 16) ? 16 : (m.nv <= 24) ? 24 : 32;
-  ALLOC(st.rw_J, (size_t)MSK_MAX_ROWS * c->nv_pad * N); ALLOC(st.rw_Y, (size_t)MSK_MAX_ROWS * c->nv_pad * N);
-  ALLOC(st.rw_d, (size_t)MSK_MAX_ROWS * N);
+  ALLOC(st.comw, (size_t)m.nb * 3 * N);
+  const size_t G = (size_t)m.G;
+  ALLOC(st.Scol, N * G * 8); ALLOC(st.W, N * G * G); ALLOC(st.vfree, N * G);
+  ALLOC(st.ct_cnt, N * m.npp); ALLOC(st.ct_rec, N * m.npp * MSK_CT_REC);
+  ALLOC(st.ov_jy, N * MSK_MAX_ROWS * G); ALLOC(st.ov_rs, N * MSK_MAX_ROWS); ALLOC(st.ov_lam, N * MSK_MAX_ROWS);
   ALLOC(st.env_ncontacts, N); ALLOC(st.env_overflow, 1);
   ALLOC(st.offsets, 3 * N);
   ALLOC(c->d_art_dof0, 8); ALLOC(c->d_art_ndof, 8);
@@ -373,6 +393,7 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   }
   HIP_TRY(hipMemcpy(st.bpose, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
   c->finalized = true;
+  c->kin_dirty = false;
   hipLaunchKernelGGL(k_kinematics, dim3((num_envs + 63) / 64), dim3(64), 0, 0, c->d_model, c->st);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
@@ -409,6 +430,10 @@ MSK_API int msk_apply(msk_ctx* c, uint32_t mask, void* stream) {
 MSK_API int msk_fetch(msk_ctx* c, uint32_t mask, void* stream) {
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "fetch before finalize");
   const int N = c->model.N;
+  if (c->kin_dirty && (mask & MSK_FETCH_RIGID_DATA)) { /* link frames of the post-step (q, qd) */
+    hipLaunchKernelGGL(k_kinematics, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, c->d_model, c->st);
+    c->kin_dirty = false;
+  }
   hipLaunchKernelGGL(k_fetch, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->bufs, mask,
                      c->d_art_dof0, c->d_art_ndof);
   HIP_TRY(hipGetLastError());
@@ -419,6 +444,7 @@ MSK_API int msk_update_kinematics(msk_ctx* c, void* stream) {
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "update_kinematics before finalize");
   const int N = c->model.N;
   hipLaunchKernelGGL(k_kinematics, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, c->d_model, c->st);
+  c->kin_dirty = false;
   HIP_TRY(hipGetLastError());
   return MSK_OK;
 }
@@ -435,11 +461,12 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
   if (timed) hipEventRecord(ev[1], s);
   if (c->model.np > 0) hipLaunchKernelGGL(k_collide, dim3(nblk, c->model.np), dim3(64), 0, s, c->d_model, c->st);
   if (timed) hipEventRecord(ev[2], s);
-  switch (c->nv_pad) {
-    case 8: hipLaunchKernelGGL(k_solve<8>, dim3(nblk), dim3(64), 0, s, c->d_model, c->st); break;
-    case 16: hipLaunchKernelGGL(k_solve<16>, dim3(nblk), dim3(64), 0, s, c->d_model, c->st); break;
-    case 24: hipLaunchKernelGGL(k_solve<24>, dim3(nblk), dim3(64), 0, s, c->d_model, c->st); break;
-    default: hipLaunchKernelGGL(k_solve<32>, dim3(nblk), dim3(64), 0, s, c->d_model, c->st); break;
+  {
+    const int G = c->model.G;
+    const int nsb = (N * G + 63) / 64;
+    if (G == 16) hipLaunchKernelGGL(k_solve<16>, dim3(nsb), dim3(64), 0, s, c->d_model, c->st);
+    else hipLaunchKernelGGL(k_solve<32>, dim3(nsb), dim3(64), 0, s, c->d_model, c->st);
+    c->kin_dirty = true;
   }
   if (timed) { hipEventRecord(ev[3], s); c->t_n++; }
   HIP_TRY(hipGetLastError());
@@ -517,23 +544,26 @@ MSK_API int msk_get_sizes(msk_ctx* c, int32_t out[8]) {
   return MSK_OK;
 }
 
+MSK_API int msk_get_env_contact_counts(msk_ctx* c, int32_t* out) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "get_env_contact_counts before finalize");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, c->st.env_ncontacts, sizeof(int) * (size_t)c->model.N, hipMemcpyDeviceToHost));
+  return MSK_OK;
+}
+
 MSK_API int msk_get_contacts(msk_ctx* c, int env, int32_t* ids, float* vals, int max_points) {
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "get_contacts before finalize");
   const DModel& m = c->model;
   if (env < 0 || env >= m.N) return fail(c, MSK_ERR_INVALID, "bad env");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipDeviceSynchronize());
-  const size_t N = (size_t)m.N;
   const int np = m.np;
-  std::vector<int> cnt(np > 0 ? np : 1);
-  std::vector<float> pos((size_t)np * 12 + 1), nrm((size_t)np * 3 + 1), sep((size_t)np * 4 + 1), lam((size_t)np * 12 + 1);
   if (np == 0) return 0;
-  const size_t pitch = N * sizeof(float);
-  HIP_TRY(hipMemcpy2D(cnt.data(), sizeof(int), c->st.ct_cnt + env, pitch, sizeof(int), np, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy2D(pos.data(), sizeof(float), c->st.ct_pos + env, pitch, sizeof(float), (size_t)np * 12, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy2D(nrm.data(), sizeof(float), c->st.ct_n + env, pitch, sizeof(float), (size_t)np * 3, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy2D(sep.data(), sizeof(float), c->st.ct_sep + env, pitch, sizeof(float), (size_t)np * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy2D(lam.data(), sizeof(float), c->st.ct_lam + env, pitch, sizeof(float), (size_t)np * 12, hipMemcpyDeviceToHost));
+  std::vector<int> cnt(m.npp);
+  std::vector<float> rec((size_t)m.npp * MSK_CT_REC);
+  HIP_TRY(hipMemcpy(cnt.data(), c->st.ct_cnt + (size_t)env * m.npp, sizeof(int) * m.npp, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(rec.data(), c->st.ct_rec + (size_t)env * m.npp * MSK_CT_REC, sizeof(float) * rec.size(), hipMemcpyDeviceToHost));
   int total = 0;
   for (int p = 0; p < np; ++p)
     for (int k = 0; k < cnt[p]; ++k) {
@@ -542,9 +572,10 @@ MSK_API int msk_get_contacts(msk_ctx* c, int env, int32_t* ids, float* vals, int
         ids[3 * total] = sa; ids[3 * total + 1] = sb;
         ids[3 * total + 2] = m.shapes[sa].body * 256 + (m.shapes[sb].body & 255);
         float* v = vals + 8 * total;
-        v[0] = pos[p * 12 + k * 3 + 0]; v[1] = pos[p * 12 + k * 3 + 1]; v[2] = pos[p * 12 + k * 3 + 2];
-        v[3] = nrm[p * 3 + 0]; v[4] = nrm[p * 3 + 1]; v[5] = nrm[p * 3 + 2];
-        v[6] = sep[p * 4 + k]; v[7] = lam[p * 12 + k * 3 + 0];
+        const float* r = &rec[(size_t)p * MSK_CT_REC];
+        v[0] = r[4 + k * 3 + 0]; v[1] = r[4 + k * 3 + 1]; v[2] = r[4 + k * 3 + 2];
+        v[3] = r[0]; v[4] = r[1]; v[5] = r[2];
+        v[6] = r[16 + k]; v[7] = r[20 + k * 3 + 0];
       }
       total++;
     }

@@ -176,7 +176,7 @@ class CudaArrayHandle:
             self._t = torch.from_numpy(arr)
         else:
             self._t = torch.as_tensor(_DevicePointer(ptr, self.shape), device=device)
-            assert self._t.data_ptr() == ptr, "zero-copy wrap of the device buffer failed"
+            assert self._t.numel() == 0 or self._t.data_ptr() == ptr, "zero-copy wrap of the device buffer failed"
 
     def torch(self) -> torch.Tensor:
         return self._t
@@ -369,6 +369,13 @@ class PhysxGpuSystem:
         n = min(n, max_points)
         return (np.array(ids[: 3 * n], dtype=np.int32).reshape(n, 3),
                 np.array(vals[: 8 * n], dtype=np.float32).reshape(n, 8))
+
+    def get_env_contact_counts(self) -> np.ndarray:
+        """(num_envs,) int32: contact points solved per env in the last step (synchronises)."""
+        out = np.zeros(self.num_envs, dtype=np.int32)
+        self.lib.check(self.ctx, self.lib.get_env_contact_counts(self.ctx, out.ctypes.data_as(C.POINTER(C.c_int32))),
+                       "get_env_contact_counts")
+        return out
 
     def get_overflow(self) -> int:
         """1 if any env exceeded its contact capacity since gpu_init (synchronises)."""

@@ -270,6 +270,7 @@ ORC_EXPORT int orc_apply(orc_ctx* c, uint32_t mask, void* stream) {
   for (int e = 0; e < c->num_envs; ++e) {
     orc_env* env = &c->envs[e];
     const float* off = c->offsets + 3 * e;
+    int teleported = 0; /* a pose or joint position was overwritten: the env's contact cache is stale */
     for (int i = 0; i < c->nb; ++i) {
       const orc_body* b = &c->bodies[i];
       const float* r = c->buf[MSK_BUF_RIGID_BODY_DATA] + ((size_t)e * c->nb + i) * 13;
@@ -283,6 +284,7 @@ ORC_EXPORT int orc_apply(orc_ctx* c, uint32_t mask, void* stream) {
         if (!same) {
           env->bpose[i].p = v3_make(r[0] - off[0], r[1] - off[1], r[2] - off[2]);
           env->bpose[i].q = quat_normalize(quat_make(r[3], r[4], r[5], r[6]));
+          teleported = 1;
         }
         if (b->kind == MSK_BODY_DYNAMIC) {
           env->blin[i] = v3_make(r[7], r[8], r[9]);
@@ -293,12 +295,17 @@ ORC_EXPORT int orc_apply(orc_ctx* c, uint32_t mask, void* stream) {
     for (int a = 0; a < c->na; ++a)
       for (int j = 0; j < c->art_ndof[a]; ++j) {
         int d = c->art_dof0[a] + j;
-        if (mask & MSK_APPLY_ART_QPOS) env->q[d] = art_row(c, MSK_BUF_ART_QPOS, e, a)[j];
+        if (mask & MSK_APPLY_ART_QPOS) {
+          const float nq = art_row(c, MSK_BUF_ART_QPOS, e, a)[j];
+          if (nq != env->q[d]) teleported = 1;
+          env->q[d] = nq;
+        }
         if (mask & MSK_APPLY_ART_QVEL) env->qd[d] = art_row(c, MSK_BUF_ART_QVEL, e, a)[j];
         if (mask & MSK_APPLY_ART_QF) env->qf[d] = art_row(c, MSK_BUF_ART_QF, e, a)[j];
         if (mask & MSK_APPLY_ART_TARGET_QPOS) env->qt[d] = art_row(c, MSK_BUF_ART_TARGET_QPOS, e, a)[j];
         if (mask & MSK_APPLY_ART_TARGET_QVEL) env->qdt[d] = art_row(c, MSK_BUF_ART_TARGET_QVEL, e, a)[j];
       }
+    if (teleported) env->ncontacts = 0; /* no warm start across a teleport: replays from a state are reproducible */
   }
   return MSK_OK;
 }
@@ -420,5 +427,11 @@ ORC_EXPORT int orc_timing_enable(orc_ctx* c, int max_steps) { (void)c; (void)max
 ORC_EXPORT int orc_timing_read(orc_ctx* c, int slot, double* total_ms, int32_t* launches) {
   (void)c; (void)slot;
   *total_ms = 0.0; *launches = 0;
+  return MSK_OK;
+}
+
+/* msk_get_env_contact_counts */
+ORC_EXPORT int orc_get_env_contact_counts(orc_ctx* c, int32_t* out) {
+  for (int e = 0; e < c->num_envs; ++e) out[e] = c->envs[e].ncontacts;
   return MSK_OK;
 }

@@ -13,11 +13,16 @@
  *                      a drive whose predicted force exceeds its limit is re-solved as a
  *                      constant force at the limit
  *   3. collision       orc_collide.c over the static candidate pair table
- *   4. rows            joint limits, contact normal + 2 friction rows per point, in
- *                      generalized coordinates, with response Y = A^-1 J^T
+ *   4. rows            joint limits (only within ORC_LIMIT_DISTANCE of the limit, the joint
+ *                      counterpart of contact_offset), contact normal + 2 friction rows per
+ *                      point, in generalized coordinates: J_k = (+-) S_k . F for every coordinate k
+ *                      that moves the body (S_k = motion subspace column of coordinate k, free
+ *                      bodies included), response Y = W J^T with W = block-diag(A^-1, 1/m, Iw^-1)
  *   5. TGS             position iterations = sub-steps of dt/Np: one Gauss-Seidel sweep
  *                      each, errors re-linearised from the accumulated displacement dq;
- *                      then velocity iterations without penetration bias
+ *                      then velocity iterations without penetration bias.  Dot products over
+ *                      the generalized coordinates are balanced pairwise trees over the padded
+ *                      width (16 or 32): the order a 16/32-lane butterfly reduction produces
  *   6. integrate       q += dq, free bodies x += dq_lin, R = exp(dq_ang) R; kinematics
  */
 #include "orc_sim.h"
@@ -27,13 +32,16 @@
 #define ORC_MAX_DEPEN_VEL 3.0f   /* m/s cap on the penetration-recovery bias            */
 #define ORC_WARM_DIST 5.0e-3f    /* contact matching radius for warm starting             */
 #define ORC_WARM_FACTOR 0.9f     /* fraction of last step's impulses applied up front     */
+#define ORC_LIMIT_DISTANCE 0.1f  /* a joint-limit row exists while q is within this of the limit */
 
 enum { ROW_LIMLO, ROW_LIMHI, ROW_CN, ROW_CT1, ROW_CT2 };
 
 typedef struct {
   int kind, idx;
   float J[MSK_MAX_NV], Y[MSK_MAX_NV];
-  float d;      /* J . Y */
+  float c0;     /* position-level error at the start of the step (separation / distance to the limit) */
+  float rinv;   /* 1 / (J . Y) */
+  float mu;
   float lam;    /* accumulated impulse */
 } orc_row;
 
@@ -45,6 +53,12 @@ typedef struct {
   float Minv[MSK_MAX_DOF][MSK_MAX_DOF];
   float Iwinv[MSK_MAX_BODIES][6];
   float vfree[MSK_MAX_NV];
+  /* per generalized coordinate k: motion subspace column about the env origin, row k of the
+   * block-diagonal inverse mass matrix W (zero padded to npad), bodies moved by k (bit mask) */
+  sv6 Scol[MSK_MAX_NV];
+  float W[MSK_MAX_NV][MSK_MAX_NV];
+  uint64_t moves[MSK_MAX_NV];
+  int npad;
 } orc_scratch;
 
 /* ---- 1. kinematics ---------------------------------------------------------------- */
@@ -289,46 +303,65 @@ static void collide(const orc_ctx* c, orc_env* e) {
 }
 
 /* ---- 4. rows ---------------------------------------------------------------------- */
-/* J += sgn * (generalized velocity -> velocity of the body-fixed point p along dir) */
-static void jac_point(const orc_ctx* c, const orc_scratch* s, int body, v3 p, v3 dir, float sgn, float* J) {
-  if (body < 0) return;
-  const orc_body* b = &c->bodies[body];
-  if (b->kind == MSK_BODY_LINK) {
-    sv6 F = {v3_cross(p, dir), dir};
-    int j = body;
-    while (j >= 0) {
-      const orc_body* bj = &c->bodies[j];
-      if (bj->dof >= 0) J[bj->dof] = fmaf(sgn, sv6_dot(s->S[j], F), J[bj->dof]);
-      j = bj->parent;
-    }
-  } else if (b->kind == MSK_BODY_DYNAMIC) {
-    v3 r = v3_cross(v3_sub(p, s->comw[body]), dir);
-    J[b->vofs + 0] += sgn * dir.x; J[b->vofs + 1] += sgn * dir.y; J[b->vofs + 2] += sgn * dir.z;
-    J[b->vofs + 3] += sgn * r.x; J[b->vofs + 4] += sgn * r.y; J[b->vofs + 5] += sgn * r.z;
-  }
+/* balanced pairwise sum of a[i]*b[i], i < npad (npad = 16 or 32; entries >= nv are zero) */
+static float tree_dot(const float* a, const float* b, int nv, int npad) {
+  float t[MSK_MAX_NV];
+  for (int i = 0; i < npad; ++i) t[i] = (i < nv) ? a[i] * b[i] : 0.0f;
+  for (int w = npad; w > 1; w >>= 1)
+    for (int i = 0; i < w / 2; ++i) t[i] = t[2 * i] + t[2 * i + 1];
+  return t[0];
 }
 
-static void apply_minv(const orc_ctx* c, const orc_scratch* s, orc_row* r) {
-  const int nd = c->ndof;
-  for (int i = 0; i < nd; ++i) {
-    float a = 0.0f;
-    for (int k = 0; k < nd; ++k) a = fmaf(s->Minv[i][k], r->J[k], a);
-    r->Y[i] = a;
+/* per-coordinate tables: Scol, W, moves */
+static void coordinate_tables(const orc_ctx* c, orc_scratch* s) {
+  const int nd = c->ndof, nv = c->nv;
+  s->npad = (nv <= 16) ? 16 : 32;
+  for (int k = 0; k < nv; ++k) {
+    s->Scol[k] = sv6_zero();
+    s->moves[k] = 0;
+    for (int j = 0; j < MSK_MAX_NV; ++j) s->W[k][j] = 0.0f;
   }
   for (int i = 0; i < c->nb; ++i) {
     const orc_body* b = &c->bodies[i];
-    if (b->kind != MSK_BODY_DYNAMIC) continue;
-    float im = 1.0f / b->mass;
-    r->Y[b->vofs + 0] = r->J[b->vofs + 0] * im;
-    r->Y[b->vofs + 1] = r->J[b->vofs + 1] * im;
-    r->Y[b->vofs + 2] = r->J[b->vofs + 2] * im;
-    v3 ja = v3_make(r->J[b->vofs + 3], r->J[b->vofs + 4], r->J[b->vofs + 5]);
-    v3 ya = sym6_mulv(s->Iwinv[i], ja);
-    r->Y[b->vofs + 3] = ya.x; r->Y[b->vofs + 4] = ya.y; r->Y[b->vofs + 5] = ya.z;
+    if (b->kind == MSK_BODY_LINK) {
+      if (b->dof >= 0) s->Scol[b->dof] = s->S[i];
+      for (int j = i; j >= 0; j = c->bodies[j].parent)
+        if (c->bodies[j].dof >= 0) s->moves[c->bodies[j].dof] |= (uint64_t)1 << i;
+    } else if (b->kind == MSK_BODY_DYNAMIC) {
+      const v3 ex[3] = {v3_make(1, 0, 0), v3_make(0, 1, 0), v3_make(0, 0, 1)};
+      const float im = 1.0f / b->mass;
+      const float* Ii = s->Iwinv[i];
+      const float Im[3][3] = {{Ii[0], Ii[3], Ii[4]}, {Ii[3], Ii[1], Ii[5]}, {Ii[4], Ii[5], Ii[2]}};
+      for (int a = 0; a < 3; ++a) {
+        s->Scol[b->vofs + a].l = ex[a];                          /* v_com */
+        s->Scol[b->vofs + 3 + a].a = ex[a];                      /* omega: point velocity = w x (p - c) */
+        s->Scol[b->vofs + 3 + a].l = v3_cross(s->comw[i], ex[a]);
+        s->moves[b->vofs + a] = s->moves[b->vofs + 3 + a] = (uint64_t)1 << i;
+        s->W[b->vofs + a][b->vofs + a] = im;
+        for (int j = 0; j < 3; ++j) s->W[b->vofs + 3 + a][b->vofs + 3 + j] = Im[a][j];
+      }
+    }
   }
-  float d = 0.0f;
-  for (int k = 0; k < c->nv; ++k) d = fmaf(r->J[k], r->Y[k], d);
-  r->d = d;
+  for (int i = 0; i < nd; ++i)
+    for (int j = 0; j < nd; ++j) s->W[i][j] = s->Minv[i][j];
+}
+
+/* J[k] += sgn * S_k . F for every coordinate k that moves `body`; F = [p x dir; dir] */
+static void jac_point(const orc_ctx* c, const orc_scratch* s, int body, v3 p, v3 dir, float sgn, float* J) {
+  if (body < 0) return;
+  sv6 F = {v3_cross(p, dir), dir};
+  for (int k = 0; k < c->nv; ++k)
+    if ((s->moves[k] >> body) & 1) J[k] = fmaf(sgn, sv6_dot(s->Scol[k], F), J[k]);
+}
+
+/* Y = W J^T (full padded width, in coordinate order), rinv = 1 / (J . Y) */
+static void finish_row(const orc_ctx* c, const orc_scratch* s, orc_row* r) {
+  for (int i = 0; i < c->nv; ++i) {
+    float a = 0.0f;
+    for (int k = 0; k < s->npad; ++k) a = fmaf(s->W[i][k], (k < c->nv) ? r->J[k] : 0.0f, a);
+    r->Y[i] = a;
+  }
+  r->rinv = 1.0f / tree_dot(r->J, r->Y, c->nv, s->npad);
 }
 
 /* ---- 5./6. solve and integrate ----------------------------------------------------- */
@@ -339,10 +372,15 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
   const float dt = c->cfg.timestep;
   const int Np = c->cfg.solver_position_iterations, Nv = c->cfg.solver_velocity_iterations;
   const float h = dt / (float)Np;
+  const float inv_h = 1.0f / h, inv_dt = 1.0f / dt, beta_dt = ORC_PEN_BETA / dt;
 
   kinematics(c, e, &s);
   dynamics(c, e, &s);
   collide(c, e);
+  coordinate_tables(c, &s);
+
+  float v[MSK_MAX_NV], dq[MSK_MAX_NV];
+  for (int k = 0; k < nv; ++k) { v[k] = s.vfree[k]; dq[k] = 0.0f; }
 
   int nr = 0;
   for (int i = 0; i < c->nb; ++i) {
@@ -350,12 +388,15 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
     if (b->kind != MSK_BODY_LINK || b->dof < 0) continue;
     if (b->lim_lo < -1e30f && b->lim_hi > 1e30f) continue;
     for (int kind = ROW_LIMLO; kind <= ROW_LIMHI; ++kind) {
+      const float c0 = (kind == ROW_LIMLO) ? (e->q[b->dof] - b->lim_lo) : (b->lim_hi - e->q[b->dof]);
+      if (!(c0 < ORC_LIMIT_DISTANCE)) continue;
       orc_row* r = &rows[nr++];
       memset(r, 0, sizeof(*r));
       r->kind = kind;
       r->idx = i;
+      r->c0 = c0;
       r->J[b->dof] = (kind == ROW_LIMHI) ? -1.0f : 1.0f;
-      apply_minv(c, &s, r);
+      finish_row(c, &s, r);
     }
   }
   for (int k = 0; k < e->ncontacts; ++k) {
@@ -367,60 +408,40 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
       memset(r, 0, sizeof(*r));
       r->kind = ROW_CN + a;
       r->idx = k;
+      r->c0 = ct->sep;
+      r->mu = ct->mu;
       jac_point(c, &s, ct->ba, ct->pos, dirs[a], 1.0f, r->J);
       jac_point(c, &s, ct->bb, ct->pos, dirs[a], -1.0f, r->J);
-      apply_minv(c, &s, r);
+      finish_row(c, &s, r);
       r->lam = ct->lam[a];
+      if (r->lam != 0.0f) /* warm start */
+        for (int kk = 0; kk < nv; ++kk) v[kk] = fmaf(r->Y[kk], r->lam, v[kk]);
     }
   }
 
-  float v[MSK_MAX_NV], dq[MSK_MAX_NV];
-  for (int k = 0; k < nv; ++k) { v[k] = s.vfree[k]; dq[k] = 0.0f; }
-  for (int ri = 0; ri < nr; ++ri)
-    if (rows[ri].lam != 0.0f)
-      for (int k = 0; k < nv; ++k) v[k] = fmaf(rows[ri].Y[k], rows[ri].lam, v[k]);
-
   for (int it = 0; it < Np + Nv; ++it) {
     const int posit = it < Np;
+    float lam_n = 0.0f; /* impulse of the most recent normal row: friction cone of the two rows after it */
     for (int ri = 0; ri < nr; ++ri) {
       orc_row* r = &rows[ri];
-      float jv = 0.0f, jdq = 0.0f;
-      for (int k = 0; k < nv; ++k) { jv = fmaf(r->J[k], v[k], jv); jdq = fmaf(r->J[k], dq[k], jdq); }
-      float dl = 0.0f;
-      switch (r->kind) {
-        case ROW_LIMLO:
-        case ROW_LIMHI:
-        case ROW_CN: {
-          float c0;
-          if (r->kind == ROW_CN) c0 = e->contacts[r->idx].sep;
-          else {
-            const orc_body* b = &c->bodies[r->idx];
-            c0 = (r->kind == ROW_LIMLO) ? (e->q[b->dof] - b->lim_lo) : (b->lim_hi - e->q[b->dof]);
-          }
-          float cur = c0 + jdq;
-          float bias;
-          if (posit) bias = (cur > 0.0f) ? cur / h : fmaxf(cur * (ORC_PEN_BETA / dt), -ORC_MAX_DEPEN_VEL);
-          else bias = (cur > 0.0f) ? cur / dt : 0.0f;
-          dl = -(jv + bias) / r->d;
-          float nl = fmaxf(r->lam + dl, 0.0f);
-          dl = nl - r->lam;
-          r->lam = nl;
-          break;
-        }
-        default: { /* friction */
-          const orc_contact* ct = &e->contacts[r->idx];
-          const orc_row* rn = &rows[ri - (r->kind - ROW_CN)];
-          float bias = posit ? jdq / h : 0.0f;
-          dl = -(jv + bias) / r->d;
-          float lim = ct->mu * rn->lam;
-          float nl = fminf(fmaxf(r->lam + dl, -lim), lim);
-          dl = nl - r->lam;
-          r->lam = nl;
-          break;
-        }
+      const float jv = tree_dot(r->J, v, nv, s.npad), jdq = tree_dot(r->J, dq, nv, s.npad);
+      /* new impulse = clamp(lam - (jv + bias) / (J.Y)); the bias part does not depend on v and is folded first */
+      float bias, lo, hi;
+      if (r->kind <= ROW_CN) {
+        const float cur = r->c0 + jdq;
+        if (posit) bias = (cur > 0.0f) ? cur * inv_h : fmaxf(cur * beta_dt, -ORC_MAX_DEPEN_VEL);
+        else bias = (cur > 0.0f) ? cur * inv_dt : 0.0f;
+        lo = 0.0f; hi = INFINITY;
+      } else { /* friction */
+        bias = posit ? jdq * inv_h : 0.0f;
+        hi = r->mu * lam_n; lo = -hi;
       }
-      if (dl != 0.0f)
-        for (int k = 0; k < nv; ++k) v[k] = fmaf(r->Y[k], dl, v[k]);
+      const float t0 = r->lam - bias * r->rinv;
+      const float nl = fminf(fmaxf(fmaf(-jv, r->rinv, t0), lo), hi);
+      if (r->kind <= ROW_CN) lam_n = nl;
+      const float dl = nl - r->lam;
+      r->lam = nl;
+      for (int k = 0; k < nv; ++k) v[k] = fmaf(r->Y[k], dl, v[k]);
     }
     if (posit)
       for (int k = 0; k < nv; ++k) dq[k] = fmaf(h, v[k], dq[k]);

@@ -162,8 +162,10 @@ def test_full_size_properties_4096():
         oh, *_ = half.step(a[n // 2:])
     assert torch.isfinite(o).all()
     assert torch.equal(o[n // 2:], oh), "env results depend on the batch they run in"
-    # state round trip (reference tests/test_envs.py:196-212): two replays from the same state agree
+    # state round trip (reference tests/test_envs.py:196-212): replays from a saved state are reproducible
+    # (a teleport drops the env's contact warm-start cache, so nothing but the state carries over)
     st = env.get_state().clone()
+    cont = [env.step(a)[0].clone() for a in acts[6:9]]
 
     def replay():
         env.set_state(st)
@@ -171,7 +173,11 @@ def test_full_size_properties_4096():
         return [env.step(a)[0].clone() for a in acts[6:9]]
 
     r1, r2 = replay(), replay()
-    assert all(_close(x.cpu().numpy(), y.cpu().numpy()) for x, y in zip(r1, r2))
+    assert all(torch.equal(x, y) for x, y in zip(r1, r2))
+    # against the original continuation only the first step is compared: set_state re-derives the internal
+    # pose from the offset frame (1 ulp) and the continuation kept its warm-start cache
+    dev = (r1[0] - cont[0]).abs().max(dim=1)[0]
+    assert (dev < 1e-2).float().mean().item() > 0.95
     # partial reset leaves the other envs bit-identical
     before = env.get_state().clone()
     idx = torch.arange(0, n, 3, device=DEV)
