@@ -1,0 +1,426 @@
+/*
+ * msk_dynamics.h — kinematics + articulation dynamics, one wavefront per env (gfx950, wave64).
+ *
+ * (two envs share a wavefront, 32 lanes each, when the template has <= 32 bodies and <= 15 dofs)
+ *
+ *   lane i  <-> body i   link frames / velocities / RNEA, level-synchronous over the tree depth
+ *                        (a lane reads its parent's pose, V, acc from LDS; parents gather the
+ *                        children's forces and composite inertias on the way back)
+ *   lane i  <-> dof i    CRBA row, implicit-PD system matrix row, Cholesky row
+ *   lane c  <-> column c of A^-1 (c < nd) and lane 16 <-> the unconstrained velocity: 17 independent
+ *                        triangular solves run side by side, each in the oracle's sequential order
+ *
+ * Everything a lane owns stays in registers; LDS carries only what crosses lanes (parent/child
+ * hand-offs, the matrices M and L).  Every per-element fmaf chain is the oracle's (oracle/orc_sim.c
+ * kinematics()/dynamics()), so results are bit-identical while the serial depth drops from
+ * O(bodies + dof^3) per lane to O(tree depth + dof) per wave.
+ *
+ * Outputs: link poses / velocities and world COMs in the env record, and the solver tables
+ * W (block-diagonal inverse mass matrix), Scol (motion subspace columns), vfree.
+ */
+#ifndef MSK_DYNAMICS_H
+#define MSK_DYNAMICS_H
+
+#include "msk_model.h"
+
+MSK_DEV void dyn_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+/* dynamic LDS carve (floats) for a template with nb bodies */
+struct DynLds {
+  int pose, S, V, acc, Ic, M, L, vec, total;
+  __host__ __device__ explicit DynLds(int nb) {
+    int o = 0;
+    pose = o; o += nb * 8;
+    S = o; o += nb * 6;
+    V = o; o += nb * 6;
+    acc = o; o += nb * 6;            /* acc on the way down, f on the way back */
+    Ic = o; o += nb * 10;
+    M = o; o += MSK_MAX_DOF * (MSK_MAX_DOF + 1);
+    L = o; o += MSK_MAX_DOF * (MSK_MAX_DOF + 1);
+    vec = o; o += 8 * MSK_MAX_DOF;   /* qd | bias | Kd | Dd | fconst | err | rhs | vfree */
+    total = o;
+  }
+};
+enum { DV_QD = 0, DV_BIAS = 1, DV_KD = 2, DV_DD = 3, DV_FC = 4, DV_ERR = 5, DV_RHS = 6, DV_VF = 7 };
+
+MSK_DEV sv6 lds_sv6(const float* p) { sv6 r = {v3_make(p[0], p[1], p[2]), v3_make(p[3], p[4], p[5])}; return r; }
+MSK_DEV void lds_put_sv6(float* p, sv6 v) { p[0] = v.a.x; p[1] = v.a.y; p[2] = v.a.z; p[3] = v.l.x; p[4] = v.l.y; p[5] = v.l.z; }
+
+/* Forward pass shared by k_dynamics and k_kinematics: link frames, joint subspaces, spatial
+ * velocities (and accelerations with zero joint acceleration), level by level.
+ * Returns this lane's body frame; S/V/acc of every body are in LDS afterwards. */
+template <bool WITH_ACC>
+MSK_DEV pose forward_pass(const DModel* m, const float* E, float* lds, const DynLds& ly, int i, bool has, sv6* Sout, sv6* Vout,
+                          sv6* Aout) {
+  const DBody* b = &m->bodies[has ? i : 0];
+  pose T;
+  T.p = v3_make(0, 0, 0);
+  T.q = quat_make(1, 0, 0, 0);
+  sv6 S = sv6_zero(), V = sv6_zero(), A = sv6_zero();
+  if (has) {
+    T = load_pose(E, m->lay.bpose, i);
+    float* pp = lds + ly.pose + i * 8;
+    pp[0] = T.p.x; pp[1] = T.p.y; pp[2] = T.p.z; pp[3] = T.q.w; pp[4] = T.q.x; pp[5] = T.q.y; pp[6] = T.q.z;
+    lds_put_sv6(lds + ly.S + i * 6, S);
+    lds_put_sv6(lds + ly.V + i * 6, V);
+    if (WITH_ACC) lds_put_sv6(lds + ly.acc + i * 6, A);
+  }
+  dyn_sync();
+  const bool child_link = has && b->kind == MSK_BODY_LINK && b->parent >= 0;
+  const int mydepth = has ? m->depth[i] : -1;
+  for (int d = 1; d <= m->maxdepth; ++d) {
+    if (child_link && mydepth == d) {
+      const float* pp = lds + ly.pose + b->parent * 8;
+      pose Tp;
+      Tp.p = v3_make(pp[0], pp[1], pp[2]);
+      Tp.q = quat_make(pp[3], pp[4], pp[5], pp[6]);
+      const sv6 Vp = lds_sv6(lds + ly.V + b->parent * 6);
+      pose Tj = pose_mul(Tp, b->Xp);
+      v3 axis = quat_rotate(Tj.q, v3_make(1, 0, 0));
+      pose Jq;
+      Jq.p = v3_make(0, 0, 0);
+      Jq.q = quat_make(1, 0, 0, 0);
+      const float qi = (b->dof >= 0) ? E[m->lay.q + b->dof] : 0.0f;
+      const float qdi = (b->dof >= 0) ? E[m->lay.qd + b->dof] : 0.0f;
+      if (b->jtype == MSK_JOINT_REVOLUTE) {
+        float sn, cs;
+        msk_sincos(0.5f * qi, &sn, &cs);
+        Jq.q = quat_make(cs, sn, 0, 0);
+        S.a = axis;
+        S.l = v3_cross(Tj.p, axis);
+      } else if (b->jtype == MSK_JOINT_PRISMATIC) {
+        Jq.p = v3_make(qi, 0, 0);
+        S.l = axis;
+      }
+      T = pose_mul(pose_mul(Tj, Jq), b->XcInv);
+      T.q = quat_normalize(T.q);
+      V = Vp;
+      if (b->dof >= 0) V = sv6_madd(V, S, qdi);
+      if (WITH_ACC) {
+        A = lds_sv6(lds + ly.acc + b->parent * 6);
+        if (b->dof >= 0) {
+          sv6 sq = {v3_scale(S.a, qdi), v3_scale(S.l, qdi)};
+          A = sv6_add(A, sv6_crossm(Vp, sq));
+        }
+        lds_put_sv6(lds + ly.acc + i * 6, A);
+      }
+      float* po = lds + ly.pose + i * 8;
+      po[0] = T.p.x; po[1] = T.p.y; po[2] = T.p.z; po[3] = T.q.w; po[4] = T.q.x; po[5] = T.q.y; po[6] = T.q.z;
+      lds_put_sv6(lds + ly.S + i * 6, S);
+      lds_put_sv6(lds + ly.V + i * 6, V);
+    }
+    dyn_sync();
+  }
+  *Sout = S; *Vout = V; *Aout = A;
+  return T;
+}
+
+/* publishes what the reference exposes per body: link pose, COM linear velocity, angular velocity */
+MSK_DEV void publish_body(const DModel* m, float* E, int i, const DBody* b, pose T, sv6 V, v3 comw) {
+  if (b->kind == MSK_BODY_LINK) {
+    if (b->parent >= 0) store_pose(E, m->lay.bpose, i, T);
+    store_v3(E, m->lay.bang, i, V.a);
+    store_v3(E, m->lay.blin, i, v3_add(V.l, v3_cross(V.a, comw)));
+  } else if (b->kind == MSK_BODY_KINEMATIC) {
+    store_v3(E, m->lay.blin, i, v3_make(0, 0, 0));
+    store_v3(E, m->lay.bang, i, v3_make(0, 0, 0));
+  }
+}
+
+/* PhysxGpuSystem.gpu_update_articulation_kinematics: frames and velocities only */
+template <int LPE>
+__global__ void __launch_bounds__(64) k_kinematics(const DModel* __restrict__ m, DState st) {
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  const DynLds ly(m->nb);
+  const int sub = threadIdx.x / LPE, i = threadIdx.x % LPE;
+  const int e_raw = blockIdx.x * (64 / LPE) + sub;
+  const bool live = e_raw < m->N;
+  const int e = live ? e_raw : m->N - 1;
+  float* lds = lds_all + sub * ly.total;
+  const bool has = live && i < m->nb;
+  float* E = EREC(st, m, e);
+  sv6 S, V, A;
+  pose T = forward_pass<false>(m, E, lds, ly, i, has, &S, &V, &A);
+  if (!has) return;
+  const DBody* b = &m->bodies[i];
+  m33 R = quat_to_m33(T.q);
+  v3 comw = v3_add(T.p, m33_mulv(&R, b->com));
+  publish_body(m, E, i, b, T, V, comw);
+}
+
+template <int LPE>
+__global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, DState st) {
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  const DynLds ly(m->nb);
+  const int sub = threadIdx.x / LPE, i = threadIdx.x % LPE;
+  const int e_raw = blockIdx.x * (64 / LPE) + sub;
+  const bool live = e_raw < m->N;      /* a surplus half-wave shadows the last env and stores nothing */
+  const int e = live ? e_raw : m->N - 1;
+  float* lds = lds_all + sub * ly.total;
+  const int nb = m->nb, nd = m->nd, G = m->G;
+  const bool has = live && i < nb;
+  const float dt = m->cfg.timestep;
+  const v3 g = v3_make(m->cfg.gravity[0], m->cfg.gravity[1], m->cfg.gravity[2]);
+  float* E = EREC(st, m, e);
+  float* Wenv = st.W + (size_t)e * G * G;     /* entries outside the blocks stay zero from allocation */
+  float* Senv = st.Scol + (size_t)e * G * 8;
+  float* vfenv = st.vfree + (size_t)e * G;
+  float* Lm = lds + ly.M;
+  float* Ll = lds + ly.L;
+  float* vec = lds + ly.vec;
+  const int LD = MSK_MAX_DOF + 1;
+
+  /* ---- 1. frames, velocities, bias accelerations (down the tree) ------------------------------------ */
+  sv6 S, V, acc;
+  const pose T = forward_pass<true>(m, E, lds, ly, i, has, &S, &V, &acc);
+  const DBody* b = &m->bodies[has ? i : 0];
+  const bool link = has && b->kind == MSK_BODY_LINK;
+  v3 comw = v3_make(0, 0, 0);
+  m33 R;
+  sinertia Ic;
+  sv6 f = sv6_zero();
+  if (has) {
+    R = quat_to_m33(T.q);
+    comw = v3_add(T.p, m33_mulv(&R, b->com));
+    publish_body(m, E, i, b, T, V, comw);
+  }
+  /* zero M while the forward results settle */
+  for (int k = i; k < MSK_MAX_DOF * LD; k += LPE) Lm[k] = 0.0f;
+  if (i < nd) vec[DV_QD * MSK_MAX_DOF + i] = E[m->lay.qd + i];
+  /* ---- 2. RNEA body forces, spatial inertias about the env origin ---------------------------------------- */
+  if (link) {
+    float Iw[6];
+    sym6_rotate(&R, b->I6, Iw);
+    const v3 cw = comw;
+    const float ms = b->mass;
+    Ic.m = ms;
+    Ic.h = v3_scale(cw, ms);
+    const float cc = v3_dot(cw, cw);
+    Ic.I[0] = Iw[0] + ms * (cc - cw.x * cw.x);
+    Ic.I[1] = Iw[1] + ms * (cc - cw.y * cw.y);
+    Ic.I[2] = Iw[2] + ms * (cc - cw.z * cw.z);
+    Ic.I[3] = Iw[3] - ms * (cw.x * cw.y);
+    Ic.I[4] = Iw[4] - ms * (cw.x * cw.z);
+    Ic.I[5] = Iw[5] - ms * (cw.y * cw.z);
+    sv6 Iv = sinertia_mul(&Ic, V);
+    f = sv6_add(sinertia_mul(&Ic, acc), sv6_crossf(V, Iv));
+    if (!b->nograv) {
+      v3 mg = v3_scale(g, ms);
+      f.a = v3_sub(f.a, v3_cross(cw, mg));
+      f.l = v3_sub(f.l, mg);
+    }
+  }
+  dyn_sync(); /* everybody has read its parent's acc: the slot now carries f */
+  float* fi = lds + ly.acc + (has ? i : 0) * 6;
+  float* Ii = lds + ly.Ic + (has ? i : 0) * 10;
+  if (link) {
+    lds_put_sv6(fi, f);
+    Ii[0] = Ic.m; Ii[1] = Ic.h.x; Ii[2] = Ic.h.y; Ii[3] = Ic.h.z;
+    for (int k = 0; k < 6; ++k) Ii[4 + k] = Ic.I[k];
+  }
+  dyn_sync();
+  /* ---- 3. back up the tree: parents absorb their children (descending body index, as the oracle) --------- */
+  const int mydepth = has ? m->depth[i] : -1;
+  for (int d = m->maxdepth; d >= 1; --d) {
+    if (link && mydepth == d - 1) {
+      const int c0 = m->child_off[i], c1 = m->child_off[i + 1];
+      if (c1 > c0) {
+        for (int cc = c0; cc < c1; ++cc) {
+          const int ch = m->child_idx[cc];
+          f = sv6_add(f, lds_sv6(lds + ly.acc + ch * 6));
+          const float* Ic_c = lds + ly.Ic + ch * 10;
+          Ic.m += Ic_c[0];
+          Ic.h = v3_add(Ic.h, v3_make(Ic_c[1], Ic_c[2], Ic_c[3]));
+          for (int k = 0; k < 6; ++k) Ic.I[k] += Ic_c[4 + k];
+        }
+        lds_put_sv6(fi, f);
+        Ii[0] = Ic.m; Ii[1] = Ic.h.x; Ii[2] = Ic.h.y; Ii[3] = Ic.h.z;
+        for (int k = 0; k < 6; ++k) Ii[4 + k] = Ic.I[k];
+      }
+    }
+    dyn_sync();
+  }
+  /* ---- 4. bias torques and CRBA rows (lane = body with a dof) ------------------------------------------------ */
+  if (link && b->dof >= 0) {
+    const int di = b->dof;
+    vec[DV_BIAS * MSK_MAX_DOF + di] = sv6_dot(S, f);
+    const sv6 F = sinertia_mul(&Ic, S);
+    Lm[di * LD + di] = sv6_dot(S, F) + b->armature;
+    int j = b->parent;
+    while (j >= 0) {
+      const DBody* bj = &m->bodies[j];
+      if (bj->dof >= 0) {
+        const float v = sv6_dot(lds_sv6(lds + ly.S + j * 6), F);
+        Lm[di * LD + bj->dof] = v;
+        Lm[bj->dof * LD + di] = v;
+      }
+      j = bj->parent;
+    }
+    float* sc = Senv + di * 8;   /* motion subspace column of coordinate di, for the row assembly */
+    sc[0] = S.a.x; sc[1] = S.a.y; sc[2] = S.a.z; sc[3] = S.l.x; sc[4] = S.l.y; sc[5] = S.l.z;
+    /* drive of this joint */
+    vec[DV_KD * MSK_MAX_DOF + di] = b->K;
+    vec[DV_DD * MSK_MAX_DOF + di] = b->D;
+    vec[DV_FC * MSK_MAX_DOF + di] = 0.0f;
+    vec[DV_ERR * MSK_MAX_DOF + di] = E[m->lay.q + di] - E[m->lay.qt + di];
+  }
+  dyn_sync();
+
+  /* ---- 5. implicit PD: A = M + dt D + dt^2 K (+ tendons), Cholesky, solves; second pass if a drive saturates ---- */
+  const bool rowlane = i < nd;   /* surplus half-waves compute along (LDS only) and store nothing */
+  const float fmax_i = rowlane ? m->bodies[m->dof_body[i]].fmax : 0.0f;
+  const float qdt_i = rowlane ? E[m->lay.qdt + i] : 0.0f;
+  const float qf_i = rowlane ? E[m->lay.qf + i] : 0.0f;
+  const float bias_i = rowlane ? vec[DV_BIAS * MSK_MAX_DOF + i] : 0.0f;
+  float Kd = rowlane ? vec[DV_KD * MSK_MAX_DOF + i] : 0.0f, Dd = rowlane ? vec[DV_DD * MSK_MAX_DOF + i] : 0.0f;
+  float fconst = 0.0f, err = rowlane ? vec[DV_ERR * MSK_MAX_DOF + i] : 0.0f;
+  for (int pass = 0; pass < 2; ++pass) {
+    float Arow[MSK_MAX_DOF];
+    float rhs = 0.0f;
+    if (rowlane) {
+      float mv = 0.0f;
+#pragma unroll
+      for (int k = 0; k < MSK_MAX_DOF; ++k) {
+        const float mk = (k < nd) ? Lm[i * LD + k] : 0.0f;
+        Arow[k] = mk;
+        if (k < nd) mv = fmaf(mk, vec[DV_QD * MSK_MAX_DOF + k], mv);
+      }
+      const float dadd = dt * fmaf(dt, Kd, Dd);
+#pragma unroll
+      for (int k = 0; k < MSK_MAX_DOF; ++k)
+        if (k == i) Arow[k] += dadd;
+      const float tau = qf_i - bias_i - Kd * err + Dd * qdt_i + fconst;
+      rhs = fmaf(dt, tau, mv);
+      for (int t = 0; t < m->nt; ++t) {
+        const DTendon* tn = &m->tendons[t];
+        const float g2 = dt * fmaf(dt, tn->K, tn->D);
+        const float te = fmaf(tn->ca, E[m->lay.q + tn->dof_a], tn->cb * E[m->lay.q + tn->dof_b]) - tn->rest;
+        if (i == tn->dof_a) {
+#pragma unroll
+          for (int k = 0; k < MSK_MAX_DOF; ++k) {
+            if (k == tn->dof_a) Arow[k] += g2 * tn->ca * tn->ca;
+            if (k == tn->dof_b) Arow[k] += g2 * tn->ca * tn->cb;
+          }
+          rhs -= dt * tn->K * te * tn->ca;
+        }
+        if (i == tn->dof_b) {
+#pragma unroll
+          for (int k = 0; k < MSK_MAX_DOF; ++k) {
+            if (k == tn->dof_b) Arow[k] += g2 * tn->cb * tn->cb;
+            if (k == tn->dof_a) Arow[k] += g2 * tn->ca * tn->cb;
+          }
+          rhs -= dt * tn->K * te * tn->cb;
+        }
+      }
+      vec[DV_RHS * MSK_MAX_DOF + i] = rhs;
+    }
+    /* Cholesky A = L L^T, lane i owns row i; column j is finished at step j */
+    float Lrow[MSK_MAX_DOF];
+#pragma unroll
+    for (int k = 0; k < MSK_MAX_DOF; ++k) Lrow[k] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < MSK_MAX_DOF; ++j) {
+      if (j < nd) {
+        float sum = 0.0f;
+        if (rowlane && i >= j) {
+          sum = Arow[j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) sum = fmaf(-Lrow[k], Ll[j * LD + k], sum);
+          if (i == j) {
+            Lrow[j] = sqrtf(sum);
+            Ll[j * LD + j] = Lrow[j];
+          }
+        }
+        dyn_sync();
+        if (rowlane && i > j) {
+          Lrow[j] = sum / Ll[j * LD + j];
+          Ll[i * LD + j] = Lrow[j];
+        }
+        dyn_sync();
+      }
+    }
+    /* triangular solves: lane c < nd -> column c of A^-1, lane MSK_MAX_DOF -> vfree = A^-1 rhs */
+    const bool col = i < nd, vf = i == MSK_MAX_DOF;
+    float y[MSK_MAX_DOF], x[MSK_MAX_DOF];
+    if (col || vf) {
+#pragma unroll
+      for (int r = 0; r < MSK_MAX_DOF; ++r) {
+        y[r] = 0.0f;
+        if (r < nd) {
+          float sum = vf ? vec[DV_RHS * MSK_MAX_DOF + r] : ((r == i) ? 1.0f : 0.0f);
+#pragma unroll
+          for (int k = 0; k < r; ++k) sum = fmaf(-Ll[r * LD + k], y[k], sum);
+          y[r] = sum / Ll[r * LD + r];
+        }
+      }
+#pragma unroll
+      for (int r = MSK_MAX_DOF - 1; r >= 0; --r) {
+        x[r] = 0.0f;
+        if (r < nd) {
+          float sum = y[r];
+#pragma unroll
+          for (int k = r + 1; k < MSK_MAX_DOF; ++k)
+            if (k < nd) sum = fmaf(-Ll[k * LD + r], x[k], sum);
+          x[r] = sum / Ll[r * LD + r];
+        }
+      }
+      if (vf) {
+#pragma unroll
+        for (int r = 0; r < MSK_MAX_DOF; ++r)
+          if (r < nd) { vec[DV_VF * MSK_MAX_DOF + r] = x[r]; if (live) vfenv[r] = x[r]; }
+      } else if (live) {
+#pragma unroll
+        for (int r = 0; r < MSK_MAX_DOF; ++r)
+          if (r < nd) Wenv[r * G + i] = x[r];
+      }
+    }
+    dyn_sync();
+    if (pass == 1) break;
+    /* drive force limits: predict the PD force at v*, saturate where it exceeds the limit */
+    bool sat = false;
+    if (rowlane && !(Kd == 0.0f && Dd == 0.0f)) {
+      const float vfi = vec[DV_VF * MSK_MAX_DOF + i];
+      const float F = -Kd * fmaf(dt, vfi, err) - Dd * (vfi - qdt_i);
+      if (fabsf(F) > fmax_i) {
+        fconst = (F > 0.0f) ? fmax_i : -fmax_i;
+        Kd = 0.0f; Dd = 0.0f; err = 0.0f;
+        sat = true;
+      }
+    }
+    /* wave-uniform decision: an env that did not saturate recomputes the identical pass */
+    if (__ballot(sat) == 0ull) break;
+  }
+
+  /* ---- 6. free bodies: unconstrained velocity, world inverse inertia, subspace columns -------------------- */
+  if (has && b->kind == MSK_BODY_DYNAMIC) {
+    v3 v = load_v3(E, m->lay.blin, i), w = load_v3(E, m->lay.bang, i);
+    if (!b->nograv) v = v3_madd(v, g, dt);
+    const float kl = fmaxf(0.0f, 1.0f - dt * b->lin_damp);
+    const float ka = fmaxf(0.0f, 1.0f - dt * b->ang_damp);
+    v = v3_scale(v, kl);
+    w = v3_scale(w, ka);
+    const int o = b->vofs;
+    vfenv[o + 0] = v.x; vfenv[o + 1] = v.y; vfenv[o + 2] = v.z;
+    vfenv[o + 3] = w.x; vfenv[o + 4] = w.y; vfenv[o + 5] = w.z;
+    float Iinv[6];
+    sym6_rotate(&R, b->Iinv6, Iinv);
+    const float im = 1.0f / b->mass;
+    const float Im[3][3] = {{Iinv[0], Iinv[3], Iinv[4]}, {Iinv[3], Iinv[1], Iinv[5]}, {Iinv[4], Iinv[5], Iinv[2]}};
+    const v3 ex[3] = {v3_make(1, 0, 0), v3_make(0, 1, 0), v3_make(0, 0, 1)};
+    for (int a = 0; a < 3; ++a) {
+      Wenv[(o + a) * G + o + a] = im;
+      for (int j = 0; j < 3; ++j) Wenv[(o + 3 + a) * G + o + 3 + j] = Im[a][j];
+      float* sl = Senv + (o + a) * 8;       /* v_com */
+      sl[0] = 0.0f; sl[1] = 0.0f; sl[2] = 0.0f; sl[3] = ex[a].x; sl[4] = ex[a].y; sl[5] = ex[a].z;
+      float* sa = Senv + (o + 3 + a) * 8;   /* omega: point velocity = w x (p - c) */
+      const v3 cl = v3_cross(comw, ex[a]);
+      sa[0] = ex[a].x; sa[1] = ex[a].y; sa[2] = ex[a].z; sa[3] = cl.x; sa[4] = cl.y; sa[5] = cl.z;
+    }
+    store_v3(E, m->lay.comw, i, comw);
+  }
+}
+
+#endif

@@ -1,9 +1,9 @@
 /*
  * msk_model.h — device-resident description of the env template and the SoA state layout.
  *
- * HBM layout: every per-env quantity is stored struct-of-arrays with the env
- * index fastest, arr[k * N + env].  A wavefront = 64 consecutive envs, so every load/store
- * of "field k of my env" is one fully coalesced 256-byte transaction.  The template
+ * HBM layout: everything that belongs to one env is contiguous (env-major): the
+ * persistent state record (EnvLayout), the solver tables, the contact slots.  The kernels map a
+ * wavefront (or a 16/32-lane group) to an env, so its loads are wide and coalesced.  The template
  * (bodies, shapes, hull vertices, candidate pairs) is shared by all envs, lives once in
  * HBM/L2 and is read through wave-uniform (scalar) loads.
  */
@@ -12,6 +12,13 @@
 
 #include "../../include/msk_physx.h"
 #include "msk_math.h"
+
+/* Persistent state of ONE env: a contiguous record of `stride` floats (offsets in floats).
+ *   q qd qacc qf qt qdt : MSK_MAX_DOF each      off : scene offset xyz (+pad)
+ *   bpose : nb x 8  [px py pz qw qx qy qz pad]   blin, bang, comw : nb x 4 [x y z pad]
+ * A wavefront that works on one env (or a lane group on a few) reads its record with wide
+ * contiguous loads; the record of PickCube (18 bodies) is 1840 bytes. */
+struct EnvLayout { int q, qd, qacc, qf, qt, qdt, off, bpose, blin, bang, comw, stride; };
 
 struct DBody {
   int kind, art, parent, jtype, dof, vofs, nograv, movable;
@@ -42,6 +49,13 @@ struct DModel {
   DTendon tendons[MSK_MAX_TENDONS];
   DPair pairs[MSK_MAX_PAIRS];
   v3 verts[MSK_MAX_SHAPES * 16]; /* hull vertex pool (<= 1024 vertices per template) */
+  EnvLayout lay;
+  /* tree tables for the wave-per-env dynamics (msk_dynamics.h) */
+  int depth[MSK_MAX_BODIES];           /* links: distance to the root link; actors: 0            */
+  int maxdepth;
+  int child_off[MSK_MAX_BODIES + 1];   /* CSR of child links, each list in DESCENDING body index */
+  int child_idx[MSK_MAX_BODIES];
+  int dof_body[MSK_MAX_DOF];           /* link whose incoming joint is dof d                     */
   /* lane-group solver tables: one lane per generalized coordinate k (msk_solve.h) */
   int G;                               /* lanes per env = nv padded to 16 or 32                  */
   int npp;                             /* np padded to a multiple of G (contact slot stride)     */
@@ -61,12 +75,8 @@ struct DModel {
 
 /* All device arrays of one context.  Sizes are in floats / ints per env times N. */
 struct DState {
-  /* persistent state */
-  float *q, *qd, *qacc, *qf, *qt, *qdt;       /* [nd][N] */
-  float *bpose;                                /* [nb*7][N]  px py pz qw qx qy qz */
-  float *blin, *bang;                          /* [nb*3][N]  COM linear / angular velocity */
-  /* per-step scratch */
-  float *comw;                                 /* [nb*3][N] */
+  /* persistent state, env-major: [N][lay.stride] (EnvLayout) */
+  float *env;
   /* env-major tables for the lane-group solver (lane k of an env reads a contiguous row) */
   float *Scol;                                 /* [N][G][8]  motion subspace column of coordinate k (a, l, pad) */
   float *W;                                    /* [N][G][G]  block-diagonal inverse mass matrix, zero padded    */
@@ -78,9 +88,28 @@ struct DState {
   float2 *ov_jy;                               /* [N][MSK_MAX_ROWS][G] */
   float4 *ov_rs;                               /* [N][MSK_MAX_ROWS] */
   float *ov_lam;                               /* [N][MSK_MAX_ROWS] */
+  /* narrowphase work lists per env and type (plane / box-box / GJK): surviving pair indices in pair order */
+  int *np_count;                               /* [N][4] */
+  int *np_items;                               /* [N][3][np] */
   int *env_ncontacts;                          /* [N] */
   int *env_overflow;                           /* [1] */
-  float *offsets;                              /* [3][N] */
 };
+
+/* accessors of the env record E (EnvLayout): scalar fields by offset, poses 8 floats, vectors 4 floats */
+#define EREC(st, m, e) ((st).env + (size_t)(e) * (size_t)(m)->lay.stride)
+
+MSK_DEV pose load_pose(const float* E, int ofs, int body) {
+  const float* r = E + ofs + body * 8;
+  pose p;
+  p.p = v3_make(r[0], r[1], r[2]);
+  p.q = quat_make(r[3], r[4], r[5], r[6]);
+  return p;
+}
+MSK_DEV void store_pose(float* E, int ofs, int body, pose p) {
+  float* r = E + ofs + body * 8;
+  r[0] = p.p.x; r[1] = p.p.y; r[2] = p.p.z; r[3] = p.q.w; r[4] = p.q.x; r[5] = p.q.y; r[6] = p.q.z;
+}
+MSK_DEV v3 load_v3(const float* E, int ofs, int k) { const float* r = E + ofs + k * 4; return v3_make(r[0], r[1], r[2]); }
+MSK_DEV void store_v3(float* E, int ofs, int k, v3 v) { float* r = E + ofs + k * 4; r[0] = v.x; r[1] = v.y; r[2] = v.z; }
 
 #endif

@@ -16,6 +16,21 @@
 
 struct HostQuery { int npairs; int* d_pairs; float* d_out; };
 
+/* wave-per-env kernels: two envs share a wavefront when the template is small enough */
+static int lanes_per_env(const DModel& m) { return (m.nb <= 32 && m.nd < MSK_MAX_DOF) ? 32 : 64; }
+static void launch_kinematics(const DModel& m, const DModel* d_model, const DState& st, hipStream_t s) {
+  const int lpe = lanes_per_env(m), epb = 64 / lpe;
+  const size_t lds = (size_t)DynLds(m.nb).total * sizeof(float) * epb;
+  if (lpe == 32) hipLaunchKernelGGL(k_kinematics<32>, dim3((m.N + 1) / 2), dim3(64), lds, s, d_model, st);
+  else hipLaunchKernelGGL(k_kinematics<64>, dim3(m.N), dim3(64), lds, s, d_model, st);
+}
+static void launch_dynamics(const DModel& m, const DModel* d_model, const DState& st, hipStream_t s) {
+  const int lpe = lanes_per_env(m), epb = 64 / lpe;
+  const size_t lds = (size_t)DynLds(m.nb).total * sizeof(float) * epb;
+  if (lpe == 32) hipLaunchKernelGGL(k_dynamics<32>, dim3((m.N + 1) / 2), dim3(64), lds, s, d_model, st);
+  else hipLaunchKernelGGL(k_dynamics<64>, dim3(m.N), dim3(64), lds, s, d_model, st);
+}
+
 struct msk_ctx {
   int device;
   bool finalized;
@@ -352,6 +367,22 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
       m.coord_body[b->vofs] = i;
     }
   }
+  m.maxdepth = 0;
+  for (int i = 0; i < m.nb; ++i) {
+    const DBody* b = &m.bodies[i];
+    m.depth[i] = (b->kind == MSK_BODY_LINK && b->parent >= 0) ? m.depth[b->parent] + 1 : 0;
+    if (m.depth[i] > m.maxdepth) m.maxdepth = m.depth[i];
+    if (b->kind == MSK_BODY_LINK && b->dof >= 0) m.dof_body[b->dof] = i;
+  }
+  {
+    int o = 0;
+    for (int i = 0; i < m.nb; ++i) {
+      m.child_off[i] = o;
+      for (int j = m.nb - 1; j > i; --j)
+        if (m.bodies[j].kind == MSK_BODY_LINK && m.bodies[j].parent == i) m.child_idx[o++] = j;
+    }
+    m.child_off[m.nb] = o;
+  }
   for (int p = 0; p < m.np; ++p) {
     const DShape* A = &m.shapes[m.pairs[p].sa];
     const DShape* B = &m.shapes[m.pairs[p].sb];
@@ -359,21 +390,27 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
     m.pinfo[p].mu = 0.5f * (A->df + B->df);
     m.pinfo[p].pad = 0;
   }
+  {
+    EnvLayout& L = m.lay;
+    int o = 0;
+    L.q = o; o += MSK_MAX_DOF; L.qd = o; o += MSK_MAX_DOF; L.qacc = o; o += MSK_MAX_DOF;
+    L.qf = o; o += MSK_MAX_DOF; L.qt = o; o += MSK_MAX_DOF; L.qdt = o; o += MSK_MAX_DOF;
+    L.off = o; o += 4;
+    L.bpose = o; o += m.nb * 8;
+    L.blin = o; o += m.nb * 4; L.bang = o; o += m.nb * 4; L.comw = o; o += m.nb * 4;
+    L.stride = o;
+  }
   const size_t N = (size_t)num_envs;
   ALLOC(c->d_model, 1);
   HIP_TRY(hipMemcpy(c->d_model, &m, sizeof(DModel), hipMemcpyHostToDevice));
   DState& st = c->st;
-  const size_t nd = m.nd > 0 ? m.nd : 1;
-  ALLOC(st.q, nd * N); ALLOC(st.qd, nd * N); ALLOC(st.qacc, nd * N); ALLOC(st.qf, nd * N);
-  ALLOC(st.qt, nd * N); ALLOC(st.qdt, nd * N);
-  ALLOC(st.bpose, (size_t)m.nb * 7 * N); ALLOC(st.blin, (size_t)m.nb * 3 * N); ALLOC(st.bang, (size_t)m.nb * 3 * N);
-  ALLOC(st.comw, (size_t)m.nb * 3 * N);
+  ALLOC(st.env, N * (size_t)m.lay.stride);
   const size_t G = (size_t)m.G;
   ALLOC(st.Scol, N * G * 8); ALLOC(st.W, N * G * G); ALLOC(st.vfree, N * G);
   ALLOC(st.ct_cnt, N * m.npp); ALLOC(st.ct_rec, N * m.npp * MSK_CT_REC);
   ALLOC(st.ov_jy, N * MSK_MAX_ROWS * G); ALLOC(st.ov_rs, N * MSK_MAX_ROWS); ALLOC(st.ov_lam, N * MSK_MAX_ROWS);
   ALLOC(st.env_ncontacts, N); ALLOC(st.env_overflow, 1);
-  ALLOC(st.offsets, 3 * N);
+  ALLOC(st.np_count, N * 4); ALLOC(st.np_items, N * NP_TYPES * (size_t)(m.np > 0 ? m.np : 1));
   ALLOC(c->d_art_dof0, 8); ALLOC(c->d_art_ndof, 8);
   HIP_TRY(hipMemcpy(c->d_art_dof0, c->art_dof0, sizeof(int) * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->d_art_ndof, c->art_ndof, sizeof(int) * 8, hipMemcpyHostToDevice));
@@ -384,17 +421,17 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   for (int b = MSK_BUF_ART_QPOS; b < MSK_BUF_COUNT; ++b) ALLOC(c->bufs.buf[b], nart);
   c->bufs.max_dof = c->max_dof;
   /* initial poses (template replicated) */
-  std::vector<float> h((size_t)m.nb * 7 * N);
-  for (int i = 0; i < m.nb; ++i) {
-    const pose& p = c->init_pose[i];
-    const float vals[7] = {p.p.x, p.p.y, p.p.z, p.q.w, p.q.x, p.q.y, p.q.z};
-    for (int k = 0; k < 7; ++k)
-      for (size_t e = 0; e < N; ++e) h[((size_t)i * 7 + k) * N + e] = vals[k];
-  }
-  HIP_TRY(hipMemcpy(st.bpose, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  std::vector<float> h(N * (size_t)m.lay.stride, 0.0f);
+  for (size_t e = 0; e < N; ++e)
+    for (int i = 0; i < m.nb; ++i) {
+      const pose& p = c->init_pose[i];
+      const float vals[7] = {p.p.x, p.p.y, p.p.z, p.q.w, p.q.x, p.q.y, p.q.z};
+      memcpy(&h[e * m.lay.stride + m.lay.bpose + i * 8], vals, sizeof(vals));
+    }
+  HIP_TRY(hipMemcpy(st.env, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
   c->finalized = true;
   c->kin_dirty = false;
-  hipLaunchKernelGGL(k_kinematics, dim3((num_envs + 63) / 64), dim3(64), 0, 0, c->d_model, c->st);
+  launch_kinematics(m, c->d_model, c->st, 0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   return MSK_OK;
@@ -403,11 +440,9 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
 MSK_API int msk_set_scene_offsets(msk_ctx* c, const float* offsets) {
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "set_scene_offsets before finalize");
   const size_t N = (size_t)c->model.N;
-  std::vector<float> h(3 * N);
-  for (size_t e = 0; e < N; ++e)
-    for (int k = 0; k < 3; ++k) h[(size_t)k * N + e] = offsets[3 * e + k];
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipMemcpy(c->st.offsets, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy2D(c->st.env + c->model.lay.off, sizeof(float) * c->model.lay.stride, offsets, 3 * sizeof(float),
+                      3 * sizeof(float), N, hipMemcpyHostToDevice));
   return MSK_OK;
 }
 
@@ -431,7 +466,7 @@ MSK_API int msk_fetch(msk_ctx* c, uint32_t mask, void* stream) {
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "fetch before finalize");
   const int N = c->model.N;
   if (c->kin_dirty && (mask & MSK_FETCH_RIGID_DATA)) { /* link frames of the post-step (q, qd) */
-    hipLaunchKernelGGL(k_kinematics, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, c->d_model, c->st);
+    launch_kinematics(c->model, c->d_model, c->st, (hipStream_t)stream);
     c->kin_dirty = false;
   }
   hipLaunchKernelGGL(k_fetch, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->bufs, mask,
@@ -443,7 +478,7 @@ MSK_API int msk_fetch(msk_ctx* c, uint32_t mask, void* stream) {
 MSK_API int msk_update_kinematics(msk_ctx* c, void* stream) {
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "update_kinematics before finalize");
   const int N = c->model.N;
-  hipLaunchKernelGGL(k_kinematics, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, c->d_model, c->st);
+  launch_kinematics(c->model, c->d_model, c->st, (hipStream_t)stream);
   c->kin_dirty = false;
   HIP_TRY(hipGetLastError());
   return MSK_OK;
@@ -457,9 +492,12 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
   const bool timed = c->t_n < c->t_cap;
   hipEvent_t* ev = timed ? &c->tev[(size_t)c->t_n * (MSK_K_SLOTS + 1)] : nullptr;
   if (timed) hipEventRecord(ev[0], s);
-  hipLaunchKernelGGL(k_dynamics, dim3(nblk), dim3(64), 0, s, c->d_model, c->st);
+  launch_dynamics(c->model, c->d_model, c->st, s);
   if (timed) hipEventRecord(ev[1], s);
-  if (c->model.np > 0) hipLaunchKernelGGL(k_collide, dim3(nblk, c->model.np), dim3(64), 0, s, c->d_model, c->st);
+  if (c->model.np > 0) {
+    hipLaunchKernelGGL(k_broadphase, dim3(N), dim3(64), 0, s, c->d_model, c->st);
+    hipLaunchKernelGGL(k_narrowphase, dim3((N + NP_GROUP - 1) / NP_GROUP, NP_TYPES), dim3(64), 0, s, c->d_model, c->st);
+  }
   if (timed) hipEventRecord(ev[2], s);
   {
     const int G = c->model.G;

@@ -161,8 +161,9 @@ __global__ void __launch_bounds__(64) k_solve(const DModel* __restrict__ m, DSta
   const unsigned long long moves = (k < nv) ? m->coord_moves[k] : 0ull;
   float v = st.vfree[(size_t)e * G + k];  /* zero for k >= nv */
   float dq = 0.0f;
-  const float qk = (k < nd) ? st.q[(size_t)k * N + e] : 0.0f;
-  const float qdk = (k < nd) ? st.qd[(size_t)k * N + e] : 0.0f;
+  float* E = EREC(st, m, e);
+  const float qk = (k < nd) ? E[m->lay.q + k] : 0.0f;
+  const float qdk = (k < nd) ? E[m->lay.qd + k] : 0.0f;
   int* cnts = st.ct_cnt + (size_t)e * npp;
   float* recs = st.ct_rec + (size_t)e * npp * MSK_CT_REC;
 
@@ -320,27 +321,23 @@ __global__ void __launch_bounds__(64) k_solve(const DModel* __restrict__ m, DSta
   Lvd[G + k] = dq;
   wave_sync();
   if (live && k < nd) {
-    st.qacc[(size_t)k * N + e] = (v - qdk) / dt;
-    st.q[(size_t)k * N + e] = qk + dq;
-    st.qd[(size_t)k * N + e] = v;
+    E[m->lay.qacc + k] = (v - qdk) / dt;
+    E[m->lay.q + k] = qk + dq;
+    E[m->lay.qd + k] = v;
   }
   const int fb = (k < nv) ? m->coord_body[k] : -1;
   if (live && fb >= 0) {
     const DBody* b = &m->bodies[fb];
     const v3 dx = v3_make(Lvd[G + k], Lvd[G + k + 1], Lvd[G + k + 2]);
     const v3 dr = v3_make(Lvd[G + k + 3], Lvd[G + k + 4], Lvd[G + k + 5]);
-    const size_t Ns = (size_t)N;
-    const v3 cw0 = v3_make(st.comw[(fb * 3 + 0) * Ns + e], st.comw[(fb * 3 + 1) * Ns + e], st.comw[(fb * 3 + 2) * Ns + e]);
-    const v3 cw = v3_add(cw0, dx);
-    quat q0 = quat_make(st.bpose[(fb * 7 + 3) * Ns + e], st.bpose[(fb * 7 + 4) * Ns + e], st.bpose[(fb * 7 + 5) * Ns + e],
-                        st.bpose[(fb * 7 + 6) * Ns + e]);
-    const quat qn = quat_normalize(quat_mul(quat_from_rotvec(dr), q0));
-    const v3 pn = v3_sub(cw, quat_rotate(qn, b->com));
-    st.bpose[(fb * 7 + 0) * Ns + e] = pn.x; st.bpose[(fb * 7 + 1) * Ns + e] = pn.y; st.bpose[(fb * 7 + 2) * Ns + e] = pn.z;
-    st.bpose[(fb * 7 + 3) * Ns + e] = qn.w; st.bpose[(fb * 7 + 4) * Ns + e] = qn.x; st.bpose[(fb * 7 + 5) * Ns + e] = qn.y;
-    st.bpose[(fb * 7 + 6) * Ns + e] = qn.z;
-    st.blin[(fb * 3 + 0) * Ns + e] = Lvd[k]; st.blin[(fb * 3 + 1) * Ns + e] = Lvd[k + 1]; st.blin[(fb * 3 + 2) * Ns + e] = Lvd[k + 2];
-    st.bang[(fb * 3 + 0) * Ns + e] = Lvd[k + 3]; st.bang[(fb * 3 + 1) * Ns + e] = Lvd[k + 4]; st.bang[(fb * 3 + 2) * Ns + e] = Lvd[k + 5];
+    const v3 cw = v3_add(load_v3(E, m->lay.comw, fb), dx);
+    pose T = load_pose(E, m->lay.bpose, fb);
+    const quat qn = quat_normalize(quat_mul(quat_from_rotvec(dr), T.q));
+    T.q = qn;
+    T.p = v3_sub(cw, quat_rotate(qn, b->com));
+    store_pose(E, m->lay.bpose, fb, T);
+    store_v3(E, m->lay.blin, fb, v3_make(Lvd[k], Lvd[k + 1], Lvd[k + 2]));
+    store_v3(E, m->lay.bang, fb, v3_make(Lvd[k + 3], Lvd[k + 4], Lvd[k + 5]));
   }
 }
 
