@@ -61,14 +61,12 @@ struct DModel {
   int npp;                             /* np padded to a multiple of G (contact slot stride)     */
   unsigned long long coord_moves[MSK_MAX_NV]; /* bit b: coordinate k moves body b                */
   int coord_body[MSK_MAX_NV];          /* free body whose first coordinate is k, else -1         */
+  unsigned body_coords[MSK_MAX_BODIES]; /* bit k: coordinate k moves body b (transpose of coord_moves) */
   float dof_lo[MSK_MAX_DOF], dof_hi[MSK_MAX_DOF];
   DPairInfo pinfo[MSK_MAX_PAIRS];
 };
 
 #define MSK_MAX_ROWS (2 * MSK_MAX_DOF + 3 * MSK_MAX_CONTACTS)
-#define MSK_ROWS_LDS 64                        /* solver rows per env in the workgroup's LDS row pool
-                                                  (shared: one env may use its neighbours' share); rows
-                                                  that do not fit spill to HBM (st.ov_*)          */
 /* contact slot of one candidate pair of one env: 32 floats
  *   [0..2] normal  [4+3k..] point k  [16+k] separation k  [20+3k+a] impulse k (normal, t1, t2) */
 #define MSK_CT_REC 32
@@ -84,13 +82,13 @@ struct DState {
   /* contacts, env-major, one slot of <= 4 points per candidate pair (persistent: warm starting) */
   int *ct_cnt;                                 /* [N][npp] */
   float *ct_rec;                               /* [N][npp][MSK_CT_REC] */
-  /* solver rows that did not fit the LDS pool */
-  float2 *ov_jy;                               /* [N][MSK_MAX_ROWS][G] */
-  float4 *ov_rs;                               /* [N][MSK_MAX_ROWS] */
-  float *ov_lam;                               /* [N][MSK_MAX_ROWS] */
+  /* envs with more constraint blocks than the small solver launch holds (msk_solve.h) */
+  int *big_list;                               /* [N] */
+  int *big_count;                              /* [1]; zeroed by k_dynamics of the same substep */
   /* narrowphase work lists per env and type (plane / box-box / GJK): surviving pair indices in pair order */
   int *np_count;                               /* [N][4] */
   int *np_items;                               /* [N][3][np] */
+  long long *dbg;                              /* [N][8] phase time stamps (MSK_PROFILE_PHASES builds only) */
   int *env_ncontacts;                          /* [N] */
   int *env_overflow;                           /* [1] */
 };

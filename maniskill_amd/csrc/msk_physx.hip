@@ -46,6 +46,7 @@ struct msk_ctx {
   pose init_pose[MSK_MAX_BODIES];
   pose pending_root;
   int nverts_total;
+  size_t lds_small, lds_big; /* dynamic LDS of the two solver launches */
   bool kin_dirty;        /* link frames in st.bpose are older than (q, qd): run k_kinematics before reading them */
   uint32_t groups[MSK_MAX_SHAPES][4]; /* collision groups: only the static pair filter needs them */
   std::vector<void*> allocs;
@@ -383,6 +384,11 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
     }
     m.child_off[m.nb] = o;
   }
+  for (int b = 0; b < m.nb; ++b) {
+    m.body_coords[b] = 0;
+    for (int k = 0; k < m.nv; ++k)
+      if ((m.coord_moves[k] >> b) & 1ull) m.body_coords[b] |= 1u << k;
+  }
   for (int p = 0; p < m.np; ++p) {
     const DShape* A = &m.shapes[m.pairs[p].sa];
     const DShape* B = &m.shapes[m.pairs[p].sb];
@@ -408,7 +414,20 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   const size_t G = (size_t)m.G;
   ALLOC(st.Scol, N * G * 8); ALLOC(st.W, N * G * G); ALLOC(st.vfree, N * G);
   ALLOC(st.ct_cnt, N * m.npp); ALLOC(st.ct_rec, N * m.npp * MSK_CT_REC);
-  ALLOC(st.ov_jy, N * MSK_MAX_ROWS * G); ALLOC(st.ov_rs, N * MSK_MAX_ROWS); ALLOC(st.ov_lam, N * MSK_MAX_ROWS);
+  ALLOC(st.big_list, N); ALLOC(st.big_count, 1);
+  ALLOC(st.dbg, N * 8);
+  /* the big solver launch needs more than the default 64 KB of dynamic LDS */
+  if (m.G == 16) {
+    auto kb = k_csolve_big<16>;
+    c->lds_small = CsLds<16, 16>::TOTAL * sizeof(float);
+    c->lds_big = CsLds<16, 64>::TOTAL * sizeof(float);
+    HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_big));
+  } else {
+    auto kb = k_csolve_big<32>;
+    c->lds_small = CsLds<32, 32>::TOTAL * sizeof(float);
+    c->lds_big = CsLds<32, 64>::TOTAL * sizeof(float);
+    HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_big));
+  }
   ALLOC(st.env_ncontacts, N); ALLOC(st.env_overflow, 1);
   ALLOC(st.np_count, N * 4); ALLOC(st.np_items, N * NP_TYPES * (size_t)(m.np > 0 ? m.np : 1));
   ALLOC(c->d_art_dof0, 8); ALLOC(c->d_art_ndof, 8);
@@ -500,10 +519,19 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
   }
   if (timed) hipEventRecord(ev[2], s);
   {
-    const int G = c->model.G;
-    const int nsb = (N * G + 63) / 64;
-    if (G == 16) hipLaunchKernelGGL(k_solve<16>, dim3(nsb), dim3(64), 0, s, c->d_model, c->st);
-    else hipLaunchKernelGGL(k_solve<32>, dim3(nsb), dim3(64), 0, s, c->d_model, c->st);
+    /* every env in the 16-block launch; the few that do not fit queue themselves for the big one */
+    const int nbig = N < 512 ? N : 512;
+    if (c->model.G == 16) {
+      auto ks = k_csolve<16, 16>;
+      auto kb = k_csolve_big<16>;
+      hipLaunchKernelGGL(ks, dim3((N + 3) / 4), dim3(64), c->lds_small, s, c->d_model, c->st);
+      hipLaunchKernelGGL(kb, dim3(nbig), dim3(64), c->lds_big, s, c->d_model, c->st);
+    } else {
+      auto ks = k_csolve<32, 32>;
+      auto kb = k_csolve_big<32>;
+      hipLaunchKernelGGL(ks, dim3((N + 1) / 2), dim3(64), c->lds_small, s, c->d_model, c->st);
+      hipLaunchKernelGGL(kb, dim3(nbig), dim3(64), c->lds_big, s, c->d_model, c->st);
+    }
     c->kin_dirty = true;
   }
   if (timed) { hipEventRecord(ev[3], s); c->t_n++; }
@@ -579,6 +607,14 @@ MSK_API int msk_get_sizes(msk_ctx* c, int32_t out[8]) {
     HIP_TRY(hipMemcpy(&flag, c->st.env_overflow, sizeof(int), hipMemcpyDeviceToHost));
     out[7] = flag;
   }
+  return MSK_OK;
+}
+
+/* development aid (MSK_PROFILE_PHASES builds): per-env cycle stamps of the solver phases, out[num_envs*8] */
+MSK_API int msk_debug_phases(msk_ctx* c, long long* out) {
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, c->st.dbg, sizeof(long long) * 8 * (size_t)c->model.N, hipMemcpyDeviceToHost));
   return MSK_OK;
 }
 

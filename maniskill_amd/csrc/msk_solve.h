@@ -1,335 +1,491 @@
 /*
- * msk_solve.h — the TGS row solver, lane-group form (gfx950, wave64).
+ * msk_solve.h — the TGS row solver in constraint space, one wavefront per env (gfx950, wave64).
  *
- * One lane per generalized coordinate: an env owns G = 16 (nv <= 16) or 32 consecutive lanes of a
- * wavefront, a 64-thread workgroup holds 64/G envs, the grid is N*G/64 single-wave workgroups
- * (4096 PickCube envs -> 1024 waves = one per SIMD of the chip).
+ * The Gauss-Seidel sweeps are serial in the rows, so the quantity to minimise is the dependent chain
+ * of ONE row update.  Carrying a = J v per row (instead of v per coordinate) removes every cross-lane
+ * reduction from that chain:
  *
- *   build   every constraint row r (joint limit or contact normal / tangent) is a pair of
- *           G-vectors J_r, Y_r = W J_r^T; lane k computes J_r[k] = +-S_k . F from its own motion
- *           subspace column S_k and Y_r[k] from its own row of W (both in registers), and the row
- *           is parked in LDS as float2 {J,Y} per lane together with {c0, 1/(J.Y), mu, kind}.  The
- *           envs of a workgroup share one LDS pool of 64/G * MSK_ROWS_LDS rows, carved after a
- *           counting pass (most envs need ~16 rows, a few need > 100); what does not fit spills to HBM.
- *   sweep   Gauss-Seidel over the rows, Np + Nv times: lane k keeps v[k] and dq[k] in registers,
- *           J.v and J.dq are 4-step DPP butterflies inside the 16-lane row (+1 bpermute for G = 32),
- *           the clamp is computed redundantly by all G lanes, v[k] += Y[k] * dlambda.
- *           The next row's {J,Y} and scalars are fetched from LDS while the current one reduces.
- *   finish  impulses back to the contact slots, q/qd/qacc, free bodies integrated by the lane of
- *           their first coordinate.
+ *   lane b  <->  constraint block b: a joint with an active limit (rows: lower, upper) or a contact
+ *                point (rows: normal, tangent 1, tangent 2); <= 16 + 48 = 64 blocks per env.
+ *                The lane keeps a, b = J dq, lambda, sum(lambda), c0, 1/A_rr of its <= 3 rows in VGPRs.
+ *   build        the lane assembles its rows J (S_k . F against the LDS-resident motion subspace
+ *                columns), Y = W J^T (W in LDS), parks Y in LDS, then walks all columns r and stores
+ *                A[i][r] = J_i . Y_r for its rows i (column-major in LDS: a sweep step reads 3
+ *                conflict-free dwords per lane).
+ *   sweep step   every lane evaluates the clamp for its own slot s (5 VALU), the owner's impulse change
+ *                is broadcast (DPP row_newbcast / v_readlane), every lane does a[s'] += A[s'][r] * dl
+ *                (3 FMA on operands prefetched one block ahead).  Chain: fma, max, min, sub, bcast, fma.
+ *   finish       v = v* + Y^T lambda and dq = h (Np v* + Y^T sum lambda) by the first NVP lanes,
+ *                impulses back to the contact slots, q/qd/qacc, free bodies.
  *
- * Arithmetic order is the oracle's (oracle/orc_sim.c): coordinate-wise fmaf chains and balanced
- * pairwise-tree dot products, which is exactly what the butterfly produces — results are bit-identical.
+ * Two launches share this code.  k_csolve packs FOUR envs into a wavefront (16 lanes = 16 blocks each;
+ * the broadcast is one DPP row_newbcast) because the median env has 6 blocks and a whole wave per env
+ * would be issue-bound on idle lanes; the four share an LDS pool for Y and A, carved after counting.
+ * An env with more than 16 blocks, or one that does not fit the pool (a few percent under random
+ * actions: fingers or links lying on the table), appends itself to a list and is solved by
+ * k_csolve_big: one wavefront per env, 64 blocks, v_readlane broadcast, the full 159 KB LDS image.
+ * Arithmetic is the oracle's (oracle/orc_sim.c), operation for operation.
  */
 #ifndef MSK_SOLVE_H
 #define MSK_SOLVE_H
+
+#include <type_traits>
 
 #include "msk_model.h"
 
 #define MSK_PEN_BETA 0.8f
 #define MSK_MAX_DEPEN_VEL 3.0f
 #define MSK_LIMIT_DISTANCE 0.1f
+#define MSK_SMALL_BLOCKS 16
 
-enum { ROW_LIMLO = 0, ROW_LIMHI = 1, ROW_CN = 2, ROW_CT1 = 3, ROW_CT2 = 4 };
-
-/* ---- cross-lane primitives ---------------------------------------------------------------- */
-template <int CTRL>
-MSK_DEV float dpp_mov(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
-}
-/* sum over the G lanes of a group as a balanced tree over adjacent pairs; every lane gets the result */
-template <int G>
-MSK_DEV float group_sum(float x) {
-  x = x + dpp_mov<0xB1>(x);   /* quad_perm [1,0,3,2]  : lane ^ 1                         */
-  x = x + dpp_mov<0x4E>(x);   /* quad_perm [2,3,0,1]  : lane ^ 2                         */
-  x = x + dpp_mov<0x141>(x);  /* row_half_mirror      : the other quad of the 8-lane half */
-  x = x + dpp_mov<0x140>(x);  /* row_mirror           : the other half of the 16-lane row */
-  if (G == 32) x = x + __shfl_xor(x, 16, 64);
-  return x;
-}
-/* wave-synchronous LDS hand-off inside one single-wave workgroup: LDS operations of a wave execute
- * in order, the fence keeps the compiler from moving accesses across it */
 MSK_DEV void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
+MSK_DEV float readlane_f(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
 
-template <int G>
-struct SolveLds {
-  static constexpr int EPB = 64 / G;                           /* envs per single-wave workgroup        */
-  static constexpr int POOL = EPB * MSK_ROWS_LDS;              /* rows of the block-shared LDS row pool */
-  static constexpr int JY = 0;                                 /* float2 [POOL][G]                      */
-  static constexpr int RS = 2 * POOL * G;                      /* float4 [POOL]                         */
-  static constexpr int LAM = RS + 4 * POOL;                    /* float  [POOL]                         */
-  static constexpr int JT = LAM + POOL;                        /* float  [EPB][G]  J of the row being built */
-  static constexpr int VD = JT + EPB * G;                      /* float  [EPB][2G] v | dq for the finish    */
-  static constexpr int CNT = VD + EPB * 2 * G;                 /* int    [EPB]     rows per env             */
-  static constexpr int TOTAL = CNT + 4;
+template <int CTRL>
+MSK_DEV float dpp_mov(float x) { /* every source lane of a row broadcast exists: `old` is never used */
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+/* value of lane `blk` of my GL-lane group, in every lane of the group (blk is wave-uniform) */
+template <int GL>
+MSK_DEV float group_bcast(float x, int blk) {
+  if (GL == 64) return readlane_f(x, blk);
+  if (GL == 32) return __shfl(x, blk, 32);
+  switch (blk) { /* row_newbcast:n — folds to one v_mov_dpp once the caller's loop is unrolled */
+    case 0: return dpp_mov<0x150>(x); case 1: return dpp_mov<0x151>(x); case 2: return dpp_mov<0x152>(x);
+    case 3: return dpp_mov<0x153>(x); case 4: return dpp_mov<0x154>(x); case 5: return dpp_mov<0x155>(x);
+    case 6: return dpp_mov<0x156>(x); case 7: return dpp_mov<0x157>(x); case 8: return dpp_mov<0x158>(x);
+    case 9: return dpp_mov<0x159>(x); case 10: return dpp_mov<0x15A>(x); case 11: return dpp_mov<0x15B>(x);
+    case 12: return dpp_mov<0x15C>(x); case 13: return dpp_mov<0x15D>(x); case 14: return dpp_mov<0x15E>(x);
+    default: return dpp_mov<0x15F>(x);
+  }
+}
+
+/* LDS image of one workgroup: 64/GL envs, each with a fixed part, plus one pool for Y and A */
+template <int NVP, int GL>
+struct CsLds {
+  static constexpr int EPW = 64 / GL;               /* envs per wavefront                              */
+  static constexpr int COLS = 3 * GL;
+  static constexpr int NDESC = GL < MSK_MAX_CONTACTS ? GL : MSK_MAX_CONTACTS;
+  static constexpr int W = 0;                       /* [NVP][NVP]                                   */
+  static constexpr int SC = W + NVP * NVP;          /* [NVP][8]  motion subspace columns            */
+  static constexpr int VF = SC + NVP * 8;           /* [NVP]     v*                                 */
+  static constexpr int VD = VF + NVP;               /* [2 NVP]   v | dq for the integration         */
+  static constexpr int LAMF = VD + 2 * NVP;         /* [COLS]    lambda per row (lambda_0, then final) */
+  static constexpr int LAMS = LAMF + COLS;          /* [COLS]    sum of lambda over position sweeps */
+  static constexpr int DESC = LAMS + COLS;          /* int [NDESC] pair*4 + point                   */
+  static constexpr int FIX = ((DESC + NDESC + 3) / 4) * 4;
+  /* pool (floats): per env  Y [3 nblk][NVP]  then  A [3 nblk][3][nblk]  (A[(lane, s')][col]) */
+  /* the big launch (GL = 64) owns the CU's whole LDS: as many blocks as fit in 160 KB */
+  static constexpr int MAXBLK = (GL < 64) ? GL : ((NVP <= 16) ? 64 : 60);
+  static constexpr int POOL = (GL == 64) ? (MAXBLK * 3 * NVP + 9 * MAXBLK * MAXBLK) : 5888;
+  static constexpr int TOTAL = EPW * FIX + POOL;
 };
 
-/* one Gauss-Seidel row update; all G lanes of the env hold the same scalars.
- * new impulse = clamp(lam - (J.v + bias) / (J.Y)); the bias part does not depend on v and is folded first */
-template <int G, bool POSIT>
-MSK_DEV float row_step(const float2 jy, const float4 rs, const float lam0, const float inv_h, const float inv_dt,
-                       const float beta_dt, float& v, const float dq, float& lam_n) {
-  const float jv = group_sum<G>(jy.x * v);
-  const float jdq = group_sum<G>(jy.x * dq);
-  const bool is_n = (__float_as_int(rs.w) & 7) <= ROW_CN;
-  const float cur = rs.x + jdq;
-  float bias_n;
-  if (POSIT) bias_n = (cur > 0.0f) ? cur * inv_h : fmaxf(cur * beta_dt, -MSK_MAX_DEPEN_VEL);
-  else bias_n = (cur > 0.0f) ? cur * inv_dt : 0.0f;
-  const float bias_t = POSIT ? jdq * inv_h : 0.0f;
-  const float bias = is_n ? bias_n : bias_t;
-  const float lim = rs.z * lam_n;
-  const float lo = is_n ? 0.0f : -lim, hi = is_n ? INFINITY : lim;
-  const float t0 = lam0 - bias * rs.y;
-  const float nl = fminf(fmaxf(fmaf(-jv, rs.y, t0), lo), hi);
-  if (is_n) lam_n = nl;
-  v = fmaf(jy.y, nl - lam0, v);
-  return nl;
+/* Sweep-invariant part of a row update: bias / A_rr, with the bias of a limit / normal row (penetration
+ * recovery or approach speed from c0 + J.dq) or of a friction row (drift J.dq).  b = J.dq only changes
+ * between sweeps, so every lane evaluates this once per sweep for its own rows, off the serial chain. */
+template <bool POSIT, bool FRICTION>
+MSK_DEV float bias_over_arr(float b, float c0, float rinv, float inv_h, float inv_dt, float beta_dt) {
+  float bias;
+  if (!FRICTION) {
+    const float cur = c0 + b;
+    if (POSIT) bias = (cur > 0.0f) ? cur * inv_h : fmaxf(cur * beta_dt, -MSK_MAX_DEPEN_VEL);
+    else bias = (cur > 0.0f) ? cur * inv_dt : 0.0f;
+  } else {
+    bias = POSIT ? b * inv_h : 0.0f;
+  }
+  return bias * rinv;
 }
 
-/* one sweep over the rows of an env: rl rows in the LDS pool (next row prefetched while the current one
- * reduces), the rest (rare: the block's pool is full) in the HBM spill area */
-template <int G, bool POSIT>
-MSK_DEV void sweep_once(const int nr, const int rl, const float inv_h, const float inv_dt, const float beta_dt,
-                        const float2* Ljy_k, const float4* Lrs, float* Llam, const float2* ovjy_k, const float4* ovrs,
-                        float* ovlam, const bool live, float& v, const float dq) {
-  float lam_n = 0.0f;
-  if (rl > 0) {
-    float2 jy = Ljy_k[0];
-    float4 rs = Lrs[0];
-    for (int r = 0; r < rl; ++r) {
-      const float lam0 = Llam[r];
-      const int rn = (r + 1 < rl) ? r + 1 : 0;
-      const float2 jy_n = Ljy_k[rn * G];
-      const float4 rs_n = Lrs[rn];
-      Llam[r] = row_step<G, POSIT>(jy, rs, lam0, inv_h, inv_dt, beta_dt, v, dq, lam_n);
-      jy = jy_n;
-      rs = rs_n;
-    }
-  }
-  for (int r = rl; r < nr; ++r) {
-    const float2 jy = ovjy_k[(r - rl) * G];
-    const float4 rs = ovrs[r - rl];
-    const float lam0 = ovlam[r - rl];
-    const float nl = row_step<G, POSIT>(jy, rs, lam0, inv_h, inv_dt, beta_dt, v, dq, lam_n);
-    if (live) ovlam[r - rl] = nl;
-  }
-}
-
-template <int G>
-__global__ void __launch_bounds__(64) k_solve(const DModel* __restrict__ m, DState st) {
-  typedef SolveLds<G> LY;
-  __shared__ __attribute__((aligned(16))) float lds[LY::TOTAL];
-  const int N = m->N;
-  const int lane = threadIdx.x;
-  const int k = lane % G;              /* my generalized coordinate */
-  const int le = lane / G;             /* env slot inside the wave  */
-  const int e_raw = blockIdx.x * LY::EPB + le;
-  const bool live = e_raw < N;
-  const int e = live ? e_raw : N - 1;  /* surplus groups shadow the last env and store nothing */
+/* GL lanes per env (16: four envs per wave, 64: one); e_first = env of group 0; DEFER: envs that do not fit
+ * queue themselves for the big launch */
+template <int NVP, int GL, bool DEFER>
+MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int e_first, float* lds_all) {
+  typedef CsLds<NVP, GL> LY;
+  constexpr int CAP = GL;
+  const int g = threadIdx.x / GL, lane = threadIdx.x % GL;   /* `lane` = my block / coordinate inside the env */
+  const int gshift = g * GL;
+  const unsigned long long gmask = (GL == 64) ? ~0ull : ((1ull << GL) - 1ull);
+  const bool in_range = e_first + g < m->N;
+  const int e = in_range ? e_first + g : m->N - 1;
+  float* lds = lds_all + g * LY::FIX;
+  float* pool = lds_all + LY::EPW * LY::FIX;
+#define GBALLOT(pred) ((__ballot(pred) >> gshift) & gmask)
+#ifdef MSK_PROFILE_PHASES
+  long long tph[8]; int nph = 0;
+#define PHASE() tph[nph++] = (long long)__builtin_readcyclecounter()
+#else
+#define PHASE()
+#endif
+  PHASE();
   const int nv = m->nv, nd = m->nd, np = m->np, npp = m->npp;
   const float dt = m->cfg.timestep;
   const int Np = m->cfg.solver_position_iterations, Nv = m->cfg.solver_velocity_iterations;
   const float h = dt / (float)Np;
   const float inv_h = 1.0f / h, inv_dt = 1.0f / dt, beta_dt = MSK_PEN_BETA / dt;
-  const unsigned gmask = (G == 32) ? 0xFFFFFFFFu : 0xFFFFu;
-
-  float* Ljt = lds + LY::JT + le * G;
-  float* Lvd = lds + LY::VD + le * 2 * G;
-  int* Lcnt = (int*)(lds + LY::CNT);
-
-  /* my coordinate's tables */
-  float Wk[G];
-  {
-    const float4* wp = (const float4*)(st.W + ((size_t)e * G + k) * G);
-#pragma unroll
-    for (int j = 0; j < G / 4; ++j) {
-      float4 w = wp[j];
-      Wk[4 * j] = w.x; Wk[4 * j + 1] = w.y; Wk[4 * j + 2] = w.z; Wk[4 * j + 3] = w.w;
-    }
-  }
-  sv6 Sk;
-  {
-    const float4* sp = (const float4*)(st.Scol + ((size_t)e * G + k) * 8);
-    float4 a = sp[0], b = sp[1];
-    Sk.a = v3_make(a.x, a.y, a.z);
-    Sk.l = v3_make(a.w, b.x, b.y);
-  }
-  const unsigned long long moves = (k < nv) ? m->coord_moves[k] : 0ull;
-  float v = st.vfree[(size_t)e * G + k];  /* zero for k >= nv */
-  float dq = 0.0f;
   float* E = EREC(st, m, e);
-  const float qk = (k < nd) ? E[m->lay.q + k] : 0.0f;
-  const float qdk = (k < nd) ? E[m->lay.qd + k] : 0.0f;
   int* cnts = st.ct_cnt + (size_t)e * npp;
   float* recs = st.ct_rec + (size_t)e * npp * MSK_CT_REC;
+  float* Lw = lds + LY::W;
+  float* Lsc = lds + LY::SC;
+  float* Lvf = lds + LY::VF;
+  float* Lvd = lds + LY::VD;
+  float* Llamf = lds + LY::LAMF;
+  float* Llams = lds + LY::LAMS;
+  int* Ldesc = (int*)(lds + LY::DESC);
 
-  /* ---- count the rows of every env of the block, carve the LDS pool ------------------------------- */
-  float c_lo = 3.0e38f, c_hi = 3.0e38f;   /* lane k owns dof k: distance to its limits */
-  if (k < nd) {
-    const float lo = m->dof_lo[k], hi = m->dof_hi[k];
-    if (!(lo < -1e30f && hi > 1e30f)) { c_lo = qk - lo; c_hi = hi - qk; }
+  /* ---- joint limits: lane d owns dof d ---------------------------------------------------------------- */
+  float c_lo = 3.0e38f, c_hi = 3.0e38f;
+  if (lane < nd) {
+    const float lo = m->dof_lo[lane], hi = m->dof_hi[lane], q = E[m->lay.q + lane];
+    if (!(lo < -1e30f && hi > 1e30f)) { c_lo = q - lo; c_hi = hi - q; }
   }
-  const unsigned bits_lo = (unsigned)(__ballot(c_lo < MSK_LIMIT_DISTANCE) >> (le * G)) & gmask;
-  const unsigned bits_hi = (unsigned)(__ballot(c_hi < MSK_LIMIT_DISTANCE) >> (le * G)) & gmask;
-  int my_points = 0;
-  for (int p0 = 0; p0 < np; p0 += G) my_points += (p0 + k < np) ? cnts[p0 + k] : 0;
-  const int points = (int)group_sum<G>((float)my_points);  /* <= 4 * MSK_MAX_PAIRS: exact in fp32 */
-  const int nr_total = __popc(bits_lo) + __popc(bits_hi) + 3 * min(points, MSK_MAX_CONTACTS);
-  if (k == 0) Lcnt[le] = nr_total;
-  wave_sync();
+  const unsigned long long blo = GBALLOT(c_lo < MSK_LIMIT_DISTANCE), bhi = GBALLOT(c_hi < MSK_LIMIT_DISTANCE);
+  const int nlim = __popcll(blo | bhi);
+
+  /* ---- contact points in canonical (pair, point) order; capacity MSK_MAX_CONTACTS ----------------------- */
   int base = 0;
+  for (int p0 = 0; p0 < np; p0 += GL) {
+    const int p = p0 + lane;
+    int cnt = (p < np) ? cnts[p] : 0;
+    int pre = 0, tot = 0;
 #pragma unroll
-  for (int j = 0; j < LY::EPB; ++j) base += (j < le) ? Lcnt[j] : 0;
-  const int rl = max(0, min(nr_total, LY::POOL - base));  /* my rows in LDS: pool slots base .. base+rl-1 */
-  float2* Ljy = (float2*)(lds + LY::JY) + (size_t)(base < LY::POOL ? base : 0) * G + k;
-  float4* Lrs = (float4*)(lds + LY::RS) + (base < LY::POOL ? base : 0);
-  float* Llam = lds + LY::LAM + (base < LY::POOL ? base : 0);
-  float2* ovjy = st.ov_jy + (size_t)e * MSK_MAX_ROWS * G + k;
-  float4* ovrs = st.ov_rs + (size_t)e * MSK_MAX_ROWS;
-  float* ovlam = st.ov_lam + (size_t)e * MSK_MAX_ROWS;
-
-  int nr = 0;
-  /* stores one finished row: all lanes pass the same scalars */
-  auto put_row = [&](float J, int kind, int code, float c0, float mu, float lam0) {
-    Ljt[k] = J;
-    wave_sync();
-    float Y = 0.0f;
-#pragma unroll
-    for (int j = 0; j < G / 4; ++j) {
-      const float4 jj = ((const float4*)Ljt)[j];
-      Y = fmaf(Wk[4 * j], jj.x, Y);
-      Y = fmaf(Wk[4 * j + 1], jj.y, Y);
-      Y = fmaf(Wk[4 * j + 2], jj.z, Y);
-      Y = fmaf(Wk[4 * j + 3], jj.w, Y);
+    for (int c = 1; c <= 4; ++c) {
+      const unsigned long long mk = GBALLOT(cnt >= c);
+      pre += __popcll(mk & ((1ull << lane) - 1ull));
+      tot += __popcll(mk);
     }
-    wave_sync();
-    const float d = group_sum<G>(J * Y);
-    const float rinv = 1.0f / d;
-    const float4 rs = make_float4(c0, rinv, mu, __int_as_float(kind | (code << 3)));
-    if (nr < rl) {
-      Ljy[nr * G] = make_float2(J, Y);
-      Lrs[nr] = rs;
-      Llam[nr] = lam0;
-    } else if (live) {
-      ovjy[(nr - rl) * G] = make_float2(J, Y);
-      ovrs[nr - rl] = rs;
-      ovlam[nr - rl] = lam0;
+    const int first = base + pre;
+    if (!DEFER && first + cnt > MSK_MAX_CONTACTS) { /* capacity exhausted: later points are dropped, the slot is trimmed */
+      const int keep = max(0, MSK_MAX_CONTACTS - first);
+      if (cnt > 0) cnts[p] = keep;
+      cnt = keep;
     }
-    if (lam0 != 0.0f) v = fmaf(Y, lam0, v); /* warm start */
-    nr++;
-  };
-
-  /* ---- joint-limit rows -------------------------------------------------------------------------- */
+    if (first + cnt <= LY::NDESC)
+      for (int kk = 0; kk < cnt; ++kk) Ldesc[first + kk] = p * 4 + kk;
+    base += tot;
+  }
+  bool overflow = base > MSK_MAX_CONTACTS;
+  int ncont = overflow ? MSK_MAX_CONTACTS : base;
+  if (!DEFER && nlim + ncont > LY::MAXBLK) { /* LDS image of the big launch exhausted (NVP = 32 only): trailing points ignored */
+    ncont = LY::MAXBLK - nlim;
+    overflow = true;
+  }
+  int nblk = nlim + ncont;
+  /* carve the pool: groups in order; a group that does not fit (or is out of range) sits this launch out */
+  bool active = in_range;
+  int pbase = 0;
   {
-    unsigned both = bits_lo | bits_hi;
-    while (both) {
-      const int d = __ffs(both) - 1;
-      both &= both - 1;
-      const float c0lo = __shfl(c_lo, d, G), c0hi = __shfl(c_hi, d, G);
-      if ((bits_lo >> d) & 1) put_row((k == d) ? 1.0f : 0.0f, ROW_LIMLO, d, c0lo, 0.0f, 0.0f);
-      if ((bits_hi >> d) & 1) put_row((k == d) ? -1.0f : 0.0f, ROW_LIMHI, d, c0hi, 0.0f, 0.0f);
+    int off = 0;
+#pragma unroll
+    for (int j = 0; j < LY::EPW; ++j) {
+      const int nbj = __builtin_amdgcn_readlane(nblk, j * GL);
+      const int need = nbj * 3 * NVP + 9 * nbj * nbj;
+      const bool fits = nbj <= CAP && off + need <= LY::POOL;
+      if (j == g) { pbase = off; if (!fits) active = false; }
+      if (fits) off += need;
     }
   }
-
-  /* ---- contact rows, candidate pairs in canonical order ------------------------------------------- */
-  int ncontacts = 0;
-  bool overflow = false;
-  for (int p0 = 0; p0 < np; p0 += G) {
-    const int cnt_mine = (p0 + k < np) ? cnts[p0 + k] : 0;
-    unsigned bits = (unsigned)(__ballot(cnt_mine > 0) >> (le * G)) & gmask;
-    if (overflow) { /* capacity exhausted earlier: the remaining slots are emptied */
-      if (live && p0 + k < np && cnt_mine > 0) cnts[p0 + k] = 0;
-      continue;
-    }
-    while (bits) {
-      const int j = __ffs(bits) - 1;
-      bits &= bits - 1;
-      const int p = p0 + j;
-      const int cnt = __shfl(cnt_mine, j, G);
-      if (overflow) {
-        if (live && k == 0) cnts[p] = 0;
-        continue;
-      }
-      const DPairInfo pi = m->pinfo[p];
-      const float4* rec = (const float4*)(recs + (size_t)p * MSK_CT_REC);
-      const float4 r0 = rec[0];
-      const v3 n = v3_make(r0.x, r0.y, r0.z);
-      v3 t1, t2;
-      msk_tangents(n, &t1, &t2);
-      const float4 p01 = rec[1], p12 = rec[2], p23 = rec[3], sp = rec[4];
-      const float pos[12] = {p01.x, p01.y, p01.z, p01.w, p12.x, p12.y, p12.z, p12.w, p23.x, p23.y, p23.z, p23.w};
-      const float sep[4] = {sp.x, sp.y, sp.z, sp.w};
-      const float4 l0 = rec[5], l1 = rec[6], l2 = rec[7];
-      const float lam[12] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w};
-      const bool mvA = pi.ba >= 0 && ((moves >> pi.ba) & 1), mvB = pi.bb >= 0 && ((moves >> pi.bb) & 1);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        if (kk >= cnt) break;
-        if (ncontacts >= MSK_MAX_CONTACTS) {
-          overflow = true;
-          if (live && k == 0) cnts[p] = kk;
-          break;
-        }
-        const v3 pt = v3_make(pos[3 * kk], pos[3 * kk + 1], pos[3 * kk + 2]);
-        const v3 dirs[3] = {n, t1, t2};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          sv6 F;
-          F.a = v3_cross(pt, dirs[a]);
-          F.l = dirs[a];
-          const float x = sv6_dot(Sk, F);
-          float J = 0.0f;
-          if (mvA) J = fmaf(1.0f, x, J);
-          if (mvB) J = fmaf(-1.0f, x, J);
-          put_row(J, ROW_CN + a, p * 4 + kk, sep[kk], pi.mu, lam[3 * kk + a]);
-        }
-        ncontacts++;
-      }
-    }
-  }
-  if (live && k == 0) {
-    st.env_ncontacts[e] = ncontacts;
+  if (DEFER && in_range && !active && lane == 0) st.big_list[atomicAdd(st.big_count, 1)] = e;
+  if (!active) nblk = 0;
+  if (active && lane == 0) {
+    st.env_ncontacts[e] = ncont;
     if (overflow) atomicOr(st.env_overflow, 1);
   }
-  wave_sync();
+  const int nbmax = (GL == 64) ? nblk : max(max(__builtin_amdgcn_readlane(nblk, 0), __builtin_amdgcn_readlane(nblk, 16 % 64)),
+                                           max(__builtin_amdgcn_readlane(nblk, 32 % 64), __builtin_amdgcn_readlane(nblk, 48 % 64)));
+  if (nbmax == 0 && __ballot(active) == 0ull) return;
+  float* Ly = pool + pbase;
+  float* La = Ly + nblk * 3 * NVP;
+  const int nb = nblk > 0 ? nblk : 1; /* row stride of my A image */
 
-  /* ---- Gauss-Seidel sweeps: Np position iterations (dq advances by h*v after each), Nv velocity ones --- */
-  for (int it = 0; it < Np; ++it) {
-    sweep_once<G, true>(nr, rl, inv_h, inv_dt, beta_dt, Ljy, Lrs, Llam, ovjy, ovrs, ovlam, live, v, dq);
-    dq = fmaf(h, v, dq);
+  PHASE();
+  /* ---- stage the env's solver tables in LDS -------------------------------------------------------------- */
+  {
+    const float4* wsrc = (const float4*)(st.W + (size_t)e * NVP * NVP);
+    for (int i = lane; i < NVP * NVP / 4; i += GL) ((float4*)Lw)[i] = wsrc[i];
+    const float4* ssrc = (const float4*)(st.Scol + (size_t)e * NVP * 8);
+    for (int i = lane; i < NVP * 2; i += GL) ((float4*)Lsc)[i] = ssrc[i];
+    if (lane < NVP) Lvf[lane] = st.vfree[(size_t)e * NVP + lane];
   }
-  for (int it = 0; it < Nv; ++it)
-    sweep_once<G, false>(nr, rl, inv_h, inv_dt, beta_dt, Ljy, Lrs, Llam, ovjy, ovrs, ovlam, live, v, dq);
   wave_sync();
 
-  /* ---- impulses back to the contact slots (reports + next step's warm start) ------------------------ */
-  for (int r = k; r < nr; r += G) {
-    const float4 rs = (r < rl) ? Lrs[r] : ovrs[r - rl];
-    const int w = __float_as_int(rs.w), kind = w & 7, code = w >> 3;
-    if (kind >= ROW_CN && live) {
-      const float lam = (r < rl) ? Llam[r] : ovlam[r - rl];
-      recs[(size_t)(code >> 2) * MSK_CT_REC + 20 + (code & 3) * 3 + (kind - ROW_CN)] = lam;
+  /* ---- my block: rows J, scalars ---------------------------------------------------------------------------- */
+  float J[3][NVP];
+  float c0[3] = {0.0f, 0.0f, 0.0f}, lam[3] = {0.0f, 0.0f, 0.0f};
+  bool valid[3] = {false, false, false};
+  float mu = 0.0f;
+  int code = -1; /* contact blocks: pair * 4 + point */
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) J[s][k] = 0.0f;
+  const bool is_contact = lane >= nlim && lane < nblk;
+  if (lane < nlim) {
+    unsigned long long mk = blo | bhi;
+    for (int t = 0; t < lane; ++t) mk &= mk - 1ull;
+    const int d = __ffsll((long long)mk) - 1;
+    valid[0] = (blo >> d) & 1ull;
+    valid[1] = (bhi >> d) & 1ull;
+    const float q = E[m->lay.q + d];
+    c0[0] = q - m->dof_lo[d];
+    c0[1] = m->dof_hi[d] - q;
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) {
+      if (k == d) { J[0][k] = valid[0] ? 1.0f : 0.0f; J[1][k] = valid[1] ? -1.0f : 0.0f; }
+    }
+  } else if (is_contact) {
+    code = Ldesc[lane - nlim];
+    const int p = code >> 2, kk = code & 3;
+    const DPairInfo pi = m->pinfo[p];
+    const float* rec = recs + (size_t)p * MSK_CT_REC;
+    const v3 n = v3_make(rec[0], rec[1], rec[2]);
+    v3 t1, t2;
+    msk_tangents(n, &t1, &t2);
+    const v3 pt = v3_make(rec[4 + 3 * kk], rec[4 + 3 * kk + 1], rec[4 + 3 * kk + 2]);
+    const float sep = rec[16 + kk];
+    mu = pi.mu;
+    /* coordinates that move the two bodies (bit k) */
+    const unsigned coordsA = pi.ba >= 0 ? m->body_coords[pi.ba] : 0u, coordsB = pi.bb >= 0 ? m->body_coords[pi.bb] : 0u;
+    const v3 dirs[3] = {n, t1, t2};
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      valid[s] = true;
+      c0[s] = sep;
+      lam[s] = rec[20 + 3 * kk + s];
+      sv6 F;
+      F.a = v3_cross(pt, dirs[s]);
+      F.l = dirs[s];
+#pragma unroll
+      for (int k = 0; k < NVP; ++k) {
+        if (k < nv) {
+          const bool mvA = (coordsA >> k) & 1u, mvB = (coordsB >> k) & 1u;
+          const float* sc = Lsc + k * 8;
+          sv6 Sk;
+          Sk.a = v3_make(sc[0], sc[1], sc[2]);
+          Sk.l = v3_make(sc[3], sc[4], sc[5]);
+          const float x = sv6_dot(Sk, F);
+          float Jk = 0.0f;
+          if (mvA) Jk = fmaf(1.0f, x, Jk);
+          if (mvB) Jk = fmaf(-1.0f, x, Jk);
+          J[s][k] = Jk;
+        }
+      }
     }
   }
-
-  /* ---- integrate ------------------------------------------------------------------------------------- */
-  Lvd[k] = v;
-  Lvd[G + k] = dq;
-  wave_sync();
-  if (live && k < nd) {
-    E[m->lay.qacc + k] = (v - qdk) / dt;
-    E[m->lay.q + k] = qk + dq;
-    E[m->lay.qd + k] = v;
+  PHASE();
+  /* Y = W J^T, parked in LDS; lambda_0 published for the warm start */
+  if (lane < nblk) {
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) {
+      float y0 = 0.0f, y1 = 0.0f, y2 = 0.0f;
+#pragma unroll
+      for (int j = 0; j < NVP; ++j) {
+        const float w = Lw[k * NVP + j];
+        y0 = fmaf(w, J[0][j], y0);
+        y1 = fmaf(w, J[1][j], y1);
+        y2 = fmaf(w, J[2][j], y2);
+      }
+      Ly[(lane * 3 + 0) * NVP + k] = y0;
+      Ly[(lane * 3 + 1) * NVP + k] = y1;
+      Ly[(lane * 3 + 2) * NVP + k] = y2;
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) Llamf[lane * 3 + s] = lam[s];
   }
-  const int fb = (k < nv) ? m->coord_body[k] : -1;
-  if (live && fb >= 0) {
+  wave_sync();
+  const unsigned long long vm0 = GBALLOT(valid[0]), vm1 = GBALLOT(valid[1]), vm2 = GBALLOT(valid[2]);
+
+  PHASE();
+  /* ---- constraint-space operator: A[(me, s')][col] = J_(me,s') . Y_col, column-major in LDS -------------------- */
+  float av[3], bv[3] = {0.0f, 0.0f, 0.0f}, ls[3] = {0.0f, 0.0f, 0.0f}, rinv[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) acc = fmaf(J[s][k], Lvf[k], acc);
+    av[s] = acc;
+  }
+  for (int blk = 0; blk < nblk; ++blk) { /* per-group trip count: the groups of a wave diverge here, no cross-lane ops inside */
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const unsigned long long vm = (s == 0) ? vm0 : ((s == 1) ? vm1 : vm2);
+      const int col = blk * 3 + s;
+      if (!((vm >> blk) & 1ull)) { /* a row that does not exist is an all-zero row: its column is zero */
+        if (lane < nblk) {
+          La[(col * 3 + 0) * nb + lane] = 0.0f;
+          La[(col * 3 + 1) * nb + lane] = 0.0f;
+          La[(col * 3 + 2) * nb + lane] = 0.0f;
+        }
+        continue;
+      }
+      const float* ycol = Ly + col * NVP;
+      float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
+#pragma unroll
+      for (int k = 0; k < NVP; ++k) {
+        const float y = ycol[k];
+        d0 = fmaf(J[0][k], y, d0);
+        d1 = fmaf(J[1][k], y, d1);
+        d2 = fmaf(J[2][k], y, d2);
+      }
+      if (lane < nblk) {
+        La[(col * 3 + 0) * nb + lane] = d0;
+        La[(col * 3 + 1) * nb + lane] = d1;
+        La[(col * 3 + 2) * nb + lane] = d2;
+      }
+      if (lane == blk) { /* my own diagonal */
+        if (s == 0) rinv[0] = 1.0f / d0;
+        if (s == 1) rinv[1] = 1.0f / d1;
+        if (s == 2) rinv[2] = 1.0f / d2;
+      }
+      /* warm start: a += A[:, col] * lambda_0[col] (rows ascending == columns ascending) */
+      const float l0 = Llamf[col];
+      av[0] = fmaf(d0, l0, av[0]);
+      av[1] = fmaf(d1, l0, av[1]);
+      av[2] = fmaf(d2, l0, av[2]);
+    }
+  }
+  wave_sync();
+
+  PHASE();
+  /* ---- Gauss-Seidel sweeps ----------------------------------------------------------------------------------------- */
+  /* my rows' entries of the three columns of block blk.  Lanes past their env's last block re-read its last
+   * block: the impulse change they receive for such a step is exactly zero (zero rows), so any finite value does */
+  const int lrow = lane < nblk ? lane : 0;
+  auto load_cols = [&](int blk, float* dst) {
+    const int bc = blk < nblk ? blk : (nblk > 0 ? nblk - 1 : 0);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dst[i] = La[(bc * 9 + i) * nb + lrow];
+  };
+  /* rows that exist in at least one env of the wave: bit blk*3+s (wave-uniform, tested with scalar ops) */
+  unsigned long long wrows = 0ull;
+  if (GL == 64) {
+    for (int blk = 0; blk < nblk; ++blk)
+      wrows |= (((vm0 >> blk) & 1ull) | (((vm1 >> blk) & 1ull) << 1) | (((vm2 >> blk) & 1ull) << 2)) << ((blk * 3) & 63);
+  } else {
+#pragma unroll
+    for (int blk = 0; blk < 16; ++blk) {
+      if (blk >= nbmax) break;
+      if (__ballot((vm0 >> blk) & 1ull)) wrows |= 1ull << (blk * 3);
+      if (__ballot((vm1 >> blk) & 1ull)) wrows |= 1ull << (blk * 3 + 1);
+      if (__ballot((vm2 >> blk) & 1ull)) wrows |= 1ull << (blk * 3 + 2);
+    }
+  }
+  /* clamp bounds without selects: hi = fma(flim, lam_n, hi_c), lo = fma(-flim, lam_n, 0)
+   *   contact block: flim = mu, hi_c = 0 -> +-mu*lam_n ; limit block (slot 1 = upper limit row): flim = 0, hi_c = inf -> [0, inf) */
+  const float flim = is_contact ? mu : 0.0f;
+  const float hi_c = is_contact ? 0.0f : INFINITY;
+  auto sweep = [&](auto posit_tag) {
+    constexpr bool POSIT = decltype(posit_tag)::value;
+    /* sweep-invariant bias terms of my rows */
+    const float t0 = bias_over_arr<POSIT, false>(bv[0], c0[0], rinv[0], inv_h, inv_dt, beta_dt);
+    const float t1f = bias_over_arr<POSIT, true>(bv[1], c0[1], rinv[1], inv_h, inv_dt, beta_dt);
+    const float t1n = bias_over_arr<POSIT, false>(bv[1], c0[1], rinv[1], inv_h, inv_dt, beta_dt);
+    const float t1 = is_contact ? t1f : t1n;
+    const float t2 = bias_over_arr<POSIT, true>(bv[2], c0[2], rinv[2], inv_h, inv_dt, beta_dt);
+    float Ac[9], An[9];
+    load_cols(0, Ac);
+    auto block_steps = [&](const int blk) {
+      load_cols((blk + 1 < nbmax) ? blk + 1 : 0, An);
+      const bool owner = lane == blk;
+      const unsigned rowbits = (GL == 64) ? (unsigned)(((vm0 >> blk) & 1ull) | (((vm1 >> blk) & 1ull) << 1) | (((vm2 >> blk) & 1ull) << 2))
+                                          : (unsigned)((wrows >> (blk * 3)) & 7ull);
+      /* new impulse = clamp(lam - (J.v + bias) / A_rr); a row that does not exist has rinv = lam = 0 -> stays 0 */
+      if (rowbits & 1u) {
+        const float nl = fminf(fmaxf(fmaf(-av[0], rinv[0], lam[0] - t0), 0.0f), INFINITY);
+        const float dl = group_bcast<GL>(nl - lam[0], blk);
+        if (owner) lam[0] = nl;
+        av[0] = fmaf(Ac[0], dl, av[0]); av[1] = fmaf(Ac[1], dl, av[1]); av[2] = fmaf(Ac[2], dl, av[2]);
+      }
+      if (rowbits & 2u) {
+        const float hi = fmaf(flim, lam[0], hi_c), lo = fmaf(-flim, lam[0], 0.0f);
+        const float nl = fminf(fmaxf(fmaf(-av[1], rinv[1], lam[1] - t1), lo), hi);
+        const float dl = group_bcast<GL>(nl - lam[1], blk);
+        if (owner) lam[1] = nl;
+        av[0] = fmaf(Ac[3], dl, av[0]); av[1] = fmaf(Ac[4], dl, av[1]); av[2] = fmaf(Ac[5], dl, av[2]);
+      }
+      if (rowbits & 4u) {
+        const float hi = flim * lam[0];
+        const float nl = fminf(fmaxf(fmaf(-av[2], rinv[2], lam[2] - t2), -hi), hi);
+        const float dl = group_bcast<GL>(nl - lam[2], blk);
+        if (owner) lam[2] = nl;
+        av[0] = fmaf(Ac[6], dl, av[0]); av[1] = fmaf(Ac[7], dl, av[1]); av[2] = fmaf(Ac[8], dl, av[2]);
+      }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Ac[i] = An[i];
+    };
+    if (GL == 16) { /* unrolled: the block index becomes the immediate of row_newbcast */
+#pragma unroll
+      for (int blk = 0; blk < 16; ++blk) {
+        if (blk >= nbmax) break;
+        block_steps(blk);
+      }
+    } else {
+      for (int blk = 0; blk < nbmax; ++blk) block_steps(blk);
+    }
+    if (POSIT) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        bv[s] = fmaf(h, av[s], bv[s]);
+        ls[s] += lam[s];
+      }
+    }
+  };
+  for (int it = 0; it < Np; ++it) sweep(std::true_type{});
+  for (int it = 0; it < Nv; ++it) sweep(std::false_type{});
+
+  PHASE();
+  /* ---- back to generalized coordinates ----------------------------------------------------------------------------------- */
+  if (lane < nblk) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      Llamf[lane * 3 + s] = lam[s];
+      Llams[lane * 3 + s] = ls[s];
+    }
+    if (is_contact) { /* impulses back to the contact slot (reports + next step's warm start) */
+      float* rec = recs + (size_t)(code >> 2) * MSK_CT_REC + 20 + (code & 3) * 3;
+      rec[0] = lam[0]; rec[1] = lam[1]; rec[2] = lam[2];
+    }
+  }
+  wave_sync();
+  float v = 0.0f, dq = 0.0f;
+  if (lane < NVP) {
+    const float vf = Lvf[lane];
+    float vk = vf, sk = (float)Np * vf;
+    for (int blk = 0; blk < nblk; ++blk) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const unsigned long long vm = (s == 0) ? vm0 : ((s == 1) ? vm1 : vm2);
+        if (!((vm >> blk) & 1ull)) continue;
+        const int col = blk * 3 + s;
+        const float y = Ly[col * NVP + lane];
+        vk = fmaf(y, Llamf[col], vk);
+        sk = fmaf(y, Llams[col], sk);
+      }
+    }
+    v = vk;
+    dq = h * sk;
+    Lvd[lane] = v;
+    Lvd[NVP + lane] = dq;
+  }
+  wave_sync();
+
+  /* ---- integrate ------------------------------------------------------------------------------------------------------------ */
+  if (active && lane < nd) {
+    const float q = E[m->lay.q + lane], qd = E[m->lay.qd + lane];
+    E[m->lay.qacc + lane] = (v - qd) / dt;
+    E[m->lay.q + lane] = q + dq;
+    E[m->lay.qd + lane] = v;
+  }
+  const int fb = (active && lane < nv) ? m->coord_body[lane] : -1;
+  if (fb >= 0) {
+    const int k = lane;
     const DBody* b = &m->bodies[fb];
-    const v3 dx = v3_make(Lvd[G + k], Lvd[G + k + 1], Lvd[G + k + 2]);
-    const v3 dr = v3_make(Lvd[G + k + 3], Lvd[G + k + 4], Lvd[G + k + 5]);
+    const v3 dx = v3_make(Lvd[NVP + k], Lvd[NVP + k + 1], Lvd[NVP + k + 2]);
+    const v3 dr = v3_make(Lvd[NVP + k + 3], Lvd[NVP + k + 4], Lvd[NVP + k + 5]);
     const v3 cw = v3_add(load_v3(E, m->lay.comw, fb), dx);
     pose T = load_pose(E, m->lay.bpose, fb);
     const quat qn = quat_normalize(quat_mul(quat_from_rotvec(dr), T.q));
@@ -338,6 +494,29 @@ __global__ void __launch_bounds__(64) k_solve(const DModel* __restrict__ m, DSta
     store_pose(E, m->lay.bpose, fb, T);
     store_v3(E, m->lay.blin, fb, v3_make(Lvd[k], Lvd[k + 1], Lvd[k + 2]));
     store_v3(E, m->lay.bang, fb, v3_make(Lvd[k + 3], Lvd[k + 4], Lvd[k + 5]));
+  }
+  PHASE();
+#ifdef MSK_PROFILE_PHASES
+  if (active && lane == 0) for (int i = 0; i < 7; ++i) st.dbg[(size_t)e * 8 + i] = tph[i];
+#endif
+#undef PHASE
+#undef GBALLOT
+}
+
+/* every env, 64/GL per wavefront; envs that do not fit the LDS pool defer to k_csolve_big */
+template <int NVP, int GL>
+__global__ void __launch_bounds__(64) k_csolve(const DModel* __restrict__ m, DState st) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  solve_env<NVP, GL, true>(m, st, blockIdx.x * (64 / GL), lds);
+}
+
+template <int NVP>
+__global__ void __launch_bounds__(64) k_csolve_big(const DModel* __restrict__ m, DState st) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int count = *st.big_count;
+  for (int i = blockIdx.x; i < count; i += gridDim.x) {
+    solve_env<NVP, 64, false>(m, st, st.big_list[i], lds);
+    wave_sync();
   }
 }
 

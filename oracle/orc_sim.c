@@ -18,11 +18,13 @@
  *                      point, in generalized coordinates: J_k = (+-) S_k . F for every coordinate k
  *                      that moves the body (S_k = motion subspace column of coordinate k, free
  *                      bodies included), response Y = W J^T with W = block-diag(A^-1, 1/m, Iw^-1)
- *   5. TGS             position iterations = sub-steps of dt/Np: one Gauss-Seidel sweep
- *                      each, errors re-linearised from the accumulated displacement dq;
- *                      then velocity iterations without penetration bias.  Dot products over
- *                      the generalized coordinates are balanced pairwise trees over the padded
- *                      width (16 or 32): the order a 16/32-lane butterfly reduction produces
+ *   5. TGS             in constraint space: A = J W J^T (row-by-row sequential dot products),
+ *                      a = J v is carried per row instead of v, b = J dq likewise; position
+ *                      iterations = sub-steps of dt/Np, one Gauss-Seidel sweep each (a row update
+ *                      adds its column of A, scaled by the impulse change, to a), errors
+ *                      re-linearised from b; then velocity iterations without penetration bias.
+ *                      v and dq are recovered at the end from the impulses: v = v* + Y^T lambda,
+ *                      dq = h (Np v* + Y^T sum_it lambda_it)
  *   6. integrate       q += dq, free bodies x += dq_lin, R = exp(dq_ang) R; kinematics
  */
 #include "orc_sim.h"
@@ -43,6 +45,8 @@ typedef struct {
   float rinv;   /* 1 / (J . Y) */
   float mu;
   float lam;    /* accumulated impulse */
+  float a, b;   /* J . v and J . dq, carried in constraint space */
+  float lsum;   /* sum of lam over the position iterations */
 } orc_row;
 
 typedef struct {
@@ -303,13 +307,11 @@ static void collide(const orc_ctx* c, orc_env* e) {
 }
 
 /* ---- 4. rows ---------------------------------------------------------------------- */
-/* balanced pairwise sum of a[i]*b[i], i < npad (npad = 16 or 32; entries >= nv are zero) */
-static float tree_dot(const float* a, const float* b, int nv, int npad) {
-  float t[MSK_MAX_NV];
-  for (int i = 0; i < npad; ++i) t[i] = (i < nv) ? a[i] * b[i] : 0.0f;
-  for (int w = npad; w > 1; w >>= 1)
-    for (int i = 0; i < w / 2; ++i) t[i] = t[2 * i] + t[2 * i + 1];
-  return t[0];
+/* sequential dot product over the padded width (entries >= nv are zero) */
+static float dot_seq(const float* a, const float* b, int nv, int npad) {
+  float acc = 0.0f;
+  for (int k = 0; k < npad; ++k) acc = fmaf((k < nv) ? a[k] : 0.0f, (k < nv) ? b[k] : 0.0f, acc);
+  return acc;
 }
 
 /* per-coordinate tables: Scol, W, moves */
@@ -354,14 +356,13 @@ static void jac_point(const orc_ctx* c, const orc_scratch* s, int body, v3 p, v3
     if ((s->moves[k] >> body) & 1) J[k] = fmaf(sgn, sv6_dot(s->Scol[k], F), J[k]);
 }
 
-/* Y = W J^T (full padded width, in coordinate order), rinv = 1 / (J . Y) */
+/* Y = W J^T (full padded width, in coordinate order) */
 static void finish_row(const orc_ctx* c, const orc_scratch* s, orc_row* r) {
   for (int i = 0; i < c->nv; ++i) {
     float a = 0.0f;
     for (int k = 0; k < s->npad; ++k) a = fmaf(s->W[i][k], (k < c->nv) ? r->J[k] : 0.0f, a);
     r->Y[i] = a;
   }
-  r->rinv = 1.0f / tree_dot(r->J, r->Y, c->nv, s->npad);
 }
 
 /* ---- 5./6. solve and integrate ----------------------------------------------------- */
@@ -379,9 +380,7 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
   collide(c, e);
   coordinate_tables(c, &s);
 
-  float v[MSK_MAX_NV], dq[MSK_MAX_NV];
-  for (int k = 0; k < nv; ++k) { v[k] = s.vfree[k]; dq[k] = 0.0f; }
-
+  static _Thread_local float A[2 * MSK_MAX_DOF + 3 * MSK_MAX_CONTACTS][2 * MSK_MAX_DOF + 3 * MSK_MAX_CONTACTS];
   int nr = 0;
   for (int i = 0; i < c->nb; ++i) {
     const orc_body* b = &c->bodies[i];
@@ -413,10 +412,16 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
       jac_point(c, &s, ct->ba, ct->pos, dirs[a], 1.0f, r->J);
       jac_point(c, &s, ct->bb, ct->pos, dirs[a], -1.0f, r->J);
       finish_row(c, &s, r);
-      r->lam = ct->lam[a];
-      if (r->lam != 0.0f) /* warm start */
-        for (int kk = 0; kk < nv; ++kk) v[kk] = fmaf(r->Y[kk], r->lam, v[kk]);
+      r->lam = ct->lam[a]; /* warm start */
     }
+  }
+  /* constraint-space operator and initial state: a = J (v* + Y^T lambda_0) */
+  for (int i = 0; i < nr; ++i) {
+    for (int r = 0; r < nr; ++r) A[i][r] = dot_seq(rows[i].J, rows[r].Y, nv, s.npad);
+    rows[i].rinv = 1.0f / A[i][i];
+    float a = dot_seq(rows[i].J, s.vfree, nv, s.npad);
+    for (int r = 0; r < nr; ++r) a = fmaf(A[i][r], rows[r].lam, a);
+    rows[i].a = a;
   }
 
   for (int it = 0; it < Np + Nv; ++it) {
@@ -424,27 +429,40 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
     float lam_n = 0.0f; /* impulse of the most recent normal row: friction cone of the two rows after it */
     for (int ri = 0; ri < nr; ++ri) {
       orc_row* r = &rows[ri];
-      const float jv = tree_dot(r->J, v, nv, s.npad), jdq = tree_dot(r->J, dq, nv, s.npad);
-      /* new impulse = clamp(lam - (jv + bias) / (J.Y)); the bias part does not depend on v and is folded first */
+      /* new impulse = clamp(lam - (J.v + bias) / (J.Y)); the bias part does not depend on v and is folded first */
       float bias, lo, hi;
       if (r->kind <= ROW_CN) {
-        const float cur = r->c0 + jdq;
+        const float cur = r->c0 + r->b;
         if (posit) bias = (cur > 0.0f) ? cur * inv_h : fmaxf(cur * beta_dt, -ORC_MAX_DEPEN_VEL);
         else bias = (cur > 0.0f) ? cur * inv_dt : 0.0f;
         lo = 0.0f; hi = INFINITY;
       } else { /* friction */
-        bias = posit ? jdq * inv_h : 0.0f;
-        hi = r->mu * lam_n; lo = -hi;
+        bias = posit ? r->b * inv_h : 0.0f;
+        hi = r->mu * lam_n; lo = -hi; /* == fma(+-mu, lam_n, 0) on the device */
       }
       const float t0 = r->lam - bias * r->rinv;
-      const float nl = fminf(fmaxf(fmaf(-jv, r->rinv, t0), lo), hi);
+      const float nl = fminf(fmaxf(fmaf(-r->a, r->rinv, t0), lo), hi);
       if (r->kind <= ROW_CN) lam_n = nl;
       const float dl = nl - r->lam;
       r->lam = nl;
-      for (int k = 0; k < nv; ++k) v[k] = fmaf(r->Y[k], dl, v[k]);
+      for (int i = 0; i < nr; ++i) rows[i].a = fmaf(A[i][ri], dl, rows[i].a);
     }
     if (posit)
-      for (int k = 0; k < nv; ++k) dq[k] = fmaf(h, v[k], dq[k]);
+      for (int i = 0; i < nr; ++i) {
+        rows[i].b = fmaf(h, rows[i].a, rows[i].b);
+        rows[i].lsum += rows[i].lam;
+      }
+  }
+  /* back to generalized coordinates */
+  float v[MSK_MAX_NV], dq[MSK_MAX_NV];
+  for (int k = 0; k < nv; ++k) {
+    float vk = s.vfree[k], sk = (float)Np * s.vfree[k];
+    for (int r = 0; r < nr; ++r) {
+      vk = fmaf(rows[r].Y[k], rows[r].lam, vk);
+      sk = fmaf(rows[r].Y[k], rows[r].lsum, sk);
+    }
+    v[k] = vk;
+    dq[k] = h * sk;
   }
 
   /* contact impulses for the reports */

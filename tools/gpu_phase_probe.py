@@ -1,0 +1,33 @@
+"""Development aid: builds the library with -DMSK_PROFILE_PHASES into /tmp and prints the mean cycles of the
+solver phases (count | stage | rows J | Y | A | sweeps | finish) per contact-count class."""
+import ctypes as C, os, subprocess, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+src = os.path.join(ROOT, "maniskill_amd", "csrc")
+lib = "/tmp/libmsk_prof.so"
+subprocess.check_call(f"cd {src} && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden "
+                      f"-Wno-unused-value -DMSK_PROFILE_PHASES -o {lib} msk_physx.hip", shell=True)
+from maniskill_amd import _native as N
+N.DEFAULT_LIB = lib
+from maniskill_amd.envs.pick_cube import PickCubeEnv
+n = 4096
+env = PickCubeEnv(num_envs=n, device="cuda:0")
+env.reset(seed=2022); torch.manual_seed(0)
+dll = env.px.lib.dll
+dll.msk_debug_phases.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+names = ["count", "stage", "rowsJ", "Y", "A", "sweeps", "finish"]
+def report(tag):
+    out = np.zeros(n * 8, dtype=np.int64)
+    dll.msk_debug_phases(env.px.ctx, out.ctypes.data_as(C.POINTER(C.c_longlong)))
+    t = out.reshape(n, 8)
+    d = np.diff(t[:, :7], axis=1)
+    c = env.px.get_env_contact_counts()
+    for lo, hi in ((0, 4), (5, 12), (13, 20), (21, 48)):
+        sel = (c >= lo) & (c <= hi)
+        if sel.sum():
+            print(tag, f"contacts {lo}-{hi} n={sel.sum()}", {k: int(v) for k, v in zip(names[1:], d[sel].mean(0))}, "total", int((t[sel, 6] - t[sel, 0]).mean()))
+for _ in range(3): env.step(torch.zeros(n, 8, device="cuda:0"))
+report("zero  ")
+for _ in range(60): env.step(2 * torch.rand(n, 8, device="cuda:0") - 1)
+report("random")
