@@ -1,0 +1,55 @@
+/*
+ * msk_task.h — C ABI of the fused task kernels (PickCube-v1).
+ *
+ * ManiSkill's per-step task code is ~120 tiny torch launches per env.step on top of the physics
+ * (controller: agents/controllers/pd_joint_pos.py:76-93,207-228; struct gathers: utils/structs/
+ * actor.py:341-365, link.py:235-249, articulation.py:769-801; Panda.is_grasping / is_static:
+ * agents/robots/panda/panda.py:237-277; PickCubeEnv.evaluate / _get_obs_extra / compute_dense_reward:
+ * envs/tasks/tabletop/pick_cube.py:132-191; flatten_state_dict: utils/common.py:195-263).  At 4096
+ * envs those launches cost as much as a physics substep, so the backend offers the same arithmetic
+ * as two kernels that read the simulator's own state records (no fetch / gather / hstack round trip).
+ * The torch implementation in maniskill_amd/envs/pick_cube.py stays the readable reference; the two
+ * are compared in tests/test_gpu_parity.py.
+ */
+#ifndef MSK_TASK_H
+#define MSK_TASK_H
+
+#include "msk_physx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct msk_pickcube_desc {
+  int32_t cube, goal, tcp, left_finger, right_finger; /* template body ids                              */
+  int32_t arm_dofs;            /* 7: joints driven by pd_joint_delta_pos                                   */
+  float arm_delta;             /* 0.1 rad per unit action (panda.py:90-98)                                  */
+  float gripper_mid, gripper_half; /* 0.5 (high + low), 0.5 (high - low) of the mimic gripper range (panda.py:177-185) */
+  float goal_thresh;           /* 0.025 (pick_cube.py:41)                                                    */
+  float min_force, max_angle_deg; /* is_grasping thresholds: 0.5 N, 85 deg (panda.py:237)                    */
+  float static_thresh;         /* is_static: 0.2 rad/s (pick_cube.py:152)                                    */
+  int32_t max_episode_steps;   /* 50 (registration)                                                         */
+} msk_pickcube_desc;
+
+/* Binds the task to a finalized context. */
+int msk_task_pickcube_init(msk_ctx* ctx, const msk_pickcube_desc* desc);
+
+/* CombinedController.set_action for pd_joint_delta_pos: clip to [-1, 1], arm target = qpos + delta * a,
+ * gripper target = affine(a[7]) on both finger joints; commits the targets into the simulator (what
+ * set_joint_drive_targets + gpu_apply_articulation_target_position do).  actions: device [num_envs][8]. */
+int msk_task_pickcube_set_action(msk_ctx* ctx, const float* actions, void* stream);
+
+/* `substeps` calls of msk_step plus the link-frame update, from one host call. */
+int msk_control_step(msk_ctx* ctx, int substeps, void* stream);
+
+/* elapsed_steps += 1, evaluate(), get_obs(), normalized dense reward, terminated / truncated.
+ * obs: device [num_envs][42] f32; reward: [num_envs] f32; flags: [num_envs][8] u8 =
+ * {success, is_obj_placed, is_robot_static, is_grasped, terminated, truncated, 0, 0};
+ * elapsed: [num_envs] i32 (read-modify-write; pass advance = 0 to evaluate without counting a step). */
+int msk_task_pickcube_observe(msk_ctx* ctx, float* obs, float* reward, uint8_t* flags, int32_t* elapsed, int advance,
+                              void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSK_TASK_H */

@@ -29,6 +29,8 @@ EXPORTS = [
     "fetch", "update_kinematics", "step", "query_create_pairs", "query_buffer", "query_run",
     "get_sizes", "get_contacts", "get_env_contact_counts", "timing_enable", "timing_read",
 ]
+# include/msk_task.h — fused task kernels (HIP library only; the test-suite's CPU checker has no counterpart)
+TASK_EXPORTS = ["task_pickcube_init", "task_pickcube_set_action", "control_step", "task_pickcube_observe"]
 K_DYNAMICS, K_COLLIDE, K_SOLVE = 0, 1, 2
 KERNEL_SLOTS = {"k_dynamics": K_DYNAMICS, "k_collide": K_COLLIDE, "k_solve": K_SOLVE}
 
@@ -46,6 +48,15 @@ class MskConfig(C.Structure):
         ("enable_tgs", C.c_int32),
         ("enable_pcm", C.c_int32),
         ("reserved", C.c_int32 * 6),
+    ]
+
+
+class PickCubeDesc(C.Structure):
+    _fields_ = [
+        ("cube", C.c_int32), ("goal", C.c_int32), ("tcp", C.c_int32), ("left_finger", C.c_int32), ("right_finger", C.c_int32),
+        ("arm_dofs", C.c_int32), ("arm_delta", C.c_float), ("gripper_mid", C.c_float), ("gripper_half", C.c_float),
+        ("goal_thresh", C.c_float), ("min_force", C.c_float), ("max_angle_deg", C.c_float), ("static_thresh", C.c_float),
+        ("max_episode_steps", C.c_int32),
     ]
 
 
@@ -102,6 +113,18 @@ class NativeLib:
             fn = f(name)
             fn.restype, fn.argtypes = res, args
             setattr(self, name, fn)
+        task_sig = {
+            "task_pickcube_init": (i32, [vp, C.POINTER(PickCubeDesc)]),
+            "task_pickcube_set_action": (i32, [vp, vp, vp]),
+            "control_step": (i32, [vp, i32, vp]),
+            "task_pickcube_observe": (i32, [vp, vp, vp, vp, vp, i32, vp]),
+        }
+        self.has_task_kernels = all(hasattr(self.dll, prefix + n) for n in task_sig)
+        if self.has_task_kernels:
+            for name, (res, args) in task_sig.items():
+                fn = f(name)
+                fn.restype, fn.argtypes = res, args
+                setattr(self, name, fn)
 
     def check(self, ctx, code: int, what: str) -> int:
         if code < 0:

@@ -6,6 +6,7 @@
  * every entry point that computes anything launches a kernel.
  */
 #include "msk_kernels.h"
+#include "msk_task.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -47,6 +48,8 @@ struct msk_ctx {
   pose pending_root;
   int nverts_total;
   size_t lds_small, lds_big; /* dynamic LDS of the two solver launches */
+  msk_pickcube_desc pickcube; /* fused task kernels (include/msk_task.h) */
+  bool has_pickcube;
   bool kin_dirty;        /* link frames in st.bpose are older than (q, qd): run k_kinematics before reading them */
   uint32_t groups[MSK_MAX_SHAPES][4]; /* collision groups: only the static pair filter needs them */
   std::vector<void*> allocs;
@@ -118,6 +121,7 @@ MSK_API msk_ctx* msk_create(int hip_device, const msk_config* cfg) {
   c->nverts_total = 0;
   c->max_dof = 0;
   c->t_cap = 0; c->t_n = 0;
+  c->has_pickcube = false;
   c->err[0] = 0;
   return c;
 }
@@ -610,6 +614,54 @@ MSK_API int msk_get_sizes(msk_ctx* c, int32_t out[8]) {
   return MSK_OK;
 }
 
+/* ---- fused task kernels (include/msk_task.h) ---------------------------------------------------------- */
+MSK_API int msk_task_pickcube_init(msk_ctx* c, const msk_pickcube_desc* d) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "task init before finalize");
+  const int nb = c->model.nb;
+  const int ids[5] = {d->cube, d->goal, d->tcp, d->left_finger, d->right_finger};
+  for (int i = 0; i < 5; ++i)
+    if (ids[i] < 0 || ids[i] >= nb) return fail(c, MSK_ERR_INVALID, "pickcube: bad body id");
+  if (d->arm_dofs + 2 != c->model.nd || 2 * (d->arm_dofs + 2) + 24 != 42) return fail(c, MSK_ERR_INVALID, "pickcube: expects a 7+2 dof arm");
+  c->pickcube = *d;
+  c->has_pickcube = true;
+  return MSK_OK;
+}
+
+MSK_API int msk_task_pickcube_set_action(msk_ctx* c, const float* actions, void* stream) {
+  if (!c->has_pickcube) return fail(c, MSK_ERR_INVALID, "pickcube task not initialised");
+  const int N = c->model.N;
+  hipLaunchKernelGGL(k_pickcube_set_action, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->pickcube, actions);
+  HIP_TRY(hipGetLastError());
+  return MSK_OK;
+}
+
+MSK_API int msk_control_step(msk_ctx* c, int substeps, void* stream) {
+  for (int i = 0; i < substeps; ++i) {
+    const int r = msk_step(c, stream);
+    if (r < 0) return r;
+  }
+  launch_kinematics(c->model, c->d_model, c->st, (hipStream_t)stream);
+  c->kin_dirty = false;
+  HIP_TRY(hipGetLastError());
+  return MSK_OK;
+}
+
+MSK_API int msk_task_pickcube_observe(msk_ctx* c, float* obs, float* reward, uint8_t* flags, int32_t* elapsed, int advance,
+                                      void* stream) {
+  if (!c->has_pickcube) return fail(c, MSK_ERR_INVALID, "pickcube task not initialised");
+  const int N = c->model.N;
+  if (c->kin_dirty) {
+    launch_kinematics(c->model, c->d_model, c->st, (hipStream_t)stream);
+    c->kin_dirty = false;
+  }
+  const float cos_max = cosf(c->pickcube.max_angle_deg * 3.14159265358979323846f / 180.0f);
+  hipLaunchKernelGGL(k_pickcube_observe, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->pickcube, obs,
+                     reward, flags, elapsed, advance, cos_max);
+  HIP_TRY(hipGetLastError());
+  return MSK_OK;
+}
+
+#ifdef MSK_PROFILE_PHASES
 /* development aid (MSK_PROFILE_PHASES builds): per-env cycle stamps of the solver phases, out[num_envs*8] */
 MSK_API int msk_debug_phases(msk_ctx* c, long long* out) {
   HIP_TRY(hipSetDevice(c->device));
@@ -617,6 +669,7 @@ MSK_API int msk_debug_phases(msk_ctx* c, long long* out) {
   HIP_TRY(hipMemcpy(out, c->st.dbg, sizeof(long long) * 8 * (size_t)c->model.N, hipMemcpyDeviceToHost));
   return MSK_OK;
 }
+#endif
 
 MSK_API int msk_get_env_contact_counts(msk_ctx* c, int32_t* out) {
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "get_env_contact_counts before finalize");

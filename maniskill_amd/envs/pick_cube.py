@@ -100,7 +100,8 @@ class PickCubeEnv:
 
     def __init__(self, num_envs: int = 1, device: Optional[str] = None, sim_config: Optional[SimConfig] = None,
                  robot_init_qpos_noise: float = 0.02, reward_mode: str = "normalized_dense",
-                 env_index_offset: int = 0, total_envs: Optional[int] = None, px_factory=None):
+                 env_index_offset: int = 0, total_envs: Optional[int] = None, px_factory=None,
+                 fused: Optional[bool] = None):
         self.num_envs = int(num_envs)
         self.sim_config = sim_config or SimConfig()
         self.robot_init_qpos_noise = robot_init_qpos_noise
@@ -154,10 +155,34 @@ class PickCubeEnv:
         self._episode_count = np.zeros(N, dtype=np.uint64)
         self.action_low = -torch.ones(self.action_dim, device=dev)
         self.action_high = torch.ones(self.action_dim, device=dev)
+        # fused task kernels (include/msk_task.h): same arithmetic as the torch code below, two launches per step
+        # instead of ~120.  Default on the HIP backend; the torch path stays the readable reference (fused=False).
+        can_fuse = getattr(self.px.lib, "has_task_kernels", False) and not self.px.host_memory
+        self.fused = can_fuse if fused is None else bool(fused)
+        if self.fused:
+            if not can_fuse:
+                raise RuntimeError("fused task kernels need the HIP backend")
+            from .. import _native as NN
+            import ctypes as C
+            d = NN.PickCubeDesc(cube=self._b_cube, goal=self._b_goal, tcp=self._b_tcp, left_finger=self._b_f1, right_finger=self._b_f2,
+                                arm_dofs=7, arm_delta=self.arm_delta, gripper_mid=0.5 * (self.gripper_high + self.gripper_low),
+                                gripper_half=0.5 * (self.gripper_high - self.gripper_low),
+                                goal_thresh=self.goal_thresh, min_force=0.5, max_angle_deg=85.0, static_thresh=0.2,
+                                max_episode_steps=self.max_episode_steps)
+            self.px.lib.check(self.px.ctx, self.px.lib.task_pickcube_init(self.px.ctx, C.byref(d)), "task_pickcube_init")
+            self._f_obs = torch.zeros(N, self.obs_dim, dtype=torch.float32, device=dev)
+            self._f_rew = torch.zeros(N, dtype=torch.float32, device=dev)
+            self._f_flags = torch.zeros(N, 8, dtype=torch.uint8, device=dev)
         self.reset(seed=None)
 
     # ---------------------------------------------------------------- struct-style views
+    def _fresh(self):
+        """Fused mode publishes the sapien-style buffers lazily: refresh them before any host-side read."""
+        if getattr(self, "fused", False) and getattr(self, "_buffers_stale", False):
+            self.sync_buffers()
+
     def _pose(self, body):  # Actor.pose / Link.pose .raw_pose with the scene offset removed (actor.py:341-365)
+        self._fresh()
         raw = self._rbd[:, body, :7].clone()
         raw[:, :3] -= self._offsets
         return raw
@@ -165,13 +190,19 @@ class PickCubeEnv:
     @property
     def cube_pose(self): return self._pose(self._b_cube)
     @property
-    def goal_pos(self): return self._rbd[:, self._b_goal, :3] - self._offsets
+    def goal_pos(self):
+        self._fresh()
+        return self._rbd[:, self._b_goal, :3] - self._offsets
     @property
     def tcp_pose(self): return self._pose(self._b_tcp)
     @property
-    def qpos(self): return self._qpos[:, :9]
+    def qpos(self):
+        self._fresh()
+        return self._qpos[:, :9]
     @property
-    def qvel(self): return self._qvel[:, :9]
+    def qvel(self):
+        self._fresh()
+        return self._qvel[:, :9]
 
     # ---------------------------------------------------------------- reset
     def reset(self, seed=None, options: Optional[dict] = None):
@@ -182,6 +213,8 @@ class PickCubeEnv:
         else:
             env_idx = torch.arange(self.num_envs, device=dev)
         idx_np = env_idx.cpu().numpy()
+        if getattr(self, "fused", False) and getattr(self, "_buffers_stale", False):
+            self.sync_buffers()   # the masked setters below write into the torch-visible buffers
         if seed is not None:
             seeds = (np.asarray(seed).reshape(-1) if not np.isscalar(seed) else np.array([seed])).astype(np.int64)
             if len(seeds) == 1:
@@ -238,6 +271,9 @@ class PickCubeEnv:
         self.px.gpu_apply_all()
         self.px.gpu_update_articulation_kinematics()
         self.px.gpu_fetch_all()
+        if getattr(self, "fused", False):
+            obs, _, _, _, info = self._fused_observe(False)
+            return obs, info
         info = self.get_info()
         obs = self.get_obs(info)
         return obs, info
@@ -267,7 +303,41 @@ class PickCubeEnv:
         self.px.gpu_fetch_all()
         return action
 
+    def _fused_observe(self, advance: bool):
+        import ctypes as C
+        L, px = self.px.lib, self.px
+        L.check(px.ctx, L.task_pickcube_observe(px.ctx, C.c_void_p(self._f_obs.data_ptr()), C.c_void_p(self._f_rew.data_ptr()),
+                                                C.c_void_p(self._f_flags.data_ptr()), C.c_void_p(self._elapsed_steps.data_ptr()),
+                                                1 if advance else 0, px._stream()), "task_pickcube_observe")
+        fl = self._f_flags.bool()
+        info = dict(elapsed_steps=self._elapsed_steps.clone(), success=fl[:, 0], is_obj_placed=fl[:, 1], is_robot_static=fl[:, 2],
+                    is_grasped=fl[:, 3])
+        return self._f_obs.clone(), self._f_rew.clone(), fl[:, 4], fl[:, 5], info
+
+    def _fused_step(self, action):
+        """BaseEnv.step on the fused kernels: controller, substeps + link frames, evaluate/obs/reward."""
+        import ctypes as C
+        L, px = self.px.lib, self.px
+        if action is not None:
+            action = torch.as_tensor(action, dtype=torch.float32, device=self.device)
+            if action.ndim == 1:
+                action = action[None]
+            if action.shape != (self.num_envs, self.action_dim):
+                raise AssertionError(f"Received action of shape {tuple(action.shape)} but expected shape ({self.num_envs}, {self.action_dim})")
+            action = action.contiguous()
+            L.check(px.ctx, L.task_pickcube_set_action(px.ctx, C.c_void_p(action.data_ptr()), px._stream()), "task_pickcube_set_action")
+        L.check(px.ctx, L.control_step(px.ctx, self._sim_steps_per_control, px._stream()), "control_step")
+        self._buffers_stale = True   # the sapien-style external buffers are refreshed on demand (sync_buffers)
+        return self._fused_observe(True)
+
+    def sync_buffers(self):
+        """Publishes the simulator state into the torch-visible sapien buffers (scene._gpu_fetch_all)."""
+        self.px.gpu_fetch_all()
+        self._buffers_stale = False
+
     def step(self, action):
+        if self.fused:
+            return self._fused_step(action)
         action = self._step_action(action)
         self._elapsed_steps += 1
         info = self.get_info()
@@ -283,6 +353,7 @@ class PickCubeEnv:
         return query.cuda_impulses.torch().clone() / self.px.timestep
 
     def is_grasping(self, min_force=0.5, max_angle=85):
+        self._fresh()
         lf = self.get_pairwise_contact_forces(self._q_lgrasp)
         rf = self.get_pairwise_contact_forces(self._q_rgrasp)
         lforce, rforce = torch.linalg.norm(lf, dim=1), torch.linalg.norm(rf, dim=1)
@@ -338,6 +409,9 @@ class PickCubeEnv:
     def get_state(self):
         """(N, 13*3 + 13 + 9*2): actors [table, cube, goal] then articulation [root pose/vel, qpos, qvel]
         (tests/test_sim_state.py:10-37)."""
+        if getattr(self, "fused", False) and getattr(self, "_buffers_stale", False):
+            self.sync_buffers()
+
         def actor(bid):
             s = self._rbd[:, bid, :].clone()
             s[:, :3] -= self._offsets
@@ -349,6 +423,8 @@ class PickCubeEnv:
         if env_idx is None:
             env_idx = torch.arange(self.num_envs, device=self.device)
         state = torch.as_tensor(state, dtype=torch.float32, device=self.device)
+        if getattr(self, "fused", False) and getattr(self, "_buffers_stale", False):
+            self.sync_buffers()
         off = self._offsets[env_idx]
         for k, bid in enumerate([self._b_table, self._b_cube, self._b_goal, self._b_root]):
             s = state[:, 13 * k: 13 * (k + 1)].clone()

@@ -26,6 +26,17 @@ def test_hip_library_exports_every_symbol(built):
         assert hasattr(dll, name), f"libmsk_physx.so does not export {name}"
 
 
+def test_task_header_entry_points_are_exported(built):
+    """include/msk_task.h (fused task kernels): declared, bound in _native.py, exported by the HIP library."""
+    text = open(os.path.join(ROOT, "include", "msk_task.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(msk_[a-z_0-9]+)\s*\(", text)))
+    assert {"msk_" + n for n in N.TASK_EXPORTS} == set(names)
+    dll = ctypes.CDLL(N.DEFAULT_LIB)
+    for name in names:
+        assert hasattr(dll, name), f"libmsk_physx.so does not export {name}"
+
+
 def test_oracle_exports_same_surface(built):
     from oracle_backend import ORACLE_LIB
 

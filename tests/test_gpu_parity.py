@@ -36,7 +36,7 @@ def test_native_library_is_what_runs():
 
 def test_rollout_matches_oracle_100_steps(oracle_factory):
     n, steps = 256, 100
-    gpu = PickCubeEnv(num_envs=n, device=DEV)
+    gpu = PickCubeEnv(num_envs=n, device=DEV, fused=False)   # same host code on both sides: a pure physics comparison
     cpu = PickCubeEnv(num_envs=n, px_factory=oracle_factory)
     og, _ = gpu.reset(seed=2022)
     oc, _ = cpu.reset(seed=2022)
@@ -65,7 +65,7 @@ def test_matches_committed_golden_rollout():
     """tests/golden/pickcube_oracle_rollout.npz travels to the GPU box (made by tests/golden/make_golden.py)."""
     g = np.load(os.path.join(HERE, "golden", "pickcube_oracle_rollout.npz"))
     n = g["actions"].shape[1]
-    env = PickCubeEnv(num_envs=n, device=DEV)
+    env = PickCubeEnv(num_envs=n, device=DEV, fused=False)
     obs, _ = env.reset(seed=2022)
     assert _close(obs.cpu().numpy(), g["obs"][0])
     off = g["contact_ids_offsets"]
@@ -87,7 +87,7 @@ def test_scripted_grasp_matches_oracle(oracle_factory):
     wp = json.load(open(os.path.join(HERE, "golden", "grasp_waypoints.json")))
     n = 8
     outs = []
-    for kw in (dict(device=DEV), dict(px_factory=oracle_factory)):
+    for kw in (dict(device=DEV, fused=False), dict(px_factory=oracle_factory)):
         env = PickCubeEnv(num_envs=n, robot_init_qpos_noise=0.0, **kw)
         env.reset(seed=0)
         dev = env.device
@@ -189,6 +189,34 @@ def test_full_size_properties_4096():
     assert not torch.equal(before[idx], after[idx])
     sizes = env.px.get_overflow()
     assert sizes == 0, "per-env contact capacity exceeded"
+
+
+def test_fused_task_kernels_match_torch_reference():
+    """include/msk_task.h: the fused controller / evaluate / obs / reward kernels against the torch mirror of
+    the reference task code (maniskill_amd/envs/pick_cube.py), same physics, 4096 envs, 30 steps."""
+    n = 4096
+    a = PickCubeEnv(num_envs=n, device=DEV, fused=True)
+    b = PickCubeEnv(num_envs=n, device=DEV, fused=False)
+    oa, _ = a.reset(seed=2022)
+    ob, _ = b.reset(seed=2022)
+    # the torch path reports (p + offset) - offset: its positions carry the fp32 spacing of the 160 m scene grid
+    assert np.allclose(oa.cpu().numpy(), ob.cpu().numpy(), rtol=1e-4, atol=5e-5)
+    torch.manual_seed(3)
+    nflag = 0
+    for t in range(30):
+        act = 3 * torch.rand(n, 8, device=DEV) - 1.5   # exercises the clipping too
+        oa, ra, ta, ua, ia = a.step(act)
+        ob, rb, tb, ub, ib = b.step(act)
+        assert torch.equal(a.get_state(), b.get_state()), f"physics state differs at step {t}"
+        A, B = oa.cpu().numpy(), ob.cpu().numpy()
+        same_flag = A[:, 18] == B[:, 18]
+        nflag += int((~same_flag).sum())
+        assert np.allclose(np.delete(A, 18, axis=1), np.delete(B, 18, axis=1), rtol=1e-4, atol=5e-5)
+        assert np.allclose(ra.cpu().numpy()[same_flag], rb.cpu().numpy()[same_flag], atol=2e-5)
+        assert torch.equal(ua, ub) and (ta == tb).float().mean().item() > 0.999
+        for k in ("success", "is_obj_placed", "is_robot_static", "is_grasped"):
+            assert (ia[k] == ib[k]).float().mean().item() > 0.999, k
+    assert nflag <= 0.001 * 30 * n   # is_grasped may flip only on the 85 degree / 0.5 N boundary
 
 
 def test_timing_api_reports_kernels():
