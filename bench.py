@@ -117,6 +117,13 @@ def main():
         avg_s = tot_ms / max(launches, 1) * 1e-3
         alg_bytes = ALG_BYTES_PER_ENV_SUBSTEP * n_local
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        # HBM traffic of the dominant kernel: PMC FETCH_SIZE / WRITE_SIZE cannot be read from inside this process; the
+        # value below comes from the committed rocprofv3 --pmc passes of this same command (profiles/, see its "source")
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_counters_4096.json")
+        if args.envs == 4096 and world == 1 and os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f)["substep_groups"].get(dom, {}).get("hbm_bytes_per_launch")
         result = {
             "metric": "env steps/sec (whole node), 4096 parallel PickCube-v1 envs",
             "value": args.envs * args.steps / dt,
@@ -133,7 +140,8 @@ def main():
                        "envs_per_gpu": n_local, "parallelism": f"env-shard x{world}"},
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_counters_4096.json (rocprofv3 --pmc, (2*FETCH_SIZE + WRITE_SIZE) KiB)" if traffic else None,
                 "avg_kernel_us": avg_s * 1e6, "launches": launches,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_us": {k: v[0] / max(v[1], 1) * 1e3 for k, v in kernels.items()},

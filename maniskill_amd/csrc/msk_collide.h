@@ -2,10 +2,10 @@
  * msk_collide.h — per-pair narrowphase device functions (one HIP thread = one (pair, env)).
  *
  * box-box SAT, GJK distance + EPA penetration for hulls, plane-vs-vertices, and the one-shot
- * support-feature clipping manifold (<= 4 points per pair).  The pair index is uniform over a
- * wavefront (64 lanes = 64 envs of the same pair), so shape constants and hull vertices are
- * fetched with scalar loads and all lanes follow the same shape-type branch; only iteration
- * counts diverge.  Arithmetic is kept operation-for-operation identical to the CPU oracle.
+ * support-feature clipping manifold (<= 4 points per pair).  A wavefront holds 64 surviving pairs
+ * of one narrowphase type (k_narrowphase), so all lanes follow the same branch; hull vertices come
+ * from an LDS copy of the template's vertex pool.  Arithmetic is kept operation-for-operation
+ * identical to the CPU oracle.
  */
 #ifndef MSK_COLLIDE_H
 #define MSK_COLLIDE_H
@@ -20,16 +20,21 @@
 
 struct DContactOut { v3 pos; v3 n; float sep; };
 
+/* what the narrowphase functions need besides the two shapes: the hull vertex pool (an LDS copy: the
+ * support loops read 64 vertices per call) and this lane's column of an LDS scratch row (stride 64,
+ * conflict-free) for the per-vertex heights of select_feature */
+struct CCtx { const v3* verts; float* hh; };
+
 MSK_DEV int shape_nverts(const DShape* sh) { return sh->type == MSK_SHAPE_BOX ? 8 : sh->nverts; }
-MSK_DEV v3 shape_vert(const DModel* m, const DShape* sh, int i) {
+MSK_DEV v3 shape_vert(const CCtx& m, const DShape* sh, int i) {
   if (sh->type == MSK_SHAPE_BOX)
     return v3_make((i & 1) ? sh->par[0] : -sh->par[0], (i & 2) ? sh->par[1] : -sh->par[1],
                    (i & 4) ? sh->par[2] : -sh->par[2]);
-  return m->verts[sh->vbase + i];
+  return m.verts[sh->vbase + i];
 }
 
 /* support point (world) of a box / hull in world direction d */
-MSK_DEV v3 support(const DModel* m, const DShape* sh, const pose* T, v3 d) {
+MSK_DEV v3 support(const CCtx& m, const DShape* sh, const pose* T, v3 d) {
   v3 dl = quat_rotate_inv(T->q, d);
   v3 pl;
   if (sh->type == MSK_SHAPE_BOX) {
@@ -37,12 +42,12 @@ MSK_DEV v3 support(const DModel* m, const DShape* sh, const pose* T, v3 d) {
                  dl.z >= 0.0f ? sh->par[2] : -sh->par[2]);
   } else {
     int best = 0;
-    float bd = v3_dot(m->verts[sh->vbase], dl);
+    float bd = v3_dot(m.verts[sh->vbase], dl);
     for (int i = 1; i < sh->nverts; ++i) {
-      float di = v3_dot(m->verts[sh->vbase + i], dl);
+      float di = v3_dot(m.verts[sh->vbase + i], dl);
       if (di > bd) { bd = di; best = i; }
     }
-    pl = m->verts[sh->vbase + best];
+    pl = m.verts[sh->vbase + best];
   }
   return pose_apply(*T, pl);
 }
@@ -59,17 +64,16 @@ MSK_DEV void world_aabb(const DShape* sh, const pose* T, v3* c, v3* h) {
 typedef struct { float u, v, h; } p3;   /* coordinates in the (t1, t2, n) contact frame */
 
 /* support feature of `sh` along sign*n: up to 8 extreme points, CCW about n */
-MSK_DEV int select_feature(const DModel* m, const DShape* sh, const pose* T, v3 n, v3 t1, v3 t2, float sign, p3* out) {
+MSK_DEV int select_feature(const CCtx& m, const DShape* sh, const pose* T, v3 n, v3 t1, v3 t2, float sign, p3* out) {
   const float DX[8] = {1.0f, 0.70710678f, 0.0f, -0.70710678f, -1.0f, -0.70710678f, 0.0f, 0.70710678f};
   const float DY[8] = {0.0f, 0.70710678f, 1.0f, 0.70710678f, 0.0f, -0.70710678f, -1.0f, -0.70710678f};
   v3 nl = quat_rotate_inv(T->q, n), t1l = quat_rotate_inv(T->q, t1), t2l = quat_rotate_inv(T->q, t2);
   float on = v3_dot(T->p, n), o1 = v3_dot(T->p, t1), o2 = v3_dot(T->p, t2);
   int nv = shape_nverts(sh);
-  float hh[MSK_MAX_HULL_VERTS];
   float hbest = -3.0e38f;
   for (int i = 0; i < nv; ++i) {
-    hh[i] = v3_dot(shape_vert(m, sh, i), nl);
-    float s = sign * hh[i];
+    m.hh[(i) * 64] = v3_dot(shape_vert(m, sh, i), nl);
+    float s = sign * m.hh[(i) * 64];
     if (s > hbest) hbest = s;
   }
   int sel[8];
@@ -77,7 +81,7 @@ MSK_DEV int select_feature(const DModel* m, const DShape* sh, const pose* T, v3 
     int best = -1;
     float bd = -3.0e38f;
     for (int i = 0; i < nv; ++i) {
-      if (sign * hh[i] < hbest - ORC_FEAT_EPS) continue;
+      if (sign * m.hh[(i) * 64] < hbest - ORC_FEAT_EPS) continue;
       v3 p = shape_vert(m, sh, i);
       float d = fmaf(v3_dot(p, t1l), DX[k], v3_dot(p, t2l) * DY[k]);
       if (d > bd) { bd = d; best = i; }
@@ -95,7 +99,7 @@ MSK_DEV int select_feature(const DModel* m, const DShape* sh, const pose* T, v3 
     v3 p = shape_vert(m, sh, kept[k]);
     out[k].u = v3_dot(p, t1l) + o1;
     out[k].v = v3_dot(p, t2l) + o2;
-    out[k].h = hh[kept[k]] + on;
+    out[k].h = m.hh[kept[k] * 64] + on;
   }
   return cnt;
 }
@@ -241,7 +245,7 @@ MSK_DEV int reduce4(cand* cs, int n) {
   return m;
 }
 
-MSK_DEV int build_manifold(const DModel* m, const DShape* A, const pose* TA, const DShape* B, const pose* TB, v3 n,
+MSK_DEV int build_manifold(const CCtx& m, const DShape* A, const pose* TA, const DShape* B, const pose* TB, v3 n,
                           float margin, v3 wa, v3 wb, float sep_hint, DContactOut* out) {
   v3 t1, t2;
   msk_tangents(n, &t1, &t2);
@@ -330,7 +334,7 @@ MSK_DEV int sat_box_box(const DShape* A, const pose* TA, const DShape* B, const 
 /* ---- GJK / EPA ------------------------------------------------------------------------ */
 typedef struct { v3 w, a, b; } mvert;
 
-MSK_DEV mvert msupport(const DModel* m, const DShape* A, const pose* TA, const DShape* B, const pose* TB, v3 d) {
+MSK_DEV mvert msupport(const CCtx& m, const DShape* A, const pose* TA, const DShape* B, const pose* TB, v3 d) {
   mvert r;
   r.a = support(m, A, TA, d);
   r.b = support(m, B, TB, v3_neg(d));
@@ -439,7 +443,7 @@ MSK_DEV int epa_make_face(const mvert* vs, epa_face* f, int a, int b, int c) {
 }
 
 /* penetration of two overlapping convex shapes; starts from the GJK simplex */
-MSK_DEV int epa(const DModel* m, const DShape* A, const pose* TA, const DShape* B, const pose* TB, mvert* simplex, int ns,
+MSK_DEV int epa(const CCtx& m, const DShape* A, const pose* TA, const DShape* B, const pose* TB, mvert* simplex, int ns,
                v3* n_out, float* depth_out, v3* wa, v3* wb) {
   mvert vs[ORC_EPA_MAXV];
   epa_face fs[ORC_EPA_MAXF];
@@ -545,7 +549,7 @@ MSK_DEV int epa(const DModel* m, const DShape* A, const pose* TA, const DShape* 
 }
 
 /* GJK distance + EPA. Returns 0 if farther apart than margin. n from B to A. */
-MSK_DEV int gjk_epa(const DModel* m, const DShape* A, const pose* TA, const DShape* B, const pose* TB, v3 ca, v3 cb, float margin,
+MSK_DEV int gjk_epa(const CCtx& m, const DShape* A, const pose* TA, const DShape* B, const pose* TB, v3 ca, v3 cb, float margin,
                    v3* n_out, float* sep_out, v3* wa, v3* wb) {
   mvert s[4];
   float bary[4] = {1, 0, 0, 0};
@@ -600,7 +604,7 @@ MSK_DEV int gjk_epa(const DModel* m, const DShape* A, const pose* TA, const DSha
 }
 
 /* ---- plane ----------------------------------------------------------------------------- */
-MSK_DEV int plane_convex(const DModel* m, const DShape* P, const pose* TP, const DShape* C, const pose* TC, float margin,
+MSK_DEV int plane_convex(const CCtx& m, const DShape* P, const pose* TP, const DShape* C, const pose* TC, float margin,
                         int plane_is_a, DContactOut* out) {
   v3 pn = quat_rotate(TP->q, v3_make(1, 0, 0));
   float pd = v3_dot(pn, TP->p);

@@ -99,6 +99,12 @@ __global__ void __launch_bounds__(64) k_broadphase(const DModel* __restrict__ m,
 #define NP_GROUP 16 /* envs whose lists one narrowphase wave walks (dense waves: the kernel is bound by issue slots and scratch traffic) */
 __global__ void __launch_bounds__(64) k_narrowphase(const DModel* __restrict__ m, DState st) {
   __shared__ int pref[NP_GROUP + 1];
+  __shared__ v3 s_verts[MSK_MAX_SHAPES * 16];   /* the template's hull vertex pool (12 KB) */
+  __shared__ float s_hh[MSK_MAX_HULL_VERTS * 64];
+  for (int i = threadIdx.x; i < m->nverts_total; i += 64) s_verts[i] = m->verts[i];
+  CCtx cx;
+  cx.verts = s_verts;
+  cx.hh = s_hh + threadIdx.x;
   const int type = blockIdx.y, e0 = blockIdx.x * NP_GROUP, lane = threadIdx.x;
   const float margin = 2.0f * m->cfg.contact_offset;
   if (lane == 0) {
@@ -125,7 +131,7 @@ __global__ void __launch_bounds__(64) k_narrowphase(const DModel* __restrict__ m
   int n = 0;
   if (type == NP_PLANE) {
     const int pa = A->type == MSK_SHAPE_PLANE;
-    n = plane_convex(m, pa ? A : B, pa ? &TA : &TB, pa ? B : A, pa ? &TB : &TA, margin, pa, out);
+    n = plane_convex(cx, pa ? A : B, pa ? &TA : &TB, pa ? B : A, pa ? &TB : &TA, margin, pa, out);
   } else {
     v3 nrm, wa, wb;
     float sep;
@@ -133,16 +139,16 @@ __global__ void __launch_bounds__(64) k_narrowphase(const DModel* __restrict__ m
     if (type == NP_BOXBOX) {
       hit = sat_box_box(A, &TA, B, &TB, margin, &nrm, &sep);
       if (hit) {
-        wa = support(m, A, &TA, v3_neg(nrm));
-        wb = support(m, B, &TB, nrm);
+        wa = support(cx, A, &TA, v3_neg(nrm));
+        wb = support(cx, B, &TB, nrm);
       }
     } else {
       v3 ca, ha, cb, hb;
       world_aabb(A, &TA, &ca, &ha);
       world_aabb(B, &TB, &cb, &hb);
-      hit = gjk_epa(m, A, &TA, B, &TB, ca, cb, margin, &nrm, &sep, &wa, &wb);
+      hit = gjk_epa(cx, A, &TA, B, &TB, ca, cb, margin, &nrm, &sep, &wa, &wb);
     }
-    if (hit) n = build_manifold(m, A, &TA, B, &TB, nrm, margin, wa, wb, sep, out);
+    if (hit) n = build_manifold(cx, A, &TA, B, &TB, nrm, margin, wa, wb, sep, out);
   }
   /* warm start from the previous contents of this pair's slot, then overwrite it */
   int* cntp = st.ct_cnt + (size_t)e * m->npp + pi;

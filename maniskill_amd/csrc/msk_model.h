@@ -49,6 +49,7 @@ struct DModel {
   DTendon tendons[MSK_MAX_TENDONS];
   DPair pairs[MSK_MAX_PAIRS];
   v3 verts[MSK_MAX_SHAPES * 16]; /* hull vertex pool (<= 1024 vertices per template) */
+  int nverts_total;
   EnvLayout lay;
   /* tree tables for the wave-per-env dynamics (msk_dynamics.h) */
   int depth[MSK_MAX_BODIES];           /* links: distance to the root link; actors: 0            */

@@ -356,6 +356,7 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
         m.np++;
       }
   m.N = num_envs;
+  m.nverts_total = c->nverts_total;
   /* lane-group solver tables */
   m.G = (m.nv <= 16) ? 16 : 32;
   m.npp = ((m.np + m.G - 1) / m.G) * m.G;
