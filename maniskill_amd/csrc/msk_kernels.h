@@ -96,31 +96,33 @@ __global__ void __launch_bounds__(64) k_broadphase(const DModel* __restrict__ m,
   if (lane < NP_TYPES) st.np_count[(size_t)e * 4 + lane] = (lane == 0) ? base[0] : ((lane == 1) ? base[1] : base[2]);
 }
 
-#define NP_GROUP 16 /* envs whose lists one narrowphase wave walks (dense waves: the kernel is bound by issue slots and scratch traffic) */
-__global__ void __launch_bounds__(64) k_narrowphase(const DModel* __restrict__ m, DState st) {
-  __shared__ int pref[NP_GROUP + 1];
+#define NP_GROUP_MAX 16
+/* `group` = envs whose lists one wave walks: 16 at 4096 envs (dense waves: the launch is bound by issue slots and
+ * memory waits), fewer when there are few envs (then the launch is bound by its slowest wave) */
+__global__ void __launch_bounds__(64) k_narrowphase(const DModel* __restrict__ m, DState st, const int group) {
+  __shared__ int pref[NP_GROUP_MAX + 1];
   __shared__ v3 s_verts[MSK_MAX_SHAPES * 16];   /* the template's hull vertex pool (12 KB) */
   __shared__ float s_hh[MSK_MAX_HULL_VERTS * 64];
   for (int i = threadIdx.x; i < m->nverts_total; i += 64) s_verts[i] = m->verts[i];
   CCtx cx;
   cx.verts = s_verts;
   cx.hh = s_hh + threadIdx.x;
-  const int type = blockIdx.y, e0 = blockIdx.x * NP_GROUP, lane = threadIdx.x;
+  const int type = blockIdx.y, e0 = blockIdx.x * group, lane = threadIdx.x;
   const float margin = 2.0f * m->cfg.contact_offset;
   if (lane == 0) {
     int acc = 0;
-    for (int j = 0; j < NP_GROUP; ++j) {
+    for (int j = 0; j < NP_GROUP_MAX; ++j) {
       pref[j] = acc;
-      acc += (e0 + j < m->N) ? st.np_count[(size_t)(e0 + j) * 4 + type] : 0;
+      acc += (j < group && e0 + j < m->N) ? st.np_count[(size_t)(e0 + j) * 4 + type] : 0;
     }
-    pref[NP_GROUP] = acc;
+    pref[NP_GROUP_MAX] = acc;
   }
   __syncthreads();
-  const int count = pref[NP_GROUP];
+  const int count = pref[NP_GROUP_MAX];
   for (int idx = lane; idx < count; idx += 64) {
   int j = 0;
 #pragma unroll
-  for (int k = 1; k < NP_GROUP; ++k) j += (idx >= pref[k]) ? 1 : 0;
+  for (int k = 1; k < NP_GROUP_MAX; ++k) j += (k < group && idx >= pref[k]) ? 1 : 0;
   const int e = e0 + j;
   const int pi = st.np_items[((size_t)e * NP_TYPES + type) * m->np + (idx - pref[j])];
   float* E = EREC(st, m, e);

@@ -520,7 +520,9 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
   if (timed) hipEventRecord(ev[1], s);
   if (c->model.np > 0) {
     hipLaunchKernelGGL(k_broadphase, dim3(N), dim3(64), 0, s, c->d_model, c->st);
-    hipLaunchKernelGGL(k_narrowphase, dim3((N + NP_GROUP - 1) / NP_GROUP, NP_TYPES), dim3(64), 0, s, c->d_model, c->st);
+    int group = N / 256;   /* ~768 waves whatever the env count */
+    group = group < 1 ? 1 : (group > NP_GROUP_MAX ? NP_GROUP_MAX : group);
+    hipLaunchKernelGGL(k_narrowphase, dim3((N + group - 1) / group, NP_TYPES), dim3(64), 0, s, c->d_model, c->st, group);
   }
   if (timed) hipEventRecord(ev[2], s);
   {
