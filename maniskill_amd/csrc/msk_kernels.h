@@ -129,6 +129,9 @@ __global__ void __launch_bounds__(64) k_narrowphase(const DModel* __restrict__ m
   const DShape* A = &m->shapes[m->pairs[pi].sa];
   const DShape* B = &m->shapes[m->pairs[pi].sb];
   pose TA = shape_pose_dev(m, E, A), TB = shape_pose_dev(m, E, B);
+#ifdef MSK_PROFILE_PHASES
+  long long tq[5]; tq[0] = (long long)__builtin_readcyclecounter(); tq[1] = tq[2] = tq[0];
+#endif
   DContactOut out[4];
   int n = 0;
   if (type == NP_PLANE) {
@@ -150,8 +153,21 @@ __global__ void __launch_bounds__(64) k_narrowphase(const DModel* __restrict__ m
       world_aabb(B, &TB, &cb, &hb);
       hit = gjk_epa(cx, A, &TA, B, &TB, ca, cb, margin, &nrm, &sep, &wa, &wb);
     }
+#ifdef MSK_PROFILE_PHASES
+    tq[1] = (long long)__builtin_readcyclecounter();
+#endif
     if (hit) n = build_manifold(cx, A, &TA, B, &TB, nrm, margin, wa, wb, sep, out);
   }
+#ifdef MSK_PROFILE_PHASES
+  tq[2] = (long long)__builtin_readcyclecounter();
+  { /* per type: [0] items, [1] sum primary, [2] max primary, [3] sum manifold, [4] max manifold, [5] hits */
+    unsigned long long* d = (unsigned long long*)st.dbg + (size_t)m->N * 8 + type * 8;
+    atomicAdd(&d[0], 1ull);
+    atomicAdd(&d[1], (unsigned long long)(tq[1] - tq[0])); atomicMax(&d[2], (unsigned long long)(tq[1] - tq[0]));
+    atomicAdd(&d[3], (unsigned long long)(tq[2] - tq[1])); atomicMax(&d[4], (unsigned long long)(tq[2] - tq[1]));
+    if (n > 0) atomicAdd(&d[5], 1ull);
+  }
+#endif
   /* warm start from the previous contents of this pair's slot, then overwrite it */
   int* cntp = st.ct_cnt + (size_t)e * m->npp + pi;
   float* rec = st.ct_rec + ((size_t)e * m->npp + pi) * MSK_CT_REC;

@@ -420,7 +420,7 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   ALLOC(st.Scol, N * G * 8); ALLOC(st.W, N * G * G); ALLOC(st.vfree, N * G);
   ALLOC(st.ct_cnt, N * m.npp); ALLOC(st.ct_rec, N * m.npp * MSK_CT_REC);
   ALLOC(st.big_list, N); ALLOC(st.big_count, 1);
-  ALLOC(st.dbg, N * 8);
+  ALLOC(st.dbg, N * 8 + 64);
   /* the big solver launch needs more than the default 64 KB of dynamic LDS */
   if (m.G == 16) {
     auto kb = k_csolve_big<16>;
@@ -669,7 +669,7 @@ MSK_API int msk_task_pickcube_observe(msk_ctx* c, float* obs, float* reward, uin
 MSK_API int msk_debug_phases(msk_ctx* c, long long* out) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out, c->st.dbg, sizeof(long long) * 8 * (size_t)c->model.N, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, c->st.dbg, sizeof(long long) * (8 * (size_t)c->model.N + 64), hipMemcpyDeviceToHost));
   return MSK_OK;
 }
 #endif

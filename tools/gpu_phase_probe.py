@@ -18,16 +18,24 @@ dll = env.px.lib.dll
 dll.msk_debug_phases.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 names = ["count", "stage", "rowsJ", "Y", "A", "sweeps", "finish"]
 def report(tag):
-    out = np.zeros(n * 8, dtype=np.int64)
+    out = np.zeros(n * 8 + 64, dtype=np.int64)
     dll.msk_debug_phases(env.px.ctx, out.ctypes.data_as(C.POINTER(C.c_longlong)))
-    t = out.reshape(n, 8)
+    t = out[:n * 8].reshape(n, 8)
     d = np.diff(t[:, :7], axis=1)
     c = env.px.get_env_contact_counts()
     for lo, hi in ((0, 4), (5, 12), (13, 20), (21, 48)):
         sel = (c >= lo) & (c <= hi)
         if sel.sum():
             print(tag, f"contacts {lo}-{hi} n={sel.sum()}", {k: int(v) for k, v in zip(names[1:], d[sel].mean(0))}, "total", int((t[sel, 6] - t[sel, 0]).mean()))
+def np_report(tag, launches):
+    out = np.zeros(n * 8 + 64, dtype=np.int64)
+    dll.msk_debug_phases(env.px.ctx, out.ctypes.data_as(C.POINTER(C.c_longlong)))
+    d = out[n * 8:n * 8 + 24].reshape(3, 8)
+    for t, name in enumerate(("plane", "boxbox", "gjk")):
+        it = max(d[t, 0], 1)
+        print(tag, name, f"items/launch {d[t,0]/launches:.0f} hits {d[t,5]/launches:.0f} primary mean {d[t,1]/it:.0f} max {d[t,2]} manifold mean {d[t,3]/it:.0f} max {d[t,4]} cycles")
 for _ in range(3): env.step(torch.zeros(n, 8, device="cuda:0"))
 report("zero  ")
 for _ in range(60): env.step(2 * torch.rand(n, 8, device="cuda:0") - 1)
 report("random")
+np_report("random(all steps)", 63 * 5 + 5)
