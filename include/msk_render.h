@@ -1,0 +1,54 @@
+/*
+ * msk_render.h — C ABI of the batched camera pipeline (depth + segmentation).
+ *
+ * Stands in for what ManiSkill reaches through `sapien.render` on its camera hot path
+ * (mani_skill/envs/scene.py:382-427 update_render, :1026-1110 GPU render setup and camera groups;
+ * mani_skill/utils/structs/render_camera.py:160-182,269-273 take_picture / get_picture_cuda;
+ * mani_skill/render/shaders.py:68-84,141-145: the `minimal` shader pack's `PositionSegmentation`
+ * texture, r16g16b16a16sint = camera-space OpenGL xyz in millimetres + per-scene segmentation id,
+ * background 0).  Render shapes are attached to the bodies of the env template (one description,
+ * every env draws it at its own poses, read straight from the simulator's env records — the
+ * `set_cuda_poses(px.cuda_rigid_body_data)` coupling of scene.py:1026-1037 without a copy).
+ *
+ * Conventions (mani_skill/utils/sapien_utils.py:320-324, structs/render_camera.py:140-141):
+ * camera frame x forward, y left, z up; OpenGL frame x right, y up, -z forward; a pixel belongs to
+ * the nearest surface whose projection covers the pixel centre (i + 0.5, j + 0.5), row 0 at the top.
+ */
+#ifndef MSK_RENDER_H
+#define MSK_RENDER_H
+
+#include "msk_physx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSK_MAX_RENDER_VERTS 4096
+#define MSK_MAX_RENDER_TRIS 8192
+#define MSK_MAX_RENDER_SHAPES 128
+#define MSK_MAX_CAMERAS 4
+
+/* RenderShapeTriangleMesh / Box / Plane attached to a body (RenderBodyComponent.attach,
+ * building/actor_builder.py:166-191).  body = -1: static (env frame).  verts: nverts*3 floats in shape-local
+ * coordinates; tris: ntris*3 vertex indices, counter-clockwise seen from outside.  seg_id = Entity.per_scene_id
+ * written to the segmentation channel (sapien_env.py:1254-1265).  Call after msk_finalize, before
+ * msk_render_finalize.  Returns the render shape index. */
+int msk_render_add_mesh(msk_ctx* ctx, int body, const float local_pose[7], const float* verts, int nverts,
+                        const int32_t* tris, int ntris, int seg_id);
+/* RenderSystemGroup creation + set_cuda_poses (scene.py:1026-1037): uploads the geometry. */
+int msk_render_finalize(msk_ctx* ctx);
+/* RenderCameraComponent(width, height) + set_fovy(fovy, compute_x=True) + near / far + local pose
+ * (scene.py:198-297; sensors/camera.py:126-186).  mount_body = -1: the camera is fixed in the env frame.
+ * width and height must be multiples of 16.  Returns the camera id. */
+int msk_camera_create(msk_ctx* ctx, int width, int height, float fovy, float near_plane, float far_plane,
+                      int mount_body, const float local_pose[7]);
+/* camera_group.get_picture_cuda("PositionSegmentation"): device pointer to int16 [num_envs][height][width][4],
+ * valid until msk_destroy; shape gets the four extents. */
+void* msk_camera_buffer(msk_ctx* ctx, int camera, int64_t shape[4]);
+/* render_system_group.update_render() + camera_group.take_picture(): rasterises every env. */
+int msk_camera_take_picture(msk_ctx* ctx, int camera, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSK_RENDER_H */

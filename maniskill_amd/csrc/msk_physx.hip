@@ -7,6 +7,7 @@
  */
 #include "msk_kernels.h"
 #include "msk_task.h"
+#include "msk_render.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -48,6 +49,11 @@ struct msk_ctx {
   pose pending_root;
   int nverts_total;
   size_t lds_small, lds_big; /* dynamic LDS of the two solver launches */
+  RModel* rmodel;            /* host copy of the render geometry (include/msk_render.h) */
+  RModel* d_rmodel;
+  bool render_finalized;
+  int ncams;
+  RCamera cams[MSK_MAX_CAMERAS];
   msk_pickcube_desc pickcube; /* fused task kernels (include/msk_task.h) */
   bool has_pickcube;
   bool kin_dirty;        /* link frames in st.bpose are older than (q, qd): run k_kinematics before reading them */
@@ -122,6 +128,7 @@ MSK_API msk_ctx* msk_create(int hip_device, const msk_config* cfg) {
   c->max_dof = 0;
   c->t_cap = 0; c->t_n = 0;
   c->has_pickcube = false;
+  c->rmodel = nullptr; c->d_rmodel = nullptr; c->render_finalized = false; c->ncams = 0;
   c->err[0] = 0;
   return c;
 }
@@ -132,6 +139,7 @@ MSK_API void msk_destroy(msk_ctx* c) {
   hipDeviceSynchronize();
   for (void* p : c->allocs) hipFree(p);
   for (hipEvent_t e : c->tev) hipEventDestroy(e);
+  delete c->rmodel;
   delete c;
 }
 
@@ -614,6 +622,94 @@ MSK_API int msk_get_sizes(msk_ctx* c, int32_t out[8]) {
     HIP_TRY(hipMemcpy(&flag, c->st.env_overflow, sizeof(int), hipMemcpyDeviceToHost));
     out[7] = flag;
   }
+  return MSK_OK;
+}
+
+/* ---- camera pipeline (include/msk_render.h) ------------------------------------------------------------ */
+MSK_API int msk_render_add_mesh(msk_ctx* c, int body, const float local_pose[7], const float* verts, int nverts,
+                                const int32_t* tris, int ntris, int seg_id) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "render shapes are added after finalize");
+  if (c->render_finalized) return fail(c, MSK_ERR_INVALID, "render_add_mesh after render_finalize");
+  if (body >= c->model.nb) return fail(c, MSK_ERR_INVALID, "bad body");
+  if (!c->rmodel) { c->rmodel = new RModel(); memset(c->rmodel, 0, sizeof(RModel)); }
+  RModel& r = *c->rmodel;
+  if (r.ns >= MSK_MAX_RENDER_SHAPES || r.nv + nverts > MSK_MAX_RENDER_VERTS || r.nt + ntris > MSK_MAX_RENDER_TRIS)
+    return fail(c, MSK_ERR_CAPACITY, "render geometry capacity exceeded");
+  RShape& sh = r.shapes[r.ns];
+  sh.body = body; sh.seg = seg_id; sh.local = pose_from7(local_pose);
+  for (int i = 0; i < nverts; ++i) {
+    r.verts[r.nv + i].x = verts[3 * i]; r.verts[r.nv + i].y = verts[3 * i + 1]; r.verts[r.nv + i].z = verts[3 * i + 2];
+    r.vshape[r.nv + i] = (unsigned char)r.ns;
+  }
+  for (int i = 0; i < ntris; ++i) {
+    for (int k = 0; k < 3; ++k)
+      if (tris[3 * i + k] < 0 || tris[3 * i + k] >= nverts) return fail(c, MSK_ERR_INVALID, "triangle index out of range");
+    RTri& t = r.tris[r.nt + i];
+    t.v0 = r.nv + tris[3 * i]; t.v1 = r.nv + tris[3 * i + 1]; t.v2 = r.nv + tris[3 * i + 2]; t.shape = r.ns;
+  }
+  r.nv += nverts; r.nt += ntris;
+  return r.ns++;
+}
+
+MSK_API int msk_render_finalize(msk_ctx* c) {
+  if (!c->rmodel) return fail(c, MSK_ERR_INVALID, "no render shapes");
+  if (c->render_finalized) return fail(c, MSK_ERR_INVALID, "render_finalize twice");
+  HIP_TRY(hipSetDevice(c->device));
+  ALLOC(c->d_rmodel, 1);
+  HIP_TRY(hipMemcpy(c->d_rmodel, c->rmodel, sizeof(RModel), hipMemcpyHostToDevice));
+  c->render_finalized = true;
+  return MSK_OK;
+}
+
+MSK_API int msk_camera_create(msk_ctx* c, int width, int height, float fovy, float near_plane, float far_plane, int mount_body,
+                              const float local_pose[7]) {
+  if (!c->render_finalized) return fail(c, MSK_ERR_INVALID, "camera_create before render_finalize");
+  if (c->ncams >= MSK_MAX_CAMERAS) return fail(c, MSK_ERR_CAPACITY, "too many cameras");
+  if (width % MSK_TILE || height % MSK_TILE || width <= 0 || height <= 0 || (width / MSK_TILE) * (height / MSK_TILE) > MSK_MAX_TILES)
+    return fail(c, MSK_ERR_INVALID, "camera size must be a multiple of 16, at most 256 tiles");
+  if (mount_body >= c->model.nb) return fail(c, MSK_ERR_INVALID, "bad mount body");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t N = (size_t)c->model.N;
+  RCamera& cam = c->cams[c->ncams];
+  memset(&cam, 0, sizeof(cam));
+  cam.W = width; cam.H = height; cam.mount = mount_body;
+  cam.tiles_x = width / MSK_TILE; cam.tiles_y = height / MSK_TILE;
+  /* set_fovy(fovy, compute_x=True): square pixels, principal point at the image centre */
+  cam.fy = (float)(0.5 * height / tan(0.5 * (double)fovy));
+  cam.fx = cam.fy;
+  cam.cx = 0.5f * width; cam.cy = 0.5f * height;
+  cam.near_ = near_plane; cam.far_ = far_plane;
+  cam.local = pose_from7(local_pose);
+  cam.setup_cap = 2 * c->rmodel->nt < 65535 ? 2 * c->rmodel->nt : 65535;   /* list entries are 16-bit setup indices */
+  cam.list_cap = 4 * cam.setup_cap + 64 * cam.tiles_x * cam.tiles_y;
+  ALLOC(cam.setups, N * cam.setup_cap * MSK_SETUP_WORDS);
+  ALLOC(cam.nsetup, N);
+  ALLOC(cam.tile_off, N * (MSK_MAX_TILES + 1));
+  ALLOC(cam.lists, N * cam.list_cap);
+  ALLOC(cam.out, N * (size_t)width * height * 4);
+  ALLOC(cam.overflow, 1);
+  return c->ncams++;
+}
+
+MSK_API void* msk_camera_buffer(msk_ctx* c, int camera, int64_t shape[4]) {
+  if (camera < 0 || camera >= c->ncams) return nullptr;
+  shape[0] = c->model.N; shape[1] = c->cams[camera].H; shape[2] = c->cams[camera].W; shape[3] = 4;
+  return c->cams[camera].out;
+}
+
+MSK_API int msk_camera_take_picture(msk_ctx* c, int camera, void* stream) {
+  if (camera < 0 || camera >= c->ncams) return fail(c, MSK_ERR_INVALID, "bad camera");
+  const int N = c->model.N;
+  hipStream_t s = (hipStream_t)stream;
+  if (c->kin_dirty) { /* link frames of the current (q, qd) */
+    launch_kinematics(c->model, c->d_model, c->st, s);
+    c->kin_dirty = false;
+  }
+  const RCamera& cam = c->cams[camera];
+  const size_t lds = (MSK_MAX_RENDER_SHAPES * 8 + 2 * MSK_MAX_TILES + 4 + (size_t)c->rmodel->nv * 3) * sizeof(float);
+  hipLaunchKernelGGL(k_render_setup, dim3(N), dim3(256), lds, s, c->d_model, c->st, c->d_rmodel, cam);
+  hipLaunchKernelGGL(k_render_tiles, dim3(cam.tiles_x * cam.tiles_y, N), dim3(256), 0, s, cam);
+  HIP_TRY(hipGetLastError());
   return MSK_OK;
 }
 

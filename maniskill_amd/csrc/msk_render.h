@@ -1,0 +1,250 @@
+/*
+ * msk_render.h — batched depth + segmentation rasteriser (include/msk_render.h), gfx950.
+ *
+ *   k_render_setup   one 256-thread workgroup per env.  Threads first build the camera-from-shape
+ *                    transforms (body poses come straight from the simulator's env record), then
+ *                    transform the render vertices into the camera frame (LDS), then set up the
+ *                    triangles: near-plane clip, projection, back-face cull, edge + 1/depth plane
+ *                    equations, pixel bounding box -> 64-byte TriSetup records, binned into
+ *                    16x16-pixel tiles (LDS counters, prefix, per-tile index lists).
+ *   k_render_tiles   one workgroup per (tile, env), thread = pixel: the tile's setups are staged
+ *                    through LDS 64 at a time; per pixel 3 edge evaluations + 1/depth compare; the
+ *                    winner's camera-space position (mm, int16) and segmentation id are written as
+ *                    one 8-byte store per pixel, 128 contiguous bytes per tile row.
+ *
+ * The output (N x H x W x 8 bytes = 512 MiB at 4096 envs, 128x128) is the algorithmic traffic of
+ * this path: it is HBM-write-bound by construction.  Arithmetic follows oracle/orc_render.c
+ * statement by statement (the images are compared bit for bit).
+ */
+#ifndef MSK_RENDER_KERNELS_H
+#define MSK_RENDER_KERNELS_H
+
+#include "../../include/msk_render.h"
+#include "msk_model.h"
+
+#define MSK_TILE 16
+#define MSK_MAX_TILES 256          /* up to 256x256 images */
+#define MSK_SETUP_WORDS 16
+
+struct RShape { int body, seg; pose local; };
+struct RTri { int v0, v1, v2, shape; };
+struct RModel {
+  int nv, nt, ns;
+  RShape shapes[MSK_MAX_RENDER_SHAPES];
+  v3 verts[MSK_MAX_RENDER_VERTS];
+  unsigned char vshape[MSK_MAX_RENDER_VERTS];
+  RTri tris[MSK_MAX_RENDER_TRIS];
+};
+struct RCamera {
+  int W, H, mount, tiles_x, tiles_y;
+  float fx, fy, cx, cy, near_, far_;
+  pose local;
+  int setup_cap, list_cap;         /* per env */
+  float* setups;                   /* [N][setup_cap][16]  */
+  int* nsetup;                     /* [N]                 */
+  int* tile_off;                   /* [N][ntiles + 1]     */
+  unsigned short* lists;           /* [N][list_cap]       */
+  short* out;                      /* [N][H][W][4]        */
+  int* overflow;                   /* [1]                 */
+};
+
+/* One screen triangle: A,B,C of the three edge functions (inside = all >= 0), the 1/depth plane,
+ * segmentation id, primitive id (tie break), pixel bounding box. */
+struct TriSetup {
+  float A0, B0, C0, A1, B1, C1, A2, B2, C2, Aw, Bw, Cw;
+  int seg, prim, bbx, bby;         /* bbx = x0 | x1 << 16, bby = y0 | y1 << 16 */
+};
+
+/* projects a camera-frame point (x forward, y left, z up): pixel coordinates and 1/depth */
+MSK_DEV void project_point(const RCamera& cam, v3 p, float* u, float* v, float* w) {
+  const float iw = 1.0f / p.x;
+  *u = fmaf(cam.fx, -p.y * iw, cam.cx);
+  *v = fmaf(-cam.fy, p.z * iw, cam.cy);
+  *w = iw;
+}
+
+/* sets up the screen triangle (p0, p1, p2), all in front of the near plane; returns 0 if it is culled */
+MSK_DEV int setup_triangle(const RCamera& cam, v3 p0, v3 p1, v3 p2, int seg, int prim, TriSetup* t) {
+  float u0, v0, w0, u1, v1, w1, u2, v2, w2;
+  project_point(cam, p0, &u0, &v0, &w0);
+  project_point(cam, p1, &u1, &v1, &w1);
+  project_point(cam, p2, &u2, &v2, &w2);
+  /* image rows grow downwards: a triangle that is counter-clockwise seen from outside has negative area here */
+  const float area = fmaf(u1 - u0, v2 - v0, -((v1 - v0) * (u2 - u0)));
+  if (!(area < -1e-12f)) return 0;
+  /* swap 1 <-> 2: positive orientation, interior = all edge functions >= 0 */
+  float t_; t_ = u1; u1 = u2; u2 = t_; t_ = v1; v1 = v2; v2 = t_; t_ = w1; w1 = w2; w2 = t_;
+  const float a2 = -area;
+  const float umin = fminf(u0, fminf(u1, u2)), umax = fmaxf(u0, fmaxf(u1, u2));
+  const float vmin = fminf(v0, fminf(v1, v2)), vmax = fmaxf(v0, fmaxf(v1, v2));
+  /* pixel centres at +0.5 */
+  int x0 = (int)ceilf(umin - 0.5f), x1 = (int)floorf(umax - 0.5f);
+  int y0 = (int)ceilf(vmin - 0.5f), y1 = (int)floorf(vmax - 0.5f);
+  if (!(umin < 1e9f && umax > -1e9f && vmin < 1e9f && vmax > -1e9f)) return 0;
+  x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, cam.W - 1); y1 = min(y1, cam.H - 1);
+  if (x0 > x1 || y0 > y1) return 0;
+  /* edge a->b: E(x, y) = (b.u - a.u)(y - a.v) - (b.v - a.v)(x - a.u) = A x + B y + C */
+  t->A0 = -(v1 - v0); t->B0 = u1 - u0; t->C0 = -fmaf(t->A0, u0, t->B0 * v0);
+  t->A1 = -(v2 - v1); t->B1 = u2 - u1; t->C1 = -fmaf(t->A1, u1, t->B1 * v1);
+  t->A2 = -(v0 - v2); t->B2 = u0 - u2; t->C2 = -fmaf(t->A2, u2, t->B2 * v2);
+  /* 1/depth is affine on the screen: w = (E12 w0 + E20 w1 + E01 w2) / area */
+  const float ia = 1.0f / a2;
+  t->Aw = fmaf(t->A1, w0, fmaf(t->A2, w1, t->A0 * w2)) * ia;
+  t->Bw = fmaf(t->B1, w0, fmaf(t->B2, w1, t->B0 * w2)) * ia;
+  t->Cw = fmaf(t->C1, w0, fmaf(t->C2, w1, t->C0 * w2)) * ia;
+  t->seg = seg; t->prim = prim;
+  t->bbx = x0 | (x1 << 16); t->bby = y0 | (y1 << 16);
+  return 1;
+}
+
+MSK_DEV v3 lerp_near(v3 a, v3 b, float near_) { /* point of segment a-b on the plane x = near */
+  const float s = (near_ - a.x) / (b.x - a.x);
+  return v3_make(near_, fmaf(s, b.y - a.y, a.y), fmaf(s, b.z - a.z, a.z));
+}
+
+__global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__ m, DState st, const RModel* __restrict__ rm, RCamera cam) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int e = blockIdx.x, tid = threadIdx.x;
+  const int ntiles = cam.tiles_x * cam.tiles_y;
+  /* LDS: shape transforms [ns][8] | tile counters [ntiles] | tile fill [ntiles] | nsetup | camera-frame vertices [nv][3] */
+  float* Lshape = lds;
+  int* Lcnt = (int*)(lds + MSK_MAX_RENDER_SHAPES * 8);
+  int* Lfill = Lcnt + MSK_MAX_TILES;
+  int* Lns = Lfill + MSK_MAX_TILES;
+  float* Lv = (float*)(Lns + 4);
+  const float* E = EREC(st, m, e);
+  for (int i = tid; i < ntiles; i += 256) { Lcnt[i] = 0; Lfill[i] = 0; }
+  if (tid == 0) *Lns = 0;
+  /* camera-from-shape transforms */
+  pose Tc = cam.local;
+  if (cam.mount >= 0) Tc = pose_mul(load_pose(E, m->lay.bpose, cam.mount), cam.local);
+  const pose Tci = pose_inv(Tc);
+  for (int s = tid; s < rm->ns; s += 256) {
+    const RShape* sh = &rm->shapes[s];
+    pose T = sh->local;
+    if (sh->body >= 0) T = pose_mul(load_pose(E, m->lay.bpose, sh->body), sh->local);
+    T = pose_mul(Tci, T);
+    float* o = Lshape + s * 8;
+    o[0] = T.p.x; o[1] = T.p.y; o[2] = T.p.z; o[3] = T.q.w; o[4] = T.q.x; o[5] = T.q.y; o[6] = T.q.z;
+  }
+  __syncthreads();
+  for (int vi = tid; vi < rm->nv; vi += 256) {
+    const float* o = Lshape + rm->vshape[vi] * 8;
+    pose T;
+    T.p = v3_make(o[0], o[1], o[2]);
+    T.q = quat_make(o[3], o[4], o[5], o[6]);
+    const v3 p = pose_apply(T, rm->verts[vi]);
+    Lv[vi * 3 + 0] = p.x; Lv[vi * 3 + 1] = p.y; Lv[vi * 3 + 2] = p.z;
+  }
+  __syncthreads();
+  TriSetup* setups = (TriSetup*)(cam.setups + (size_t)e * cam.setup_cap * MSK_SETUP_WORDS);
+  for (int ti = tid; ti < rm->nt; ti += 256) {
+    const RTri tr = rm->tris[ti];
+    const v3 p[3] = {v3_make(Lv[tr.v0 * 3], Lv[tr.v0 * 3 + 1], Lv[tr.v0 * 3 + 2]), v3_make(Lv[tr.v1 * 3], Lv[tr.v1 * 3 + 1], Lv[tr.v1 * 3 + 2]),
+                     v3_make(Lv[tr.v2 * 3], Lv[tr.v2 * 3 + 1], Lv[tr.v2 * 3 + 2])};
+    const int seg = rm->shapes[tr.shape].seg;
+    /* clip against the near plane x >= near: a triangle becomes 0, 1 or 2 triangles */
+    const bool in0 = p[0].x >= cam.near_, in1 = p[1].x >= cam.near_, in2 = p[2].x >= cam.near_;
+    const int nin = (int)in0 + (int)in1 + (int)in2;
+    v3 q[4];
+    int nq = 0;
+    if (nin == 3) { q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; nq = 3; }
+    else if (nin > 0) {
+      for (int k = 0; k < 3; ++k) { /* Sutherland-Hodgman against one plane, keeps the winding */
+        const v3 a = p[k], b = p[(k + 1) % 3];
+        const bool ia = a.x >= cam.near_, ib = b.x >= cam.near_;
+        if (ia) q[nq++] = a;
+        if (ia != ib) q[nq++] = ia ? lerp_near(a, b, cam.near_) : lerp_near(b, a, cam.near_);
+      }
+    }
+    for (int sub = 0; sub + 2 < nq; ++sub) {
+      TriSetup t;
+      if (!setup_triangle(cam, q[0], q[sub + 1], q[sub + 2], seg, ti * 2 + sub, &t)) continue;
+      const int slot = atomicAdd(Lns, 1);
+      if (slot >= cam.setup_cap) { atomicOr(cam.overflow, 1); continue; }
+      setups[slot] = t;
+      const int tx0 = (t.bbx & 0xFFFF) / MSK_TILE, tx1 = (t.bbx >> 16) / MSK_TILE, ty0 = (t.bby & 0xFFFF) / MSK_TILE, ty1 = (t.bby >> 16) / MSK_TILE;
+      for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&Lcnt[ty * cam.tiles_x + tx], 1);
+    }
+  }
+  __syncthreads();
+  const int ns = min(*Lns, cam.setup_cap);
+  int* toff = cam.tile_off + (size_t)e * (MSK_MAX_TILES + 1);
+  if (tid == 0) {
+    int acc = 0;
+    for (int i = 0; i < ntiles; ++i) {
+      const int c = Lcnt[i];
+      if (acc + c > cam.list_cap) atomicOr(cam.overflow, 1);
+      Lcnt[i] = acc;              /* Lcnt now holds the start of the tile's list */
+      toff[i] = acc;
+      acc = min(acc + c, cam.list_cap);
+    }
+    toff[ntiles] = acc;
+    Lcnt[ntiles] = acc;
+    cam.nsetup[e] = ns;
+  }
+  __syncthreads();
+  unsigned short* list = cam.lists + (size_t)e * cam.list_cap;
+  for (int s = tid; s < ns; s += 256) {
+    const TriSetup* t = &setups[s];
+    const int bbx = t->bbx, bby = t->bby;
+    const int tx0 = (bbx & 0xFFFF) / MSK_TILE, tx1 = (bbx >> 16) / MSK_TILE, ty0 = (bby & 0xFFFF) / MSK_TILE, ty1 = (bby >> 16) / MSK_TILE;
+    for (int ty = ty0; ty <= ty1; ++ty)
+      for (int tx = tx0; tx <= tx1; ++tx) {
+        const int tile = ty * cam.tiles_x + tx;
+        const int pos = Lcnt[tile] + atomicAdd(&Lfill[tile], 1);
+        if (pos < Lcnt[tile + 1]) list[pos] = (unsigned short)s;
+      }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_render_tiles(RCamera cam) {
+  __shared__ __attribute__((aligned(16))) float Ls[64 * MSK_SETUP_WORDS];
+  const int tile = blockIdx.x, e = blockIdx.y, tid = threadIdx.x;
+  const int tx = tile % cam.tiles_x, ty = tile / cam.tiles_x;
+  const int px = tx * MSK_TILE + (tid % MSK_TILE), py = ty * MSK_TILE + (tid / MSK_TILE);
+  const float x = (float)px + 0.5f, y = (float)py + 0.5f;
+  const int* toff = cam.tile_off + (size_t)e * (MSK_MAX_TILES + 1);
+  const int l0 = toff[tile], l1 = toff[tile + 1];
+  const unsigned short* list = cam.lists + (size_t)e * cam.list_cap;
+  const float4* setups = (const float4*)(cam.setups + (size_t)e * cam.setup_cap * MSK_SETUP_WORDS);
+  float best_w = 0.0f;
+  int best_seg = 0, best_prim = 0x7FFFFFFF;
+  const float wmin = 1.0f / cam.far_;
+  for (int c0 = l0; c0 < l1; c0 += 64) {
+    const int n = min(64, l1 - c0);
+    __syncthreads();
+    { /* stage up to 64 setups: 256 threads x one float4 */
+      const int r = tid / 4, part = tid % 4;
+      if (r < n) ((float4*)Ls)[r * 4 + part] = setups[(size_t)list[c0 + r] * 4 + part];
+    }
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+      const float* t = Ls + k * MSK_SETUP_WORDS;
+      const float e0 = fmaf(t[0], x, fmaf(t[1], y, t[2]));
+      const float e1 = fmaf(t[3], x, fmaf(t[4], y, t[5]));
+      const float e2 = fmaf(t[6], x, fmaf(t[7], y, t[8]));
+      if (e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f) {
+        const float w = fmaf(t[9], x, fmaf(t[10], y, t[11]));
+        const int prim = __float_as_int(t[13]);
+        if (w >= wmin && (w > best_w || (w == best_w && prim < best_prim))) {
+          best_w = w; best_prim = prim; best_seg = __float_as_int(t[12]);
+        }
+      }
+    }
+  }
+  /* camera-space OpenGL position in millimetres (x right, y up, z backwards), int16 saturated */
+  short4 o = make_short4(0, 0, 0, 0);
+  if (best_w > 0.0f) {
+    const float d = 1.0f / best_w;
+    const float gx = (x - cam.cx) / cam.fx * d, gy = -(y - cam.cy) / cam.fy * d, gz = -d;
+    o.x = (short)fminf(fmaxf(rintf(gx * 1000.0f), -32768.0f), 32767.0f);
+    o.y = (short)fminf(fmaxf(rintf(gy * 1000.0f), -32768.0f), 32767.0f);
+    o.z = (short)fminf(fmaxf(rintf(gz * 1000.0f), -32768.0f), 32767.0f);
+    o.w = (short)best_seg;
+  }
+  ((short4*)cam.out)[((size_t)e * cam.H + py) * cam.W + px] = o;
+}
+
+#endif

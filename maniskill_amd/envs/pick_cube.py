@@ -101,7 +101,7 @@ class PickCubeEnv:
     def __init__(self, num_envs: int = 1, device: Optional[str] = None, sim_config: Optional[SimConfig] = None,
                  robot_init_qpos_noise: float = 0.02, reward_mode: str = "normalized_dense",
                  env_index_offset: int = 0, total_envs: Optional[int] = None, px_factory=None,
-                 fused: Optional[bool] = None):
+                 fused: Optional[bool] = None, obs_mode: str = "state"):
         self.num_envs = int(num_envs)
         self.sim_config = sim_config or SimConfig()
         self.robot_init_qpos_noise = robot_init_qpos_noise
@@ -173,7 +173,25 @@ class PickCubeEnv:
             self._f_obs = torch.zeros(N, self.obs_dim, dtype=torch.float32, device=dev)
             self._f_rew = torch.zeros(N, dtype=torch.float32, device=dev)
             self._f_flags = torch.zeros(N, 8, dtype=torch.uint8, device=dev)
+        # sensors: PickCube-v1's base_camera (pick_cube.py:64-71), 128 x 128, fov pi/2, depth + segmentation textures
+        if obs_mode not in ("state", "depth+segmentation"):
+            raise NotImplementedError(f"obs_mode {obs_mode!r}: this backend provides 'state' and 'depth+segmentation'")
+        self.obs_mode = obs_mode
+        self.camera = None
+        if obs_mode != "state":
+            from ..render import CameraConfig, RenderCameraGroup, attach_template_visuals, look_at
+            attach_template_visuals(self.px, tpl, hidden_bodies=(self._b_goal,))   # goal_site is in _hidden_objects
+            p, q = look_at(eye=[0.3, 0, 0.6], target=[-0.1, 0, 0.1])
+            self.camera = RenderCameraGroup(self.px, CameraConfig("base_camera", p, q, 128, 128, np.pi / 2, 0.01, 100.0))
         self.reset(seed=None)
+
+    def _with_sensor_data(self, state_obs):
+        """_get_obs_with_sensor_data (sapien_env.py:627-634): update_render, take_picture, texture transforms."""
+        if self.camera is None:
+            return state_obs
+        self.camera.take_picture()
+        return dict(state=state_obs, sensor_data=dict(base_camera=self.camera.get_obs()),
+                    sensor_param=dict(base_camera=dict(intrinsic_cv=self.camera.intrinsic_cv)))
 
     # ---------------------------------------------------------------- struct-style views
     def _fresh(self):
@@ -275,7 +293,7 @@ class PickCubeEnv:
             obs, _, _, _, info = self._fused_observe(False)
             return obs, info
         info = self.get_info()
-        obs = self.get_obs(info)
+        obs = self._with_sensor_data(self.get_obs(info))
         return obs, info
 
     # ---------------------------------------------------------------- step
@@ -312,7 +330,7 @@ class PickCubeEnv:
         fl = self._f_flags.bool()
         info = dict(elapsed_steps=self._elapsed_steps.clone(), success=fl[:, 0], is_obj_placed=fl[:, 1], is_robot_static=fl[:, 2],
                     is_grasped=fl[:, 3])
-        return self._f_obs.clone(), self._f_rew.clone(), fl[:, 4], fl[:, 5], info
+        return self._with_sensor_data(self._f_obs.clone()), self._f_rew.clone(), fl[:, 4], fl[:, 5], info
 
     def _fused_step(self, action):
         """BaseEnv.step on the fused kernels: controller, substeps + link frames, evaluate/obs/reward."""
@@ -341,8 +359,9 @@ class PickCubeEnv:
         action = self._step_action(action)
         self._elapsed_steps += 1
         info = self.get_info()
-        obs = self.get_obs(info)
-        reward = self.get_reward(obs, action, info)
+        sobs = self.get_obs(info)
+        reward = self.get_reward(sobs, action, info)
+        obs = self._with_sensor_data(sobs)
         terminated = info["success"].clone()
         truncated = self._elapsed_steps >= self.max_episode_steps  # TimeLimitWrapper
         return obs, reward, terminated, truncated, info

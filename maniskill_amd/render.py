@@ -1,0 +1,204 @@
+"""Host-side mirror of the ``sapien.render`` surface on ManiSkill's camera hot path.
+
+Reference call sites (names and argument meaning kept):
+  * ``RenderSystemGroup`` / ``set_cuda_poses`` / ``update_render``       mani_skill/envs/scene.py:382-427,1026-1037
+  * ``create_camera_group`` / ``take_picture`` / ``get_picture_cuda``   scene.py:1087-1110; utils/structs/render_camera.py:160-182,269-273
+  * ``CameraConfig`` (uid, pose, width, height, fov, near, far)         mani_skill/sensors/camera.py:32-67
+  * ``look_at``                                                         mani_skill/utils/sapien_utils.py:317-364
+  * texture transforms of the ``minimal`` shader pack                   mani_skill/render/shaders.py:68-84
+
+All pixels are produced by the C-ABI library (include/msk_render.h: tile-binned HIP rasteriser); this module owns
+handles, builds the triangle lists of the template's shapes once (cold path) and exposes zero-copy tensor views.
+
+What is drawn: every collision shape of the template that belongs to a visible body (boxes, convex hulls, the
+ground plane as a large quad).  The reference draws the robots' visual GLB meshes (~135 k triangles per Panda);
+here the robot appears as its cooked collision hulls — same silhouettes to within the hull-vs-mesh
+deviation, segmentation ids per link identical.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+GROUND_HALF_EXTENT = 50.0  # building/ground.py:46-119 draws a 100 x 100 m grid
+
+
+@dataclass
+class CameraConfig:
+    """sensors/camera.py:32-67 (the fields the camera hot path reads)."""
+    uid: str
+    p: Sequence[float]
+    q: Sequence[float]
+    width: int = 128
+    height: int = 128
+    fov: float = np.pi / 2
+    near: float = 0.01
+    far: float = 100.0
+    mount: int = -1            # template body id the camera rides on, -1 = fixed in the sub-scene frame
+
+
+def look_at(eye, target, up=(0.0, 0.0, 1.0)):
+    """sapien_utils.look_at: camera pose (p, q wxyz) with x forward, y left, z up."""
+    eye, target, up = (np.asarray(v, dtype=np.float64) for v in (eye, target, up))
+    f = target - eye
+    f /= np.linalg.norm(f)
+    left = np.cross(up / np.linalg.norm(up), f)
+    left /= np.linalg.norm(left)
+    upv = np.cross(f, left)
+    R = np.stack([f, left, upv], axis=1)
+    # rotation matrix -> quaternion (wxyz)
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = np.zeros(4)
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    if q[0] < 0:
+        q = -q
+    return eye.astype(np.float32), (q / np.linalg.norm(q)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# triangle lists of the primitive shapes (counter-clockwise seen from outside)
+# --------------------------------------------------------------------------------------
+def box_mesh(half):
+    hx, hy, hz = [float(h) for h in half]
+    v = np.array([[sx * hx, sy * hy, sz * hz] for sz in (-1, 1) for sy in (-1, 1) for sx in (-1, 1)], dtype=np.float32)
+    quads = [(0, 2, 3, 1), (4, 5, 7, 6), (0, 1, 5, 4), (2, 6, 7, 3), (0, 4, 6, 2), (1, 3, 7, 5)]
+    t = []
+    for a, b, c, d in quads:
+        t += [(a, b, c), (a, c, d)]
+    return v, _outward(v, np.asarray(t, dtype=np.int32))
+
+
+def plane_mesh(half_extent=GROUND_HALF_EXTENT):
+    """Plane through the shape origin with normal +x (SAPIEN convention), as one quad."""
+    L = float(half_extent)
+    v = np.array([[0, -L, -L], [0, L, -L], [0, L, L], [0, -L, L]], dtype=np.float32)
+    return v, np.array([[0, 1, 2], [0, 2, 3]], dtype=np.int32)   # counter-clockwise seen from +x
+
+
+def hull_mesh(verts):
+    from scipy.spatial import ConvexHull
+
+    v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+    h = ConvexHull(v.astype(np.float64))
+    return v, _outward(v, h.simplices.astype(np.int32))
+
+
+def _outward(v, tris):
+    c = v.mean(axis=0)
+    out = tris.copy()
+    for i, (a, b, cc) in enumerate(tris):
+        n = np.cross(v[b] - v[a], v[cc] - v[a])
+        if np.dot(n, v[a] - c) < 0:
+            out[i] = (a, cc, b)
+    return out
+
+
+class PictureHandle:
+    """``camera_group.get_picture_cuda(name)``: an object with ``.torch()``."""
+
+    def __init__(self, tensor):
+        self._t = tensor
+
+    def torch(self):
+        return self._t
+
+
+class _DevPtr:
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(int(s) for s in shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class RenderCameraGroup:
+    """One batched camera: ``take_picture()`` rasterises every sub-scene, ``get_picture_cuda`` returns the
+    ``PositionSegmentation`` texture (N, H, W, 4) int16."""
+
+    def __init__(self, px, cfg: CameraConfig):
+        self.px, self.cfg = px, cfg
+        L = px.lib
+        cam = L.check(px.ctx, L.camera_create(px.ctx, int(cfg.width), int(cfg.height), float(cfg.fov), float(cfg.near), float(cfg.far),
+                                              int(cfg.mount), N._fa(list(cfg.p) + list(cfg.q), 7)), "camera_create")
+        self.id = cam
+        shape = (C.c_int64 * 4)()
+        ptr = L.camera_buffer(px.ctx, cam, shape)
+        if not ptr:
+            raise RuntimeError("msk_camera_buffer returned NULL")
+        shp = tuple(int(s) for s in shape)
+        if px.host_memory:
+            n = int(np.prod(shp))
+            arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int16)), shape=(n,)).reshape(shp)
+            self._tex = torch.from_numpy(arr)
+        else:
+            self._tex = torch.as_tensor(_DevPtr(ptr, shp, "<i2"), device=px.device)
+            assert self._tex.data_ptr() == ptr
+        # intrinsics of set_fovy(fovy, compute_x=True) (scene.py:250-257)
+        fy = 0.5 * cfg.height / np.tan(0.5 * cfg.fov)
+        self.intrinsic_cv = torch.tensor([[fy, 0, 0.5 * cfg.width], [0, fy, 0.5 * cfg.height], [0, 0, 1]], dtype=torch.float32)
+
+    def take_picture(self):
+        L, px = self.px.lib, self.px
+        L.check(px.ctx, L.camera_take_picture(px.ctx, self.id, px._stream()), "camera_take_picture")
+
+    def get_picture_cuda(self, name: str = "PositionSegmentation") -> PictureHandle:
+        if name != "PositionSegmentation":
+            raise KeyError(f"the minimal shader pack of this backend provides PositionSegmentation only, not {name}")
+        return PictureHandle(self._tex)
+
+    def get_obs(self, depth=True, segmentation=True, position=False):
+        """Camera.get_obs (sensors/camera.py:190-242) with the minimal pack's texture transform."""
+        data = self._tex
+        out = {}
+        if position:
+            out["position"] = data[..., :3]
+        if depth:
+            out["depth"] = -data[..., [2]]
+        if segmentation:
+            out["segmentation"] = data[..., [3]]
+        return out
+
+
+def attach_template_visuals(px, template, hidden_bodies=()):
+    """RenderBodyComponent per body from the template's collision shapes (building/actor_builder.py:166-191 attaches the
+    visual records; this backend draws the collision geometry).  Segmentation id = body id + 1 (per_scene_id in
+    add_entity order, 0 = background); the static ground gets bodies_per_env + 1."""
+    L = px.lib
+    nb = px.bodies_per_env
+    n = 0
+    for op, a in template.ops:
+        if op != "add_shape":
+            continue
+        body, stype, pose7, params, verts = a[0], a[1], a[2], a[3], a[4]
+        if body in hidden_bodies:
+            continue
+        if stype == N.SHAPE_BOX:
+            v, t = box_mesh(params)
+        elif stype == N.SHAPE_PLANE:
+            v, t = plane_mesh()
+        elif stype == N.SHAPE_CONVEX:
+            v, t = hull_mesh(verts)
+        else:
+            continue
+        seg = (body + 1) if body >= 0 else nb + 1
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        t = np.ascontiguousarray(t, dtype=np.int32)
+        L.check(px.ctx, L.render_add_mesh(px.ctx, int(body), N._fa(pose7, 7), v.ctypes.data_as(C.POINTER(C.c_float)), len(v),
+                                          t.ctypes.data_as(C.POINTER(C.c_int32)), len(t), int(seg)), "render_add_mesh")
+        n += 1
+    L.check(px.ctx, L.render_finalize(px.ctx), "render_finalize")
+    return n

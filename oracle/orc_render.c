@@ -1,0 +1,229 @@
+/*
+ * orc_render.c — scalar CPU restatement of the depth + segmentation camera (TEST INFRASTRUCTURE ONLY).
+ *
+ * Stands in for `render_system_group.update_render()` + `camera_group.take_picture()` +
+ * `get_picture_cuda("PositionSegmentation")` (mani_skill/envs/scene.py:382-427,
+ * mani_skill/utils/structs/render_camera.py:160-182,269-273) under the `minimal` shader contract of
+ * mani_skill/render/shaders.py:68-84,141-145: int16 x 4 per pixel = camera-space OpenGL position in
+ * millimetres + segmentation id, background 0.  The arithmetic behind those calls (SAPIEN's Vulkan
+ * rasteriser) is not in the reference tree: parity unpinned against it.  What is restated here is the
+ * textbook pipeline the HIP kernels implement — camera-frame vertices, near-plane clip, projection
+ * with the reference's camera conventions (x forward / y left / z up, pixel centres at +0.5, row 0 on
+ * top), back-face cull, edge functions, nearest surface per pixel — one env, one pixel, one triangle
+ * at a time, in triangle order.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/msk_render.h"
+#include "orc_sim.h"
+
+#define ORC_EXPORT __attribute__((visibility("default")))
+
+typedef struct { int body, seg; pose local; } r_shape;
+typedef struct { int v0, v1, v2, shape; } r_tri;
+typedef struct {
+  int W, H, mount;
+  float fx, fy, cx, cy, near_, far_;
+  pose local;
+  int16_t* out;
+} r_camera;
+typedef struct {
+  int nv, nt, ns, finalized, ncams;
+  r_shape shapes[MSK_MAX_RENDER_SHAPES];
+  v3 verts[MSK_MAX_RENDER_VERTS];
+  unsigned char vshape[MSK_MAX_RENDER_VERTS];
+  r_tri tris[MSK_MAX_RENDER_TRIS];
+  r_camera cams[MSK_MAX_CAMERAS];
+} r_model;
+
+typedef struct {
+  float A0, B0, C0, A1, B1, C1, A2, B2, C2, Aw, Bw, Cw;
+  int seg, prim, x0, x1, y0, y1;
+} r_setup;
+
+static int rfail(orc_ctx* c, int code, const char* msg) {
+  strncpy(c->err, msg, sizeof(c->err) - 1);
+  return code;
+}
+static pose r_pose7(const float* p) {
+  pose r;
+  r.p = v3_make(p[0], p[1], p[2]);
+  r.q = quat_normalize(quat_make(p[3], p[4], p[5], p[6]));
+  return r;
+}
+
+ORC_EXPORT int orc_render_add_mesh(orc_ctx* c, int body, const float local_pose[7], const float* verts, int nverts,
+                                   const int32_t* tris, int ntris, int seg_id) {
+  if (!c->finalized) return rfail(c, MSK_ERR_INVALID, "render shapes are added after finalize");
+  if (!c->render) c->render = calloc(1, sizeof(r_model));
+  r_model* r = (r_model*)c->render;
+  if (r->finalized) return rfail(c, MSK_ERR_INVALID, "render_add_mesh after render_finalize");
+  if (r->ns >= MSK_MAX_RENDER_SHAPES || r->nv + nverts > MSK_MAX_RENDER_VERTS || r->nt + ntris > MSK_MAX_RENDER_TRIS)
+    return rfail(c, MSK_ERR_CAPACITY, "render geometry capacity exceeded");
+  r->shapes[r->ns].body = body;
+  r->shapes[r->ns].seg = seg_id;
+  r->shapes[r->ns].local = r_pose7(local_pose);
+  for (int i = 0; i < nverts; ++i) {
+    r->verts[r->nv + i] = v3_make(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
+    r->vshape[r->nv + i] = (unsigned char)r->ns;
+  }
+  for (int i = 0; i < ntris; ++i) {
+    r_tri* t = &r->tris[r->nt + i];
+    t->v0 = r->nv + tris[3 * i]; t->v1 = r->nv + tris[3 * i + 1]; t->v2 = r->nv + tris[3 * i + 2]; t->shape = r->ns;
+  }
+  r->nv += nverts; r->nt += ntris;
+  return r->ns++;
+}
+
+ORC_EXPORT int orc_render_finalize(orc_ctx* c) {
+  if (!c->render) return rfail(c, MSK_ERR_INVALID, "no render shapes");
+  ((r_model*)c->render)->finalized = 1;
+  return MSK_OK;
+}
+
+ORC_EXPORT int orc_camera_create(orc_ctx* c, int width, int height, float fovy, float near_plane, float far_plane, int mount_body,
+                                 const float local_pose[7]) {
+  r_model* r = (r_model*)c->render;
+  if (!r || !r->finalized) return rfail(c, MSK_ERR_INVALID, "camera_create before render_finalize");
+  if (r->ncams >= MSK_MAX_CAMERAS) return rfail(c, MSK_ERR_CAPACITY, "too many cameras");
+  if (width % 16 || height % 16 || width <= 0 || height <= 0) return rfail(c, MSK_ERR_INVALID, "camera size must be a multiple of 16");
+  r_camera* cam = &r->cams[r->ncams];
+  cam->W = width; cam->H = height; cam->mount = mount_body;
+  cam->fy = (float)(0.5 * height / tan(0.5 * (double)fovy));
+  cam->fx = cam->fy;
+  cam->cx = 0.5f * width; cam->cy = 0.5f * height;
+  cam->near_ = near_plane; cam->far_ = far_plane;
+  cam->local = r_pose7(local_pose);
+  cam->out = (int16_t*)calloc((size_t)c->num_envs * width * height * 4, sizeof(int16_t));
+  return r->ncams++;
+}
+
+ORC_EXPORT void* orc_camera_buffer(orc_ctx* c, int camera, int64_t shape[4]) {
+  r_model* r = (r_model*)c->render;
+  if (!r || camera < 0 || camera >= r->ncams) return NULL;
+  shape[0] = c->num_envs; shape[1] = r->cams[camera].H; shape[2] = r->cams[camera].W; shape[3] = 4;
+  return r->cams[camera].out;
+}
+
+static void project_point(const r_camera* cam, v3 p, float* u, float* v, float* w) {
+  const float iw = 1.0f / p.x;
+  *u = fmaf(cam->fx, -p.y * iw, cam->cx);
+  *v = fmaf(-cam->fy, p.z * iw, cam->cy);
+  *w = iw;
+}
+
+static int setup_triangle(const r_camera* cam, v3 p0, v3 p1, v3 p2, int seg, int prim, r_setup* t) {
+  float u0, v0, w0, u1, v1, w1, u2, v2, w2;
+  project_point(cam, p0, &u0, &v0, &w0);
+  project_point(cam, p1, &u1, &v1, &w1);
+  project_point(cam, p2, &u2, &v2, &w2);
+  /* rows grow downwards: counter-clockwise (seen from outside) = negative area; others are back faces */
+  const float area = fmaf(u1 - u0, v2 - v0, -((v1 - v0) * (u2 - u0)));
+  if (!(area < -1e-12f)) return 0;
+  float t_; t_ = u1; u1 = u2; u2 = t_; t_ = v1; v1 = v2; v2 = t_; t_ = w1; w1 = w2; w2 = t_;
+  const float a2 = -area;
+  const float umin = fminf(u0, fminf(u1, u2)), umax = fmaxf(u0, fmaxf(u1, u2));
+  const float vmin = fminf(v0, fminf(v1, v2)), vmax = fmaxf(v0, fmaxf(v1, v2));
+  if (!(umin < 1e9f && umax > -1e9f && vmin < 1e9f && vmax > -1e9f)) return 0;
+  int x0 = (int)ceilf(umin - 0.5f), x1 = (int)floorf(umax - 0.5f);
+  int y0 = (int)ceilf(vmin - 0.5f), y1 = (int)floorf(vmax - 0.5f);
+  if (x0 < 0) x0 = 0;
+  if (y0 < 0) y0 = 0;
+  if (x1 > cam->W - 1) x1 = cam->W - 1;
+  if (y1 > cam->H - 1) y1 = cam->H - 1;
+  if (x0 > x1 || y0 > y1) return 0;
+  t->A0 = -(v1 - v0); t->B0 = u1 - u0; t->C0 = -fmaf(t->A0, u0, t->B0 * v0);
+  t->A1 = -(v2 - v1); t->B1 = u2 - u1; t->C1 = -fmaf(t->A1, u1, t->B1 * v1);
+  t->A2 = -(v0 - v2); t->B2 = u0 - u2; t->C2 = -fmaf(t->A2, u2, t->B2 * v2);
+  const float ia = 1.0f / a2;
+  t->Aw = fmaf(t->A1, w0, fmaf(t->A2, w1, t->A0 * w2)) * ia;
+  t->Bw = fmaf(t->B1, w0, fmaf(t->B2, w1, t->B0 * w2)) * ia;
+  t->Cw = fmaf(t->C1, w0, fmaf(t->C2, w1, t->C0 * w2)) * ia;
+  t->seg = seg; t->prim = prim;
+  t->x0 = x0; t->x1 = x1; t->y0 = y0; t->y1 = y1;
+  return 1;
+}
+
+static v3 lerp_near(v3 a, v3 b, float near_) {
+  const float s = (near_ - a.x) / (b.x - a.x);
+  return v3_make(near_, fmaf(s, b.y - a.y, a.y), fmaf(s, b.z - a.z, a.z));
+}
+
+static int16_t to_mm(float x) {
+  float r = rintf(x * 1000.0f);
+  r = fminf(fmaxf(r, -32768.0f), 32767.0f);
+  return (int16_t)r;
+}
+
+ORC_EXPORT int orc_camera_take_picture(orc_ctx* c, int camera, void* stream) {
+  (void)stream;
+  r_model* r = (r_model*)c->render;
+  if (!r || camera < 0 || camera >= r->ncams) return rfail(c, MSK_ERR_INVALID, "bad camera");
+  const r_camera* cam = &r->cams[camera];
+  const float wmin = 1.0f / cam->far_;
+  v3* cv = (v3*)malloc(sizeof(v3) * (size_t)(r->nv > 0 ? r->nv : 1));
+  r_setup* st = (r_setup*)malloc(sizeof(r_setup) * (size_t)(2 * r->nt + 1));
+  float* bw = (float*)malloc(sizeof(float) * (size_t)cam->W * cam->H);
+  for (int e = 0; e < c->num_envs; ++e) {
+    orc_env* env = &c->envs[e];
+    orc_forward_kinematics(c, env);
+    pose Tc = cam->local;
+    if (cam->mount >= 0) Tc = pose_mul(env->bpose[cam->mount], cam->local);
+    const pose Tci = pose_inv(Tc);
+    pose shapeT[MSK_MAX_RENDER_SHAPES];
+    for (int s = 0; s < r->ns; ++s) {
+      pose T = r->shapes[s].local;
+      if (r->shapes[s].body >= 0) T = pose_mul(env->bpose[r->shapes[s].body], r->shapes[s].local);
+      shapeT[s] = pose_mul(Tci, T);
+    }
+    for (int i = 0; i < r->nv; ++i) cv[i] = pose_apply(shapeT[r->vshape[i]], r->verts[i]);
+    int ns = 0;
+    for (int ti = 0; ti < r->nt; ++ti) {
+      const r_tri* tr = &r->tris[ti];
+      const v3 p[3] = {cv[tr->v0], cv[tr->v1], cv[tr->v2]};
+      const int seg = r->shapes[tr->shape].seg;
+      const int in0 = p[0].x >= cam->near_, in1 = p[1].x >= cam->near_, in2 = p[2].x >= cam->near_;
+      const int nin = in0 + in1 + in2;
+      v3 q[4];
+      int nq = 0;
+      if (nin == 3) { q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; nq = 3; }
+      else if (nin > 0) {
+        for (int k = 0; k < 3; ++k) {
+          const v3 a = p[k], b = p[(k + 1) % 3];
+          const int ia = a.x >= cam->near_, ib = b.x >= cam->near_;
+          if (ia) q[nq++] = a;
+          if (ia != ib) q[nq++] = ia ? lerp_near(a, b, cam->near_) : lerp_near(b, a, cam->near_);
+        }
+      }
+      for (int sub = 0; sub + 2 < nq; ++sub)
+        if (setup_triangle(cam, q[0], q[sub + 1], q[sub + 2], seg, ti * 2 + sub, &st[ns])) ns++;
+    }
+    int16_t* img = cam->out + (size_t)e * cam->W * cam->H * 4;
+    memset(img, 0, sizeof(int16_t) * (size_t)cam->W * cam->H * 4);
+    for (int i = 0; i < cam->W * cam->H; ++i) bw[i] = 0.0f;
+    /* triangles in primitive order; strictly nearer wins, so equal depths keep the lower primitive id */
+    for (int k = 0; k < ns; ++k) {
+      const r_setup* t = &st[k];
+      for (int py = t->y0; py <= t->y1; ++py)
+        for (int px = t->x0; px <= t->x1; ++px) {
+          const float x = (float)px + 0.5f, y = (float)py + 0.5f;
+          const float e0 = fmaf(t->A0, x, fmaf(t->B0, y, t->C0));
+          const float e1 = fmaf(t->A1, x, fmaf(t->B1, y, t->C1));
+          const float e2 = fmaf(t->A2, x, fmaf(t->B2, y, t->C2));
+          if (!(e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f)) continue;
+          const float w = fmaf(t->Aw, x, fmaf(t->Bw, y, t->Cw));
+          if (!(w >= wmin) || !(w > bw[py * cam->W + px])) continue;
+          bw[py * cam->W + px] = w;
+          const float d = 1.0f / w;
+          int16_t* o = img + ((size_t)py * cam->W + px) * 4;
+          o[0] = to_mm((x - cam->cx) / cam->fx * d);
+          o[1] = to_mm(-(y - cam->cy) / cam->fy * d);
+          o[2] = to_mm(-d);
+          o[3] = (int16_t)t->seg;
+        }
+    }
+  }
+  free(cv); free(st); free(bw);
+  return MSK_OK;
+}

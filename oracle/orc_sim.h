@@ -103,6 +103,7 @@ typedef struct orc_ctx {
   float* buf[MSK_BUF_COUNT];
   int nqueries;
   struct { int npairs; int32_t* pairs; float* out; } queries[16];
+  void* render;      /* orc_render.c: render geometry and cameras */
   char err[256];
 } orc_ctx;
 

@@ -1,0 +1,170 @@
+"""Camera path (include/msk_render.h): known answers of the CPU oracle rasteriser (no GPU needed) and, under
+``-m gpu``, bit-exact parity of the HIP tile rasteriser with it.
+
+No reference test or golden image pins pixels (the reference suite only checks shapes and dtypes of the textures,
+tests/test_gpu_envs.py:89-104; SAPIEN's renderer is not available): parity unpinned.  The oracle is pinned by
+geometric known answers under the reference's camera conventions (utils/sapien_utils.py:320-324,
+render/shaders.py:68-84)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from maniskill_amd import _native as N
+from maniskill_amd.envs import scene_builders as sb
+from maniskill_amd.physx import SceneTemplate
+from maniskill_amd.render import CameraConfig, RenderCameraGroup, attach_template_visuals, look_at
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _boxes_scene(factory, boxes, n=1, cam=None, ground=False):
+    tpl = SceneTemplate()
+    ids = []
+    for i, (p, half) in enumerate(boxes):
+        b = tpl.add_actor(f"box{i}", N.BODY_KINEMATIC, p=p)
+        tpl.add_shape(b, N.SHAPE_BOX, params=half)
+        ids.append(b)
+    if ground:
+        tpl.add_shape(-1, N.SHAPE_PLANE, p=(0, 0, 0), q=(0.7071068, 0, -0.7071068, 0))
+    mover = tpl.add_actor("mover", N.BODY_DYNAMIC, p=(50, 50, 50), mass=1.0)   # a template needs one movable body
+    tpl.add_shape(mover, N.SHAPE_BOX, params=(0.1, 0.1, 0.1))
+    px = factory(tpl, n, None)
+    px.gpu_init()
+    attach_template_visuals(px, tpl, hidden_bodies=(mover,))
+    cfg = cam or CameraConfig("c", (0, 0, 0), (1, 0, 0, 0), 128, 128, np.pi / 2, 0.01, 100.0)
+    return px, RenderCameraGroup(px, cfg), ids
+
+
+def test_render_header_is_exported_by_both_libraries(built):
+    from oracle_backend import ORACLE_LIB
+
+    text = open(os.path.join(ROOT, "include", "msk_render.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(msk_[a-z_0-9]+)\s*\(", text)))
+    assert {"msk_" + n for n in N.RENDER_EXPORTS} == set(names)
+    hip, orc = ctypes.CDLL(N.DEFAULT_LIB), ctypes.CDLL(ORACLE_LIB)
+    for name in names:
+        assert hasattr(hip, name) and hasattr(orc, name.replace("msk_", "orc_", 1))
+
+
+def test_box_in_front_of_the_camera(oracle_factory):
+    """Camera at the origin looking along +x; a 1 m cube centred 2 m ahead: the front face is 1.5 m away."""
+    px, cam, ids = _boxes_scene(oracle_factory, [((2, 0, 0), (0.5, 0.5, 0.5))])
+    cam.take_picture()
+    tex = cam.get_picture_cuda("PositionSegmentation").torch()[0]
+    seg, z = tex[..., 3].numpy(), tex[..., 2].numpy()
+    assert tex.dtype == torch.int16 and tex.shape == (128, 128, 4)
+    # silhouette: half-width 0.5 at 1.5 m, fx = 64 px -> pixel centres within 64 +- 21.33
+    cols = np.nonzero(seg[64] > 0)[0]
+    rows = np.nonzero(seg[:, 64] > 0)[0]
+    assert (cols.min(), cols.max()) == (43, 84) and (rows.min(), rows.max()) == (43, 84)
+    assert (seg[seg > 0] == ids[0] + 1).all()
+    assert (z[seg > 0] == -1500).all()            # OpenGL z = -depth, millimetres
+    assert (tex[seg == 0] == 0).all()             # background: position 0, id 0
+    # position channels: x right, y up of the pixel centre's ray at depth 1.5 m
+    x, y = tex[..., 0].numpy(), tex[..., 1].numpy()
+    assert x[64, 84] == round((84.5 - 64) / 64 * 1500) and x[64, 43] == round((43.5 - 64) / 64 * 1500)
+    assert y[43, 64] == round(-(43.5 - 64) / 64 * 1500) and y[84, 64] == round(-(84.5 - 64) / 64 * 1500)
+    obs = cam.get_obs()
+    assert obs["depth"].shape == (1, 128, 128, 1) and obs["depth"][0, 64, 64, 0] == 1500 and obs["segmentation"][0, 64, 64, 0] == ids[0] + 1
+
+
+def test_nearest_surface_wins_and_ids_follow_bodies(oracle_factory):
+    px, cam, ids = _boxes_scene(oracle_factory, [((3, 0, 0), (0.5, 1.0, 1.0)), ((1.5, 0.3, 0), (0.25, 0.25, 0.25))])
+    cam.take_picture()
+    tex = cam.get_picture_cuda().torch()[0].numpy()
+    assert tex[64, 64 - 15, 3] == ids[1] + 1 and tex[64, 64 - 15, 2] == -1250   # small box: y left = image left
+    assert tex[64, 64 + 20, 3] == ids[0] + 1 and tex[64, 64 + 20, 2] == -2500
+    assert set(np.unique(tex[..., 3])) == {0, ids[0] + 1, ids[1] + 1}
+
+
+def test_ground_plane_is_clipped_at_the_near_plane(oracle_factory):
+    """A camera 1 m above an infinite ground, looking horizontally: the lower half of the image is ground whose depth
+    along the optical axis is h / tan(angle below the horizon); the quad passes behind the camera (near-plane clip)."""
+    cfg = CameraConfig("c", (0, 0, 1.0), (1, 0, 0, 0), 128, 128, np.pi / 2, 0.01, 100.0)
+    px, cam, _ = _boxes_scene(oracle_factory, [((200, 0, 0), (0.1, 0.1, 0.1))], cam=cfg, ground=True)
+    cam.take_picture()
+    tex = cam.get_picture_cuda().torch()[0].numpy().astype(np.int64)
+    gid = px.bodies_per_env + 1
+    assert (tex[:64, :, 3] == 0).all() and (tex[70:, :, 3] == gid).all()
+    for row in (70, 90, 127):
+        tan = (row + 0.5 - 64) / 64
+        d = 1.0 / tan
+        assert abs(-tex[row, 64, 2] - min(round(d * 1000), 32767)) <= 1
+        assert abs(tex[row, 64, 1] + 1000) <= 1      # OpenGL y of every ground point = -h
+
+
+def test_look_at_matches_the_reference_convention():
+    p, q = look_at(eye=[0.3, 0, 0.6], target=[-0.1, 0, 0.1])
+    w, x, y, z = q
+    fwd = np.array([1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y)])
+    want = np.array([-0.4, 0, -0.5]) / np.linalg.norm([-0.4, 0, -0.5])
+    assert np.allclose(fwd, want, atol=1e-6) and np.allclose(p, [0.3, 0, 0.6])
+    left = np.array([2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x)])
+    assert abs(left[2]) < 1e-6      # the camera's y axis stays horizontal
+
+
+def test_pickcube_depth_segmentation_observation(oracle_factory):
+    from maniskill_amd.envs.pick_cube import PickCubeEnv
+
+    env = PickCubeEnv(num_envs=2, px_factory=oracle_factory, obs_mode="depth+segmentation")
+    obs, _ = env.reset(seed=3)
+    cam = obs["sensor_data"]["base_camera"]
+    assert cam["depth"].shape == (2, 128, 128, 1) and cam["depth"].dtype == torch.int16
+    assert cam["segmentation"].shape == (2, 128, 128, 1) and obs["state"].shape == (2, 42)
+    seg = cam["segmentation"][0, :, :, 0].numpy()
+    ids = set(np.unique(seg))
+    assert env._b_cube + 1 in ids and env._b_table + 1 in ids and env.px.bodies_per_env + 1 in ids   # cube, table, ground
+    assert env._b_goal + 1 not in ids                                                                 # hidden object
+    assert len(ids & set(range(1, 16))) >= 5                                                          # several robot links
+    # the cube is 4 cm wide, ~0.67 m from the camera: a handful of pixels, all at plausible depth
+    d = cam["depth"][0, :, :, 0].numpy()[seg == env._b_cube + 1]
+    assert 4 <= d.size <= 80 and 400 < d.min() and d.max() < 1000
+    obs2, *_ = env.step(torch.zeros(2, 8))
+    assert obs2["sensor_data"]["base_camera"]["depth"].shape == (2, 128, 128, 1)
+
+
+@pytest.mark.gpu
+def test_hip_rasteriser_matches_oracle_bit_for_bit(oracle_factory):
+    from maniskill_amd.envs.pick_cube import PickCubeEnv
+
+    n = 64
+    gpu = PickCubeEnv(num_envs=n, device="cuda:0", obs_mode="depth+segmentation", fused=False)
+    cpu = PickCubeEnv(num_envs=n, px_factory=oracle_factory, obs_mode="depth+segmentation")
+    og, _ = gpu.reset(seed=2022)
+    oc, _ = cpu.reset(seed=2022)
+    gen = torch.Generator().manual_seed(0)
+    for t in range(12):
+        a = 2 * torch.rand(n, 8, generator=gen) - 1
+        og, *_ = gpu.step(a.to("cuda:0"))
+        oc, *_ = cpu.step(a)
+        tg = gpu.camera.get_picture_cuda().torch().cpu()
+        tc = cpu.camera.get_picture_cuda().torch()
+        assert torch.equal(tg, tc), f"PositionSegmentation differs at step {t}: {(tg != tc).sum().item()} values"
+    assert torch.equal(og["sensor_data"]["base_camera"]["depth"].cpu(), oc["sensor_data"]["base_camera"]["depth"])
+
+
+@pytest.mark.gpu
+def test_hip_rasteriser_known_answers_and_full_size():
+    from maniskill_amd.physx import PhysxGpuSystem
+    from maniskill_amd.envs.pick_cube import PickCubeEnv
+
+    px, cam, ids = _boxes_scene(lambda tpl, n, cfg: PhysxGpuSystem("cuda:0", tpl, n, cfg), [((2, 0, 0), (0.5, 0.5, 0.5))], n=8)
+    cam.take_picture()
+    tex = cam.get_picture_cuda().torch().cpu().numpy()
+    assert (tex[:, 64, 64, 2] == -1500).all() and (tex[:, 64, 64, 3] == ids[0] + 1).all() and (tex[:, 0, 0] == 0).all()
+    env = PickCubeEnv(num_envs=4096, device="cuda:0", obs_mode="depth+segmentation")
+    obs, _ = env.reset(seed=2022)
+    obs, *_ = env.step(2 * torch.rand(4096, 8, device="cuda:0") - 1)
+    seg = obs["sensor_data"]["base_camera"]["segmentation"]
+    assert seg.shape == (4096, 128, 128, 1) and seg.is_cuda
+    # every env sees table, ground and its cube; partition invariance of the picture
+    assert ((seg == env._b_table + 1).flatten(1).any(1)).all() and ((seg == env._b_cube + 1).flatten(1).any(1)).all()
+    half = PickCubeEnv(num_envs=64, device="cuda:0", obs_mode="depth+segmentation", env_index_offset=128, total_envs=4096)
+    env.reset(seed=2022); o2, _ = half.reset(seed=2022)
+    env.camera.take_picture()
+    assert torch.equal(env.camera.get_picture_cuda().torch()[128:192], half.camera.get_picture_cuda().torch())
