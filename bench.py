@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--envs", type=int, default=4096, help="total env count over all ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--obs-mode", default="state", choices=["state", "depth+segmentation"],
+                    help="state (BASELINE.json's metric, default) or the camera path: 128x128 depth+segmentation per env")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -78,7 +80,11 @@ def main():
     if world_env != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
-    env, gather, rank, world = make_sharded_pick_cube(args.envs, device_type="cuda")
+    env, gather, rank, world = make_sharded_pick_cube(args.envs, device_type="cuda", obs_mode=args.obs_mode)
+    camera_mode = args.obs_mode != "state"
+    if camera_mode:   # image observations stay on their GPU; only the state part is gathered
+        _gather = gather
+        gather = lambda o, r, t, u: _gather(o["state"], r, t, u)
     dev = env.device
     n_local = env.num_envs
 
@@ -105,6 +111,16 @@ def main():
         dt = time.perf_counter() - t0
         kernels = env.px.timing_read()
         env.px.timing_enable(0)
+        cam_us = None
+        if camera_mode:   # the rasteriser alone, HIP events on the launch stream
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            torch.cuda.synchronize(dev)
+            ev[0].record()
+            for _ in range(20):
+                env.camera.take_picture()
+            ev[1].record()
+            torch.cuda.synchronize(dev)
+            cam_us = ev[0].elapsed_time(ev[1]) / 20 * 1e3
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -147,6 +163,14 @@ def main():
                 "kernel_us": {k: v[0] / max(v[1], 1) * 1e3 for k, v in kernels.items()},
             },
         }
+        if camera_mode:
+            img_bytes = n_local * 128 * 128 * 8      # PositionSegmentation int16 x 4 per pixel: the algorithmic output
+            result["metric"] = "env steps/sec (whole node), 4096 parallel PickCube-v1 envs, 128x128 depth+segmentation camera obs"
+            result["config"]["workload"] += ", base_camera 128x128 PositionSegmentation"
+            result["camera"] = {"kernel": "k_render_setup + k_render_tiles", "us_per_frame": cam_us,
+                                "bound": "hbm", "algorithmic_bytes_per_frame": img_bytes,
+                                "achieved": img_bytes / (cam_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": img_bytes / (cam_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(512, 100)
         print(json.dumps(result), flush=True)

@@ -665,8 +665,8 @@ MSK_API int msk_camera_create(msk_ctx* c, int width, int height, float fovy, flo
                               const float local_pose[7]) {
   if (!c->render_finalized) return fail(c, MSK_ERR_INVALID, "camera_create before render_finalize");
   if (c->ncams >= MSK_MAX_CAMERAS) return fail(c, MSK_ERR_CAPACITY, "too many cameras");
-  if (width % MSK_TILE || height % MSK_TILE || width <= 0 || height <= 0 || (width / MSK_TILE) * (height / MSK_TILE) > MSK_MAX_TILES)
-    return fail(c, MSK_ERR_INVALID, "camera size must be a multiple of 16, at most 256 tiles");
+  if (width % 16 || height % 16 || width <= 0 || height <= 0 || (width / MSK_TILE) * (height / MSK_TILE) > MSK_MAX_TILES)
+    return fail(c, MSK_ERR_INVALID, "camera size must be a multiple of 16, at most 256 x 256");
   if (mount_body >= c->model.nb) return fail(c, MSK_ERR_INVALID, "bad mount body");
   HIP_TRY(hipSetDevice(c->device));
   const size_t N = (size_t)c->model.N;
@@ -685,7 +685,7 @@ MSK_API int msk_camera_create(msk_ctx* c, int width, int height, float fovy, flo
   ALLOC(cam.setups, N * cam.setup_cap * MSK_SETUP_WORDS);
   ALLOC(cam.nsetup, N);
   ALLOC(cam.tile_off, N * (MSK_MAX_TILES + 1));
-  ALLOC(cam.lists, N * cam.list_cap);
+  ALLOC(cam.tile_recs, N * (size_t)cam.list_cap * MSK_SETUP_WORDS);
   ALLOC(cam.out, N * (size_t)width * height * 4);
   ALLOC(cam.overflow, 1);
   return c->ncams++;
@@ -706,9 +706,9 @@ MSK_API int msk_camera_take_picture(msk_ctx* c, int camera, void* stream) {
     c->kin_dirty = false;
   }
   const RCamera& cam = c->cams[camera];
-  const size_t lds = (MSK_MAX_RENDER_SHAPES * 8 + 2 * MSK_MAX_TILES + 4 + (size_t)c->rmodel->nv * 3) * sizeof(float);
+  const size_t lds = (MSK_MAX_RENDER_SHAPES * 8 + 2 * MSK_MAX_TILES + 8 + MSK_MAX_BIG + (size_t)c->rmodel->nv * 3) * sizeof(float);
   hipLaunchKernelGGL(k_render_setup, dim3(N), dim3(256), lds, s, c->d_model, c->st, c->d_rmodel, cam);
-  hipLaunchKernelGGL(k_render_tiles, dim3(cam.tiles_x * cam.tiles_y, N), dim3(256), 0, s, cam);
+  hipLaunchKernelGGL(k_render_tiles, dim3((cam.tiles_x * cam.tiles_y + MSK_TILES_PER_WAVE - 1) / MSK_TILES_PER_WAVE, N), dim3(64), 0, s, cam);
   HIP_TRY(hipGetLastError());
   return MSK_OK;
 }

@@ -6,11 +6,11 @@
  *                    transform the render vertices into the camera frame (LDS), then set up the
  *                    triangles: near-plane clip, projection, back-face cull, edge + 1/depth plane
  *                    equations, pixel bounding box -> 64-byte TriSetup records, binned into
- *                    16x16-pixel tiles (LDS counters, prefix, per-tile index lists).
- *   k_render_tiles   one workgroup per (tile, env), thread = pixel: the tile's setups are staged
- *                    through LDS 64 at a time; per pixel 3 edge evaluations + 1/depth compare; the
- *                    winner's camera-space position (mm, int16) and segmentation id are written as
- *                    one 8-byte store per pixel, 128 contiguous bytes per tile row.
+ *                    8x8-pixel tiles (LDS counters, prefix, per-tile record arrays).
+ *   k_render_tiles   one wavefront per (4 consecutive 8x8 tiles, env), lane = pixel: a tile's records go through
+ *                    LDS (read back as broadcasts) while the next tile's are already in flight; per pixel 3 edge
+ *                    evaluations + 1/depth compare; the winner's camera-space position (mm, int16) and
+ *                    segmentation id leave as one 8-byte store per pixel.
  *
  * The output (N x H x W x 8 bytes = 512 MiB at 4096 envs, 128x128) is the algorithmic traffic of
  * this path: it is HBM-write-bound by construction.  Arithmetic follows oracle/orc_render.c
@@ -22,8 +22,11 @@
 #include "../../include/msk_render.h"
 #include "msk_model.h"
 
-#define MSK_TILE 16
-#define MSK_MAX_TILES 256          /* up to 256x256 images */
+#define MSK_TILE 8                 /* one wavefront rasterises an 8 x 8 tile, lane = pixel */
+#define MSK_MAX_TILES 1024         /* up to 256x256 images */
+#define MSK_BIG_TILES 16           /* a triangle over more tiles than this is binned by the whole workgroup */
+#define MSK_MAX_BIG 256
+#define MSK_TILES_PER_WAVE 4        /* consecutive tiles a wavefront walks, prefetching the next one's records */
 #define MSK_SETUP_WORDS 16
 
 struct RShape { int body, seg; pose local; };
@@ -43,7 +46,7 @@ struct RCamera {
   float* setups;                   /* [N][setup_cap][16]  */
   int* nsetup;                     /* [N]                 */
   int* tile_off;                   /* [N][ntiles + 1]     */
-  unsigned short* lists;           /* [N][list_cap]       */
+  float* tile_recs;                /* [N][list_cap][16]: per tile, the records that touch it */
   short* out;                      /* [N][H][W][4]        */
   int* overflow;                   /* [1]                 */
 };
@@ -109,12 +112,14 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
   /* LDS: shape transforms [ns][8] | tile counters [ntiles] | tile fill [ntiles] | nsetup | camera-frame vertices [nv][3] */
   float* Lshape = lds;
   int* Lcnt = (int*)(lds + MSK_MAX_RENDER_SHAPES * 8);
-  int* Lfill = Lcnt + MSK_MAX_TILES;
+  int* Lfill = Lcnt + MSK_MAX_TILES + 4;
   int* Lns = Lfill + MSK_MAX_TILES;
-  float* Lv = (float*)(Lns + 4);
+  int* Lnbig = Lns + 1;
+  int* Lbig = Lns + 4;
+  float* Lv = (float*)(Lbig + MSK_MAX_BIG);
   const float* E = EREC(st, m, e);
   for (int i = tid; i < ntiles; i += 256) { Lcnt[i] = 0; Lfill[i] = 0; }
-  if (tid == 0) *Lns = 0;
+  if (tid == 0) { *Lns = 0; *Lnbig = 0; }
   /* camera-from-shape transforms */
   pose Tc = cam.local;
   if (cam.mount >= 0) Tc = pose_mul(load_pose(E, m->lay.bpose, cam.mount), cam.local);
@@ -164,8 +169,25 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
       if (slot >= cam.setup_cap) { atomicOr(cam.overflow, 1); continue; }
       setups[slot] = t;
       const int tx0 = (t.bbx & 0xFFFF) / MSK_TILE, tx1 = (t.bbx >> 16) / MSK_TILE, ty0 = (t.bby & 0xFFFF) / MSK_TILE, ty1 = (t.bby >> 16) / MSK_TILE;
+      if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > MSK_BIG_TILES) { /* table / ground sized: binned by the whole workgroup below */
+        const int b = atomicAdd(Lnbig, 1);
+        if (b < MSK_MAX_BIG) Lbig[b] = slot;
+        else atomicOr(cam.overflow, 1);
+        continue;
+      }
       for (int ty = ty0; ty <= ty1; ++ty)
         for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&Lcnt[ty * cam.tiles_x + tx], 1);
+    }
+  }
+  __threadfence_block();   /* the records are read back by other threads of the workgroup */
+  __syncthreads();
+  const int nbig = min(*Lnbig, MSK_MAX_BIG);
+  for (int b = 0; b < nbig; ++b) { /* thread = tile */
+    const TriSetup* t = &setups[Lbig[b]];
+    const int tx0 = (t->bbx & 0xFFFF) / MSK_TILE, tx1 = (t->bbx >> 16) / MSK_TILE, ty0 = (t->bby & 0xFFFF) / MSK_TILE, ty1 = (t->bby >> 16) / MSK_TILE;
+    for (int tile = tid; tile < ntiles; tile += 256) {
+      const int tx = tile % cam.tiles_x, ty = tile / cam.tiles_x;
+      if (tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1) Lcnt[tile] += 1;   /* one thread per tile: no atomic needed */
     }
   }
   __syncthreads();
@@ -185,66 +207,131 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
     cam.nsetup[e] = ns;
   }
   __syncthreads();
-  unsigned short* list = cam.lists + (size_t)e * cam.list_cap;
+  /* every tile gets its own contiguous copy of the records that touch it: the tile kernel then needs one
+   * dependent load (offsets -> records) instead of two (offsets -> indices -> records) */
+  float4* recs = (float4*)(cam.tile_recs + (size_t)e * cam.list_cap * MSK_SETUP_WORDS);
   for (int s = tid; s < ns; s += 256) {
-    const TriSetup* t = &setups[s];
-    const int bbx = t->bbx, bby = t->bby;
+    const float4* src = (const float4*)&setups[s];
+    const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+    const int bbx = __float_as_int(r3.z), bby = __float_as_int(r3.w);
     const int tx0 = (bbx & 0xFFFF) / MSK_TILE, tx1 = (bbx >> 16) / MSK_TILE, ty0 = (bby & 0xFFFF) / MSK_TILE, ty1 = (bby >> 16) / MSK_TILE;
+    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > MSK_BIG_TILES) continue;
     for (int ty = ty0; ty <= ty1; ++ty)
       for (int tx = tx0; tx <= tx1; ++tx) {
         const int tile = ty * cam.tiles_x + tx;
         const int pos = Lcnt[tile] + atomicAdd(&Lfill[tile], 1);
-        if (pos < Lcnt[tile + 1]) list[pos] = (unsigned short)s;
+        if (pos < Lcnt[tile + 1]) {
+          float4* dst = recs + (size_t)pos * 4;
+          dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+        }
       }
+  }
+  __syncthreads();
+  for (int b = 0; b < nbig; ++b) { /* thread = tile */
+    const float4* src = (const float4*)&setups[Lbig[b]];
+    const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+    const int bbx = __float_as_int(r3.z), bby = __float_as_int(r3.w);
+    const int tx0 = (bbx & 0xFFFF) / MSK_TILE, tx1 = (bbx >> 16) / MSK_TILE, ty0 = (bby & 0xFFFF) / MSK_TILE, ty1 = (bby >> 16) / MSK_TILE;
+    for (int tile = tid; tile < ntiles; tile += 256) {
+      const int tx = tile % cam.tiles_x, ty = tile / cam.tiles_x;
+      if (tx < tx0 || tx > tx1 || ty < ty0 || ty > ty1) continue;
+      const int pos = Lcnt[tile] + Lfill[tile];
+      Lfill[tile] += 1;
+      if (pos < Lcnt[tile + 1]) {
+        float4* dst = recs + (size_t)pos * 4;
+        dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
+      }
+    }
   }
 }
 
-__global__ void __launch_bounds__(256) k_render_tiles(RCamera cam) {
+/* One wavefront per (group of MSK_TILES_PER_WAVE consecutive 8 x 8 tiles, env), lane = pixel.  The launch is bound by
+ * the dependent loads of a tile (offsets -> records), not by arithmetic or by the 8 bytes per pixel it writes, so a wave
+ * keeps the NEXT tile's records in flight (registers) while it rasterises the current one out of LDS. */
+__global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
   __shared__ __attribute__((aligned(16))) float Ls[64 * MSK_SETUP_WORDS];
-  const int tile = blockIdx.x, e = blockIdx.y, tid = threadIdx.x;
-  const int tx = tile % cam.tiles_x, ty = tile / cam.tiles_x;
-  const int px = tx * MSK_TILE + (tid % MSK_TILE), py = ty * MSK_TILE + (tid / MSK_TILE);
-  const float x = (float)px + 0.5f, y = (float)py + 0.5f;
+  const int e = blockIdx.y, lane = threadIdx.x;
+  const int ntiles = cam.tiles_x * cam.tiles_y;
+  const int t0 = blockIdx.x * MSK_TILES_PER_WAVE;
   const int* toff = cam.tile_off + (size_t)e * (MSK_MAX_TILES + 1);
-  const int l0 = toff[tile], l1 = toff[tile + 1];
-  const unsigned short* list = cam.lists + (size_t)e * cam.list_cap;
-  const float4* setups = (const float4*)(cam.setups + (size_t)e * cam.setup_cap * MSK_SETUP_WORDS);
-  float best_w = 0.0f;
-  int best_seg = 0, best_prim = 0x7FFFFFFF;
+  const float4* recs = (const float4*)(cam.tile_recs + (size_t)e * cam.list_cap * MSK_SETUP_WORDS);
   const float wmin = 1.0f / cam.far_;
-  for (int c0 = l0; c0 < l1; c0 += 64) {
-    const int n = min(64, l1 - c0);
-    __syncthreads();
-    { /* stage up to 64 setups: 256 threads x one float4 */
-      const int r = tid / 4, part = tid % 4;
-      if (r < n) ((float4*)Ls)[r * 4 + part] = setups[(size_t)list[c0 + r] * 4 + part];
-    }
-    __syncthreads();
-    for (int k = 0; k < n; ++k) {
-      const float* t = Ls + k * MSK_SETUP_WORDS;
-      const float e0 = fmaf(t[0], x, fmaf(t[1], y, t[2]));
-      const float e1 = fmaf(t[3], x, fmaf(t[4], y, t[5]));
-      const float e2 = fmaf(t[6], x, fmaf(t[7], y, t[8]));
-      if (e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f) {
-        const float w = fmaf(t[9], x, fmaf(t[10], y, t[11]));
-        const int prim = __float_as_int(t[13]);
-        if (w >= wmin && (w > best_w || (w == best_w && prim < best_prim))) {
-          best_w = w; best_prim = prim; best_seg = __float_as_int(t[12]);
+  /* list bounds of my tiles: lane i holds toff[t0 + i] */
+  const int myoff = (lane <= MSK_TILES_PER_WAVE && t0 + lane <= ntiles) ? toff[t0 + lane] : 0;
+  int lo = __builtin_amdgcn_readlane(myoff, 0);
+  float4 pf0, pf1, pf2, pf3;   /* prefetched record `lane` of the upcoming tile's first chunk */
+  {
+    const int hi = __builtin_amdgcn_readlane(myoff, 1);
+    const int idx = min(lo + lane, max(hi - 1, lo));
+    const float4* src = recs + (size_t)idx * 4;
+    pf0 = src[0]; pf1 = src[1]; pf2 = src[2]; pf3 = src[3];
+  }
+#pragma unroll
+  for (int i = 0; i < MSK_TILES_PER_WAVE; ++i) {
+    const int tile = t0 + i;
+    if (tile >= ntiles) break;
+    const int l0 = lo, l1 = __builtin_amdgcn_readlane(myoff, i + 1);
+    lo = l1;
+    const int tx = tile % cam.tiles_x, ty = tile / cam.tiles_x;
+    const int px = tx * MSK_TILE + (lane % MSK_TILE), py = ty * MSK_TILE + (lane / MSK_TILE);
+    const float x = (float)px + 0.5f, y = (float)py + 0.5f;
+    float best_w = 0.0f;
+    int best_seg = 0, best_prim = 0x7FFFFFFF;
+    for (int c0 = l0; c0 < l1; c0 += 64) {
+      const int n = min(64, l1 - c0);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (c0 == l0) { /* first chunk: already in registers */
+        float4* dst = (float4*)Ls + lane * 4;
+        dst[0] = pf0; dst[1] = pf1; dst[2] = pf2; dst[3] = pf3;
+      } else if (lane < n) {
+        const float4* src = recs + (size_t)(c0 + lane) * 4;
+        float4* dst = (float4*)Ls + lane * 4;
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (c0 == l0 && i + 1 < MSK_TILES_PER_WAVE && tile + 1 < ntiles) { /* next tile's first chunk into flight */
+        const int nhi = __builtin_amdgcn_readlane(myoff, (i + 2 <= MSK_TILES_PER_WAVE) ? i + 2 : MSK_TILES_PER_WAVE);
+        const int idx = min(l1 + lane, max(nhi - 1, l1));
+        const float4* src = recs + (size_t)idx * 4;
+        pf0 = src[0]; pf1 = src[1]; pf2 = src[2]; pf3 = src[3];
+      }
+      for (int k = 0; k < n; ++k) {
+        /* record: A0 B0 C0 A1 | B1 C1 A2 B2 | C2 Aw Bw Cw | seg prim bbx bby (same address in every lane: LDS broadcast) */
+        const float4* t4 = (const float4*)(Ls + k * MSK_SETUP_WORDS);
+        const float4 ta = t4[0], tb = t4[1], tc = t4[2];
+        const float e0 = fmaf(ta.x, x, fmaf(ta.y, y, ta.z));
+        const float e1 = fmaf(ta.w, x, fmaf(tb.x, y, tb.y));
+        const float e2 = fmaf(tb.z, x, fmaf(tb.w, y, tc.x));
+        if (e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f) {
+          const float w = fmaf(tc.y, x, fmaf(tc.z, y, tc.w));
+          const float4 td = t4[3];
+          const int prim = __float_as_int(td.y);
+          if (w >= wmin && (w > best_w || (w == best_w && prim < best_prim))) {
+            best_w = w; best_prim = prim; best_seg = __float_as_int(td.x);
+          }
         }
       }
     }
+    if (l0 == l1 && i + 1 < MSK_TILES_PER_WAVE && tile + 1 < ntiles) { /* empty tile: still start the next prefetch */
+      const int nhi = __builtin_amdgcn_readlane(myoff, (i + 2 <= MSK_TILES_PER_WAVE) ? i + 2 : MSK_TILES_PER_WAVE);
+      const int idx = min(l1 + lane, max(nhi - 1, l1));
+      const float4* src = recs + (size_t)idx * 4;
+      pf0 = src[0]; pf1 = src[1]; pf2 = src[2]; pf3 = src[3];
+    }
+    /* camera-space OpenGL position in millimetres (x right, y up, z backwards), int16 saturated */
+    short4 o = make_short4(0, 0, 0, 0);
+    if (best_w > 0.0f) {
+      const float d = 1.0f / best_w;
+      const float gx = (x - cam.cx) / cam.fx * d, gy = -(y - cam.cy) / cam.fy * d, gz = -d;
+      o.x = (short)fminf(fmaxf(rintf(gx * 1000.0f), -32768.0f), 32767.0f);
+      o.y = (short)fminf(fmaxf(rintf(gy * 1000.0f), -32768.0f), 32767.0f);
+      o.z = (short)fminf(fmaxf(rintf(gz * 1000.0f), -32768.0f), 32767.0f);
+      o.w = (short)best_seg;
+    }
+    ((short4*)cam.out)[((size_t)e * cam.H + py) * cam.W + px] = o;
   }
-  /* camera-space OpenGL position in millimetres (x right, y up, z backwards), int16 saturated */
-  short4 o = make_short4(0, 0, 0, 0);
-  if (best_w > 0.0f) {
-    const float d = 1.0f / best_w;
-    const float gx = (x - cam.cx) / cam.fx * d, gy = -(y - cam.cy) / cam.fy * d, gz = -d;
-    o.x = (short)fminf(fmaxf(rintf(gx * 1000.0f), -32768.0f), 32767.0f);
-    o.y = (short)fminf(fmaxf(rintf(gy * 1000.0f), -32768.0f), 32767.0f);
-    o.z = (short)fminf(fmaxf(rintf(gz * 1000.0f), -32768.0f), 32767.0f);
-    o.w = (short)best_seg;
-  }
-  ((short4*)cam.out)[((size_t)e * cam.H + py) * cam.W + px] = o;
 }
 
 #endif
