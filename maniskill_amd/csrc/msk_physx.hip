@@ -686,6 +686,8 @@ MSK_API int msk_camera_create(msk_ctx* c, int width, int height, float fovy, flo
   ALLOC(cam.nsetup, N);
   ALLOC(cam.tile_off, N * (MSK_MAX_TILES + 1));
   ALLOC(cam.tile_recs, N * (size_t)cam.list_cap * MSK_SETUP_WORDS);
+  ALLOC(cam.big_recs, N * (size_t)MSK_MAX_BIG * MSK_SETUP_WORDS);
+  ALLOC(cam.nbig, N);
   ALLOC(cam.out, N * (size_t)width * height * 4);
   ALLOC(cam.overflow, 1);
   return c->ncams++;

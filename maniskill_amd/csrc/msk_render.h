@@ -25,7 +25,8 @@
 #define MSK_TILE 8                 /* one wavefront rasterises an 8 x 8 tile, lane = pixel */
 #define MSK_MAX_TILES 1024         /* up to 256x256 images */
 #define MSK_BIG_TILES 16           /* a triangle over more tiles than this is binned by the whole workgroup */
-#define MSK_MAX_BIG 256
+#define MSK_MAX_BIG 16
+#define MSK_SEG_BIG 0x40000000      /* flag in TriSetup::seg: the record is in the env's list of large triangles */
 #define MSK_TILES_PER_WAVE 4        /* consecutive tiles a wavefront walks, prefetching the next one's records */
 #define MSK_SETUP_WORDS 16
 
@@ -46,7 +47,9 @@ struct RCamera {
   float* setups;                   /* [N][setup_cap][16]  */
   int* nsetup;                     /* [N]                 */
   int* tile_off;                   /* [N][ntiles + 1]     */
-  float* tile_recs;                /* [N][list_cap][16]: per tile, the records that touch it */
+  float* tile_recs;                /* [N][list_cap][16]: per tile, the records of the small triangles that touch it */
+  float* big_recs;                 /* [N][MSK_MAX_BIG][16]: triangles over many tiles (table, ground): tested by every tile */
+  int* nbig;                       /* [N] */
   short* out;                      /* [N][H][W][4]        */
   int* overflow;                   /* [1]                 */
 };
@@ -167,14 +170,17 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
       if (!setup_triangle(cam, q[0], q[sub + 1], q[sub + 2], seg, ti * 2 + sub, &t)) continue;
       const int slot = atomicAdd(Lns, 1);
       if (slot >= cam.setup_cap) { atomicOr(cam.overflow, 1); continue; }
-      setups[slot] = t;
       const int tx0 = (t.bbx & 0xFFFF) / MSK_TILE, tx1 = (t.bbx >> 16) / MSK_TILE, ty0 = (t.bby & 0xFFFF) / MSK_TILE, ty1 = (t.bby >> 16) / MSK_TILE;
-      if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > MSK_BIG_TILES) { /* table / ground sized: binned by the whole workgroup below */
+      if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > MSK_BIG_TILES) { /* table / ground sized: goes to the env's list of large triangles */
         const int b = atomicAdd(Lnbig, 1);
-        if (b < MSK_MAX_BIG) Lbig[b] = slot;
-        else atomicOr(cam.overflow, 1);
-        continue;
+        if (b < MSK_MAX_BIG) {
+          Lbig[b] = slot;
+          t.seg |= MSK_SEG_BIG;
+          setups[slot] = t;
+          continue;
+        } /* list full: binned like a small one */
       }
+      setups[slot] = t;
       for (int ty = ty0; ty <= ty1; ++ty)
         for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&Lcnt[ty * cam.tiles_x + tx], 1);
     }
@@ -182,14 +188,6 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
   __threadfence_block();   /* the records are read back by other threads of the workgroup */
   __syncthreads();
   const int nbig = min(*Lnbig, MSK_MAX_BIG);
-  for (int b = 0; b < nbig; ++b) { /* thread = tile */
-    const TriSetup* t = &setups[Lbig[b]];
-    const int tx0 = (t->bbx & 0xFFFF) / MSK_TILE, tx1 = (t->bbx >> 16) / MSK_TILE, ty0 = (t->bby & 0xFFFF) / MSK_TILE, ty1 = (t->bby >> 16) / MSK_TILE;
-    for (int tile = tid; tile < ntiles; tile += 256) {
-      const int tx = tile % cam.tiles_x, ty = tile / cam.tiles_x;
-      if (tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1) Lcnt[tile] += 1;   /* one thread per tile: no atomic needed */
-    }
-  }
   __syncthreads();
   const int ns = min(*Lns, cam.setup_cap);
   int* toff = cam.tile_off + (size_t)e * (MSK_MAX_TILES + 1);
@@ -215,7 +213,7 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
     const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
     const int bbx = __float_as_int(r3.z), bby = __float_as_int(r3.w);
     const int tx0 = (bbx & 0xFFFF) / MSK_TILE, tx1 = (bbx >> 16) / MSK_TILE, ty0 = (bby & 0xFFFF) / MSK_TILE, ty1 = (bby >> 16) / MSK_TILE;
-    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > MSK_BIG_TILES) continue;
+    if (__float_as_int(r3.x) & MSK_SEG_BIG) continue;   /* lives in the list of large triangles */
     for (int ty = ty0; ty <= ty1; ++ty)
       for (int tx = tx0; tx <= tx1; ++tx) {
         const int tile = ty * cam.tiles_x + tx;
@@ -226,23 +224,10 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
         }
       }
   }
-  __syncthreads();
-  for (int b = 0; b < nbig; ++b) { /* thread = tile */
-    const float4* src = (const float4*)&setups[Lbig[b]];
-    const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
-    const int bbx = __float_as_int(r3.z), bby = __float_as_int(r3.w);
-    const int tx0 = (bbx & 0xFFFF) / MSK_TILE, tx1 = (bbx >> 16) / MSK_TILE, ty0 = (bby & 0xFFFF) / MSK_TILE, ty1 = (bby >> 16) / MSK_TILE;
-    for (int tile = tid; tile < ntiles; tile += 256) {
-      const int tx = tile % cam.tiles_x, ty = tile / cam.tiles_x;
-      if (tx < tx0 || tx > tx1 || ty < ty0 || ty > ty1) continue;
-      const int pos = Lcnt[tile] + Lfill[tile];
-      Lfill[tile] += 1;
-      if (pos < Lcnt[tile + 1]) {
-        float4* dst = recs + (size_t)pos * 4;
-        dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = r3;
-      }
-    }
-  }
+  /* large triangles: one copy per env, every tile tests them against its own pixel box */
+  float4* bigr = (float4*)(cam.big_recs + (size_t)e * MSK_MAX_BIG * MSK_SETUP_WORDS);
+  for (int i = tid; i < nbig * 4; i += 256) bigr[i] = ((const float4*)&setups[Lbig[i / 4]])[i % 4];
+  if (tid == 0) cam.nbig[e] = nbig;
 }
 
 /* One wavefront per (group of MSK_TILES_PER_WAVE consecutive 8 x 8 tiles, env), lane = pixel.  The launch is bound by
@@ -250,8 +235,15 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
  * keeps the NEXT tile's records in flight (registers) while it rasterises the current one out of LDS. */
 __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
   __shared__ __attribute__((aligned(16))) float Ls[64 * MSK_SETUP_WORDS];
+  __shared__ __attribute__((aligned(16))) float Lb[MSK_MAX_BIG * MSK_SETUP_WORDS];
   const int e = blockIdx.y, lane = threadIdx.x;
   const int ntiles = cam.tiles_x * cam.tiles_y;
+  const int nbig = cam.nbig[e];
+  if (lane < nbig) {
+    const float4* src = (const float4*)(cam.big_recs + ((size_t)e * MSK_MAX_BIG + lane) * MSK_SETUP_WORDS);
+    float4* dst = (float4*)Lb + lane * 4;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+  }
   const int t0 = blockIdx.x * MSK_TILES_PER_WAVE;
   const int* toff = cam.tile_off + (size_t)e * (MSK_MAX_TILES + 1);
   const float4* recs = (const float4*)(cam.tile_recs + (size_t)e * cam.list_cap * MSK_SETUP_WORDS);
@@ -277,6 +269,24 @@ __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
     const float x = (float)px + 0.5f, y = (float)py + 0.5f;
     float best_w = 0.0f;
     int best_seg = 0, best_prim = 0x7FFFFFFF;
+    for (int k = 0; k < nbig; ++k) { /* the env's large triangles (LDS, staged once per wave) */
+      const float4* t4 = (const float4*)(Lb + k * MSK_SETUP_WORDS);
+      const float4 td = t4[3];
+      const int bbx = __float_as_int(td.z), bby = __float_as_int(td.w);
+      const int qx0 = tx * MSK_TILE, qy0 = ty * MSK_TILE;
+      if ((bbx & 0xFFFF) > qx0 + MSK_TILE - 1 || (bbx >> 16) < qx0 || (bby & 0xFFFF) > qy0 + MSK_TILE - 1 || (bby >> 16) < qy0) continue;
+      const float4 ta = t4[0], tb = t4[1], tc = t4[2];
+      const float e0 = fmaf(ta.x, x, fmaf(ta.y, y, ta.z));
+      const float e1 = fmaf(ta.w, x, fmaf(tb.x, y, tb.y));
+      const float e2 = fmaf(tb.z, x, fmaf(tb.w, y, tc.x));
+      if (e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f) {
+        const float w = fmaf(tc.y, x, fmaf(tc.z, y, tc.w));
+        const int prim = __float_as_int(td.y);
+        if (w >= wmin && (w > best_w || (w == best_w && prim < best_prim))) {
+          best_w = w; best_prim = prim; best_seg = __float_as_int(td.x);
+        }
+      }
+    }
     for (int c0 = l0; c0 < l1; c0 += 64) {
       const int n = min(64, l1 - c0);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -328,7 +338,7 @@ __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
       o.x = (short)fminf(fmaxf(rintf(gx * 1000.0f), -32768.0f), 32767.0f);
       o.y = (short)fminf(fmaxf(rintf(gy * 1000.0f), -32768.0f), 32767.0f);
       o.z = (short)fminf(fmaxf(rintf(gz * 1000.0f), -32768.0f), 32767.0f);
-      o.w = (short)best_seg;
+      o.w = (short)(best_seg & 0xFFFF);
     }
     ((short4*)cam.out)[((size_t)e * cam.H + py) * cam.W + px] = o;
   }
