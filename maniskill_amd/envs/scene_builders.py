@@ -81,3 +81,51 @@ def build_pick_cube_template(cube_half_size=0.02):
     cube = add_cube(tpl, "cube", cube_half_size, (0, 0, cube_half_size))
     goal = add_site(tpl, "goal_site")
     return tpl, dict(art=art, table=table, cube=cube, goal_site=goal)
+
+
+# ---- PushT-v1 (mani_skill/envs/tasks/tabletop/push_t.py) ------------------------------------------------------
+PANDA_STICK_REST_QPOS = np.array([0.662, 0.212, 0.086, -2.685, -0.115, 2.898, 1.673])  # WhiteTableSceneBuilder.initialize
+TEE_COM_Y = 0.0375
+TEE_BOXES = [((0.0, 0.0 - TEE_COM_Y, 0.0), (0.1, 0.025, 0.02)),            # horizontal bar (push_t.py:205-213)
+             ((0.0, 4 * 0.025 - TEE_COM_Y, 0.0), (0.025, 0.075, 0.02))]     # vertical bar   (push_t.py:238-241)
+
+
+def add_panda_stick(tpl: SceneTemplate, root_p=(-0.615, 0.0, 0.0), stiffness=1e3, damping=1e2, force_limit=100.0):
+    """PandaStick (agents/robots/panda/panda_stick.py): 7 dof arm, a 10 cm stick (16-sided prism hull) on the hand."""
+    model = load_model("panda_stick.json")
+    art = add_urdf_articulation(tpl, model, "panda_stick", root_p=root_p, disable_gravity=True)
+    for bid in tpl.art_active[art]:
+        tpl.set_drive(bid, stiffness, damping, force_limit, "force")
+    return art
+
+
+def add_tee(tpl: SceneTemplate, name="Tee", mass=0.8, friction=3.0):
+    """The T block (push_t.py:193-251): two boxes about the common centre of mass, mass 0.8, friction 3."""
+    vols = [8 * h[0] * h[1] * h[2] for _, h in TEE_BOXES]
+    dens = mass / sum(vols)
+    I = np.zeros(3)
+    for (c, h), v in zip(TEE_BOXES, vols):
+        m = dens * v
+        I += m / 3.0 * np.array([h[1] ** 2 + h[2] ** 2, h[0] ** 2 + h[2] ** 2, h[0] ** 2 + h[1] ** 2])
+        I += m * np.array([c[1] ** 2 + c[2] ** 2, c[0] ** 2 + c[2] ** 2, c[0] ** 2 + c[1] ** 2])   # parallel axis (products vanish: x = 0)
+    tee = tpl.add_actor(name, N.BODY_DYNAMIC, p=(0, 0, 0.1), mass=mass, inertia6=(I[0], I[1], I[2], 0, 0, 0))
+    for c, h in TEE_BOXES:
+        tpl.add_shape(tee, N.SHAPE_BOX, p=c, params=h, static_friction=friction, dynamic_friction=friction, restitution=0.0)
+    return tee
+
+
+def build_push_t_template():
+    """Body order: 11 panda_stick links, table-workspace, Tee, goal_Tee, goal_ee (push_t.py:159-262)."""
+    tpl = SceneTemplate()
+    art = add_panda_stick(tpl)
+    table = add_table_scene(tpl)
+    tee = add_tee(tpl)
+    goal_tee = tpl.add_actor("goal_Tee", N.BODY_KINEMATIC, p=(0, 0, 0.1))
+    for c, h in TEE_BOXES:                                  # visual only, 0.2 mm thick
+        tpl.add_visual(goal_tee, N.SHAPE_BOX, p=c, params=(h[0], h[1], 1e-4))
+    goal_ee = tpl.add_actor("goal_ee", N.BODY_KINEMATIC, p=(0, 0, 0.1))
+    ang = np.arange(16) * (2 * np.pi / 16)                 # cylinder visual r = 0.02, half length 1e-4, axis = local x
+    disc = np.concatenate([np.c_[np.full(16, -1e-4), 0.02 * np.cos(ang), 0.02 * np.sin(ang)],
+                           np.c_[np.full(16, 1e-4), 0.02 * np.cos(ang), 0.02 * np.sin(ang)]])
+    tpl.add_visual(goal_ee, N.SHAPE_CONVEX, verts=disc)
+    return tpl, dict(art=art, table=table, tee=tee, goal_tee=goal_tee, goal_ee=goal_ee)

@@ -144,6 +144,12 @@ class SceneTemplate:
         self.nshapes += 1
         return self.nshapes - 1
 
+    def add_visual(self, body, shape_type, p=(0, 0, 0), q=(1, 0, 0, 0), params=(0, 0, 0), verts=None):
+        """Visual-only shape (builder.add_box_visual & co. without a collision record, building/actor_builder.py:166-191):
+        consumed by render.attach_template_visuals, ignored by the physics."""
+        v = None if verts is None else np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+        self.ops.append(("add_visual", (body, shape_type, _pose7(p, q), list(map(float, params)), v)))
+
     def disable_collision(self, body_a, body_b):
         self.ops.append(("disable_collision", (body_a, body_b)))
 
@@ -245,6 +251,8 @@ class PhysxGpuSystem:
                                          groups, a[9], a[10]), op)
             elif op == "disable_collision":
                 L.check(ctx, L.disable_collision(ctx, *a), op)
+            elif op == "add_visual":
+                pass  # render.attach_template_visuals
             else:  # pragma: no cover
                 raise AssertionError(op)
 

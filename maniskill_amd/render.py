@@ -181,7 +181,7 @@ def attach_template_visuals(px, template, hidden_bodies=()):
     nb = px.bodies_per_env
     n = 0
     for op, a in template.ops:
-        if op != "add_shape":
+        if op not in ("add_shape", "add_visual"):
             continue
         body, stype, pose7, params, verts = a[0], a[1], a[2], a[3], a[4]
         if body in hidden_bodies:

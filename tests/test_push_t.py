@@ -1,0 +1,105 @@
+"""PushT-v1 (BASELINE.json config 3): host logic and known answers on the CPU oracle; HIP parity under -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from maniskill_amd.envs.push_t import PushTEnv
+
+
+def test_obs_shapes_and_truncation(oracle_factory):
+    env = PushTEnv(num_envs=3, px_factory=oracle_factory)
+    obs, info = env.reset(seed=0)
+    assert obs.shape == (3, 31) and obs.dtype == torch.float32 and not info["success"].any()
+    for t in range(100):
+        obs, r, term, trunc, info = env.step(None)
+    assert trunc.all() and r.shape == (3,) and torch.isfinite(obs).all()        # max_episode_steps = 100 (push_t.py:68)
+    # with no action the arm holds its keyframe and the T block stays where it was dropped
+    assert (env.qvel.abs() < 1e-2).all() and abs(env._pose(env._b_tee)[0, 2].item() - 0.02) < 1e-3
+
+
+def test_tee_at_the_goal_pose_is_a_success(oracle_factory):
+    """pseudo_render_intersection: the T block on the goal T covers >= 90 % of it (push_t.py:343-431,484-491)."""
+    env = PushTEnv(num_envs=2, px_factory=oracle_factory)
+    env.reset(seed=1)
+    assert (env.pseudo_render_intersection() < 0.9).all()
+    gq = torch.tensor([np.cos(env.goal_z_rot / 2), 0, 0, np.sin(env.goal_z_rot / 2)], dtype=torch.float32)
+    env._rbd[:, env._b_tee, :3] = torch.tensor([env.goal_offset[0], env.goal_offset[1], 0.021]) + env._offsets
+    env._rbd[:, env._b_tee, 3:7] = gq
+    env.px.gpu_apply_all(); env.px.gpu_fetch_all()
+    assert env.evaluate()["success"].all()
+    assert torch.allclose(env.compute_normalized_dense_reward(env.get_info()), torch.ones(2))
+    # rotated by 90 degrees it is not
+    env._rbd[:, env._b_tee, 3:7] = torch.tensor([np.cos(env.goal_z_rot / 2 + np.pi / 4), 0, 0, np.sin(env.goal_z_rot / 2 + np.pi / 4)], dtype=torch.float32)
+    env.px.gpu_apply_all(); env.px.gpu_fetch_all()
+    assert not env.evaluate()["success"].any()
+
+
+def test_seeded_reset_and_partial_reset(oracle_factory):
+    a, b = PushTEnv(num_envs=4, px_factory=oracle_factory), PushTEnv(num_envs=4, px_factory=oracle_factory)
+    oa, _ = a.reset(seed=9); ob, _ = b.reset(seed=9)
+    assert torch.equal(oa, ob)
+    tee = a._pose(a._b_tee)
+    assert ((tee[:, 0] >= -0.256 - 1e-6) & (tee[:, 0] <= -0.056 + 1e-6)).all()     # goal x + [-0.1, 0.1]
+    assert ((tee[:, 1] >= -0.2 - 1e-6) & (tee[:, 1] <= 0.1 + 1e-6)).all()          # goal y + [-0.1, 0.2]
+    before = a.get_state().clone()
+    a.reset(options={"env_idx": [1, 3]})
+    after = a.get_state()
+    assert torch.equal(before[[0, 2]], after[[0, 2]]) and not torch.equal(before[[1, 3]], after[[1, 3]])
+
+
+def test_stick_pushes_the_tee(oracle_factory):
+    """The stick (a 16-sided prism hull on the hand) sweeping across the table moves the T block."""
+    env = PushTEnv(num_envs=1, px_factory=oracle_factory, robot_init_qpos_noise=0.0)
+    env.reset(seed=2)
+    tcp = env.tcp_pose[0]
+    assert abs(tcp[0].item() + 0.321) < 0.02 and abs(tcp[1].item() - 0.284) < 0.02 and tcp[2].item() < 0.06   # ee_starting_pos (push_t.py:101-105)
+    # put the T right next to the stick, on the -y side, then rotate joint 1 towards it
+    env._rbd[:, env._b_tee, :3] = torch.tensor([-0.321, 0.16, 0.021]) + env._offsets
+    env._rbd[:, env._b_tee, 3:7] = torch.tensor([1.0, 0, 0, 0])
+    env.px.gpu_apply_all(); env.px.gpu_fetch_all()
+    y0 = env._pose(env._b_tee)[0, 1].item()
+    a = torch.zeros(1, 7); a[0, 0] = -1.0
+    for _ in range(25):
+        env.step(a)
+    assert env._pose(env._b_tee)[0, 1].item() < y0 - 0.03
+    assert abs(env._pose(env._b_tee)[0, 2].item() - 0.02) < 8e-3 and torch.isfinite(env.get_state()).all()   # it may tilt a little under the stick
+
+
+def test_camera_observation(oracle_factory):
+    env = PushTEnv(num_envs=2, px_factory=oracle_factory, obs_mode="depth+segmentation")
+    obs, _ = env.reset(seed=3)
+    cam = obs["sensor_data"]["base_camera"]
+    assert obs["state"].shape == (2, 21) and cam["depth"].shape == (2, 128, 128, 1) and cam["segmentation"].dtype == torch.int16
+    ids = set(np.unique(cam["segmentation"][0].numpy()))
+    assert {env._b_tee + 1, env._b_goal + 1, env._b_ee + 1, env._b_table + 1} <= ids    # T, goal T, ee goal disc, table
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_rollout_with_camera(oracle_factory):
+    n = 64
+    gpu = PushTEnv(num_envs=n, device="cuda:0", obs_mode="depth+segmentation")
+    cpu = PushTEnv(num_envs=n, px_factory=oracle_factory, obs_mode="depth+segmentation")
+    og, _ = gpu.reset(seed=2022); oc, _ = cpu.reset(seed=2022)
+    assert torch.equal(og["state"].cpu(), oc["state"])
+    gen = torch.Generator().manual_seed(0)
+    for t in range(40):
+        a = 2 * torch.rand(n, 7, generator=gen) - 1
+        og, rg, tg, ug, _ = gpu.step(a.to("cuda:0"))
+        oc, rc, tc, uc, _ = cpu.step(a)
+        assert np.allclose(og["state"].cpu().numpy(), oc["state"].numpy(), rtol=1e-4, atol=1e-5), t
+        assert np.allclose(rg.cpu().numpy(), rc.numpy(), atol=1e-5) and torch.equal(tg.cpu(), tc)
+    assert np.allclose(gpu.get_state().cpu().numpy(), cpu.get_state().numpy(), rtol=1e-4, atol=1e-5)
+    assert torch.equal(gpu.camera.get_picture_cuda().torch().cpu(), cpu.camera.get_picture_cuda().torch())
+
+
+@pytest.mark.gpu
+def test_full_size_4096_with_camera():
+    env = PushTEnv(num_envs=4096, device="cuda:0", obs_mode="depth+segmentation")
+    obs, _ = env.reset(seed=2022)
+    for _ in range(3):
+        obs, r, *_ = env.step(2 * torch.rand(4096, 7, device="cuda:0") - 1)
+    d = obs["sensor_data"]["base_camera"]["depth"]
+    assert d.shape == (4096, 128, 128, 1) and d.is_cuda and torch.isfinite(r).all()
+    seg = obs["sensor_data"]["base_camera"]["segmentation"]
+    assert ((seg == env._b_tee + 1).flatten(1).any(1)).all()
+    assert env.px.get_overflow() == 0

@@ -123,6 +123,14 @@ def cook_urdf(urdf_path, srdf_path, mesh_root):
                 fn = g.find("mesh").get("filename")
                 verts = reduce_hull(read_stl(os.path.join(mesh_root, fn)))
                 C.update(type="convex", source=fn, verts=np.round(verts, 6).tolist())
+            elif g.find("cylinder") is not None:
+                # cylinders are cooked as 16-sided prisms (PhysX has no cylinder primitive either: SAPIEN hands it a
+                # convex mesh [ext]); URDF cylinders are along the local z axis
+                r, clen = float(g.find("cylinder").get("radius")), float(g.find("cylinder").get("length"))
+                ang = np.arange(16) * (2 * np.pi / 16)
+                ring = np.stack([r * np.cos(ang), r * np.sin(ang)], axis=1)
+                verts = np.concatenate([np.c_[ring, np.full(16, -clen / 2)], np.c_[ring, np.full(16, clen / 2)]])
+                C.update(type="convex", source=f"cylinder r={r} l={clen}", verts=np.round(verts, 6).tolist())
             elif g.find("sphere") is not None:
                 C.update(type="sphere", radius=float(g.find("sphere").get("radius")))
             else:
@@ -202,6 +210,11 @@ def main():
         json.dump(model, f, separators=(",", ":"))
     nv = [len(c["verts"]) for L in model["links"] for c in L["collisions"] if c["type"] == "convex"]
     print("links", len(model["links"]), "hull verts", nv)
+    stick = cook_urdf(os.path.join(base, "panda_stick.urdf"), os.path.join(base, "panda_stick.srdf"), base)
+    stick["source"] = "mani_skill/assets/robots/panda/panda_stick.urdf (+ .srdf, collision STLs); cooked by tools/cook_assets.py"
+    with open(os.path.join(out_dir, "panda_stick.json"), "w") as f:
+        json.dump(stick, f, separators=(",", ":"))
+    print("panda_stick links", len(stick["links"]), [L["name"] for L in stick["links"]])
 
 
 if __name__ == "__main__":
