@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from maniskill_amd.dist import make_sharded_pick_cube  # noqa: E402
+from maniskill_amd.dist import make_sharded_env  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 # algorithmic bytes of one physics substep of one PickCube env
@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--envs", type=int, default=4096, help="total env count over all ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--env", default="PickCube-v1", choices=["PickCube-v1", "PushT-v1"],
+                    help="PickCube-v1 (BASELINE.json's metric, default) or PushT-v1 (its camera config)")
     ap.add_argument("--obs-mode", default="state", choices=["state", "depth+segmentation"],
                     help="state (BASELINE.json's metric, default) or the camera path: 128x128 depth+segmentation per env")
     args = ap.parse_args()
@@ -80,7 +82,7 @@ def main():
     if world_env != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
-    env, gather, rank, world = make_sharded_pick_cube(args.envs, device_type="cuda", obs_mode=args.obs_mode)
+    env, gather, rank, world = make_sharded_env(args.env, args.envs, device_type="cuda", obs_mode=args.obs_mode)
     camera_mode = args.obs_mode != "state"
     if camera_mode:   # image observations stay on their GPU; only the state part is gathered
         _gather = gather
@@ -137,11 +139,11 @@ def main():
         # value below comes from the committed rocprofv3 --pmc passes of this same command (profiles/, see its "source")
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_counters_4096.json")
-        if args.envs == 4096 and world == 1 and os.path.exists(pmc):
+        if args.envs == 4096 and world == 1 and args.env == "PickCube-v1" and os.path.exists(pmc):
             with open(pmc) as f:
                 traffic = json.load(f)["substep_groups"].get(dom, {}).get("hbm_bytes_per_launch")
         result = {
-            "metric": "env steps/sec (whole node), 4096 parallel PickCube-v1 envs",
+            "metric": f"env steps/sec (whole node), {args.envs} parallel {args.env} envs",
             "value": args.envs * args.steps / dt,
             "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -151,7 +153,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (uniform random actions in [-1,1], seed-2022 resets)",
-            "config": {"workload": f"PickCube-v1, num_envs={args.envs}, state obs, pd_joint_delta_pos, "
+            "config": {"workload": f"{args.env}, num_envs={args.envs}, state obs, pd_joint_delta_pos, "
                                    f"sim 100 Hz / control 20 Hz ({substeps} substeps, 15+1 TGS iterations)",
                        "envs_per_gpu": n_local, "parallelism": f"env-shard x{world}"},
             "roofline": {
@@ -165,7 +167,7 @@ def main():
         }
         if camera_mode:
             img_bytes = n_local * 128 * 128 * 8      # PositionSegmentation int16 x 4 per pixel: the algorithmic output
-            result["metric"] = "env steps/sec (whole node), 4096 parallel PickCube-v1 envs, 128x128 depth+segmentation camera obs"
+            result["metric"] = f"env steps/sec (whole node), {args.envs} parallel {args.env} envs, 128x128 depth+segmentation camera obs"
             result["config"]["workload"] += ", base_camera 128x128 PositionSegmentation"
             result["camera"] = {"kernel": "k_render_setup + k_render_tiles", "us_per_frame": cam_us,
                                 "bound": "hbm", "algorithmic_bytes_per_frame": img_bytes,

@@ -45,6 +45,12 @@ int msk_camera_create(msk_ctx* ctx, int width, int height, float fovy, float nea
 /* camera_group.get_picture_cuda("PositionSegmentation"): device pointer to int16 [num_envs][height][width][4],
  * valid until msk_destroy; shape gets the four extents. */
 void* msk_camera_buffer(msk_ctx* ctx, int camera, int64_t shape[4]);
+/* Camera.get_obs(depth=True, segmentation=True) under the minimal pack's texture transform
+ * (sensors/camera.py:190-242; render/shaders.py:141-145: depth = -position[..., [2]], segmentation = position[..., [3]]):
+ * device pointers to int16 [num_envs][height][width][1] planes that msk_camera_take_picture fills together with the
+ * PositionSegmentation texture, so the observation needs no gather pass over the texture. */
+enum msk_camera_plane { MSK_CAM_DEPTH = 0, MSK_CAM_SEGMENTATION = 1 };
+void* msk_camera_obs_buffer(msk_ctx* ctx, int camera, int which, int64_t shape[4]);
 /* render_system_group.update_render() + camera_group.take_picture(): rasterises every env. */
 int msk_camera_take_picture(msk_ctx* ctx, int camera, void* stream);
 

@@ -30,7 +30,7 @@ EXPORTS = [
     "get_sizes", "get_contacts", "get_env_contact_counts", "timing_enable", "timing_read",
 ]
 # include/msk_render.h — camera pipeline (both libraries)
-RENDER_EXPORTS = ["render_add_mesh", "render_finalize", "camera_create", "camera_buffer", "camera_take_picture"]
+RENDER_EXPORTS = ["render_add_mesh", "render_finalize", "camera_create", "camera_buffer", "camera_obs_buffer", "camera_take_picture"]
 # include/msk_task.h — fused task kernels (HIP library only; the test-suite's CPU checker has no counterpart)
 TASK_EXPORTS = ["task_pickcube_init", "task_pickcube_set_action", "control_step", "task_pickcube_observe"]
 K_DYNAMICS, K_COLLIDE, K_SOLVE = 0, 1, 2
@@ -120,6 +120,7 @@ class NativeLib:
             "render_finalize": (i32, [vp]),
             "camera_create": (i32, [vp, i32, i32, f32, f32, f32, i32, fp]),
             "camera_buffer": (vp, [vp, i32, C.POINTER(C.c_int64)]),
+            "camera_obs_buffer": (vp, [vp, i32, i32, C.POINTER(C.c_int64)]),
             "camera_take_picture": (i32, [vp, i32, vp]),
         }
         for name, (res, args) in render_sig.items():

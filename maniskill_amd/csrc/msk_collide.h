@@ -21,9 +21,8 @@
 struct DContactOut { v3 pos; v3 n; float sep; };
 
 /* what the narrowphase functions need besides the two shapes: the hull vertex pool (an LDS copy: the
- * support loops read 64 vertices per call) and this lane's column of an LDS scratch row (stride 64,
- * conflict-free) for the per-vertex heights of select_feature */
-struct CCtx { const v3* verts; float* hh; };
+ * support loops read 64 vertices per call) */
+struct CCtx { const v3* verts; };
 
 MSK_DEV int shape_nverts(const DShape* sh) { return sh->type == MSK_SHAPE_BOX ? 8 : sh->nverts; }
 MSK_DEV v3 shape_vert(const CCtx& m, const DShape* sh, int i) {
@@ -63,44 +62,49 @@ MSK_DEV void world_aabb(const DShape* sh, const pose* T, v3* c, v3* h) {
 /* ---- manifold ------------------------------------------------------------------------ */
 typedef struct { float u, v, h; } p3;   /* coordinates in the (t1, t2, n) contact frame */
 
-/* support feature of `sh` along sign*n: up to 8 extreme points, CCW about n */
+/* support feature of `sh` along sign*n: up to 8 extreme points, CCW about n.
+ * Two passes over the vertices (extreme height, then the eight directional maxima kept in registers side by side);
+ * every comparison sees the same operands in the same vertex order as the oracle's direction-by-direction scan. */
 MSK_DEV int select_feature(const CCtx& m, const DShape* sh, const pose* T, v3 n, v3 t1, v3 t2, float sign, p3* out) {
   const float DX[8] = {1.0f, 0.70710678f, 0.0f, -0.70710678f, -1.0f, -0.70710678f, 0.0f, 0.70710678f};
   const float DY[8] = {0.0f, 0.70710678f, 1.0f, 0.70710678f, 0.0f, -0.70710678f, -1.0f, -0.70710678f};
   v3 nl = quat_rotate_inv(T->q, n), t1l = quat_rotate_inv(T->q, t1), t2l = quat_rotate_inv(T->q, t2);
   float on = v3_dot(T->p, n), o1 = v3_dot(T->p, t1), o2 = v3_dot(T->p, t2);
-  int nv = shape_nverts(sh);
+  const int nv = shape_nverts(sh);
   float hbest = -3.0e38f;
   for (int i = 0; i < nv; ++i) {
-    m.hh[(i) * 64] = v3_dot(shape_vert(m, sh, i), nl);
-    float s = sign * m.hh[(i) * 64];
+    const float s = sign * v3_dot(shape_vert(m, sh, i), nl);
     if (s > hbest) hbest = s;
   }
+  const float thr = hbest - ORC_FEAT_EPS;
   int sel[8];
-  for (int k = 0; k < 8; ++k) {
-    int best = -1;
-    float bd = -3.0e38f;
-    for (int i = 0; i < nv; ++i) {
-      if (sign * m.hh[(i) * 64] < hbest - ORC_FEAT_EPS) continue;
-      v3 p = shape_vert(m, sh, i);
-      float d = fmaf(v3_dot(p, t1l), DX[k], v3_dot(p, t2l) * DY[k]);
-      if (d > bd) { bd = d; best = i; }
+  float bd[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sel[k] = -1; bd[k] = -3.0e38f; }
+  for (int i = 0; i < nv; ++i) {
+    const v3 p = shape_vert(m, sh, i);
+    if (sign * v3_dot(p, nl) < thr) continue;
+    const float pu = v3_dot(p, t1l), pv = v3_dot(p, t2l);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float d = fmaf(pu, DX[k], pv * DY[k]);
+      if (d > bd[k]) { bd[k] = d; sel[k] = i; }
     }
-    sel[k] = best;
   }
-  int cnt = 0;
-  int kept[8];
+  /* drop repeats of the previous kept vertex, and a last one equal to the first */
+  int cnt = 0, first = -1, last = -1;
+#pragma unroll
   for (int k = 0; k < 8; ++k) {
-    if (cnt > 0 && sel[k] == kept[cnt - 1]) continue;
-    kept[cnt++] = sel[k];
+    if (cnt > 0 && sel[k] == last) continue;
+    last = sel[k];
+    if (cnt == 0) first = last;
+    const v3 p = shape_vert(m, sh, last);
+    out[cnt].u = v3_dot(p, t1l) + o1;
+    out[cnt].v = v3_dot(p, t2l) + o2;
+    out[cnt].h = v3_dot(p, nl) + on;
+    cnt++;
   }
-  if (cnt > 1 && kept[cnt - 1] == kept[0]) cnt--;
-  for (int k = 0; k < cnt; ++k) {
-    v3 p = shape_vert(m, sh, kept[k]);
-    out[k].u = v3_dot(p, t1l) + o1;
-    out[k].v = v3_dot(p, t2l) + o2;
-    out[k].h = m.hh[kept[k] * 64] + on;
-  }
+  if (cnt > 1 && last == first) cnt--;
   return cnt;
 }
 

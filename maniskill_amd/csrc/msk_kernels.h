@@ -102,11 +102,9 @@ __global__ void __launch_bounds__(64) k_broadphase(const DModel* __restrict__ m,
 __global__ void __launch_bounds__(64) k_narrowphase(const DModel* __restrict__ m, DState st, const int group) {
   __shared__ int pref[NP_GROUP_MAX + 1];
   __shared__ v3 s_verts[MSK_MAX_SHAPES * 16];   /* the template's hull vertex pool (12 KB) */
-  __shared__ float s_hh[MSK_MAX_HULL_VERTS * 64];
   for (int i = threadIdx.x; i < m->nverts_total; i += 64) s_verts[i] = m->verts[i];
   CCtx cx;
   cx.verts = s_verts;
-  cx.hh = s_hh + threadIdx.x;
   const int type = blockIdx.y, e0 = blockIdx.x * group, lane = threadIdx.x;
   const float margin = 2.0f * m->cfg.contact_offset;
   if (lane == 0) {

@@ -689,6 +689,8 @@ MSK_API int msk_camera_create(msk_ctx* c, int width, int height, float fovy, flo
   ALLOC(cam.big_recs, N * (size_t)MSK_MAX_BIG * MSK_SETUP_WORDS);
   ALLOC(cam.nbig, N);
   ALLOC(cam.out, N * (size_t)width * height * 4);
+  ALLOC(cam.depth, N * (size_t)width * height);
+  ALLOC(cam.seg, N * (size_t)width * height);
   ALLOC(cam.overflow, 1);
   return c->ncams++;
 }
@@ -697,6 +699,12 @@ MSK_API void* msk_camera_buffer(msk_ctx* c, int camera, int64_t shape[4]) {
   if (camera < 0 || camera >= c->ncams) return nullptr;
   shape[0] = c->model.N; shape[1] = c->cams[camera].H; shape[2] = c->cams[camera].W; shape[3] = 4;
   return c->cams[camera].out;
+}
+
+MSK_API void* msk_camera_obs_buffer(msk_ctx* c, int camera, int which, int64_t shape[4]) {
+  if (camera < 0 || camera >= c->ncams || (which != MSK_CAM_DEPTH && which != MSK_CAM_SEGMENTATION)) return nullptr;
+  shape[0] = c->model.N; shape[1] = c->cams[camera].H; shape[2] = c->cams[camera].W; shape[3] = 1;
+  return which == MSK_CAM_DEPTH ? c->cams[camera].depth : c->cams[camera].seg;
 }
 
 MSK_API int msk_camera_take_picture(msk_ctx* c, int camera, void* stream) {

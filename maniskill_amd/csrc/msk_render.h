@@ -51,6 +51,8 @@ struct RCamera {
   float* big_recs;                 /* [N][MSK_MAX_BIG][16]: triangles over many tiles (table, ground): tested by every tile */
   int* nbig;                       /* [N] */
   short* out;                      /* [N][H][W][4]        */
+  short* depth;                    /* [N][H][W]: -z of out (Camera.get_obs's depth), written by the same store */
+  short* seg;                      /* [N][H][W]: w of out                                                      */
   int* overflow;                   /* [1]                 */
 };
 
@@ -340,7 +342,10 @@ __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
       o.z = (short)fminf(fmaxf(rintf(gz * 1000.0f), -32768.0f), 32767.0f);
       o.w = (short)(best_seg & 0xFFFF);
     }
-    ((short4*)cam.out)[((size_t)e * cam.H + py) * cam.W + px] = o;
+    const size_t pix = ((size_t)e * cam.H + py) * cam.W + px;
+    ((short4*)cam.out)[pix] = o;
+    cam.depth[pix] = (short)(-(int)o.z);   /* int16 negation wraps like the host-side `-position[..., 2]` */
+    cam.seg[pix] = o.w;
   }
 }
 

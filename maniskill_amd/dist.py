@@ -62,6 +62,22 @@ class ObservationGather:
         return r[:, : self.obs_dim], r[:, self.obs_dim], r[:, self.obs_dim + 1] > 0.5, r[:, self.obs_dim + 2] > 0.5
 
 
+def make_sharded_env(env_id: str, total_envs: int, device_type: str = "cuda", px_factory=None, **kw):
+    """One env shard per process (env_id: "PickCube-v1" or "PushT-v1").  Returns (env, gather, rank, world)."""
+    from .envs.pick_cube import PickCubeEnv
+    from .envs.push_t import PushTEnv
+
+    cls = {"PickCube-v1": PickCubeEnv, "PushT-v1": PushTEnv}[env_id]
+    rank, world, local = init_distributed(device_type)
+    start, count = shard_range(total_envs, rank, world)
+    assert total_envs % world == 0, "num_envs must divide evenly over the ranks"
+    device: Optional[str] = f"cuda:{local}" if device_type == "cuda" else None
+    env = cls(num_envs=count, device=device, env_index_offset=start, total_envs=total_envs, px_factory=px_factory, **kw)
+    obs_dim = env.obs_dim if kw.get("obs_mode", "state") == "state" else (21 if env_id == "PushT-v1" else env.obs_dim)
+    gather = ObservationGather(count, obs_dim, world, env.device)
+    return env, gather, rank, world
+
+
 def make_sharded_pick_cube(total_envs: int, device_type: str = "cuda", px_factory=None, **kw):
     """One PickCubeEnv shard per process.  Returns (env, gather, rank, world)."""
     from .envs.pick_cube import PickCubeEnv

@@ -135,18 +135,22 @@ class RenderCameraGroup:
         cam = L.check(px.ctx, L.camera_create(px.ctx, int(cfg.width), int(cfg.height), float(cfg.fov), float(cfg.near), float(cfg.far),
                                               int(cfg.mount), N._fa(list(cfg.p) + list(cfg.q), 7)), "camera_create")
         self.id = cam
+        def wrap(ptr, shape, what):
+            if not ptr:
+                raise RuntimeError(f"{what} returned NULL")
+            shp = tuple(int(s) for s in shape)
+            if px.host_memory:
+                n = int(np.prod(shp))
+                return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int16)), shape=(n,)).reshape(shp))
+            t = torch.as_tensor(_DevPtr(ptr, shp, "<i2"), device=px.device)
+            assert t.data_ptr() == ptr
+            return t
+
         shape = (C.c_int64 * 4)()
-        ptr = L.camera_buffer(px.ctx, cam, shape)
-        if not ptr:
-            raise RuntimeError("msk_camera_buffer returned NULL")
-        shp = tuple(int(s) for s in shape)
-        if px.host_memory:
-            n = int(np.prod(shp))
-            arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int16)), shape=(n,)).reshape(shp)
-            self._tex = torch.from_numpy(arr)
-        else:
-            self._tex = torch.as_tensor(_DevPtr(ptr, shp, "<i2"), device=px.device)
-            assert self._tex.data_ptr() == ptr
+        self._tex = wrap(L.camera_buffer(px.ctx, cam, shape), shape, "msk_camera_buffer")
+        # depth / segmentation planes written by the rasteriser's own store (no gather pass over the texture)
+        self._depth = wrap(L.camera_obs_buffer(px.ctx, cam, 0, shape), shape, "msk_camera_obs_buffer")
+        self._seg = wrap(L.camera_obs_buffer(px.ctx, cam, 1, shape), shape, "msk_camera_obs_buffer")
         # intrinsics of set_fovy(fovy, compute_x=True) (scene.py:250-257)
         fy = 0.5 * cfg.height / np.tan(0.5 * cfg.fov)
         self.intrinsic_cv = torch.tensor([[fy, 0, 0.5 * cfg.width], [0, fy, 0.5 * cfg.height], [0, 0, 1]], dtype=torch.float32)
@@ -160,16 +164,17 @@ class RenderCameraGroup:
             raise KeyError(f"the minimal shader pack of this backend provides PositionSegmentation only, not {name}")
         return PictureHandle(self._tex)
 
-    def get_obs(self, depth=True, segmentation=True, position=False):
-        """Camera.get_obs (sensors/camera.py:190-242) with the minimal pack's texture transform."""
+    def get_obs(self, depth=True, segmentation=True, position=False, copy=True):
+        """Camera.get_obs (sensors/camera.py:190-242) with the minimal pack's texture transform.  ``copy=False`` hands
+        out the rasteriser's own planes (overwritten by the next take_picture) instead of a snapshot."""
         data = self._tex
         out = {}
         if position:
             out["position"] = data[..., :3]
-        if depth:
-            out["depth"] = -data[..., [2]]
-        if segmentation:
-            out["segmentation"] = data[..., [3]]
+        if depth:        # == -data[..., [2]]
+            out["depth"] = self._depth.clone() if copy else self._depth
+        if segmentation:  # == data[..., [3]]
+            out["segmentation"] = self._seg.clone() if copy else self._seg
         return out
 
 

@@ -27,6 +27,7 @@ typedef struct {
   float fx, fy, cx, cy, near_, far_;
   pose local;
   int16_t* out;
+  int16_t *depth, *seg;
 } r_camera;
 typedef struct {
   int nv, nt, ns, finalized, ncams;
@@ -96,6 +97,8 @@ ORC_EXPORT int orc_camera_create(orc_ctx* c, int width, int height, float fovy, 
   cam->near_ = near_plane; cam->far_ = far_plane;
   cam->local = r_pose7(local_pose);
   cam->out = (int16_t*)calloc((size_t)c->num_envs * width * height * 4, sizeof(int16_t));
+  cam->depth = (int16_t*)calloc((size_t)c->num_envs * width * height, sizeof(int16_t));
+  cam->seg = (int16_t*)calloc((size_t)c->num_envs * width * height, sizeof(int16_t));
   return r->ncams++;
 }
 
@@ -104,6 +107,14 @@ ORC_EXPORT void* orc_camera_buffer(orc_ctx* c, int camera, int64_t shape[4]) {
   if (!r || camera < 0 || camera >= r->ncams) return NULL;
   shape[0] = c->num_envs; shape[1] = r->cams[camera].H; shape[2] = r->cams[camera].W; shape[3] = 4;
   return r->cams[camera].out;
+}
+
+/* Camera.get_obs planes (sensors/camera.py:190-242 with render/shaders.py:141-145) */
+ORC_EXPORT void* orc_camera_obs_buffer(orc_ctx* c, int camera, int which, int64_t shape[4]) {
+  r_model* r = (r_model*)c->render;
+  if (!r || camera < 0 || camera >= r->ncams || (which != MSK_CAM_DEPTH && which != MSK_CAM_SEGMENTATION)) return NULL;
+  shape[0] = c->num_envs; shape[1] = r->cams[camera].H; shape[2] = r->cams[camera].W; shape[3] = 1;
+  return which == MSK_CAM_DEPTH ? r->cams[camera].depth : r->cams[camera].seg;
 }
 
 static void project_point(const r_camera* cam, v3 p, float* u, float* v, float* w) {
@@ -222,6 +233,10 @@ ORC_EXPORT int orc_camera_take_picture(orc_ctx* c, int camera, void* stream) {
           o[2] = to_mm(-d);
           o[3] = (int16_t)t->seg;
         }
+    }
+    for (int i = 0; i < cam->W * cam->H; ++i) {
+      cam->depth[(size_t)e * cam->W * cam->H + i] = (int16_t)(-(int)img[4 * i + 2]);
+      cam->seg[(size_t)e * cam->W * cam->H + i] = img[4 * i + 3];
     }
   }
   free(cv); free(st); free(bw);

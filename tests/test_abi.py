@@ -37,6 +37,20 @@ def test_task_header_entry_points_are_exported(built):
         assert hasattr(dll, name), f"libmsk_physx.so does not export {name}"
 
 
+def test_render_header_entry_points_are_exported(built):
+    """include/msk_render.h (camera pipeline): declared, bound in _native.py, exported by both libraries."""
+    from oracle_backend import ORACLE_LIB
+
+    text = open(os.path.join(ROOT, "include", "msk_render.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(msk_[a-z_0-9]+)\s*\(", text)))
+    assert {"msk_" + n for n in N.RENDER_EXPORTS} == set(names)
+    dll, orc = ctypes.CDLL(N.DEFAULT_LIB), ctypes.CDLL(ORACLE_LIB)
+    for name in names:
+        assert hasattr(dll, name), f"libmsk_physx.so does not export {name}"
+        assert hasattr(orc, name.replace("msk_", "orc_", 1))
+
+
 def test_oracle_exports_same_surface(built):
     from oracle_backend import ORACLE_LIB
 

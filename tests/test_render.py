@@ -70,6 +70,8 @@ def test_box_in_front_of_the_camera(oracle_factory):
     assert x[64, 84] == round((84.5 - 64) / 64 * 1500) and x[64, 43] == round((43.5 - 64) / 64 * 1500)
     assert y[43, 64] == round(-(43.5 - 64) / 64 * 1500) and y[84, 64] == round(-(84.5 - 64) / 64 * 1500)
     obs = cam.get_obs()
+    tex = cam.get_picture_cuda("PositionSegmentation").torch()
+    assert torch.equal(obs["depth"], -tex[..., [2]]) and torch.equal(obs["segmentation"], tex[..., [3]])
     assert obs["depth"].shape == (1, 128, 128, 1) and obs["depth"][0, 64, 64, 0] == 1500 and obs["segmentation"][0, 64, 64, 0] == ids[0] + 1
 
 
