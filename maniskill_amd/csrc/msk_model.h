@@ -86,6 +86,12 @@ struct DState {
   /* envs with more constraint blocks than the small solver launch holds (msk_solve.h) */
   int *big_list;                               /* [N] */
   int *big_count;                              /* [1]; zeroed by k_dynamics of the same substep */
+  /* envs expected to need the big launch in substep `tick` (they did in substep tick - 1): solved on a second stream
+   * while the small launch runs; purely a scheduling hint, both launches compute the same bits for an env */
+  int *pred_list;                              /* [2][N]: list of substep t at (t & 1) * N */
+  int *pred_count;                             /* [2]; entry (t + 1) & 1 zeroed by k_dynamics of substep t */
+  int *pred_tick;                              /* [N]: substep for which the env is on the predicted list */
+  int tick;                                    /* current substep (by value, set per launch) */
   /* narrowphase work lists per env and type (plane / box-box / GJK): surviving pair indices in pair order */
   int *np_count;                               /* [N][4] */
   int *np_items;                               /* [N][3][np] */

@@ -49,6 +49,8 @@ struct msk_ctx {
   pose pending_root;
   int nverts_total;
   size_t lds_small, lds_big; /* dynamic LDS of the two solver launches */
+  hipStream_t side = nullptr; /* predicted big solver launch, beside the small one */
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   RModel* rmodel;            /* host copy of the render geometry (include/msk_render.h) */
   RModel* d_rmodel;
   bool render_finalized;
@@ -139,6 +141,9 @@ MSK_API void msk_destroy(msk_ctx* c) {
   hipDeviceSynchronize();
   for (void* p : c->allocs) hipFree(p);
   for (hipEvent_t e : c->tev) hipEventDestroy(e);
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  if (c->ev_join) hipEventDestroy(c->ev_join);
+  if (c->side) hipStreamDestroy(c->side);
   delete c->rmodel;
   delete c;
 }
@@ -428,18 +433,27 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   ALLOC(st.Scol, N * G * 8); ALLOC(st.W, N * G * G); ALLOC(st.vfree, N * G);
   ALLOC(st.ct_cnt, N * m.npp); ALLOC(st.ct_rec, N * m.npp * MSK_CT_REC);
   ALLOC(st.big_list, N); ALLOC(st.big_count, 1);
+  ALLOC(st.pred_list, 2 * N); ALLOC(st.pred_count, 2); ALLOC(st.pred_tick, N);
+  st.tick = 1;
+  HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   ALLOC(st.dbg, N * 8 + 64);
   /* the big solver launch needs more than the default 64 KB of dynamic LDS */
   if (m.G == 16) {
-    auto kb = k_csolve_big<16>;
+    auto kb = k_csolve_big<16, false>;
+    auto kp = k_csolve_big<16, true>;
     c->lds_small = CsLds<16, 16>::TOTAL * sizeof(float);
     c->lds_big = CsLds<16, 64>::TOTAL * sizeof(float);
     HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_big));
+    HIP_TRY(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_big));
   } else {
-    auto kb = k_csolve_big<32>;
+    auto kb = k_csolve_big<32, false>;
+    auto kp = k_csolve_big<32, true>;
     c->lds_small = CsLds<32, 32>::TOTAL * sizeof(float);
     c->lds_big = CsLds<32, 64>::TOTAL * sizeof(float);
     HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_big));
+    HIP_TRY(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_big));
   }
   ALLOC(st.env_ncontacts, N); ALLOC(st.env_overflow, 1);
   ALLOC(st.np_count, N * 4); ALLOC(st.np_items, N * NP_TYPES * (size_t)(m.np > 0 ? m.np : 1));
@@ -534,19 +548,29 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
   }
   if (timed) hipEventRecord(ev[2], s);
   {
-    /* every env in the 16-block launch; the few that do not fit queue themselves for the big one */
+    /* envs that needed the big launch last substep go straight to it on the side stream; every other env in the small
+     * launch, and the few of those that do not fit queue themselves for a second big launch behind it */
     const int nbig = N < 512 ? N : 512;
+    HIP_TRY(hipEventRecord(c->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     if (c->model.G == 16) {
       auto ks = k_csolve<16, 16>;
-      auto kb = k_csolve_big<16>;
+      auto kb = k_csolve_big<16, false>;
+      auto kp = k_csolve_big<16, true>;
+      hipLaunchKernelGGL(kp, dim3(nbig), dim3(64), c->lds_big, c->side, c->d_model, c->st);
       hipLaunchKernelGGL(ks, dim3((N + 3) / 4), dim3(64), c->lds_small, s, c->d_model, c->st);
       hipLaunchKernelGGL(kb, dim3(nbig), dim3(64), c->lds_big, s, c->d_model, c->st);
     } else {
       auto ks = k_csolve<32, 32>;
-      auto kb = k_csolve_big<32>;
+      auto kb = k_csolve_big<32, false>;
+      auto kp = k_csolve_big<32, true>;
+      hipLaunchKernelGGL(kp, dim3(nbig), dim3(64), c->lds_big, c->side, c->d_model, c->st);
       hipLaunchKernelGGL(ks, dim3((N + 1) / 2), dim3(64), c->lds_small, s, c->d_model, c->st);
       hipLaunchKernelGGL(kb, dim3(nbig), dim3(64), c->lds_big, s, c->d_model, c->st);
     }
+    HIP_TRY(hipEventRecord(c->ev_join, c->side));
+    HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
+    c->st.tick++;
     c->kin_dirty = true;
   }
   if (timed) { hipEventRecord(ev[3], s); c->t_n++; }

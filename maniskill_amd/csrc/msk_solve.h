@@ -10,7 +10,7 @@
  *                The lane keeps a, b = J dq, lambda, sum(lambda), c0, 1/A_rr of its <= 3 rows in VGPRs.
  *   build        the lane assembles its rows J (S_k . F against the LDS-resident motion subspace
  *                columns), Y = W J^T (W in LDS), parks Y in LDS, then walks all columns r and stores
- *                A[i][r] = J_i . Y_r for its rows i (column-major in LDS: a sweep step reads 3
+ *                A[i][r] = J_i . Y_r for its rows i (per (column block, row block) nine contiguous words in LDS: a sweep step reads 3
  *                conflict-free dwords per lane).
  *   sweep step   every lane evaluates the clamp for its own slot s (5 VALU), the owner's impulse change
  *                is broadcast (DPP row_newbcast / v_readlane), every lane does a[s'] += A[s'][r] * dl
@@ -100,6 +100,7 @@ MSK_DEV float bias_over_arr(float b, float c0, float rinv, float inv_h, float in
   return bias * rinv;
 }
 
+#define MSK_PRED_BLOCKS 8   /* an env solved by a big launch stays predicted while it has more constraint blocks than this */
 /* GL lanes per env (16: four envs per wave, 64: one); e_first = env of group 0; DEFER: envs that do not fit
  * queue themselves for the big launch */
 template <int NVP, int GL, bool DEFER>
@@ -176,7 +177,11 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   }
   int nblk = nlim + ncont;
   /* carve the pool: groups in order; a group that does not fit (or is out of range) sits this launch out */
-  bool active = in_range;
+  /* DEFER launch: envs on this substep's predicted list are being solved by the concurrent big launch (which may
+   * already have stamped them for the next substep, hence >=) */
+  const bool mine = in_range && !(DEFER && st.pred_tick[e] >= st.tick);
+  if (!mine) nblk = 0;
+  bool active = mine;
   int pbase = 0;
   {
     int off = 0;
@@ -189,8 +194,15 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
       if (fits) off += need;
     }
   }
-  if (DEFER && in_range && !active && lane == 0) st.big_list[atomicAdd(st.big_count, 1)] = e;
+  if (DEFER && mine && !active && lane == 0) st.big_list[atomicAdd(st.big_count, 1)] = e;
+  /* next substep: straight to the big launch (an env the small launch deferred has stamped itself already) */
+  if (in_range && lane == 0 && (DEFER ? (mine && !active) : (nblk > MSK_PRED_BLOCKS && st.pred_tick[e] <= st.tick))) {
+    const int t1 = st.tick + 1;
+    st.pred_tick[e] = t1;
+    st.pred_list[(size_t)(t1 & 1) * m->N + atomicAdd(&st.pred_count[t1 & 1], 1)] = e;
+  }
   if (!active) nblk = 0;
+  if (GL == 64) nblk = __builtin_amdgcn_readfirstlane(nblk); /* one env per wave: let the loops below run on scalar counters */
   if (active && lane == 0) {
     st.env_ncontacts[e] = ncont;
     if (overflow) atomicOr(st.env_overflow, 1);
@@ -300,7 +312,7 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   const unsigned long long vm0 = GBALLOT(valid[0]), vm1 = GBALLOT(valid[1]), vm2 = GBALLOT(valid[2]);
 
   PHASE();
-  /* ---- constraint-space operator: A[(me, s')][col] = J_(me,s') . Y_col, column-major in LDS -------------------- */
+  /* ---- constraint-space operator: A[(me, s')][col] = J_(me,s') . Y_col, per (column block, row block) nine contiguous words in LDS -------------------- */
   float av[3], bv[3] = {0.0f, 0.0f, 0.0f}, ls[3] = {0.0f, 0.0f, 0.0f}, rinv[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
@@ -316,9 +328,8 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
       const int col = blk * 3 + s;
       if (!((vm >> blk) & 1ull)) { /* a row that does not exist is an all-zero row: its column is zero */
         if (lane < nblk) {
-          La[(col * 3 + 0) * nb + lane] = 0.0f;
-          La[(col * 3 + 1) * nb + lane] = 0.0f;
-          La[(col * 3 + 2) * nb + lane] = 0.0f;
+          float* a = La + ((size_t)blk * nb + lane) * 9 + s * 3;
+          a[0] = 0.0f; a[1] = 0.0f; a[2] = 0.0f;
         }
         continue;
       }
@@ -332,9 +343,8 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
         d2 = fmaf(J[2][k], y, d2);
       }
       if (lane < nblk) {
-        La[(col * 3 + 0) * nb + lane] = d0;
-        La[(col * 3 + 1) * nb + lane] = d1;
-        La[(col * 3 + 2) * nb + lane] = d2;
+        float* a = La + ((size_t)blk * nb + lane) * 9 + s * 3;
+        a[0] = d0; a[1] = d1; a[2] = d2;
       }
       if (lane == blk) { /* my own diagonal */
         if (s == 0) rinv[0] = 1.0f / d0;
@@ -358,7 +368,7 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   auto load_cols = [&](int blk, float* dst) {
     const int bc = blk < nblk ? blk : (nblk > 0 ? nblk - 1 : 0);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) dst[i] = La[(bc * 9 + i) * nb + lrow];
+    for (int i = 0; i < 9; ++i) dst[i] = La[(bc * nb + lrow) * 9 + i];   /* one address, nine immediate offsets */
   };
   /* rows that exist in at least one env of the wave: bit blk*3+s (wave-uniform, tested with scalar ops) */
   unsigned long long wrows = 0ull;
@@ -388,11 +398,12 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
     const float t2 = bias_over_arr<POSIT, true>(bv[2], c0[2], rinv[2], inv_h, inv_dt, beta_dt);
     float Ac[9], An[9];
     load_cols(0, Ac);
-    auto block_steps = [&](const int blk) {
+    auto block_steps = [&](const int blk, auto all_rows_tag) {
       load_cols((blk + 1 < nbmax) ? blk + 1 : 0, An);
       const bool owner = lane == blk;
-      const unsigned rowbits = (GL == 64) ? (unsigned)(((vm0 >> blk) & 1ull) | (((vm1 >> blk) & 1ull) << 1) | (((vm2 >> blk) & 1ull) << 2))
-                                          : (unsigned)((wrows >> (blk * 3)) & 7ull);
+      const unsigned rowbits = decltype(all_rows_tag)::value ? 7u
+                               : (GL == 64) ? (unsigned)(((vm0 >> blk) & 1ull) | (((vm1 >> blk) & 1ull) << 1) | (((vm2 >> blk) & 1ull) << 2))
+                                            : (unsigned)((wrows >> (blk * 3)) & 7ull);
       /* new impulse = clamp(lam - (J.v + bias) / A_rr); a row that does not exist has rinv = lam = 0 -> stays 0 */
       if (rowbits & 1u) {
         const float nl = fminf(fmaxf(fmaf(-av[0], rinv[0], lam[0] - t0), 0.0f), INFINITY);
@@ -421,10 +432,13 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
 #pragma unroll
       for (int blk = 0; blk < 16; ++blk) {
         if (blk >= nbmax) break;
-        block_steps(blk);
+        block_steps(blk, std::false_type{});
       }
-    } else {
-      for (int blk = 0; blk < nbmax; ++blk) block_steps(blk);
+    } else { /* one env: limit blocks first (rows 0 / 1 as present), then contact blocks, whose three rows all exist */
+      const int nl0 = __builtin_amdgcn_readfirstlane(nlim < nbmax ? nlim : nbmax);
+      for (int blk = 0; blk < nl0; ++blk) block_steps(blk, std::false_type{});
+#pragma unroll 2
+      for (int blk = nl0; blk < nbmax; ++blk) block_steps(blk, std::true_type{});
     }
     if (POSIT) {
 #pragma unroll
@@ -510,12 +524,15 @@ __global__ void __launch_bounds__(64) k_csolve(const DModel* __restrict__ m, DSt
   solve_env<NVP, GL, true>(m, st, blockIdx.x * (64 / GL), lds);
 }
 
-template <int NVP>
+/* PRED: the list predicted in the previous substep (runs beside k_csolve on a second stream); otherwise the
+ * envs k_csolve deferred in this substep */
+template <int NVP, bool PRED>
 __global__ void __launch_bounds__(64) k_csolve_big(const DModel* __restrict__ m, DState st) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int count = *st.big_count;
+  const int count = PRED ? st.pred_count[st.tick & 1] : *st.big_count;
+  const int* list = PRED ? st.pred_list + (size_t)(st.tick & 1) * m->N : st.big_list;
   for (int i = blockIdx.x; i < count; i += gridDim.x) {
-    solve_env<NVP, 64, false>(m, st, st.big_list[i], lds);
+    solve_env<NVP, 64, false>(m, st, list[i], lds);
     wave_sync();
   }
 }
