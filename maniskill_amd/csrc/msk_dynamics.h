@@ -173,10 +173,7 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
   float* vec = lds + ly.vec;
   const int LD = MSK_MAX_DOF + 1;
 
-  if (blockIdx.x == 0 && threadIdx.x == 0) { /* this substep's list of big solver envs, and the prediction it builds */
-    *st.big_count = 0;
-    st.pred_count[(st.tick + 1) & 1] = 0;
-  }
+  if (blockIdx.x == 0 && threadIdx.x < MSK_SOLVE_CLASSES) st.cls_count[threadIdx.x] = 0; /* this substep's solver lists */
   /* ---- 1. frames, velocities, bias accelerations (down the tree) ------------------------------------ */
   sv6 S, V, acc;
   const pose T = forward_pass<true>(m, E, lds, ly, i, has, &S, &V, &acc);

@@ -96,6 +96,43 @@ __global__ void __launch_bounds__(64) k_broadphase(const DModel* __restrict__ m,
   if (lane < NP_TYPES) st.np_count[(size_t)e * 4 + lane] = (lane == 0) ? base[0] : ((lane == 1) ? base[1] : base[2]);
 }
 
+/* Solver capacity class of env e: constraint blocks = joints within MSK_LIMIT_DISTANCE of a limit + contact points
+ * (the same count solve_env makes), against the per-template class capacities. */
+MSK_DEV int solver_class(const DModel* __restrict__ m, const DState& st, const int e) {
+  const float* E = EREC(st, m, e);
+  int nblk = 0;
+  for (int d = 0; d < m->nd; ++d) {
+    const float lo = m->dof_lo[d], hi = m->dof_hi[d], q = E[m->lay.q + d];
+    if (!(lo < -1e30f && hi > 1e30f) && (q - lo < MSK_LIMIT_DISTANCE || hi - q < MSK_LIMIT_DISTANCE)) nblk++;
+  }
+  const int* cnts = st.ct_cnt + (size_t)e * m->npp;
+  int base = 0;
+  for (int p = 0; p < m->np; ++p) base += cnts[p];
+  nblk += base < MSK_MAX_CONTACTS ? base : MSK_MAX_CONTACTS;
+  return nblk <= m->cls_cap[0] ? 0 : (nblk <= m->cls_cap[1] ? 1 : (nblk <= m->cls_cap[2] ? 2 : 3));
+}
+
+/* lanes 0 .. n-1 of the calling wave append envs e0 .. e0+n-1 to their class lists (one atomic per class) */
+MSK_DEV void classify_envs(const DModel* __restrict__ m, const DState& st, const int e0, const int n) {
+  const int lane = threadIdx.x & 63;
+  const bool mine = lane < n && e0 + lane < m->N;
+  const int cls = mine ? solver_class(m, st, e0 + lane) : -1;
+#pragma unroll
+  for (int c = 0; c < MSK_SOLVE_CLASSES; ++c) {
+    const unsigned long long mask = __ballot(cls == c);
+    if (mask == 0ull) continue;
+    int base = 0;
+    if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&st.cls_count[c], __popcll(mask));
+    base = __builtin_amdgcn_readlane(base, __ffsll((long long)mask) - 1);
+    if (cls == c) st.cls_list[(size_t)c * m->N + base + __popcll(mask & ((1ull << lane) - 1ull))] = e0 + lane;
+  }
+}
+
+/* scenes without collision pairs: the narrowphase is not launched, the lists are built here */
+__global__ void __launch_bounds__(64) k_classify(const DModel* __restrict__ m, DState st) {
+  classify_envs(m, st, blockIdx.x * 64, 64);
+}
+
 #define NP_GROUP_MAX 16
 /* `group` = envs whose lists one wave walks: 16 at 4096 envs (dense waves: the launch is bound by issue slots and
  * memory waits), fewer when there are few envs (then the launch is bound by its slowest wave) */
@@ -197,6 +234,16 @@ __global__ void __launch_bounds__(64) k_narrowphase(const DModel* __restrict__ m
     rec[16 + k] = out[k].sep - m->cfg.rest_offset * 2.0f;
     for (int a = 0; a < 3; ++a) rec[20 + k * 3 + a] = lam[a];
   }
+  }
+  /* the block (of the NP_TYPES working on this env group) that finishes last sorts the group's envs into the solver lists */
+  __threadfence();
+  int done = 0;
+  if (lane == 0) done = atomicAdd(&st.np_done[blockIdx.x], 1);
+  done = __builtin_amdgcn_readfirstlane(done);
+  if (done == NP_TYPES - 1) {
+    __threadfence();
+    if (lane == 0) st.np_done[blockIdx.x] = 0;
+    classify_envs(m, st, e0, group);
   }
 }
 

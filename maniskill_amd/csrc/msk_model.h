@@ -41,6 +41,9 @@ struct DTendon { int dof_a, dof_b; float ca, cb, rest, K, D; };
 struct DPair { int sa, sb; };
 struct DPairInfo { int ba, bb; float mu; int pad; }; /* bodies of the two shapes, friction of the pair */
 
+#define MSK_SOLVE_CLASSES 4
+#define MSK_LIMIT_DISTANCE 0.1f   /* a joint closer than this to a limit gets a limit block (solver and classifier) */
+
 struct DModel {
   msk_config cfg;
   int nb, na, nd, nv, ns, np, nt, N;
@@ -65,6 +68,7 @@ struct DModel {
   unsigned body_coords[MSK_MAX_BODIES]; /* bit k: coordinate k moves body b (transpose of coord_moves) */
   float dof_lo[MSK_MAX_DOF], dof_hi[MSK_MAX_DOF];
   DPairInfo pinfo[MSK_MAX_PAIRS];
+  int cls_cap[MSK_SOLVE_CLASSES - 1];  /* largest block count of solver classes 0, 1, 2 (the last class takes the rest) */
 };
 
 #define MSK_MAX_ROWS (2 * MSK_MAX_DOF + 3 * MSK_MAX_CONTACTS)
@@ -83,15 +87,11 @@ struct DState {
   /* contacts, env-major, one slot of <= 4 points per candidate pair (persistent: warm starting) */
   int *ct_cnt;                                 /* [N][npp] */
   float *ct_rec;                               /* [N][npp][MSK_CT_REC] */
-  /* envs with more constraint blocks than the small solver launch holds (msk_solve.h) */
-  int *big_list;                               /* [N] */
-  int *big_count;                              /* [1]; zeroed by k_dynamics of the same substep */
-  /* envs expected to need the big launch in substep `tick` (they did in substep tick - 1): solved on a second stream
-   * while the small launch runs; purely a scheduling hint, both launches compute the same bits for an env */
-  int *pred_list;                              /* [2][N]: list of substep t at (t & 1) * N */
-  int *pred_count;                             /* [2]; entry (t + 1) & 1 zeroed by k_dynamics of substep t */
-  int *pred_tick;                              /* [N]: substep for which the env is on the predicted list */
-  int tick;                                    /* current substep (by value, set per launch) */
+  /* solver work lists by LDS capacity class (msk_solve.h): class 0 = packed small launch, 1..3 = one wave per env with
+   * room for cls_cap[] blocks; built by the narrowphase block that finishes an env group last (classify_envs) */
+  int *cls_list;                               /* [MSK_SOLVE_CLASSES][N] */
+  int *cls_count;                              /* [MSK_SOLVE_CLASSES]; zeroed by k_dynamics of the same substep */
+  int *np_done;                                /* [N]: narrowphase blocks of an env group that have finished (self-resetting) */
   /* narrowphase work lists per env and type (plane / box-box / GJK): surviving pair indices in pair order */
   int *np_count;                               /* [N][4] */
   int *np_items;                               /* [N][3][np] */

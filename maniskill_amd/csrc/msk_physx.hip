@@ -48,9 +48,7 @@ struct msk_ctx {
   pose init_pose[MSK_MAX_BODIES];
   pose pending_root;
   int nverts_total;
-  size_t lds_small, lds_big; /* dynamic LDS of the two solver launches */
-  hipStream_t side = nullptr; /* predicted big solver launch, beside the small one */
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  size_t lds_cls[MSK_SOLVE_CLASSES]; /* dynamic LDS of the solver launches, per capacity class */
   RModel* rmodel;            /* host copy of the render geometry (include/msk_render.h) */
   RModel* d_rmodel;
   bool render_finalized;
@@ -141,9 +139,6 @@ MSK_API void msk_destroy(msk_ctx* c) {
   hipDeviceSynchronize();
   for (void* p : c->allocs) hipFree(p);
   for (hipEvent_t e : c->tev) hipEventDestroy(e);
-  if (c->ev_fork) hipEventDestroy(c->ev_fork);
-  if (c->ev_join) hipEventDestroy(c->ev_join);
-  if (c->side) hipStreamDestroy(c->side);
   delete c->rmodel;
   delete c;
 }
@@ -425,6 +420,9 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
     L.stride = o;
   }
   const size_t N = (size_t)num_envs;
+  m.cls_cap[0] = (m.G == 16) ? CsLds<16, 16, 16>::fit() : CsLds<32, 32, 32>::fit();   /* solver capacity classes (msk_solve.h) */
+  m.cls_cap[1] = MSK_CLASS1_BLOCKS;
+  m.cls_cap[2] = MSK_CLASS2_BLOCKS;
   ALLOC(c->d_model, 1);
   HIP_TRY(hipMemcpy(c->d_model, &m, sizeof(DModel), hipMemcpyHostToDevice));
   DState& st = c->st;
@@ -432,28 +430,21 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   const size_t G = (size_t)m.G;
   ALLOC(st.Scol, N * G * 8); ALLOC(st.W, N * G * G); ALLOC(st.vfree, N * G);
   ALLOC(st.ct_cnt, N * m.npp); ALLOC(st.ct_rec, N * m.npp * MSK_CT_REC);
-  ALLOC(st.big_list, N); ALLOC(st.big_count, 1);
-  ALLOC(st.pred_list, 2 * N); ALLOC(st.pred_count, 2); ALLOC(st.pred_tick, N);
-  st.tick = 1;
-  HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  ALLOC(st.cls_list, MSK_SOLVE_CLASSES * N); ALLOC(st.cls_count, MSK_SOLVE_CLASSES); ALLOC(st.np_done, N);
   ALLOC(st.dbg, N * 8 + 64);
-  /* the big solver launch needs more than the default 64 KB of dynamic LDS */
+  /* solver launches (msk_solve.h): classes 0..2 share one, the last class owns a CU's LDS (more than the default 64 KB) */
   if (m.G == 16) {
-    auto kb = k_csolve_big<16, false>;
-    auto kp = k_csolve_big<16, true>;
-    c->lds_small = CsLds<16, 16>::TOTAL * sizeof(float);
-    c->lds_big = CsLds<16, 64>::TOTAL * sizeof(float);
-    HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_big));
-    HIP_TRY(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_big));
+    auto k3 = k_csolve_wave<16, CsBig<16>::CAP>;
+    c->lds_cls[0] = CsLds<16, 16, 16>::TOTAL * sizeof(float);
+    c->lds_cls[3] = CsLds<16, 64, CsBig<16>::CAP>::TOTAL * sizeof(float);
+    HIP_TRY(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_cls[3]));
   } else {
-    auto kb = k_csolve_big<32, false>;
-    auto kp = k_csolve_big<32, true>;
-    c->lds_small = CsLds<32, 32>::TOTAL * sizeof(float);
-    c->lds_big = CsLds<32, 64>::TOTAL * sizeof(float);
-    HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_big));
-    HIP_TRY(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_big));
+    auto k0 = k_csolve_main<32, 32>;
+    auto k3 = k_csolve_wave<32, CsBig<32>::CAP>;
+    c->lds_cls[0] = CsLds<32, 32, 32>::TOTAL * sizeof(float);
+    c->lds_cls[3] = CsLds<32, 64, CsBig<32>::CAP>::TOTAL * sizeof(float);
+    HIP_TRY(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_cls[0]));
+    HIP_TRY(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_cls[3]));
   }
   ALLOC(st.env_ncontacts, N); ALLOC(st.env_overflow, 1);
   ALLOC(st.np_count, N * 4); ALLOC(st.np_items, N * NP_TYPES * (size_t)(m.np > 0 ? m.np : 1));
@@ -545,32 +536,24 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
     int group = N / 256;   /* ~768 waves whatever the env count */
     group = group < 1 ? 1 : (group > NP_GROUP_MAX ? NP_GROUP_MAX : group);
     hipLaunchKernelGGL(k_narrowphase, dim3((N + group - 1) / group, NP_TYPES), dim3(64), 0, s, c->d_model, c->st, group);
+  } else {
+    hipLaunchKernelGGL(k_classify, dim3(nblk), dim3(64), 0, s, c->d_model, c->st);
   }
   if (timed) hipEventRecord(ev[2], s);
   {
-    /* envs that needed the big launch last substep go straight to it on the side stream; every other env in the small
-     * launch, and the few of those that do not fit queue themselves for a second big launch behind it */
-    const int nbig = N < 512 ? N : 512;
-    HIP_TRY(hipEventRecord(c->ev_fork, s));
-    HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    /* classes 0..2 in one launch; then the envs with more blocks than that (usually none: an empty launch) */
+    const int gm = N < 768 ? N : 768, g3 = N < 256 ? N : 256;
     if (c->model.G == 16) {
-      auto ks = k_csolve<16, 16>;
-      auto kb = k_csolve_big<16, false>;
-      auto kp = k_csolve_big<16, true>;
-      hipLaunchKernelGGL(kp, dim3(nbig), dim3(64), c->lds_big, c->side, c->d_model, c->st);
-      hipLaunchKernelGGL(ks, dim3((N + 3) / 4), dim3(64), c->lds_small, s, c->d_model, c->st);
-      hipLaunchKernelGGL(kb, dim3(nbig), dim3(64), c->lds_big, s, c->d_model, c->st);
+      auto k0 = k_csolve_main<16, 16>;
+      auto k3 = k_csolve_wave<16, CsBig<16>::CAP>;
+      hipLaunchKernelGGL(k0, dim3(gm + (N + 3) / 4), dim3(64), c->lds_cls[0], s, c->d_model, c->st, gm);
+      hipLaunchKernelGGL(k3, dim3(g3), dim3(64), c->lds_cls[3], s, c->d_model, c->st, 3);
     } else {
-      auto ks = k_csolve<32, 32>;
-      auto kb = k_csolve_big<32, false>;
-      auto kp = k_csolve_big<32, true>;
-      hipLaunchKernelGGL(kp, dim3(nbig), dim3(64), c->lds_big, c->side, c->d_model, c->st);
-      hipLaunchKernelGGL(ks, dim3((N + 1) / 2), dim3(64), c->lds_small, s, c->d_model, c->st);
-      hipLaunchKernelGGL(kb, dim3(nbig), dim3(64), c->lds_big, s, c->d_model, c->st);
+      auto k0 = k_csolve_main<32, 32>;
+      auto k3 = k_csolve_wave<32, CsBig<32>::CAP>;
+      hipLaunchKernelGGL(k0, dim3(gm + (N + 1) / 2), dim3(64), c->lds_cls[0], s, c->d_model, c->st, gm);
+      hipLaunchKernelGGL(k3, dim3(g3), dim3(64), c->lds_cls[3], s, c->d_model, c->st, 3);
     }
-    HIP_TRY(hipEventRecord(c->ev_join, c->side));
-    HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
-    c->st.tick++;
     c->kin_dirty = true;
   }
   if (timed) { hipEventRecord(ev[3], s); c->t_n++; }

@@ -35,7 +35,6 @@
 
 #define MSK_PEN_BETA 0.8f
 #define MSK_MAX_DEPEN_VEL 3.0f
-#define MSK_LIMIT_DISTANCE 0.1f
 #define MSK_SMALL_BLOCKS 16
 
 MSK_DEV void wave_sync() {
@@ -63,8 +62,10 @@ MSK_DEV float group_bcast(float x, int blk) {
   }
 }
 
+#define MSK_CLASS1_BLOCKS 20   /* capacity classes of the one-env-per-wave images (class 3: CsBig) */
+#define MSK_CLASS2_BLOCKS 32
 /* LDS image of one workgroup: 64/GL envs, each with a fixed part, plus one pool for Y and A */
-template <int NVP, int GL>
+template <int NVP, int GL, int CAP>
 struct CsLds {
   static constexpr int EPW = 64 / GL;               /* envs per wavefront                              */
   static constexpr int COLS = 3 * GL;
@@ -78,11 +79,23 @@ struct CsLds {
   static constexpr int DESC = LAMS + COLS;          /* int [NDESC] pair*4 + point                   */
   static constexpr int FIX = ((DESC + NDESC + 3) / 4) * 4;
   /* pool (floats): per env  Y [3 nblk][NVP]  then  A [3 nblk][3][nblk]  (A[(lane, s')][col]) */
-  /* the big launch (GL = 64) owns the CU's whole LDS: as many blocks as fit in 160 KB */
-  static constexpr int MAXBLK = (GL < 64) ? GL : ((NVP <= 16) ? 64 : 60);
-  static constexpr int POOL = (GL == 64) ? (MAXBLK * 3 * NVP + 9 * MAXBLK * MAXBLK) : 5888;
+  /* one env per wave (GL = 64): room for CAP blocks; packed launch: a shared pool, carved after counting */
+  static constexpr int MAXBLK = (GL < 64) ? GL : CAP;
+  static constexpr int need(int nb) { return nb * 3 * NVP + 9 * nb * nb; }
+  /* the packed class shares its launch with the MSK_CLASS2_BLOCKS image (k_csolve_main): same LDS bytes per workgroup */
+  static constexpr int FIX64 = ((NVP * NVP + NVP * 8 + NVP + 2 * NVP + 6 * 64 + MSK_MAX_CONTACTS + 3) / 4) * 4;
+  static constexpr int POOL = (GL == 64) ? need(MAXBLK) : (FIX64 + MSK_CLASS2_BLOCKS * 3 * NVP + 9 * MSK_CLASS2_BLOCKS * MSK_CLASS2_BLOCKS - EPW * FIX);
   static constexpr int TOTAL = EPW * FIX + POOL;
+  /* packed launch: the block count up to which EPW envs always fit the pool together */
+  static constexpr int fit() {
+    int nb = 0;
+    while (nb + 1 <= GL && EPW * need(nb + 1) <= POOL) ++nb;
+    return nb;
+  }
 };
+/* the last class owns the CU's whole LDS: as many blocks as fit in 160 KB */
+template <int NVP> struct CsBig { static constexpr int CAP = (NVP <= 16) ? 64 : 60; };
+
 
 /* Sweep-invariant part of a row update: bias / A_rr, with the bias of a limit / normal row (penetration
  * recovery or approach speed from c0 + J.dq) or of a friction row (drift J.dq).  b = J.dq only changes
@@ -100,18 +113,16 @@ MSK_DEV float bias_over_arr(float b, float c0, float rinv, float inv_h, float in
   return bias * rinv;
 }
 
-#define MSK_PRED_BLOCKS 8   /* an env solved by a big launch stays predicted while it has more constraint blocks than this */
-/* GL lanes per env (16: four envs per wave, 64: one); e_first = env of group 0; DEFER: envs that do not fit
- * queue themselves for the big launch */
-template <int NVP, int GL, bool DEFER>
-MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int e_first, float* lds_all) {
-  typedef CsLds<NVP, GL> LY;
-  constexpr int CAP = GL;
+/* GL lanes per env (16: four envs per wave, 64: one); the envs are entries first .. first + 64/GL - 1 of `list` */
+template <int NVP, int GL, int CAP>
+MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int* __restrict__ list, const int first, const int count,
+                       float* lds_all) {
+  typedef CsLds<NVP, GL, CAP> LY;
   const int g = threadIdx.x / GL, lane = threadIdx.x % GL;   /* `lane` = my block / coordinate inside the env */
   const int gshift = g * GL;
   const unsigned long long gmask = (GL == 64) ? ~0ull : ((1ull << GL) - 1ull);
-  const bool in_range = e_first + g < m->N;
-  const int e = in_range ? e_first + g : m->N - 1;
+  const bool in_range = first + g < count;
+  const int e = list[in_range ? first + g : first];
   float* lds = lds_all + g * LY::FIX;
   float* pool = lds_all + LY::EPW * LY::FIX;
 #define GBALLOT(pred) ((__ballot(pred) >> gshift) & gmask)
@@ -160,7 +171,7 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
       tot += __popcll(mk);
     }
     const int first = base + pre;
-    if (!DEFER && first + cnt > MSK_MAX_CONTACTS) { /* capacity exhausted: later points are dropped, the slot is trimmed */
+    if (first + cnt > MSK_MAX_CONTACTS) { /* capacity exhausted: later points are dropped, the slot is trimmed */
       const int keep = max(0, MSK_MAX_CONTACTS - first);
       if (cnt > 0) cnts[p] = keep;
       cnt = keep;
@@ -171,36 +182,27 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   }
   bool overflow = base > MSK_MAX_CONTACTS;
   int ncont = overflow ? MSK_MAX_CONTACTS : base;
-  if (!DEFER && nlim + ncont > LY::MAXBLK) { /* LDS image of the big launch exhausted (NVP = 32 only): trailing points ignored */
+  if (GL == 64 && nlim + ncont > LY::MAXBLK) { /* LDS image of the last class exhausted (NVP = 32 only): trailing points ignored */
     ncont = LY::MAXBLK - nlim;
     overflow = true;
   }
   int nblk = nlim + ncont;
-  /* carve the pool: groups in order; a group that does not fit (or is out of range) sits this launch out */
-  /* DEFER launch: envs on this substep's predicted list are being solved by the concurrent big launch (which may
-   * already have stamped them for the next substep, hence >=) */
-  const bool mine = in_range && !(DEFER && st.pred_tick[e] >= st.tick);
-  if (!mine) nblk = 0;
-  bool active = mine;
+  /* carve the pool: groups in order (class 0 admits only block counts that fit together: CsLds::fit) */
+  if (!in_range) nblk = 0;
+  bool active = in_range;
   int pbase = 0;
   {
     int off = 0;
 #pragma unroll
     for (int j = 0; j < LY::EPW; ++j) {
       const int nbj = __builtin_amdgcn_readlane(nblk, j * GL);
-      const int need = nbj * 3 * NVP + 9 * nbj * nbj;
-      const bool fits = nbj <= CAP && off + need <= LY::POOL;
+      const int need = LY::need(nbj);
+      const bool fits = nbj <= LY::MAXBLK && off + need <= LY::POOL;
       if (j == g) { pbase = off; if (!fits) active = false; }
       if (fits) off += need;
     }
   }
-  if (DEFER && mine && !active && lane == 0) st.big_list[atomicAdd(st.big_count, 1)] = e;
-  /* next substep: straight to the big launch (an env the small launch deferred has stamped itself already) */
-  if (in_range && lane == 0 && (DEFER ? (mine && !active) : (nblk > MSK_PRED_BLOCKS && st.pred_tick[e] <= st.tick))) {
-    const int t1 = st.tick + 1;
-    st.pred_tick[e] = t1;
-    st.pred_list[(size_t)(t1 & 1) * m->N + atomicAdd(&st.pred_count[t1 & 1], 1)] = e;
-  }
+  if (in_range && !active && lane == 0) atomicOr(st.env_overflow, 2); /* misclassified env: never expected */
   if (!active) nblk = 0;
   if (GL == 64) nblk = __builtin_amdgcn_readfirstlane(nblk); /* one env per wave: let the loops below run on scalar counters */
   if (active && lane == 0) {
@@ -517,22 +519,35 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
 #undef GBALLOT
 }
 
-/* every env, 64/GL per wavefront; envs that do not fit the LDS pool defer to k_csolve_big */
+/* Classes 0..2 in ONE launch (no cross-stream joins): workgroups 0 .. gm-1 walk the one-env-per-wave list, class 2
+ * before class 1 (longest solves first: they are dispatched first and bound the launch), the rest take 64/GL
+ * consecutive class-0 envs each.  Both kinds use the same LDS bytes. */
 template <int NVP, int GL>
-__global__ void __launch_bounds__(64) k_csolve(const DModel* __restrict__ m, DState st) {
+__global__ void __launch_bounds__(64) k_csolve_main(const DModel* __restrict__ m, DState st, const int gm) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  solve_env<NVP, GL, true>(m, st, blockIdx.x * (64 / GL), lds);
+  static_assert(CsLds<NVP, GL, GL>::TOTAL == CsLds<NVP, 64, MSK_CLASS2_BLOCKS>::TOTAL, "one LDS size for both kinds of workgroup");
+  if ((int)blockIdx.x < gm) {
+    const int n2 = st.cls_count[2], n1 = st.cls_count[1];
+    for (int i = blockIdx.x; i < n2 + n1; i += gm) {
+      if (i < n2) solve_env<NVP, 64, MSK_CLASS2_BLOCKS>(m, st, st.cls_list + (size_t)2 * m->N, i, n2, lds);
+      else solve_env<NVP, 64, MSK_CLASS2_BLOCKS>(m, st, st.cls_list + (size_t)1 * m->N, i - n2, n1, lds);
+      wave_sync();
+    }
+  } else {
+    const int count = st.cls_count[0], first = ((int)blockIdx.x - gm) * (64 / GL);
+    if (first >= count) return;
+    solve_env<NVP, GL, GL>(m, st, st.cls_list, first, count, lds);
+  }
 }
 
-/* PRED: the list predicted in the previous substep (runs beside k_csolve on a second stream); otherwise the
- * envs k_csolve deferred in this substep */
-template <int NVP, bool PRED>
-__global__ void __launch_bounds__(64) k_csolve_big(const DModel* __restrict__ m, DState st) {
+/* class 3 (more than MSK_CLASS2_BLOCKS blocks: rare): one wavefront per env, the CU's whole LDS */
+template <int NVP, int CAP>
+__global__ void __launch_bounds__(64) k_csolve_wave(const DModel* __restrict__ m, DState st, const int cls) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int count = PRED ? st.pred_count[st.tick & 1] : *st.big_count;
-  const int* list = PRED ? st.pred_list + (size_t)(st.tick & 1) * m->N : st.big_list;
+  const int count = st.cls_count[cls];
+  const int* list = st.cls_list + (size_t)cls * m->N;
   for (int i = blockIdx.x; i < count; i += gridDim.x) {
-    solve_env<NVP, 64, false>(m, st, list[i], lds);
+    solve_env<NVP, 64, CAP>(m, st, list, i, count, lds);
     wave_sync();
   }
 }
