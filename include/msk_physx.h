@@ -181,6 +181,15 @@ int msk_get_contacts(msk_ctx* ctx, int env, int32_t* ids, float* vals, int max_p
 /* Number of contact points each env solved in the last step(): out[num_envs]. */
 int msk_get_env_contact_counts(msk_ctx* ctx, int32_t* out);
 
+/* Solver scheduling (no counterpart in the reference; results do not depend on it).  Envs are sorted by their number
+ * of constraint blocks (joints near a limit + contact points) into four capacity classes: class 0 is solved four
+ * (two for > 16 coordinates) envs to a wavefront, classes 1..3 one env per wavefront.  caps[k] = largest block count
+ * of class k (k = 0..2; class 3 takes the rest, up to 64); caps[0] may not exceed what the packed LDS pool holds and
+ * caps[2] may not exceed 32 (both are clamped).  A negative caps[0..2] empties that class: {-1,-1,-1} sends every env
+ * through class 3.  msk_get_solver_class_counts returns the four list lengths of the last step(). */
+int msk_set_solver_classes(msk_ctx* ctx, const int32_t caps[3]);
+int msk_get_solver_class_counts(msk_ctx* ctx, int32_t out[4]);
+
 /* ---- measurement (bench.py: roofline.achieved) --------------------------------------- */
 /* Per-kernel HIP-event timing of msk_step(), on the stream the kernels are launched on.
  * The reference's harness only has wall-clock (examples/benchmarking/profiling.py:96-113);

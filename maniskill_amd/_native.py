@@ -28,6 +28,7 @@ EXPORTS = [
     "add_actor", "add_shape", "disable_collision", "finalize", "set_scene_offsets", "buffer", "apply",
     "fetch", "update_kinematics", "step", "query_create_pairs", "query_buffer", "query_run",
     "get_sizes", "get_contacts", "get_env_contact_counts", "timing_enable", "timing_read",
+    "set_solver_classes", "get_solver_class_counts",
 ]
 # include/msk_render.h — camera pipeline (both libraries)
 RENDER_EXPORTS = ["render_add_mesh", "render_finalize", "camera_create", "camera_buffer", "camera_obs_buffer", "camera_take_picture"]
@@ -108,6 +109,8 @@ class NativeLib:
             "get_sizes": (i32, [vp, C.POINTER(C.c_int32)]),
             "get_contacts": (i32, [vp, i32, C.POINTER(C.c_int32), fp, i32]),
             "get_env_contact_counts": (i32, [vp, C.POINTER(C.c_int32)]),
+            "set_solver_classes": (i32, [vp, C.POINTER(C.c_int32)]),
+            "get_solver_class_counts": (i32, [vp, C.POINTER(C.c_int32)]),
             "timing_enable": (i32, [vp, i32]),
             "timing_read": (i32, [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
         }

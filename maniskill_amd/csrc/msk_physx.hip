@@ -48,7 +48,8 @@ struct msk_ctx {
   pose init_pose[MSK_MAX_BODIES];
   pose pending_root;
   int nverts_total;
-  size_t lds_cls[MSK_SOLVE_CLASSES]; /* dynamic LDS of the solver launches, per capacity class */
+  size_t lds_solve = 0;  /* dynamic LDS of the solver launch */
+  int solve_workers = 0; /* its one-env-per-wave workgroups */
   RModel* rmodel;            /* host copy of the render geometry (include/msk_render.h) */
   RModel* d_rmodel;
   bool render_finalized;
@@ -432,19 +433,17 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   ALLOC(st.ct_cnt, N * m.npp); ALLOC(st.ct_rec, N * m.npp * MSK_CT_REC);
   ALLOC(st.cls_list, MSK_SOLVE_CLASSES * N); ALLOC(st.cls_count, MSK_SOLVE_CLASSES); ALLOC(st.np_done, N);
   ALLOC(st.dbg, N * 8 + 64);
-  /* solver launches (msk_solve.h): classes 0..2 share one, the last class owns a CU's LDS (more than the default 64 KB) */
+  /* the solver launch (msk_solve.h): one LDS size for every kind of workgroup; one-env-per-wave workers */
+  c->solve_workers = num_envs < 768 ? num_envs : 768;
+  ALLOC(st.a_scratch, (size_t)c->solve_workers * 9 * MSK_CLASS3_BLOCKS * MSK_CLASS3_BLOCKS);
   if (m.G == 16) {
-    auto k3 = k_csolve_wave<16, CsBig<16>::CAP>;
-    c->lds_cls[0] = CsLds<16, 16, 16>::TOTAL * sizeof(float);
-    c->lds_cls[3] = CsLds<16, 64, CsBig<16>::CAP>::TOTAL * sizeof(float);
-    HIP_TRY(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_cls[3]));
+    auto k0 = k_csolve<16, 16>;
+    c->lds_solve = CsLds<16, 16, 16>::TOTAL * sizeof(float);
+    HIP_TRY(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_solve));
   } else {
-    auto k0 = k_csolve_main<32, 32>;
-    auto k3 = k_csolve_wave<32, CsBig<32>::CAP>;
-    c->lds_cls[0] = CsLds<32, 32, 32>::TOTAL * sizeof(float);
-    c->lds_cls[3] = CsLds<32, 64, CsBig<32>::CAP>::TOTAL * sizeof(float);
-    HIP_TRY(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_cls[0]));
-    HIP_TRY(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_cls[3]));
+    auto k0 = k_csolve<32, 32>;
+    c->lds_solve = CsLds<32, 32, 32>::TOTAL * sizeof(float);
+    HIP_TRY(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_solve));
   }
   ALLOC(st.env_ncontacts, N); ALLOC(st.env_overflow, 1);
   ALLOC(st.np_count, N * 4); ALLOC(st.np_items, N * NP_TYPES * (size_t)(m.np > 0 ? m.np : 1));
@@ -541,18 +540,13 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
   }
   if (timed) hipEventRecord(ev[2], s);
   {
-    /* classes 0..2 in one launch; then the envs with more blocks than that (usually none: an empty launch) */
-    const int gm = N < 768 ? N : 768, g3 = N < 256 ? N : 256;
+    const int gm = c->solve_workers;
     if (c->model.G == 16) {
-      auto k0 = k_csolve_main<16, 16>;
-      auto k3 = k_csolve_wave<16, CsBig<16>::CAP>;
-      hipLaunchKernelGGL(k0, dim3(gm + (N + 3) / 4), dim3(64), c->lds_cls[0], s, c->d_model, c->st, gm);
-      hipLaunchKernelGGL(k3, dim3(g3), dim3(64), c->lds_cls[3], s, c->d_model, c->st, 3);
+      auto k0 = k_csolve<16, 16>;
+      hipLaunchKernelGGL(k0, dim3(gm + (N + 3) / 4), dim3(64), c->lds_solve, s, c->d_model, c->st, gm);
     } else {
-      auto k0 = k_csolve_main<32, 32>;
-      auto k3 = k_csolve_wave<32, CsBig<32>::CAP>;
-      hipLaunchKernelGGL(k0, dim3(gm + (N + 1) / 2), dim3(64), c->lds_cls[0], s, c->d_model, c->st, gm);
-      hipLaunchKernelGGL(k3, dim3(g3), dim3(64), c->lds_cls[3], s, c->d_model, c->st, 3);
+      auto k0 = k_csolve<32, 32>;
+      hipLaunchKernelGGL(k0, dim3(gm + (N + 1) / 2), dim3(64), c->lds_solve, s, c->d_model, c->st, gm);
     }
     c->kin_dirty = true;
   }
@@ -786,6 +780,27 @@ MSK_API int msk_debug_phases(msk_ctx* c, long long* out) {
   return MSK_OK;
 }
 #endif
+
+MSK_API int msk_set_solver_classes(msk_ctx* c, const int32_t caps[3]) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "set_solver_classes before finalize");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());
+  DModel& m = c->model;
+  const int fit = (m.G == 16) ? CsLds<16, 16, 16>::fit() : CsLds<32, 32, 32>::fit();
+  m.cls_cap[0] = caps[0] < fit ? caps[0] : fit;
+  m.cls_cap[1] = caps[1] < MSK_CLASS2_BLOCKS ? caps[1] : MSK_CLASS2_BLOCKS;
+  m.cls_cap[2] = caps[2] < MSK_CLASS2_BLOCKS ? caps[2] : MSK_CLASS2_BLOCKS;
+  HIP_TRY(hipMemcpy(c->d_model, &m, sizeof(DModel), hipMemcpyHostToDevice));
+  return MSK_OK;
+}
+
+MSK_API int msk_get_solver_class_counts(msk_ctx* c, int32_t out[4]) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "get_solver_class_counts before finalize");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, c->st.cls_count, sizeof(int) * MSK_SOLVE_CLASSES, hipMemcpyDeviceToHost));
+  return MSK_OK;
+}
 
 MSK_API int msk_get_env_contact_counts(msk_ctx* c, int32_t* out) {
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "get_env_contact_counts before finalize");

@@ -62,8 +62,9 @@ MSK_DEV float group_bcast(float x, int blk) {
   }
 }
 
-#define MSK_CLASS1_BLOCKS 20   /* capacity classes of the one-env-per-wave images (class 3: CsBig) */
+#define MSK_CLASS1_BLOCKS 20   /* capacity classes of the one-env-per-wave images */
 #define MSK_CLASS2_BLOCKS 32
+#define MSK_CLASS3_BLOCKS 64   /* one lane per block: MSK_MAX_DOF limit blocks + MSK_MAX_CONTACTS contact points */
 /* LDS image of one workgroup: 64/GL envs, each with a fixed part, plus one pool for Y and A */
 template <int NVP, int GL, int CAP>
 struct CsLds {
@@ -93,8 +94,6 @@ struct CsLds {
     return nb;
   }
 };
-/* the last class owns the CU's whole LDS: as many blocks as fit in 160 KB */
-template <int NVP> struct CsBig { static constexpr int CAP = (NVP <= 16) ? 64 : 60; };
 
 
 /* Sweep-invariant part of a row update: bias / A_rr, with the bias of a limit / normal row (penetration
@@ -113,8 +112,10 @@ MSK_DEV float bias_over_arr(float b, float c0, float rinv, float inv_h, float in
   return bias * rinv;
 }
 
-/* GL lanes per env (16: four envs per wave, 64: one); the envs are entries first .. first + 64/GL - 1 of `list` */
-template <int NVP, int GL, int CAP>
+/* GL lanes per env (16: four envs per wave, 64: one); the envs are entries first .. first + 64/GL - 1 of `list`.
+ * AGLOB (class 3, one env per wave): the A image lives in this workgroup's slice of st.a_scratch instead of LDS; every
+ * lane reads back only what it wrote itself, and the sweeps prefetch four blocks ahead to cover the L2 round trip. */
+template <int NVP, int GL, int CAP, bool AGLOB>
 MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int* __restrict__ list, const int first, const int count,
                        float* lds_all) {
   typedef CsLds<NVP, GL, CAP> LY;
@@ -196,7 +197,7 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
 #pragma unroll
     for (int j = 0; j < LY::EPW; ++j) {
       const int nbj = __builtin_amdgcn_readlane(nblk, j * GL);
-      const int need = LY::need(nbj);
+      const int need = AGLOB ? nbj * 3 * NVP : LY::need(nbj);
       const bool fits = nbj <= LY::MAXBLK && off + need <= LY::POOL;
       if (j == g) { pbase = off; if (!fits) active = false; }
       if (fits) off += need;
@@ -213,7 +214,9 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
                                            max(__builtin_amdgcn_readlane(nblk, 32 % 64), __builtin_amdgcn_readlane(nblk, 48 % 64)));
   if (nbmax == 0 && __ballot(active) == 0ull) return;
   float* Ly = pool + pbase;
-  float* La = Ly + nblk * 3 * NVP;
+  float* La;
+  if constexpr (AGLOB) La = st.a_scratch + (size_t)blockIdx.x * (9 * CAP * CAP);
+  else La = Ly + nblk * 3 * NVP;
   const int nb = nblk > 0 ? nblk : 1; /* row stride of my A image */
 
   PHASE();
@@ -398,10 +401,8 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
     const float t1n = bias_over_arr<POSIT, false>(bv[1], c0[1], rinv[1], inv_h, inv_dt, beta_dt);
     const float t1 = is_contact ? t1f : t1n;
     const float t2 = bias_over_arr<POSIT, true>(bv[2], c0[2], rinv[2], inv_h, inv_dt, beta_dt);
-    float Ac[9], An[9];
-    load_cols(0, Ac);
-    auto block_steps = [&](const int blk, auto all_rows_tag) {
-      load_cols((blk + 1 < nbmax) ? blk + 1 : 0, An);
+    /* one block step; Ac = my rows' nine entries of the three columns of block blk (already in registers) */
+    auto block_steps = [&](const int blk, const float* Ac, auto all_rows_tag) {
       const bool owner = lane == blk;
       const unsigned rowbits = decltype(all_rows_tag)::value ? 7u
                                : (GL == 64) ? (unsigned)(((vm0 >> blk) & 1ull) | (((vm1 >> blk) & 1ull) << 1) | (((vm2 >> blk) & 1ull) << 2))
@@ -427,20 +428,44 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
         if (owner) lam[2] = nl;
         av[0] = fmaf(Ac[6], dl, av[0]); av[1] = fmaf(Ac[7], dl, av[1]); av[2] = fmaf(Ac[8], dl, av[2]);
       }
-#pragma unroll
-      for (int i = 0; i < 9; ++i) Ac[i] = An[i];
     };
-    if (GL == 16) { /* unrolled: the block index becomes the immediate of row_newbcast */
+    if (GL == 16) { /* unrolled: the block index becomes the immediate of row_newbcast, the copies are renames */
+      float Ac[9], An[9];
+      load_cols(0, Ac);
 #pragma unroll
       for (int blk = 0; blk < 16; ++blk) {
         if (blk >= nbmax) break;
-        block_steps(blk, std::false_type{});
+        load_cols((blk + 1 < nbmax) ? blk + 1 : 0, An);
+        block_steps(blk, Ac, std::false_type{});
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Ac[i] = An[i];
       }
     } else { /* one env: limit blocks first (rows 0 / 1 as present), then contact blocks, whose three rows all exist */
       const int nl0 = __builtin_amdgcn_readfirstlane(nlim < nbmax ? nlim : nbmax);
-      for (int blk = 0; blk < nl0; ++blk) block_steps(blk, std::false_type{});
-#pragma unroll 2
-      for (int blk = nl0; blk < nbmax; ++blk) block_steps(blk, std::true_type{});
+      {
+        float Ac[9], An[9];
+        load_cols(0, Ac);
+        for (int blk = 0; blk < nl0; ++blk) {
+          load_cols(blk + 1, An);
+          block_steps(blk, Ac, std::false_type{});
+#pragma unroll
+          for (int i = 0; i < 9; ++i) Ac[i] = An[i];
+        }
+      }
+      /* ring of D register sets: at step k the set of block k + D - 1 is requested, the set of block k consumed */
+      constexpr int D = AGLOB ? 4 : 2;
+      float R[D][9];
+#pragma unroll
+      for (int u = 0; u + 1 < D; ++u) load_cols(nl0 + u, R[u]);
+      for (int blk = nl0; blk < nbmax; blk += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+          if (blk + u < nbmax) {
+            load_cols(blk + u + D - 1, R[(u + D - 1) % D]);
+            block_steps(blk + u, R[u], std::true_type{});
+          }
+        }
+      }
     }
     if (POSIT) {
 #pragma unroll
@@ -519,36 +544,28 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
 #undef GBALLOT
 }
 
-/* Classes 0..2 in ONE launch (no cross-stream joins): workgroups 0 .. gm-1 walk the one-env-per-wave list, class 2
- * before class 1 (longest solves first: they are dispatched first and bound the launch), the rest take 64/GL
- * consecutive class-0 envs each.  Both kinds use the same LDS bytes. */
+/* Every class in ONE launch (no cross-stream joins): workgroups 0 .. gm-1 walk the one-env-per-wave classes, 3 before 2
+ * before 1 (longest solves first: they are dispatched first and bound the launch), the rest take 64/GL consecutive
+ * class-0 envs each.  All kinds use the same LDS bytes; class 3 (more than MSK_CLASS2_BLOCKS blocks: rare) keeps its
+ * A image in global memory. */
 template <int NVP, int GL>
-__global__ void __launch_bounds__(64) k_csolve_main(const DModel* __restrict__ m, DState st, const int gm) {
+__global__ void __launch_bounds__(64) k_csolve(const DModel* __restrict__ m, DState st, const int gm) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(CsLds<NVP, GL, GL>::TOTAL == CsLds<NVP, 64, MSK_CLASS2_BLOCKS>::TOTAL, "one LDS size for both kinds of workgroup");
+  static_assert(MSK_CLASS3_BLOCKS * 3 * NVP <= CsLds<NVP, 64, MSK_CLASS2_BLOCKS>::POOL, "Y of the largest env fits the pool");
   if ((int)blockIdx.x < gm) {
-    const int n2 = st.cls_count[2], n1 = st.cls_count[1];
-    for (int i = blockIdx.x; i < n2 + n1; i += gm) {
-      if (i < n2) solve_env<NVP, 64, MSK_CLASS2_BLOCKS>(m, st, st.cls_list + (size_t)2 * m->N, i, n2, lds);
-      else solve_env<NVP, 64, MSK_CLASS2_BLOCKS>(m, st, st.cls_list + (size_t)1 * m->N, i - n2, n1, lds);
+    const int n3 = st.cls_count[3], n2 = st.cls_count[2], n1 = st.cls_count[1];
+    const size_t N = (size_t)m->N;
+    for (int i = blockIdx.x; i < n3 + n2 + n1; i += gm) {
+      if (i < n3) solve_env<NVP, 64, MSK_CLASS3_BLOCKS, true>(m, st, st.cls_list + 3 * N, i, n3, lds);
+      else if (i < n3 + n2) solve_env<NVP, 64, MSK_CLASS2_BLOCKS, false>(m, st, st.cls_list + 2 * N, i - n3, n2, lds);
+      else solve_env<NVP, 64, MSK_CLASS2_BLOCKS, false>(m, st, st.cls_list + N, i - n3 - n2, n1, lds);
       wave_sync();
     }
   } else {
     const int count = st.cls_count[0], first = ((int)blockIdx.x - gm) * (64 / GL);
     if (first >= count) return;
-    solve_env<NVP, GL, GL>(m, st, st.cls_list, first, count, lds);
-  }
-}
-
-/* class 3 (more than MSK_CLASS2_BLOCKS blocks: rare): one wavefront per env, the CU's whole LDS */
-template <int NVP, int CAP>
-__global__ void __launch_bounds__(64) k_csolve_wave(const DModel* __restrict__ m, DState st, const int cls) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int count = st.cls_count[cls];
-  const int* list = st.cls_list + (size_t)cls * m->N;
-  for (int i = blockIdx.x; i < count; i += gridDim.x) {
-    solve_env<NVP, 64, CAP>(m, st, list, i, count, lds);
-    wave_sync();
+    solve_env<NVP, GL, GL, false>(m, st, st.cls_list, first, count, lds);
   }
 }
 

@@ -378,6 +378,16 @@ class PhysxGpuSystem:
         return (np.array(ids[: 3 * n], dtype=np.int32).reshape(n, 3),
                 np.array(vals[: 8 * n], dtype=np.float32).reshape(n, 8))
 
+    def set_solver_classes(self, caps):
+        """Scheduling only (include/msk_physx.h): largest block counts of solver classes 0..2; negative empties a class."""
+        arr = (C.c_int32 * 3)(*[int(x) for x in caps])
+        self.lib.check(self.ctx, self.lib.set_solver_classes(self.ctx, arr), "set_solver_classes")
+
+    def get_solver_class_counts(self) -> np.ndarray:
+        out = (C.c_int32 * 4)()
+        self.lib.check(self.ctx, self.lib.get_solver_class_counts(self.ctx, out), "get_solver_class_counts")
+        return np.array(list(out), dtype=np.int32)
+
     def get_env_contact_counts(self) -> np.ndarray:
         """(num_envs,) int32: contact points solved per env in the last step (synchronises)."""
         out = np.zeros(self.num_envs, dtype=np.int32)

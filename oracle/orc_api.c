@@ -430,6 +430,13 @@ ORC_EXPORT int orc_timing_read(orc_ctx* c, int slot, double* total_ms, int32_t* 
   return MSK_OK;
 }
 
+/* msk_set_solver_classes / msk_get_solver_class_counts: GPU scheduling knobs; the scalar restatement has one path */
+ORC_EXPORT int orc_set_solver_classes(orc_ctx* c, const int32_t caps[3]) { (void)c; (void)caps; return MSK_OK; }
+ORC_EXPORT int orc_get_solver_class_counts(orc_ctx* c, int32_t out[4]) {
+  out[0] = c->num_envs; out[1] = out[2] = out[3] = 0;
+  return MSK_OK;
+}
+
 /* msk_get_env_contact_counts */
 ORC_EXPORT int orc_get_env_contact_counts(orc_ctx* c, int32_t* out) {
   for (int e = 0; e < c->num_envs; ++e) out[e] = c->envs[e].ncontacts;

@@ -226,3 +226,33 @@ def test_timing_api_reports_kernels():
     t = env.px.timing_read()
     assert set(t) >= {"k_solve"} and all(v[1] == 5 for v in t.values())
     assert all(v[0] > 0 for v in t.values())
+
+
+@pytest.mark.parametrize("caps", [(-1, -1, -1), (-1, -1, 32), (-1, 20, 32), (4, 8, 16)])
+def test_every_solver_class_computes_the_same_bits(caps):
+    """The solver sorts envs into LDS capacity classes (include/msk_physx.h: msk_set_solver_classes); which class an
+    env lands in is scheduling only.  Force every env through class 3 (A image in global memory), class 2, classes
+    1-2, and a fine split: each rollout must equal, bit for bit, the default schedule's (which the tests above hold
+    against the oracle)."""
+    n, steps = 64, 40
+    ref = PickCubeEnv(num_envs=n, device=DEV, fused=False)
+    alt = PickCubeEnv(num_envs=n, device=DEV, fused=False)
+    alt.px.set_solver_classes(caps)
+    ref.reset(seed=7)
+    alt.reset(seed=7)
+    gen = torch.Generator().manual_seed(1)
+    seen = np.zeros(4, dtype=np.int64)
+    for t in range(steps):
+        a = (2 * torch.rand(n, 8, generator=gen) - 1).to(DEV)
+        ref.step(a)
+        alt.step(a)
+        counts = alt.px.get_solver_class_counts()
+        assert counts.sum() == n
+        seen += counts
+        assert torch.equal(ref.get_state(), alt.get_state()), f"classes {caps}: state differs at step {t}"
+    if caps[0] < 0:
+        assert seen[0] == 0
+    if caps == (-1, -1, -1):
+        assert seen[3] == n * steps
+    assert seen[1:].sum() > 0
+    assert alt.px.get_overflow() == 0
