@@ -1,11 +1,22 @@
 /*
- * msk_collide.h — per-pair narrowphase device functions (one HIP thread = one (pair, env)).
+ * msk_collide.h — narrowphase device functions, one 16-lane group (a DPP row) per (pair, env) item.
  *
  * box-box SAT, GJK distance + EPA penetration for hulls, plane-vs-vertices, and the one-shot
- * support-feature clipping manifold (<= 4 points per pair).  A wavefront holds 64 surviving pairs
- * of one narrowphase type (k_narrowphase), so all lanes follow the same branch; hull vertices come
- * from an LDS copy of the template's vertex pool.  Arithmetic is kept operation-for-operation
- * identical to the CPU oracle.
+ * support-feature clipping manifold (<= 4 points per pair).
+ *
+ * Why lane groups: one thread per item kept every polygon, simplex and polytope in private arrays with
+ * dynamic indices, i.e. in scratch memory (6.5 KB per lane), and walked up to 64 hull vertices per support
+ * call serially; a launch was as slow as its slowest lane (~100k cycles per item).  Here the 16 lanes of a
+ * group share the item:
+ *   - loops over vertices / candidates / polygon corners are split over the lanes and finished with a
+ *     DPP butterfly (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) — max / arg-max reductions are
+ *     exact and order-independent, ties go to the lower index exactly as the oracle's ascending scans do;
+ *   - Sutherland-Hodgman keeps one polygon corner per lane and compacts with ballot ranks;
+ *   - everything with a dynamic index (features, candidates, EPA polytope) lives in the group's LDS
+ *     workspace, the GJK simplex in four named register slots; the serial parts (SAT axes, simplex logic,
+ *     EPA face bookkeeping) run replicated in every lane of the group, on identical operands, so the
+ *     group stays uniform (lane 0 does the stores).
+ * Arithmetic is kept operation-for-operation identical to the CPU oracle (oracle/orc_collide.c).
  */
 #ifndef MSK_COLLIDE_H
 #define MSK_COLLIDE_H
@@ -17,35 +28,106 @@
 #define ORC_EPA_ITERS 32
 #define ORC_EPA_MAXV 40
 #define ORC_EPA_MAXF 96
+#define ORC_CLIP_MAXV 16   /* corners of a clipped polygon (8 + 8 for convex inputs): one per lane */
+
+#define NPG 16             /* lanes per item */
+/* group workspace in LDS (floats) */
+#define WS_FA 0            /* p3[8]   feature of A                       */
+#define WS_FB 24           /* p3[8]   feature of B                       */
+#define WS_PTS 48          /* [16][2] clipped polygon                    */
+#define WS_BUF 80          /* [16][2] compaction buffer                  */
+#define WS_CS 112          /* cand[64] contact candidates                */
+#define WS_TOTAL 368
+/* EPA workspace (floats): one per wavefront — deep penetration is rare, the groups that need it take turns */
+#define WE_CAND 0          /* mvert[10] seed candidates                  */
+#define WE_VS 90           /* mvert[ORC_EPA_MAXV]                        */
+#define WE_FS (WE_VS + ORC_EPA_MAXV * 9)          /* epa_face[ORC_EPA_MAXF] (8 words each) */
+#define WE_EDGES (WE_FS + ORC_EPA_MAXF * 8)       /* int[ORC_EPA_MAXF][2]                  */
+#define WE_TOTAL (WE_EDGES + ORC_EPA_MAXF * 2)
 
 struct DContactOut { v3 pos; v3 n; float sep; };
+/* the fields of a DShape the narrowphase keeps reading, copied to registers once per item */
+struct CShape { int type, nverts, vbase; float par[3]; };
+MSK_DEV CShape cshape_of(const DShape* sh) {
+  CShape c;
+  c.type = sh->type; c.nverts = sh->nverts; c.vbase = sh->vbase;
+  c.par[0] = sh->par[0]; c.par[1] = sh->par[1]; c.par[2] = sh->par[2];
+  return c;
+}
 
-/* what the narrowphase functions need besides the two shapes: the hull vertex pool (an LDS copy: the
- * support loops read 64 vertices per call) */
-struct CCtx { const v3* verts; };
+/* what the narrowphase functions need besides the two shapes: the hull vertex pool (the template's table in global
+ * memory: 12 KB, L1-resident), the group's workspace, the wave's EPA workspace, the lane's index in its group and
+ * the group's index in its wave */
+struct CCtx { const v3* verts; float* ws; float* we; int gl, grp; unsigned long long* dbg; };
 
-MSK_DEV int shape_nverts(const DShape* sh) { return sh->type == MSK_SHAPE_BOX ? 8 : sh->nverts; }
-MSK_DEV v3 shape_vert(const CCtx& m, const DShape* sh, int i) {
+/* ---- group primitives (a group = one DPP row of 16 lanes) ------------------------------------------------ */
+template <int CTRL>
+MSK_DEV float row_xchg_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+MSK_DEV int row_xchg_i(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false); }
+#define ROW_XOR1 0xB1         /* quad_perm [1,0,3,2] */
+#define ROW_XOR2 0x4E         /* quad_perm [2,3,0,1] */
+#define ROW_HALF_MIRROR 0x141 /* i <-> 7 - i within 8 */
+#define ROW_MIRROR 0x140      /* i <-> 15 - i         */
+
+MSK_DEV float grp_max(float x) {
+  x = fmaxf(x, row_xchg_f<ROW_XOR1>(x));
+  x = fmaxf(x, row_xchg_f<ROW_XOR2>(x));
+  x = fmaxf(x, row_xchg_f<ROW_HALF_MIRROR>(x));
+  x = fmaxf(x, row_xchg_f<ROW_MIRROR>(x));
+  return x;
+}
+/* arg-max over the group; equal values keep the lower index (an ascending scan with `>` does the same) */
+template <int CTRL>
+MSK_DEV void argmax_step(float& v, int& i) {
+  const float ov = row_xchg_f<CTRL>(v);
+  const int oi = row_xchg_i<CTRL>(i);
+  const bool take = ov > v || (ov == v && oi < i);
+  v = take ? ov : v;
+  i = take ? oi : i;
+}
+MSK_DEV void grp_argmax(float& v, int& i) {
+  argmax_step<ROW_XOR1>(v, i);
+  argmax_step<ROW_XOR2>(v, i);
+  argmax_step<ROW_HALF_MIRROR>(v, i);
+  argmax_step<ROW_MIRROR>(v, i);
+}
+/* 16-bit ballot of my group */
+MSK_DEV unsigned grp_ballot(bool p) { return (unsigned)((__ballot(p) >> (threadIdx.x & 48)) & 0xFFFFull); }
+MSK_DEV float grp_shfl(float x, int src) { return __shfl(x, src, NPG); }
+/* LDS hand-off inside a wavefront: DS instructions of one wave execute in issue order, so the only thing to stop is
+ * the compiler moving the accesses (no s_waitcnt, and the global loads in flight are left alone) */
+MSK_DEV void grp_sync() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+#define NO_INDEX 0x7fffffff
+
+MSK_DEV int shape_nverts(const CShape* sh) { return sh->type == MSK_SHAPE_BOX ? 8 : sh->nverts; }
+MSK_DEV v3 shape_vert(const CCtx& m, const CShape* sh, int i) {
   if (sh->type == MSK_SHAPE_BOX)
     return v3_make((i & 1) ? sh->par[0] : -sh->par[0], (i & 2) ? sh->par[1] : -sh->par[1],
                    (i & 4) ? sh->par[2] : -sh->par[2]);
   return m.verts[sh->vbase + i];
 }
 
-/* support point (world) of a box / hull in world direction d */
-MSK_DEV v3 support(const CCtx& m, const DShape* sh, const pose* T, v3 d) {
+/* support point (world) of a box / hull in world direction d; the hull scan is split over the group */
+MSK_DEV v3 support(const CCtx& m, const CShape* sh, const pose* T, v3 d) {
   v3 dl = quat_rotate_inv(T->q, d);
   v3 pl;
   if (sh->type == MSK_SHAPE_BOX) {
     pl = v3_make(dl.x >= 0.0f ? sh->par[0] : -sh->par[0], dl.y >= 0.0f ? sh->par[1] : -sh->par[1],
                  dl.z >= 0.0f ? sh->par[2] : -sh->par[2]);
   } else {
-    int best = 0;
-    float bd = v3_dot(m.verts[sh->vbase], dl);
-    for (int i = 1; i < sh->nverts; ++i) {
+    int best = NO_INDEX;
+    float bd = -3.0e38f;
+    for (int i = m.gl; i < sh->nverts; i += NPG) {
       float di = v3_dot(m.verts[sh->vbase + i], dl);
-      if (di > bd) { bd = di; best = i; }
+      if (di > bd || best == NO_INDEX) { bd = di; best = i; }
     }
+    grp_argmax(bd, best);
     pl = m.verts[sh->vbase + best];
   }
   return pose_apply(*T, pl);
@@ -62,49 +144,59 @@ MSK_DEV void world_aabb(const DShape* sh, const pose* T, v3* c, v3* h) {
 /* ---- manifold ------------------------------------------------------------------------ */
 typedef struct { float u, v, h; } p3;   /* coordinates in the (t1, t2, n) contact frame */
 
-/* support feature of `sh` along sign*n: up to 8 extreme points, CCW about n.
- * Two passes over the vertices (extreme height, then the eight directional maxima kept in registers side by side);
- * every comparison sees the same operands in the same vertex order as the oracle's direction-by-direction scan. */
-MSK_DEV int select_feature(const CCtx& m, const DShape* sh, const pose* T, v3 n, v3 t1, v3 t2, float sign, p3* out) {
-  const float DX[8] = {1.0f, 0.70710678f, 0.0f, -0.70710678f, -1.0f, -0.70710678f, 0.0f, 0.70710678f};
-  const float DY[8] = {0.0f, 0.70710678f, 1.0f, 0.70710678f, 0.0f, -0.70710678f, -1.0f, -0.70710678f};
+/* support feature of `sh` along sign*n: up to 8 extreme points, CCW about n, written to the LDS array `out`.
+ * Pass 1 (vertices over lanes): contact-frame coordinates of every vertex staged in LDS, extreme height by group max.
+ * Pass 2 (directions over lanes): lane k scans the vertices in ascending order for direction k — the oracle's loop for
+ * that direction, verbatim.  Loops, not unrolled code: a wave runs this once per four pairs, so what it costs is
+ * instruction fetch, and a loop body is fetched once. */
+MSK_DEV int select_feature(const CCtx& m, const CShape* sh, const pose* T, v3 n, v3 t1, v3 t2, float sign, p3* out) {
   v3 nl = quat_rotate_inv(T->q, n), t1l = quat_rotate_inv(T->q, t1), t2l = quat_rotate_inv(T->q, t2);
   float on = v3_dot(T->p, n), o1 = v3_dot(T->p, t1), o2 = v3_dot(T->p, t2);
+  float* H = m.ws + WS_CS;     /* the candidate array is not in use yet: [64] heights, [64] u, [64] v */
+  float* PU = H + 64;
+  float* PV = PU + 64;
   const int nv = shape_nverts(sh);
   float hbest = -3.0e38f;
-  for (int i = 0; i < nv; ++i) {
-    const float s = sign * v3_dot(shape_vert(m, sh, i), nl);
+#pragma unroll 1
+  for (int i = m.gl; i < nv; i += NPG) {
+    const v3 p = shape_vert(m, sh, i);
+    const float h = v3_dot(p, nl);
+    H[i] = h; PU[i] = v3_dot(p, t1l); PV[i] = v3_dot(p, t2l);
+    const float s = sign * h;
     if (s > hbest) hbest = s;
   }
+  hbest = grp_max(hbest);
   const float thr = hbest - ORC_FEAT_EPS;
-  int sel[8];
-  float bd[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { sel[k] = -1; bd[k] = -3.0e38f; }
+  grp_sync();
+  const int k = m.gl & 7;   /* lanes 8..15 repeat 0..7 */
+  const float c = 0.70710678f;
+  const float dx = (k == 0) ? 1.0f : ((k == 1 || k == 7) ? c : ((k == 2 || k == 6) ? 0.0f : ((k == 4) ? -1.0f : -c)));
+  const float dy = (k == 2) ? 1.0f : ((k == 1 || k == 3) ? c : ((k == 0 || k == 4) ? 0.0f : ((k == 6) ? -1.0f : -c)));
+  int sel = -1;
+  float bd = -3.0e38f;
+#pragma unroll 1
   for (int i = 0; i < nv; ++i) {
-    const v3 p = shape_vert(m, sh, i);
-    if (sign * v3_dot(p, nl) < thr) continue;
-    const float pu = v3_dot(p, t1l), pv = v3_dot(p, t2l);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float d = fmaf(pu, DX[k], pv * DY[k]);
-      if (d > bd[k]) { bd[k] = d; sel[k] = i; }
-    }
+    if (sign * H[i] < thr) continue;
+    const float d = fmaf(PU[i], dx, PV[i] * dy);
+    if (d > bd) { bd = d; sel = i; }
   }
   /* drop repeats of the previous kept vertex, and a last one equal to the first */
   int cnt = 0, first = -1, last = -1;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    if (cnt > 0 && sel[k] == last) continue;
-    last = sel[k];
+#pragma unroll 1
+  for (int kk = 0; kk < 8; ++kk) {
+    const int sk = __shfl(sel, kk, NPG);
+    if (cnt > 0 && sk == last) continue;
+    last = sk;
     if (cnt == 0) first = last;
-    const v3 p = shape_vert(m, sh, last);
-    out[cnt].u = v3_dot(p, t1l) + o1;
-    out[cnt].v = v3_dot(p, t2l) + o2;
-    out[cnt].h = v3_dot(p, nl) + on;
+    if (m.gl == 0) {
+      out[cnt].u = PU[sk] + o1;
+      out[cnt].v = PV[sk] + o2;
+      out[cnt].h = H[sk] + on;
+    }
     cnt++;
   }
   if (cnt > 1 && last == first) cnt--;
+  grp_sync();
   return cnt;
 }
 
@@ -120,9 +212,10 @@ MSK_DEV float feature_height(const p3* f, int n, float u, float v) {
   }
   /* Newell normal and centroid */
   float mx = 0, my = 0, mz = 0, gu = 0, gv = 0, gh = 0;
+#pragma unroll 1
   for (int i = 0; i < n; ++i) {
     const p3* a = &f[i];
-    const p3* b = &f[(i + 1) % n];
+    const p3* b = &f[(i + 1 == n) ? 0 : i + 1];
     mx += (a->v - b->v) * (a->h + b->h);
     my += (a->h - b->h) * (a->u + b->u);
     mz += (a->u - b->u) * (a->v + b->v);
@@ -136,13 +229,15 @@ MSK_DEV float feature_height(const p3* f, int n, float u, float v) {
 
 MSK_DEV float cross2(float ax, float ay, float bx, float by) { return fmaf(ax, by, -(ay * bx)); }
 
-/* clip the segment p0-p1 against the convex CCW polygon poly; returns number of points (0..2) */
-MSK_DEV int clip_segment_poly(const p3* seg, const p3* poly, int np, float out[][2]) {
+/* clip the segment p0-p1 against the convex CCW polygon poly; returns number of points (0..2), written to the
+ * LDS array out[][2] (every lane computes the same values; lane 0 stores) */
+MSK_DEV int clip_segment_poly(const CCtx& m, const p3* seg, const p3* poly, int np, float* out) {
   float t0 = 0.0f, t1 = 1.0f;
   float dx = seg[1].u - seg[0].u, dy = seg[1].v - seg[0].v;
+#pragma unroll 1
   for (int i = 0; i < np; ++i) {
     const p3* a = &poly[i];
-    const p3* b = &poly[(i + 1) % np];
+    const p3* b = &poly[(i + 1 == np) ? 0 : i + 1];
     float ex = b->u - a->u, ey = b->v - a->v;
     float c0 = cross2(ex, ey, seg[0].u - a->u, seg[0].v - a->v);
     float cd = cross2(ex, ey, dx, dy);
@@ -155,46 +250,57 @@ MSK_DEV int clip_segment_poly(const p3* seg, const p3* poly, int np, float out[]
     else { if (t < t1) t1 = t; }
   }
   if (t0 > t1 + 1e-6f) return 0;
-  out[0][0] = fmaf(t0, dx, seg[0].u); out[0][1] = fmaf(t0, dy, seg[0].v);
+  if (m.gl == 0) { out[0] = fmaf(t0, dx, seg[0].u); out[1] = fmaf(t0, dy, seg[0].v); }
   if (t1 - t0 < 1e-6f) return 1;
-  out[1][0] = fmaf(t1, dx, seg[0].u); out[1][1] = fmaf(t1, dy, seg[0].v);
+  if (m.gl == 0) { out[2] = fmaf(t1, dx, seg[0].u); out[3] = fmaf(t1, dy, seg[0].v); }
   return 2;
 }
 
-/* Sutherland-Hodgman: subject polygon (CCW) clipped by convex CCW polygon */
-MSK_DEV int clip_poly_poly(const p3* subj, int ns, const p3* clip, int nc, float out[][2]) {
-  float bufa[24][2], bufb[24][2];
+/* Sutherland-Hodgman: subject polygon (CCW) clipped by convex CCW polygon, one corner per lane.  A lane emits its
+ * corner P if P is inside the clip edge and the crossing with the edge to the next corner if exactly one of the two
+ * is inside — in that order, at positions given by the ballot ranks, which is the order the serial loop produces;
+ * emissions past ORC_CLIP_MAXV are dropped like the serial loop's capacity test drops them.  Result in out[][2]. */
+MSK_DEV int clip_poly_poly(const CCtx& m, const p3* subj, int ns, const p3* clip, int nc, float* out) {
+  float* buf = m.ws + WS_BUF;
+  const int j = m.gl;
   int na = ns;
-  for (int i = 0; i < ns; ++i) { bufa[i][0] = subj[i].u; bufa[i][1] = subj[i].v; }
-  float(*in)[2] = bufa;
-  float(*ot)[2] = bufb;
+  float px = 0.0f, py = 0.0f;
+  if (j < ns) { px = subj[j].u; py = subj[j].v; }
+#pragma unroll 1
   for (int ci = 0; ci < nc && na > 0; ++ci) {
     const p3* a = &clip[ci];
-    const p3* b = &clip[(ci + 1) % nc];
-    float ex = b->u - a->u, ey = b->v - a->v;
-    int no = 0;
-    for (int i = 0; i < na; ++i) {
-      const float* P = in[i];
-      const float* Q = in[(i + 1) % na];
-      float cp = cross2(ex, ey, P[0] - a->u, P[1] - a->v);
-      float cq = cross2(ex, ey, Q[0] - a->u, Q[1] - a->v);
-      int pin = cp >= -1e-9f, qin = cq >= -1e-9f;
-      if (pin && no < 24) { ot[no][0] = P[0]; ot[no][1] = P[1]; no++; }
-      if (pin != qin && no < 24) {
-        float t = cp / (cp - cq);
-        ot[no][0] = fmaf(t, Q[0] - P[0], P[0]);
-        ot[no][1] = fmaf(t, Q[1] - P[1], P[1]);
-        no++;
-      }
+    const p3* b = &clip[(ci + 1 == nc) ? 0 : ci + 1];
+    const float ex = b->u - a->u, ey = b->v - a->v;
+    const float au = a->u, av = a->v;
+    const int nxt = (j + 1 < na) ? j + 1 : 0;
+    const float qx = grp_shfl(px, nxt), qy = grp_shfl(py, nxt);
+    const float cp = cross2(ex, ey, px - au, py - av);
+    const float cq = cross2(ex, ey, qx - au, qy - av);
+    const bool live = j < na;
+    const bool pin = live && cp >= -1e-9f, qin = cq >= -1e-9f;
+    const bool cross = live && (pin != qin);
+    const unsigned bp = grp_ballot(pin), bx = grp_ballot(cross);
+    const unsigned below = (1u << j) - 1u;
+    const int pos = __popc(bp & below) + __popc(bx & below);
+    if (pin && pos < ORC_CLIP_MAXV) { buf[pos * 2] = px; buf[pos * 2 + 1] = py; }
+    const int posx = pos + (pin ? 1 : 0);
+    if (cross && posx < ORC_CLIP_MAXV) {
+      const float t = cp / (cp - cq);
+      buf[posx * 2] = fmaf(t, qx - px, px);
+      buf[posx * 2 + 1] = fmaf(t, qy - py, py);
     }
-    float(*tmp)[2] = in; in = ot; ot = tmp;
-    na = no;
+    const int total = __popc(bp) + __popc(bx);
+    na = total < ORC_CLIP_MAXV ? total : ORC_CLIP_MAXV;
+    grp_sync();
+    if (j < na) { px = buf[j * 2]; py = buf[j * 2 + 1]; }
+    grp_sync();
   }
-  for (int i = 0; i < na; ++i) { out[i][0] = in[i][0]; out[i][1] = in[i][1]; }
+  if (j < na) { out[j * 2] = px; out[j * 2 + 1] = py; }
+  grp_sync();
   return na;
 }
 
-MSK_DEV int seg_seg(const p3* a, const p3* b, float out[][2]) {
+MSK_DEV int seg_seg(const CCtx& m, const p3* a, const p3* b, float* out) {
   float d1x = a[1].u - a[0].u, d1y = a[1].v - a[0].v;
   float d2x = b[1].u - b[0].u, d2y = b[1].v - b[0].v;
   float rx = b[0].u - a[0].u, ry = b[0].v - a[0].v;
@@ -203,94 +309,138 @@ MSK_DEV int seg_seg(const p3* a, const p3* b, float out[][2]) {
   if (den * den > 1e-6f * l1 * l2) {
     float s = cross2(rx, ry, d2x, d2y) / den;
     s = fminf(fmaxf(s, 0.0f), 1.0f);
-    out[0][0] = fmaf(s, d1x, a[0].u); out[0][1] = fmaf(s, d1y, a[0].v);
+    if (m.gl == 0) { out[0] = fmaf(s, d1x, a[0].u); out[1] = fmaf(s, d1y, a[0].v); }
     return 1;
   }
   /* parallel: overlap of b's endpoints projected on a */
-  if (l1 < 1e-12f) { out[0][0] = a[0].u; out[0][1] = a[0].v; return 1; }
+  if (l1 < 1e-12f) { if (m.gl == 0) { out[0] = a[0].u; out[1] = a[0].v; } return 1; }
   float s0 = fmaf(rx, d1x, ry * d1y) / l1;
   float s1 = fmaf(b[1].u - a[0].u, d1x, (b[1].v - a[0].v) * d1y) / l1;
   float lo = fmaxf(fminf(s0, s1), 0.0f), hi = fminf(fmaxf(s0, s1), 1.0f);
-  if (lo > hi) { float m = fminf(fmaxf(0.5f * (s0 + s1), 0.0f), 1.0f); lo = hi = m; }
-  out[0][0] = fmaf(lo, d1x, a[0].u); out[0][1] = fmaf(lo, d1y, a[0].v);
+  if (lo > hi) { float mm = fminf(fmaxf(0.5f * (s0 + s1), 0.0f), 1.0f); lo = hi = mm; }
+  if (m.gl == 0) { out[0] = fmaf(lo, d1x, a[0].u); out[1] = fmaf(lo, d1y, a[0].v); }
   if (hi - lo < 1e-6f) return 1;
-  out[1][0] = fmaf(hi, d1x, a[0].u); out[1][1] = fmaf(hi, d1y, a[0].v);
+  if (m.gl == 0) { out[2] = fmaf(hi, d1x, a[0].u); out[3] = fmaf(hi, d1y, a[0].v); }
   return 2;
 }
 
 typedef struct { float u, v, hm, sep; } cand;
 
-/* keep at most 4 candidates: deepest, farthest from it, and the extremes on both sides of that line */
-MSK_DEV int reduce4(cand* cs, int n) {
-  if (n <= 4) return n;
-  int i0 = 0;
-  for (int i = 1; i < n; ++i) if (cs[i].sep < cs[i0].sep) i0 = i;
-  int i1 = -1; float best = -1.0f;
-  for (int i = 0; i < n; ++i) {
+/* keep at most 4 of the n candidates cs[] (LDS): deepest, farthest from it, and the extremes on both sides of that
+ * line; returns them (group-uniform) in res[].  Four group arg-max scans, each over candidates gl, gl + 16, ... */
+MSK_DEV int reduce4(const CCtx& m, const cand* cs, int n, cand res[4]) {
+  if (n <= 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i < n) res[i] = cs[i];
+    return n;
+  }
+  int i0 = NO_INDEX; float b0 = -3.0e38f;  /* deepest = max of -sep; first among equals */
+  for (int i = m.gl; i < n; i += NPG) { const float s = -cs[i].sep; if (s > b0 || i0 == NO_INDEX) { b0 = s; i0 = i; } }
+  grp_argmax(b0, i0);
+  const cand c0 = cs[i0];
+  int i1 = NO_INDEX; float b1 = -1.0f;
+  for (int i = m.gl; i < n; i += NPG) {
     if (i == i0) continue;
-    float du = cs[i].u - cs[i0].u, dv = cs[i].v - cs[i0].v;
+    float du = cs[i].u - c0.u, dv = cs[i].v - c0.v;
     float d = fmaf(du, du, dv * dv);
-    if (d > best) { best = d; i1 = i; }
+    if (d > b1) { b1 = d; i1 = i; }
   }
-  float ex = cs[i1].u - cs[i0].u, ey = cs[i1].v - cs[i0].v;
-  int i2 = -1, i3 = -1; float bp = 0.0f, bn = 0.0f;
-  for (int i = 0; i < n; ++i) {
+  grp_argmax(b1, i1);
+  const cand c1 = cs[i1];
+  float ex = c1.u - c0.u, ey = c1.v - c0.v;
+  int i2 = NO_INDEX, i3 = NO_INDEX; float bp = 0.0f, bn = 0.0f;   /* bn holds -cr: arg-max of it = arg-min of cr */
+  for (int i = m.gl; i < n; i += NPG) {
     if (i == i0 || i == i1) continue;
-    float cr = cross2(ex, ey, cs[i].u - cs[i0].u, cs[i].v - cs[i0].v);
+    float cr = cross2(ex, ey, cs[i].u - c0.u, cs[i].v - c0.v);
     if (cr > bp) { bp = cr; i2 = i; }
-    if (cr < bn) { bn = cr; i3 = i; }
+    if (-cr > bn) { bn = -cr; i3 = i; }
   }
-  cand out[4];
-  int m = 0;
-  out[m++] = cs[i0]; out[m++] = cs[i1];
-  if (i2 >= 0) out[m++] = cs[i2];
-  if (i3 >= 0) out[m++] = cs[i3];
-  for (int i = 0; i < m; ++i) cs[i] = out[i];
-  return m;
+  grp_argmax(bp, i2);
+  grp_argmax(bn, i3);
+  int k = 2;
+  res[0] = c0; res[1] = c1;
+  if (i2 != NO_INDEX) { res[2] = cs[i2]; k = 3; }
+  if (i3 != NO_INDEX) { const cand c = cs[i3]; if (k == 2) res[2] = c; else res[3] = c; k++; }
+  return k;
 }
 
-MSK_DEV int build_manifold(const CCtx& m, const DShape* A, const pose* TA, const DShape* B, const pose* TB, v3 n,
+#ifdef MSK_PROFILE_PHASES
+#define MF_STAMP(k) do { const long long _t = (long long)__builtin_readcyclecounter(); if (m.gl == 0 && m.dbg) m.dbg[k] = (unsigned long long)(_t - _t0); _t0 = _t; } while (0)
+#else
+#define MF_STAMP(k)
+#endif
+MSK_DEV int build_manifold(const CCtx& m, const CShape* A, const pose* TA, const CShape* B, const pose* TB, v3 n,
                           float margin, v3 wa, v3 wb, float sep_hint, DContactOut* out) {
+#ifdef MSK_PROFILE_PHASES
+  long long _t0 = (long long)__builtin_readcyclecounter();
+#endif
   v3 t1, t2;
   msk_tangents(n, &t1, &t2);
-  p3 fa[8], fb[8];
-  int ka = select_feature(m, A, TA, n, t1, t2, -1.0f, fa);
-  int kb = select_feature(m, B, TB, n, t1, t2, 1.0f, fb);
-  float pts[24][2];
-  int np = 0;
-  if (ka == 1) { pts[0][0] = fa[0].u; pts[0][1] = fa[0].v; np = 1; }
-  else if (kb == 1) { pts[0][0] = fb[0].u; pts[0][1] = fb[0].v; np = 1; }
-  else if (ka >= 3 && kb >= 3) np = clip_poly_poly(fa, ka, fb, kb, pts);
-  else if (ka == 2 && kb >= 3) np = clip_segment_poly(fa, fb, kb, pts);
-  else if (kb == 2 && ka >= 3) np = clip_segment_poly(fb, fa, ka, pts);
-  else np = seg_seg(fa, fb, pts);
-  cand cs[24];
-  int nc = 0;
-  for (int i = 0; i < np; ++i) {
-    float ha = feature_height(fa, ka, pts[i][0], pts[i][1]);
-    float hb = feature_height(fb, kb, pts[i][0], pts[i][1]);
-    float sep = ha - hb;
-    if (sep > margin) continue;
-    cs[nc].u = pts[i][0]; cs[nc].v = pts[i][1]; cs[nc].hm = 0.5f * (ha + hb); cs[nc].sep = sep;
-    nc++;
+  p3* fa = (p3*)(m.ws + WS_FA);
+  p3* fb = (p3*)(m.ws + WS_FB);
+  float* pts = m.ws + WS_PTS;
+  cand* cs = (cand*)(m.ws + WS_CS);
+  int ka = 0, kb = 0;
+#pragma unroll 1
+  for (int side = 0; side < 2; ++side) { /* one copy of the code for both shapes */
+    const CShape sh = side ? *B : *A;
+    const pose T = side ? *TB : *TA;
+    const int kf = select_feature(m, &sh, &T, n, t1, t2, side ? 1.0f : -1.0f, side ? fb : fa);
+    if (side) kb = kf; else ka = kf;
   }
+  MF_STAMP(0);
+  int np = 0;
+  if (ka == 1) { if (m.gl == 0) { pts[0] = fa[0].u; pts[1] = fa[0].v; } np = 1; }
+  else if (kb == 1) { if (m.gl == 0) { pts[0] = fb[0].u; pts[1] = fb[0].v; } np = 1; }
+  else if (ka >= 3 && kb >= 3) np = clip_poly_poly(m, fa, ka, fb, kb, pts);
+  else if (ka == 2 && kb >= 3) np = clip_segment_poly(m, fa, fb, kb, pts);
+  else if (kb == 2 && ka >= 3) np = clip_segment_poly(m, fb, fa, ka, pts);
+  else np = seg_seg(m, fa, fb, pts);
+  grp_sync();
+  MF_STAMP(1);
+  /* one clipped point per lane: heights on both features, keep the ones within the margin, in order */
+  const int i = m.gl;
+  float pu = 0.0f, pv = 0.0f, ha = 0.0f, hb = 0.0f, sep = 3.0e38f;
+  if (i < np) {
+    pu = pts[i * 2]; pv = pts[i * 2 + 1];
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+      const float hh = feature_height(side ? fb : fa, side ? kb : ka, pu, pv);
+      if (side) hb = hh; else ha = hh;
+    }
+    sep = ha - hb;
+  }
+  const bool keep = i < np && !(sep > margin);
+  const unsigned bk = grp_ballot(keep);
+  int nc = __popc(bk);
+  if (keep) {
+    const int pos = __popc(bk & ((1u << i) - 1u));
+    cs[pos].u = pu; cs[pos].v = pv; cs[pos].hm = 0.5f * (ha + hb); cs[pos].sep = sep;
+  }
+  grp_sync();
+  MF_STAMP(2);
   if (nc == 0) {
     if (sep_hint > margin) return 0;
     v3 mid = v3_scale(v3_add(wa, wb), 0.5f);
     out[0].pos = mid; out[0].n = n; out[0].sep = sep_hint;
     return 1;
   }
-  nc = reduce4(cs, nc);
-  for (int i = 0; i < nc; ++i) {
-    out[i].pos = v3_madd(v3_madd(v3_scale(t1, cs[i].u), t2, cs[i].v), n, cs[i].hm);
-    out[i].n = n;
-    out[i].sep = cs[i].sep;
+  cand res[4];
+  nc = reduce4(m, cs, nc, res);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k < nc) {
+      out[k].pos = v3_madd(v3_madd(v3_scale(t1, res[k].u), t2, res[k].v), n, res[k].hm);
+      out[k].n = n;
+      out[k].sep = res[k].sep;
+    }
   }
+  MF_STAMP(3);
   return nc;
 }
 
 /* ---- box-box SAT ---------------------------------------------------------------------- */
-MSK_DEV int sat_box_box(const DShape* A, const pose* TA, const DShape* B, const pose* TB, float margin,
+MSK_DEV int sat_box_box(const CShape* A, const pose* TA, const CShape* B, const pose* TB, float margin,
                        v3* n_out, float* sep_out) {
   m33 Ra = quat_to_m33(TA->q), Rb = quat_to_m33(TB->q);
   v3 au[3] = {m33_col(&Ra, 0), m33_col(&Ra, 1), m33_col(&Ra, 2)};
@@ -299,15 +449,19 @@ MSK_DEV int sat_box_box(const DShape* A, const pose* TA, const DShape* B, const 
   const float* b = B->par;
   v3 dc = v3_sub(TA->p, TB->p); /* from B to A */
   float R[3][3], AR[3][3];
+#pragma unroll
   for (int i = 0; i < 3; ++i)
+#pragma unroll
     for (int j = 0; j < 3; ++j) { R[i][j] = v3_dot(au[i], bu[j]); AR[i][j] = fabsf(R[i][j]); }
   float best_f = -3.0e38f; v3 nf = v3_make(0, 0, 1);
+#pragma unroll
   for (int i = 0; i < 3; ++i) {
     float t = v3_dot(dc, au[i]);
     float rb = fmaf(b[0], AR[i][0], fmaf(b[1], AR[i][1], b[2] * AR[i][2]));
     float s = fabsf(t) - (a[i] + rb);
     if (s > best_f) { best_f = s; nf = (t >= 0.0f) ? au[i] : v3_neg(au[i]); }
   }
+#pragma unroll
   for (int j = 0; j < 3; ++j) {
     float t = v3_dot(dc, bu[j]);
     float ra = fmaf(a[0], AR[0][j], fmaf(a[1], AR[1][j], a[2] * AR[2][j]));
@@ -316,13 +470,15 @@ MSK_DEV int sat_box_box(const DShape* A, const pose* TA, const DShape* B, const 
   }
   if (best_f > margin) return 0;
   float best_e = -3.0e38f; v3 ne = nf;
+#pragma unroll
   for (int i = 0; i < 3; ++i)
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
       v3 L = v3_cross(au[i], bu[j]);
       float l2 = v3_len2(L);
       if (l2 < 1e-6f) continue;
       float inv = 1.0f / sqrtf(l2);
-      int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
       float ra = fmaf(a[i1], AR[i2][j], a[i2] * AR[i1][j]);
       float rb = fmaf(b[j1], AR[i][j2], b[j2] * AR[i][j1]);
       float t = v3_dot(dc, L);
@@ -338,10 +494,15 @@ MSK_DEV int sat_box_box(const DShape* A, const pose* TA, const DShape* B, const 
 /* ---- GJK / EPA ------------------------------------------------------------------------ */
 typedef struct { v3 w, a, b; } mvert;
 
-MSK_DEV mvert msupport(const CCtx& m, const DShape* A, const pose* TA, const DShape* B, const pose* TB, v3 d) {
+MSK_DEV mvert msupport(const CCtx& m, const CShape* A, const pose* TA, const CShape* B, const pose* TB, v3 d) {
   mvert r;
-  r.a = support(m, A, TA, d);
-  r.b = support(m, B, TB, v3_neg(d));
+#pragma unroll 1
+  for (int side = 0; side < 2; ++side) { /* one copy of the support code for both shapes */
+    const CShape sh = side ? *B : *A;
+    const pose T = side ? *TB : *TA;
+    const v3 p = support(m, &sh, &T, side ? v3_neg(d) : d);
+    if (side) r.b = p; else r.a = p;
+  }
   r.w = v3_sub(r.a, r.b);
   return r;
 }
@@ -381,37 +542,53 @@ MSK_DEV v3 closest_tri(v3 a, v3 b, v3 c, float* bary, int* mask) {
   return v3_madd(v3_madd(a, ab, v), ac, w);
 }
 
+/* The simplex (<= 4 vertices) is kept in registers as four named slots; the slot shuffles of the serial code
+ * (s[m] = s[i] for ascending i >= m) become selects. */
+struct Simplex { mvert s0, s1, s2, s3; };
+MSK_DEV mvert simplex_get(const Simplex& S, int i) { return i == 0 ? S.s0 : (i == 1 ? S.s1 : (i == 2 ? S.s2 : S.s3)); }
+MSK_DEV void simplex_set(Simplex& S, int i, const mvert& v) {
+  if (i == 0) S.s0 = v; else if (i == 1) S.s1 = v; else if (i == 2) S.s2 = v; else S.s3 = v;
+}
+MSK_DEV void bary_set(float* bary, int i, float x) {
+  if (i == 0) bary[0] = x; else if (i == 1) bary[1] = x; else if (i == 2) bary[2] = x; else bary[3] = x;
+}
+
 /* reduce the simplex to the sub-simplex closest to the origin; returns 1 if the origin is enclosed */
-MSK_DEV int simplex_closest(mvert* s, int* n, v3* v, float* bary) {
-  if (*n == 1) { *v = s[0].w; bary[0] = 1; return 0; }
+MSK_DEV int simplex_closest(Simplex& S, int* n, v3* v, float* bary) {
+  if (*n == 1) { *v = S.s0.w; bary[0] = 1; return 0; }
   if (*n == 2) {
-    v3 ab = v3_sub(s[1].w, s[0].w);
-    float t = -v3_dot(s[0].w, ab);
+    v3 ab = v3_sub(S.s1.w, S.s0.w);
+    float t = -v3_dot(S.s0.w, ab);
     float l2 = v3_len2(ab);
-    if (t <= 0.0f || l2 < 1e-20f) { *n = 1; *v = s[0].w; bary[0] = 1; return 0; }
-    if (t >= l2) { s[0] = s[1]; *n = 1; *v = s[0].w; bary[0] = 1; return 0; }
+    if (t <= 0.0f || l2 < 1e-20f) { *n = 1; *v = S.s0.w; bary[0] = 1; return 0; }
+    if (t >= l2) { S.s0 = S.s1; *n = 1; *v = S.s0.w; bary[0] = 1; return 0; }
     t /= l2;
     bary[0] = 1.0f - t; bary[1] = t;
-    *v = v3_madd(s[0].w, ab, t);
+    *v = v3_madd(S.s0.w, ab, t);
     return 0;
   }
   if (*n == 3) {
     float bc[3]; int mask;
-    *v = closest_tri(s[0].w, s[1].w, s[2].w, bc, &mask);
-    int m = 0;
+    *v = closest_tri(S.s0.w, S.s1.w, S.s2.w, bc, &mask);
+    const mvert t[3] = {S.s0, S.s1, S.s2};
+    int mm = 0;
+#pragma unroll
     for (int i = 0; i < 3; ++i)
-      if (mask & (1 << i)) { s[m] = s[i]; bary[m] = bc[i]; m++; }
-    *n = m;
+      if (mask & (1 << i)) { simplex_set(S, mm, t[i]); bary_set(bary, mm, bc[i]); mm++; }
+    *n = mm;
     return 0;
   }
   /* tetrahedron: test the four faces */
-  const int F[4][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 3, 1}, {1, 2, 3, 0}};
   float bestd = 3.0e38f;
   int bestf = -1, bestmask = 0;
-  float bestb[3];
+  float bestb[3] = {0.0f, 0.0f, 0.0f};
   v3 bestv = v3_make(0, 0, 0);
+  const mvert q[4] = {S.s0, S.s1, S.s2, S.s3};
+#pragma unroll
   for (int f = 0; f < 4; ++f) {
-    v3 a = s[F[f][0]].w, b = s[F[f][1]].w, c = s[F[f][2]].w, d = s[F[f][3]].w;
+    /* faces {0,1,2|3}, {0,1,3|2}, {0,2,3|1}, {1,2,3|0} */
+    const int f0 = (f == 3) ? 1 : 0, f1 = (f < 2) ? 1 : 2, f2 = (f == 0) ? 2 : 3, f3 = 3 - f;
+    v3 a = q[f0].w, b = q[f1].w, c = q[f2].w, d = q[f3].w;
     v3 nrm = v3_cross(v3_sub(b, a), v3_sub(c, a));
     float sd = v3_dot(nrm, v3_sub(d, a));  /* side of the opposite vertex */
     float so = v3_dot(nrm, v3_neg(a));     /* side of the origin */
@@ -424,55 +601,68 @@ MSK_DEV int simplex_closest(mvert* s, int* n, v3* v, float* bary) {
     if (d2 < bestd) { bestd = d2; bestf = f; bestmask = mask; bestv = p; bestb[0] = bc[0]; bestb[1] = bc[1]; bestb[2] = bc[2]; }
   }
   if (bestf < 0) return 1;
-  mvert t[3] = {s[F[bestf][0]], s[F[bestf][1]], s[F[bestf][2]]};
-  int m = 0;
+  const int g0 = (bestf == 3) ? 1 : 0, g1 = (bestf < 2) ? 1 : 2, g2 = (bestf == 0) ? 2 : 3;
+  const mvert t[3] = {simplex_get(S, g0), simplex_get(S, g1), simplex_get(S, g2)};
+  int mm = 0;
+#pragma unroll
   for (int i = 0; i < 3; ++i)
-    if (bestmask & (1 << i)) { s[m] = t[i]; bary[m] = bestb[i]; m++; }
-  *n = m;
+    if (bestmask & (1 << i)) { simplex_set(S, mm, t[i]); bary_set(bary, mm, bestb[i]); mm++; }
+  *n = mm;
   *v = bestv;
   return 0;
 }
 
+/* EPA polytope in the group's LDS workspace: every lane of the group runs the same bookkeeping on the same
+ * values (lane 0 stores), the support calls inside are the split ones */
 typedef struct { int i[3]; v3 n; float d; int alive; } epa_face;
 
-MSK_DEV int epa_make_face(const mvert* vs, epa_face* f, int a, int b, int c) {
-  f->i[0] = a; f->i[1] = b; f->i[2] = c;
+MSK_DEV void lds_put_mvert(const CCtx& m, mvert* dst, const mvert& v) { if (m.gl == 0) *dst = v; }
+
+MSK_DEV int epa_make_face(const CCtx& m, const mvert* vs, epa_face* f, int a, int b, int c) {
   v3 nrm = v3_cross(v3_sub(vs[b].w, vs[a].w), v3_sub(vs[c].w, vs[a].w));
   float l = v3_len(nrm);
-  f->alive = 1;
-  if (l < 1e-12f) { f->n = v3_make(0, 0, 0); f->d = 3.0e38f; return 0; }
-  f->n = v3_scale(nrm, 1.0f / l);
-  f->d = v3_dot(f->n, vs[a].w);
-  return 1;
+  epa_face r;
+  r.i[0] = a; r.i[1] = b; r.i[2] = c;
+  r.alive = 1;
+  int ok = 1;
+  if (l < 1e-12f) { r.n = v3_make(0, 0, 0); r.d = 3.0e38f; ok = 0; }
+  else { r.n = v3_scale(nrm, 1.0f / l); r.d = v3_dot(r.n, vs[a].w); }
+  if (m.gl == 0) *f = r;
+  return ok;
 }
 
 /* penetration of two overlapping convex shapes; starts from the GJK simplex */
-MSK_DEV int epa(const CCtx& m, const DShape* A, const pose* TA, const DShape* B, const pose* TB, mvert* simplex, int ns,
+MSK_DEV int epa(const CCtx& m, const CShape* A, const pose* TA, const CShape* B, const pose* TB, const Simplex& S, int ns,
                v3* n_out, float* depth_out, v3* wa, v3* wb) {
-  mvert vs[ORC_EPA_MAXV];
-  epa_face fs[ORC_EPA_MAXF];
+  mvert* vs = (mvert*)(m.we + WE_VS);
+  epa_face* fs = (epa_face*)(m.we + WE_FS);
+  int* edges = (int*)(m.we + WE_EDGES);
+  mvert* cand_ = (mvert*)(m.we + WE_CAND);
   int nv = 0, nf = 0;
   /* grow a degenerate simplex into a tetrahedron with axis-direction supports */
-  mvert cand_[10];
   int ncand = 0;
-  for (int i = 0; i < ns; ++i) cand_[ncand++] = simplex[i];
+  for (int i = 0; i < ns; ++i) lds_put_mvert(m, &cand_[ncand++], simplex_get(S, i));
   if (ns < 4) {
     const float D[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
-    for (int k = 0; k < 6; ++k) cand_[ncand++] = msupport(m, A, TA, B, TB, v3_make(D[k][0], D[k][1], D[k][2]));
+    for (int k = 0; k < 6; ++k) lds_put_mvert(m, &cand_[ncand++], msupport(m, A, TA, B, TB, v3_make(D[k][0], D[k][1], D[k][2])));
   }
-  vs[0] = cand_[0];
+  grp_sync();
+  lds_put_mvert(m, &vs[0], cand_[0]);
+  grp_sync();
   {
     int b1 = -1; float bd = 1e-12f;
     for (int i = 1; i < ncand; ++i) { float d = v3_len2(v3_sub(cand_[i].w, vs[0].w)); if (d > bd) { bd = d; b1 = i; } }
     if (b1 < 0) return 0;
-    vs[1] = cand_[b1];
+    lds_put_mvert(m, &vs[1], cand_[b1]);
+    grp_sync();
     int b2 = -1; bd = 1e-14f;
     for (int i = 1; i < ncand; ++i) {
       float d = v3_len2(v3_cross(v3_sub(vs[1].w, vs[0].w), v3_sub(cand_[i].w, vs[0].w)));
       if (d > bd) { bd = d; b2 = i; }
     }
     if (b2 < 0) return 0;
-    vs[2] = cand_[b2];
+    lds_put_mvert(m, &vs[2], cand_[b2]);
+    grp_sync();
     v3 nrm = v3_cross(v3_sub(vs[1].w, vs[0].w), v3_sub(vs[2].w, vs[0].w));
     int b3 = -1; float bv = 1e-16f;
     for (int i = 1; i < ncand; ++i) {
@@ -484,17 +674,25 @@ MSK_DEV int epa(const CCtx& m, const DShape* A, const pose* TA, const DShape* B,
       mvert p = msupport(m, A, TA, B, TB, nrm), q = msupport(m, A, TA, B, TB, v3_neg(nrm));
       float dp = fabsf(v3_dot(nrm, v3_sub(p.w, vs[0].w))), dq = fabsf(v3_dot(nrm, v3_sub(q.w, vs[0].w)));
       if (fmaxf(dp, dq) < 1e-16f) return 0;
-      vs[3] = (dp > dq) ? p : q;
-    } else vs[3] = cand_[b3];
+      lds_put_mvert(m, &vs[3], (dp > dq) ? p : q);
+    } else lds_put_mvert(m, &vs[3], cand_[b3]);
+    grp_sync();
     nv = 4;
     /* orient so that face normals point away from the 4th vertex */
     v3 n012 = v3_cross(v3_sub(vs[1].w, vs[0].w), v3_sub(vs[2].w, vs[0].w));
-    if (v3_dot(n012, v3_sub(vs[3].w, vs[0].w)) > 0.0f) { mvert t = vs[1]; vs[1] = vs[2]; vs[2] = t; }
-    epa_make_face(vs, &fs[0], 0, 1, 2);
-    epa_make_face(vs, &fs[1], 0, 3, 1);
-    epa_make_face(vs, &fs[2], 0, 2, 3);
-    epa_make_face(vs, &fs[3], 1, 3, 2);
+    if (v3_dot(n012, v3_sub(vs[3].w, vs[0].w)) > 0.0f) {
+      const mvert t1 = vs[1], t2 = vs[2];
+      grp_sync();
+      lds_put_mvert(m, &vs[1], t2);
+      lds_put_mvert(m, &vs[2], t1);
+      grp_sync();
+    }
+    epa_make_face(m, vs, &fs[0], 0, 1, 2);
+    epa_make_face(m, vs, &fs[1], 0, 3, 1);
+    epa_make_face(m, vs, &fs[2], 0, 2, 3);
+    epa_make_face(m, vs, &fs[3], 1, 3, 2);
     nf = 4;
+    grp_sync();
   }
   int bestf = 0;
   for (int it = 0; it < ORC_EPA_ITERS; ++it) {
@@ -503,33 +701,46 @@ MSK_DEV int epa(const CCtx& m, const DShape* A, const pose* TA, const DShape* B,
     for (int f = 0; f < nf; ++f)
       if (fs[f].alive && fs[f].d < bd) { bd = fs[f].d; bestf = f; }
     if (bestf < 0) return 0;
-    mvert w = msupport(m, A, TA, B, TB, fs[bestf].n);
-    float dist = v3_dot(w.w, fs[bestf].n);
-    if (dist - fs[bestf].d < 2e-5f || nv >= ORC_EPA_MAXV) break;
+    const v3 bn = fs[bestf].n;
+    const float bdist = fs[bestf].d;
+    mvert w = msupport(m, A, TA, B, TB, bn);
+    float dist = v3_dot(w.w, bn);
+    if (dist - bdist < 2e-5f || nv >= ORC_EPA_MAXV) break;
     /* remove faces visible from w, collect the horizon */
-    int edges[ORC_EPA_MAXF][2];
     int ne = 0;
     for (int f = 0; f < nf; ++f) {
       if (!fs[f].alive) continue;
-      if (v3_dot(fs[f].n, v3_sub(w.w, vs[fs[f].i[0]].w)) > 0.0f) {
-        fs[f].alive = 0;
+      const int fi0 = fs[f].i[0], fi1 = fs[f].i[1], fi2 = fs[f].i[2];
+      if (v3_dot(fs[f].n, v3_sub(w.w, vs[fi0].w)) > 0.0f) {
+        grp_sync();
+        if (m.gl == 0) fs[f].alive = 0;
         for (int k = 0; k < 3; ++k) {
-          int a = fs[f].i[k], b = fs[f].i[(k + 1) % 3];
+          int a = (k == 0) ? fi0 : ((k == 1) ? fi1 : fi2), b = (k == 0) ? fi1 : ((k == 1) ? fi2 : fi0);
           int found = -1;
-          for (int q = 0; q < ne; ++q) if (edges[q][0] == b && edges[q][1] == a) { found = q; break; }
-          if (found >= 0) { edges[found][0] = edges[ne - 1][0]; edges[found][1] = edges[ne - 1][1]; ne--; }
-          else if (ne < ORC_EPA_MAXF) { edges[ne][0] = a; edges[ne][1] = b; ne++; }
+          for (int q = 0; q < ne; ++q) if (edges[q * 2] == b && edges[q * 2 + 1] == a) { found = q; break; }
+          grp_sync();
+          if (found >= 0) {
+            if (m.gl == 0) { edges[found * 2] = edges[(ne - 1) * 2]; edges[found * 2 + 1] = edges[(ne - 1) * 2 + 1]; }
+            ne--;
+          } else if (ne < ORC_EPA_MAXF) {
+            if (m.gl == 0) { edges[ne * 2] = a; edges[ne * 2 + 1] = b; }
+            ne++;
+          }
+          grp_sync();
         }
       }
     }
     if (ne == 0) break;
-    vs[nv] = w;
+    lds_put_mvert(m, &vs[nv], w);
+    grp_sync();
     int stop = 0;
     for (int q = 0; q < ne; ++q) {
       int slot = -1;
       for (int f = 0; f < nf; ++f) if (!fs[f].alive) { slot = f; break; }
       if (slot < 0) { if (nf >= ORC_EPA_MAXF) { stop = 1; break; } slot = nf++; }
-      epa_make_face(vs, &fs[slot], edges[q][0], edges[q][1], nv);
+      grp_sync();
+      epa_make_face(m, vs, &fs[slot], edges[q * 2], edges[q * 2 + 1], nv);
+      grp_sync();
     }
     nv++;
     if (stop) break;
@@ -553,16 +764,17 @@ MSK_DEV int epa(const CCtx& m, const DShape* A, const pose* TA, const DShape* B,
 }
 
 /* GJK distance + EPA. Returns 0 if farther apart than margin. n from B to A. */
-MSK_DEV int gjk_epa(const CCtx& m, const DShape* A, const pose* TA, const DShape* B, const pose* TB, v3 ca, v3 cb, float margin,
+MSK_DEV int gjk_epa(const CCtx& m, const CShape* A, const pose* TA, const CShape* B, const pose* TB, v3 ca, v3 cb, float margin,
                    v3* n_out, float* sep_out, v3* wa, v3* wb) {
-  mvert s[4];
+  Simplex S;
   float bary[4] = {1, 0, 0, 0};
   int n = 0;
   v3 d0 = v3_sub(ca, cb);
   if (v3_len2(d0) < 1e-12f) d0 = v3_make(1, 0, 0);
-  s[0] = msupport(m, A, TA, B, TB, v3_neg(d0));
+  S.s0 = msupport(m, A, TA, B, TB, v3_neg(d0));
+  S.s1 = S.s0; S.s2 = S.s0; S.s3 = S.s0;
   n = 1;
-  v3 v = s[0].w;
+  v3 v = S.s0.w;
   float vv = v3_len2(v);
   int hit = 0;
   for (int it = 0; it < ORC_GJK_ITERS; ++it) {
@@ -572,11 +784,13 @@ MSK_DEV int gjk_epa(const CCtx& m, const DShape* A, const pose* TA, const DShape
     if (vw > 0.0f && vw * vw > margin * margin * vv) return 0; /* separated by more than margin */
     if (vv - vw <= 1e-6f * vv) break;                          /* converged */
     int dupl = 0;
-    for (int i = 0; i < n; ++i) if (v3_len2(v3_sub(s[i].w, w.w)) < 1e-14f) dupl = 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i < n && v3_len2(v3_sub(simplex_get(S, i).w, w.w)) < 1e-14f) dupl = 1;
     if (dupl) break;
-    s[n++] = w;
+    simplex_set(S, n, w);
+    n++;
     v3 nvv;
-    if (simplex_closest(s, &n, &nvv, bary)) { hit = 1; break; }
+    if (simplex_closest(S, &n, &nvv, bary)) { hit = 1; break; }
     float nvl = v3_len2(nvv);
     if (nvl >= vv) break; /* no progress (numerical) */
     v = nvv;
@@ -587,15 +801,20 @@ MSK_DEV int gjk_epa(const CCtx& m, const DShape* A, const pose* TA, const DShape
     if (dist > margin) return 0;
     if (dist > 1e-5f) {
       v3 pa = v3_make(0, 0, 0), pb = v3_make(0, 0, 0);
-      for (int i = 0; i < n; ++i) { pa = v3_madd(pa, s[i].a, bary[i]); pb = v3_madd(pb, s[i].b, bary[i]); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < n) { const mvert s = simplex_get(S, i); pa = v3_madd(pa, s.a, bary[i]); pb = v3_madd(pb, s.b, bary[i]); }
       *n_out = v3_scale(v, 1.0f / dist);
       *sep_out = dist;
       *wa = pa; *wb = pb;
       return 1;
     }
   }
-  float depth;
-  if (!epa(m, A, TA, B, TB, s, n, n_out, &depth, wa, wb)) {
+  float depth = 0.0f;
+  int ok = 0;
+  for (int g = 0; g < 64 / NPG; ++g) /* one EPA workspace per wave: the groups that got here take turns */
+    if (g == m.grp) ok = epa(m, A, TA, B, TB, S, n, n_out, &depth, wa, wb);
+  if (!ok) {
     /* degenerate: fall back to the centre direction with zero separation */
     *n_out = v3_normalize(d0);
     *sep_out = 0.0f;
@@ -608,30 +827,42 @@ MSK_DEV int gjk_epa(const CCtx& m, const DShape* A, const pose* TA, const DShape
 }
 
 /* ---- plane ----------------------------------------------------------------------------- */
-MSK_DEV int plane_convex(const CCtx& m, const DShape* P, const pose* TP, const DShape* C, const pose* TC, float margin,
+MSK_DEV int plane_convex(const CCtx& m, const CShape* P, const pose* TP, const CShape* C, const pose* TC, float margin,
                         int plane_is_a, DContactOut* out) {
   v3 pn = quat_rotate(TP->q, v3_make(1, 0, 0));
   float pd = v3_dot(pn, TP->p);
   v3 t1, t2;
   msk_tangents(pn, &t1, &t2);
-  cand cs[MSK_MAX_HULL_VERTS];
+  cand* cs = (cand*)(m.ws + WS_CS);
   int nc = 0;
-  int nv = shape_nverts(C);
-  for (int i = 0; i < nv; ++i) {
-    v3 w = pose_apply(*TC, shape_vert(m, C, i));
-    float sep = v3_dot(pn, w) - pd;
-    if (sep > margin) continue;
-    cs[nc].u = v3_dot(w, t1); cs[nc].v = v3_dot(w, t2); cs[nc].hm = pd + 0.5f * sep; cs[nc].sep = sep;
-    nc++;
+  const int nv = shape_nverts(C);
+  /* vertices in rounds of 16, candidates appended in vertex order by ballot rank */
+  for (int i0 = 0; i0 < nv; i0 += NPG) {
+    const int i = i0 + m.gl;
+    bool keep = false;
+    cand c;
+    c.u = c.v = c.hm = c.sep = 0.0f;
+    if (i < nv) {
+      v3 w = pose_apply(*TC, shape_vert(m, C, i));
+      float sep = v3_dot(pn, w) - pd;
+      if (!(sep > margin)) { keep = true; c.u = v3_dot(w, t1); c.v = v3_dot(w, t2); c.hm = pd + 0.5f * sep; c.sep = sep; }
+    }
+    const unsigned bk = grp_ballot(keep);
+    if (keep) cs[nc + __popc(bk & ((1u << m.gl) - 1u))] = c;
+    nc += __popc(bk);
   }
-  nc = reduce4(cs, nc);
-  for (int i = 0; i < nc; ++i) {
-    out[i].pos = v3_madd(v3_madd(v3_scale(t1, cs[i].u), t2, cs[i].v), pn, cs[i].hm);
-    out[i].n = plane_is_a ? v3_neg(pn) : pn;
-    out[i].sep = cs[i].sep;
+  grp_sync();
+  cand res[4];
+  nc = reduce4(m, cs, nc, res);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k < nc) {
+      out[k].pos = v3_madd(v3_madd(v3_scale(t1, res[k].u), t2, res[k].v), pn, res[k].hm);
+      out[k].n = plane_is_a ? v3_neg(pn) : pn;
+      out[k].sep = res[k].sep;
+    }
   }
   return nc;
 }
-
 
 #endif

@@ -14,6 +14,7 @@
 #define MSK_KERNELS_H
 
 #include "msk_collide.h"
+#include "msk_collide_lane.h"
 #include "msk_solve.h"
 #include "msk_dynamics.h"
 
@@ -134,68 +135,99 @@ __global__ void __launch_bounds__(64) k_classify(const DModel* __restrict__ m, D
 }
 
 #define NP_GROUP_MAX 16
-/* `group` = envs whose lists one wave walks: 16 at 4096 envs (dense waves: the launch is bound by issue slots and
- * memory waits), fewer when there are few envs (then the launch is bound by its slowest wave) */
-__global__ void __launch_bounds__(64) k_narrowphase(const DModel* __restrict__ m, DState st, const int group) {
-  __shared__ int pref[NP_GROUP_MAX + 1];
-  __shared__ v3 s_verts[MSK_MAX_SHAPES * 16];   /* the template's hull vertex pool (12 KB) */
-  for (int i = threadIdx.x; i < m->nverts_total; i += 64) s_verts[i] = m->verts[i];
-  CCtx cx;
-  cx.verts = s_verts;
-  const int type = blockIdx.y, e0 = blockIdx.x * group, lane = threadIdx.x;
+/* One wavefront per (env group, narrowphase list).
+ *   plane and box-box lists (blockIdx.y = 0, 1): one lane per surviving pair of `group` envs (msk_collide_lane.h) — the
+ *     lists are long, a wave holds up to 64 pairs and fetches the per-pair code once for all of them;
+ *   hull list (blockIdx.y = 2 ..): a 16-lane group per pair (msk_collide.h), four pairs in flight, on a quarter of the
+ *     env group per block — few pairs, each a long chain of support scans over up to 64 vertices.
+ * `group` = 16 at 4096 envs, fewer when there are few envs (then the launch is bound by its slowest wave). */
+template <int TYPE, int LPI>   /* LPI = lanes per item: 1 or NPG */
+MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, const int e0, const int group, int* pref, float* s_ws,
+                              float* s_we) {
+  constexpr int type = TYPE;
+  const int lane = threadIdx.x;
   const float margin = 2.0f * m->cfg.contact_offset;
-  if (lane == 0) {
-    int acc = 0;
-    for (int j = 0; j < NP_GROUP_MAX; ++j) {
-      pref[j] = acc;
-      acc += (j < group && e0 + j < m->N) ? st.np_count[(size_t)(e0 + j) * 4 + type] : 0;
+  { /* exclusive prefix of the group's list lengths: one load per lane, a 16-lane scan */
+    int c = (lane < group && e0 + lane < m->N) ? st.np_count[(size_t)(e0 + lane) * 4 + type] : 0;
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < NP_GROUP_MAX; d <<= 1) {
+      const int o = __shfl_up(incl, d, NP_GROUP_MAX);
+      if ((lane & (NP_GROUP_MAX - 1)) >= d) incl += o;
     }
-    pref[NP_GROUP_MAX] = acc;
+    if (lane < NP_GROUP_MAX) pref[lane] = incl - c;
+    if (lane == NP_GROUP_MAX - 1) pref[NP_GROUP_MAX] = incl;
   }
   __syncthreads();
   const int count = pref[NP_GROUP_MAX];
-  for (int idx = lane; idx < count; idx += 64) {
+  for (int idx = lane / LPI; idx < count; idx += 64 / LPI) {
   int j = 0;
 #pragma unroll
   for (int k = 1; k < NP_GROUP_MAX; ++k) j += (k < group && idx >= pref[k]) ? 1 : 0;
   const int e = e0 + j;
   const int pi = st.np_items[((size_t)e * NP_TYPES + type) * m->np + (idx - pref[j])];
   float* E = EREC(st, m, e);
-  const DShape* A = &m->shapes[m->pairs[pi].sa];
-  const DShape* B = &m->shapes[m->pairs[pi].sb];
-  pose TA = shape_pose_dev(m, E, A), TB = shape_pose_dev(m, E, B);
+  const DShape* dA = &m->shapes[m->pairs[pi].sa];
+  const DShape* dB = &m->shapes[m->pairs[pi].sb];
+  pose TA = shape_pose_dev(m, E, dA), TB = shape_pose_dev(m, E, dB);
+  CShape cA = cshape_of(dA), cB = cshape_of(dB);
+  if (TYPE == NP_BOXBOX) cA.type = cB.type = MSK_SHAPE_BOX;   /* known: lets the compiler drop the hull paths */
+  const CShape* A = &cA;
+  const CShape* B = &cB;
 #ifdef MSK_PROFILE_PHASES
   long long tq[5]; tq[0] = (long long)__builtin_readcyclecounter(); tq[1] = tq[2] = tq[0];
 #endif
-  DContactOut out[4];
+  v3 opos[4], onrm = v3_make(0, 0, 1);
+  float osep[4];
   int n = 0;
-  if (type == NP_PLANE) {
-    const int pa = A->type == MSK_SHAPE_PLANE;
-    n = plane_convex(cx, pa ? A : B, pa ? &TA : &TB, pa ? B : A, pa ? &TB : &TA, margin, pa, out);
-  } else {
-    v3 nrm, wa, wb;
-    float sep;
-    int hit;
-    if (type == NP_BOXBOX) {
-      hit = sat_box_box(A, &TA, B, &TB, margin, &nrm, &sep);
-      if (hit) {
-        wa = support(cx, A, &TA, v3_neg(nrm));
-        wb = support(cx, B, &TB, nrm);
-      }
+  bool writer = true;
+  if constexpr (LPI == 1) {
+    perlane::CCtx cx;
+    cx.verts = m->verts;
+    perlane::DContactOut out[4];
+    if (type == NP_PLANE) {
+      const int pa = A->type == MSK_SHAPE_PLANE;
+      n = perlane::plane_convex(cx, pa ? A : B, pa ? &TA : &TB, pa ? B : A, pa ? &TB : &TA, margin, pa, out);
     } else {
-      v3 ca, ha, cb, hb;
-      world_aabb(A, &TA, &ca, &ha);
-      world_aabb(B, &TB, &cb, &hb);
-      hit = gjk_epa(cx, A, &TA, B, &TB, ca, cb, margin, &nrm, &sep, &wa, &wb);
+      v3 nrm;
+      float sep;
+      if (perlane::sat_box_box(A, &TA, B, &TB, margin, &nrm, &sep)) {
+        const v3 wa = perlane::support(cx, A, &TA, v3_neg(nrm)), wb = perlane::support(cx, B, &TB, nrm);
+#ifdef MSK_PROFILE_PHASES
+        tq[1] = (long long)__builtin_readcyclecounter();
+#endif
+        n = perlane::build_manifold(cx, A, &TA, B, &TB, nrm, margin, wa, wb, sep, out);
+      }
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { opos[k] = out[k].pos; osep[k] = out[k].sep; }
+    onrm = out[0].n;
+  } else {
+    CCtx cx;
+    cx.verts = m->verts;
+    cx.ws = s_ws + (lane / NPG) * WS_TOTAL;
+    cx.we = s_we;
+    cx.gl = lane % NPG;
+    cx.grp = lane / NPG;
+    cx.dbg = nullptr;
+    DContactOut out[4];
+    v3 nrm, wa, wb, ca, ha, cb, hb;
+    float sep;
+    world_aabb(dA, &TA, &ca, &ha);
+    world_aabb(dB, &TB, &cb, &hb);
+    const int hit = gjk_epa(cx, A, &TA, B, &TB, ca, cb, margin, &nrm, &sep, &wa, &wb);
 #ifdef MSK_PROFILE_PHASES
     tq[1] = (long long)__builtin_readcyclecounter();
 #endif
     if (hit) n = build_manifold(cx, A, &TA, B, &TB, nrm, margin, wa, wb, sep, out);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { opos[k] = out[k].pos; osep[k] = out[k].sep; }
+    onrm = out[0].n;
+    writer = cx.gl == 0;   /* the group's first lane owns the contact slot */
   }
 #ifdef MSK_PROFILE_PHASES
   tq[2] = (long long)__builtin_readcyclecounter();
-  { /* per type: [0] items, [1] sum primary, [2] max primary, [3] sum manifold, [4] max manifold, [5] hits */
+  if (writer) { /* per type: [0] items, [1] sum primary, [2] max primary, [3] sum manifold, [4] max manifold, [5] hits */
     unsigned long long* d = (unsigned long long*)st.dbg + (size_t)m->N * 8 + type * 8;
     atomicAdd(&d[0], 1ull);
     atomicAdd(&d[1], (unsigned long long)(tq[1] - tq[0])); atomicMax(&d[2], (unsigned long long)(tq[1] - tq[0]));
@@ -203,47 +235,72 @@ __global__ void __launch_bounds__(64) k_narrowphase(const DModel* __restrict__ m
     if (n > 0) atomicAdd(&d[5], 1ull);
   }
 #endif
+  if (!writer) continue;
   /* warm start from the previous contents of this pair's slot, then overwrite it */
   int* cntp = st.ct_cnt + (size_t)e * m->npp + pi;
   float* rec = st.ct_rec + ((size_t)e * m->npp + pi) * MSK_CT_REC;
   const int nprev = *cntp;
   v3 ppos[4];
   float plam[4][3];
-  for (int j = 0; j < 4; ++j) {
-    if (j < nprev) {
-      ppos[j] = v3_make(rec[4 + j * 3 + 0], rec[4 + j * 3 + 1], rec[4 + j * 3 + 2]);
-      for (int a = 0; a < 3; ++a) plam[j][a] = rec[20 + j * 3 + a];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    if (jj < nprev) {
+      ppos[jj] = v3_make(rec[4 + jj * 3 + 0], rec[4 + jj * 3 + 1], rec[4 + jj * 3 + 2]);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) plam[jj][a] = rec[20 + jj * 3 + a];
     }
   }
   if (n == 0 && nprev == 0) continue;
   *cntp = n;
-  if (n > 0) { rec[0] = out[0].n.x; rec[1] = out[0].n.y; rec[2] = out[0].n.z; }
-  for (int k = 0; k < n; ++k) {
+  if (n > 0) { rec[0] = onrm.x; rec[1] = onrm.y; rec[2] = onrm.z; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k >= n) continue;
     float lam[3] = {0.0f, 0.0f, 0.0f};
     int best = -1;
     float bd = MSK_WARM_DIST * MSK_WARM_DIST;
-    for (int j = 0; j < nprev; ++j) {
-      float d2 = v3_len2(v3_sub(ppos[j], out[k].pos));
-      if (d2 < bd) { bd = d2; best = j; }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      if (jj >= nprev) continue;
+      float d2 = v3_len2(v3_sub(ppos[jj], opos[k]));
+      if (d2 < bd) { bd = d2; best = jj; }
     }
-    if (best >= 0)
-      for (int a = 0; a < 3; ++a) lam[a] = MSK_WARM_FACTOR * plam[best][a];
-    rec[4 + k * 3 + 0] = out[k].pos.x;
-    rec[4 + k * 3 + 1] = out[k].pos.y;
-    rec[4 + k * 3 + 2] = out[k].pos.z;
-    rec[16 + k] = out[k].sep - m->cfg.rest_offset * 2.0f;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      if (best == jj) { lam[0] = MSK_WARM_FACTOR * plam[jj][0]; lam[1] = MSK_WARM_FACTOR * plam[jj][1]; lam[2] = MSK_WARM_FACTOR * plam[jj][2]; }
+    rec[4 + k * 3 + 0] = opos[k].x;
+    rec[4 + k * 3 + 1] = opos[k].y;
+    rec[4 + k * 3 + 2] = opos[k].z;
+    rec[16 + k] = osep[k] - m->cfg.rest_offset * 2.0f;
+#pragma unroll
     for (int a = 0; a < 3; ++a) rec[20 + k * 3 + a] = lam[a];
   }
   }
-  /* the block (of the NP_TYPES working on this env group) that finishes last sorts the group's envs into the solver lists */
+}
+
+/* blockIdx.y: 0 = plane list, 1 = box-box list of env group blockIdx.x; 2 + q = hull list of quarter q of the group.
+ * Per 64 consecutive envs, the block that finishes last sorts them into the solver lists (one wave, one env per lane:
+ * a handful of same-address atomics per 64 envs). */
+__global__ void __launch_bounds__(64) k_narrowphase(const DModel* __restrict__ m, DState st, const int group) {
+  __shared__ int pref[NP_GROUP_MAX + 1];
+  __shared__ float s_ws[(64 / NPG) * WS_TOTAL]; /* the lane groups' workspaces */
+  __shared__ float s_we[WE_TOTAL];              /* the wave's EPA workspace    */
+  const int e0 = blockIdx.x * group;
+  const int gsub = group >= 4 ? group / 4 : 1;
+  if (blockIdx.y == NP_PLANE) narrowphase_body<NP_PLANE, 1>(m, st, e0, group, pref, s_ws, s_we);
+  else if (blockIdx.y == NP_BOXBOX) narrowphase_body<NP_BOXBOX, 1>(m, st, e0, group, pref, s_ws, s_we);
+  else narrowphase_body<NP_GJK, NPG>(m, st, e0 + ((int)blockIdx.y - 2) * gsub, gsub, pref, s_ws, s_we);
   __threadfence();
+  const int chunk = e0 / 64;
+  const int first_blk = (chunk * 64 + group - 1) / group, end_env = min(chunk * 64 + 64, m->N);
+  const int nblk_chunk = (end_env + group - 1) / group - first_blk;
   int done = 0;
-  if (lane == 0) done = atomicAdd(&st.np_done[blockIdx.x], 1);
+  if (threadIdx.x == 0) done = atomicAdd(&st.np_done[chunk], 1);
   done = __builtin_amdgcn_readfirstlane(done);
-  if (done == NP_TYPES - 1) {
+  if (done == nblk_chunk * (int)gridDim.y - 1) {
     __threadfence();
-    if (lane == 0) st.np_done[blockIdx.x] = 0;
-    classify_envs(m, st, e0, group);
+    if (threadIdx.x == 0) st.np_done[chunk] = 0;
+    classify_envs(m, st, chunk * 64, 64);
   }
 }
 

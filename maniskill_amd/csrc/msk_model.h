@@ -88,11 +88,11 @@ struct DState {
   int *ct_cnt;                                 /* [N][npp] */
   float *ct_rec;                               /* [N][npp][MSK_CT_REC] */
   /* solver work lists by LDS capacity class (msk_solve.h): class 0 = packed small launch, 1..3 = one wave per env with
-   * room for cls_cap[] blocks; built by the narrowphase block that finishes an env group last (classify_envs) */
+   * room for cls_cap[] blocks; built by the last narrowphase launch (classify_envs) */
   int *cls_list;                               /* [MSK_SOLVE_CLASSES][N] */
+  int *np_done;                                /* [N]: narrowphase blocks of an env group that have finished (self-resetting) */
   int *cls_count;                              /* [MSK_SOLVE_CLASSES]; zeroed by k_dynamics of the same substep */
   float *a_scratch;                            /* [solver workers][9 * 64 * 64]: A images of class-3 envs */
-  int *np_done;                                /* [N]: narrowphase blocks of an env group that have finished (self-resetting) */
   /* narrowphase work lists per env and type (plane / box-box / GJK): surviving pair indices in pair order */
   int *np_count;                               /* [N][4] */
   int *np_items;                               /* [N][3][np] */

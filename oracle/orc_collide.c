@@ -23,6 +23,7 @@
 #define ORC_EPA_ITERS 32
 #define ORC_EPA_MAXV 40
 #define ORC_EPA_MAXF 96
+#define ORC_CLIP_MAXV 16 /* corners kept while clipping (8 + 8 for convex inputs; the HIP kernel holds one per lane of a 16-lane group) */
 
 /* ---- shape helpers ----------------------------------------------------------------- */
 static pose shape_pose(const orc_ctx* c, const orc_env* e, const orc_shape* sh) {
@@ -181,8 +182,8 @@ static int clip_poly_poly(const p3* subj, int ns, const p3* clip, int nc, float 
       float cp = cross2(ex, ey, P[0] - a->u, P[1] - a->v);
       float cq = cross2(ex, ey, Q[0] - a->u, Q[1] - a->v);
       int pin = cp >= -1e-9f, qin = cq >= -1e-9f;
-      if (pin && no < 24) { ot[no][0] = P[0]; ot[no][1] = P[1]; no++; }
-      if (pin != qin && no < 24) {
+      if (pin && no < ORC_CLIP_MAXV) { ot[no][0] = P[0]; ot[no][1] = P[1]; no++; }
+      if (pin != qin && no < ORC_CLIP_MAXV) {
         float t = cp / (cp - cq);
         ot[no][0] = fmaf(t, Q[0] - P[0], P[0]);
         ot[no][1] = fmaf(t, Q[1] - P[1], P[1]);
