@@ -211,15 +211,30 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
     cx.grp = lane / NPG;
     cx.dbg = nullptr;
     DContactOut out[4];
-    v3 nrm, wa, wb, ca, ha, cb, hb;
-    float sep;
-    world_aabb(dA, &TA, &ca, &ha);
-    world_aabb(dB, &TB, &cb, &hb);
-    const int hit = gjk_epa(cx, A, &TA, B, &TB, ca, cb, margin, &nrm, &sep, &wa, &wb);
+    if (type == NP_PLANE) {
+      const int pa = A->type == MSK_SHAPE_PLANE;
+      n = plane_convex(cx, pa ? A : B, pa ? &TA : &TB, pa ? B : A, pa ? &TB : &TA, margin, pa, out);
+    } else {
+      v3 nrm, wa, wb;
+      float sep;
+      int hit;
+      if (type == NP_BOXBOX) {
+        hit = sat_box_box(A, &TA, B, &TB, margin, &nrm, &sep);
+        if (hit) {
+          wa = support(cx, A, &TA, v3_neg(nrm));
+          wb = support(cx, B, &TB, nrm);
+        }
+      } else {
+        v3 ca, ha, cb, hb;
+        world_aabb(dA, &TA, &ca, &ha);
+        world_aabb(dB, &TB, &cb, &hb);
+        hit = gjk_epa(cx, A, &TA, B, &TB, ca, cb, margin, &nrm, &sep, &wa, &wb);
+      }
 #ifdef MSK_PROFILE_PHASES
-    tq[1] = (long long)__builtin_readcyclecounter();
+      tq[1] = (long long)__builtin_readcyclecounter();
 #endif
-    if (hit) n = build_manifold(cx, A, &TA, B, &TB, nrm, margin, wa, wb, sep, out);
+      if (hit) n = build_manifold(cx, A, &TA, B, &TB, nrm, margin, wa, wb, sep, out);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { opos[k] = out[k].pos; osep[k] = out[k].sep; }
     onrm = out[0].n;
@@ -278,18 +293,29 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
   }
 }
 
-/* blockIdx.y: 0 = plane list, 1 = box-box list of env group blockIdx.x; 2 + q = hull list of quarter q of the group.
+/* blockIdx.y walks [plane | box-box | hull] sub-blocks of env group blockIdx.x: cfg.x/y/z of them, each on an equal
+ * share of the group's envs; box_lpi picks the box-box code (1 lane or 16 lanes per pair).
  * Per 64 consecutive envs, the block that finishes last sorts them into the solver lists (one wave, one env per lane:
  * a handful of same-address atomics per 64 envs). */
-__global__ void __launch_bounds__(64) k_narrowphase(const DModel* __restrict__ m, DState st, const int group) {
+struct NpCfg { int nplane, nbox, nhull, box_lpi; };
+__global__ void __launch_bounds__(64) k_narrowphase(const DModel* __restrict__ m, DState st, const int group, const NpCfg cfg) {
   __shared__ int pref[NP_GROUP_MAX + 1];
   __shared__ float s_ws[(64 / NPG) * WS_TOTAL]; /* the lane groups' workspaces */
   __shared__ float s_we[WE_TOTAL];              /* the wave's EPA workspace    */
   const int e0 = blockIdx.x * group;
-  const int gsub = group >= 4 ? group / 4 : 1;
-  if (blockIdx.y == NP_PLANE) narrowphase_body<NP_PLANE, 1>(m, st, e0, group, pref, s_ws, s_we);
-  else if (blockIdx.y == NP_BOXBOX) narrowphase_body<NP_BOXBOX, 1>(m, st, e0, group, pref, s_ws, s_we);
-  else narrowphase_body<NP_GJK, NPG>(m, st, e0 + ((int)blockIdx.y - 2) * gsub, gsub, pref, s_ws, s_we);
+  int y = blockIdx.y;
+  if (y < cfg.nplane) {
+    const int sub = group / cfg.nplane;
+    narrowphase_body<NP_PLANE, NPG>(m, st, e0 + y * sub, sub, pref, s_ws, s_we);
+  } else if ((y -= cfg.nplane) < cfg.nbox) {
+    const int sub = group / cfg.nbox;
+    if (cfg.box_lpi == 1) narrowphase_body<NP_BOXBOX, 1>(m, st, e0 + y * sub, sub, pref, s_ws, s_we);
+    else narrowphase_body<NP_BOXBOX, NPG>(m, st, e0 + y * sub, sub, pref, s_ws, s_we);
+  } else {
+    y -= cfg.nbox;
+    const int sub = group / cfg.nhull;
+    narrowphase_body<NP_GJK, NPG>(m, st, e0 + y * sub, sub, pref, s_ws, s_we);
+  }
   __threadfence();
   const int chunk = e0 / 64;
   const int first_blk = (chunk * 64 + group - 1) / group, end_env = min(chunk * 64 + 64, m->N);
