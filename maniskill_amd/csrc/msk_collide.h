@@ -325,19 +325,21 @@ MSK_DEV int seg_seg(const CCtx& m, const p3* a, const p3* b, float* out) {
 }
 
 typedef struct { float u, v, hm, sep; } cand;
+/* field-by-field copies: a struct assignment from LDS would be staged through a stack temporary */
+MSK_DEV cand cand_ld(const cand* p) { cand c; c.u = p->u; c.v = p->v; c.hm = p->hm; c.sep = p->sep; return c; }
 
 /* keep at most 4 of the n candidates cs[] (LDS): deepest, farthest from it, and the extremes on both sides of that
  * line; returns them (group-uniform) in res[].  Four group arg-max scans, each over candidates gl, gl + 16, ... */
 MSK_DEV int reduce4(const CCtx& m, const cand* cs, int n, cand res[4]) {
   if (n <= 4) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) if (i < n) res[i] = cs[i];
+    for (int i = 0; i < 4; ++i) if (i < n) res[i] = cand_ld(&cs[i]);
     return n;
   }
   int i0 = NO_INDEX; float b0 = -3.0e38f;  /* deepest = max of -sep; first among equals */
   for (int i = m.gl; i < n; i += NPG) { const float s = -cs[i].sep; if (s > b0 || i0 == NO_INDEX) { b0 = s; i0 = i; } }
   grp_argmax(b0, i0);
-  const cand c0 = cs[i0];
+  const cand c0 = cand_ld(&cs[i0]);
   int i1 = NO_INDEX; float b1 = -1.0f;
   for (int i = m.gl; i < n; i += NPG) {
     if (i == i0) continue;
@@ -346,7 +348,7 @@ MSK_DEV int reduce4(const CCtx& m, const cand* cs, int n, cand res[4]) {
     if (d > b1) { b1 = d; i1 = i; }
   }
   grp_argmax(b1, i1);
-  const cand c1 = cs[i1];
+  const cand c1 = cand_ld(&cs[i1]);
   float ex = c1.u - c0.u, ey = c1.v - c0.v;
   int i2 = NO_INDEX, i3 = NO_INDEX; float bp = 0.0f, bn = 0.0f;   /* bn holds -cr: arg-max of it = arg-min of cr */
   for (int i = m.gl; i < n; i += NPG) {
@@ -359,8 +361,8 @@ MSK_DEV int reduce4(const CCtx& m, const cand* cs, int n, cand res[4]) {
   grp_argmax(bn, i3);
   int k = 2;
   res[0] = c0; res[1] = c1;
-  if (i2 != NO_INDEX) { res[2] = cs[i2]; k = 3; }
-  if (i3 != NO_INDEX) { const cand c = cs[i3]; if (k == 2) res[2] = c; else res[3] = c; k++; }
+  if (i2 != NO_INDEX) { res[2] = cand_ld(&cs[i2]); k = 3; }
+  if (i3 != NO_INDEX) { const cand c = cand_ld(&cs[i3]); if (k == 2) res[2] = c; else res[3] = c; k++; }
   return k;
 }
 
@@ -545,9 +547,16 @@ MSK_DEV v3 closest_tri(v3 a, v3 b, v3 c, float* bary, int* mask) {
 /* The simplex (<= 4 vertices) is kept in registers as four named slots; the slot shuffles of the serial code
  * (s[m] = s[i] for ascending i >= m) become selects. */
 struct Simplex { mvert s0, s1, s2, s3; };
-MSK_DEV mvert simplex_get(const Simplex& S, int i) { return i == 0 ? S.s0 : (i == 1 ? S.s1 : (i == 2 ? S.s2 : S.s3)); }
+/* component-wise selects: struct-valued ternaries would go through stack temporaries (scratch memory) */
+MSK_DEV v3 v3_sel(bool c, v3 a, v3 b) { return v3_make(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+MSK_DEV mvert mv_sel(bool c, const mvert& a, const mvert& b) {
+  mvert r;
+  r.w = v3_sel(c, a.w, b.w); r.a = v3_sel(c, a.a, b.a); r.b = v3_sel(c, a.b, b.b);
+  return r;
+}
+MSK_DEV mvert simplex_get(const Simplex& S, int i) { return mv_sel(i == 0, S.s0, mv_sel(i == 1, S.s1, mv_sel(i == 2, S.s2, S.s3))); }
 MSK_DEV void simplex_set(Simplex& S, int i, const mvert& v) {
-  if (i == 0) S.s0 = v; else if (i == 1) S.s1 = v; else if (i == 2) S.s2 = v; else S.s3 = v;
+  S.s0 = mv_sel(i == 0, v, S.s0); S.s1 = mv_sel(i == 1, v, S.s1); S.s2 = mv_sel(i == 2, v, S.s2); S.s3 = mv_sel(i == 3, v, S.s3);
 }
 MSK_DEV void bary_set(float* bary, int i, float x) {
   if (i == 0) bary[0] = x; else if (i == 1) bary[1] = x; else if (i == 2) bary[2] = x; else bary[3] = x;
@@ -616,7 +625,14 @@ MSK_DEV int simplex_closest(Simplex& S, int* n, v3* v, float* bary) {
  * values (lane 0 stores), the support calls inside are the split ones */
 typedef struct { int i[3]; v3 n; float d; int alive; } epa_face;
 
-MSK_DEV void lds_put_mvert(const CCtx& m, mvert* dst, const mvert& v) { if (m.gl == 0) *dst = v; }
+MSK_DEV void lds_put_mvert(const CCtx& m, mvert* dst, const mvert& v) {
+  if (m.gl == 0) { dst->w.x = v.w.x; dst->w.y = v.w.y; dst->w.z = v.w.z; dst->a.x = v.a.x; dst->a.y = v.a.y; dst->a.z = v.a.z; dst->b.x = v.b.x; dst->b.y = v.b.y; dst->b.z = v.b.z; }
+}
+MSK_DEV mvert lds_get_mvert(const mvert* p) {
+  mvert r;
+  r.w = v3_make(p->w.x, p->w.y, p->w.z); r.a = v3_make(p->a.x, p->a.y, p->a.z); r.b = v3_make(p->b.x, p->b.y, p->b.z);
+  return r;
+}
 
 MSK_DEV int epa_make_face(const CCtx& m, const mvert* vs, epa_face* f, int a, int b, int c) {
   v3 nrm = v3_cross(v3_sub(vs[b].w, vs[a].w), v3_sub(vs[c].w, vs[a].w));
@@ -627,7 +643,7 @@ MSK_DEV int epa_make_face(const CCtx& m, const mvert* vs, epa_face* f, int a, in
   int ok = 1;
   if (l < 1e-12f) { r.n = v3_make(0, 0, 0); r.d = 3.0e38f; ok = 0; }
   else { r.n = v3_scale(nrm, 1.0f / l); r.d = v3_dot(r.n, vs[a].w); }
-  if (m.gl == 0) *f = r;
+  if (m.gl == 0) { f->i[0] = r.i[0]; f->i[1] = r.i[1]; f->i[2] = r.i[2]; f->n.x = r.n.x; f->n.y = r.n.y; f->n.z = r.n.z; f->d = r.d; f->alive = r.alive; }
   return ok;
 }
 
@@ -643,17 +659,20 @@ MSK_DEV int epa(const CCtx& m, const CShape* A, const pose* TA, const CShape* B,
   int ncand = 0;
   for (int i = 0; i < ns; ++i) lds_put_mvert(m, &cand_[ncand++], simplex_get(S, i));
   if (ns < 4) {
-    const float D[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
-    for (int k = 0; k < 6; ++k) lds_put_mvert(m, &cand_[ncand++], msupport(m, A, TA, B, TB, v3_make(D[k][0], D[k][1], D[k][2])));
+    for (int k = 0; k < 6; ++k) { /* +x, -x, +y, -y, +z, -z */
+      const float sgn = (k & 1) ? -1.0f : 1.0f;
+      const v3 dir = v3_make((k >> 1) == 0 ? sgn : 0.0f, (k >> 1) == 1 ? sgn : 0.0f, (k >> 1) == 2 ? sgn : 0.0f);
+      lds_put_mvert(m, &cand_[ncand++], msupport(m, A, TA, B, TB, dir));
+    }
   }
   grp_sync();
-  lds_put_mvert(m, &vs[0], cand_[0]);
+  lds_put_mvert(m, &vs[0], lds_get_mvert(&cand_[0]));
   grp_sync();
   {
     int b1 = -1; float bd = 1e-12f;
     for (int i = 1; i < ncand; ++i) { float d = v3_len2(v3_sub(cand_[i].w, vs[0].w)); if (d > bd) { bd = d; b1 = i; } }
     if (b1 < 0) return 0;
-    lds_put_mvert(m, &vs[1], cand_[b1]);
+    lds_put_mvert(m, &vs[1], lds_get_mvert(&cand_[b1]));
     grp_sync();
     int b2 = -1; bd = 1e-14f;
     for (int i = 1; i < ncand; ++i) {
@@ -661,7 +680,7 @@ MSK_DEV int epa(const CCtx& m, const CShape* A, const pose* TA, const CShape* B,
       if (d > bd) { bd = d; b2 = i; }
     }
     if (b2 < 0) return 0;
-    lds_put_mvert(m, &vs[2], cand_[b2]);
+    lds_put_mvert(m, &vs[2], lds_get_mvert(&cand_[b2]));
     grp_sync();
     v3 nrm = v3_cross(v3_sub(vs[1].w, vs[0].w), v3_sub(vs[2].w, vs[0].w));
     int b3 = -1; float bv = 1e-16f;
@@ -674,14 +693,14 @@ MSK_DEV int epa(const CCtx& m, const CShape* A, const pose* TA, const CShape* B,
       mvert p = msupport(m, A, TA, B, TB, nrm), q = msupport(m, A, TA, B, TB, v3_neg(nrm));
       float dp = fabsf(v3_dot(nrm, v3_sub(p.w, vs[0].w))), dq = fabsf(v3_dot(nrm, v3_sub(q.w, vs[0].w)));
       if (fmaxf(dp, dq) < 1e-16f) return 0;
-      lds_put_mvert(m, &vs[3], (dp > dq) ? p : q);
-    } else lds_put_mvert(m, &vs[3], cand_[b3]);
+      lds_put_mvert(m, &vs[3], mv_sel(dp > dq, p, q));
+    } else lds_put_mvert(m, &vs[3], lds_get_mvert(&cand_[b3]));
     grp_sync();
     nv = 4;
     /* orient so that face normals point away from the 4th vertex */
     v3 n012 = v3_cross(v3_sub(vs[1].w, vs[0].w), v3_sub(vs[2].w, vs[0].w));
     if (v3_dot(n012, v3_sub(vs[3].w, vs[0].w)) > 0.0f) {
-      const mvert t1 = vs[1], t2 = vs[2];
+      const mvert t1 = lds_get_mvert(&vs[1]), t2 = lds_get_mvert(&vs[2]);
       grp_sync();
       lds_put_mvert(m, &vs[1], t2);
       lds_put_mvert(m, &vs[2], t1);
@@ -848,7 +867,7 @@ MSK_DEV int plane_convex(const CCtx& m, const CShape* P, const pose* TP, const C
       if (!(sep > margin)) { keep = true; c.u = v3_dot(w, t1); c.v = v3_dot(w, t2); c.hm = pd + 0.5f * sep; c.sep = sep; }
     }
     const unsigned bk = grp_ballot(keep);
-    if (keep) cs[nc + __popc(bk & ((1u << m.gl) - 1u))] = c;
+    if (keep) { cand* d = &cs[nc + __popc(bk & ((1u << m.gl) - 1u))]; d->u = c.u; d->v = c.v; d->hm = c.hm; d->sep = c.sep; }
     nc += __popc(bk);
   }
   grp_sync();

@@ -160,7 +160,8 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
   }
   __syncthreads();
   const int count = pref[NP_GROUP_MAX];
-  for (int idx = lane / LPI; idx < count; idx += 64 / LPI) {
+  constexpr int STEP = (LPI == 1) ? PL_LANES : 64 / LPI;   /* pairs per pass */
+  for (int idx = (LPI == 1) ? (lane < PL_LANES ? lane : count) : lane / LPI; idx < count; idx += STEP) {
   int j = 0;
 #pragma unroll
   for (int k = 1; k < NP_GROUP_MAX; ++k) j += (k < group && idx >= pref[k]) ? 1 : 0;
@@ -181,23 +182,18 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
   float osep[4];
   int n = 0;
   bool writer = true;
-  if constexpr (LPI == 1) {
-    perlane::CCtx cx;
-    cx.verts = m->verts;
+  if constexpr (LPI == 1) { /* box-box: one lane per pair, its polygon arrays interleaved in LDS */
+    CCtx cx;
+    cx.verts = m->verts; cx.ws = nullptr; cx.we = nullptr; cx.gl = 0; cx.grp = 0; cx.dbg = nullptr;
     perlane::DContactOut out[4];
-    if (type == NP_PLANE) {
-      const int pa = A->type == MSK_SHAPE_PLANE;
-      n = perlane::plane_convex(cx, pa ? A : B, pa ? &TA : &TB, pa ? B : A, pa ? &TB : &TA, margin, pa, out);
-    } else {
-      v3 nrm;
-      float sep;
-      if (perlane::sat_box_box(A, &TA, B, &TB, margin, &nrm, &sep)) {
-        const v3 wa = perlane::support(cx, A, &TA, v3_neg(nrm)), wb = perlane::support(cx, B, &TB, nrm);
+    v3 nrm;
+    float sep;
+    if (sat_box_box(A, &TA, B, &TB, margin, &nrm, &sep)) {
+      const v3 wa = support(cx, A, &TA, v3_neg(nrm)), wb = support(cx, B, &TB, nrm);
 #ifdef MSK_PROFILE_PHASES
-        tq[1] = (long long)__builtin_readcyclecounter();
+      tq[1] = (long long)__builtin_readcyclecounter();
 #endif
-        n = perlane::build_manifold(cx, A, &TA, B, &TB, nrm, margin, wa, wb, sep, out);
-      }
+      n = perlane::build_manifold(s_ws + lane, A, &TA, B, &TB, nrm, margin, wa, wb, sep, out);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { opos[k] = out[k].pos; osep[k] = out[k].sep; }
@@ -294,14 +290,18 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
 }
 
 /* blockIdx.y walks [plane | box-box | hull] sub-blocks of env group blockIdx.x: cfg.x/y/z of them, each on an equal
- * share of the group's envs; box_lpi picks the box-box code (1 lane or 16 lanes per pair).
+ * share of the group's envs.
  * Per 64 consecutive envs, the block that finishes last sorts them into the solver lists (one wave, one env per lane:
  * a handful of same-address atomics per 64 envs). */
-struct NpCfg { int nplane, nbox, nhull, box_lpi; };
-__global__ void __launch_bounds__(64) k_narrowphase(const DModel* __restrict__ m, DState st, const int group, const NpCfg cfg) {
+struct NpCfg { int nplane, nbox, nhull; };
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_narrowphase(const DModel* __restrict__ m, DState st, const int group, const NpCfg cfg) {
   __shared__ int pref[NP_GROUP_MAX + 1];
-  __shared__ float s_ws[(64 / NPG) * WS_TOTAL]; /* the lane groups' workspaces */
-  __shared__ float s_we[WE_TOTAL];              /* the wave's EPA workspace    */
+  /* one LDS image for both kinds of block: 32 lanes x 208 words of per-pair arrays (box-box), or four group workspaces
+   * and the wave's EPA workspace (plane, hull) */
+  constexpr int LDS_WORDS = PL_WORDS * PL_LANES > (64 / NPG) * WS_TOTAL + WE_TOTAL ? PL_WORDS * PL_LANES : (64 / NPG) * WS_TOTAL + WE_TOTAL;
+  __shared__ float s_lds[LDS_WORDS];
+  float* s_ws = s_lds;
+  float* s_we = s_lds + (64 / NPG) * WS_TOTAL;
   const int e0 = blockIdx.x * group;
   int y = blockIdx.y;
   if (y < cfg.nplane) {
@@ -309,8 +309,7 @@ __global__ void __launch_bounds__(64) k_narrowphase(const DModel* __restrict__ m
     narrowphase_body<NP_PLANE, NPG>(m, st, e0 + y * sub, sub, pref, s_ws, s_we);
   } else if ((y -= cfg.nplane) < cfg.nbox) {
     const int sub = group / cfg.nbox;
-    if (cfg.box_lpi == 1) narrowphase_body<NP_BOXBOX, 1>(m, st, e0 + y * sub, sub, pref, s_ws, s_we);
-    else narrowphase_body<NP_BOXBOX, NPG>(m, st, e0 + y * sub, sub, pref, s_ws, s_we);
+    narrowphase_body<NP_BOXBOX, 1>(m, st, e0 + y * sub, sub, pref, s_ws, s_we);
   } else {
     y -= cfg.nbox;
     const int sub = group / cfg.nhull;

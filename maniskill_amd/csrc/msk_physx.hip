@@ -535,14 +535,12 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
     int group = N / 256;   /* ~256 x 6 waves whatever the env count */
     group = group < 1 ? 1 : (group > NP_GROUP_MAX ? NP_GROUP_MAX : group);
     while (group & (group - 1)) group &= group - 1;   /* a power of two: groups never straddle the 64-env classification chunks */
-    static const int e_box_lpi = getenv("MSK_NP_BOX_LPI") ? atoi(getenv("MSK_NP_BOX_LPI")) : 1;       /* tuning aids */
-    static const int e_nbox = getenv("MSK_NP_NBOX") ? atoi(getenv("MSK_NP_NBOX")) : 1;
+    static const int e_nbox = getenv("MSK_NP_NBOX") ? atoi(getenv("MSK_NP_NBOX")) : 1;       /* tuning aids */
     static const int e_nhull = getenv("MSK_NP_NHULL") ? atoi(getenv("MSK_NP_NHULL")) : 4;
     NpCfg cfg;
     cfg.nplane = 1;
     cfg.nbox = e_nbox < group ? e_nbox : group;
     cfg.nhull = e_nhull < group ? e_nhull : group;
-    cfg.box_lpi = e_box_lpi;
     hipLaunchKernelGGL(k_narrowphase, dim3((N + group - 1) / group, cfg.nplane + cfg.nbox + cfg.nhull), dim3(64), 0, s, c->d_model,
                        c->st, group, cfg);
   } else {
