@@ -1,0 +1,11 @@
+#!/bin/bash
+# HBM traffic counters of the bench command, one rocprofv3 --pmc pass per counter (guides/MI355X_MICROARCH.md: PMC passes
+# on their own, never combined with the system / runtime trace domains).  Run on the GPU box from the repo root:
+#   bash tools/pmc_collect.sh [extra bench.py flags]      -> gpurun_out/pmc/<counter>/..., then tools/pmc_summarise.py
+set -u
+cd /tmp && export TMPDIR=/tmp
+OUT=${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/pmc
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/$ctr -- \
+    python ${GRAFT_REPO_ROOT:-/root/repo}/bench.py --steps 20 --warmup 40 --no-cpu-baseline "$@" > $OUT.$ctr.log 2>&1
+done

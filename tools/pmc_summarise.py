@@ -1,0 +1,51 @@
+"""Turns the rocprofv3 --pmc passes of tools/pmc_collect.sh into profiles/<name>.json: per kernel, the mean FETCH_SIZE /
+WRITE_SIZE (KiB, as reported) over the last launches and hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 — FETCH_SIZE doubled
+as guides/MI355X_MICROARCH.md prescribes for gfx950 — plus the sums per timing slot of include/msk_physx.h."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "pmc")
+out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles", "r01_pmc_counters_4096.json")
+command = sys.argv[3] if len(sys.argv) > 3 else "python bench.py --steps 20 --warmup 40 --no-cpu-baseline"
+LAST = 100
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0].split("<")[0]
+
+
+kernels = defaultdict(dict)
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = glob.glob(os.path.join(src, ctr, "**", "*counter_collection.csv"), recursive=True)
+    vals = defaultdict(list)
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == ctr:
+                vals[short(r["Kernel_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    for k, v in vals.items():
+        v.sort()
+        tail = [x for _, x in v[-LAST:]]
+        kernels[k][ctr] = sum(tail) / len(tail)
+        kernels[k]["launches_seen"] = len(v)
+for k, d in kernels.items():
+    d["hbm_bytes_per_launch"] = (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0
+slots = {"k_dynamics": ["k_dynamics"], "k_collide": ["k_broadphase", "k_narrowphase", "k_classify"], "k_solve": ["k_csolve"],
+         "camera": ["k_render_setup", "k_render_tiles"]}
+groups = {}
+for slot, names in slots.items():
+    present = [n for n in names if n in kernels]
+    if present:
+        groups[slot] = {"kernels": present, "hbm_bytes_per_launch": sum(kernels[n]["hbm_bytes_per_launch"] for n in present)}
+doc = {
+    "source": f"rocprofv3 --pmc <counter> --kernel-trace -- {command} (tools/pmc_collect.sh: one pass per counter, MI355X); "
+              f"mean over the last {LAST} launches of each kernel",
+    "units": "FETCH_SIZE / WRITE_SIZE in KiB per launch as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE doubled "
+             "per guides/MI355X_MICROARCH.md (gfx950 reports half of a coalesced read stream; narrow accesses are uncalibrated, so "
+             "this is an upper bound on the read side)",
+    "kernels": {k: kernels[k] for k in sorted(kernels) if k.startswith("k_")},
+    "substep_groups": groups,
+}
+json.dump(doc, open(out, "w"), indent=1)
+print(json.dumps(groups, indent=1))
