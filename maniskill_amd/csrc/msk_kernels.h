@@ -39,6 +39,7 @@ enum { NP_PLANE = 0, NP_BOXBOX = 1, NP_GJK = 2, NP_TYPES = 3 };
 
 __global__ void __launch_bounds__(64) k_broadphase(const DModel* __restrict__ m, DState st) {
   __shared__ float aabb[MSK_MAX_SHAPES][6];
+  __shared__ float obb[MSK_MAX_SHAPES][13];   /* rotation columns (9), local half extents (3); odd stride: no bank conflicts */
   const int e = blockIdx.x, lane = threadIdx.x;
   const float* E = EREC(st, m, e);
   const float margin = 2.0f * m->cfg.contact_offset;
@@ -50,6 +51,10 @@ __global__ void __launch_bounds__(64) k_broadphase(const DModel* __restrict__ m,
       world_aabb(sh, &T, &c, &h);
       aabb[lane][0] = c.x; aabb[lane][1] = c.y; aabb[lane][2] = c.z;
       aabb[lane][3] = h.x; aabb[lane][4] = h.y; aabb[lane][5] = h.z;
+      const m33 R = quat_to_m33(T.q);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { obb[lane][j * 3] = R.m[0][j]; obb[lane][j * 3 + 1] = R.m[1][j]; obb[lane][j * 3 + 2] = R.m[2][j]; }
+      obb[lane][9] = sh->aabb_h.x; obb[lane][10] = sh->aabb_h.y; obb[lane][11] = sh->aabb_h.z;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -81,6 +86,25 @@ __global__ void __launch_bounds__(64) k_broadphase(const DModel* __restrict__ m,
       keep = valid && !(fabsf(aabb[sa][0] - aabb[sb][0]) > aabb[sa][3] + aabb[sb][3] + margin) &&
              !(fabsf(aabb[sa][1] - aabb[sb][1]) > aabb[sa][4] + aabb[sb][4] + margin) &&
              !(fabsf(aabb[sa][2] - aabb[sb][2]) > aabb[sa][5] + aabb[sb][5] + margin);
+      if (keep && type == NP_GJK) { /* second stage (oracle: obb_separated): the two oriented boxes along their six face normals */
+        const v3 d = v3_make(aabb[sa][0] - aabb[sb][0], aabb[sa][1] - aabb[sb][1], aabb[sa][2] - aabb[sb][2]);
+        v3 au[3], bu[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          au[j] = v3_make(obb[sa][j * 3], obb[sa][j * 3 + 1], obb[sa][j * 3 + 2]);
+          bu[j] = v3_make(obb[sb][j * 3], obb[sb][j * 3 + 1], obb[sb][j * 3 + 2]);
+        }
+        const float hax = obb[sa][9], hay = obb[sa][10], haz = obb[sa][11], hbx = obb[sb][9], hby = obb[sb][10], hbz = obb[sb][11];
+        bool sep = false;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const v3 L = (k < 3) ? au[k] : bu[k - 3];
+          const float ra = fmaf(hax, fabsf(v3_dot(au[0], L)), fmaf(hay, fabsf(v3_dot(au[1], L)), haz * fabsf(v3_dot(au[2], L))));
+          const float rb = fmaf(hbx, fabsf(v3_dot(bu[0], L)), fmaf(hby, fabsf(v3_dot(bu[1], L)), hbz * fabsf(v3_dot(bu[2], L))));
+          if (fabsf(v3_dot(d, L)) > ra + rb + margin) sep = true;
+        }
+        keep = !sep;
+      }
     }
     /* append to this env's per-type list, in pair order (ballot ranks: no atomics, deterministic) */
 #pragma unroll

@@ -66,6 +66,23 @@ static void world_aabb(const orc_shape* sh, const pose* T, v3* c, v3* h) {
   h->z = fmaf(fabsf(R.m[2][0]), sh->aabb_h.x, fmaf(fabsf(R.m[2][1]), sh->aabb_h.y, fabsf(R.m[2][2]) * sh->aabb_h.z));
 }
 
+/* Second-stage cull for pairs that go to GJK: the oriented boxes of the two shapes' local AABBs, tested along their six
+ * face normals (they contain the shapes, so a gap of more than `margin` along any of them means no contact).  Most hull
+ * pairs whose world AABBs overlap are links hovering over the table or next to each other; this keeps them out of GJK. */
+static int obb_separated(const orc_shape* A, const pose* TA, const orc_shape* B, const pose* TB, v3 ca, v3 cb, float margin) {
+  m33 Ra = quat_to_m33(TA->q), Rb = quat_to_m33(TB->q);
+  v3 au[3] = {m33_col(&Ra, 0), m33_col(&Ra, 1), m33_col(&Ra, 2)};
+  v3 bu[3] = {m33_col(&Rb, 0), m33_col(&Rb, 1), m33_col(&Rb, 2)};
+  v3 d = v3_sub(ca, cb);
+  for (int k = 0; k < 6; ++k) {
+    v3 L = (k < 3) ? au[k] : bu[k - 3];
+    float ra = fmaf(A->aabb_h.x, fabsf(v3_dot(au[0], L)), fmaf(A->aabb_h.y, fabsf(v3_dot(au[1], L)), A->aabb_h.z * fabsf(v3_dot(au[2], L))));
+    float rb = fmaf(B->aabb_h.x, fabsf(v3_dot(bu[0], L)), fmaf(B->aabb_h.y, fabsf(v3_dot(bu[1], L)), B->aabb_h.z * fabsf(v3_dot(bu[2], L))));
+    if (fabsf(v3_dot(d, L)) > ra + rb + margin) return 1;
+  }
+  return 0;
+}
+
 /* ---- manifold ------------------------------------------------------------------------ */
 typedef struct { float u, v, h; } p3;   /* coordinates in the (t1, t2, n) contact frame */
 
@@ -670,6 +687,7 @@ int orc_collide_pair(const orc_ctx* c, const orc_env* e, int pi, orc_contact* ou
       wa = support(A, &TA, v3_neg(nrm));
       wb = support(B, &TB, nrm);
     } else {
+      if (obb_separated(A, &TA, B, &TB, ca, cb, margin)) return 0;
       if (!gjk_epa(A, &TA, B, &TB, ca, cb, margin, &nrm, &sep, &wa, &wb)) return 0;
     }
     n = build_manifold(A, &TA, B, &TB, nrm, margin, wa, wb, sep, out);
