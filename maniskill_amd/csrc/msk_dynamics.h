@@ -24,7 +24,7 @@
 #include "msk_model.h"
 
 MSK_DEV void dyn_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  asm volatile("" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -71,37 +71,47 @@ MSK_DEV pose forward_pass(const DModel* m, const float* E, float* lds, const Dyn
   dyn_sync();
   const bool child_link = has && b->kind == MSK_BODY_LINK && b->parent >= 0;
   const int mydepth = has ? m->depth[i] : -1;
-  for (int d = 1; d <= m->maxdepth; ++d) {
+  /* everything a lane needs from the template and the env record is fetched here, side by side for all levels: inside
+   * the level loop (one dependent hop per tree level) only the parent's LDS image is read */
+  const int maxdepth = m->maxdepth;
+  int parent = 0, dof = -1, jtype = MSK_JOINT_FIXED;
+  pose Xp, XcInv;
+  Xp.p = XcInv.p = v3_make(0, 0, 0);
+  Xp.q = XcInv.q = quat_make(1, 0, 0, 0);
+  float qi = 0.0f, qdi = 0.0f, sn = 0.0f, cs = 1.0f;
+  if (child_link) {
+    parent = b->parent; dof = b->dof; jtype = b->jtype;
+    Xp = b->Xp; XcInv = b->XcInv;
+    if (dof >= 0) { qi = E[m->lay.q + dof]; qdi = E[m->lay.qd + dof]; }
+    if (jtype == MSK_JOINT_REVOLUTE) msk_sincos(0.5f * qi, &sn, &cs);
+  }
+  for (int d = 1; d <= maxdepth; ++d) {
     if (child_link && mydepth == d) {
-      const float* pp = lds + ly.pose + b->parent * 8;
+      const float* pp = lds + ly.pose + parent * 8;
       pose Tp;
       Tp.p = v3_make(pp[0], pp[1], pp[2]);
       Tp.q = quat_make(pp[3], pp[4], pp[5], pp[6]);
-      const sv6 Vp = lds_sv6(lds + ly.V + b->parent * 6);
-      pose Tj = pose_mul(Tp, b->Xp);
+      const sv6 Vp = lds_sv6(lds + ly.V + parent * 6);
+      pose Tj = pose_mul(Tp, Xp);
       v3 axis = quat_rotate(Tj.q, v3_make(1, 0, 0));
       pose Jq;
       Jq.p = v3_make(0, 0, 0);
       Jq.q = quat_make(1, 0, 0, 0);
-      const float qi = (b->dof >= 0) ? E[m->lay.q + b->dof] : 0.0f;
-      const float qdi = (b->dof >= 0) ? E[m->lay.qd + b->dof] : 0.0f;
-      if (b->jtype == MSK_JOINT_REVOLUTE) {
-        float sn, cs;
-        msk_sincos(0.5f * qi, &sn, &cs);
+      if (jtype == MSK_JOINT_REVOLUTE) {
         Jq.q = quat_make(cs, sn, 0, 0);
         S.a = axis;
         S.l = v3_cross(Tj.p, axis);
-      } else if (b->jtype == MSK_JOINT_PRISMATIC) {
+      } else if (jtype == MSK_JOINT_PRISMATIC) {
         Jq.p = v3_make(qi, 0, 0);
         S.l = axis;
       }
-      T = pose_mul(pose_mul(Tj, Jq), b->XcInv);
+      T = pose_mul(pose_mul(Tj, Jq), XcInv);
       T.q = quat_normalize(T.q);
       V = Vp;
-      if (b->dof >= 0) V = sv6_madd(V, S, qdi);
+      if (dof >= 0) V = sv6_madd(V, S, qdi);
       if (WITH_ACC) {
-        A = lds_sv6(lds + ly.acc + b->parent * 6);
-        if (b->dof >= 0) {
+        A = lds_sv6(lds + ly.acc + parent * 6);
+        if (dof >= 0) {
           sv6 sq = {v3_scale(S.a, qdi), v3_scale(S.l, qdi)};
           A = sv6_add(A, sv6_crossm(Vp, sq));
         }
@@ -174,6 +184,14 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
   const int LD = MSK_MAX_DOF + 1;
 
   if (blockIdx.x == 0 && threadIdx.x < MSK_SOLVE_CLASSES) st.cls_count[threadIdx.x] = 0; /* this substep's solver lists */
+#ifdef MSK_PROFILE_PHASES
+  long long* dstamp = st.dbg + (size_t)m->N * 8 + 64 + (size_t)e * 8;
+  int dsi = 0;
+#define DPHASE() do { if (live && i == 0) dstamp[dsi] = (long long)__builtin_readcyclecounter(); dsi++; } while (0)
+#else
+#define DPHASE()
+#endif
+  DPHASE();
   /* ---- 1. frames, velocities, bias accelerations (down the tree) ------------------------------------ */
   sv6 S, V, acc;
   const pose T = forward_pass<true>(m, E, lds, ly, i, has, &S, &V, &acc);
@@ -191,6 +209,7 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
   /* zero M while the forward results settle */
   for (int k = i; k < MSK_MAX_DOF * LD; k += LPE) Lm[k] = 0.0f;
   if (i < nd) vec[DV_QD * MSK_MAX_DOF + i] = E[m->lay.qd + i];
+  DPHASE();
   /* ---- 2. RNEA body forces, spatial inertias about the env origin ---------------------------------------- */
   if (link) {
     float Iw[6];
@@ -223,14 +242,21 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
     for (int k = 0; k < 6; ++k) Ii[4 + k] = Ic.I[k];
   }
   dyn_sync();
+  DPHASE();
   /* ---- 3. back up the tree: parents absorb their children (descending body index, as the oracle) --------- */
   const int mydepth = has ? m->depth[i] : -1;
-  for (int d = m->maxdepth; d >= 1; --d) {
+  /* child lists fetched before the level loop (the first four children in registers) */
+  const int maxdepth = m->maxdepth;
+  const int c0 = link ? m->child_off[i] : 0, c1 = link ? m->child_off[i + 1] : 0;
+  int chs[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) if (c0 + k < c1) chs[k] = m->child_idx[c0 + k];
+  for (int d = maxdepth; d >= 1; --d) {
     if (link && mydepth == d - 1) {
-      const int c0 = m->child_off[i], c1 = m->child_off[i + 1];
       if (c1 > c0) {
         for (int cc = c0; cc < c1; ++cc) {
-          const int ch = m->child_idx[cc];
+          const int kc = cc - c0;
+          const int ch = (kc == 0) ? chs[0] : ((kc == 1) ? chs[1] : ((kc == 2) ? chs[2] : ((kc == 3) ? chs[3] : m->child_idx[cc])));
           f = sv6_add(f, lds_sv6(lds + ly.acc + ch * 6));
           const float* Ic_c = lds + ly.Ic + ch * 10;
           Ic.m += Ic_c[0];
@@ -244,6 +270,7 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
     }
     dyn_sync();
   }
+  DPHASE();
   /* ---- 4. bias torques and CRBA rows (lane = body with a dof) ------------------------------------------------ */
   if (link && b->dof >= 0) {
     const int di = b->dof;
@@ -270,6 +297,7 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
   }
   dyn_sync();
 
+  DPHASE();
   /* ---- 5. implicit PD: A = M + dt D + dt^2 K (+ tendons), Cholesky, solves; second pass if a drive saturates ---- */
   const bool rowlane = i < nd;   /* surplus half-waves compute along (LDS only) and store nothing */
   const float fmax_i = rowlane ? m->bodies[m->dof_body[i]].fmax : 0.0f;
@@ -395,6 +423,7 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
     if (__ballot(sat) == 0ull) break;
   }
 
+  DPHASE();
   /* ---- 6. free bodies: unconstrained velocity, world inverse inertia, subspace columns -------------------- */
   if (has && b->kind == MSK_BODY_DYNAMIC) {
     v3 v = load_v3(E, m->lay.blin, i), w = load_v3(E, m->lay.bang, i);
@@ -422,6 +451,8 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
     }
     store_v3(E, m->lay.comw, i, comw);
   }
+  DPHASE();
+#undef DPHASE
 }
 
 #endif

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(64) k_broadphase(const DModel* __restrict__ m,
       obb[lane][9] = sh->aabb_h.x; obb[lane][10] = sh->aabb_h.y; obb[lane][11] = sh->aabb_h.z;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  asm volatile("" ::: "memory");
   __builtin_amdgcn_wave_barrier();
   int* cnts = st.ct_cnt + (size_t)e * m->npp;
   int base[NP_TYPES] = {0, 0, 0};

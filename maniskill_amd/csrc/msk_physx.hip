@@ -432,7 +432,7 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   ALLOC(st.Scol, N * G * 8); ALLOC(st.W, N * G * G); ALLOC(st.vfree, N * G);
   ALLOC(st.ct_cnt, N * m.npp); ALLOC(st.ct_rec, N * m.npp * MSK_CT_REC);
   ALLOC(st.cls_list, MSK_SOLVE_CLASSES * N); ALLOC(st.cls_count, MSK_SOLVE_CLASSES); ALLOC(st.np_done, N);
-  ALLOC(st.dbg, N * 12 + 64);
+  ALLOC(st.dbg, N * 16 + 64);
   /* the solver launch (msk_solve.h): one LDS size for every kind of workgroup; one-env-per-wave workers */
   c->solve_workers = num_envs < 768 ? num_envs : 768;
   ALLOC(st.a_scratch, (size_t)c->solve_workers * 9 * MSK_CLASS3_BLOCKS * MSK_CLASS3_BLOCKS);
@@ -783,14 +783,14 @@ MSK_API int msk_task_pickcube_observe(msk_ctx* c, float* obs, float* reward, uin
 MSK_API int msk_debug_reset(msk_ctx* c) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemset(c->st.dbg, 0, sizeof(long long) * (12 * (size_t)c->model.N + 64)));
+  HIP_TRY(hipMemset(c->st.dbg, 0, sizeof(long long) * (16 * (size_t)c->model.N + 64)));
   return MSK_OK;
 }
 /* development aid (MSK_PROFILE_PHASES builds): per-env cycle stamps of the solver phases, out[num_envs*8] */
 MSK_API int msk_debug_phases(msk_ctx* c, long long* out) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out, c->st.dbg, sizeof(long long) * (12 * (size_t)c->model.N + 64), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, c->st.dbg, sizeof(long long) * (16 * (size_t)c->model.N + 64), hipMemcpyDeviceToHost));
   return MSK_OK;
 }
 #endif

@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
     }
     for (int c0 = l0; c0 < l1; c0 += 64) {
       const int n = min(64, l1 - c0);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       if (c0 == l0) { /* first chunk: already in registers */
         float4* dst = (float4*)Ls + lane * 4;
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
         float4* dst = (float4*)Ls + lane * 4;
         dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       if (c0 == l0 && i + 1 < MSK_TILES_PER_WAVE && tile + 1 < ntiles) { /* next tile's first chunk into flight */
         const int nhi = __builtin_amdgcn_readlane(myoff, (i + 2 <= MSK_TILES_PER_WAVE) ? i + 2 : MSK_TILES_PER_WAVE);

@@ -37,8 +37,10 @@
 #define MSK_MAX_DEPEN_VEL 3.0f
 #define MSK_SMALL_BLOCKS 16
 
+/* LDS hand-off inside a wavefront: DS instructions of one wave execute in issue order, so only the compiler has to be
+ * stopped from moving the accesses — a wavefront-scope fence would also drain the global loads / stores in flight */
 MSK_DEV void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  asm volatile("" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
 MSK_DEV float readlane_f(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }

@@ -18,7 +18,7 @@ dll = env.px.lib.dll
 dll.msk_debug_phases.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 names = ["count", "stage", "rowsJ", "Y", "A", "sweeps", "finish"]
 def report(tag):
-    out = np.zeros(n * 12 + 64, dtype=np.int64)
+    out = np.zeros(n * 16 + 64, dtype=np.int64)
     dll.msk_debug_phases(env.px.ctx, out.ctypes.data_as(C.POINTER(C.c_longlong)))
     t = out[:n * 8].reshape(n, 8)
     d = np.diff(t[:, :7], axis=1)
@@ -28,7 +28,7 @@ def report(tag):
         if sel.sum():
             print(tag, f"contacts {lo}-{hi} n={sel.sum()}", {k: int(v) for k, v in zip(names[1:], d[sel].mean(0))}, "total", int((t[sel, 6] - t[sel, 0]).mean()))
 def np_report(tag, launches):
-    out = np.zeros(n * 12 + 64, dtype=np.int64)
+    out = np.zeros(n * 16 + 64, dtype=np.int64)
     dll.msk_debug_phases(env.px.ctx, out.ctypes.data_as(C.POINTER(C.c_longlong)))
     d = out[n * 8:n * 8 + 24].reshape(3, 8)
     for t, name in enumerate(("plane", "boxbox", "gjk")):
@@ -47,3 +47,8 @@ for _ in range(40): env.step(2 * torch.rand(n, 8, device="cuda:0") - 1)
 report("random, steps 160-200")
 np_report("random(steps 160-200)", 40 * 5)
 print("solver classes", env.px.get_solver_class_counts())
+out = np.zeros(n * 16 + 64, dtype=np.int64)
+dll.msk_debug_phases(env.px.ctx, out.ctypes.data_as(C.POINTER(C.c_longlong)))
+dd = np.diff(out[n * 8 + 64:n * 16 + 64].reshape(n, 8)[:, :7], axis=1)
+print("k_dynamics phases (mean cycles): forward", int(dd[:, 0].mean()), "rnea", int(dd[:, 1].mean()), "backward", int(dd[:, 2].mean()),
+      "crba", int(dd[:, 3].mean()), "solve", int(dd[:, 4].mean()), "free", int(dd[:, 5].mean()), "total", int(dd.sum(1).mean()))
