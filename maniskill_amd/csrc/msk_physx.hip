@@ -697,6 +697,7 @@ MSK_API int msk_camera_create(msk_ctx* c, int width, int height, float fovy, flo
   ALLOC(cam.tile_recs, N * (size_t)cam.list_cap * MSK_SETUP_WORDS);
   ALLOC(cam.big_recs, N * (size_t)MSK_MAX_BIG * MSK_SETUP_WORDS);
   ALLOC(cam.nbig, N);
+  ALLOC(cam.tile_bigmask, N * MSK_MAX_TILES);
   ALLOC(cam.out, N * (size_t)width * height * 4);
   ALLOC(cam.depth, N * (size_t)width * height);
   ALLOC(cam.seg, N * (size_t)width * height);

@@ -50,6 +50,7 @@ struct RCamera {
   float* tile_recs;                /* [N][list_cap][16]: per tile, the records of the small triangles that touch it */
   float* big_recs;                 /* [N][MSK_MAX_BIG][16]: triangles over many tiles (table, ground): tested by every tile */
   int* nbig;                       /* [N] */
+  unsigned short* tile_bigmask;    /* [N][MSK_MAX_TILES]: bit b = large triangle b can cover a pixel centre of the tile */
   short* out;                      /* [N][H][W][4]        */
   short* depth;                    /* [N][H][W]: -z of out (Camera.get_obs's depth), written by the same store */
   short* seg;                      /* [N][H][W]: w of out                                                      */
@@ -62,6 +63,18 @@ struct TriSetup {
   float A0, B0, C0, A1, B1, C1, A2, B2, C2, Aw, Bw, Cw;
   int seg, prim, bbx, bby;         /* bbx = x0 | x1 << 16, bby = y0 | y1 << 16 */
 };
+
+/* Can the triangle cover a pixel centre of tile (tx, ty)?  An edge function fma(A, x, fma(B, y, C)) is monotone in x and
+ * in y (rounding is monotone), so over the tile's pixel centres it peaks at one of the four corner centres: if that
+ * peak is negative for some edge, no centre of the tile passes the inside test.  Exact, not just conservative in R. */
+MSK_DEV bool tile_touches(float A0, float B0, float C0, float A1, float B1, float C1, float A2, float B2, float C2, int tx, int ty) {
+  const float x0 = (float)(tx * MSK_TILE) + 0.5f, x1 = (float)(tx * MSK_TILE + MSK_TILE - 1) + 0.5f;
+  const float y0 = (float)(ty * MSK_TILE) + 0.5f, y1 = (float)(ty * MSK_TILE + MSK_TILE - 1) + 0.5f;
+  const float m0 = fmaxf(fmaxf(fmaf(A0, x0, fmaf(B0, y0, C0)), fmaf(A0, x1, fmaf(B0, y0, C0))), fmaxf(fmaf(A0, x0, fmaf(B0, y1, C0)), fmaf(A0, x1, fmaf(B0, y1, C0))));
+  const float m1 = fmaxf(fmaxf(fmaf(A1, x0, fmaf(B1, y0, C1)), fmaf(A1, x1, fmaf(B1, y0, C1))), fmaxf(fmaf(A1, x0, fmaf(B1, y1, C1)), fmaf(A1, x1, fmaf(B1, y1, C1))));
+  const float m2 = fmaxf(fmaxf(fmaf(A2, x0, fmaf(B2, y0, C2)), fmaf(A2, x1, fmaf(B2, y0, C2))), fmaxf(fmaf(A2, x0, fmaf(B2, y1, C2)), fmaf(A2, x1, fmaf(B2, y1, C2))));
+  return m0 >= 0.0f && m1 >= 0.0f && m2 >= 0.0f;
+}
 
 /* projects a camera-frame point (x forward, y left, z up): pixel coordinates and 1/depth */
 MSK_DEV void project_point(const RCamera& cam, v3 p, float* u, float* v, float* w) {
@@ -184,7 +197,8 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
       }
       setups[slot] = t;
       for (int ty = ty0; ty <= ty1; ++ty)
-        for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&Lcnt[ty * cam.tiles_x + tx], 1);
+        for (int tx = tx0; tx <= tx1; ++tx)
+          if (tile_touches(t.A0, t.B0, t.C0, t.A1, t.B1, t.C1, t.A2, t.B2, t.C2, tx, ty)) atomicAdd(&Lcnt[ty * cam.tiles_x + tx], 1);
     }
   }
   __threadfence_block();   /* the records are read back by other threads of the workgroup */
@@ -218,6 +232,7 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
     if (__float_as_int(r3.x) & MSK_SEG_BIG) continue;   /* lives in the list of large triangles */
     for (int ty = ty0; ty <= ty1; ++ty)
       for (int tx = tx0; tx <= tx1; ++tx) {
+        if (!tile_touches(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, tx, ty)) continue;   /* same test as the count pass */
         const int tile = ty * cam.tiles_x + tx;
         const int pos = Lcnt[tile] + atomicAdd(&Lfill[tile], 1);
         if (pos < Lcnt[tile + 1]) {
@@ -230,6 +245,19 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
   float4* bigr = (float4*)(cam.big_recs + (size_t)e * MSK_MAX_BIG * MSK_SETUP_WORDS);
   for (int i = tid; i < nbig * 4; i += 256) bigr[i] = ((const float4*)&setups[Lbig[i / 4]])[i % 4];
   if (tid == 0) cam.nbig[e] = nbig;
+  /* per tile, the large triangles that can cover one of its pixel centres (bit b = entry b of the list) */
+  unsigned short* bmask = cam.tile_bigmask + (size_t)e * MSK_MAX_TILES;
+  for (int tile = tid; tile < ntiles; tile += 256) {
+    const int tx = tile % cam.tiles_x, ty = tile / cam.tiles_x;
+    unsigned mk = 0u;
+    for (int b = 0; b < nbig; ++b) {
+      const TriSetup* t = &setups[Lbig[b]];
+      const int qx0 = tx * MSK_TILE, qy0 = ty * MSK_TILE;
+      if ((t->bbx & 0xFFFF) > qx0 + MSK_TILE - 1 || (t->bbx >> 16) < qx0 || (t->bby & 0xFFFF) > qy0 + MSK_TILE - 1 || (t->bby >> 16) < qy0) continue;
+      if (tile_touches(t->A0, t->B0, t->C0, t->A1, t->B1, t->C1, t->A2, t->B2, t->C2, tx, ty)) mk |= 1u << b;
+    }
+    bmask[tile] = (unsigned short)mk;
+  }
 }
 
 /* One wavefront per (group of MSK_TILES_PER_WAVE consecutive 8 x 8 tiles, env), lane = pixel.  The launch is bound by
@@ -247,6 +275,7 @@ __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
   }
   const int t0 = blockIdx.x * MSK_TILES_PER_WAVE;
+  const unsigned short* bigmask = cam.tile_bigmask + (size_t)e * MSK_MAX_TILES;
   const int* toff = cam.tile_off + (size_t)e * (MSK_MAX_TILES + 1);
   const float4* recs = (const float4*)(cam.tile_recs + (size_t)e * cam.list_cap * MSK_SETUP_WORDS);
   const float wmin = 1.0f / cam.far_;
@@ -271,18 +300,17 @@ __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
     const float x = (float)px + 0.5f, y = (float)py + 0.5f;
     float best_w = 0.0f;
     int best_seg = 0, best_prim = 0x7FFFFFFF;
-    for (int k = 0; k < nbig; ++k) { /* the env's large triangles (LDS, staged once per wave) */
+    /* the env's large triangles that reach this tile (LDS, staged once per wave) */
+    for (unsigned mk = __builtin_amdgcn_readfirstlane((int)bigmask[tile]); mk != 0u; mk &= mk - 1u) {
+      const int k = __builtin_ctz(mk);
       const float4* t4 = (const float4*)(Lb + k * MSK_SETUP_WORDS);
-      const float4 td = t4[3];
-      const int bbx = __float_as_int(td.z), bby = __float_as_int(td.w);
-      const int qx0 = tx * MSK_TILE, qy0 = ty * MSK_TILE;
-      if ((bbx & 0xFFFF) > qx0 + MSK_TILE - 1 || (bbx >> 16) < qx0 || (bby & 0xFFFF) > qy0 + MSK_TILE - 1 || (bby >> 16) < qy0) continue;
       const float4 ta = t4[0], tb = t4[1], tc = t4[2];
       const float e0 = fmaf(ta.x, x, fmaf(ta.y, y, ta.z));
       const float e1 = fmaf(ta.w, x, fmaf(tb.x, y, tb.y));
       const float e2 = fmaf(tb.z, x, fmaf(tb.w, y, tc.x));
       if (e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f) {
         const float w = fmaf(tc.y, x, fmaf(tc.z, y, tc.w));
+        const float4 td = t4[3];
         const int prim = __float_as_int(td.y);
         if (w >= wmin && (w > best_w || (w == best_w && prim < best_prim))) {
           best_w = w; best_prim = prim; best_seg = __float_as_int(td.x);
