@@ -170,9 +170,6 @@ class PickCubeEnv:
                                 goal_thresh=self.goal_thresh, min_force=0.5, max_angle_deg=85.0, static_thresh=0.2,
                                 max_episode_steps=self.max_episode_steps)
             self.px.lib.check(self.px.ctx, self.px.lib.task_pickcube_init(self.px.ctx, C.byref(d)), "task_pickcube_init")
-            self._f_obs = torch.zeros(N, self.obs_dim, dtype=torch.float32, device=dev)
-            self._f_rew = torch.zeros(N, dtype=torch.float32, device=dev)
-            self._f_flags = torch.zeros(N, 8, dtype=torch.uint8, device=dev)
         # sensors: PickCube-v1's base_camera (pick_cube.py:64-71), 128 x 128, fov pi/2, depth + segmentation textures
         if obs_mode not in ("state", "depth+segmentation"):
             raise NotImplementedError(f"obs_mode {obs_mode!r}: this backend provides 'state' and 'depth+segmentation'")
@@ -324,13 +321,18 @@ class PickCubeEnv:
     def _fused_observe(self, advance: bool):
         import ctypes as C
         L, px = self.px.lib, self.px
-        L.check(px.ctx, L.task_pickcube_observe(px.ctx, C.c_void_p(self._f_obs.data_ptr()), C.c_void_p(self._f_rew.data_ptr()),
-                                                C.c_void_p(self._f_flags.data_ptr()), C.c_void_p(self._elapsed_steps.data_ptr()),
+        # the kernel writes straight into this step's fresh output tensors (no staging buffers, no copies); the flag bytes
+        # are 0 / 1, i.e. valid torch.bool storage
+        N, dev = self.num_envs, self.device
+        obs = torch.empty(N, self.obs_dim, dtype=torch.float32, device=dev)
+        rew = torch.empty(N, dtype=torch.float32, device=dev)
+        fl = torch.empty(N, 8, dtype=torch.bool, device=dev)
+        L.check(px.ctx, L.task_pickcube_observe(px.ctx, C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()),
+                                                C.c_void_p(fl.data_ptr()), C.c_void_p(self._elapsed_steps.data_ptr()),
                                                 1 if advance else 0, px._stream()), "task_pickcube_observe")
-        fl = self._f_flags.bool()
         info = dict(elapsed_steps=self._elapsed_steps.clone(), success=fl[:, 0], is_obj_placed=fl[:, 1], is_robot_static=fl[:, 2],
                     is_grasped=fl[:, 3])
-        return self._with_sensor_data(self._f_obs.clone()), self._f_rew.clone(), fl[:, 4], fl[:, 5], info
+        return self._with_sensor_data(obs), rew, fl[:, 4], fl[:, 5], info
 
     def _fused_step(self, action):
         """BaseEnv.step on the fused kernels: controller, substeps + link frames, evaluate/obs/reward."""
