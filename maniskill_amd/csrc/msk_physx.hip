@@ -435,7 +435,7 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   ALLOC(st.dbg, N * 16 + 64);
   /* the solver launch (msk_solve.h): one LDS size for every kind of workgroup; one-env-per-wave workers */
   c->solve_workers = num_envs < 768 ? num_envs : 768;
-  ALLOC(st.a_scratch, (size_t)c->solve_workers * 9 * MSK_CLASS3_BLOCKS * MSK_CLASS3_BLOCKS);
+  ALLOC(st.a_scratch, (size_t)c->solve_workers * 9 * MSK_CLASS3_BLOCKS * (MSK_CLASS3_BLOCKS + 4));   /* + prefetch slack */
   if (m.G == 16) {
     auto k0 = k_csolve<16, 16>;
     c->lds_solve = CsLds<16, 16, 16>::TOTAL * sizeof(float);

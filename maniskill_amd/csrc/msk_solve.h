@@ -217,7 +217,7 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   if (nbmax == 0 && __ballot(active) == 0ull) return;
   float* Ly = pool + pbase;
   float* La;
-  if constexpr (AGLOB) La = st.a_scratch + (size_t)blockIdx.x * (9 * CAP * CAP);
+  if constexpr (AGLOB) La = st.a_scratch + (size_t)blockIdx.x * (9 * CAP * (CAP + 4));
   else La = Ly + nblk * 3 * NVP;
   const int nb = nblk > 0 ? nblk : 1; /* row stride of my A image */
 
@@ -373,7 +373,9 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
    * block: the impulse change they receive for such a step is exactly zero (zero rows), so any finite value does */
   const int lrow = lane < nblk ? lane : 0;
   auto load_cols = [&](int blk, float* dst) {
-    const int bc = blk < nblk ? blk : (nblk > 0 ? nblk - 1 : 0);
+    /* one env per wave: a prefetch past the last block reads words nobody consumes (LDS: in range of the pool or zero;
+     * global image: one block of slack behind every worker's slice), so the index needs no clamp */
+    const int bc = (GL == 64) ? blk : (blk < nblk ? blk : (nblk > 0 ? nblk - 1 : 0));
 #pragma unroll
     for (int i = 0; i < 9; ++i) dst[i] = La[(bc * nb + lrow) * 9 + i];   /* one address, nine immediate offsets */
   };
