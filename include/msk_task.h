@@ -1,5 +1,5 @@
 /*
- * msk_task.h — C ABI of the fused task kernels (PickCube-v1).
+ * msk_task.h — C ABI of the fused task kernels (PickCube-v1, PushT-v1).
  *
  * ManiSkill's per-step task code is ~120 tiny torch launches per env.step on top of the physics
  * (controller: agents/controllers/pd_joint_pos.py:76-93,207-228; struct gathers: utils/structs/
@@ -48,6 +48,31 @@ int msk_control_step(msk_ctx* ctx, int substeps, void* stream);
  * elapsed: [num_envs] i32 (read-modify-write; pass advance = 0 to evaluate without counting a step). */
 int msk_task_pickcube_observe(msk_ctx* ctx, float* obs, float* reward, uint8_t* flags, int32_t* elapsed, int advance,
                               void* stream);
+
+/* ---- PushT-v1 (envs/tasks/tabletop/push_t.py:69-540; PandaStick, pd_joint_delta_pos on the 7 arm joints) -------- */
+typedef struct msk_pusht_desc {
+  int32_t tee, goal, tcp;      /* template body ids                                                          */
+  int32_t arm_dofs;            /* 7                                                                          */
+  float arm_delta;             /* 0.1 rad per unit action (panda_stick.py:100-110)                          */
+  float goal_xy[2];            /* goal_offset (push_t.py:96)                                                 */
+  float goal_z_rot;            /* 5/3 pi (push_t.py:97)                                                      */
+  float world_to_goal[6];      /* first two rows of inv([[c,-s,gx],[s,c,gy],[0,0,1]]) (push_t.py:300-318)    */
+  float uv_scale;              /* (res / 2) / uv_half_width = 32 / 0.15 (push_t.py:262-275)                  */
+  float intersection_thresh;   /* 0.90 (push_t.py:101)                                                       */
+  int32_t max_episode_steps;   /* 100                                                                        */
+} msk_pusht_desc;
+
+/* tee_render: host pointer to the res x res (64 x 64) uint8 mask of the T block in its own frame (push_t.py:277-298). */
+int msk_task_pusht_init(msk_ctx* ctx, const msk_pusht_desc* desc, const uint8_t* tee_render);
+/* PDJointPos(use_delta): clip to [-1, 1], arm target = qpos + delta * a, committed into the simulator.
+ * actions: device [num_envs][7]. */
+int msk_task_pusht_set_action(msk_ctx* ctx, const float* actions, void* stream);
+/* elapsed_steps += 1, evaluate() = pseudo_render_intersection >= thresh (push_t.py:343-431,484-497), observation,
+ * normalized dense reward (:511-540), terminated / truncated.  obs: device [num_envs][obs_dim] f32 with obs_dim = 31
+ * (state mode: qpos 7, qvel 7, tcp pose 7, goal position 3, T pose 7) or 21 (sensor modes: qpos, qvel, tcp pose);
+ * reward [num_envs]; flags [num_envs][8] u8 = {success, 0, 0, 0, terminated, truncated, 0, 0}; elapsed as above. */
+int msk_task_pusht_observe(msk_ctx* ctx, float* obs, int obs_dim, float* reward, uint8_t* flags, int32_t* elapsed, int advance,
+                           void* stream);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,8 @@ EXPORTS = [
 # include/msk_render.h — camera pipeline (both libraries)
 RENDER_EXPORTS = ["render_add_mesh", "render_finalize", "camera_create", "camera_buffer", "camera_obs_buffer", "camera_take_picture"]
 # include/msk_task.h — fused task kernels (HIP library only; the test-suite's CPU checker has no counterpart)
-TASK_EXPORTS = ["task_pickcube_init", "task_pickcube_set_action", "control_step", "task_pickcube_observe"]
+TASK_EXPORTS = ["task_pickcube_init", "task_pickcube_set_action", "control_step", "task_pickcube_observe",
+                "task_pusht_init", "task_pusht_set_action", "task_pusht_observe"]
 K_DYNAMICS, K_COLLIDE, K_SOLVE = 0, 1, 2
 KERNEL_SLOTS = {"k_dynamics": K_DYNAMICS, "k_collide": K_COLLIDE, "k_solve": K_SOLVE}
 
@@ -60,6 +61,14 @@ class PickCubeDesc(C.Structure):
         ("arm_dofs", C.c_int32), ("arm_delta", C.c_float), ("gripper_mid", C.c_float), ("gripper_half", C.c_float),
         ("goal_thresh", C.c_float), ("min_force", C.c_float), ("max_angle_deg", C.c_float), ("static_thresh", C.c_float),
         ("max_episode_steps", C.c_int32),
+    ]
+
+
+class PushTDesc(C.Structure):
+    _fields_ = [
+        ("tee", C.c_int32), ("goal", C.c_int32), ("tcp", C.c_int32), ("arm_dofs", C.c_int32), ("arm_delta", C.c_float),
+        ("goal_xy", C.c_float * 2), ("goal_z_rot", C.c_float), ("world_to_goal", C.c_float * 6), ("uv_scale", C.c_float),
+        ("intersection_thresh", C.c_float), ("max_episode_steps", C.c_int32),
     ]
 
 
@@ -135,6 +144,9 @@ class NativeLib:
             "task_pickcube_set_action": (i32, [vp, vp, vp]),
             "control_step": (i32, [vp, i32, vp]),
             "task_pickcube_observe": (i32, [vp, vp, vp, vp, vp, i32, vp]),
+            "task_pusht_init": (i32, [vp, C.POINTER(PushTDesc), C.POINTER(C.c_uint8)]),
+            "task_pusht_set_action": (i32, [vp, vp, vp]),
+            "task_pusht_observe": (i32, [vp, vp, i32, vp, vp, vp, i32, vp]),
         }
         self.has_task_kernels = all(hasattr(self.dll, prefix + n) for n in task_sig)
         if self.has_task_kernels:

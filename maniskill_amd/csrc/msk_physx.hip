@@ -57,6 +57,9 @@ struct msk_ctx {
   RCamera cams[MSK_MAX_CAMERAS];
   msk_pickcube_desc pickcube; /* fused task kernels (include/msk_task.h) */
   bool has_pickcube;
+  msk_pusht_desc pusht;
+  PushTTables pusht_tb;
+  bool has_pusht = false;
   bool kin_dirty;        /* link frames in st.bpose are older than (q, qd): run k_kinematics before reading them */
   uint32_t groups[MSK_MAX_SHAPES][4]; /* collision groups: only the static pair filter needs them */
   std::vector<void*> allocs;
@@ -750,6 +753,59 @@ MSK_API int msk_task_pickcube_set_action(msk_ctx* c, const float* actions, void*
   if (!c->has_pickcube) return fail(c, MSK_ERR_INVALID, "pickcube task not initialised");
   const int N = c->model.N;
   hipLaunchKernelGGL(k_pickcube_set_action, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->pickcube, actions);
+  HIP_TRY(hipGetLastError());
+  return MSK_OK;
+}
+
+MSK_API int msk_task_pusht_init(msk_ctx* c, const msk_pusht_desc* d, const uint8_t* tee_render) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "task init before finalize");
+  const int nb = c->model.nb;
+  const int ids[3] = {d->tee, d->goal, d->tcp};
+  for (int i = 0; i < 3; ++i)
+    if (ids[i] < 0 || ids[i] >= nb) return fail(c, MSK_ERR_INVALID, "pusht: bad body id");
+  if (d->arm_dofs != c->model.nd || d->arm_dofs > MSK_MAX_DOF) return fail(c, MSK_ERR_INVALID, "pusht: expects an arm without gripper joints");
+  HIP_TRY(hipSetDevice(c->device));
+  /* the mask's pixels in row-major order (the order of the boolean-mask gather of push_t.py:383), and the image of the goal
+   * mask under final.permute(0, 2, 1).flip(1): a mark at (ix, iy) is compared with tee_render[63 - iy][ix] */
+  std::vector<unsigned short> src;
+  std::vector<unsigned> hit(128, 0u);
+  for (int r = 0; r < 64; ++r)
+    for (int col = 0; col < 64; ++col)
+      if (tee_render[r * 64 + col]) src.push_back((unsigned short)(r << 8 | col));
+  for (int ix = 0; ix < 64; ++ix)
+    for (int iy = 0; iy < 64; ++iy)
+      if (tee_render[(63 - iy) * 64 + ix]) hit[(ix * 64 + iy) >> 5] |= 1u << ((ix * 64 + iy) & 31);
+  if (src.empty()) return fail(c, MSK_ERR_INVALID, "pusht: empty mask");
+  unsigned short* d_src = nullptr;
+  unsigned* d_hit = nullptr;
+  ALLOC(d_src, src.size());
+  ALLOC(d_hit, 128);
+  HIP_TRY(hipMemcpy(d_src, src.data(), src.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_hit, hit.data(), 128 * sizeof(unsigned), hipMemcpyHostToDevice));
+  c->pusht = *d;
+  c->pusht_tb.src = d_src; c->pusht_tb.nsrc = (int)src.size(); c->pusht_tb.hit = d_hit;
+  c->has_pusht = true;
+  return MSK_OK;
+}
+
+MSK_API int msk_task_pusht_set_action(msk_ctx* c, const float* actions, void* stream) {
+  if (!c->has_pusht) return fail(c, MSK_ERR_INVALID, "pusht task not initialised");
+  const int N = c->model.N;
+  hipLaunchKernelGGL(k_pusht_set_action, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->pusht, actions);
+  HIP_TRY(hipGetLastError());
+  return MSK_OK;
+}
+
+MSK_API int msk_task_pusht_observe(msk_ctx* c, float* obs, int obs_dim, float* reward, uint8_t* flags, int32_t* elapsed, int advance,
+                                   void* stream) {
+  if (!c->has_pusht) return fail(c, MSK_ERR_INVALID, "pusht task not initialised");
+  if (obs_dim != 2 * c->pusht.arm_dofs + 7 && obs_dim != 2 * c->pusht.arm_dofs + 17) return fail(c, MSK_ERR_INVALID, "pusht: obs_dim is 21 or 31");
+  if (c->kin_dirty) {
+    launch_kinematics(c->model, c->d_model, c->st, (hipStream_t)stream);
+    c->kin_dirty = false;
+  }
+  hipLaunchKernelGGL(k_pusht_observe, dim3(c->model.N), dim3(64), 0, (hipStream_t)stream, c->d_model, c->st, c->pusht, c->pusht_tb, obs,
+                     obs_dim, reward, flags, elapsed, advance);
   HIP_TRY(hipGetLastError());
   return MSK_OK;
 }

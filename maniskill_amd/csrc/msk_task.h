@@ -118,4 +118,97 @@ __global__ void __launch_bounds__(256) k_pickcube_observe(const DModel* __restri
   f[6] = 0; f[7] = 0;
 }
 
+/* ---- PushT-v1 ------------------------------------------------------------------------------------------------------ */
+struct PushTTables {
+  const unsigned short* src;   /* [nsrc] masked source pixels of the T in its own frame: row << 8 | column (row-major order) */
+  int nsrc;
+  const unsigned* hit;         /* [128] bit (ix * 64 + iy): a mark at (ix, iy) lands on the goal T's mask (permute + flip folded in) */
+};
+
+__global__ void __launch_bounds__(256) k_pusht_set_action(const DModel* __restrict__ m, DState st, msk_pusht_desc d,
+                                                          const float* __restrict__ actions) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= m->N) return;
+  float* E = EREC(st, m, e);
+  const float* a = actions + (size_t)e * d.arm_dofs;
+  for (int j = 0; j < d.arm_dofs; ++j) {
+    const float aj = fminf(fmaxf(a[j], -1.0f), 1.0f);
+    E[m->lay.qt + j] = E[m->lay.q + j] + d.arm_delta * aj;
+  }
+}
+
+/* quat_to_z_euler (push_t.py:322-327): 2 acos(clamp(w * sign(z))) */
+MSK_DEV float pusht_z_euler(quat q) {
+  const float sg = (q.z < 0.0f) ? -1.0f : 1.0f;
+  return 2.0f * acosf(fminf(fmaxf(q.w * sg, -1.0f), 1.0f));
+}
+
+/* one wavefront per env: the T's mask pixels are pushed through goal-from-world x world-from-T and marked in a 64 x 64 bit
+ * image in LDS; the marks that fall on the goal mask are counted */
+__global__ void __launch_bounds__(64) k_pusht_observe(const DModel* __restrict__ m, DState st, msk_pusht_desc d, PushTTables tb,
+                                                      float* __restrict__ obs, int obs_dim, float* __restrict__ reward,
+                                                      uint8_t* __restrict__ flags, int* __restrict__ elapsed, int advance) {
+  __shared__ unsigned img[128];
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const float* E = EREC(st, m, e);
+  img[lane] = 0u; img[lane + 64] = 0u;
+  const pose tee = load_pose(E, m->lay.bpose, d.tee);
+  const float a = pusht_z_euler(tee.q);
+  const float ca = cosf(a), sa = sinf(a);
+  /* T = world_to_goal @ [[c, -s, x], [s, c, y], [0, 0, 1]] */
+  const float* W = d.world_to_goal;
+  const float t00 = W[0] * ca + W[1] * sa, t01 = W[0] * -sa + W[1] * ca, t02 = W[0] * tee.p.x + W[1] * tee.p.y + W[2];
+  const float t10 = W[3] * ca + W[4] * sa, t11 = W[3] * -sa + W[4] * ca, t12 = W[3] * tee.p.x + W[4] * tee.p.y + W[5];
+  __syncthreads();
+  for (int j = lane; j < tb.nsrc; j += 64) {
+    const int rc = tb.src[j], r = rc >> 8, c = rc & 255;
+    const float u = ((float)(c - 32) + 0.5f) / d.uv_scale, v = ((float)(32 - r) + 0.5f) / d.uv_scale;
+    const float x = t00 * u + t01 * v + t02, y = t10 * u + t11 * v + t12;
+    int ix = (int)(x * d.uv_scale + 32.0f), iy = (int)(y * d.uv_scale + 32.0f);   /* .long(): towards zero */
+    if (ix < 0 || ix >= 64 || iy < 0 || iy >= 64) { ix = 0; iy = 0; }
+    const int bit = ix * 64 + iy;
+    atomicOr(&img[bit >> 5], 1u << (bit & 31));
+  }
+  __syncthreads();
+  int cnt = __popc(img[lane] & tb.hit[lane]) + __popc(img[lane + 64] & tb.hit[lane + 64]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if (lane != 0) return;
+  const float inter = (float)cnt / (float)tb.nsrc;
+  const bool success = inter >= d.intersection_thresh;
+  /* observation */
+  float* o = obs + (size_t)e * obs_dim;
+  const int nq = d.arm_dofs;
+  for (int j = 0; j < nq; ++j) { o[j] = E[m->lay.q + j]; o[nq + j] = E[m->lay.qd + j]; }
+  const pose tcp = load_pose(E, m->lay.bpose, d.tcp);
+  float* ot = o + 2 * nq;
+  ot[0] = tcp.p.x; ot[1] = tcp.p.y; ot[2] = tcp.p.z; ot[3] = tcp.q.w; ot[4] = tcp.q.x; ot[5] = tcp.q.y; ot[6] = tcp.q.z;
+  const pose goal = load_pose(E, m->lay.bpose, d.goal);
+  if (obs_dim >= 2 * nq + 17) {
+    float* og = ot + 7;
+    og[0] = goal.p.x; og[1] = goal.p.y; og[2] = goal.p.z;
+    og[3] = tee.p.x; og[4] = tee.p.y; og[5] = tee.p.z; og[6] = tee.q.w; og[7] = tee.q.x; og[8] = tee.q.y; og[9] = tee.q.z;
+  }
+  /* compute_dense_reward / 3 (push_t.py:511-540) */
+  const float rot_rew = cosf(a - d.goal_z_rot);
+  const float h = (rot_rew + 1.0f) / 2.0f;
+  float rew = (h * h) / 2.0f;
+  const float dgx = tee.p.x - goal.p.x, dgy = tee.p.y - goal.p.y;
+  const float d_goal = sqrtf(dgx * dgx + dgy * dgy);
+  const float g1 = 1.0f - tanhf(5.0f * d_goal);
+  rew = rew + (g1 * g1) / 2.0f;
+  const float dx = tee.p.x - tcp.p.x, dy = tee.p.y - tcp.p.y, dz = tee.p.z - tcp.p.z;
+  const float d_tcp = sqrtf(dx * dx + dy * dy + dz * dz);
+  rew = rew + sqrtf(1.0f - tanhf(5.0f * d_tcp)) / 20.0f;
+  if (success) rew = 3.0f;
+  reward[e] = rew / 3.0f;
+  int el = elapsed[e] + (advance ? 1 : 0);
+  elapsed[e] = el;
+  uint8_t* f = flags + (size_t)e * 8;
+  f[0] = success; f[1] = 0; f[2] = 0; f[3] = 0;
+  f[4] = success;
+  f[5] = el >= d.max_episode_steps;
+  f[6] = 0; f[7] = 0;
+}
+
 #endif

@@ -41,7 +41,7 @@ class PushTEnv:
 
     def __init__(self, num_envs: int = 1, device: Optional[str] = None, sim_config: Optional[SimConfig] = None,
                  robot_init_qpos_noise: float = 0.02, obs_mode: str = "state", env_index_offset: int = 0,
-                 total_envs: Optional[int] = None, px_factory=None):
+                 total_envs: Optional[int] = None, px_factory=None, fused: Optional[bool] = None):
         self.num_envs = int(num_envs)
         self.sim_config = sim_config or SimConfig()
         self.robot_init_qpos_noise = robot_init_qpos_noise
@@ -89,6 +89,24 @@ class PushTEnv:
             p, q = look_at(eye=[0.3, 0, 0.6], target=[-0.1, 0, 0.1])
             self.camera = RenderCameraGroup(self.px, CameraConfig("base_camera", p, q, 128, 128, np.pi / 2, 0.01, 100.0))
         self.obs_dim = 7 + 7 + 7 + 3 + 7
+        # fused task kernels (include/msk_task.h): controller, evaluate / obs / reward as two launches instead of ~100 torch ops
+        can_fuse = getattr(self.px.lib, "has_task_kernels", False) and not self.px.host_memory
+        self.fused = can_fuse if fused is None else bool(fused)
+        self._buffers_stale = False
+        if self.fused:
+            if not can_fuse:
+                raise RuntimeError("fused task kernels need the HIP backend")
+            from .. import _native as NN
+            import ctypes as C
+            w2g = self.world_to_goal_trans.cpu().numpy().astype(np.float32)
+            d = NN.PushTDesc(tee=self._b_tee, goal=self._b_goal, tcp=self._b_tcp, arm_dofs=7, arm_delta=self.arm_delta,
+                             goal_xy=(C.c_float * 2)(*self.goal_offset), goal_z_rot=float(self.goal_z_rot),
+                             world_to_goal=(C.c_float * 6)(*[float(x) for x in w2g[:2].reshape(-1)]),
+                             uv_scale=float(np.float32((self.res / 2) / self.uv_half_width)),
+                             intersection_thresh=self.intersection_thresh, max_episode_steps=self.max_episode_steps)
+            mask = np.ascontiguousarray(self.tee_render.cpu().numpy().astype(np.uint8))
+            self.px.lib.check(self.px.ctx, self.px.lib.task_pusht_init(self.px.ctx, C.byref(d), mask.ctypes.data_as(C.POINTER(C.c_uint8))),
+                              "task_pusht_init")
         self.reset(seed=None)
 
     # ---------------------------------------------------------------- the 64 x 64 "pseudo render" tables (push_t.py:264-320)
@@ -148,15 +166,26 @@ class PushTEnv:
         return inter / self.tee_render.bool().sum().float()
 
     # ---------------------------------------------------------------- struct-style views
+    def _fresh(self):
+        """Fused mode publishes the sapien-style buffers lazily: refresh them before any host-side read."""
+        if self.fused and self._buffers_stale:
+            self.px.gpu_fetch_all()
+            self._buffers_stale = False
+
     def _pose(self, body):
+        self._fresh()
         raw = self._rbd[:, body, :7].clone()
         raw[:, :3] -= self._offsets
         return raw
 
     @property
-    def qpos(self): return self._qpos[:, :7]
+    def qpos(self):
+        self._fresh()
+        return self._qpos[:, :7]
     @property
-    def qvel(self): return self._qvel[:, :7]
+    def qvel(self):
+        self._fresh()
+        return self._qvel[:, :7]
     @property
     def tcp_pose(self): return self._pose(self._b_tcp)
 
@@ -166,6 +195,7 @@ class PushTEnv:
         dev = self.device
         env_idx = torch.as_tensor(options["env_idx"], device=dev, dtype=torch.long) if "env_idx" in options else torch.arange(self.num_envs, device=dev)
         idx_np = env_idx.cpu().numpy()
+        self._fresh()
         if seed is not None:
             seeds = (np.asarray(seed).reshape(-1) if not np.isscalar(seed) else np.array([seed])).astype(np.int64)
             if len(seeds) == 1:
@@ -208,11 +238,48 @@ class PushTEnv:
         self.px.gpu_apply_all()
         self.px.gpu_update_articulation_kinematics()
         self.px.gpu_fetch_all()
+        self._buffers_stale = False
+        if self.fused:
+            obs, _, _, _, info = self._fused_observe(False)
+            return obs, info
         info = self.get_info()
         return self.get_obs(info), info
 
     # ---------------------------------------------------------------- step
+    def _fused_observe(self, advance: bool):
+        import ctypes as C
+        L, px, N, dev = self.px.lib, self.px, self.num_envs, self.device
+        od = self.obs_dim if self.camera is None else 21
+        obs = torch.empty(N, od, dtype=torch.float32, device=dev)
+        rew = torch.empty(N, dtype=torch.float32, device=dev)
+        fl = torch.empty(N, 8, dtype=torch.bool, device=dev)
+        L.check(px.ctx, L.task_pusht_observe(px.ctx, C.c_void_p(obs.data_ptr()), od, C.c_void_p(rew.data_ptr()), C.c_void_p(fl.data_ptr()),
+                                             C.c_void_p(self._elapsed_steps.data_ptr()), 1 if advance else 0, px._stream()), "task_pusht_observe")
+        info = dict(elapsed_steps=self._elapsed_steps.clone(), success=fl[:, 0])
+        if self.camera is not None:
+            self.camera.take_picture()
+            obs = dict(state=obs, sensor_data=dict(base_camera=self.camera.get_obs()),
+                       sensor_param=dict(base_camera=dict(intrinsic_cv=self.camera.intrinsic_cv)))
+        return obs, rew, fl[:, 4], fl[:, 5], info
+
+    def _fused_step(self, action):
+        import ctypes as C
+        L, px = self.px.lib, self.px
+        if action is not None:
+            action = torch.as_tensor(action, dtype=torch.float32, device=self.device)
+            if action.ndim == 1:
+                action = action[None]
+            if action.shape != (self.num_envs, self.action_dim):
+                raise AssertionError(f"Received action of shape {tuple(action.shape)} but expected shape ({self.num_envs}, {self.action_dim})")
+            action = action.contiguous()
+            L.check(px.ctx, L.task_pusht_set_action(px.ctx, C.c_void_p(action.data_ptr()), px._stream()), "task_pusht_set_action")
+        L.check(px.ctx, L.control_step(px.ctx, self._sim_steps_per_control, px._stream()), "control_step")
+        self._buffers_stale = True
+        return self._fused_observe(True)
+
     def step(self, action):
+        if self.fused:
+            return self._fused_step(action)
         if action is not None:
             action = torch.as_tensor(action, dtype=torch.float32, device=self.device)
             if action.ndim == 1:
@@ -265,6 +332,8 @@ class PushTEnv:
         return self.compute_dense_reward(info) / 3.0
 
     def get_state(self):
+        self._fresh()
+
         def actor(bid):
             s = self._rbd[:, bid, :].clone()
             s[:, :3] -= self._offsets

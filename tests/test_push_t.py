@@ -77,7 +77,7 @@ def test_camera_observation(oracle_factory):
 @pytest.mark.gpu
 def test_hip_matches_oracle_rollout_with_camera(oracle_factory):
     n = 64
-    gpu = PushTEnv(num_envs=n, device="cuda:0", obs_mode="depth+segmentation")
+    gpu = PushTEnv(num_envs=n, device="cuda:0", obs_mode="depth+segmentation", fused=False)   # same host code on both sides
     cpu = PushTEnv(num_envs=n, px_factory=oracle_factory, obs_mode="depth+segmentation")
     og, _ = gpu.reset(seed=2022); oc, _ = cpu.reset(seed=2022)
     assert torch.equal(og["state"].cpu(), oc["state"])
@@ -103,3 +103,46 @@ def test_full_size_4096_with_camera():
     seg = obs["sensor_data"]["base_camera"]["segmentation"]
     assert ((seg == env._b_tee + 1).flatten(1).any(1)).all()
     assert env.px.get_overflow() == 0
+
+
+@pytest.mark.gpu
+def test_fused_task_kernels_match_the_torch_path():
+    """include/msk_task.h PushT kernels (product default) against the readable torch implementation, same HIP physics:
+    rollout obs / reward, and the pseudo-render success flag over T poses scattered around the goal (both sides of the
+    0.9 coverage threshold)."""
+    n = 512
+    fz = PushTEnv(num_envs=n, device="cuda:0")
+    th = PushTEnv(num_envs=n, device="cuda:0", fused=False)
+    assert fz.fused and not th.fused
+    of, _ = fz.reset(seed=5); ot, _ = th.reset(seed=5)
+    assert torch.allclose(of, ot, atol=1e-6)
+    gen = torch.Generator().manual_seed(3)
+    for t in range(20):
+        a = (2 * torch.rand(n, 7, generator=gen) - 1).to("cuda:0")
+        of, rf, tf, uf, inf_ = fz.step(a)
+        ot, rt, tt, ut, int_ = th.step(a)
+        assert torch.allclose(of, ot, rtol=1e-5, atol=1e-6), t
+        assert torch.allclose(rf, rt, atol=1e-5) and torch.equal(tf, tt) and torch.equal(uf, ut)
+        assert torch.equal(inf_["elapsed_steps"], int_["elapsed_steps"])
+    assert torch.equal(fz.get_state(), th.get_state())
+    # T blocks teleported around the goal pose: coverage from ~0 to 1
+    g = torch.Generator().manual_seed(11)
+    dxy = (torch.rand(n, 2, generator=g) - 0.5) * 0.04
+    dang = (torch.rand(n, generator=g) - 0.5) * 0.3
+    dxy[:32] = 0.0; dang[:32] = 0.0
+    ang = fz.goal_z_rot + dang
+    for env in (fz, th):
+        env._fresh() if env.fused else None
+        env._rbd[:, env._b_tee, 0] = fz.goal_offset[0] + dxy[:, 0].to("cuda:0") + env._offsets[:, 0]
+        env._rbd[:, env._b_tee, 1] = fz.goal_offset[1] + dxy[:, 1].to("cuda:0") + env._offsets[:, 1]
+        env._rbd[:, env._b_tee, 2] = 0.021
+        env._rbd[:, env._b_tee, 3] = torch.cos(ang / 2).to("cuda:0"); env._rbd[:, env._b_tee, 4:6] = 0.0
+        env._rbd[:, env._b_tee, 6] = torch.sin(ang / 2).to("cuda:0")
+        env.px.gpu_apply_all(); env.px.gpu_fetch_all()
+    sf = fz._fused_observe(False)[4]["success"]
+    ratio = th.pseudo_render_intersection()
+    st = ratio >= th.intersection_thresh
+    assert sf[:32].all() and st[:32].all() and 0.05 < st.float().mean() < 0.95
+    near = (ratio - th.intersection_thresh).abs() < 3.0 / 795.0     # a pixel or two of the 64 x 64 mask: rounding of the transform
+    assert torch.equal(sf[~near], st[~near])
+    assert (sf != st).float().mean() < 0.01
