@@ -51,6 +51,8 @@ class ObservationGather:
         assert equal_shards, "all_gather_into_tensor needs equal shard sizes (pad the env count to a multiple of world)"
 
     def __call__(self, obs, reward, terminated, truncated):
+        if self.world == 1:   # one shard: nothing to exchange, nothing to pack
+            return obs, reward, terminated, truncated
         s = self.send
         s[:, : self.obs_dim] = obs
         s[:, self.obs_dim] = reward

@@ -256,3 +256,20 @@ def test_every_solver_class_computes_the_same_bits(caps):
         assert seen[3] == n * steps
     assert seen[1:].sum() > 0
     assert alt.px.get_overflow() == 0
+
+
+@pytest.mark.parametrize("n", [1, 37, 100, 1000])
+def test_env_counts_that_are_not_powers_of_two(oracle_factory, n):
+    """The launch geometry (env groups, 64-env classification chunks, solver lists) must not care about the env count."""
+    gpu = PickCubeEnv(num_envs=n, device=DEV, fused=False)
+    cpu = PickCubeEnv(num_envs=n, px_factory=oracle_factory)
+    gpu.reset(seed=3)
+    cpu.reset(seed=3)
+    gen = torch.Generator().manual_seed(5)
+    for t in range(12):
+        a = 2 * torch.rand(n, 8, generator=gen) - 1
+        gpu.step(a.to(DEV))
+        cpu.step(a)
+        assert gpu.px.get_solver_class_counts().sum() == n
+    assert _close(gpu.get_state().cpu().numpy(), cpu.get_state().numpy())
+    assert gpu.px.get_overflow() == 0
