@@ -162,12 +162,12 @@ __global__ void __launch_bounds__(64) k_classify(const DModel* __restrict__ m, D
 /* One wavefront per (env group, narrowphase list).
  *   plane and box-box lists (blockIdx.y = 0, 1): one lane per surviving pair of `group` envs (msk_collide_lane.h) — the
  *     lists are long, a wave holds up to 64 pairs and fetches the per-pair code once for all of them;
- *   hull list (blockIdx.y = 2 ..): a 16-lane group per pair (msk_collide.h), four pairs in flight, on a quarter of the
- *     env group per block — few pairs, each a long chain of support scans over up to 64 vertices.
+ *   hull list (blockIdx.y = 2 ..): a 16-lane group per pair (msk_collide.h), four pairs in flight, four blocks sharing
+ *     the group's list — few pairs, each a long chain of support scans over up to 64 vertices.
  * `group` = 16 at 4096 envs, fewer when there are few envs (then the launch is bound by its slowest wave). */
 template <int TYPE, int LPI>   /* LPI = lanes per item: 1 or NPG */
-MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, const int e0, const int group, int* pref, float* s_ws,
-                              float* s_we) {
+MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, const int e0, const int group, const int part,
+                              const int nparts, int* pref, float* s_ws, float* s_we) {
   constexpr int type = TYPE;
   const int lane = threadIdx.x;
   const float margin = 2.0f * m->cfg.contact_offset;
@@ -184,8 +184,10 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
   }
   __syncthreads();
   const int count = pref[NP_GROUP_MAX];
+  /* the group's list is dealt out pass by pass to the `nparts` blocks that share it (part = which one I am): the blocks
+   * stay balanced even when one env of the group owns most of the pairs (an arm lying on the table) */
   constexpr int STEP = (LPI == 1) ? PL_LANES : 64 / LPI;   /* pairs per pass */
-  for (int idx = (LPI == 1) ? (lane < PL_LANES ? lane : count) : lane / LPI; idx < count; idx += STEP) {
+  for (int idx = part * STEP + ((LPI == 1) ? (lane < PL_LANES ? lane : count) : lane / LPI); idx < count; idx += STEP * nparts) {
   int j = 0;
 #pragma unroll
   for (int k = 1; k < NP_GROUP_MAX; ++k) j += (k < group && idx >= pref[k]) ? 1 : 0;
@@ -313,8 +315,8 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
   }
 }
 
-/* blockIdx.y walks [plane | box-box | hull] sub-blocks of env group blockIdx.x: cfg.x/y/z of them, each on an equal
- * share of the group's envs.
+/* blockIdx.y walks [plane | box-box | hull] blocks of env group blockIdx.x: cfg.nplane / nbox / nhull of them, the
+ * blocks of one kind share the group's list of that kind.
  * Per 64 consecutive envs, the block that finishes last sorts them into the solver lists (one wave, one env per lane:
  * a handful of same-address atomics per 64 envs). */
 struct NpCfg { int nplane, nbox, nhull; };
@@ -328,17 +330,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   float* s_we = s_lds + (64 / NPG) * WS_TOTAL;
   const int e0 = blockIdx.x * group;
   int y = blockIdx.y;
-  if (y < cfg.nplane) {
-    const int sub = group / cfg.nplane;
-    narrowphase_body<NP_PLANE, NPG>(m, st, e0 + y * sub, sub, pref, s_ws, s_we);
-  } else if ((y -= cfg.nplane) < cfg.nbox) {
-    const int sub = group / cfg.nbox;
-    narrowphase_body<NP_BOXBOX, 1>(m, st, e0 + y * sub, sub, pref, s_ws, s_we);
-  } else {
-    y -= cfg.nbox;
-    const int sub = group / cfg.nhull;
-    narrowphase_body<NP_GJK, NPG>(m, st, e0 + y * sub, sub, pref, s_ws, s_we);
-  }
+  if (y < cfg.nplane) narrowphase_body<NP_PLANE, NPG>(m, st, e0, group, y, cfg.nplane, pref, s_ws, s_we);
+  else if ((y -= cfg.nplane) < cfg.nbox) narrowphase_body<NP_BOXBOX, 1>(m, st, e0, group, y, cfg.nbox, pref, s_ws, s_we);
+  else narrowphase_body<NP_GJK, NPG>(m, st, e0, group, y - cfg.nbox, cfg.nhull, pref, s_ws, s_we);
   __threadfence();
   const int chunk = e0 / 64;
   const int first_blk = (chunk * 64 + group - 1) / group, end_env = min(chunk * 64 + 64, m->N);

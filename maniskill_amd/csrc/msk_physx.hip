@@ -542,8 +542,8 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
     static const int e_nhull = getenv("MSK_NP_NHULL") ? atoi(getenv("MSK_NP_NHULL")) : 4;
     NpCfg cfg;
     cfg.nplane = 1;
-    cfg.nbox = e_nbox < group ? e_nbox : group;
-    cfg.nhull = e_nhull < group ? e_nhull : group;
+    cfg.nbox = e_nbox;
+    cfg.nhull = e_nhull;
     hipLaunchKernelGGL(k_narrowphase, dim3((N + group - 1) / group, cfg.nplane + cfg.nbox + cfg.nhull), dim3(64), 0, s, c->d_model,
                        c->st, group, cfg);
   } else {

@@ -41,7 +41,7 @@ report("random")
 np_report("random(all steps)", 63 * 5 + 5)
 env.px.lib.dll.msk_debug_reset.argtypes = [C.c_void_p]
 env.px.lib.dll.msk_debug_reset(env.px.ctx)
-for _ in range(100): env.step(2 * torch.rand(n, 8, device="cuda:0") - 1)
+for _ in range(int(os.environ.get("PROBE_STEPS", "100"))): env.step(2 * torch.rand(n, 8, device="cuda:0") - 1)
 env.px.lib.dll.msk_debug_reset(env.px.ctx)
 for _ in range(40): env.step(2 * torch.rand(n, 8, device="cuda:0") - 1)
 report("random, steps 160-200")
