@@ -188,7 +188,7 @@ class PickCubeEnv:
             return state_obs
         self.camera.take_picture()
         return dict(state=state_obs, sensor_data=dict(base_camera=self.camera.get_obs()),
-                    sensor_param=dict(base_camera=dict(intrinsic_cv=self.camera.intrinsic_cv)))
+                    sensor_param=dict(base_camera=self.camera.get_params()))
 
     # ---------------------------------------------------------------- struct-style views
     def _fresh(self):

@@ -259,7 +259,7 @@ class PushTEnv:
         if self.camera is not None:
             self.camera.take_picture()
             obs = dict(state=obs, sensor_data=dict(base_camera=self.camera.get_obs()),
-                       sensor_param=dict(base_camera=dict(intrinsic_cv=self.camera.intrinsic_cv)))
+                       sensor_param=dict(base_camera=self.camera.get_params()))
         return obs, rew, fl[:, 4], fl[:, 5], info
 
     def _fused_step(self, action):
@@ -316,7 +316,7 @@ class PushTEnv:
             return torch.hstack([self.qpos, self.qvel, tcp, self._pose(self._b_goal)[:, :3], self._pose(self._b_tee)])
         self.camera.take_picture()
         return dict(state=torch.hstack([self.qpos, self.qvel, tcp]), sensor_data=dict(base_camera=self.camera.get_obs()),
-                    sensor_param=dict(base_camera=dict(intrinsic_cv=self.camera.intrinsic_cv)))
+                    sensor_param=dict(base_camera=self.camera.get_params()))
 
     def compute_dense_reward(self, info):
         tee = self._pose(self._b_tee)

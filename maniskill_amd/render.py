@@ -154,6 +154,78 @@ class RenderCameraGroup:
         # intrinsics of set_fovy(fovy, compute_x=True) (scene.py:250-257)
         fy = 0.5 * cfg.height / np.tan(0.5 * cfg.fov)
         self.intrinsic_cv = torch.tensor([[fy, 0, 0.5 * cfg.width], [0, fy, 0.5 * cfg.height], [0, 0, 1]], dtype=torch.float32)
+        self._cached_extrinsic = None
+        self._cached_model = None
+
+    # ---- camera matrices (utils/structs/render_camera.py:77-155; sensors/camera.py:248-253) ---------------------
+    @staticmethod
+    def _pose_to_matrix(p: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
+        """(B,3), (B,4 wxyz) -> (B,4,4)"""
+        w, x, y, z = q.unbind(-1)
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                         2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=-1).view(-1, 3, 3)
+        T = torch.zeros(p.shape[0], 4, 4, dtype=torch.float32, device=p.device)
+        T[:, :3, :3] = R
+        T[:, :3, 3] = p
+        T[:, 3, 3] = 1
+        return T
+
+    def get_global_pose(self) -> torch.Tensor:
+        """(N, 7) camera pose in its sub-scene's frame: the local pose, or mount.pose * local_pose (render_camera.py:313-317)."""
+        cfg, px = self.cfg, self.px
+        local = torch.tensor(list(cfg.p) + list(cfg.q), dtype=torch.float32, device=px.device)
+        N = px.num_envs
+        if cfg.mount < 0:
+            return local[None].repeat(N, 1)
+        px.gpu_fetch_all()
+        rbd = px.cuda_rigid_body_data.torch().view(N, px.bodies_per_env, 13)
+        mp = rbd[:, cfg.mount, :3] - px.scene_offsets
+        mq = rbd[:, cfg.mount, 3:7]
+        # pose product: p = mp + R(mq) lp ; q = mq * lq
+        Tm = self._pose_to_matrix(mp, mq)
+        lp = local[:3]
+        p = (Tm[:, :3, :3] @ lp) + mp
+        w1, x1, y1, z1 = mq.unbind(-1)
+        w2, x2, y2, z2 = local[3:7]
+        q = torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                         w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], dim=-1)
+        return torch.cat([p, q], dim=-1)
+
+    def get_extrinsic_matrix(self) -> torch.Tensor:
+        """(N, 3, 4) OpenCV extrinsic: ros2opencv @ inv(global pose)."""
+        if self.cfg.mount < 0 and self._cached_extrinsic is not None:
+            return self._cached_extrinsic
+        g = self.get_global_pose()
+        T = self._pose_to_matrix(g[:, :3], g[:, 3:7])
+        Tinv = torch.linalg.inv(T)
+        ros2opencv = torch.tensor([[0, 0, 1, 0], [-1, 0, 0, 0], [0, -1, 0, 0], [0, 0, 0, 1]], dtype=torch.float32, device=g.device).T
+        res = (ros2opencv @ Tinv)[:, :3, :4]
+        if self.cfg.mount < 0:
+            self._cached_extrinsic = res
+        return res
+
+    def get_model_matrix(self) -> torch.Tensor:
+        """(N, 4, 4) OpenGL camera-to-world: global pose * POSE_GL_TO_ROS (q = [-0.5, -0.5, 0.5, 0.5])."""
+        if self.cfg.mount < 0 and self._cached_model is not None:
+            return self._cached_model
+        g = self.get_global_pose()
+        gl = torch.tensor([-0.5, -0.5, 0.5, 0.5], dtype=torch.float32, device=g.device)
+        w1, x1, y1, z1 = g[:, 3:7].unbind(-1)
+        w2, x2, y2, z2 = gl
+        q = torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                         w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], dim=-1)
+        res = self._pose_to_matrix(g[:, :3], q)
+        if self.cfg.mount < 0:
+            self._cached_model = res
+        return res
+
+    def get_intrinsic_matrix(self) -> torch.Tensor:
+        return self.intrinsic_cv[None].repeat(self.px.num_envs, 1, 1).to(self.px.device)
+
+    def get_params(self) -> dict:
+        """Camera.get_params (sensors/camera.py:248-253)."""
+        return dict(extrinsic_cv=self.get_extrinsic_matrix(), cam2world_gl=self.get_model_matrix(), intrinsic_cv=self.get_intrinsic_matrix())
 
     def take_picture(self):
         L, px = self.px.lib, self.px

@@ -170,3 +170,29 @@ def test_hip_rasteriser_known_answers_and_full_size():
     env.reset(seed=2022); o2, _ = half.reset(seed=2022)
     env.camera.take_picture()
     assert torch.equal(env.camera.get_picture_cuda().torch()[128:192], half.camera.get_picture_cuda().torch())
+
+
+def test_camera_matrices_project_a_world_point_onto_the_pixel_the_rasteriser_drew(oracle_factory):
+    """get_params (render_camera.py:77-155): K @ extrinsic_cv of a small box's centre is where its segmentation id shows up;
+    cam2world_gl maps the camera's -z axis onto the viewing direction."""
+    from maniskill_amd.envs.pick_cube import PickCubeEnv
+
+    env = PickCubeEnv(num_envs=2, px_factory=oracle_factory, obs_mode="depth+segmentation")
+    obs, _ = env.reset(seed=4)
+    par = obs["sensor_param"]["base_camera"]
+    assert par["extrinsic_cv"].shape == (2, 3, 4) and par["cam2world_gl"].shape == (2, 4, 4) and par["intrinsic_cv"].shape == (2, 3, 3)
+    seg = obs["sensor_data"]["base_camera"]["segmentation"][..., 0]
+    depth = obs["sensor_data"]["base_camera"]["depth"][..., 0]
+    cube = env.cube_pose[:, :3]
+    for e in range(2):
+        pc = par["extrinsic_cv"][e] @ torch.cat([cube[e], torch.ones(1)])            # OpenCV camera frame: x right, y down, z forward
+        uv = par["intrinsic_cv"][e] @ pc
+        u, v = (uv[0] / uv[2]).item(), (uv[1] / uv[2]).item()
+        rows, cols = torch.nonzero(seg[e] == env._b_cube + 1, as_tuple=True)
+        assert len(rows) > 0
+        assert abs(cols.float().mean().item() + 0.5 - u) < 1.5 and abs(rows.float().mean().item() + 0.5 - v) < 1.5
+        assert abs(depth[e][rows, cols].float().mean().item() / 1000.0 - pc[2].item()) < 0.03   # depth (mm) = z of the OpenCV frame
+    fwd = par["cam2world_gl"][0, :3, :3] @ torch.tensor([0.0, 0.0, -1.0])
+    eye = par["cam2world_gl"][0, :3, 3]
+    to_target = torch.tensor([-0.1, 0.0, 0.1]) - eye                                   # PickCube's base_camera: look_at([0.3, 0, 0.6], [-0.1, 0, 0.1])
+    assert torch.allclose(fwd, to_target / to_target.norm(), atol=1e-4)
