@@ -155,6 +155,7 @@ class RenderCameraGroup:
         fy = 0.5 * cfg.height / np.tan(0.5 * cfg.fov)
         self.intrinsic_cv = torch.tensor([[fy, 0, 0.5 * cfg.width], [0, fy, 0.5 * cfg.height], [0, 0, 1]], dtype=torch.float32)
         self._cached_extrinsic = None
+        self._cached_intrinsic = None
         self._cached_model = None
 
     # ---- camera matrices (utils/structs/render_camera.py:77-155; sensors/camera.py:248-253) ---------------------
@@ -221,7 +222,9 @@ class RenderCameraGroup:
         return res
 
     def get_intrinsic_matrix(self) -> torch.Tensor:
-        return self.intrinsic_cv[None].repeat(self.px.num_envs, 1, 1).to(self.px.device)
+        if self._cached_intrinsic is None:
+            self._cached_intrinsic = self.intrinsic_cv[None].repeat(self.px.num_envs, 1, 1).to(self.px.device)
+        return self._cached_intrinsic
 
     def get_params(self) -> dict:
         """Camera.get_params (sensors/camera.py:248-253)."""
