@@ -165,6 +165,11 @@ int msk_step(msk_ctx* ctx, void* stream);
  * env*npairs + pair; value = sum of contact impulses of the last step() applied ON
  * body_a BY body_b.  Returns query id. */
 int msk_query_create_pairs(msk_ctx* ctx, const int32_t* body_pairs, int npairs);
+/* gpu_create_contact_body_impulse_query(bodies) (utils/structs/base.py:116-136, articulation.py:447-462): the net contact
+ * impulse of the last step() on each listed body, from every other body and the static scene.  Same buffer / run calls;
+ * output (num_envs*nbodies, 3), row = env*nbodies + i.  (A pair query whose second id is MSK_ANY_BODY.) */
+#define MSK_ANY_BODY (-2)
+int msk_query_create_bodies(msk_ctx* ctx, const int32_t* bodies, int nbodies);
 void* msk_query_buffer(msk_ctx* ctx, int query, int64_t shape[2]);
 /* gpu_query_contact_pair_impulses(query) */
 int msk_query_run(msk_ctx* ctx, int query, void* stream);

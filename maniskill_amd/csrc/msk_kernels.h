@@ -445,8 +445,8 @@ __global__ void __launch_bounds__(256) k_query(const DModel* __restrict__ m, DSt
     for (int p = 0; p < m->np; ++p) {
       const int ba = m->pinfo[p].ba, bb = m->pinfo[p].bb;
       float sgn;
-      if (ba == x && bb == y) sgn = 1.0f;
-      else if (ba == y && bb == x) sgn = -1.0f;
+      if (ba == x && (bb == y || y == MSK_ANY_BODY)) sgn = 1.0f;
+      else if (bb == x && (ba == y || y == MSK_ANY_BODY)) sgn = -1.0f;
       else continue;
       const int cnt = cnts[p];
       if (cnt == 0) continue;

@@ -608,6 +608,12 @@ MSK_API int msk_query_create_pairs(msk_ctx* c, const int32_t* body_pairs, int np
   return (int)c->queries.size() - 1;
 }
 
+MSK_API int msk_query_create_bodies(msk_ctx* c, const int32_t* bodies, int nbodies) {
+  std::vector<int32_t> pairs(2 * (size_t)(nbodies > 0 ? nbodies : 0));
+  for (int i = 0; i < nbodies; ++i) { pairs[2 * i] = bodies[i]; pairs[2 * i + 1] = MSK_ANY_BODY; }
+  return msk_query_create_pairs(c, pairs.data(), nbodies);
+}
+
 MSK_API void* msk_query_buffer(msk_ctx* c, int q, int64_t shape[2]) {
   if (q < 0 || q >= (int)c->queries.size()) return nullptr;
   shape[0] = (int64_t)c->model.N * c->queries[q].npairs; shape[1] = 3;

@@ -352,6 +352,20 @@ class PhysxGpuSystem:
         self._queries.append(q)
         return q
 
+    def gpu_create_contact_body_impulse_query(self, bodies) -> ContactPairImpulseQuery:
+        """bodies: template body ids; the query returns the net contact impulse on each of them (structs/base.py:116-136)."""
+        flat = np.ascontiguousarray(np.asarray(bodies, dtype=np.int32).reshape(-1))
+        qid = self.lib.check(self.ctx, self.lib.query_create_bodies(
+            self.ctx, flat.ctypes.data_as(C.POINTER(C.c_int32)), flat.shape[0]), "query_create_bodies")
+        shape = (C.c_int64 * 2)()
+        ptr = self.lib.query_buffer(self.ctx, qid, shape)
+        q = ContactPairImpulseQuery(qid, CudaArrayHandle(ptr, (shape[0], shape[1]), self.device, host=self.host_memory))
+        self._queries.append(q)
+        return q
+
+    def gpu_query_contact_body_impulses(self, query: ContactPairImpulseQuery):
+        self.lib.check(self.ctx, self.lib.query_run(self.ctx, query.id, self._stream()), "query_run")
+
     def gpu_query_contact_pair_impulses(self, query: ContactPairImpulseQuery):
         self.lib.check(self.ctx, self.lib.query_run(self.ctx, query.id, self._stream()), "query_run")
 

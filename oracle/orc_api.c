@@ -370,6 +370,13 @@ ORC_EXPORT int orc_query_create_pairs(orc_ctx* c, const int32_t* body_pairs, int
   return q;
 }
 
+ORC_EXPORT int orc_query_create_bodies(orc_ctx* c, const int32_t* bodies, int nbodies) {
+  int32_t pairs[2 * 64];
+  if (nbodies < 0 || nbodies > 64) return fail(c, MSK_ERR_CAPACITY, "too many bodies in one query");
+  for (int i = 0; i < nbodies; ++i) { pairs[2 * i] = bodies[i]; pairs[2 * i + 1] = MSK_ANY_BODY; }
+  return orc_query_create_pairs(c, pairs, nbodies);
+}
+
 ORC_EXPORT void* orc_query_buffer(orc_ctx* c, int q, int64_t shape[2]) {
   if (q < 0 || q >= c->nqueries) return NULL;
   shape[0] = (int64_t)c->num_envs * c->queries[q].npairs; shape[1] = 3;
@@ -388,8 +395,8 @@ ORC_EXPORT int orc_query_run(orc_ctx* c, int q, void* stream) {
       for (int k = 0; k < env->ncontacts; ++k) {
         const orc_contact* ct = &env->contacts[k];
         float sgn = 0.0f;
-        if (ct->ba == x && ct->bb == y) sgn = 1.0f;
-        else if (ct->ba == y && ct->bb == x) sgn = -1.0f;
+        if (ct->ba == x && (ct->bb == y || y == MSK_ANY_BODY)) sgn = 1.0f;
+        else if (ct->bb == x && (ct->ba == y || y == MSK_ANY_BODY)) sgn = -1.0f;
         else continue;
         v3 imp = v3_madd(v3_madd(v3_scale(ct->n, ct->lam[0]), ct->t1, ct->lam[1]), ct->t2, ct->lam[2]);
         sum = v3_madd(sum, imp, sgn);

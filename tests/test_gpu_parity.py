@@ -273,3 +273,23 @@ def test_env_counts_that_are_not_powers_of_two(oracle_factory, n):
         assert gpu.px.get_solver_class_counts().sum() == n
     assert _close(gpu.get_state().cpu().numpy(), cpu.get_state().numpy())
     assert gpu.px.get_overflow() == 0
+
+
+def test_body_impulse_query_matches_oracle(oracle_factory):
+    """gpu_create_contact_body_impulse_query: net contact impulses on the cube, a finger and the table, after a random rollout."""
+    n = 128
+    gpu = PickCubeEnv(num_envs=n, device=DEV, fused=False)
+    cpu = PickCubeEnv(num_envs=n, px_factory=oracle_factory)
+    bodies = [gpu._b_cube, gpu._b_f1, gpu._b_table, gpu._b_tcp]
+    qg = gpu.px.gpu_create_contact_body_impulse_query(bodies)
+    qc = cpu.px.gpu_create_contact_body_impulse_query(bodies)
+    gpu.reset(seed=21); cpu.reset(seed=21)
+    gen = torch.Generator().manual_seed(8)
+    for _ in range(25):
+        a = 2 * torch.rand(n, 8, generator=gen) - 1
+        gpu.step(a.to(DEV)); cpu.step(a)
+    gpu.px.gpu_query_contact_body_impulses(qg)
+    cpu.px.gpu_query_contact_body_impulses(qc)
+    g, c = qg.cuda_impulses.torch().cpu().numpy(), qc.cuda_impulses.torch().numpy()
+    assert g.shape == (n * 4, 3) and np.abs(c).max() > 1e-4
+    assert np.allclose(g, c, rtol=1e-4, atol=1e-6)

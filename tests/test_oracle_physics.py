@@ -250,3 +250,23 @@ def test_oracle_matches_its_golden_rollout(oracle_factory):
         obs, r, *_ = env.step(torch.from_numpy(g["actions"][t]))
         assert np.allclose(obs.numpy(), g["obs"][t + 1], rtol=1e-4, atol=1e-5), t
     assert np.allclose(env.get_state().numpy(), g["state"], rtol=1e-4, atol=1e-5)
+
+
+def test_body_impulse_query_is_the_weight_of_the_resting_cube(oracle_factory):
+    """gpu_create_contact_body_impulse_query (structs/base.py:116-136): net contact impulse on the cube at rest = m g dt upwards,
+    and the table receives the opposite; equals the pair query cube<-table when nothing else touches the cube."""
+    from maniskill_amd.envs.pick_cube import PickCubeEnv
+
+    env = PickCubeEnv(num_envs=2, px_factory=oracle_factory)
+    env.reset(seed=0)
+    qb = env.px.gpu_create_contact_body_impulse_query([env._b_cube, env._b_table])
+    qp = env.px.gpu_create_contact_pair_impulse_query([(env._b_cube, env._b_table)])
+    for _ in range(20):
+        env.step(None)
+    env.px.gpu_query_contact_body_impulses(qb)
+    env.px.gpu_query_contact_pair_impulses(qp)
+    b = qb.cuda_impulses.torch().view(2, 2, 3)
+    p = qp.cuda_impulses.torch().view(2, 1, 3)
+    mgdt = 0.064 * 9.81 * env.px.timestep
+    assert torch.allclose(b[:, 0, 2], torch.full((2,), mgdt), rtol=2e-2) and b[:, 0, :2].abs().max() < 1e-4
+    assert torch.allclose(b[:, 1], -b[:, 0], atol=1e-6) and torch.allclose(b[:, 0], p[:, 0], atol=1e-7)
