@@ -1,13 +1,14 @@
 /*
- * msk_kernels.h — the HIP kernels of one physics substep (gfx950, wave64).
+ * msk_kernels.h — collision, layout-converter and query kernels of one physics substep (gfx950, wave64).
  *
- * Launch shapes (N envs, P candidate pairs):
- *   k_dynamics   <<<N, 64>>>             one wavefront per env, lane = body / dof / A^-1 column: msk_dynamics.h
- *   k_broadphase <<<N, 64>>>             one wavefront per env: shape AABBs, pair culling, work lists
- *   k_narrowphase<<<(B, 3), 64>>>        grid-stride over the per-type work lists, one lane per surviving pair
- *   k_solve<G>   <<<N*G/64, 64>>>        G lanes per env (one per generalized coordinate): msk_solve.h
- *   k_apply / k_fetch / k_kinematics / k_query   memcpy-class layout converters (AoS rows <-> SoA)
- * All per-env data is SoA with env fastest (msk_model.h), so a wave's accesses coalesce.
+ * Launches of a substep (N envs):
+ *   k_dynamics    <<<N/2, 64>>>                half a wavefront per env, lane = body / dof / A^-1 column: msk_dynamics.h
+ *   k_broadphase  <<<N, 64>>>                  one wavefront per env: shape AABBs and oriented boxes, pair culling, work lists
+ *   k_narrowphase <<<(N/16, 1 + 1 + 4), 64>>>  per 16-env group: plane list, box-box list, four blocks sharing the hull list;
+ *                                              the last block of a 64-env chunk sorts its envs into the solver lists
+ *   k_csolve      <<<768 + N/4, 64>>>          constraint-space TGS, every capacity class in one launch: msk_solve.h
+ *   k_apply / k_fetch / k_kinematics / k_query / k_classify   on demand: layout converters (AoS rows <-> env records), queries
+ * All per-env data is env-major (msk_model.h: EnvLayout), so a wave's accesses to its env(s) are contiguous.
  * Arithmetic order mirrors the CPU oracle statement for statement (bitwise parity target).
  */
 #ifndef MSK_KERNELS_H
@@ -28,12 +29,11 @@ MSK_DEV pose shape_pose_dev(const DModel* m, const float* E, const DShape* sh) {
 }
 
 /* Collision runs in two kernels.
- *   k_broadphase  one wavefront per env: lane s computes the world AABB of shape s (LDS), lane p tests
- *                 candidate pair p against it; survivors are appended to the env's three work lists (one per
- *                 narrowphase type), culled pairs get their contact slot emptied.
- *   k_narrowphase one wave walks the lists of 16 consecutive envs for one type (blockIdx.y), so it runs one
- *                 code path on real items instead of 64 mostly-culled ones: contact generation + warm-start
- *                 matching.  Lists are per env and filled by ballot rank: no atomics, deterministic order.
+ *   k_broadphase  one wavefront per env: lane s computes the world AABB and the oriented box of shape s (LDS), lane p
+ *                 tests candidate pair p (AABBs; for hull pairs also the six face normals of the two oriented boxes);
+ *                 survivors are appended to the env's three work lists (one per narrowphase type) by ballot rank — no
+ *                 atomics, deterministic order —, culled pairs get their contact slot emptied.
+ *   k_narrowphase contact generation + warm-start matching, see the comment at the kernel.
  * The cull tests are the oracle's, so the set of pairs that reach the narrowphase is identical. */
 enum { NP_PLANE = 0, NP_BOXBOX = 1, NP_GJK = 2, NP_TYPES = 3 };
 

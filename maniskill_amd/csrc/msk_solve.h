@@ -10,20 +10,22 @@
  *                The lane keeps a, b = J dq, lambda, sum(lambda), c0, 1/A_rr of its <= 3 rows in VGPRs.
  *   build        the lane assembles its rows J (S_k . F against the LDS-resident motion subspace
  *                columns), Y = W J^T (W in LDS), parks Y in LDS, then walks all columns r and stores
- *                A[i][r] = J_i . Y_r for its rows i (per (column block, row block) nine contiguous words in LDS: a sweep step reads 3
- *                conflict-free dwords per lane).
+ *                A[i][r] = J_i . Y_r for its rows i (nine contiguous words per (column block, row block): a sweep
+ *                step reads them from one address with immediate offsets).
  *   sweep step   every lane evaluates the clamp for its own slot s (5 VALU), the owner's impulse change
  *                is broadcast (DPP row_newbcast / v_readlane), every lane does a[s'] += A[s'][r] * dl
  *                (3 FMA on operands prefetched one block ahead).  Chain: fma, max, min, sub, bcast, fma.
  *   finish       v = v* + Y^T lambda and dq = h (Np v* + Y^T sum lambda) by the first NVP lanes,
  *                impulses back to the contact slots, q/qd/qacc, free bodies.
  *
- * Two launches share this code.  k_csolve packs FOUR envs into a wavefront (16 lanes = 16 blocks each;
- * the broadcast is one DPP row_newbcast) because the median env has 6 blocks and a whole wave per env
- * would be issue-bound on idle lanes; the four share an LDS pool for Y and A, carved after counting.
- * An env with more than 16 blocks, or one that does not fit the pool (a few percent under random
- * actions: fingers or links lying on the table), appends itself to a list and is solved by
- * k_csolve_big: one wavefront per env, 64 blocks, v_readlane broadcast, the full 159 KB LDS image.
+ * One launch, four LDS capacity classes (k_csolve).  The median env has 6 blocks and a whole wave per env would be
+ * issue-bound on idle lanes, so class 0 (<= 13 blocks for nv <= 16) packs FOUR envs into a wavefront (16 lanes each, the
+ * broadcast is one DPP row_newbcast) sharing an LDS pool for Y and A, carved after counting.  Classes 1..3 (<= 20, <= 32,
+ * <= 64 blocks: fingers or links lying on the table) get one wavefront per env with v_readlane broadcast; class 3 keeps
+ * its A image in global memory (L2) behind a four-deep register prefetch ring, so every workgroup of the launch needs
+ * the same 46.5 KB of LDS.  The envs are sorted into the classes by the narrowphase (classify_envs) — exactly, from the
+ * same block count the solver computes —, the one-env-per-wave workgroups come first in the grid and walk the classes
+ * from the largest down: the longest solves start first, and they are what bounds the launch.
  * Arithmetic is the oracle's (oracle/orc_sim.c), operation for operation.
  */
 #ifndef MSK_SOLVE_H
