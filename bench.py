@@ -72,8 +72,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--env", default="PickCube-v1", choices=["PickCube-v1", "PushT-v1"],
                     help="PickCube-v1 (BASELINE.json's metric, default) or PushT-v1 (its camera config)")
-    ap.add_argument("--obs-mode", default="state", choices=["state", "depth+segmentation"],
-                    help="state (BASELINE.json's metric, default) or the camera path: 128x128 depth+segmentation per env")
+    ap.add_argument("--obs-mode", default="state", choices=["state", "depth+segmentation", "rgb", "rgbd", "rgb+depth+segmentation"],
+                    help="state (BASELINE.json's metric, default) or the camera path: 128x128 textures per env")
     ap.add_argument("--control-freq", type=int, default=20,
                     help="control frequency at sim 100 Hz: 20 = the task default (5 substeps, the metric); 50 = the frequency the "
                          "reference's own benchmark harness uses (2 substeps, examples/benchmarking/scripts/maniskill.sh)")
@@ -176,9 +176,9 @@ def main():
             },
         }
         if camera_mode:
-            img_bytes = n_local * 128 * 128 * 8      # PositionSegmentation int16 x 4 per pixel: the algorithmic output
-            result["metric"] = f"env steps/sec (whole node), {args.envs} parallel {args.env} envs, 128x128 depth+segmentation camera obs"
-            result["config"]["workload"] += ", base_camera 128x128 PositionSegmentation"
+            img_bytes = n_local * 128 * 128 * (8 + (4 if "rgb" in args.obs_mode else 0))   # PositionSegmentation int16 x 4 (+ Color u8 x 4) per pixel
+            result["metric"] = f"env steps/sec (whole node), {args.envs} parallel {args.env} envs, 128x128 {args.obs_mode} camera obs"
+            result["config"]["workload"] += ", base_camera 128x128 PositionSegmentation" + (" + Color" if "rgb" in args.obs_mode else "")
             result["camera"] = {"kernel": "k_render_setup + k_render_tiles", "us_per_frame": cam_us,
                                 "bound": "hbm", "algorithmic_bytes_per_frame": img_bytes,
                                 "achieved": img_bytes / (cam_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -35,6 +35,11 @@ extern "C" {
  * msk_render_finalize.  Returns the render shape index. */
 int msk_render_add_mesh(msk_ctx* ctx, int body, const float local_pose[7], const float* verts, int nverts,
                         const int32_t* tris, int ntris, int seg_id);
+/* RenderMaterial(base_color=rgba) of a render shape (building/actor_builder.py:166-191); default (0.8, 0.8, 0.8, 1). */
+int msk_render_set_base_color(msk_ctx* ctx, int render_shape, const float rgba[4]);
+/* scene.set_ambient_light + add_directional_light (envs/sapien_env.py:849-853; envs/scene.py:566-718): at most 4 directional
+ * lights, directions in the sub-scene frame.  Default: ManiSkill's default lighting (ambient 0.3; (1, 1, -1) and (0, 0, -1), white). */
+int msk_render_set_lights(msk_ctx* ctx, const float ambient[3], int ndir, const float* directions, const float* colors);
 /* RenderSystemGroup creation + set_cuda_poses (scene.py:1026-1037): uploads the geometry. */
 int msk_render_finalize(msk_ctx* ctx);
 /* RenderCameraComponent(width, height) + set_fovy(fovy, compute_x=True) + near / far + local pose
@@ -47,9 +52,13 @@ int msk_camera_create(msk_ctx* ctx, int width, int height, float fovy, float nea
 void* msk_camera_buffer(msk_ctx* ctx, int camera, int64_t shape[4]);
 /* Camera.get_obs(depth=True, segmentation=True) under the minimal pack's texture transform
  * (sensors/camera.py:190-242; render/shaders.py:141-145: depth = -position[..., [2]], segmentation = position[..., [3]]):
- * device pointers to int16 [num_envs][height][width][1] planes that msk_camera_take_picture fills together with the
+ * device pointers to int16 [num_envs][height][width][1] planes (uint8 x 4 for MSK_CAM_COLOR) that msk_camera_take_picture fills together with the
  * PositionSegmentation texture, so the observation needs no gather pass over the texture. */
-enum msk_camera_plane { MSK_CAM_DEPTH = 0, MSK_CAM_SEGMENTATION = 1 };
+/* MSK_CAM_COLOR: the `Color` texture of the minimal pack, r8g8b8a8unorm = uint8 [num_envs][height][width][4]
+ * (render/shaders.py:68-74,141-144: rgb = Color[..., :3]); background (0, 0, 0, 0); rendered from the first request of this
+ * buffer on (a camera that only serves depth / segmentation skips shading and the store).  The pack's GLSL is not in the
+ * reference tree; this backend shades flat per triangle: base_color * min(1, ambient + sum_l light_l * max(0, n . -dir_l)). */
+enum msk_camera_plane { MSK_CAM_DEPTH = 0, MSK_CAM_SEGMENTATION = 1, MSK_CAM_COLOR = 2 };
 void* msk_camera_obs_buffer(msk_ctx* ctx, int camera, int which, int64_t shape[4]);
 /* render_system_group.update_render() + camera_group.take_picture(): rasterises every env. */
 int msk_camera_take_picture(msk_ctx* ctx, int camera, void* stream);

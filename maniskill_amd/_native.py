@@ -31,7 +31,8 @@ EXPORTS = [
     "set_solver_classes", "get_solver_class_counts",
 ]
 # include/msk_render.h — camera pipeline (both libraries)
-RENDER_EXPORTS = ["render_add_mesh", "render_finalize", "camera_create", "camera_buffer", "camera_obs_buffer", "camera_take_picture"]
+RENDER_EXPORTS = ["render_add_mesh", "render_set_base_color", "render_set_lights", "render_finalize", "camera_create", "camera_buffer",
+                  "camera_obs_buffer", "camera_take_picture"]
 # include/msk_task.h — fused task kernels (HIP library only; the test-suite's CPU checker has no counterpart)
 TASK_EXPORTS = ["task_pickcube_init", "task_pickcube_set_action", "control_step", "task_pickcube_observe",
                 "task_pusht_init", "task_pusht_set_action", "task_pusht_observe"]
@@ -132,6 +133,8 @@ class NativeLib:
             "render_add_mesh": (i32, [vp, i32, fp, fp, i32, C.POINTER(C.c_int32), i32, i32]),
             "render_finalize": (i32, [vp]),
             "camera_create": (i32, [vp, i32, i32, f32, f32, f32, i32, fp]),
+            "render_set_base_color": (i32, [vp, i32, C.POINTER(C.c_float)]),
+            "render_set_lights": (i32, [vp, C.POINTER(C.c_float), i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
             "camera_buffer": (vp, [vp, i32, C.POINTER(C.c_int64)]),
             "camera_obs_buffer": (vp, [vp, i32, i32, C.POINTER(C.c_int64)]),
             "camera_take_picture": (i32, [vp, i32, vp]),

@@ -649,12 +649,24 @@ MSK_API int msk_render_add_mesh(msk_ctx* c, int body, const float local_pose[7],
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "render shapes are added after finalize");
   if (c->render_finalized) return fail(c, MSK_ERR_INVALID, "render_add_mesh after render_finalize");
   if (body >= c->model.nb) return fail(c, MSK_ERR_INVALID, "bad body");
-  if (!c->rmodel) { c->rmodel = new RModel(); memset(c->rmodel, 0, sizeof(RModel)); }
+  if (!c->rmodel) {
+    c->rmodel = new RModel();
+    memset(c->rmodel, 0, sizeof(RModel));
+    /* ManiSkill's default lighting (envs/sapien_env.py:849-853): ambient 0.3, directional (1, 1, -1) and (0, 0, -1), white */
+    RModel& r0 = *c->rmodel;
+    r0.ambient[0] = r0.ambient[1] = r0.ambient[2] = 0.3f;
+    r0.nlights = 2;
+    const float inv3 = 1.0f / sqrtf(3.0f);
+    r0.ldir[0][0] = inv3; r0.ldir[0][1] = inv3; r0.ldir[0][2] = -inv3;
+    r0.ldir[1][0] = 0.0f; r0.ldir[1][1] = 0.0f; r0.ldir[1][2] = -1.0f;
+    for (int l = 0; l < 2; ++l) r0.lcol[l][0] = r0.lcol[l][1] = r0.lcol[l][2] = 1.0f;
+  }
   RModel& r = *c->rmodel;
   if (r.ns >= MSK_MAX_RENDER_SHAPES || r.nv + nverts > MSK_MAX_RENDER_VERTS || r.nt + ntris > MSK_MAX_RENDER_TRIS)
     return fail(c, MSK_ERR_CAPACITY, "render geometry capacity exceeded");
   RShape& sh = r.shapes[r.ns];
   sh.body = body; sh.seg = seg_id; sh.local = pose_from7(local_pose);
+  sh.color[0] = sh.color[1] = sh.color[2] = 0.8f; sh.color[3] = 1.0f;   /* until msk_render_set_base_color says otherwise */
   for (int i = 0; i < nverts; ++i) {
     r.verts[r.nv + i].x = verts[3 * i]; r.verts[r.nv + i].y = verts[3 * i + 1]; r.verts[r.nv + i].z = verts[3 * i + 2];
     r.vshape[r.nv + i] = (unsigned char)r.ns;
@@ -667,6 +679,30 @@ MSK_API int msk_render_add_mesh(msk_ctx* c, int body, const float local_pose[7],
   }
   r.nv += nverts; r.nt += ntris;
   return r.ns++;
+}
+
+MSK_API int msk_render_set_base_color(msk_ctx* c, int render_shape, const float rgba[4]) {
+  if (!c->rmodel || render_shape < 0 || render_shape >= c->rmodel->ns) return fail(c, MSK_ERR_INVALID, "bad render shape");
+  if (c->render_finalized) return fail(c, MSK_ERR_INVALID, "render_set_base_color after render_finalize");
+  for (int k = 0; k < 4; ++k) c->rmodel->shapes[render_shape].color[k] = rgba[k];
+  return MSK_OK;
+}
+
+MSK_API int msk_render_set_lights(msk_ctx* c, const float ambient[3], int ndir, const float* directions, const float* colors) {
+  if (!c->rmodel) return fail(c, MSK_ERR_INVALID, "no render shapes");
+  if (c->render_finalized) return fail(c, MSK_ERR_INVALID, "render_set_lights after render_finalize");
+  if (ndir < 0 || ndir > MSK_MAX_LIGHTS) return fail(c, MSK_ERR_CAPACITY, "too many directional lights");
+  RModel& r = *c->rmodel;
+  for (int k = 0; k < 3; ++k) r.ambient[k] = ambient[k];
+  r.nlights = ndir;
+  for (int l = 0; l < ndir; ++l) {
+    const float x = directions[3 * l], y = directions[3 * l + 1], z = directions[3 * l + 2];
+    const float len = sqrtf(x * x + y * y + z * z);
+    if (!(len > 0.0f)) return fail(c, MSK_ERR_INVALID, "zero light direction");
+    r.ldir[l][0] = x / len; r.ldir[l][1] = y / len; r.ldir[l][2] = z / len;
+    for (int k = 0; k < 3; ++k) r.lcol[l][k] = colors[3 * l + k];
+  }
+  return MSK_OK;
 }
 
 MSK_API int msk_render_finalize(msk_ctx* c) {
@@ -721,9 +757,17 @@ MSK_API void* msk_camera_buffer(msk_ctx* c, int camera, int64_t shape[4]) {
 }
 
 MSK_API void* msk_camera_obs_buffer(msk_ctx* c, int camera, int which, int64_t shape[4]) {
-  if (camera < 0 || camera >= c->ncams || (which != MSK_CAM_DEPTH && which != MSK_CAM_SEGMENTATION)) return nullptr;
-  shape[0] = c->model.N; shape[1] = c->cams[camera].H; shape[2] = c->cams[camera].W; shape[3] = 1;
-  return which == MSK_CAM_DEPTH ? c->cams[camera].depth : c->cams[camera].seg;
+  if (camera < 0 || camera >= c->ncams || which < MSK_CAM_DEPTH || which > MSK_CAM_COLOR) return nullptr;
+  shape[0] = c->model.N; shape[1] = c->cams[camera].H; shape[2] = c->cams[camera].W; shape[3] = which == MSK_CAM_COLOR ? 4 : 1;
+  if (which == MSK_CAM_COLOR) { /* allocated on first request: cameras that never hand out Color do not shade or store it */
+    RCamera& cam = c->cams[camera];
+    if (!cam.color) {
+      if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+      if (dev_alloc(c, &cam.color, (size_t)c->model.N * cam.W * cam.H) < 0) return nullptr;
+    }
+    return cam.color;
+  }
+  return which == MSK_CAM_DEPTH ? (void*)c->cams[camera].depth : (void*)c->cams[camera].seg;
 }
 
 MSK_API int msk_camera_take_picture(msk_ctx* c, int camera, void* stream) {
@@ -735,7 +779,7 @@ MSK_API int msk_camera_take_picture(msk_ctx* c, int camera, void* stream) {
     c->kin_dirty = false;
   }
   const RCamera& cam = c->cams[camera];
-  const size_t lds = (MSK_MAX_RENDER_SHAPES * 8 + 2 * MSK_MAX_TILES + 8 + MSK_MAX_BIG + (size_t)c->rmodel->nv * 3) * sizeof(float);
+  const size_t lds = (MSK_MAX_RENDER_SHAPES * 8 + 2 * MSK_MAX_TILES + 8 + MSK_MAX_BIG + MSK_MAX_LIGHTS * 3 + (size_t)c->rmodel->nv * 3) * sizeof(float);
   hipLaunchKernelGGL(k_render_setup, dim3(N), dim3(256), lds, s, c->d_model, c->st, c->d_rmodel, cam);
   hipLaunchKernelGGL(k_render_tiles, dim3((cam.tiles_x * cam.tiles_y + MSK_TILES_PER_WAVE - 1) / MSK_TILES_PER_WAVE, N), dim3(64), 0, s, cam);
   HIP_TRY(hipGetLastError());

@@ -30,7 +30,8 @@
 #define MSK_TILES_PER_WAVE 4        /* consecutive tiles a wavefront walks, prefetching the next one's records */
 #define MSK_SETUP_WORDS 16
 
-struct RShape { int body, seg; pose local; };
+struct RShape { int body, seg; pose local; float color[4]; };
+#define MSK_MAX_LIGHTS 4
 struct RTri { int v0, v1, v2, shape; };
 struct RModel {
   int nv, nt, ns;
@@ -38,6 +39,10 @@ struct RModel {
   v3 verts[MSK_MAX_RENDER_VERTS];
   unsigned char vshape[MSK_MAX_RENDER_VERTS];
   RTri tris[MSK_MAX_RENDER_TRIS];
+  /* Color: flat Lambert shading by the scene's ambient + directional lights (directions in the env frame, normalised) */
+  float ambient[3];
+  int nlights;
+  float ldir[MSK_MAX_LIGHTS][3], lcol[MSK_MAX_LIGHTS][3];
 };
 struct RCamera {
   int W, H, mount, tiles_x, tiles_y;
@@ -52,6 +57,7 @@ struct RCamera {
   int* nbig;                       /* [N] */
   unsigned short* tile_bigmask;    /* [N][MSK_MAX_TILES]: bit b = large triangle b can cover a pixel centre of the tile */
   short* out;                      /* [N][H][W][4]        */
+  unsigned* color;                 /* [N][H][W]: Color r8g8b8a8unorm (r in the low byte), 0 = background; null until asked for */
   short* depth;                    /* [N][H][W]: -z of out (Camera.get_obs's depth), written by the same store */
   short* seg;                      /* [N][H][W]: w of out                                                      */
   int* overflow;                   /* [1]                 */
@@ -61,8 +67,33 @@ struct RCamera {
  * segmentation id, primitive id (tie break), pixel bounding box. */
 struct TriSetup {
   float A0, B0, C0, A1, B1, C1, A2, B2, C2, Aw, Bw, Cw;
-  int seg, prim, bbx, bby;         /* bbx = x0 | x1 << 16, bby = y0 | y1 << 16 */
+  int seg, prim, bb;               /* bb = x0 | x1 << 8 | y0 << 16 | y1 << 24 (images are at most 256 x 256) */
+  unsigned color;                  /* shaded r8g8b8a8 of the (flat) triangle */
 };
+#define BB_X0(bb) ((bb) & 0xFF)
+#define BB_X1(bb) (((bb) >> 8) & 0xFF)
+#define BB_Y0(bb) (((bb) >> 16) & 0xFF)
+#define BB_Y1(bb) (((unsigned)(bb)) >> 24)
+
+/* flat shading of one triangle (camera-frame corners p0 p1 p2, counter-clockwise seen from outside): per channel
+ * base * min(1, ambient + sum_l light_l * max(0, n . -dir_l)), rounded to 8 bits; alpha = 255 */
+MSK_DEV unsigned shade_triangle(v3 p0, v3 p1, v3 p2, const float* base, const float* ambient, int nl, const float* ldir_cam, const float* lcol) {
+  v3 n = v3_cross(v3_sub(p1, p0), v3_sub(p2, p0));
+  const float l = v3_len(n);
+  n = (l > 0.0f) ? v3_scale(n, 1.0f / l) : v3_make(0, 0, 0);
+  float lit[3] = {ambient[0], ambient[1], ambient[2]};
+  for (int k = 0; k < nl; ++k) {
+    const float d = fmaxf(0.0f, -(n.x * ldir_cam[k * 3] + n.y * ldir_cam[k * 3 + 1] + n.z * ldir_cam[k * 3 + 2]));
+    lit[0] = fmaf(lcol[k * 3], d, lit[0]); lit[1] = fmaf(lcol[k * 3 + 1], d, lit[1]); lit[2] = fmaf(lcol[k * 3 + 2], d, lit[2]);
+  }
+  unsigned out = 0xFF000000u;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    const float v = fminf(fmaxf(base[ch] * fminf(lit[ch], 1.0f), 0.0f), 1.0f);
+    out |= ((unsigned)rintf(v * 255.0f) & 0xFFu) << (8 * ch);
+  }
+  return out;
+}
 
 /* Can the triangle cover a pixel centre of tile (tx, ty)?  An edge function fma(A, x, fma(B, y, C)) is monotone in x and
  * in y (rounding is monotone), so over the tile's pixel centres it peaks at one of the four corner centres: if that
@@ -114,7 +145,8 @@ MSK_DEV int setup_triangle(const RCamera& cam, v3 p0, v3 p1, v3 p2, int seg, int
   t->Bw = fmaf(t->B1, w0, fmaf(t->B2, w1, t->B0 * w2)) * ia;
   t->Cw = fmaf(t->C1, w0, fmaf(t->C2, w1, t->C0 * w2)) * ia;
   t->seg = seg; t->prim = prim;
-  t->bbx = x0 | (x1 << 16); t->bby = y0 | (y1 << 16);
+  t->bb = x0 | (x1 << 8) | (y0 << 16) | (y1 << 24);
+  t->color = 0u;
   return 1;
 }
 
@@ -134,7 +166,8 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
   int* Lns = Lfill + MSK_MAX_TILES;
   int* Lnbig = Lns + 1;
   int* Lbig = Lns + 4;
-  float* Lv = (float*)(Lbig + MSK_MAX_BIG);
+  float* Llight = (float*)(Lbig + MSK_MAX_BIG);          /* light directions in the camera frame [MSK_MAX_LIGHTS][3] */
+  float* Lv = Llight + MSK_MAX_LIGHTS * 3;
   const float* E = EREC(st, m, e);
   for (int i = tid; i < ntiles; i += 256) { Lcnt[i] = 0; Lfill[i] = 0; }
   if (tid == 0) { *Lns = 0; *Lnbig = 0; }
@@ -142,6 +175,10 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
   pose Tc = cam.local;
   if (cam.mount >= 0) Tc = pose_mul(load_pose(E, m->lay.bpose, cam.mount), cam.local);
   const pose Tci = pose_inv(Tc);
+  if (tid < rm->nlights) {
+    const v3 dcam = quat_rotate(Tci.q, v3_make(rm->ldir[tid][0], rm->ldir[tid][1], rm->ldir[tid][2]));
+    Llight[tid * 3] = dcam.x; Llight[tid * 3 + 1] = dcam.y; Llight[tid * 3 + 2] = dcam.z;
+  }
   for (int s = tid; s < rm->ns; s += 256) {
     const RShape* sh = &rm->shapes[s];
     pose T = sh->local;
@@ -166,6 +203,7 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
     const v3 p[3] = {v3_make(Lv[tr.v0 * 3], Lv[tr.v0 * 3 + 1], Lv[tr.v0 * 3 + 2]), v3_make(Lv[tr.v1 * 3], Lv[tr.v1 * 3 + 1], Lv[tr.v1 * 3 + 2]),
                      v3_make(Lv[tr.v2 * 3], Lv[tr.v2 * 3 + 1], Lv[tr.v2 * 3 + 2])};
     const int seg = rm->shapes[tr.shape].seg;
+    const unsigned col = cam.color ? shade_triangle(p[0], p[1], p[2], rm->shapes[tr.shape].color, rm->ambient, rm->nlights, Llight, &rm->lcol[0][0]) : 0u;
     /* clip against the near plane x >= near: a triangle becomes 0, 1 or 2 triangles */
     const bool in0 = p[0].x >= cam.near_, in1 = p[1].x >= cam.near_, in2 = p[2].x >= cam.near_;
     const int nin = (int)in0 + (int)in1 + (int)in2;
@@ -183,9 +221,10 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
     for (int sub = 0; sub + 2 < nq; ++sub) {
       TriSetup t;
       if (!setup_triangle(cam, q[0], q[sub + 1], q[sub + 2], seg, ti * 2 + sub, &t)) continue;
+      t.color = col;
       const int slot = atomicAdd(Lns, 1);
       if (slot >= cam.setup_cap) { atomicOr(cam.overflow, 1); continue; }
-      const int tx0 = (t.bbx & 0xFFFF) / MSK_TILE, tx1 = (t.bbx >> 16) / MSK_TILE, ty0 = (t.bby & 0xFFFF) / MSK_TILE, ty1 = (t.bby >> 16) / MSK_TILE;
+      const int tx0 = BB_X0(t.bb) / MSK_TILE, tx1 = BB_X1(t.bb) / MSK_TILE, ty0 = BB_Y0(t.bb) / MSK_TILE, ty1 = BB_Y1(t.bb) / MSK_TILE;
       if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > MSK_BIG_TILES) { /* table / ground sized: goes to the env's list of large triangles */
         const int b = atomicAdd(Lnbig, 1);
         if (b < MSK_MAX_BIG) {
@@ -227,8 +266,8 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
   for (int s = tid; s < ns; s += 256) {
     const float4* src = (const float4*)&setups[s];
     const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
-    const int bbx = __float_as_int(r3.z), bby = __float_as_int(r3.w);
-    const int tx0 = (bbx & 0xFFFF) / MSK_TILE, tx1 = (bbx >> 16) / MSK_TILE, ty0 = (bby & 0xFFFF) / MSK_TILE, ty1 = (bby >> 16) / MSK_TILE;
+    const int bb = __float_as_int(r3.z);
+    const int tx0 = BB_X0(bb) / MSK_TILE, tx1 = BB_X1(bb) / MSK_TILE, ty0 = BB_Y0(bb) / MSK_TILE, ty1 = BB_Y1(bb) / MSK_TILE;
     if (__float_as_int(r3.x) & MSK_SEG_BIG) continue;   /* lives in the list of large triangles */
     for (int ty = ty0; ty <= ty1; ++ty)
       for (int tx = tx0; tx <= tx1; ++tx) {
@@ -253,7 +292,7 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
     for (int b = 0; b < nbig; ++b) {
       const TriSetup* t = &setups[Lbig[b]];
       const int qx0 = tx * MSK_TILE, qy0 = ty * MSK_TILE;
-      if ((t->bbx & 0xFFFF) > qx0 + MSK_TILE - 1 || (t->bbx >> 16) < qx0 || (t->bby & 0xFFFF) > qy0 + MSK_TILE - 1 || (t->bby >> 16) < qy0) continue;
+      if (BB_X0(t->bb) > qx0 + MSK_TILE - 1 || BB_X1(t->bb) < qx0 || BB_Y0(t->bb) > qy0 + MSK_TILE - 1 || (int)BB_Y1(t->bb) < qy0) continue;
       if (tile_touches(t->A0, t->B0, t->C0, t->A1, t->B1, t->C1, t->A2, t->B2, t->C2, tx, ty)) mk |= 1u << b;
     }
     bmask[tile] = (unsigned short)mk;
@@ -300,6 +339,7 @@ __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
     const float x = (float)px + 0.5f, y = (float)py + 0.5f;
     float best_w = 0.0f;
     int best_seg = 0, best_prim = 0x7FFFFFFF;
+    unsigned best_col = 0u;
     /* the env's large triangles that reach this tile (LDS, staged once per wave) */
     for (unsigned mk = __builtin_amdgcn_readfirstlane((int)bigmask[tile]); mk != 0u; mk &= mk - 1u) {
       const int k = __builtin_ctz(mk);
@@ -313,7 +353,7 @@ __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
         const float4 td = t4[3];
         const int prim = __float_as_int(td.y);
         if (w >= wmin && (w > best_w || (w == best_w && prim < best_prim))) {
-          best_w = w; best_prim = prim; best_seg = __float_as_int(td.x);
+          best_w = w; best_prim = prim; best_seg = __float_as_int(td.x); best_col = (unsigned)__float_as_int(td.w);
         }
       }
     }
@@ -338,7 +378,7 @@ __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
         pf0 = src[0]; pf1 = src[1]; pf2 = src[2]; pf3 = src[3];
       }
       for (int k = 0; k < n; ++k) {
-        /* record: A0 B0 C0 A1 | B1 C1 A2 B2 | C2 Aw Bw Cw | seg prim bbx bby (same address in every lane: LDS broadcast) */
+        /* record: A0 B0 C0 A1 | B1 C1 A2 B2 | C2 Aw Bw Cw | seg prim bb color (same address in every lane: LDS broadcast) */
         const float4* t4 = (const float4*)(Ls + k * MSK_SETUP_WORDS);
         const float4 ta = t4[0], tb = t4[1], tc = t4[2];
         const float e0 = fmaf(ta.x, x, fmaf(ta.y, y, ta.z));
@@ -349,7 +389,7 @@ __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
           const float4 td = t4[3];
           const int prim = __float_as_int(td.y);
           if (w >= wmin && (w > best_w || (w == best_w && prim < best_prim))) {
-            best_w = w; best_prim = prim; best_seg = __float_as_int(td.x);
+            best_w = w; best_prim = prim; best_seg = __float_as_int(td.x); best_col = (unsigned)__float_as_int(td.w);
           }
         }
       }
@@ -372,6 +412,7 @@ __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
     }
     const size_t pix = ((size_t)e * cam.H + py) * cam.W + px;
     ((short4*)cam.out)[pix] = o;
+    if (cam.color) cam.color[pix] = best_col;
     cam.depth[pix] = (short)(-(int)o.z);   /* int16 negation wraps like the host-side `-position[..., 2]` */
     cam.seg[pix] = o.w;
   }

@@ -171,15 +171,21 @@ class PickCubeEnv:
                                 max_episode_steps=self.max_episode_steps)
             self.px.lib.check(self.px.ctx, self.px.lib.task_pickcube_init(self.px.ctx, C.byref(d)), "task_pickcube_init")
         # sensors: PickCube-v1's base_camera (pick_cube.py:64-71), 128 x 128, fov pi/2, depth + segmentation textures
-        if obs_mode not in ("state", "depth+segmentation"):
-            raise NotImplementedError(f"obs_mode {obs_mode!r}: this backend provides 'state' and 'depth+segmentation'")
+        if obs_mode not in ("state", "depth+segmentation", "rgb", "rgbd", "rgb+depth+segmentation"):
+            raise NotImplementedError(f"obs_mode {obs_mode!r}: this backend provides 'state', 'depth+segmentation', 'rgb', 'rgbd' "
+                                      "and 'rgb+depth+segmentation'")
         self.obs_mode = obs_mode
+        # obs mode -> textures (sapien_env.py:120-160 parse_obs_mode_to_struct)
+        self._textures = dict(rgb="rgb" in obs_mode, depth=("depth" in obs_mode or obs_mode == "rgbd"), segmentation="segmentation" in obs_mode)
+        self._want_color = self._textures["rgb"]
         self.camera = None
         if obs_mode != "state":
             from ..render import CameraConfig, RenderCameraGroup, attach_template_visuals, look_at
             attach_template_visuals(self.px, tpl, hidden_bodies=(self._b_goal,))   # goal_site is in _hidden_objects
             p, q = look_at(eye=[0.3, 0, 0.6], target=[-0.1, 0, 0.1])
             self.camera = RenderCameraGroup(self.px, CameraConfig("base_camera", p, q, 128, 128, np.pi / 2, 0.01, 100.0))
+            if self._want_color:
+                self.camera.enable_color()
         self.reset(seed=None)
 
     def _with_sensor_data(self, state_obs):
@@ -187,7 +193,7 @@ class PickCubeEnv:
         if self.camera is None:
             return state_obs
         self.camera.take_picture()
-        return dict(state=state_obs, sensor_data=dict(base_camera=self.camera.get_obs()),
+        return dict(state=state_obs, sensor_data=dict(base_camera=self.camera.get_obs(**self._textures)),
                     sensor_param=dict(base_camera=self.camera.get_params()))
 
     # ---------------------------------------------------------------- struct-style views

@@ -79,15 +79,21 @@ class PushTEnv:
         self._rng = BatchedRNG(self._main_seeds)
         self._episode_count = np.zeros(N, dtype=np.uint64)
         self._setup_pseudo_render()
-        if obs_mode not in ("state", "depth+segmentation"):
-            raise NotImplementedError(f"obs_mode {obs_mode!r}: this backend provides 'state' and 'depth+segmentation'")
+        if obs_mode not in ("state", "depth+segmentation", "rgb", "rgbd", "rgb+depth+segmentation"):
+            raise NotImplementedError(f"obs_mode {obs_mode!r}: this backend provides 'state', 'depth+segmentation', 'rgb', 'rgbd' "
+                                      "and 'rgb+depth+segmentation'")
         self.obs_mode = obs_mode
+        # obs mode -> textures (sapien_env.py:120-160 parse_obs_mode_to_struct)
+        self._textures = dict(rgb="rgb" in obs_mode, depth=("depth" in obs_mode or obs_mode == "rgbd"), segmentation="segmentation" in obs_mode)
+        self._want_color = self._textures["rgb"]
         self.camera = None
         if obs_mode != "state":
             from ..render import CameraConfig, RenderCameraGroup, attach_template_visuals, look_at
             attach_template_visuals(self.px, tpl)
             p, q = look_at(eye=[0.3, 0, 0.6], target=[-0.1, 0, 0.1])
             self.camera = RenderCameraGroup(self.px, CameraConfig("base_camera", p, q, 128, 128, np.pi / 2, 0.01, 100.0))
+            if self._want_color:
+                self.camera.enable_color()
         self.obs_dim = 7 + 7 + 7 + 3 + 7
         # fused task kernels (include/msk_task.h): controller, evaluate / obs / reward as two launches instead of ~100 torch ops
         can_fuse = getattr(self.px.lib, "has_task_kernels", False) and not self.px.host_memory
@@ -258,7 +264,7 @@ class PushTEnv:
         info = dict(elapsed_steps=self._elapsed_steps.clone(), success=fl[:, 0])
         if self.camera is not None:
             self.camera.take_picture()
-            obs = dict(state=obs, sensor_data=dict(base_camera=self.camera.get_obs()),
+            obs = dict(state=obs, sensor_data=dict(base_camera=self.camera.get_obs(**self._textures)),
                        sensor_param=dict(base_camera=self.camera.get_params()))
         return obs, rew, fl[:, 4], fl[:, 5], info
 
@@ -315,7 +321,7 @@ class PushTEnv:
         if self.camera is None:   # state: agent (qpos, qvel) + extra (tcp_pose, goal_pos, obj_pose)
             return torch.hstack([self.qpos, self.qvel, tcp, self._pose(self._b_goal)[:, :3], self._pose(self._b_tee)])
         self.camera.take_picture()
-        return dict(state=torch.hstack([self.qpos, self.qvel, tcp]), sensor_data=dict(base_camera=self.camera.get_obs()),
+        return dict(state=torch.hstack([self.qpos, self.qvel, tcp]), sensor_data=dict(base_camera=self.camera.get_obs(**self._textures)),
                     sensor_param=dict(base_camera=self.camera.get_params()))
 
     def compute_dense_reward(self, info):

@@ -80,6 +80,12 @@ def build_pick_cube_template(cube_half_size=0.02):
     table = add_table_scene(tpl)
     cube = add_cube(tpl, "cube", cube_half_size, (0, 0, cube_half_size))
     goal = add_site(tpl, "goal_site")
+    # base colours of the Color texture: cube red, goal site green (pick_cube.py:91,98); robot light grey, table / ground: default
+    tpl.set_body_color(cube, (1.0, 0.0, 0.0, 1.0))
+    tpl.set_body_color(goal, (0.0, 1.0, 0.0, 1.0))
+    for b in range(len(tpl.body_names)):
+        if tpl.body_names[b].startswith("panda_"):
+            tpl.set_body_color(b, (0.9, 0.9, 0.9, 1.0))
     return tpl, dict(art=art, table=table, cube=cube, goal_site=goal)
 
 
@@ -128,4 +134,12 @@ def build_push_t_template():
     disc = np.concatenate([np.c_[np.full(16, -1e-4), 0.02 * np.cos(ang), 0.02 * np.sin(ang)],
                            np.c_[np.full(16, 1e-4), 0.02 * np.cos(ang), 0.02 * np.sin(ang)]])
     tpl.add_visual(goal_ee, N.SHAPE_CONVEX, verts=disc)
+    # base colours (push_t.py:170-252): the T red (TARGET_RED), its goal outline and the end-effector goal disc grey, white table top
+    tpl.set_body_color(tee, (194 / 255, 19 / 255, 22 / 255, 1.0))
+    tpl.set_body_color(goal_tee, (128 / 255, 128 / 255, 128 / 255, 1.0))
+    tpl.set_body_color(goal_ee, (128 / 255, 128 / 255, 128 / 255, 1.0))
+    tpl.set_body_color(table, (1.0, 1.0, 1.0, 1.0))
+    for b in range(len(tpl.body_names)):
+        if tpl.body_names[b].startswith("panda_"):
+            tpl.set_body_color(b, (0.9, 0.9, 0.9, 1.0))
     return tpl, dict(art=art, table=table, tee=tee, goal_tee=goal_tee, goal_ee=goal_ee)

@@ -153,6 +153,13 @@ class SceneTemplate:
     def disable_collision(self, body_a, body_b):
         self.ops.append(("disable_collision", (body_a, body_b)))
 
+    def set_body_color(self, body, rgba):
+        """RenderMaterial(base_color=rgba) of every visual of `body` (-1: the static scene); consumed by
+        render.attach_template_visuals for the Color texture."""
+        if not hasattr(self, "body_colors"):
+            self.body_colors = {}
+        self.body_colors[int(body)] = [float(x) for x in rgba]
+
     def body_id(self, name) -> int:
         return self.body_names.index(name)
 

@@ -135,14 +135,14 @@ class RenderCameraGroup:
         cam = L.check(px.ctx, L.camera_create(px.ctx, int(cfg.width), int(cfg.height), float(cfg.fov), float(cfg.near), float(cfg.far),
                                               int(cfg.mount), N._fa(list(cfg.p) + list(cfg.q), 7)), "camera_create")
         self.id = cam
-        def wrap(ptr, shape, what):
+        def wrap(ptr, shape, what, ctype=C.c_int16, typestr="<i2"):
             if not ptr:
                 raise RuntimeError(f"{what} returned NULL")
             shp = tuple(int(s) for s in shape)
             if px.host_memory:
                 n = int(np.prod(shp))
-                return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int16)), shape=(n,)).reshape(shp))
-            t = torch.as_tensor(_DevPtr(ptr, shp, "<i2"), device=px.device)
+                return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)).reshape(shp))
+            t = torch.as_tensor(_DevPtr(ptr, shp, typestr), device=px.device)
             assert t.data_ptr() == ptr
             return t
 
@@ -151,6 +151,8 @@ class RenderCameraGroup:
         # depth / segmentation planes written by the rasteriser's own store (no gather pass over the texture)
         self._depth = wrap(L.camera_obs_buffer(px.ctx, cam, 0, shape), shape, "msk_camera_obs_buffer")
         self._seg = wrap(L.camera_obs_buffer(px.ctx, cam, 1, shape), shape, "msk_camera_obs_buffer")
+        self._color_t = None   # Color r8g8b8a8unorm (N, H, W, 4) uint8: requested lazily (the backend only renders it once asked)
+        self._wrap = wrap
         # intrinsics of set_fovy(fovy, compute_x=True) (scene.py:250-257)
         fy = 0.5 * cfg.height / np.tan(0.5 * cfg.fov)
         self.intrinsic_cv = torch.tensor([[fy, 0, 0.5 * cfg.width], [0, fy, 0.5 * cfg.height], [0, 0, 1]], dtype=torch.float32)
@@ -234,16 +236,32 @@ class RenderCameraGroup:
         L, px = self.px.lib, self.px
         L.check(px.ctx, L.camera_take_picture(px.ctx, self.id, px._stream()), "camera_take_picture")
 
+    @property
+    def _color(self):
+        if self._color_t is None:
+            shape = (C.c_int64 * 4)()
+            self._color_t = self._wrap(self.px.lib.camera_obs_buffer(self.px.ctx, self.id, 2, shape), shape, "msk_camera_obs_buffer",
+                                       C.c_uint8, "|u1")
+        return self._color_t
+
+    def enable_color(self):
+        """Ask for the Color texture before the first take_picture that should fill it."""
+        return self._color
+
     def get_picture_cuda(self, name: str = "PositionSegmentation") -> PictureHandle:
+        if name == "Color":
+            return PictureHandle(self._color)
         if name != "PositionSegmentation":
-            raise KeyError(f"the minimal shader pack of this backend provides PositionSegmentation only, not {name}")
+            raise KeyError(f"the minimal shader pack provides Color and PositionSegmentation, not {name}")
         return PictureHandle(self._tex)
 
-    def get_obs(self, depth=True, segmentation=True, position=False, copy=True):
+    def get_obs(self, depth=True, segmentation=True, position=False, copy=True, rgb=False):
         """Camera.get_obs (sensors/camera.py:190-242) with the minimal pack's texture transform.  ``copy=False`` hands
         out the rasteriser's own planes (overwritten by the next take_picture) instead of a snapshot."""
         data = self._tex
         out = {}
+        if rgb:          # Color[..., :3] (render/shaders.py:74)
+            out["rgb"] = self._color[..., :3].clone() if copy else self._color[..., :3]
         if position:
             out["position"] = data[..., :3]
         if depth:        # == -data[..., [2]]
@@ -277,8 +295,11 @@ def attach_template_visuals(px, template, hidden_bodies=()):
         seg = (body + 1) if body >= 0 else nb + 1
         v = np.ascontiguousarray(v, dtype=np.float32)
         t = np.ascontiguousarray(t, dtype=np.int32)
-        L.check(px.ctx, L.render_add_mesh(px.ctx, int(body), N._fa(pose7, 7), v.ctypes.data_as(C.POINTER(C.c_float)), len(v),
-                                          t.ctypes.data_as(C.POINTER(C.c_int32)), len(t), int(seg)), "render_add_mesh")
+        rs = L.check(px.ctx, L.render_add_mesh(px.ctx, int(body), N._fa(pose7, 7), v.ctypes.data_as(C.POINTER(C.c_float)), len(v),
+                                               t.ctypes.data_as(C.POINTER(C.c_int32)), len(t), int(seg)), "render_add_mesh")
+        rgba = getattr(template, "body_colors", {}).get(int(body))
+        if rgba is not None:
+            L.check(px.ctx, L.render_set_base_color(px.ctx, rs, N._fa(rgba, 4)), "render_set_base_color")
         n += 1
     L.check(px.ctx, L.render_finalize(px.ctx), "render_finalize")
     return n

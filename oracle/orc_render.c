@@ -20,7 +20,8 @@
 
 #define ORC_EXPORT __attribute__((visibility("default")))
 
-typedef struct { int body, seg; pose local; } r_shape;
+typedef struct { int body, seg; pose local; float color[4]; } r_shape;
+#define ORC_MAX_LIGHTS 4
 typedef struct { int v0, v1, v2, shape; } r_tri;
 typedef struct {
   int W, H, mount;
@@ -28,6 +29,7 @@ typedef struct {
   pose local;
   int16_t* out;
   int16_t *depth, *seg;
+  uint32_t* color;   /* Color r8g8b8a8unorm, r in the low byte */
 } r_camera;
 typedef struct {
   int nv, nt, ns, finalized, ncams;
@@ -36,11 +38,15 @@ typedef struct {
   unsigned char vshape[MSK_MAX_RENDER_VERTS];
   r_tri tris[MSK_MAX_RENDER_TRIS];
   r_camera cams[MSK_MAX_CAMERAS];
+  float ambient[3];
+  int nlights;
+  float ldir[ORC_MAX_LIGHTS][3], lcol[ORC_MAX_LIGHTS][3];
 } r_model;
 
 typedef struct {
   float A0, B0, C0, A1, B1, C1, A2, B2, C2, Aw, Bw, Cw;
   int seg, prim, x0, x1, y0, y1;
+  uint32_t color;
 } r_setup;
 
 static int rfail(orc_ctx* c, int code, const char* msg) {
@@ -57,7 +63,16 @@ static pose r_pose7(const float* p) {
 ORC_EXPORT int orc_render_add_mesh(orc_ctx* c, int body, const float local_pose[7], const float* verts, int nverts,
                                    const int32_t* tris, int ntris, int seg_id) {
   if (!c->finalized) return rfail(c, MSK_ERR_INVALID, "render shapes are added after finalize");
-  if (!c->render) c->render = calloc(1, sizeof(r_model));
+  if (!c->render) { /* ManiSkill's default lighting (envs/sapien_env.py:849-853) */
+    c->render = calloc(1, sizeof(r_model));
+    r_model* r0 = (r_model*)c->render;
+    r0->ambient[0] = r0->ambient[1] = r0->ambient[2] = 0.3f;
+    r0->nlights = 2;
+    const float inv3 = 1.0f / sqrtf(3.0f);
+    r0->ldir[0][0] = inv3; r0->ldir[0][1] = inv3; r0->ldir[0][2] = -inv3;
+    r0->ldir[1][0] = 0.0f; r0->ldir[1][1] = 0.0f; r0->ldir[1][2] = -1.0f;
+    for (int l = 0; l < 2; ++l) r0->lcol[l][0] = r0->lcol[l][1] = r0->lcol[l][2] = 1.0f;
+  }
   r_model* r = (r_model*)c->render;
   if (r->finalized) return rfail(c, MSK_ERR_INVALID, "render_add_mesh after render_finalize");
   if (r->ns >= MSK_MAX_RENDER_SHAPES || r->nv + nverts > MSK_MAX_RENDER_VERTS || r->nt + ntris > MSK_MAX_RENDER_TRIS)
@@ -65,6 +80,8 @@ ORC_EXPORT int orc_render_add_mesh(orc_ctx* c, int body, const float local_pose[
   r->shapes[r->ns].body = body;
   r->shapes[r->ns].seg = seg_id;
   r->shapes[r->ns].local = r_pose7(local_pose);
+  r->shapes[r->ns].color[0] = r->shapes[r->ns].color[1] = r->shapes[r->ns].color[2] = 0.8f;
+  r->shapes[r->ns].color[3] = 1.0f;
   for (int i = 0; i < nverts; ++i) {
     r->verts[r->nv + i] = v3_make(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
     r->vshape[r->nv + i] = (unsigned char)r->ns;
@@ -75,6 +92,50 @@ ORC_EXPORT int orc_render_add_mesh(orc_ctx* c, int body, const float local_pose[
   }
   r->nv += nverts; r->nt += ntris;
   return r->ns++;
+}
+
+ORC_EXPORT int orc_render_set_base_color(orc_ctx* c, int render_shape, const float rgba[4]) {
+  r_model* r = (r_model*)c->render;
+  if (!r || render_shape < 0 || render_shape >= r->ns) return rfail(c, MSK_ERR_INVALID, "bad render shape");
+  if (r->finalized) return rfail(c, MSK_ERR_INVALID, "render_set_base_color after render_finalize");
+  for (int k = 0; k < 4; ++k) r->shapes[render_shape].color[k] = rgba[k];
+  return MSK_OK;
+}
+
+ORC_EXPORT int orc_render_set_lights(orc_ctx* c, const float ambient[3], int ndir, const float* directions, const float* colors) {
+  r_model* r = (r_model*)c->render;
+  if (!r) return rfail(c, MSK_ERR_INVALID, "no render shapes");
+  if (r->finalized) return rfail(c, MSK_ERR_INVALID, "render_set_lights after render_finalize");
+  if (ndir < 0 || ndir > ORC_MAX_LIGHTS) return rfail(c, MSK_ERR_CAPACITY, "too many directional lights");
+  for (int k = 0; k < 3; ++k) r->ambient[k] = ambient[k];
+  r->nlights = ndir;
+  for (int l = 0; l < ndir; ++l) {
+    const float x = directions[3 * l], y = directions[3 * l + 1], z = directions[3 * l + 2];
+    const float len = sqrtf(x * x + y * y + z * z);
+    if (!(len > 0.0f)) return rfail(c, MSK_ERR_INVALID, "zero light direction");
+    r->ldir[l][0] = x / len; r->ldir[l][1] = y / len; r->ldir[l][2] = z / len;
+    for (int k = 0; k < 3; ++k) r->lcol[l][k] = colors[3 * l + k];
+  }
+  return MSK_OK;
+}
+
+/* flat shading of one triangle (camera-frame corners, counter-clockwise seen from outside): per channel
+ * base * min(1, ambient + sum_l light_l * max(0, n . -dir_l)), rounded to 8 bits; alpha = 255 */
+static uint32_t shade_triangle(v3 p0, v3 p1, v3 p2, const float* base, const float* ambient, int nl, const float* ldir_cam, const float* lcol) {
+  v3 n = v3_cross(v3_sub(p1, p0), v3_sub(p2, p0));
+  const float l = v3_len(n);
+  n = (l > 0.0f) ? v3_scale(n, 1.0f / l) : v3_make(0, 0, 0);
+  float lit[3] = {ambient[0], ambient[1], ambient[2]};
+  for (int k = 0; k < nl; ++k) {
+    const float d = fmaxf(0.0f, -(n.x * ldir_cam[k * 3] + n.y * ldir_cam[k * 3 + 1] + n.z * ldir_cam[k * 3 + 2]));
+    lit[0] = fmaf(lcol[k * 3], d, lit[0]); lit[1] = fmaf(lcol[k * 3 + 1], d, lit[1]); lit[2] = fmaf(lcol[k * 3 + 2], d, lit[2]);
+  }
+  uint32_t out = 0xFF000000u;
+  for (int ch = 0; ch < 3; ++ch) {
+    const float v = fminf(fmaxf(base[ch] * fminf(lit[ch], 1.0f), 0.0f), 1.0f);
+    out |= ((uint32_t)rintf(v * 255.0f) & 0xFFu) << (8 * ch);
+  }
+  return out;
 }
 
 ORC_EXPORT int orc_render_finalize(orc_ctx* c) {
@@ -97,6 +158,7 @@ ORC_EXPORT int orc_camera_create(orc_ctx* c, int width, int height, float fovy, 
   cam->near_ = near_plane; cam->far_ = far_plane;
   cam->local = r_pose7(local_pose);
   cam->out = (int16_t*)calloc((size_t)c->num_envs * width * height * 4, sizeof(int16_t));
+  cam->color = (uint32_t*)calloc((size_t)c->num_envs * width * height, sizeof(uint32_t));
   cam->depth = (int16_t*)calloc((size_t)c->num_envs * width * height, sizeof(int16_t));
   cam->seg = (int16_t*)calloc((size_t)c->num_envs * width * height, sizeof(int16_t));
   return r->ncams++;
@@ -112,9 +174,10 @@ ORC_EXPORT void* orc_camera_buffer(orc_ctx* c, int camera, int64_t shape[4]) {
 /* Camera.get_obs planes (sensors/camera.py:190-242 with render/shaders.py:141-145) */
 ORC_EXPORT void* orc_camera_obs_buffer(orc_ctx* c, int camera, int which, int64_t shape[4]) {
   r_model* r = (r_model*)c->render;
-  if (!r || camera < 0 || camera >= r->ncams || (which != MSK_CAM_DEPTH && which != MSK_CAM_SEGMENTATION)) return NULL;
-  shape[0] = c->num_envs; shape[1] = r->cams[camera].H; shape[2] = r->cams[camera].W; shape[3] = 1;
-  return which == MSK_CAM_DEPTH ? r->cams[camera].depth : r->cams[camera].seg;
+  if (!r || camera < 0 || camera >= r->ncams || which < MSK_CAM_DEPTH || which > MSK_CAM_COLOR) return NULL;
+  shape[0] = c->num_envs; shape[1] = r->cams[camera].H; shape[2] = r->cams[camera].W; shape[3] = which == MSK_CAM_COLOR ? 4 : 1;
+  if (which == MSK_CAM_COLOR) return r->cams[camera].color;
+  return which == MSK_CAM_DEPTH ? (void*)r->cams[camera].depth : (void*)r->cams[camera].seg;
 }
 
 static void project_point(const r_camera* cam, v3 p, float* u, float* v, float* w) {
@@ -189,11 +252,17 @@ ORC_EXPORT int orc_camera_take_picture(orc_ctx* c, int camera, void* stream) {
       shapeT[s] = pose_mul(Tci, T);
     }
     for (int i = 0; i < r->nv; ++i) cv[i] = pose_apply(shapeT[r->vshape[i]], r->verts[i]);
+    float light_cam[ORC_MAX_LIGHTS * 3];
+    for (int l = 0; l < r->nlights; ++l) {
+      const v3 d = quat_rotate(Tci.q, v3_make(r->ldir[l][0], r->ldir[l][1], r->ldir[l][2]));
+      light_cam[l * 3] = d.x; light_cam[l * 3 + 1] = d.y; light_cam[l * 3 + 2] = d.z;
+    }
     int ns = 0;
     for (int ti = 0; ti < r->nt; ++ti) {
       const r_tri* tr = &r->tris[ti];
       const v3 p[3] = {cv[tr->v0], cv[tr->v1], cv[tr->v2]};
       const int seg = r->shapes[tr->shape].seg;
+      const uint32_t col = shade_triangle(p[0], p[1], p[2], r->shapes[tr->shape].color, r->ambient, r->nlights, light_cam, &r->lcol[0][0]);
       const int in0 = p[0].x >= cam->near_, in1 = p[1].x >= cam->near_, in2 = p[2].x >= cam->near_;
       const int nin = in0 + in1 + in2;
       v3 q[4];
@@ -208,10 +277,12 @@ ORC_EXPORT int orc_camera_take_picture(orc_ctx* c, int camera, void* stream) {
         }
       }
       for (int sub = 0; sub + 2 < nq; ++sub)
-        if (setup_triangle(cam, q[0], q[sub + 1], q[sub + 2], seg, ti * 2 + sub, &st[ns])) ns++;
+        if (setup_triangle(cam, q[0], q[sub + 1], q[sub + 2], seg, ti * 2 + sub, &st[ns])) { st[ns].color = col; ns++; }
     }
     int16_t* img = cam->out + (size_t)e * cam->W * cam->H * 4;
+    uint32_t* cimg = cam->color + (size_t)e * cam->W * cam->H;
     memset(img, 0, sizeof(int16_t) * (size_t)cam->W * cam->H * 4);
+    memset(cimg, 0, sizeof(uint32_t) * (size_t)cam->W * cam->H);
     for (int i = 0; i < cam->W * cam->H; ++i) bw[i] = 0.0f;
     /* triangles in primitive order; strictly nearer wins, so equal depths keep the lower primitive id */
     for (int k = 0; k < ns; ++k) {
@@ -232,6 +303,7 @@ ORC_EXPORT int orc_camera_take_picture(orc_ctx* c, int camera, void* stream) {
           o[1] = to_mm(-(y - cam->cy) / cam->fy * d);
           o[2] = to_mm(-d);
           o[3] = (int16_t)t->seg;
+          cimg[py * cam->W + px] = t->color;
         }
     }
     for (int i = 0; i < cam->W * cam->H; ++i) {

@@ -196,3 +196,59 @@ def test_camera_matrices_project_a_world_point_onto_the_pixel_the_rasteriser_dre
     eye = par["cam2world_gl"][0, :3, 3]
     to_target = torch.tensor([-0.1, 0.0, 0.1]) - eye                                   # PickCube's base_camera: look_at([0.3, 0, 0.6], [-0.1, 0, 0.1])
     assert torch.allclose(fwd, to_target / to_target.norm(), atol=1e-4)
+
+
+def test_color_texture_known_answers(oracle_factory):
+    """Color r8g8b8a8unorm (render/shaders.py:68-74,141-144): flat Lambert shading by ManiSkill's default lights
+    (ambient 0.3 + directional (1, 1, -1) and (0, 0, -1), envs/sapien_env.py:849-853) of the body's base colour."""
+    from maniskill_amd.envs.pick_cube import PickCubeEnv
+
+    env = PickCubeEnv(num_envs=2, px_factory=oracle_factory, obs_mode="rgb+depth+segmentation")
+    obs, _ = env.reset(seed=3)
+    cam = obs["sensor_data"]["base_camera"]
+    rgb, seg = cam["rgb"], cam["segmentation"][..., 0]
+    assert rgb.shape == (2, 128, 128, 3) and rgb.dtype == torch.uint8
+    tex = env.camera.get_picture_cuda("Color").torch()
+    assert tex.shape == (2, 128, 128, 4) and torch.equal(tex[..., :3], rgb)
+    assert (tex[..., 3][seg > 0] == 255).all() and (tex[seg == 0] == 0).all()       # alpha 255 on geometry, background 0
+    # the cube's top face (normal +z): lit = 0.3 + 1/sqrt(3) + 1 > 1 -> saturated base colour (1, 0, 0)
+    cube = seg == env._b_cube + 1
+    assert cube.any()
+    top = cube & (rgb[..., 0] == 255)
+    assert top.any() and (rgb[top][:, 1:] == 0).all()
+    # any visible cube pixel is a shade of pure red; side faces are darker than the top
+    assert (rgb[cube][:, 1:] == 0).all() and rgb[cube][:, 0].min() >= int(round(0.3 * 255))
+    # the table top (normal +z, default grey 0.8): 0.8 * min(1, 1.877) = 204
+    table = seg == env._b_table + 1
+    vals, counts = torch.unique(rgb[table][:, 0], return_counts=True)
+    assert vals[counts.argmax()].item() == 204
+    # obs modes
+    e2 = PickCubeEnv(num_envs=1, px_factory=oracle_factory, obs_mode="rgbd")
+    o2, _ = e2.reset(seed=0)
+    assert set(o2["sensor_data"]["base_camera"].keys()) == {"rgb", "depth"}
+    e3 = PickCubeEnv(num_envs=1, px_factory=oracle_factory, obs_mode="rgb")
+    o3, _ = e3.reset(seed=0)
+    assert set(o3["sensor_data"]["base_camera"].keys()) == {"rgb"}
+
+
+@pytest.mark.gpu
+def test_hip_color_texture_matches_oracle(oracle_factory):
+    """Color (and the other textures) of PickCube and PushT rollouts: HIP rasteriser vs CPU rasteriser, bit for bit."""
+    from maniskill_amd.envs.pick_cube import PickCubeEnv
+    from maniskill_amd.envs.push_t import PushTEnv
+
+    for cls, adim in ((PickCubeEnv, 8), (PushTEnv, 7)):
+        n = 32
+        gpu = cls(num_envs=n, device="cuda:0", obs_mode="rgb+depth+segmentation", fused=False)
+        cpu = cls(num_envs=n, px_factory=oracle_factory, obs_mode="rgb+depth+segmentation")
+        gpu.reset(seed=6); cpu.reset(seed=6)
+        gen = torch.Generator().manual_seed(2)
+        for _ in range(8):
+            a = 2 * torch.rand(n, adim, generator=gen) - 1
+            og = gpu.step(a.to("cuda:0"))[0]
+            oc = cpu.step(a)[0]
+        cg, cc = og["sensor_data"]["base_camera"], oc["sensor_data"]["base_camera"]
+        assert torch.equal(cg["rgb"].cpu(), cc["rgb"]) and torch.equal(cg["depth"].cpu(), cc["depth"])
+        assert torch.equal(cg["segmentation"].cpu(), cc["segmentation"])
+        assert torch.equal(gpu.camera.get_picture_cuda("Color").torch().cpu(), cpu.camera.get_picture_cuda("Color").torch())
+        assert len(torch.unique(cc["rgb"].reshape(-1, 3), dim=0)) > 8       # several shades: faces of different orientation
