@@ -39,6 +39,13 @@ int msk_task_pickcube_init(msk_ctx* ctx, const msk_pickcube_desc* desc);
  * set_joint_drive_targets + gpu_apply_articulation_target_position do).  actions: device [num_envs][8]. */
 int msk_task_pickcube_set_action(msk_ctx* ctx, const float* actions, void* stream);
 
+/* The arm half of pd_ee_delta_pos (action_dim 4) / pd_ee_delta_pose (action_dim 7) (agents/controllers/pd_ee_pose.py:224-262,
+ * utils/kinematics.py:229-245; panda.py:103-124): delta pose of the tcp in the frame of `root_body`, translation = pos_bound *
+ * clip(a), rotation = rot_scale * (a clipped to unit norm) — the reference passes rot_lower there —, one Levenberg-Marquardt
+ * step with damping `lambda` on the arm's geometric Jacobian, target = qpos + dq; gripper as in msk_task_pickcube_set_action. */
+int msk_task_pickcube_set_action_ee(msk_ctx* ctx, const float* actions, int action_dim, int root_body, float pos_bound, float rot_scale,
+                                    float lambda, void* stream);
+
 /* `substeps` calls of msk_step plus the link-frame update, from one host call. */
 int msk_control_step(msk_ctx* ctx, int substeps, void* stream);
 

@@ -807,6 +807,24 @@ MSK_API int msk_task_pickcube_set_action(msk_ctx* c, const float* actions, void*
   return MSK_OK;
 }
 
+MSK_API int msk_task_pickcube_set_action_ee(msk_ctx* c, const float* actions, int action_dim, int root_body, float pos_bound,
+                                            float rot_scale, float lambda, void* stream) {
+  if (!c->has_pickcube) return fail(c, MSK_ERR_INVALID, "pickcube task not initialised");
+  if (action_dim != 4 && action_dim != 7) return fail(c, MSK_ERR_INVALID, "ee control: action_dim is 4 (pos) or 7 (pose)");
+  if (root_body < 0 || root_body >= c->model.nb || c->pickcube.arm_dofs != 7) return fail(c, MSK_ERR_INVALID, "ee control: bad root body / arm");
+  const int N = c->model.N;
+  if (c->kin_dirty) { /* the Jacobian is built from the link frames of the current qpos */
+    launch_kinematics(c->model, c->d_model, c->st, (hipStream_t)stream);
+    c->kin_dirty = false;
+  }
+  EeCtl ec;
+  ec.root = root_body; ec.adim = action_dim; ec.pos_bound = pos_bound; ec.rot_scale = rot_scale; ec.damping = lambda;
+  hipLaunchKernelGGL(k_pickcube_set_action_ee, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->pickcube, ec,
+                     actions);
+  HIP_TRY(hipGetLastError());
+  return MSK_OK;
+}
+
 MSK_API int msk_task_pusht_init(msk_ctx* c, const msk_pusht_desc* d, const uint8_t* tee_render) {
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "task init before finalize");
   const int nb = c->model.nb;

@@ -26,6 +26,85 @@ __global__ void __launch_bounds__(256) k_pickcube_set_action(const DModel* __res
   E[m->lay.qt + d.arm_dofs + 1] = g;
 }
 
+/* pd_ee_delta_pos / pd_ee_delta_pose (agents/controllers/pd_ee_pose.py:224-262; utils/kinematics.py:229-245): the action is a
+ * delta pose of the tcp in the root frame; one Levenberg-Marquardt step (J^T J + lambda I) dq = J^T delta on the geometric
+ * Jacobian of the arm's revolute joints (column k = [z_k x (p_ee - o_k); z_k]); arm target = q + dq.  One thread per env. */
+struct EeCtl { int root, adim; float pos_bound, rot_scale, damping; };
+__global__ void __launch_bounds__(256) k_pickcube_set_action_ee(const DModel* __restrict__ m, DState st, msk_pickcube_desc d, EeCtl c,
+                                                                const float* __restrict__ actions) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= m->N) return;
+  float* E = EREC(st, m, e);
+  const float* a = actions + (size_t)e * c.adim;
+  /* delta pose: translation clipped and scaled; rotation clipped by norm, scaled by rot_lower (as the reference does) */
+  float del[6] = {0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < 3; ++k) del[k] = c.pos_bound * fminf(fmaxf(a[k], -1.0f), 1.0f);
+  if (c.adim == 7) {
+    float rx = a[3], ry = a[4], rz = a[5];
+    const float nrm = sqrtf(rx * rx + ry * ry + rz * rz);
+    if (nrm > 1.0f) { const float inv = 1.0f / nrm; rx = rx * inv; ry = ry * inv; rz = rz * inv; }
+    del[3] = rx * c.rot_scale; del[4] = ry * c.rot_scale; del[5] = rz * c.rot_scale;
+  }
+  const pose root = load_pose(E, m->lay.bpose, c.root);
+  const v3 pee = load_pose(E, m->lay.bpose, d.tcp).p;
+  float J[6][7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const DBody* b = &m->bodies[m->dof_body[k]];
+    const pose Tj = pose_mul(load_pose(E, m->lay.bpose, b->parent), b->Xp);
+    const v3 z = quat_rotate_inv(root.q, quat_rotate(Tj.q, v3_make(1, 0, 0)));
+    const v3 r = quat_rotate_inv(root.q, v3_sub(pee, Tj.p));
+    const v3 jv = v3_cross(z, r);
+    J[0][k] = jv.x; J[1][k] = jv.y; J[2][k] = jv.z; J[3][k] = z.x; J[4][k] = z.y; J[5][k] = z.z;
+  }
+  /* normal equations, Cholesky, two triangular solves */
+  float A[7][7], rhs[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) acc = fmaf(J[r][i], del[r], acc);
+    rhs[i] = acc;
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      float s = (i == j) ? c.damping : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) s = fmaf(J[r][i], J[r][j], s);
+      A[i][j] = s;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      float s = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s = fmaf(-A[i][k], A[j][k], s);
+      A[i][j] = (i == j) ? sqrtf(s) : s / A[j][j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    float s = rhs[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s = fmaf(-A[i][k], rhs[k], s);
+    rhs[i] = s / A[i][i];
+  }
+#pragma unroll
+  for (int i = 6; i >= 0; --i) {
+    float s = rhs[i];
+#pragma unroll
+    for (int k = i + 1; k < 7; ++k) s = fmaf(-A[k][i], rhs[k], s);
+    rhs[i] = s / A[i][i];
+  }
+#pragma unroll
+  for (int j = 0; j < 7; ++j) E[m->lay.qt + j] = E[m->lay.q + j] + rhs[j];
+  const float ag = fminf(fmaxf(a[c.adim - 1], -1.0f), 1.0f);
+  const float g = d.gripper_mid + d.gripper_half * ag;
+  E[m->lay.qt + d.arm_dofs] = g;
+  E[m->lay.qt + d.arm_dofs + 1] = g;
+}
+
 /* sum of the contact impulses applied on body x by body y (the pair-impulse query of scene.py:771-781) */
 MSK_DEV v3 pair_impulse(const DModel* m, const DState& st, int e, int x, int y) {
   const int* cnts = st.ct_cnt + (size_t)e * m->npp;

@@ -101,11 +101,16 @@ class PickCubeEnv:
     def __init__(self, num_envs: int = 1, device: Optional[str] = None, sim_config: Optional[SimConfig] = None,
                  robot_init_qpos_noise: float = 0.02, reward_mode: str = "normalized_dense",
                  env_index_offset: int = 0, total_envs: Optional[int] = None, px_factory=None,
-                 fused: Optional[bool] = None, obs_mode: str = "state"):
+                 fused: Optional[bool] = None, obs_mode: str = "state", control_mode: str = "pd_joint_delta_pos"):
         self.num_envs = int(num_envs)
         self.sim_config = sim_config or SimConfig()
         self.robot_init_qpos_noise = robot_init_qpos_noise
         self.reward_mode = reward_mode
+        # control modes of Panda._controller_configs (panda.py:187-200): joint deltas (default) or end-effector deltas through IK
+        if control_mode not in ("pd_joint_delta_pos", "pd_ee_delta_pos", "pd_ee_delta_pose"):
+            raise NotImplementedError(f"control_mode {control_mode!r}: this backend provides pd_joint_delta_pos, pd_ee_delta_pos, pd_ee_delta_pose")
+        self.control_mode = control_mode
+        self.action_dim = {"pd_joint_delta_pos": 8, "pd_ee_delta_pos": 4, "pd_ee_delta_pose": 7}[control_mode]
         self.env_index_offset = int(env_index_offset)
         assert self.sim_config.sim_freq % self.sim_config.control_freq == 0
         self._sim_steps_per_control = self.sim_config.sim_freq // self.sim_config.control_freq
@@ -159,6 +164,7 @@ class PickCubeEnv:
         # instead of ~120.  Default on the HIP backend; the torch path stays the readable reference (fused=False).
         can_fuse = getattr(self.px.lib, "has_task_kernels", False) and not self.px.host_memory
         self.fused = can_fuse if fused is None else bool(fused)
+        self._setup_ee_controller()
         if self.fused:
             if not can_fuse:
                 raise RuntimeError("fused task kernels need the HIP backend")
@@ -310,6 +316,77 @@ class PickCubeEnv:
         self._target_qpos[:, 7:9] = g
         self._target_qpos_buf[:, :9] = self._target_qpos
 
+    # ---- end-effector control (agents/controllers/pd_ee_pose.py:24-262, utils/kinematics.py:185-259) ---------------------
+    ee_pos_bound = 0.1      # pos_lower / pos_upper of arm_pd_ee_delta_pos(e) (panda.py:103-124)
+    ee_rot_lower = -0.1     # rot_lower: the reference scales the (norm-clipped) rotation action by rot_LOWER (pd_ee_pose.py:236)
+    ik_damping = 1e-4       # levenberg_marquardt lambda (kinematics.py:237)
+
+    def _setup_ee_controller(self):
+        """Joint frames of the 7 arm joints in their parent links (pose_in_parent of the template's add_link records)."""
+        par, xp = [], []
+        for op, a in self.template.ops:
+            if op == "add_link" and a[2] != 0 and len(par) < 7:      # a = (art, parent, joint_type, pose_in_parent, ...)
+                par.append(int(a[1]))
+                xp.append([float(x) for x in a[3]])
+        self._ee_parent = torch.tensor(par, dtype=torch.long, device=self.device)
+        self._ee_xp = torch.tensor(xp, dtype=torch.float32, device=self.device)           # (7, 7) p, q(wxyz)
+
+    @staticmethod
+    def _qrot(q, v):
+        """rotate v (..., 3) by quaternion q (..., 4 wxyz)"""
+        w, u = q[..., :1], q[..., 1:]
+        t = 2.0 * torch.cross(u, v, dim=-1)
+        return v + w * t + torch.cross(u, t, dim=-1)
+
+    @staticmethod
+    def _qmul(a, b):
+        w1, x1, y1, z1 = a.unbind(-1)
+        w2, x2, y2, z2 = b.unbind(-1)
+        return torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                            w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], dim=-1)
+
+    def ee_jacobian(self) -> torch.Tensor:
+        """(N, 6, 7) geometric Jacobian [linear; angular] of panda_hand_tcp in the root link's frame (what
+        pk_chain.jacobian(q) returns, kinematics.py:232): column k = [z_k x (p_ee - o_k); z_k] of arm joint k."""
+        self._fresh()
+        poses = self._rbd[:, :, :7]
+        ppar = poses[:, self._ee_parent]                                     # (N, 7, 7) parent link poses (world)
+        xp = self._ee_xp[None]
+        o = ppar[..., :3] + self._qrot(ppar[..., 3:7], xp[..., :3].expand(self.num_envs, -1, -1))
+        qj = self._qmul(ppar[..., 3:7], xp[..., 3:7].expand(self.num_envs, -1, -1))
+        ex = torch.zeros_like(o); ex[..., 0] = 1.0
+        z = self._qrot(qj, ex)                                               # joint axis = local x of the joint frame
+        pee = poses[:, self._b_tcp, :3][:, None]
+        Jv = torch.cross(z, pee - o, dim=-1)
+        # into the root frame
+        qr = poses[:, self._b_root, 3:7][:, None]
+        qri = qr * torch.tensor([1.0, -1.0, -1.0, -1.0], device=qr.device)
+        Jv, Jw = self._qrot(qri, Jv), self._qrot(qri, z)
+        return torch.cat([Jv, Jw], dim=-1).transpose(1, 2)                  # (N, 6, 7)
+
+    def _ee_delta(self, action: torch.Tensor) -> torch.Tensor:
+        """_clip_and_scale_action of PDEEPos / PDEEPoseController (pd_ee_pose.py:224-237): (N, 6) delta pose in the root frame."""
+        pos = self.ee_pos_bound * torch.clip(action[:, :3], -1.0, 1.0)
+        if self.control_mode == "pd_ee_delta_pos":
+            return torch.hstack([pos, torch.zeros_like(pos)])
+        rot = action[:, 3:6].clone()
+        nrm = torch.linalg.norm(rot, dim=1)
+        rot[nrm > 1] = (rot / nrm[:, None])[nrm > 1]
+        return torch.hstack([pos, rot * self.ee_rot_lower])
+
+    def _set_action_ee(self, action: torch.Tensor):
+        """compute_ik with is_delta_pose (kinematics.py:229-245): one Levenberg-Marquardt step, target = q0 + dq."""
+        delta = self._ee_delta(action)
+        J = self.ee_jacobian()
+        JT = J.transpose(1, 2)
+        A = torch.bmm(JT, J) + self.ik_damping * torch.eye(7, device=J.device)
+        dq = torch.linalg.solve(A, torch.bmm(JT, delta.unsqueeze(-1))).squeeze(-1)
+        na = action.shape[1]
+        self._target_qpos[:, :7] = self.qpos[:, :7] + dq
+        g = 0.5 * (self.gripper_high + self.gripper_low) + 0.5 * (self.gripper_high - self.gripper_low) * torch.clip(action[:, na - 1:na], -1.0, 1.0)
+        self._target_qpos[:, 7:9] = g
+        self._target_qpos_buf[:, :9] = self._target_qpos
+
     def _step_action(self, action):
         if action is not None:
             action = torch.as_tensor(action, dtype=torch.float32, device=self.device)
@@ -317,7 +394,10 @@ class PickCubeEnv:
                 action = action[None]
             if action.shape != (self.num_envs, self.action_dim):
                 raise AssertionError(f"Received action of shape {tuple(action.shape)} but expected shape ({self.num_envs}, {self.action_dim})")
-            self._set_action(action)
+            if self.control_mode == "pd_joint_delta_pos":
+                self._set_action(action)
+            else:
+                self._set_action_ee(action)
             self.px.gpu_apply_articulation_target_position()
         for _ in range(self._sim_steps_per_control):
             self.px.step()
@@ -351,7 +431,12 @@ class PickCubeEnv:
             if action.shape != (self.num_envs, self.action_dim):
                 raise AssertionError(f"Received action of shape {tuple(action.shape)} but expected shape ({self.num_envs}, {self.action_dim})")
             action = action.contiguous()
-            L.check(px.ctx, L.task_pickcube_set_action(px.ctx, C.c_void_p(action.data_ptr()), px._stream()), "task_pickcube_set_action")
+            if self.control_mode == "pd_joint_delta_pos":
+                L.check(px.ctx, L.task_pickcube_set_action(px.ctx, C.c_void_p(action.data_ptr()), px._stream()), "task_pickcube_set_action")
+            else:   # end-effector control: Jacobian + Levenberg-Marquardt step per env in one kernel
+                L.check(px.ctx, L.task_pickcube_set_action_ee(px.ctx, C.c_void_p(action.data_ptr()), self.action_dim, self._b_root,
+                                                              self.ee_pos_bound, self.ee_rot_lower, self.ik_damping, px._stream()),
+                        "task_pickcube_set_action_ee")
         L.check(px.ctx, L.control_step(px.ctx, self._sim_steps_per_control, px._stream()), "control_step")
         self._buffers_stale = True   # the sapien-style external buffers are refreshed on demand (sync_buffers)
         return self._fused_observe(True)

@@ -1,0 +1,100 @@
+"""pd_ee_delta_pos / pd_ee_delta_pose: Jacobian known answers and closed-loop behaviour on the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from maniskill_amd.envs.pick_cube import PickCubeEnv
+
+
+def test_jacobian_matches_finite_differences(oracle_factory):
+    env = PickCubeEnv(num_envs=2, px_factory=oracle_factory, control_mode="pd_ee_delta_pose")
+    env.reset(seed=0)
+    J = env.ee_jacobian().clone()
+    assert J.shape == (2, 6, 7)
+    tcp0 = env.tcp_pose.clone()
+    root_p = env._rbd[:, env._b_root, :3] - env._offsets
+    eps = 1e-3
+    for k in range(7):
+        q = env._qpos[:, :9].clone()
+        env._qpos[:, k] += eps
+        env.px.gpu_apply_articulation_qpos(); env.px.gpu_update_articulation_kinematics(); env.px.gpu_fetch_all()
+        tcp = env.tcp_pose
+        dp = (tcp[:, :3] - tcp0[:, :3]) / eps                                # the root frame is axis-aligned with the world here
+        assert torch.allclose(dp, J[:, :3, k], atol=2e-3), k
+        # angular part: dq ~ 0.5 w q  ->  w = 2 (q1 q0^-1).xyz / eps
+        q0, q1 = tcp0[:, 3:7], tcp[:, 3:7]
+        q0i = q0 * torch.tensor([1.0, -1, -1, -1])
+        w = 2 * env._qmul(q1, q0i)[:, 1:] / eps
+        assert torch.allclose(w, J[:, 3:, k], atol=2e-3), k
+        env._qpos[:, :9] = q
+        env.px.gpu_apply_articulation_qpos(); env.px.gpu_update_articulation_kinematics(); env.px.gpu_fetch_all()
+    assert torch.allclose(root_p[:, 0], torch.full((2,), -0.615), atol=1e-5)
+
+
+def test_ik_step_realises_the_commanded_delta(oracle_factory):
+    """One LM step: J dq reproduces the clipped / scaled action (kinematics.py:233-245), rotation scaled by rot_lower."""
+    env = PickCubeEnv(num_envs=3, px_factory=oracle_factory, control_mode="pd_ee_delta_pose")
+    env.reset(seed=1)
+    a = torch.tensor([[0.5, -0.2, 0.3, 0.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 0.6, 0.0, 0.0, 1.0], [2.0, 0.0, 0.0, 2.0, 2.0, 0.0, -1.0]])
+    q0 = env.qpos[:, :7].clone()
+    J = env.ee_jacobian()
+    env._set_action_ee(a)
+    dq = env._target_qpos[:, :7] - q0
+    got = torch.bmm(J, dq.unsqueeze(-1)).squeeze(-1)
+    want = torch.tensor([[0.05, -0.02, 0.03, 0, 0, 0], [0, 0, 0, -0.06, 0, 0],
+                         [0.1, 0, 0, -0.1 / np.sqrt(2), -0.1 / np.sqrt(2), 0]], dtype=torch.float32)
+    assert torch.allclose(got, want, atol=2e-3)
+    assert torch.allclose(env._target_qpos[:, 7], torch.tensor([0.015, 0.04, -0.01]), atol=1e-6)     # mimic gripper
+
+
+def test_constant_upward_command_lifts_the_tcp(oracle_factory):
+    env = PickCubeEnv(num_envs=2, px_factory=oracle_factory, control_mode="pd_ee_delta_pos")
+    obs, _ = env.reset(seed=2)
+    assert env.action_dim == 4
+    z0 = env.tcp_pose[:, 2].clone()
+    xy0 = env.tcp_pose[:, :2].clone()
+    for _ in range(15):
+        obs, *_ = env.step(torch.tensor([[0.0, 0.0, 0.5, 0.0]] * 2))
+    assert ((env.tcp_pose[:, 2] - z0) > 0.25).all()                          # 15 steps x ~0.05 m, PD lag aside
+    assert ((env.tcp_pose[:, :2] - xy0).abs() < 0.03).all()
+    with pytest.raises(AssertionError):
+        env.step(torch.zeros(2, 8))
+
+
+@pytest.mark.gpu
+def test_ee_control_on_the_gpu(oracle_factory):
+    """The LM system (J^T J + 1e-4 I) is rank-deficient by one up to the damping (7 joints, 6 task dimensions), so the
+    null-space component of dq amplifies rounding differences between devices / solvers; what is pinned is the task-space
+    effect: J dq of the fused kernel vs the torch path, and the tcp trajectory of HIP rollouts vs the oracle's."""
+    n = 64
+    for mode, adim in (("pd_ee_delta_pose", 7), ("pd_ee_delta_pos", 4)):
+        th = PickCubeEnv(num_envs=n, device="cuda:0", fused=False, control_mode=mode)
+        fz = PickCubeEnv(num_envs=n, device="cuda:0", control_mode=mode)
+        cpu = PickCubeEnv(num_envs=n, px_factory=oracle_factory, control_mode=mode)
+        for env in (th, fz, cpu):
+            env.reset(seed=12)
+        # one controller evaluation from identical states: task-space delta of the two GPU implementations
+        gen = torch.Generator().manual_seed(6)
+        a = 2 * torch.rand(n, adim, generator=gen) - 1
+        J = th.ee_jacobian()
+        q0 = th.qpos[:, :7].clone()
+        th._set_action_ee(a.to("cuda:0"))
+        dq_t = th._target_qpos[:, :7] - q0
+        fz.step(a.to("cuda:0"))
+        fz.sync_buffers()
+        dq_f = fz.px.cuda_articulation_target_qpos.torch().view(n, -1)[:, :7] - q0
+        want = th._ee_delta(a.to("cuda:0"))
+        assert torch.allclose(torch.bmm(J, dq_t.unsqueeze(-1)).squeeze(-1), want, atol=2e-3)
+        assert torch.allclose(torch.bmm(J, dq_f.unsqueeze(-1)).squeeze(-1), want, atol=2e-3)
+        assert torch.allclose(dq_f, dq_t, atol=2e-2)
+        # closed loop: tcp trajectories of the three implementations stay together
+        for env in (th, fz, cpu):
+            env.reset(seed=12)
+        gen = torch.Generator().manual_seed(7)
+        for t in range(12):
+            a = 0.5 * (2 * torch.rand(n, adim, generator=gen) - 1)
+            ot = th.step(a.to("cuda:0"))[0]
+            of = fz.step(a.to("cuda:0"))[0]
+            oc = cpu.step(a)[0]
+            assert np.allclose(ot[:, 19:22].cpu().numpy(), oc[:, 19:22].numpy(), atol=3e-3), (mode, t)
+            assert np.allclose(of[:, 19:22].cpu().numpy(), oc[:, 19:22].numpy(), atol=3e-3), (mode, t)
