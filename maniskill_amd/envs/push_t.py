@@ -346,5 +346,23 @@ class PushTEnv:
             return s
         return torch.hstack([actor(self._b_table), actor(self._b_tee), actor(self._b_goal), actor(self._b_ee), actor(self._b_root), self.qpos, self.qvel])
 
+    def set_state(self, state, env_idx=None):
+        """BaseEnv.set_state (sapien_env.py:1299-1325): the layout get_state returns."""
+        if env_idx is None:
+            env_idx = torch.arange(self.num_envs, device=self.device)
+        state = torch.as_tensor(state, dtype=torch.float32, device=self.device)
+        self._fresh()
+        off = self._offsets[env_idx]
+        for k, bid in enumerate([self._b_table, self._b_tee, self._b_goal, self._b_ee, self._b_root]):
+            s = state[:, 13 * k: 13 * (k + 1)].clone()
+            s[:, :3] += off
+            self._rbd[env_idx, bid, :] = s
+        self._qpos[env_idx, :7] = state[:, 65:72]
+        self._qvel[env_idx, :7] = state[:, 72:79]
+        self.px.gpu_apply_all()
+        self.px.gpu_update_articulation_kinematics()
+        self.px.gpu_fetch_all()
+        self._buffers_stale = False
+
     def close(self):
         self.px.close()

@@ -47,6 +47,24 @@ def test_seeded_reset_and_partial_reset(oracle_factory):
     assert torch.equal(before[[0, 2]], after[[0, 2]]) and not torch.equal(before[[1, 3]], after[[1, 3]])
 
 
+def test_state_round_trip(oracle_factory):
+    """get_state / set_state (tests/test_sim_state.py:10-37): a saved state restores the rollout exactly."""
+    a = PushTEnv(num_envs=2, px_factory=oracle_factory)
+    b = PushTEnv(num_envs=2, px_factory=oracle_factory)
+    a.reset(seed=3); b.reset(seed=8)
+    gen = torch.Generator().manual_seed(0)
+    for _ in range(5):
+        a.step(2 * torch.rand(2, 7, generator=gen) - 1)
+    st = a.get_state()
+    assert st.shape == (2, 79)
+    b.set_state(st)
+    b._target_qpos[:] = a._target_qpos; b._target_qpos_buf[:, :7] = a._target_qpos; b.px.gpu_apply_articulation_target_position()
+    assert torch.allclose(b.get_state(), st, atol=1e-6)
+    act = 2 * torch.rand(2, 7, generator=gen) - 1
+    a.step(act); b.step(act)
+    assert torch.allclose(a.get_state(), b.get_state(), atol=2e-4)    # contact warm-start caches differ, the states agree
+
+
 def test_stick_pushes_the_tee(oracle_factory):
     """The stick (a 16-sided prism hull on the hand) sweeping across the table moves the T block."""
     env = PushTEnv(num_envs=1, px_factory=oracle_factory, robot_init_qpos_noise=0.0)
