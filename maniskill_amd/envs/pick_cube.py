@@ -107,14 +107,16 @@ class PickCubeEnv:
         self.robot_init_qpos_noise = robot_init_qpos_noise
         self.reward_mode = reward_mode
         # control modes of Panda._controller_configs (panda.py:187-200): joint deltas (default) or end-effector deltas through IK
-        if control_mode not in ("pd_joint_delta_pos", "pd_ee_delta_pos", "pd_ee_delta_pose"):
-            raise NotImplementedError(f"control_mode {control_mode!r}: this backend provides pd_joint_delta_pos, pd_ee_delta_pos, pd_ee_delta_pose")
+        dims = {"pd_joint_delta_pos": 8, "pd_joint_pos": 8, "pd_joint_target_delta_pos": 8, "pd_joint_vel": 8,
+                "pd_ee_delta_pos": 4, "pd_ee_delta_pose": 7, "pd_ee_target_delta_pos": 4, "pd_ee_target_delta_pose": 7}
+        if control_mode not in dims:
+            raise NotImplementedError(f"control_mode {control_mode!r}: this backend provides {sorted(dims)}")
         self.control_mode = control_mode
-        self.action_dim = {"pd_joint_delta_pos": 8, "pd_ee_delta_pos": 4, "pd_ee_delta_pose": 7}[control_mode]
+        self.action_dim = dims[control_mode]
         self.env_index_offset = int(env_index_offset)
         assert self.sim_config.sim_freq % self.sim_config.control_freq == 0
         self._sim_steps_per_control = self.sim_config.sim_freq // self.sim_config.control_freq
-        tpl, ids = sb.build_pick_cube_template(self.cube_half_size)
+        tpl, ids = sb.build_pick_cube_template(self.cube_half_size, arm_stiffness=0.0 if control_mode == "pd_joint_vel" else None)
         self.template, self.ids = tpl, ids
         if px_factory is None:
             if device is None:
@@ -155,6 +157,8 @@ class PickCubeEnv:
         self._root_pose = torch.tensor([-0.615, 0.0, 0.0, 1, 0, 0, 0], dtype=torch.float32, device=dev)
         self._elapsed_steps = torch.zeros(N, dtype=torch.int32, device=dev)
         self._target_qpos = torch.zeros(N, 9, dtype=torch.float32, device=dev)
+        self._target_qvel_buf = self.px.cuda_articulation_target_qvel.torch().view(N, -1)
+        self._target_pose = None
         self._main_seeds = 2022 + self.env_index_offset + np.arange(N)
         self._rng = BatchedRNG(self._main_seeds)
         self._episode_count = np.zeros(N, dtype=np.uint64)
@@ -295,9 +299,17 @@ class PickCubeEnv:
         # controller.reset(): targets = current qpos (pd_joint_pos.py:54-69)
         self._target_qpos[env_idx] = self._qpos[env_idx, :9]
         self._target_qpos_buf[env_idx, :9] = self._qpos[env_idx, :9]
+        if self.control_mode == "pd_joint_vel":
+            self._target_qvel_buf[env_idx] = 0.0
         self.px.gpu_apply_all()
         self.px.gpu_update_articulation_kinematics()
         self.px.gpu_fetch_all()
+        if "target_delta" in self.control_mode and self.control_mode.startswith("pd_ee"):   # controller.reset(): target = current ee pose
+            cur = self.ee_pose_at_base()
+            if getattr(self, "_target_pose", None) is None:
+                self._target_pose = cur.clone()
+            else:
+                self._target_pose[env_idx] = cur[env_idx]
         if getattr(self, "fused", False):
             obs, _, _, _, info = self._fused_observe(False)
             return obs, info
@@ -387,6 +399,70 @@ class PickCubeEnv:
         self._target_qpos[:, 7:9] = g
         self._target_qpos_buf[:, :9] = self._target_qpos
 
+    # ---- the other controllers of Panda._controller_configs (panda.py:81-211) --------------------------------------------
+    def _gripper_target(self, a_last):
+        return 0.5 * (self.gripper_high + self.gripper_low) + 0.5 * (self.gripper_high - self.gripper_low) * torch.clip(a_last, -1.0, 1.0)
+
+    @staticmethod
+    def _euler_xyz_to_quat(r):
+        """matrix_to_quaternion(euler_angles_to_matrix(r, "XYZ")): R = Rx(a) Ry(b) Rz(c)  ->  q = qx * qy * qz (wxyz)."""
+        h = 0.5 * r
+        cx, cy, cz, sx, sy, sz = h[:, 0].cos(), h[:, 1].cos(), h[:, 2].cos(), h[:, 0].sin(), h[:, 1].sin(), h[:, 2].sin()
+        return torch.stack([cx * cy * cz - sx * sy * sz, sx * cy * cz + cx * sy * sz, cx * sy * cz - sx * cy * sz, cx * cy * sz + sx * sy * cz], dim=-1)
+
+    @classmethod
+    def _quat_to_euler_xyz(cls, q):
+        """matrix_to_euler_angles(quaternion_to_matrix(q), "XYZ")."""
+        w, x, y, z = q.unbind(-1)
+        r02 = 2 * (x * z + w * y)
+        r12, r22 = 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)
+        r01, r00 = 2 * (x * y - w * z), 1 - 2 * (y * y + z * z)
+        return torch.stack([torch.atan2(-r12, r22), torch.asin(torch.clamp(r02, -1.0, 1.0)), torch.atan2(-r01, r00)], dim=-1)
+
+    def ee_pose_at_base(self):
+        """to_base * ee_pose (pd_ee_pose.py:70-73): (N, 7) tcp pose in the root link's frame."""
+        self._fresh()
+        root, tcp = self._rbd[:, self._b_root, :7], self._rbd[:, self._b_tcp, :7]
+        qri = root[:, 3:7] * torch.tensor([1.0, -1.0, -1.0, -1.0], device=root.device)
+        return torch.cat([self._qrot(qri, tcp[:, :3] - root[:, :3]), self._qmul(qri, tcp[:, 3:7])], dim=-1)
+
+    def _set_action_any(self, action: torch.Tensor):
+        """CombinedController.set_action for the control mode of this env; returns which target buffer to commit."""
+        mode, na = self.control_mode, action.shape[1]
+        if mode == "pd_joint_delta_pos":
+            self._set_action(action)
+        elif mode in ("pd_ee_delta_pos", "pd_ee_delta_pose"):
+            self._set_action_ee(action)
+        elif mode == "pd_joint_pos":          # absolute arm targets, not normalised (normalize_action=False, panda.py:81-89)
+            self._target_qpos[:, :7] = action[:, :7]
+            self._target_qpos[:, 7:9] = self._gripper_target(action[:, 7:8])
+        elif mode == "pd_joint_target_delta_pos":   # use_target: the delta accumulates on the previous target (pd_joint_pos.py:84-87)
+            self._target_qpos[:, :7] = self._target_qpos[:, :7] + self.arm_delta * torch.clip(action[:, :7], -1.0, 1.0)
+            self._target_qpos[:, 7:9] = self._gripper_target(action[:, 7:8])
+        elif mode == "pd_joint_vel":          # PDJointVelController: velocity targets in [-1, 1] rad/s on damping-only drives
+            self._target_qvel_buf[:, :7] = torch.clip(action[:, :7], -1.0, 1.0)
+            self._target_qpos[:, 7:9] = self._gripper_target(action[:, 7:8])
+            self._target_qpos[:, :7] = self.qpos[:, :7]       # stiffness 0: the position target of the arm joints is inert
+        else:                                 # pd_ee_target_delta_pos / pose: virtual target pose in the root frame (pd_ee_pose.py:104-129,239-253)
+            delta = self._ee_delta(action)
+            prev = self._target_pose
+            q = self._qmul(self._euler_xyz_to_quat(delta[:, 3:6]), prev[:, 3:7])        # root_aligned_body_rotation
+            target = torch.cat([prev[:, :3] + delta[:, :3], q], dim=-1)                # root_translation
+            self._target_pose = target
+            cur = self.ee_pose_at_base()
+            qci = cur[:, 3:7] * torch.tensor([1.0, -1.0, -1.0, -1.0], device=cur.device)
+            d6 = torch.cat([target[:, :3] - cur[:, :3], self._quat_to_euler_xyz(self._qmul(target[:, 3:7], qci))], dim=-1)   # kinematics.py:218-228
+            J = self.ee_jacobian()
+            JT = J.transpose(1, 2)
+            A = torch.bmm(JT, J) + self.ik_damping * torch.eye(7, device=J.device)
+            dq = torch.linalg.solve(A, torch.bmm(JT, d6.unsqueeze(-1))).squeeze(-1)
+            self._target_qpos[:, :7] = self.qpos[:, :7] + dq
+            self._target_qpos[:, 7:9] = self._gripper_target(action[:, na - 1:na])
+        self._target_qpos_buf[:, :9] = self._target_qpos
+        self.px.gpu_apply_articulation_target_position()
+        if mode == "pd_joint_vel":
+            self.px.gpu_apply_articulation_target_velocity()
+
     def _step_action(self, action):
         if action is not None:
             action = torch.as_tensor(action, dtype=torch.float32, device=self.device)
@@ -394,11 +470,7 @@ class PickCubeEnv:
                 action = action[None]
             if action.shape != (self.num_envs, self.action_dim):
                 raise AssertionError(f"Received action of shape {tuple(action.shape)} but expected shape ({self.num_envs}, {self.action_dim})")
-            if self.control_mode == "pd_joint_delta_pos":
-                self._set_action(action)
-            else:
-                self._set_action_ee(action)
-            self.px.gpu_apply_articulation_target_position()
+            self._set_action_any(action)
         for _ in range(self._sim_steps_per_control):
             self.px.step()
         self.px.gpu_fetch_all()
@@ -433,6 +505,9 @@ class PickCubeEnv:
             action = action.contiguous()
             if self.control_mode == "pd_joint_delta_pos":
                 L.check(px.ctx, L.task_pickcube_set_action(px.ctx, C.c_void_p(action.data_ptr()), px._stream()), "task_pickcube_set_action")
+            elif self.control_mode not in ("pd_ee_delta_pos", "pd_ee_delta_pose"):   # the less common controllers stay in torch
+                self._fresh()
+                self._set_action_any(action)
             else:   # end-effector control: Jacobian + Levenberg-Marquardt step per env in one kernel
                 L.check(px.ctx, L.task_pickcube_set_action_ee(px.ctx, C.c_void_p(action.data_ptr()), self.action_dim, self._b_root,
                                                               self.ee_pos_bound, self.ee_rot_lower, self.ik_damping, px._stream()),

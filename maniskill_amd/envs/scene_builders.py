@@ -62,21 +62,23 @@ def add_site(tpl: SceneTemplate, name, p=(0, 0, 0)):
     return tpl.add_actor(name, N.BODY_KINEMATIC, p=p)
 
 
-def add_panda(tpl: SceneTemplate, root_p=(-0.615, 0.0, 0.0), stiffness=1e3, damping=1e2, force_limit=100.0):
-    """Panda with the drive properties of its pd_joint_delta_pos controller (panda.py:68-98,177-190)."""
+def add_panda(tpl: SceneTemplate, root_p=(-0.615, 0.0, 0.0), stiffness=1e3, damping=1e2, force_limit=100.0, arm_stiffness=None):
+    """Panda with the drive properties of its controllers (panda.py:68-98,177-190); arm_stiffness = 0 is what
+    PDJointVelController.set_drive_property sets on the arm joints (pd_joint_vel.py:25-38)."""
     model = load_model("panda_v2.json")
     art = add_urdf_articulation(tpl, model, "panda", root_p=root_p, urdf_config=PANDA_URDF_CONFIG,
                                 disable_gravity=True)  # balance_passive_force (base_agent.py:263-282)
-    for bid in tpl.art_active[art]:
-        tpl.set_drive(bid, stiffness, damping, force_limit, "force")
+    for k, bid in enumerate(tpl.art_active[art]):
+        ks = stiffness if (arm_stiffness is None or k >= 7) else arm_stiffness
+        tpl.set_drive(bid, ks, damping, force_limit, "force")
     return art
 
 
-def build_pick_cube_template(cube_half_size=0.02):
+def build_pick_cube_template(cube_half_size=0.02, arm_stiffness=None):
     """Body order: 15 panda links (ids 0..14), table-workspace, cube, goal_site = 18 rows per env
     (_load_agent runs before _load_scene, sapien_env.py:725-759)."""
     tpl = SceneTemplate()
-    art = add_panda(tpl)
+    art = add_panda(tpl, arm_stiffness=arm_stiffness)
     table = add_table_scene(tpl)
     cube = add_cube(tpl, "cube", cube_half_size, (0, 0, cube_half_size))
     goal = add_site(tpl, "goal_site")

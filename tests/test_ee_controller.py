@@ -98,3 +98,49 @@ def test_ee_control_on_the_gpu(oracle_factory):
             oc = cpu.step(a)[0]
             assert np.allclose(ot[:, 19:22].cpu().numpy(), oc[:, 19:22].numpy(), atol=3e-3), (mode, t)
             assert np.allclose(of[:, 19:22].cpu().numpy(), oc[:, 19:22].numpy(), atol=3e-3), (mode, t)
+
+
+def test_the_other_panda_control_modes(oracle_factory):
+    """pd_joint_pos / pd_joint_target_delta_pos / pd_joint_vel / pd_ee_target_delta_pose (panda.py:81-211)."""
+    # absolute joint targets are tracked
+    env = PickCubeEnv(num_envs=2, px_factory=oracle_factory, control_mode="pd_joint_pos")
+    env.reset(seed=0)
+    tgt = env.qpos[:, :7].clone()
+    tgt[:, 0] += 0.3; tgt[:, 3] -= 0.2
+    act = torch.hstack([tgt, torch.ones(2, 1)])
+    for _ in range(25):
+        env.step(act)
+    assert torch.allclose(env.qpos[:, :7], tgt, atol=2e-2) and torch.allclose(env.qpos[:, 7], torch.full((2,), 0.04), atol=3e-3)
+    # use_target: deltas accumulate on the target, not on the (lagging) joint position
+    env = PickCubeEnv(num_envs=1, px_factory=oracle_factory, control_mode="pd_joint_target_delta_pos")
+    env.reset(seed=0)
+    q0 = env.qpos[0, 0].item()
+    a = torch.zeros(1, 8); a[0, 0] = 1.0
+    for _ in range(5):
+        env.step(a)
+    assert abs(env._target_qpos[0, 0].item() - (q0 + 0.5)) < 1e-5
+    # velocity control: the arm joint turns at the commanded rate
+    env = PickCubeEnv(num_envs=1, px_factory=oracle_factory, control_mode="pd_joint_vel")
+    env.reset(seed=0)
+    q0 = env.qpos[0, 0].item()
+    a = torch.zeros(1, 8); a[0, 0] = 0.5
+    for _ in range(20):
+        env.step(a)
+    assert abs(env.qvel[0, 0].item() - 0.5) < 0.05 and abs(env.qpos[0, 0].item() - (q0 + 0.5 * 20 * 0.05)) < 0.08
+    # virtual ee target: the target pose moves by exactly the commanded delta per step and the tcp follows it
+    env = PickCubeEnv(num_envs=2, px_factory=oracle_factory, control_mode="pd_ee_target_delta_pose")
+    env.reset(seed=0)
+    t0 = env._target_pose.clone()
+    assert torch.allclose(t0, env.ee_pose_at_base(), atol=1e-6)
+    a = torch.zeros(2, 7); a[:, 2] = 0.4; a[:, 5] = -0.5
+    for _ in range(10):
+        env.step(a)
+    assert torch.allclose(env._target_pose[:, :3] - t0[:, :3], torch.tensor([[0.0, 0.0, 0.4]]).repeat(2, 1), atol=1e-5)
+    cur = env.ee_pose_at_base()
+    assert (cur[:, :3] - env._target_pose[:, :3]).norm(dim=1).max() < 0.08
+    dq = env._qmul(env._target_pose[:, 3:7], t0[:, 3:7] * torch.tensor([1.0, -1, -1, -1]))
+    ang = 2 * torch.atan2(dq[:, 1:].norm(dim=1), dq[:, 0].abs())
+    assert torch.allclose(ang, torch.full((2,), 10 * 0.05), atol=1e-3)           # 10 steps x |rot_lower| x 0.5 rad about the root z axis
+    # euler helpers invert each other
+    r = torch.tensor([[0.3, -0.2, 0.5], [-1.0, 0.4, 0.1]])
+    assert torch.allclose(PickCubeEnv._quat_to_euler_xyz(PickCubeEnv._euler_xyz_to_quat(r)), r, atol=1e-6)
