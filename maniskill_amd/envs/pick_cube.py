@@ -88,6 +88,7 @@ class PickCubeEnv:
     """
 
     max_episode_steps = 50
+    max_reward = 5.0
     goal_thresh = 0.025
     cube_half_size = 0.02
     cube_spawn_half_size = 0.1
@@ -116,7 +117,7 @@ class PickCubeEnv:
         self.env_index_offset = int(env_index_offset)
         assert self.sim_config.sim_freq % self.sim_config.control_freq == 0
         self._sim_steps_per_control = self.sim_config.sim_freq // self.sim_config.control_freq
-        tpl, ids = sb.build_pick_cube_template(self.cube_half_size, arm_stiffness=0.0 if control_mode == "pd_joint_vel" else None)
+        tpl, ids = self._build_template(arm_stiffness=0.0 if control_mode == "pd_joint_vel" else None)
         self.template, self.ids = tpl, ids
         if px_factory is None:
             if device is None:
@@ -191,7 +192,7 @@ class PickCubeEnv:
         self.camera = None
         if obs_mode != "state":
             from ..render import CameraConfig, RenderCameraGroup, attach_template_visuals, look_at
-            attach_template_visuals(self.px, tpl, hidden_bodies=(self._b_goal,))   # goal_site is in _hidden_objects
+            attach_template_visuals(self.px, tpl, hidden_bodies=self._hidden_bodies())
             p, q = look_at(eye=[0.3, 0, 0.6], target=[-0.1, 0, 0.1])
             self.camera = RenderCameraGroup(self.px, CameraConfig("base_camera", p, q, 128, 128, np.pi / 2, 0.01, 100.0))
             if self._want_color:
@@ -275,27 +276,7 @@ class PickCubeEnv:
             root = self._root_pose.repeat(b, 1)
             root[:, :3] += off
             self._rbd[env_idx, self._b_root, :7] = root
-            # PickCubeEnv._initialize_episode
-            # all episode randomness is evaluated on the host in float64 and rounded once, so that the
-            # initial state is bit-identical whatever device the env lives on
-            u = self._rng.uniform(idx_np, 6)
-            hs, cc = self.cube_spawn_half_size, self.cube_spawn_center
-            xyz = np.zeros((b, 3))
-            xyz[:, 0] = u[:, 0] * hs * 2 - hs + cc[0]
-            xyz[:, 1] = u[:, 1] * hs * 2 - hs + cc[1]
-            xyz[:, 2] = self.cube_half_size
-            yaw = u[:, 2] * (2 * np.pi)  # random_quaternions(lock_x, lock_y): rotation about z
-            qs = np.zeros((b, 4))
-            qs[:, 0] = np.cos(yaw / 2)
-            qs[:, 3] = np.sin(yaw / 2)
-            self._rbd[env_idx, self._b_cube, :3] = f32(xyz) + off
-            self._rbd[env_idx, self._b_cube, 3:7] = f32(qs)
-            goal = np.zeros((b, 3))
-            goal[:, 0] = u[:, 3] * hs * 2 - hs + cc[0]
-            goal[:, 1] = u[:, 4] * hs * 2 - hs + cc[1]
-            goal[:, 2] = u[:, 5] * self.max_goal_height + xyz[:, 2]
-            self._rbd[env_idx, self._b_goal, :3] = f32(goal) + off
-            self._rbd[env_idx, self._b_goal, 3:7] = torch.tensor([1.0, 0, 0, 0], device=dev)
+            self._initialize_episode(env_idx, idx_np, off, f32)
         # controller.reset(): targets = current qpos (pd_joint_pos.py:54-69)
         self._target_qpos[env_idx] = self._qpos[env_idx, :9]
         self._target_qpos_buf[env_idx, :9] = self._qpos[env_idx, :9]
@@ -317,6 +298,30 @@ class PickCubeEnv:
         obs = self._with_sensor_data(self.get_obs(info))
         return obs, info
 
+    def _initialize_episode(self, env_idx, idx_np, off, f32):
+        """PickCubeEnv._initialize_episode (pick_cube.py:106-130)."""
+        b, dev = len(idx_np), self.device
+        # all episode randomness is evaluated on the host in float64 and rounded once, so that the
+        # initial state is bit-identical whatever device the env lives on
+        u = self._rng.uniform(idx_np, 6)
+        hs, cc = self.cube_spawn_half_size, self.cube_spawn_center
+        xyz = np.zeros((b, 3))
+        xyz[:, 0] = u[:, 0] * hs * 2 - hs + cc[0]
+        xyz[:, 1] = u[:, 1] * hs * 2 - hs + cc[1]
+        xyz[:, 2] = self.cube_half_size
+        yaw = u[:, 2] * (2 * np.pi)  # random_quaternions(lock_x, lock_y): rotation about z
+        qs = np.zeros((b, 4))
+        qs[:, 0] = np.cos(yaw / 2)
+        qs[:, 3] = np.sin(yaw / 2)
+        self._rbd[env_idx, self._b_cube, :3] = f32(xyz) + off
+        self._rbd[env_idx, self._b_cube, 3:7] = f32(qs)
+        goal = np.zeros((b, 3))
+        goal[:, 0] = u[:, 3] * hs * 2 - hs + cc[0]
+        goal[:, 1] = u[:, 4] * hs * 2 - hs + cc[1]
+        goal[:, 2] = u[:, 5] * self.max_goal_height + xyz[:, 2]
+        self._rbd[env_idx, self._b_goal, :3] = f32(goal) + off
+        self._rbd[env_idx, self._b_goal, 3:7] = torch.tensor([1.0, 0, 0, 0], device=dev)
+
     # ---------------------------------------------------------------- step
     def _set_action(self, action: torch.Tensor):
         """CombinedController.set_action -> arm PDJointPos(use_delta) + gripper PDJointPosMimic."""
@@ -327,6 +332,12 @@ class PickCubeEnv:
         g = 0.5 * (self.gripper_high + self.gripper_low) + 0.5 * (self.gripper_high - self.gripper_low) * a[:, 7:8]
         self._target_qpos[:, 7:9] = g
         self._target_qpos_buf[:, :9] = self._target_qpos
+
+    def _build_template(self, arm_stiffness=None):
+        return sb.build_pick_cube_template(self.cube_half_size, arm_stiffness=arm_stiffness)
+
+    def _hidden_bodies(self):
+        return (self._b_goal,)   # goal_site is in _hidden_objects (pick_cube.py:104)
 
     # ---- end-effector control (agents/controllers/pd_ee_pose.py:24-262, utils/kinematics.py:185-259) ---------------------
     ee_pos_bound = 0.1      # pos_lower / pos_upper of arm_pd_ee_delta_pos(e) (panda.py:103-124)
@@ -590,7 +601,7 @@ class PickCubeEnv:
 
     def get_reward(self, obs, action, info):
         r = self.compute_dense_reward(obs, action, info)
-        return r / 5 if self.reward_mode == "normalized_dense" else r
+        return r / self.max_reward if self.reward_mode == "normalized_dense" else r
 
     # ---------------------------------------------------------------- state (sapien_env.py:1272-1325)
     def get_state(self):

@@ -20,8 +20,9 @@ ENVS = {}
 def _registry():
     if not ENVS:
         from .envs.pick_cube import PickCubeEnv
+        from .envs.push_cube import PushCubeEnv
         from .envs.push_t import PushTEnv
-        ENVS.update({"PickCube-v1": PickCubeEnv, "PushT-v1": PushTEnv})
+        ENVS.update({"PickCube-v1": PickCubeEnv, "PushCube-v1": PushCubeEnv, "PushT-v1": PushTEnv})
     return ENVS
 
 
