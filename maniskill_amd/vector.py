@@ -22,7 +22,8 @@ def _registry():
         from .envs.pick_cube import PickCubeEnv
         from .envs.push_cube import PushCubeEnv
         from .envs.push_t import PushTEnv
-        ENVS.update({"PickCube-v1": PickCubeEnv, "PushCube-v1": PushCubeEnv, "PushT-v1": PushTEnv})
+        from .envs.stack_cube import StackCubeEnv
+        ENVS.update({"PickCube-v1": PickCubeEnv, "PushCube-v1": PushCubeEnv, "StackCube-v1": StackCubeEnv, "PushT-v1": PushTEnv})
     return ENVS
 
 

@@ -1,0 +1,54 @@
+"""StackCube-v1 (mani_skill/envs/tasks/tabletop/stack_cube.py): host logic and known answers on the CPU oracle; HIP parity under -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from maniskill_amd.envs.stack_cube import StackCubeEnv
+
+
+def test_reset_places_two_separate_cubes(oracle_factory):
+    env = StackCubeEnv(num_envs=8, px_factory=oracle_factory)
+    obs, info = env.reset(seed=0)
+    assert obs.shape == (8, 48) and not info["success"].any() and not info["is_cubeA_on_cubeB"].any()
+    a, b = env.cube_pose, env.cubeB_pose
+    assert torch.allclose(a[:, 2], torch.full((8,), 0.02), atol=1e-5) and torch.allclose(b[:, 2], torch.full((8,), 0.02), atol=1e-5)
+    assert ((a[:, :2] - b[:, :2]).norm(dim=1) > 2 * (np.hypot(0.02, 0.02) + 0.001) - 1e-6).all()
+    assert torch.allclose(obs[:, 45:48], b[:, :3] - a[:, :3], atol=1e-6)
+    for _ in range(10):
+        obs, r, term, trunc, info = env.step(None)
+    assert info["is_cubeA_static"].all() and not info["is_cubeA_grasped"].any() and (r > 0).all() and (r < 0.3).all()
+
+
+def test_stacked_and_released_is_a_success(oracle_factory):
+    env = StackCubeEnv(num_envs=2, px_factory=oracle_factory)
+    env.reset(seed=1)
+    b = env._rbd[:, env._b_cubeB, :7].clone()
+    env._rbd[:, env._b_cube, :3] = b[:, :3] + torch.tensor([0.0, 0.0, 0.0402])
+    env._rbd[:, env._b_cube, 3:7] = b[:, 3:7]
+    env.px.gpu_apply_all(); env.px.gpu_fetch_all()
+    for _ in range(6):
+        obs, r, term, trunc, info = env.step(None)                     # the cube settles on the base
+    assert info["is_cubeA_on_cubeB"].all() and info["is_cubeA_static"].all() and info["success"].all()
+    assert torch.allclose(r, torch.ones(2)) and term.all()
+    # 3 cm off centre: not on the base any more
+    env._rbd[:, env._b_cube, 0] += 0.04
+    env.px.gpu_apply_all(); env.px.gpu_fetch_all()
+    assert not env.evaluate()["is_cubeA_on_cubeB"].any()
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_rollout(oracle_factory):
+    n = 64
+    gpu = StackCubeEnv(num_envs=n, device="cuda:0")
+    cpu = StackCubeEnv(num_envs=n, px_factory=oracle_factory)
+    og, _ = gpu.reset(seed=2022); oc, _ = cpu.reset(seed=2022)
+    assert torch.equal(og.cpu(), oc)
+    gen = torch.Generator().manual_seed(0)
+    for t in range(40):
+        a = 2 * torch.rand(n, 8, generator=gen) - 1
+        og, rg, tg, ug, ig = gpu.step(a.to("cuda:0"))
+        oc, rc, tc, uc, ic = cpu.step(a)
+        assert np.allclose(og.cpu().numpy(), oc.numpy(), rtol=1e-4, atol=1e-5), t
+        assert np.allclose(rg.cpu().numpy(), rc.numpy(), atol=1e-5) and torch.equal(tg.cpu(), tc)
+        assert torch.equal(ig["is_cubeA_grasped"].cpu(), ic["is_cubeA_grasped"])
+    assert np.allclose(gpu.get_state().cpu().numpy(), cpu.get_state().numpy(), rtol=1e-4, atol=1e-5)
