@@ -159,6 +159,21 @@ int msk_update_kinematics(msk_ctx* ctx, void* stream);
 /* PhysxGpuSystem.step() (envs/scene.py:379-380): one substep of `timestep` for all envs. */
 int msk_step(msk_ctx* ctx, void* stream);
 
+/* ---- per-env instances of the template (heterogeneous sub-scenes) -------------------------------------------- */
+/* ManiSkill builds some tasks with a different actor per sub-scene and merges them (Actor.merge: e.g. PegInsertionSide-v1's
+ * peg and box-with-hole, one size per env, envs/tasks/tabletop/peg_insertion_side.py:133-187).  Here the template stays one
+ * description; a box shape / a dynamic actor can be declared to take its numbers from the env's own record instead:
+ *   msk_declare_env_box(shape)   before msk_finalize: half sizes and the position part of the local pose vary per env
+ *   msk_declare_env_mass(body)   before msk_finalize: mass and principal inertia vary per env (the body's centre of mass must be
+ *                                its origin and its inertia diagonal)
+ *   msk_set_env_boxes(shape, half_sizes[num_envs][3], local_pos[num_envs][3] or NULL)      after msk_finalize
+ *   msk_set_env_masses(body, mass[num_envs], principal_inertia[num_envs][3])               after msk_finalize
+ * Until set, every env uses the template's values.  Collision filtering and the candidate-pair table stay those of the template. */
+int msk_declare_env_box(msk_ctx* ctx, int shape);
+int msk_declare_env_mass(msk_ctx* ctx, int body);
+int msk_set_env_boxes(msk_ctx* ctx, int shape, const float* half_sizes, const float* local_pos);
+int msk_set_env_masses(msk_ctx* ctx, int body, const float* mass, const float* principal_inertia);
+
 /* ---- contact impulse queries (envs/scene.py:771-781) ------------------------------ */
 /* gpu_create_contact_pair_impulse_query(body_pairs): body ids are template body ids, the
  * same pair is queried in every env.  Output buffer (num_envs*npairs, 3) f32, row =

@@ -37,6 +37,9 @@ int msk_render_add_mesh(msk_ctx* ctx, int body, const float local_pose[7], const
                         const int32_t* tris, int ntris, int seg_id);
 /* RenderMaterial(base_color=rgba) of a render shape (building/actor_builder.py:166-191); default (0.8, 0.8, 0.8, 1). */
 int msk_render_set_base_color(msk_ctx* ctx, int render_shape, const float rgba[4]);
+/* The render shape draws a per-env box instance (msk_declare_env_box): its vertices — give it the unit box, corners at +-1 — are
+ * multiplied component-wise by the env's half sizes of `shape`, and its local position is the env's. */
+int msk_render_bind_env_box(msk_ctx* ctx, int render_shape, int shape);
 /* scene.set_ambient_light + add_directional_light (envs/sapien_env.py:849-853; envs/scene.py:566-718): at most 4 directional
  * lights, directions in the sub-scene frame.  Default: ManiSkill's default lighting (ambient 0.3; (1, 1, -1) and (0, 0, -1), white). */
 int msk_render_set_lights(msk_ctx* ctx, const float ambient[3], int ndir, const float* directions, const float* colors);

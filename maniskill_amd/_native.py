@@ -28,10 +28,10 @@ EXPORTS = [
     "add_actor", "add_shape", "disable_collision", "finalize", "set_scene_offsets", "buffer", "apply",
     "fetch", "update_kinematics", "step", "query_create_pairs", "query_create_bodies", "query_buffer", "query_run",
     "get_sizes", "get_contacts", "get_env_contact_counts", "timing_enable", "timing_read",
-    "set_solver_classes", "get_solver_class_counts",
+    "set_solver_classes", "get_solver_class_counts", "declare_env_box", "declare_env_mass", "set_env_boxes", "set_env_masses",
 ]
 # include/msk_render.h — camera pipeline (both libraries)
-RENDER_EXPORTS = ["render_add_mesh", "render_set_base_color", "render_set_lights", "render_finalize", "camera_create", "camera_buffer",
+RENDER_EXPORTS = ["render_add_mesh", "render_set_base_color", "render_bind_env_box", "render_set_lights", "render_finalize", "camera_create", "camera_buffer",
                   "camera_obs_buffer", "camera_take_picture"]
 # include/msk_task.h — fused task kernels (HIP library only; the test-suite's CPU checker has no counterpart)
 TASK_EXPORTS = ["task_pickcube_init", "task_pickcube_set_action", "task_pickcube_set_action_ee", "control_step", "task_pickcube_observe",
@@ -120,6 +120,10 @@ class NativeLib:
             "get_sizes": (i32, [vp, C.POINTER(C.c_int32)]),
             "get_contacts": (i32, [vp, i32, C.POINTER(C.c_int32), fp, i32]),
             "get_env_contact_counts": (i32, [vp, C.POINTER(C.c_int32)]),
+            "declare_env_box": (i32, [vp, i32]),
+            "declare_env_mass": (i32, [vp, i32]),
+            "set_env_boxes": (i32, [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+            "set_env_masses": (i32, [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
             "set_solver_classes": (i32, [vp, C.POINTER(C.c_int32)]),
             "get_solver_class_counts": (i32, [vp, C.POINTER(C.c_int32)]),
             "timing_enable": (i32, [vp, i32]),
@@ -134,6 +138,7 @@ class NativeLib:
             "render_finalize": (i32, [vp]),
             "camera_create": (i32, [vp, i32, i32, f32, f32, f32, i32, fp]),
             "render_set_base_color": (i32, [vp, i32, C.POINTER(C.c_float)]),
+            "render_bind_env_box": (i32, [vp, i32, i32]),
             "render_set_lights": (i32, [vp, C.POINTER(C.c_float), i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
             "camera_buffer": (vp, [vp, i32, C.POINTER(C.c_int64)]),
             "camera_obs_buffer": (vp, [vp, i32, i32, C.POINTER(C.c_int64)]),

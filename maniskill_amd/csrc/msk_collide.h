@@ -133,12 +133,13 @@ MSK_DEV v3 support(const CCtx& m, const CShape* sh, const pose* T, v3 d) {
   return pose_apply(*T, pl);
 }
 
-MSK_DEV void world_aabb(const DShape* sh, const pose* T, v3* c, v3* h) {
+/* world AABB of a shape whose local AABB has centre lc and half extents lh */
+MSK_DEV void world_aabb(v3 lc, v3 lh, const pose* T, v3* c, v3* h) {
   m33 R = quat_to_m33(T->q);
-  *c = v3_add(T->p, m33_mulv(&R, sh->aabb_c));
-  h->x = fmaf(fabsf(R.m[0][0]), sh->aabb_h.x, fmaf(fabsf(R.m[0][1]), sh->aabb_h.y, fabsf(R.m[0][2]) * sh->aabb_h.z));
-  h->y = fmaf(fabsf(R.m[1][0]), sh->aabb_h.x, fmaf(fabsf(R.m[1][1]), sh->aabb_h.y, fabsf(R.m[1][2]) * sh->aabb_h.z));
-  h->z = fmaf(fabsf(R.m[2][0]), sh->aabb_h.x, fmaf(fabsf(R.m[2][1]), sh->aabb_h.y, fabsf(R.m[2][2]) * sh->aabb_h.z));
+  *c = v3_add(T->p, m33_mulv(&R, lc));
+  h->x = fmaf(fabsf(R.m[0][0]), lh.x, fmaf(fabsf(R.m[0][1]), lh.y, fabsf(R.m[0][2]) * lh.z));
+  h->y = fmaf(fabsf(R.m[1][0]), lh.x, fmaf(fabsf(R.m[1][1]), lh.y, fabsf(R.m[1][2]) * lh.z));
+  h->z = fmaf(fabsf(R.m[2][0]), lh.x, fmaf(fabsf(R.m[2][1]), lh.y, fabsf(R.m[2][2]) * lh.z));
 }
 
 /* ---- manifold ------------------------------------------------------------------------ */

@@ -436,8 +436,15 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
     vfenv[o + 0] = v.x; vfenv[o + 1] = v.y; vfenv[o + 2] = v.z;
     vfenv[o + 3] = w.x; vfenv[o + 4] = w.y; vfenv[o + 5] = w.z;
     float Iinv[6];
-    sym6_rotate(&R, b->Iinv6, Iinv);
-    const float im = 1.0f / b->mass;
+    float mass_i = b->mass;
+    const int xb = m->xb_slot[i];
+    if (xb >= 0) { /* per-env instance: mass and principal inverse inertia from the env record */
+      const float* x = E + m->lay.xbody + xb * 8;
+      const float Ii[6] = {x[1], x[2], x[3], 0.0f, 0.0f, 0.0f};
+      mass_i = x[0];
+      sym6_rotate(&R, Ii, Iinv);
+    } else sym6_rotate(&R, b->Iinv6, Iinv);
+    const float im = 1.0f / mass_i;
     const float Im[3][3] = {{Iinv[0], Iinv[3], Iinv[4]}, {Iinv[3], Iinv[1], Iinv[5]}, {Iinv[4], Iinv[5], Iinv[2]}};
     const v3 ex[3] = {v3_make(1, 0, 0), v3_make(0, 1, 0), v3_make(0, 0, 1)};
     for (int a = 0; a < 3; ++a) {

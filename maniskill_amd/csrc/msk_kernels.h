@@ -23,9 +23,24 @@
 #define MSK_WARM_FACTOR 0.9f
 
 /* ---- collision -------------------------------------------------------------------------- */
+/* half sizes / local position of a shape as this env instantiates it (declared boxes: from the env record) */
+MSK_DEV v3 shape_half_dev(const DModel* m, const float* E, const DShape* sh) {
+  const int xs = m->xs_slot[sh - m->shapes];
+  if (xs < 0) return sh->aabb_h;
+  const float* x = E + m->lay.xshape + xs * 8;
+  return v3_make(x[0], x[1], x[2]);
+}
 MSK_DEV pose shape_pose_dev(const DModel* m, const float* E, const DShape* sh) {
-  if (sh->body < 0) return sh->local;
-  return pose_mul(load_pose(E, m->lay.bpose, sh->body), sh->local);
+  pose L = sh->local;
+  const int xs = m->xs_slot[sh - m->shapes];
+  if (xs >= 0) { const float* x = E + m->lay.xshape + xs * 8; L.p = v3_make(x[4], x[5], x[6]); }
+  if (sh->body < 0) return L;
+  return pose_mul(load_pose(E, m->lay.bpose, sh->body), L);
+}
+MSK_DEV CShape cshape_env(const DModel* m, const float* E, const DShape* sh) {
+  CShape c = cshape_of(sh);
+  if (m->xs_slot[sh - m->shapes] >= 0) { const v3 h = shape_half_dev(m, E, sh); c.par[0] = h.x; c.par[1] = h.y; c.par[2] = h.z; }
+  return c;
 }
 
 /* Collision runs in two kernels.
@@ -48,13 +63,14 @@ __global__ void __launch_bounds__(64) k_broadphase(const DModel* __restrict__ m,
     if (sh->type != MSK_SHAPE_PLANE) {
       const pose T = shape_pose_dev(m, E, sh);
       v3 c, h;
-      world_aabb(sh, &T, &c, &h);
+      const v3 hl = shape_half_dev(m, E, sh);
+      world_aabb(sh->aabb_c, hl, &T, &c, &h);
       aabb[lane][0] = c.x; aabb[lane][1] = c.y; aabb[lane][2] = c.z;
       aabb[lane][3] = h.x; aabb[lane][4] = h.y; aabb[lane][5] = h.z;
       const m33 R = quat_to_m33(T.q);
 #pragma unroll
       for (int j = 0; j < 3; ++j) { obb[lane][j * 3] = R.m[0][j]; obb[lane][j * 3 + 1] = R.m[1][j]; obb[lane][j * 3 + 2] = R.m[2][j]; }
-      obb[lane][9] = sh->aabb_h.x; obb[lane][10] = sh->aabb_h.y; obb[lane][11] = sh->aabb_h.z;
+      obb[lane][9] = hl.x; obb[lane][10] = hl.y; obb[lane][11] = hl.z;
     }
   }
   asm volatile("" ::: "memory");
@@ -197,7 +213,7 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
   const DShape* dA = &m->shapes[m->pairs[pi].sa];
   const DShape* dB = &m->shapes[m->pairs[pi].sb];
   pose TA = shape_pose_dev(m, E, dA), TB = shape_pose_dev(m, E, dB);
-  CShape cA = cshape_of(dA), cB = cshape_of(dB);
+  CShape cA = cshape_env(m, E, dA), cB = cshape_env(m, E, dB);
   if (TYPE == NP_BOXBOX) cA.type = cB.type = MSK_SHAPE_BOX;   /* known: lets the compiler drop the hull paths */
   const CShape* A = &cA;
   const CShape* B = &cB;
@@ -248,8 +264,8 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
         }
       } else {
         v3 ca, ha, cb, hb;
-        world_aabb(dA, &TA, &ca, &ha);
-        world_aabb(dB, &TB, &cb, &hb);
+        world_aabb(dA->aabb_c, shape_half_dev(m, E, dA), &TA, &ca, &ha);
+        world_aabb(dB->aabb_c, shape_half_dev(m, E, dB), &TB, &cb, &hb);
         hit = gjk_epa(cx, A, &TA, B, &TB, ca, cb, margin, &nrm, &sep, &wa, &wb);
       }
 #ifdef MSK_PROFILE_PHASES

@@ -18,7 +18,9 @@
  *   bpose : nb x 8  [px py pz qw qx qy qz pad]   blin, bang, comw : nb x 4 [x y z pad]
  * A wavefront that works on one env (or a lane group on a few) reads its record with wide
  * contiguous loads; the record of PickCube (18 bodies) is 1840 bytes. */
-struct EnvLayout { int q, qd, qacc, qf, qt, qdt, off, bpose, blin, bang, comw, stride; };
+struct EnvLayout { int q, qd, qacc, qf, qt, qdt, off, bpose, blin, bang, comw, xshape, xbody, stride; };
+/*   xshape : nxs x 8 [half sizes, pad, local position, pad]   xbody : nxb x 8 [mass, inverse principal inertia, pad]
+ *   (per-env instances of declared box shapes / dynamic actors: include/msk_physx.h msk_declare_env_box / _mass) */
 
 struct DBody {
   int kind, art, parent, jtype, dof, vofs, nograv, movable;
@@ -69,6 +71,9 @@ struct DModel {
   float dof_lo[MSK_MAX_DOF], dof_hi[MSK_MAX_DOF];
   DPairInfo pinfo[MSK_MAX_PAIRS];
   int cls_cap[MSK_SOLVE_CLASSES - 1];  /* largest block count of solver classes 0, 1, 2 (the last class takes the rest) */
+  /* per-env instances: slot of a declared box shape / dynamic actor in the env record, -1 = the template's values */
+  signed char xs_slot[MSK_MAX_SHAPES], xb_slot[MSK_MAX_BODIES];
+  int nxs, nxb;
 };
 
 #define MSK_MAX_ROWS (2 * MSK_MAX_DOF + 3 * MSK_MAX_CONTACTS)

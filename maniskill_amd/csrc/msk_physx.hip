@@ -48,6 +48,7 @@ struct msk_ctx {
   pose init_pose[MSK_MAX_BODIES];
   pose pending_root;
   int nverts_total;
+  std::vector<float> h_xshape, h_xbody;   /* host mirrors of the per-env instance records [N][nxs | nxb][8] */
   size_t lds_solve = 0;  /* dynamic LDS of the solver launch */
   int solve_workers = 0; /* its one-env-per-wave workgroups */
   RModel* rmodel;            /* host copy of the render geometry (include/msk_render.h) */
@@ -121,6 +122,8 @@ MSK_API msk_ctx* msk_create(int hip_device, const msk_config* cfg) {
   }
   msk_ctx* c = new msk_ctx();
   memset(&c->model, 0, sizeof(c->model));
+  memset(c->model.xs_slot, 0xFF, sizeof(c->model.xs_slot));   /* -1: no per-env instance */
+  memset(c->model.xb_slot, 0xFF, sizeof(c->model.xb_slot));
   memset(&c->st, 0, sizeof(c->st));
   memset(&c->bufs, 0, sizeof(c->bufs));
   c->device = hip_device;
@@ -421,6 +424,8 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
     L.off = o; o += 4;
     L.bpose = o; o += m.nb * 8;
     L.blin = o; o += m.nb * 4; L.bang = o; o += m.nb * 4; L.comw = o; o += m.nb * 4;
+    L.xshape = o; o += m.nxs * 8;
+    L.xbody = o; o += m.nxb * 8;
     L.stride = o;
   }
   const size_t N = (size_t)num_envs;
@@ -431,6 +436,30 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   HIP_TRY(hipMemcpy(c->d_model, &m, sizeof(DModel), hipMemcpyHostToDevice));
   DState& st = c->st;
   ALLOC(st.env, N * (size_t)m.lay.stride);
+  /* per-env instances start at the template's values */
+  c->h_xshape.assign(N * (size_t)m.nxs * 8, 0.0f);
+  c->h_xbody.assign(N * (size_t)m.nxb * 8, 0.0f);
+  for (size_t e = 0; e < N; ++e) {
+    for (int si = 0; si < m.ns; ++si) {
+      if (m.xs_slot[si] < 0) continue;
+      float* x = &c->h_xshape[(e * m.nxs + m.xs_slot[si]) * 8];
+      const DShape& sh = m.shapes[si];
+      x[0] = sh.par[0]; x[1] = sh.par[1]; x[2] = sh.par[2];
+      x[4] = sh.local.p.x; x[5] = sh.local.p.y; x[6] = sh.local.p.z;
+    }
+    for (int bi = 0; bi < m.nb; ++bi) {
+      if (m.xb_slot[bi] < 0) continue;
+      float* x = &c->h_xbody[(e * m.nxb + m.xb_slot[bi]) * 8];
+      const DBody& b = m.bodies[bi];
+      x[0] = b.mass; x[1] = b.Iinv6[0]; x[2] = b.Iinv6[1]; x[3] = b.Iinv6[2];
+    }
+  }
+  if (m.nxs > 0)
+    HIP_TRY(hipMemcpy2D(st.env + m.lay.xshape, sizeof(float) * m.lay.stride, c->h_xshape.data(), sizeof(float) * m.nxs * 8,
+                        sizeof(float) * m.nxs * 8, N, hipMemcpyHostToDevice));
+  if (m.nxb > 0)
+    HIP_TRY(hipMemcpy2D(st.env + m.lay.xbody, sizeof(float) * m.lay.stride, c->h_xbody.data(), sizeof(float) * m.nxb * 8,
+                        sizeof(float) * m.nxb * 8, N, hipMemcpyHostToDevice));
   const size_t G = (size_t)m.G;
   ALLOC(st.Scol, N * G * 8); ALLOC(st.W, N * G * G); ALLOC(st.vfree, N * G);
   ALLOC(st.ct_cnt, N * m.npp); ALLOC(st.ct_rec, N * m.npp * MSK_CT_REC);
@@ -667,6 +696,7 @@ MSK_API int msk_render_add_mesh(msk_ctx* c, int body, const float local_pose[7],
   RShape& sh = r.shapes[r.ns];
   sh.body = body; sh.seg = seg_id; sh.local = pose_from7(local_pose);
   sh.color[0] = sh.color[1] = sh.color[2] = 0.8f; sh.color[3] = 1.0f;   /* until msk_render_set_base_color says otherwise */
+  sh.xs = -1;
   for (int i = 0; i < nverts; ++i) {
     r.verts[r.nv + i].x = verts[3 * i]; r.verts[r.nv + i].y = verts[3 * i + 1]; r.verts[r.nv + i].z = verts[3 * i + 2];
     r.vshape[r.nv + i] = (unsigned char)r.ns;
@@ -685,6 +715,14 @@ MSK_API int msk_render_set_base_color(msk_ctx* c, int render_shape, const float 
   if (!c->rmodel || render_shape < 0 || render_shape >= c->rmodel->ns) return fail(c, MSK_ERR_INVALID, "bad render shape");
   if (c->render_finalized) return fail(c, MSK_ERR_INVALID, "render_set_base_color after render_finalize");
   for (int k = 0; k < 4; ++k) c->rmodel->shapes[render_shape].color[k] = rgba[k];
+  return MSK_OK;
+}
+
+MSK_API int msk_render_bind_env_box(msk_ctx* c, int render_shape, int shape) {
+  if (!c->rmodel || render_shape < 0 || render_shape >= c->rmodel->ns) return fail(c, MSK_ERR_INVALID, "bad render shape");
+  if (c->render_finalized) return fail(c, MSK_ERR_INVALID, "render_bind_env_box after render_finalize");
+  if (shape < 0 || shape >= c->model.ns || c->model.xs_slot[shape] < 0) return fail(c, MSK_ERR_INVALID, "render_bind_env_box: shape was not declared");
+  c->rmodel->shapes[render_shape].xs = c->model.xs_slot[shape];
   return MSK_OK;
 }
 
@@ -779,7 +817,7 @@ MSK_API int msk_camera_take_picture(msk_ctx* c, int camera, void* stream) {
     c->kin_dirty = false;
   }
   const RCamera& cam = c->cams[camera];
-  const size_t lds = (MSK_MAX_RENDER_SHAPES * 8 + 2 * MSK_MAX_TILES + 8 + MSK_MAX_BIG + MSK_MAX_LIGHTS * 3 + (size_t)c->rmodel->nv * 3) * sizeof(float);
+  const size_t lds = (MSK_MAX_RENDER_SHAPES * MSK_RSHAPE_WORDS + 2 * MSK_MAX_TILES + 8 + MSK_MAX_BIG + MSK_MAX_LIGHTS * 3 + (size_t)c->rmodel->nv * 3) * sizeof(float);
   hipLaunchKernelGGL(k_render_setup, dim3(N), dim3(256), lds, s, c->d_model, c->st, c->d_rmodel, cam);
   hipLaunchKernelGGL(k_render_tiles, dim3((cam.tiles_x * cam.tiles_y + MSK_TILES_PER_WAVE - 1) / MSK_TILES_PER_WAVE, N), dim3(64), 0, s, cam);
   HIP_TRY(hipGetLastError());
@@ -919,6 +957,59 @@ MSK_API int msk_debug_phases(msk_ctx* c, long long* out) {
   return MSK_OK;
 }
 #endif
+
+MSK_API int msk_declare_env_box(msk_ctx* c, int shape) {
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "declare_env_box after finalize");
+  DModel& m = c->model;
+  if (shape < 0 || shape >= m.ns || m.shapes[shape].type != MSK_SHAPE_BOX) return fail(c, MSK_ERR_INVALID, "declare_env_box: not a box shape");
+  if (m.xs_slot[shape] < 0) m.xs_slot[shape] = (signed char)m.nxs++;
+  return MSK_OK;
+}
+
+MSK_API int msk_declare_env_mass(msk_ctx* c, int body) {
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "declare_env_mass after finalize");
+  DModel& m = c->model;
+  if (body < 0 || body >= m.nb || m.bodies[body].kind != MSK_BODY_DYNAMIC) return fail(c, MSK_ERR_INVALID, "declare_env_mass: not a dynamic actor");
+  const DBody& b = m.bodies[body];
+  if (b.com.x != 0.0f || b.com.y != 0.0f || b.com.z != 0.0f || b.I6[3] != 0.0f || b.I6[4] != 0.0f || b.I6[5] != 0.0f)
+    return fail(c, MSK_ERR_INVALID, "declare_env_mass: needs the centre of mass at the origin and a diagonal inertia");
+  if (m.xb_slot[body] < 0) m.xb_slot[body] = (signed char)m.nxb++;
+  return MSK_OK;
+}
+
+MSK_API int msk_set_env_boxes(msk_ctx* c, int shape, const float* half_sizes, const float* local_pos) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "set_env_boxes before finalize");
+  const DModel& m = c->model;
+  if (shape < 0 || shape >= m.ns || m.xs_slot[shape] < 0) return fail(c, MSK_ERR_INVALID, "set_env_boxes: shape was not declared");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t N = (size_t)m.N;
+  for (size_t e = 0; e < N; ++e) {
+    float* x = &c->h_xshape[(e * m.nxs + m.xs_slot[shape]) * 8];
+    if (half_sizes) { x[0] = half_sizes[3 * e]; x[1] = half_sizes[3 * e + 1]; x[2] = half_sizes[3 * e + 2]; }
+    if (local_pos) { x[4] = local_pos[3 * e]; x[5] = local_pos[3 * e + 1]; x[6] = local_pos[3 * e + 2]; }
+  }
+  HIP_TRY(hipMemcpy2D(c->st.env + m.lay.xshape, sizeof(float) * m.lay.stride, c->h_xshape.data(), sizeof(float) * m.nxs * 8,
+                      sizeof(float) * m.nxs * 8, N, hipMemcpyHostToDevice));
+  return MSK_OK;
+}
+
+MSK_API int msk_set_env_masses(msk_ctx* c, int body, const float* mass, const float* inertia) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "set_env_masses before finalize");
+  const DModel& m = c->model;
+  if (body < 0 || body >= m.nb || m.xb_slot[body] < 0) return fail(c, MSK_ERR_INVALID, "set_env_masses: body was not declared");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t N = (size_t)m.N;
+  for (size_t e = 0; e < N; ++e) {
+    float* x = &c->h_xbody[(e * m.nxb + m.xb_slot[body]) * 8];
+    x[0] = mass[e];
+    x[1] = 1.0f / inertia[3 * e]; x[2] = 1.0f / inertia[3 * e + 1]; x[3] = 1.0f / inertia[3 * e + 2];
+  }
+  HIP_TRY(hipMemcpy2D(c->st.env + m.lay.xbody, sizeof(float) * m.lay.stride, c->h_xbody.data(), sizeof(float) * m.nxb * 8,
+                      sizeof(float) * m.nxb * 8, N, hipMemcpyHostToDevice));
+  return MSK_OK;
+}
 
 MSK_API int msk_set_solver_classes(msk_ctx* c, const int32_t caps[3]) {
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "set_solver_classes before finalize");

@@ -29,8 +29,9 @@
 #define MSK_SEG_BIG 0x40000000      /* flag in TriSetup::seg: the record is in the env's list of large triangles */
 #define MSK_TILES_PER_WAVE 4        /* consecutive tiles a wavefront walks, prefetching the next one's records */
 #define MSK_SETUP_WORDS 16
+#define MSK_RSHAPE_WORDS 12          /* LDS image of a render shape: camera-from-shape pose (7), pad, per-env scale (3), pad */
 
-struct RShape { int body, seg; pose local; float color[4]; };
+struct RShape { int body, seg; pose local; float color[4]; int xs; /* per-env box instance it follows (slot in the env record), -1: none */ };
 #define MSK_MAX_LIGHTS 4
 struct RTri { int v0, v1, v2, shape; };
 struct RModel {
@@ -159,9 +160,9 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int e = blockIdx.x, tid = threadIdx.x;
   const int ntiles = cam.tiles_x * cam.tiles_y;
-  /* LDS: shape transforms [ns][8] | tile counters [ntiles] | tile fill [ntiles] | nsetup | camera-frame vertices [nv][3] */
+  /* LDS: shape transforms and scales [ns][12] | tile counters [ntiles] | tile fill [ntiles] | nsetup | camera-frame vertices [nv][3] */
   float* Lshape = lds;
-  int* Lcnt = (int*)(lds + MSK_MAX_RENDER_SHAPES * 8);
+  int* Lcnt = (int*)(lds + MSK_MAX_RENDER_SHAPES * MSK_RSHAPE_WORDS);
   int* Lfill = Lcnt + MSK_MAX_TILES + 4;
   int* Lns = Lfill + MSK_MAX_TILES;
   int* Lnbig = Lns + 1;
@@ -181,19 +182,28 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
   }
   for (int s = tid; s < rm->ns; s += 256) {
     const RShape* sh = &rm->shapes[s];
-    pose T = sh->local;
-    if (sh->body >= 0) T = pose_mul(load_pose(E, m->lay.bpose, sh->body), sh->local);
+    pose L = sh->local;
+    v3 scale = v3_make(1.0f, 1.0f, 1.0f);
+    if (sh->xs >= 0) { /* follows a per-env box instance: unit-box vertices times the env's half sizes, the env's local position */
+      const float* x = E + m->lay.xshape + sh->xs * 8;
+      scale = v3_make(x[0], x[1], x[2]);
+      L.p = v3_make(x[4], x[5], x[6]);
+    }
+    pose T = L;
+    if (sh->body >= 0) T = pose_mul(load_pose(E, m->lay.bpose, sh->body), L);
     T = pose_mul(Tci, T);
-    float* o = Lshape + s * 8;
+    float* o = Lshape + s * MSK_RSHAPE_WORDS;
     o[0] = T.p.x; o[1] = T.p.y; o[2] = T.p.z; o[3] = T.q.w; o[4] = T.q.x; o[5] = T.q.y; o[6] = T.q.z;
+    o[8] = scale.x; o[9] = scale.y; o[10] = scale.z;
   }
   __syncthreads();
   for (int vi = tid; vi < rm->nv; vi += 256) {
-    const float* o = Lshape + rm->vshape[vi] * 8;
+    const float* o = Lshape + rm->vshape[vi] * MSK_RSHAPE_WORDS;
     pose T;
     T.p = v3_make(o[0], o[1], o[2]);
     T.q = quat_make(o[3], o[4], o[5], o[6]);
-    const v3 p = pose_apply(T, rm->verts[vi]);
+    const v3 vl = rm->verts[vi];
+    const v3 p = pose_apply(T, v3_make(vl.x * o[8], vl.y * o[9], vl.z * o[10]));
     Lv[vi * 3 + 0] = p.x; Lv[vi * 3 + 1] = p.y; Lv[vi * 3 + 2] = p.z;
   }
   __syncthreads();

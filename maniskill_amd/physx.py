@@ -153,6 +153,14 @@ class SceneTemplate:
     def disable_collision(self, body_a, body_b):
         self.ops.append(("disable_collision", (body_a, body_b)))
 
+    def declare_env_box(self, shape):
+        """The box `shape` (index returned by add_shape) takes half sizes / local position from each env's own record
+        (include/msk_physx.h: per-env instances; the reference builds one actor per sub-scene and merges them)."""
+        self.ops.append(("declare_env_box", (int(shape),)))
+
+    def declare_env_mass(self, body):
+        self.ops.append(("declare_env_mass", (int(body),)))
+
     def set_body_color(self, body, rgba):
         """RenderMaterial(base_color=rgba) of every visual of `body` (-1: the static scene); consumed by
         render.attach_template_visuals for the Color texture."""
@@ -260,6 +268,10 @@ class PhysxGpuSystem:
                 L.check(ctx, L.disable_collision(ctx, *a), op)
             elif op == "add_visual":
                 pass  # render.attach_template_visuals
+            elif op == "declare_env_box":
+                L.check(ctx, L.declare_env_box(ctx, a[0]), op)
+            elif op == "declare_env_mass":
+                L.check(ctx, L.declare_env_mass(ctx, a[0]), op)
             else:  # pragma: no cover
                 raise AssertionError(op)
 
@@ -398,6 +410,20 @@ class PhysxGpuSystem:
         n = min(n, max_points)
         return (np.array(ids[: 3 * n], dtype=np.int32).reshape(n, 3),
                 np.array(vals[: 8 * n], dtype=np.float32).reshape(n, 8))
+
+    def set_env_boxes(self, shape, half_sizes, local_pos=None):
+        """(num_envs, 3) half sizes and optionally (num_envs, 3) local positions of a declared box shape."""
+        hs = np.ascontiguousarray(half_sizes, dtype=np.float32).reshape(self.num_envs, 3)
+        lp = None if local_pos is None else np.ascontiguousarray(local_pos, dtype=np.float32).reshape(self.num_envs, 3)
+        fp = C.POINTER(C.c_float)
+        self.lib.check(self.ctx, self.lib.set_env_boxes(self.ctx, int(shape), hs.ctypes.data_as(fp), None if lp is None else lp.ctypes.data_as(fp)),
+                       "set_env_boxes")
+
+    def set_env_masses(self, body, mass, principal_inertia):
+        m = np.ascontiguousarray(mass, dtype=np.float32).reshape(self.num_envs)
+        I = np.ascontiguousarray(principal_inertia, dtype=np.float32).reshape(self.num_envs, 3)
+        fp = C.POINTER(C.c_float)
+        self.lib.check(self.ctx, self.lib.set_env_masses(self.ctx, int(body), m.ctypes.data_as(fp), I.ctypes.data_as(fp)), "set_env_masses")
 
     def set_solver_classes(self, caps):
         """Scheduling only (include/msk_physx.h): largest block counts of solver classes 0..2; negative empties a class."""

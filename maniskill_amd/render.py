@@ -278,14 +278,19 @@ def attach_template_visuals(px, template, hidden_bodies=()):
     L = px.lib
     nb = px.bodies_per_env
     n = 0
+    declared = {a[0] for op, a in template.ops if op == "declare_env_box"}   # per-env box instances: drawn at the env's own size
+    si = -1
     for op, a in template.ops:
         if op not in ("add_shape", "add_visual"):
             continue
+        if op == "add_shape":
+            si += 1
         body, stype, pose7, params, verts = a[0], a[1], a[2], a[3], a[4]
         if body in hidden_bodies:
             continue
+        follows = op == "add_shape" and si in declared
         if stype == N.SHAPE_BOX:
-            v, t = box_mesh(params)
+            v, t = box_mesh((1.0, 1.0, 1.0) if follows else params)
         elif stype == N.SHAPE_PLANE:
             v, t = plane_mesh()
         elif stype == N.SHAPE_CONVEX:
@@ -297,6 +302,8 @@ def attach_template_visuals(px, template, hidden_bodies=()):
         t = np.ascontiguousarray(t, dtype=np.int32)
         rs = L.check(px.ctx, L.render_add_mesh(px.ctx, int(body), N._fa(pose7, 7), v.ctypes.data_as(C.POINTER(C.c_float)), len(v),
                                                t.ctypes.data_as(C.POINTER(C.c_int32)), len(t), int(seg)), "render_add_mesh")
+        if follows:
+            L.check(px.ctx, L.render_bind_env_box(px.ctx, rs, si), "render_bind_env_box")
         rgba = getattr(template, "body_colors", {}).get(int(body))
         if rgba is not None:
             L.check(px.ctx, L.render_set_base_color(px.ctx, rs, N._fa(rgba, 4)), "render_set_base_color")

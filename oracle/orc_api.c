@@ -26,6 +26,8 @@ ORC_EXPORT orc_ctx* orc_create(int device, const msk_config* cfg) {
   (void)device;
   orc_ctx* c = (orc_ctx*)calloc(1, sizeof(orc_ctx));
   c->cfg = *cfg;
+  for (int i = 0; i < MSK_MAX_SHAPES; ++i) c->xs_slot[i] = -1;
+  for (int i = 0; i < MSK_MAX_BODIES; ++i) c->xb_slot[i] = -1;
   return c;
 }
 
@@ -33,6 +35,8 @@ ORC_EXPORT void orc_destroy(orc_ctx* c) {
   if (!c) return;
   free(c->envs);
   free(c->offsets);
+  free(c->xshape);
+  free(c->xbody);
   for (int i = 0; i < MSK_BUF_COUNT; ++i) free(c->buf[i]);
   for (int i = 0; i < c->nqueries; ++i) { free(c->queries[i].pairs); free(c->queries[i].out); }
   free(c);
@@ -238,6 +242,24 @@ ORC_EXPORT int orc_finalize(orc_ctx* c, int num_envs) {
   c->num_envs = num_envs;
   c->envs = (orc_env*)calloc((size_t)num_envs, sizeof(orc_env));
   c->offsets = (float*)calloc((size_t)num_envs * 3, sizeof(float));
+  /* per-env instance parameters start at the template's values */
+  if (c->nxs > 0) c->xshape = (float*)calloc((size_t)num_envs * c->nxs * 8, sizeof(float));
+  if (c->nxb > 0) c->xbody = (float*)calloc((size_t)num_envs * c->nxb * 8, sizeof(float));
+  for (int e = 0; e < num_envs; ++e) {
+    for (int si = 0; si < c->ns; ++si) {
+      if (c->xs_slot[si] < 0) continue;
+      float* x = c->xshape + ((size_t)e * c->nxs + c->xs_slot[si]) * 8;
+      const orc_shape* sh = &c->shapes[si];
+      x[0] = sh->par[0]; x[1] = sh->par[1]; x[2] = sh->par[2];
+      x[4] = sh->local.p.x; x[5] = sh->local.p.y; x[6] = sh->local.p.z;
+    }
+    for (int bi = 0; bi < c->nb; ++bi) {
+      if (c->xb_slot[bi] < 0) continue;
+      float* x = c->xbody + ((size_t)e * c->nxb + c->xb_slot[bi]) * 8;
+      const orc_body* b = &c->bodies[bi];
+      x[0] = b->mass; x[1] = b->Iinv6[0]; x[2] = b->Iinv6[1]; x[3] = b->Iinv6[2];
+    }
+  }
   for (int e = 0; e < num_envs; ++e) env_reset(c, &c->envs[e]);
   size_t nrb = (size_t)num_envs * c->nb * 13;
   size_t nart = (size_t)num_envs * (c->na > 0 ? c->na : 1) * (c->max_dof > 0 ? c->max_dof : 1);
@@ -434,6 +456,46 @@ ORC_EXPORT int orc_timing_enable(orc_ctx* c, int max_steps) { (void)c; (void)max
 ORC_EXPORT int orc_timing_read(orc_ctx* c, int slot, double* total_ms, int32_t* launches) {
   (void)c; (void)slot;
   *total_ms = 0.0; *launches = 0;
+  return MSK_OK;
+}
+
+/* msk_declare_env_box / msk_declare_env_mass / msk_set_env_boxes / msk_set_env_masses: per-env instance parameters */
+ORC_EXPORT int orc_declare_env_box(orc_ctx* c, int shape) {
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "declare_env_box after finalize");
+  if (shape < 0 || shape >= c->ns || c->shapes[shape].type != MSK_SHAPE_BOX) return fail(c, MSK_ERR_INVALID, "declare_env_box: not a box shape");
+  if (c->xs_slot[shape] < 0) c->xs_slot[shape] = c->nxs++;
+  return MSK_OK;
+}
+
+ORC_EXPORT int orc_declare_env_mass(orc_ctx* c, int body) {
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "declare_env_mass after finalize");
+  if (body < 0 || body >= c->nb || c->bodies[body].kind != MSK_BODY_DYNAMIC) return fail(c, MSK_ERR_INVALID, "declare_env_mass: not a dynamic actor");
+  const orc_body* b = &c->bodies[body];
+  if (b->com.x != 0.0f || b->com.y != 0.0f || b->com.z != 0.0f || b->I6[3] != 0.0f || b->I6[4] != 0.0f || b->I6[5] != 0.0f)
+    return fail(c, MSK_ERR_INVALID, "declare_env_mass: needs the centre of mass at the origin and a diagonal inertia");
+  if (c->xb_slot[body] < 0) c->xb_slot[body] = c->nxb++;
+  return MSK_OK;
+}
+
+ORC_EXPORT int orc_set_env_boxes(orc_ctx* c, int shape, const float* half_sizes, const float* local_pos) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "set_env_boxes before finalize");
+  if (shape < 0 || shape >= c->ns || c->xs_slot[shape] < 0) return fail(c, MSK_ERR_INVALID, "set_env_boxes: shape was not declared");
+  for (int e = 0; e < c->num_envs; ++e) {
+    float* x = c->xshape + ((size_t)e * c->nxs + c->xs_slot[shape]) * 8;
+    if (half_sizes) { x[0] = half_sizes[3 * e]; x[1] = half_sizes[3 * e + 1]; x[2] = half_sizes[3 * e + 2]; }
+    if (local_pos) { x[4] = local_pos[3 * e]; x[5] = local_pos[3 * e + 1]; x[6] = local_pos[3 * e + 2]; }
+  }
+  return MSK_OK;
+}
+
+ORC_EXPORT int orc_set_env_masses(orc_ctx* c, int body, const float* mass, const float* inertia) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "set_env_masses before finalize");
+  if (body < 0 || body >= c->nb || c->xb_slot[body] < 0) return fail(c, MSK_ERR_INVALID, "set_env_masses: body was not declared");
+  for (int e = 0; e < c->num_envs; ++e) {
+    float* x = c->xbody + ((size_t)e * c->nxb + c->xb_slot[body]) * 8;
+    x[0] = mass[e];
+    x[1] = 1.0f / inertia[3 * e]; x[2] = 1.0f / inertia[3 * e + 1]; x[3] = 1.0f / inertia[3 * e + 2];
+  }
   return MSK_OK;
 }
 

@@ -654,9 +654,23 @@ static int plane_convex(const orc_shape* P, const pose* TP, const orc_shape* C, 
 }
 
 /* ---- pair dispatch --------------------------------------------------------------------- */
+/* the shape as this env instantiates it: declared boxes take their half sizes and local position from the env's record */
+static void effective_shape(const orc_ctx* c, const orc_env* e, int si, orc_shape* out) {
+  *out = c->shapes[si];
+  const int xs = c->xs_slot[si];
+  if (xs < 0) return;
+  const float* x = c->xshape + ((size_t)(e - c->envs) * c->nxs + xs) * 8;
+  out->par[0] = x[0]; out->par[1] = x[1]; out->par[2] = x[2];
+  out->aabb_h = v3_make(x[0], x[1], x[2]);
+  out->local.p = v3_make(x[4], x[5], x[6]);
+}
+
 int orc_collide_pair(const orc_ctx* c, const orc_env* e, int pi, orc_contact* out) {
-  const orc_shape* A = &c->shapes[c->pairs[pi].sa];
-  const orc_shape* B = &c->shapes[c->pairs[pi].sb];
+  orc_shape effA, effB;
+  effective_shape(c, e, c->pairs[pi].sa, &effA);
+  effective_shape(c, e, c->pairs[pi].sb, &effB);
+  const orc_shape* A = &effA;
+  const orc_shape* B = &effB;
   pose TA = shape_pose(c, e, A), TB = shape_pose(c, e, B);
   const float margin = 2.0f * c->cfg.contact_offset;
   int n = 0;

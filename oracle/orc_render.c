@@ -20,7 +20,7 @@
 
 #define ORC_EXPORT __attribute__((visibility("default")))
 
-typedef struct { int body, seg; pose local; float color[4]; } r_shape;
+typedef struct { int body, seg; pose local; float color[4]; int xs; } r_shape;
 #define ORC_MAX_LIGHTS 4
 typedef struct { int v0, v1, v2, shape; } r_tri;
 typedef struct {
@@ -82,6 +82,7 @@ ORC_EXPORT int orc_render_add_mesh(orc_ctx* c, int body, const float local_pose[
   r->shapes[r->ns].local = r_pose7(local_pose);
   r->shapes[r->ns].color[0] = r->shapes[r->ns].color[1] = r->shapes[r->ns].color[2] = 0.8f;
   r->shapes[r->ns].color[3] = 1.0f;
+  r->shapes[r->ns].xs = -1;
   for (int i = 0; i < nverts; ++i) {
     r->verts[r->nv + i] = v3_make(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
     r->vshape[r->nv + i] = (unsigned char)r->ns;
@@ -99,6 +100,15 @@ ORC_EXPORT int orc_render_set_base_color(orc_ctx* c, int render_shape, const flo
   if (!r || render_shape < 0 || render_shape >= r->ns) return rfail(c, MSK_ERR_INVALID, "bad render shape");
   if (r->finalized) return rfail(c, MSK_ERR_INVALID, "render_set_base_color after render_finalize");
   for (int k = 0; k < 4; ++k) r->shapes[render_shape].color[k] = rgba[k];
+  return MSK_OK;
+}
+
+ORC_EXPORT int orc_render_bind_env_box(orc_ctx* c, int render_shape, int shape) {
+  r_model* r = (r_model*)c->render;
+  if (!r || render_shape < 0 || render_shape >= r->ns) return rfail(c, MSK_ERR_INVALID, "bad render shape");
+  if (r->finalized) return rfail(c, MSK_ERR_INVALID, "render_bind_env_box after render_finalize");
+  if (shape < 0 || shape >= c->ns || c->xs_slot[shape] < 0) return rfail(c, MSK_ERR_INVALID, "render_bind_env_box: shape was not declared");
+  r->shapes[render_shape].xs = c->xs_slot[shape];
   return MSK_OK;
 }
 
@@ -246,12 +256,23 @@ ORC_EXPORT int orc_camera_take_picture(orc_ctx* c, int camera, void* stream) {
     if (cam->mount >= 0) Tc = pose_mul(env->bpose[cam->mount], cam->local);
     const pose Tci = pose_inv(Tc);
     pose shapeT[MSK_MAX_RENDER_SHAPES];
+    v3 shapeS[MSK_MAX_RENDER_SHAPES];
     for (int s = 0; s < r->ns; ++s) {
-      pose T = r->shapes[s].local;
-      if (r->shapes[s].body >= 0) T = pose_mul(env->bpose[r->shapes[s].body], r->shapes[s].local);
+      pose L = r->shapes[s].local;
+      shapeS[s] = v3_make(1.0f, 1.0f, 1.0f);
+      if (r->shapes[s].xs >= 0) { /* follows a per-env box instance */
+        const float* x = c->xshape + ((size_t)e * c->nxs + r->shapes[s].xs) * 8;
+        shapeS[s] = v3_make(x[0], x[1], x[2]);
+        L.p = v3_make(x[4], x[5], x[6]);
+      }
+      pose T = L;
+      if (r->shapes[s].body >= 0) T = pose_mul(env->bpose[r->shapes[s].body], L);
       shapeT[s] = pose_mul(Tci, T);
     }
-    for (int i = 0; i < r->nv; ++i) cv[i] = pose_apply(shapeT[r->vshape[i]], r->verts[i]);
+    for (int i = 0; i < r->nv; ++i) {
+      const v3 sc = shapeS[r->vshape[i]], vl = r->verts[i];
+      cv[i] = pose_apply(shapeT[r->vshape[i]], v3_make(vl.x * sc.x, vl.y * sc.y, vl.z * sc.z));
+    }
     float light_cam[ORC_MAX_LIGHTS * 3];
     for (int l = 0; l < r->nlights; ++l) {
       const v3 d = quat_rotate(Tci.q, v3_make(r->ldir[l][0], r->ldir[l][1], r->ldir[l][2]));

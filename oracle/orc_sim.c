@@ -101,7 +101,11 @@ static void kinematics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
       e->bang[i] = s->V[i].a;
       e->blin[i] = v3_add(s->V[i].l, v3_cross(s->V[i].a, s->comw[i]));
     } else if (b->kind == MSK_BODY_DYNAMIC) {
-      sym6_rotate(&R, b->Iinv6, s->Iwinv[i]);
+      if (c->xb_slot[i] >= 0) { /* per-env instance: principal inverse inertia from the env's record */
+        const float* x = c->xbody + ((size_t)(e - c->envs) * c->nxb + c->xb_slot[i]) * 8;
+        const float Ii[6] = {x[1], x[2], x[3], 0.0f, 0.0f, 0.0f};
+        sym6_rotate(&R, Ii, s->Iwinv[i]);
+      } else sym6_rotate(&R, b->Iinv6, s->Iwinv[i]);
     } else {
       e->blin[i] = v3_make(0, 0, 0);
       e->bang[i] = v3_make(0, 0, 0);
@@ -315,7 +319,7 @@ static float dot_seq(const float* a, const float* b, int nv, int npad) {
 }
 
 /* per-coordinate tables: Scol, W, moves */
-static void coordinate_tables(const orc_ctx* c, orc_scratch* s) {
+static void coordinate_tables(const orc_ctx* c, const orc_env* e, orc_scratch* s) {
   const int nd = c->ndof, nv = c->nv;
   s->npad = (nv <= 16) ? 16 : 32;
   for (int k = 0; k < nv; ++k) {
@@ -331,7 +335,8 @@ static void coordinate_tables(const orc_ctx* c, orc_scratch* s) {
         if (c->bodies[j].dof >= 0) s->moves[c->bodies[j].dof] |= (uint64_t)1 << i;
     } else if (b->kind == MSK_BODY_DYNAMIC) {
       const v3 ex[3] = {v3_make(1, 0, 0), v3_make(0, 1, 0), v3_make(0, 0, 1)};
-      const float im = 1.0f / b->mass;
+      const float mass_i = (c->xb_slot[i] >= 0) ? c->xbody[((size_t)(e - c->envs) * c->nxb + c->xb_slot[i]) * 8] : b->mass;
+      const float im = 1.0f / mass_i;
       const float* Ii = s->Iwinv[i];
       const float Im[3][3] = {{Ii[0], Ii[3], Ii[4]}, {Ii[3], Ii[1], Ii[5]}, {Ii[4], Ii[5], Ii[2]}};
       for (int a = 0; a < 3; ++a) {
@@ -378,7 +383,7 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
   kinematics(c, e, &s);
   dynamics(c, e, &s);
   collide(c, e);
-  coordinate_tables(c, &s);
+  coordinate_tables(c, e, &s);
 
   static _Thread_local float A[2 * MSK_MAX_DOF + 3 * MSK_MAX_CONTACTS][2 * MSK_MAX_DOF + 3 * MSK_MAX_CONTACTS];
   int nr = 0;

@@ -103,6 +103,11 @@ typedef struct orc_ctx {
   float* buf[MSK_BUF_COUNT];
   int nqueries;
   struct { int npairs; int32_t* pairs; float* out; } queries[16];
+  /* per-env instance parameters (msk_declare_env_box / msk_declare_env_mass): slot per declared shape / body, -1 = template value */
+  int xs_slot[MSK_MAX_SHAPES], nxs;
+  int xb_slot[MSK_MAX_BODIES], nxb;
+  float* xshape;     /* [num_envs][nxs][8]: half sizes (3), pad, local position (3), pad */
+  float* xbody;      /* [num_envs][nxb][8]: mass, inverse principal inertia (3), pad */
   void* render;      /* orc_render.c: render geometry and cameras */
   char err[256];
 } orc_ctx;

@@ -293,3 +293,54 @@ def test_body_impulse_query_matches_oracle(oracle_factory):
     g, c = qg.cuda_impulses.torch().cpu().numpy(), qc.cuda_impulses.torch().numpy()
     assert g.shape == (n * 4, 3) and np.abs(c).max() > 1e-4
     assert np.allclose(g, c, rtol=1e-4, atol=1e-6)
+
+
+def test_per_env_box_instances_match_oracle(oracle_factory):
+    """msk_declare_env_box / msk_set_env_boxes / msk_set_env_masses: every env drops a cube of its own size and mass next to
+    a declared static block with its own size and offset; HIP state and picture against the oracle's."""
+    from maniskill_amd.physx import SimConfig
+    from maniskill_amd.render import CameraConfig, RenderCameraGroup, attach_template_visuals, look_at
+    from maniskill_amd import _native as NN
+
+    n = 64
+    rng = np.random.default_rng(5)
+    half = rng.uniform(0.01, 0.04, size=(n, 3)).astype(np.float32)
+    mass = (8 * half.prod(1) * 1000.0).astype(np.float32)
+    inertia = np.stack([mass / 3 * (half[:, 1] ** 2 + half[:, 2] ** 2), mass / 3 * (half[:, 0] ** 2 + half[:, 2] ** 2),
+                        mass / 3 * (half[:, 0] ** 2 + half[:, 1] ** 2)], axis=1).astype(np.float32)
+    bhalf = rng.uniform(0.02, 0.05, size=(n, 3)).astype(np.float32)
+    bpos = np.concatenate([rng.uniform(-0.02, 0.02, size=(n, 2)), bhalf[:, 2:3]], axis=1).astype(np.float32)
+    results = []
+    for dev, fac in ((DEV, None), (None, oracle_factory)):
+        tpl = SceneTemplate()
+        table = sb.add_table_scene(tpl)
+        cube = sb.add_cube(tpl, "cube", 0.02, (0, 0, 0.1))
+        cube_shape = tpl.nshapes - 1
+        block = tpl.add_actor("block", NN.BODY_KINEMATIC, p=(0, 0, 0))
+        block_shape = tpl.add_shape(block, NN.SHAPE_BOX, params=(0.03, 0.03, 0.03))
+        tpl.declare_env_box(cube_shape); tpl.declare_env_box(block_shape); tpl.declare_env_mass(cube)
+        px = PhysxGpuSystem(torch.device(dev), tpl, n, SimConfig()) if fac is None else fac(tpl, n, SimConfig())
+        px.gpu_init()
+        px.set_scene_offsets(np.zeros((n, 3)))
+        px.set_env_boxes(cube_shape, half); px.set_env_masses(cube, mass, inertia)
+        px.set_env_boxes(block_shape, bhalf, bpos)
+        attach_template_visuals(px, tpl)
+        p, q = look_at(eye=[0.35, 0.1, 0.4], target=[0, 0, 0.02])
+        cam = RenderCameraGroup(px, CameraConfig("cam", p, q, 128, 128, np.pi / 2, 0.01, 100.0))
+        cam.enable_color()
+        rbd = px.cuda_rigid_body_data.torch().view(n, px.bodies_per_env, 13)
+        rbd[:, cube, :3] = torch.tensor([0.01, 0.0, 0.16], device=rbd.device)      # lands on the block, topples off or stays
+        rbd[:, cube, 3:7] = torch.tensor([0.9990482, 0.0308436, 0.0308436, 0.0], device=rbd.device)
+        rbd[:, table, :7] = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)], device=rbd.device)
+        rbd[:, block, 3] = 1.0
+        px.gpu_apply_all()
+        for _ in range(120):
+            px.step()
+        px.gpu_fetch_all()
+        cam.take_picture()
+        results.append((rbd.cpu().clone(), cam.get_picture_cuda().torch().cpu().clone(), cam.get_picture_cuda("Color").torch().cpu().clone()))
+    (rg, pg, cg), (rc, pc, cc) = results
+    assert _close(rg.numpy(), rc.numpy())
+    assert torch.equal(pg, pc) and torch.equal(cg, cc)
+    z = rc[:, 1, 2]
+    assert (z > 0.005).all() and z.std() > 0.01           # different sizes, different resting heights

@@ -270,3 +270,41 @@ def test_body_impulse_query_is_the_weight_of_the_resting_cube(oracle_factory):
     mgdt = 0.064 * 9.81 * env.px.timestep
     assert torch.allclose(b[:, 0, 2], torch.full((2,), mgdt), rtol=2e-2) and b[:, 0, :2].abs().max() < 1e-4
     assert torch.allclose(b[:, 1], -b[:, 0], atol=1e-6) and torch.allclose(b[:, 0], p[:, 0], atol=1e-7)
+
+
+def test_per_env_box_sizes_and_masses(oracle_factory):
+    """msk_declare_env_box / msk_set_env_boxes / msk_set_env_masses: every env instantiates the template's cube with its own
+    half size and mass; each settles at its own height and presses on the table with its own weight."""
+    from maniskill_amd.physx import SimConfig
+
+    tpl = SceneTemplate()
+    table = sb.add_table_scene(tpl)
+    cube = sb.add_cube(tpl, "cube", 0.02, (0, 0, 0.1))
+    cube_shape = tpl.nshapes - 1
+    tpl.declare_env_box(cube_shape)
+    tpl.declare_env_mass(cube)
+    n = 4
+    px = oracle_factory(tpl, n, SimConfig())
+    px.gpu_init()
+    px.set_scene_offsets(np.zeros((n, 3)))
+    half = np.array([[0.02] * 3, [0.03] * 3, [0.05, 0.02, 0.01], [0.01] * 3], dtype=np.float32)
+    mass = (8 * half.prod(1) * 1000.0).astype(np.float32)
+    inertia = np.stack([mass / 3 * (half[:, 1] ** 2 + half[:, 2] ** 2), mass / 3 * (half[:, 0] ** 2 + half[:, 2] ** 2),
+                        mass / 3 * (half[:, 0] ** 2 + half[:, 1] ** 2)], axis=1)
+    px.set_env_boxes(cube_shape, half)
+    px.set_env_masses(cube, mass, inertia)
+    rbd = px.cuda_rigid_body_data.torch().view(n, px.bodies_per_env, 13)
+    rbd[:, cube, :3] = torch.tensor([0.0, 0.0, 0.08])
+    rbd[:, cube, 3:7] = torch.tensor([1.0, 0, 0, 0])
+    rbd[:, table, :7] = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)])
+    px.gpu_apply_all()
+    q = px.gpu_create_contact_body_impulse_query([cube])
+    for _ in range(150):
+        px.step()
+    px.gpu_fetch_all()
+    px.gpu_query_contact_body_impulses(q)
+    z = rbd[:, cube, 2]
+    assert torch.allclose(z, torch.tensor(half[:, 2]), atol=1.5e-3)                      # rests on its own half height
+    imp = q.cuda_impulses.torch().view(n, 3)[:, 2]
+    assert torch.allclose(imp, torch.tensor(mass) * 9.81 * px.timestep, rtol=3e-2)       # and weighs its own weight
+    assert (rbd[:, cube, 7:13].abs() < 2e-2).all()
