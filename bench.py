@@ -70,8 +70,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--envs", type=int, default=4096, help="total env count over all ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--env", default="PickCube-v1", choices=["PickCube-v1", "PushT-v1"],
-                    help="PickCube-v1 (BASELINE.json's metric, default) or PushT-v1 (its camera config)")
+    ap.add_argument("--env", default="PickCube-v1", choices=["PickCube-v1", "PushT-v1", "PegInsertionSide-v1"],
+                    help="PickCube-v1 (BASELINE.json's metric, default), PushT-v1 (its camera config) or "
+                         "PegInsertionSide-v1 (its contact-rich config)")
     ap.add_argument("--obs-mode", default="state", choices=["state", "depth+segmentation", "rgb", "rgbd", "rgb+depth+segmentation"],
                     help="state (BASELINE.json's metric, default) or the camera path: 128x128 textures per env")
     ap.add_argument("--control-freq", type=int, default=20,

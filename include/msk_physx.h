@@ -36,7 +36,9 @@ enum msk_status {
   MSK_ERR_INVALID = -1,   /* bad argument / wrong phase (e.g. add_* after finalize)   */
   MSK_ERR_CAPACITY = -2,  /* template exceeds a compile-time capacity (MSK_MAX_*)     */
   MSK_ERR_HIP = -3,       /* a HIP runtime call failed                                */
-  MSK_ERR_OVERFLOW = -4   /* per-env contact capacity exceeded during step()          */
+  MSK_ERR_OVERFLOW = -4   /* reserved: step() never fails on contact overflow, it drops
+                           * the contacts past the per-env capacity in (pair, point)
+                           * order and raises the sticky flag msk_get_sizes()[7]       */
 };
 
 enum msk_joint_type { MSK_JOINT_FIXED = 0, MSK_JOINT_REVOLUTE = 1, MSK_JOINT_PRISMATIC = 2 };
@@ -191,7 +193,8 @@ int msk_query_run(msk_ctx* ctx, int query, void* stream);
 
 /* ---- inspection (parity tests; synchronous, host output) --------------------------- */
 /* Template sizes: out[0]=NB bodies, out[1]=NA articulations, out[2]=max_dof, out[3]=nv,
- * out[4]=number of shapes, out[5]=number of candidate pairs, out[6]=num_envs. */
+ * out[4]=number of shapes, out[5]=number of candidate pairs, out[6]=num_envs,
+ * out[7]=1 once any env has exceeded its contact capacity since init (sticky). */
 int msk_get_sizes(msk_ctx* ctx, int32_t out[8]);
 /* Contacts generated by the last step() in env `env`: for each contact point
  * ids[3*i..] = {shape_a, shape_b, body-pair slot}, vals[8*i..] = {pos(3), normal(3), separation,

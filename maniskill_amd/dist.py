@@ -65,11 +65,13 @@ class ObservationGather:
 
 
 def make_sharded_env(env_id: str, total_envs: int, device_type: str = "cuda", px_factory=None, **kw):
-    """One env shard per process (env_id: "PickCube-v1" or "PushT-v1").  Returns (env, gather, rank, world)."""
+    """One env shard per process (env_id: "PickCube-v1", "PushT-v1" or "PegInsertionSide-v1").
+    Returns (env, gather, rank, world)."""
+    from .envs.peg_insertion_side import PegInsertionSideEnv
     from .envs.pick_cube import PickCubeEnv
     from .envs.push_t import PushTEnv
 
-    cls = {"PickCube-v1": PickCubeEnv, "PushT-v1": PushTEnv}[env_id]
+    cls = {"PickCube-v1": PickCubeEnv, "PushT-v1": PushTEnv, "PegInsertionSide-v1": PegInsertionSideEnv}[env_id]
     rank, world, local = init_distributed(device_type)
     start, count = shard_range(total_envs, rank, world)
     assert total_envs % world == 0, "num_envs must divide evenly over the ranks"

@@ -89,6 +89,8 @@ class PickCubeEnv:
 
     max_episode_steps = 50
     max_reward = 5.0
+    camera_eye, camera_target = (0.3, 0.0, 0.6), (-0.1, 0.0, 0.1)   # base_camera (pick_cube.py:64-71)
+    rest_qpos = sb.PANDA_REST_QPOS       # TableSceneBuilder.initialize keyframe (scene_builder/table/scene_builder.py:67-103)
     goal_thresh = 0.025
     cube_half_size = 0.02
     cube_spawn_half_size = 0.1
@@ -130,6 +132,7 @@ class PickCubeEnv:
             self.px = px_factory(tpl, self.num_envs, self.sim_config)
         self.device = self.px.device
         self.px.gpu_init()
+        self._after_gpu_init()
         # sub-scene grid offsets (sapien_env.py:1191-1202)
         # a shard of a larger job (dist.py) keeps the GLOBAL grid cell of each env, so that the
         # published fp32 rows (env-frame pose + offset) do not depend on the partitioning
@@ -193,7 +196,7 @@ class PickCubeEnv:
         if obs_mode != "state":
             from ..render import CameraConfig, RenderCameraGroup, attach_template_visuals, look_at
             attach_template_visuals(self.px, tpl, hidden_bodies=self._hidden_bodies())
-            p, q = look_at(eye=[0.3, 0, 0.6], target=[-0.1, 0, 0.1])
+            p, q = look_at(eye=self.camera_eye, target=self.camera_target)
             self.camera = RenderCameraGroup(self.px, CameraConfig("base_camera", p, q, 128, 128, np.pi / 2, 0.01, 100.0))
             if self._want_color:
                 self.camera.enable_color()
@@ -270,7 +273,7 @@ class PickCubeEnv:
             table = self._table_pose.repeat(b, 1)
             table[:, :3] += off
             self._rbd[env_idx, self._b_table, :7] = table
-            qpos = self._rng.normal(idx_np, 9) * self.robot_init_qpos_noise + sb.PANDA_REST_QPOS
+            qpos = self._rng.normal(idx_np, 9) * self.robot_init_qpos_noise + self.rest_qpos
             qpos[:, -2:] = 0.04
             self._qpos[env_idx, :9] = f32(qpos)
             root = self._root_pose.repeat(b, 1)
@@ -338,6 +341,9 @@ class PickCubeEnv:
 
     def _hidden_bodies(self):
         return (self._b_goal,)   # goal_site is in _hidden_objects (pick_cube.py:104)
+
+    def _after_gpu_init(self):
+        """Hook: per-env instance parameters (tasks that build a different actor per sub-scene)."""
 
     # ---- end-effector control (agents/controllers/pd_ee_pose.py:24-262, utils/kinematics.py:185-259) ---------------------
     ee_pos_bound = 0.1      # pos_lower / pos_upper of arm_pd_ee_delta_pos(e) (panda.py:103-124)

@@ -20,10 +20,12 @@ ENVS = {}
 def _registry():
     if not ENVS:
         from .envs.pick_cube import PickCubeEnv
+        from .envs.peg_insertion_side import PegInsertionSideEnv
         from .envs.push_cube import PushCubeEnv
         from .envs.push_t import PushTEnv
         from .envs.stack_cube import StackCubeEnv
-        ENVS.update({"PickCube-v1": PickCubeEnv, "PushCube-v1": PushCubeEnv, "StackCube-v1": StackCubeEnv, "PushT-v1": PushTEnv})
+        ENVS.update({"PickCube-v1": PickCubeEnv, "PushCube-v1": PushCubeEnv, "StackCube-v1": StackCubeEnv, "PushT-v1": PushTEnv,
+                     "PegInsertionSide-v1": PegInsertionSideEnv})
     return ENVS
 
 

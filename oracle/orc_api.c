@@ -377,7 +377,9 @@ ORC_EXPORT int orc_step(orc_ctx* c, void* stream) {
     orc_step_env(c, &c->envs[e]);
     overflow |= c->envs[e].overflow;
   }
-  if (overflow) return fail(c, MSK_ERR_OVERFLOW, "per-env contact capacity exceeded");
+  /* like the HIP library: contacts past the per-env capacity are dropped in (pair, point) order and the step goes on;
+   * the sticky flag is read through msk_get_sizes()[7] */
+  if (overflow) c->any_overflow = 1;
   return MSK_OK;
 }
 
@@ -432,7 +434,7 @@ ORC_EXPORT int orc_query_run(orc_ctx* c, int q, void* stream) {
 
 ORC_EXPORT int orc_get_sizes(orc_ctx* c, int32_t out[8]) {
   out[0] = c->nb; out[1] = c->na; out[2] = c->max_dof; out[3] = c->nv; out[4] = c->ns; out[5] = c->npairs;
-  out[6] = c->num_envs; out[7] = 0;
+  out[6] = c->num_envs; out[7] = c->any_overflow;
   return MSK_OK;
 }
 

@@ -108,6 +108,7 @@ typedef struct orc_ctx {
   int xb_slot[MSK_MAX_BODIES], nxb;
   float* xshape;     /* [num_envs][nxs][8]: half sizes (3), pad, local position (3), pad */
   float* xbody;      /* [num_envs][nxb][8]: mass, inverse principal inertia (3), pad */
+  int any_overflow;  /* some env dropped contacts past MSK_MAX_CONTACTS since finalize */
   void* render;      /* orc_render.c: render geometry and cameras */
   char err[256];
 } orc_ctx;

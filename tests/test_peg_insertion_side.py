@@ -1,0 +1,75 @@
+"""PegInsertionSide-v1 (BASELINE.json config 4; mani_skill/envs/tasks/tabletop/peg_insertion_side.py): per-env peg / box sizes,
+known answers on the CPU oracle; HIP parity under -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from maniskill_amd.envs.peg_insertion_side import PegInsertionSideEnv, _pose_inv, _pose_mul
+
+
+def test_sizes_layout_and_observation(oracle_factory):
+    env = PegInsertionSideEnv(num_envs=6, px_factory=oracle_factory)
+    obs, info = env.reset(seed=0)
+    assert obs.shape == (6, 43) and not info["success"].any()
+    hs = env.peg_half_sizes
+    assert ((hs[:, 0] >= 0.085) & (hs[:, 0] <= 0.125) & (hs[:, 1] >= 0.015) & (hs[:, 1] <= 0.025)).all() and hs[:, 0].std() > 1e-3
+    assert torch.allclose(env.box_hole_radii, hs[:, 1] + 0.003)
+    for _ in range(15):
+        obs, r, term, trunc, info = env.step(None)
+    peg, box = env.peg_pose, env.box_pose
+    assert torch.allclose(peg[:, 2], hs[:, 1], atol=1.5e-3)                       # every peg rests on the table at its own radius
+    assert torch.allclose(box[:, 2], hs[:, 0], atol=1e-5)                         # the kinematic box stands at its own half length
+    assert torch.allclose(obs[:, 25:32], peg) and torch.allclose(obs[:, 32:35], hs) and torch.allclose(obs[:, 42], env.box_hole_radii)
+    assert (r > 0).all() and (r < 0.2).all() and env.px.get_overflow() == 0
+
+
+def test_a_peg_put_into_its_hole_is_a_success_and_stays_there(oracle_factory):
+    env = PegInsertionSideEnv(num_envs=4, px_factory=oracle_factory)
+    env.reset(seed=2)
+    goal = env.goal_pose                                                            # peg pose with its head at the hole's centre
+    env._rbd[:, env._b_cube, :3] = goal[:, :3] + env._offsets
+    env._rbd[:, env._b_cube, 3:7] = goal[:, 3:7]
+    env._rbd[:, env._b_cube, 7:13] = 0.0
+    env.px.gpu_apply_all(); env.px.gpu_fetch_all()
+    ok, p = env.has_peg_inserted()
+    assert ok.all() and p.abs().max() < 1e-5
+    for _ in range(10):
+        obs, r, term, trunc, info = env.step(None)
+    # the four slabs of this env's box hold this env's peg: it drops by the 3 mm clearance at most and stays inserted
+    assert info["success"].all() and term.all() and torch.allclose(r, torch.ones(4))
+    assert (info["peg_head_pos_at_hole"][:, 1:].abs() <= env.box_hole_radii[:, None] + 1e-4).all()
+    assert env.px.get_overflow() == 0
+    # pulled back by 3 cm along the hole: not inserted
+    back = _pose_mul(env.peg_pose, torch.tensor([[-0.03, 0, 0, 1.0, 0, 0, 0]]).repeat(4, 1))
+    env._rbd[:, env._b_cube, :3] = back[:, :3] + env._offsets
+    env.px.gpu_apply_all(); env.px.gpu_fetch_all()
+    assert not env.has_peg_inserted()[0].any()
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_rollout(oracle_factory):
+    n = 64
+    gpu = PegInsertionSideEnv(num_envs=n, device="cuda:0", obs_mode="rgb+depth+segmentation")
+    cpu = PegInsertionSideEnv(num_envs=n, px_factory=oracle_factory, obs_mode="rgb+depth+segmentation")
+    og, _ = gpu.reset(seed=2022); oc, _ = cpu.reset(seed=2022)
+    assert torch.equal(og["state"].cpu(), oc["state"])
+    gen = torch.Generator().manual_seed(0)
+    for t in range(30):
+        a = 2 * torch.rand(n, 8, generator=gen) - 1
+        og, rg, tg, ug, _ = gpu.step(a.to("cuda:0"))
+        oc, rc, tc, uc, _ = cpu.step(a)
+        assert np.allclose(og["state"].cpu().numpy(), oc["state"].numpy(), rtol=1e-4, atol=1e-5), t
+        assert np.allclose(rg.cpu().numpy(), rc.numpy(), atol=1e-5) and torch.equal(tg.cpu(), tc)
+    cg, cc = og["sensor_data"]["base_camera"], oc["sensor_data"]["base_camera"]
+    assert torch.equal(cg["rgb"].cpu(), cc["rgb"]) and torch.equal(cg["depth"].cpu(), cc["depth"])
+    assert torch.equal(cg["segmentation"].cpu(), cc["segmentation"])
+    # inserted pegs stay inserted on the GPU too
+    for env in (gpu, cpu):
+        goal = env.goal_pose
+        env._rbd[:, env._b_cube, :3] = goal[:, :3] + env._offsets
+        env._rbd[:, env._b_cube, 3:7] = goal[:, 3:7]
+        env._rbd[:, env._b_cube, 7:13] = 0.0
+        env.px.gpu_apply_all(); env.px.gpu_fetch_all()
+    for _ in range(5):
+        ig = gpu.step(None)[4]; ic = cpu.step(None)[4]
+    assert ig["success"].all() and torch.equal(ig["success"].cpu(), ic["success"])

@@ -215,6 +215,11 @@ def main():
     with open(os.path.join(out_dir, "panda_stick.json"), "w") as f:
         json.dump(stick, f, separators=(",", ":"))
     print("panda_stick links", len(stick["links"]), [L["name"] for L in stick["links"]])
+    wrist = cook_urdf(os.path.join(base, "panda_v3.urdf"), os.path.join(base, "panda_v3.srdf"), base)
+    wrist["source"] = "mani_skill/assets/robots/panda/panda_v3.urdf (+ .srdf, collision STLs); cooked by tools/cook_assets.py"
+    with open(os.path.join(out_dir, "panda_v3.json"), "w") as f:
+        json.dump(wrist, f, separators=(",", ":"))
+    print("panda_v3 (wrist camera) links", len(wrist["links"]), [L["name"] for L in wrist["links"]][-4:])
 
 
 if __name__ == "__main__":
