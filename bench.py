@@ -80,7 +80,13 @@ def main():
                          "reference's own benchmark harness uses (2 substeps, examples/benchmarking/scripts/maniskill.sh)")
     ap.add_argument("--reset-every", type=int, default=0,
                     help="full reset every K steps inside the timed region (the harness's second pass uses 200); 0 = never")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="issue every kernel of a control step eagerly.  Default: each control step is one replay of a captured "
+                         "HIP graph (maniskill_amd/graph.py) -- same kernels, same order, same stream; a replay records no "
+                         "events, so the per-kernel durations of the roofline block are then measured with HIP events on 20 "
+                         "eager steps of the same rollout right after the timed region")
     args = ap.parse_args()
+    args.graph = not args.no_graph
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (the product path has no CPU fallback)")
@@ -105,12 +111,21 @@ def main():
 
     with torch.inference_mode():
         torch.manual_seed(0 + rank)
+        if args.graph:
+            try:
+                env.enable_step_graph()
+            except Exception as exc:   # still the HIP path, launched kernel by kernel
+                print(f"[bench] step graph capture failed ({type(exc).__name__}: {exc}); running eager", file=sys.stderr, flush=True)
+                env.disable_step_graph()
+                torch.cuda.synchronize(dev)
+                args.graph = False
         env.reset(seed=2022)
         for _ in range(args.warmup):
             out = env.step(2 * torch.rand(n_local, env.action_dim, device=dev) - 1)
             gather(*out[:4])
         substeps = env._sim_steps_per_control
-        env.px.timing_enable(args.steps * substeps)
+        if not args.graph:
+            env.px.timing_enable(args.steps * substeps)
         sync()
         t0 = time.perf_counter()
         for k in range(args.steps):
@@ -121,6 +136,12 @@ def main():
             gather(obs, rew, term, trunc)
         sync()
         dt = time.perf_counter() - t0
+        if args.graph:   # a graph replay records no events: time the kernels on eager steps of the same rollout
+            env.disable_step_graph()
+            env.px.timing_enable(20 * substeps)
+            for _ in range(20):
+                env.step(2 * torch.rand(n_local, env.action_dim, device=dev) - 1)
+            torch.cuda.synchronize(dev)
         kernels = env.px.timing_read()
         env.px.timing_enable(0)
         cam_us = None
@@ -166,7 +187,9 @@ def main():
             "config": {"workload": f"{args.env}, num_envs={args.envs}, state obs, pd_joint_delta_pos, "
                                    f"sim 100 Hz / control {args.control_freq} Hz ({substeps} substeps, 15+1 TGS iterations)"
                                    + (f", full reset every {args.reset_every} steps" if args.reset_every else ""),
-                       "envs_per_gpu": n_local, "parallelism": f"env-shard x{world}"},
+                       "envs_per_gpu": n_local, "parallelism": f"env-shard x{world}",
+                       "launch": ("one HIP graph replay per control step; kernel_us from HIP events on 20 eager steps after the "
+                                  "timed region") if args.graph else "eager launches; kernel_us from HIP events over the timed region"},
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -15,6 +15,8 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from ..graph import const
+
 from ..physx import SceneTemplate
 from .. import _native as N
 from . import scene_builders as sb
@@ -27,7 +29,7 @@ def _pose_mul(a, b):
 
 
 def _pose_inv(a):
-    qi = a[:, 3:7] * torch.tensor([1.0, -1.0, -1.0, -1.0], device=a.device)
+    qi = a[:, 3:7] * const((1.0, -1.0, -1.0, -1.0), a.device)
     return torch.cat([-PickCubeEnv._qrot(qi, a[:, :3]), qi], dim=-1)
 
 

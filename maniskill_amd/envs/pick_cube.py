@@ -20,6 +20,8 @@ from typing import Optional
 import numpy as np
 import torch
 
+from ..graph import const
+
 from ..physx import PhysxGpuSystem, SimConfig
 from . import scene_builders as sb
 
@@ -389,7 +391,7 @@ class PickCubeEnv:
         Jv = torch.cross(z, pee - o, dim=-1)
         # into the root frame
         qr = poses[:, self._b_root, 3:7][:, None]
-        qri = qr * torch.tensor([1.0, -1.0, -1.0, -1.0], device=qr.device)
+        qri = qr * const((1.0, -1.0, -1.0, -1.0), qr.device)
         Jv, Jw = self._qrot(qri, Jv), self._qrot(qri, z)
         return torch.cat([Jv, Jw], dim=-1).transpose(1, 2)                  # (N, 6, 7)
 
@@ -440,7 +442,7 @@ class PickCubeEnv:
         """to_base * ee_pose (pd_ee_pose.py:70-73): (N, 7) tcp pose in the root link's frame."""
         self._fresh()
         root, tcp = self._rbd[:, self._b_root, :7], self._rbd[:, self._b_tcp, :7]
-        qri = root[:, 3:7] * torch.tensor([1.0, -1.0, -1.0, -1.0], device=root.device)
+        qri = root[:, 3:7] * const((1.0, -1.0, -1.0, -1.0), root.device)
         return torch.cat([self._qrot(qri, tcp[:, :3] - root[:, :3]), self._qmul(qri, tcp[:, 3:7])], dim=-1)
 
     def _set_action_any(self, action: torch.Tensor):
@@ -467,7 +469,7 @@ class PickCubeEnv:
             target = torch.cat([prev[:, :3] + delta[:, :3], q], dim=-1)                # root_translation
             self._target_pose = target
             cur = self.ee_pose_at_base()
-            qci = cur[:, 3:7] * torch.tensor([1.0, -1.0, -1.0, -1.0], device=cur.device)
+            qci = cur[:, 3:7] * const((1.0, -1.0, -1.0, -1.0), cur.device)
             d6 = torch.cat([target[:, :3] - cur[:, :3], self._quat_to_euler_xyz(self._qmul(target[:, 3:7], qci))], dim=-1)   # kinematics.py:218-228
             J = self.ee_jacobian()
             JT = J.transpose(1, 2)
@@ -538,7 +540,27 @@ class PickCubeEnv:
         self.px.gpu_fetch_all()
         self._buffers_stale = False
 
+    def enable_step_graph(self, warmup: int = 2):
+        """Captures one control step (controller, substeps, fetch, task code, camera) as a HIP graph; ``step`` then
+        replays it with a single launch (maniskill_amd/graph.py).  Runs ``warmup`` + 1 throw-away steps: call
+        ``reset`` afterwards.  Needs a GPU env."""
+        from ..graph import StepGraph
+        self._step_graph = None
+        self._step_graph = StepGraph(self._step_eager, self.num_envs, self.action_dim, self.device, warmup)
+        return self._step_graph
+
+    def disable_step_graph(self):
+        self._step_graph = None
+
     def step(self, action):
+        g = getattr(self, "_step_graph", None)
+        if g is not None and action is not None:
+            if self.fused:
+                self._buffers_stale = True
+            return g(action)
+        return self._step_eager(action)
+
+    def _step_eager(self, action):
         if self.fused:
             return self._fused_step(action)
         action = self._step_action(action)

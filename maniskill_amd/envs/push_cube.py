@@ -14,6 +14,8 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from ..graph import const
+
 from . import scene_builders as sb
 from .pick_cube import PickCubeEnv
 
@@ -65,7 +67,7 @@ class PushCubeEnv(PickCubeEnv):
 
     def compute_dense_reward(self, obs, action, info):
         cube, tcp, goal = self.cube_pose[:, :3], self.tcp_pose[:, :3], self.goal_pos
-        push = cube + torch.tensor([-self.cube_half_size - 0.005, 0, 0], device=self.device)
+        push = cube + const((-self.cube_half_size - 0.005, 0, 0), self.device)
         d = torch.linalg.norm(push - tcp, dim=1)
         reward = 1 - torch.tanh(5 * d)
         reached = d < 0.01

@@ -283,7 +283,25 @@ class PushTEnv:
         self._buffers_stale = True
         return self._fused_observe(True)
 
+    def enable_step_graph(self, warmup: int = 2):
+        """One control step captured as a HIP graph (maniskill_amd/graph.py); call ``reset`` afterwards."""
+        from ..graph import StepGraph
+        self._step_graph = None
+        self._step_graph = StepGraph(self._step_eager, self.num_envs, self.action_dim, self.device, warmup)
+        return self._step_graph
+
+    def disable_step_graph(self):
+        self._step_graph = None
+
     def step(self, action):
+        g = getattr(self, "_step_graph", None)
+        if g is not None and action is not None:
+            if self.fused:
+                self._buffers_stale = True
+            return g(action)
+        return self._step_eager(action)
+
+    def _step_eager(self, action):
         if self.fused:
             return self._fused_step(action)
         if action is not None:

@@ -1,0 +1,85 @@
+"""One control step of an env captured as a HIP graph.
+
+The torch-side task code (struct gathers, evaluate, observations, reward -- SURVEY.md §8a rows A3, A5-A7) is a few
+hundred tiny kernels per step for the tasks without a fused task kernel; at 4096 envs the host cannot issue them as
+fast as the GPU retires them, so the step is launch-bound.  Everything in the step is already enqueued on torch's
+current stream (the C-ABI entry points take the stream as an argument and never synchronise), so the whole step --
+controller, S substeps, fetch, contact queries, task code, the camera if there is one -- can be captured once into a
+hipGraph and replayed with one launch.
+
+Contract of a captured env step:
+  * no host synchronisation and no host->device copy inside ``step`` (all the envs of this package comply for the
+    control modes documented in DESIGN.md §6),
+  * the action tensor is copied into a static input; the outputs are static tensors that the *next* replay
+    overwrites, so ``__call__`` hands out clones of (obs, reward, terminated, truncated) and the static ``info``,
+  * anything outside ``step`` (reset, set_state, per-env instance updates) stays eager and needs no re-capture: the
+    graph holds pointers into the simulator's persistent state, not copies of it.
+"""
+from __future__ import annotations
+
+import torch
+
+
+_CONSTANTS = {}
+
+
+def const(values, device, dtype=torch.float32):
+    """A small device constant, uploaded once per (values, device, dtype).  Step-path code uses this instead of
+    ``torch.tensor(..., device=...)``: a host->device copy per step is wasted work in eager mode and illegal inside a
+    stream capture."""
+    def freeze(v):
+        return tuple(freeze(x) for x in v) if isinstance(v, (list, tuple)) else float(v)
+    key = (freeze(values), str(device), dtype)
+    t = _CONSTANTS.get(key)
+    if t is None:
+        t = _CONSTANTS[key] = torch.tensor(values, dtype=dtype, device=device)
+    return t
+
+
+def _clone_tree(x):
+    """Snapshots of the small per-step outputs; the camera textures under ``sensor_data`` are already a snapshot taken
+    inside the step (render.py get_obs copy=True) and are handed out as they are."""
+    if isinstance(x, dict) and "sensor_data" in x:
+        return {k: (v if k in ("sensor_data", "sensor_param") else _clone_tree(v)) for k, v in x.items()}
+    if isinstance(x, torch.Tensor):
+        return x.clone()
+    if isinstance(x, dict):
+        return {k: _clone_tree(v) for k, v in x.items()}
+    return x
+
+
+class StepGraph:
+    """Captures ``step_fn(action) -> (obs, reward, terminated, truncated, info)`` of one env shard."""
+
+    def __init__(self, step_fn, num_envs: int, action_dim: int, device, warmup: int = 2):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("StepGraph needs a GPU env: HIP graphs capture device work only")
+        self.device = device
+        self.action = torch.zeros(num_envs, action_dim, dtype=torch.float32, device=device)
+        # eager warm-up on a side stream: lazy initialisation (module loads, allocator pools, lazily created camera
+        # planes) must not happen inside the capture
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step_fn(self.action)
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = step_fn(self.action)
+        self.replays = 0
+
+    def __call__(self, action):
+        if action is not None:
+            action = torch.as_tensor(action, dtype=torch.float32, device=self.device)
+            if action.ndim == 1:
+                action = action[None]
+            if action.shape != self.action.shape:
+                raise AssertionError(f"Received action of shape {tuple(action.shape)} but expected shape {tuple(self.action.shape)}")
+            self.action.copy_(action)
+        self.graph.replay()
+        self.replays += 1
+        obs, rew, term, trunc, info = self.out
+        return _clone_tree(obs), rew.clone(), term.clone(), trunc.clone(), dict(info)

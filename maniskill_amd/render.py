@@ -24,6 +24,8 @@ from typing import Optional, Sequence
 import numpy as np
 import torch
 
+from .graph import const
+
 from . import _native as N
 
 GROUND_HALF_EXTENT = 50.0  # building/ground.py:46-119 draws a 100 x 100 m grid
@@ -202,7 +204,7 @@ class RenderCameraGroup:
         g = self.get_global_pose()
         T = self._pose_to_matrix(g[:, :3], g[:, 3:7])
         Tinv = torch.linalg.inv(T)
-        ros2opencv = torch.tensor([[0, 0, 1, 0], [-1, 0, 0, 0], [0, -1, 0, 0], [0, 0, 0, 1]], dtype=torch.float32, device=g.device).T
+        ros2opencv = const(((0, 0, 1, 0), (-1, 0, 0, 0), (0, -1, 0, 0), (0, 0, 0, 1)), g.device).T
         res = (ros2opencv @ Tinv)[:, :3, :4]
         if self.cfg.mount < 0:
             self._cached_extrinsic = res
@@ -213,7 +215,7 @@ class RenderCameraGroup:
         if self.cfg.mount < 0 and self._cached_model is not None:
             return self._cached_model
         g = self.get_global_pose()
-        gl = torch.tensor([-0.5, -0.5, 0.5, 0.5], dtype=torch.float32, device=g.device)
+        gl = const((-0.5, -0.5, 0.5, 0.5), g.device)
         w1, x1, y1, z1 = g[:, 3:7].unbind(-1)
         w2, x2, y2, z2 = gl
         q = torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,

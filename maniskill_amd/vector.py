@@ -38,9 +38,11 @@ def torch_clone_dict(x):
 
 class ManiSkillVectorEnv:
     def __init__(self, env: Union[object, str], num_envs: int = 1, auto_reset: bool = True, ignore_terminations: bool = False,
-                 record_metrics: bool = False, **kwargs):
+                 record_metrics: bool = False, step_graph: bool = False, **kwargs):
         if isinstance(env, str):
             env = _registry()[env](num_envs=num_envs, **kwargs)
+        if step_graph:   # one HIP graph replay per control step (maniskill_amd/graph.py); resets stay eager
+            env.enable_step_graph()
         self._env = env
         self.num_envs = env.num_envs
         self.auto_reset = auto_reset
