@@ -133,7 +133,10 @@ enum msk_buffer_id {
   MSK_BUF_ART_QF = 4,
   MSK_BUF_ART_TARGET_QPOS = 5, /* px.cuda_articulation_target_qpos                      */
   MSK_BUF_ART_TARGET_QVEL = 6,
-  MSK_BUF_COUNT = 7
+  MSK_BUF_RIGID_BODY_FORCE = 7,  /* px.cuda_rigid_body_force (structs/actor.py:316-322): (num_envs*NB, 4) f32
+                                  * [fx fy fz -], world frame, at the centre of mass; same rows as buffer 0 */
+  MSK_BUF_RIGID_BODY_TORQUE = 8, /* px.cuda_rigid_body_torque: (num_envs*NB, 4) f32 [tx ty tz -]            */
+  MSK_BUF_COUNT = 9
 };
 void* msk_buffer(msk_ctx* ctx, int buffer_id, int64_t shape[2]);
 
@@ -145,7 +148,13 @@ enum msk_apply_mask {
   MSK_APPLY_ART_QF = 1 << 3,       /* gpu_apply_articulation_qf                          */
   MSK_APPLY_ART_TARGET_QPOS = 1 << 4, /* gpu_apply_articulation_target_position          */
   MSK_APPLY_ART_TARGET_QVEL = 1 << 5, /* gpu_apply_articulation_target_velocity          */
-  MSK_APPLY_ART_ROOT_POSE = 1 << 6    /* gpu_apply_articulation_root_pose (root link row) */
+  MSK_APPLY_ART_ROOT_POSE = 1 << 6,   /* gpu_apply_articulation_root_pose (root link row) */
+  /* gpu_apply_rigid_dynamic_force / _torque (Actor.apply_force, structs/actor.py:316-322): the buffer's rows of the
+   * dynamic actors become the external wrench of the NEXT msk_step only (PhysX clears forces after every simulate());
+   * a second apply before that step replaces the rows, it does not add.  Rows of kinematic actors and of
+   * articulation links are ignored. */
+  MSK_APPLY_RIGID_FORCE = 1 << 7,
+  MSK_APPLY_RIGID_TORQUE = 1 << 8
 };
 enum msk_fetch_mask {
   MSK_FETCH_RIGID_DATA = 1 << 0,   /* gpu_fetch_rigid_dynamic_data + link_pose/velocity  */

@@ -428,13 +428,6 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
   if (has && b->kind == MSK_BODY_DYNAMIC) {
     v3 v = load_v3(E, m->lay.blin, i), w = load_v3(E, m->lay.bang, i);
     if (!b->nograv) v = v3_madd(v, g, dt);
-    const float kl = fmaxf(0.0f, 1.0f - dt * b->lin_damp);
-    const float ka = fmaxf(0.0f, 1.0f - dt * b->ang_damp);
-    v = v3_scale(v, kl);
-    w = v3_scale(w, ka);
-    const int o = b->vofs;
-    vfenv[o + 0] = v.x; vfenv[o + 1] = v.y; vfenv[o + 2] = v.z;
-    vfenv[o + 3] = w.x; vfenv[o + 4] = w.y; vfenv[o + 5] = w.z;
     float Iinv[6];
     float mass_i = b->mass;
     const int xb = m->xb_slot[i];
@@ -444,6 +437,18 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
       mass_i = x[0];
       sym6_rotate(&R, Ii, Iinv);
     } else sym6_rotate(&R, b->Iinv6, Iinv);
+    if (st.ext_wrench) { /* external force / torque at the centre of mass, this step only (msk_apply FORCE / TORQUE) */
+      const float* wr = st.ext_wrench + ((size_t)e * m->nb + i) * 8;
+      v = v3_madd(v, v3_make(wr[0], wr[1], wr[2]), dt / mass_i);
+      w = v3_madd(w, sym6_mulv(Iinv, v3_make(wr[4], wr[5], wr[6])), dt);
+    }
+    const float kl = fmaxf(0.0f, 1.0f - dt * b->lin_damp);
+    const float ka = fmaxf(0.0f, 1.0f - dt * b->ang_damp);
+    v = v3_scale(v, kl);
+    w = v3_scale(w, ka);
+    const int o = b->vofs;
+    vfenv[o + 0] = v.x; vfenv[o + 1] = v.y; vfenv[o + 2] = v.z;
+    vfenv[o + 3] = w.x; vfenv[o + 4] = w.y; vfenv[o + 5] = w.z;
     const float im = 1.0f / mass_i;
     const float Im[3][3] = {{Iinv[0], Iinv[3], Iinv[4]}, {Iinv[3], Iinv[1], Iinv[5]}, {Iinv[4], Iinv[5], Iinv[2]}};
     const v3 ex[3] = {v3_make(1, 0, 0), v3_make(0, 1, 0), v3_make(0, 0, 1)};

@@ -366,6 +366,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 /* ---- AoS <-> SoA converters ------------------------------------------------------------------ */
 struct DBuffers { float* buf[MSK_BUF_COUNT]; int max_dof; };
 
+/* gpu_apply_rigid_dynamic_force / _torque: the buffer rows become the pending wrench of the next substep */
+__global__ void k_apply_wrench(float* __restrict__ wrench, const float* __restrict__ force, const float* __restrict__ torque,
+                               int rows, unsigned mask) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  if (mask & MSK_APPLY_RIGID_FORCE) {
+    const float4 f = *(const float4*)(force + (size_t)r * 4);
+    *(float4*)(wrench + (size_t)r * 8) = make_float4(f.x, f.y, f.z, 0.0f);
+  }
+  if (mask & MSK_APPLY_RIGID_TORQUE) {
+    const float4 t = *(const float4*)(torque + (size_t)r * 4);
+    *(float4*)(wrench + (size_t)r * 8 + 4) = make_float4(t.x, t.y, t.z, 0.0f);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_apply(const DModel* __restrict__ m, DState st, DBuffers bf, unsigned mask, const int* __restrict__ art_dof0,
                                                const int* __restrict__ art_ndof) {
   const int N = m->N;

@@ -49,6 +49,8 @@ struct msk_ctx {
   pose pending_root;
   int nverts_total;
   std::vector<float> h_xshape, h_xbody;   /* host mirrors of the per-env instance records [N][nxs | nxb][8] */
+  float* d_wrench = nullptr;    /* [N][nb][8] external wrench of the next step (msk_apply FORCE / TORQUE) */
+  bool wrench_pending = false;
   size_t lds_solve = 0;  /* dynamic LDS of the solver launch */
   int solve_workers = 0; /* its one-env-per-wave workgroups */
   RModel* rmodel;            /* host copy of the render geometry (include/msk_render.h) */
@@ -486,7 +488,11 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   const size_t nrb = N * (size_t)m.nb * 13;
   const size_t nart = N * (size_t)(m.na > 0 ? m.na : 1) * (size_t)(c->max_dof > 0 ? c->max_dof : 1);
   ALLOC(c->bufs.buf[MSK_BUF_RIGID_BODY_DATA], nrb);
-  for (int b = MSK_BUF_ART_QPOS; b < MSK_BUF_COUNT; ++b) ALLOC(c->bufs.buf[b], nart);
+  for (int b = MSK_BUF_ART_QPOS; b <= MSK_BUF_ART_TARGET_QVEL; ++b) ALLOC(c->bufs.buf[b], nart);
+  ALLOC(c->bufs.buf[MSK_BUF_RIGID_BODY_FORCE], N * (size_t)m.nb * 4);
+  ALLOC(c->bufs.buf[MSK_BUF_RIGID_BODY_TORQUE], N * (size_t)m.nb * 4);
+  ALLOC(c->d_wrench, N * (size_t)m.nb * 8);
+  c->wrench_pending = false;
   c->bufs.max_dof = c->max_dof;
   /* initial poses (template replicated) */
   std::vector<float> h(N * (size_t)m.lay.stride, 0.0f);
@@ -517,6 +523,7 @@ MSK_API int msk_set_scene_offsets(msk_ctx* c, const float* offsets) {
 MSK_API void* msk_buffer(msk_ctx* c, int id, int64_t shape[2]) {
   if (!c->finalized || id < 0 || id >= MSK_BUF_COUNT) return nullptr;
   if (id == MSK_BUF_RIGID_BODY_DATA) { shape[0] = (int64_t)c->model.N * c->model.nb; shape[1] = 13; }
+  else if (id == MSK_BUF_RIGID_BODY_FORCE || id == MSK_BUF_RIGID_BODY_TORQUE) { shape[0] = (int64_t)c->model.N * c->model.nb; shape[1] = 4; }
   else { shape[0] = (int64_t)c->model.N * c->model.na; shape[1] = c->max_dof; }
   return c->bufs.buf[id];
 }
@@ -524,6 +531,13 @@ MSK_API void* msk_buffer(msk_ctx* c, int id, int64_t shape[2]) {
 MSK_API int msk_apply(msk_ctx* c, uint32_t mask, void* stream) {
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "apply before finalize");
   const int N = c->model.N;
+  if (mask & (MSK_APPLY_RIGID_FORCE | MSK_APPLY_RIGID_TORQUE)) { /* external wrench of the next step */
+    const int rows = N * c->model.nb;
+    hipLaunchKernelGGL(k_apply_wrench, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_wrench,
+                       c->bufs.buf[MSK_BUF_RIGID_BODY_FORCE], c->bufs.buf[MSK_BUF_RIGID_BODY_TORQUE], rows, mask);
+    c->wrench_pending = true;
+    if (!(mask & ~(uint32_t)(MSK_APPLY_RIGID_FORCE | MSK_APPLY_RIGID_TORQUE))) { HIP_TRY(hipGetLastError()); return MSK_OK; }
+  }
   hipLaunchKernelGGL(k_apply, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->bufs, mask,
                      c->d_art_dof0, c->d_art_ndof);
   HIP_TRY(hipGetLastError());
@@ -560,7 +574,13 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
   const bool timed = c->t_n < c->t_cap;
   hipEvent_t* ev = timed ? &c->tev[(size_t)c->t_n * (MSK_K_SLOTS + 1)] : nullptr;
   if (timed) hipEventRecord(ev[0], s);
-  launch_dynamics(c->model, c->d_model, c->st, s);
+  if (c->wrench_pending) { /* forces act for this step only */
+    DState stw = c->st;
+    stw.ext_wrench = c->d_wrench;
+    launch_dynamics(c->model, c->d_model, stw, s);
+    hipMemsetAsync(c->d_wrench, 0, sizeof(float) * 8 * (size_t)N * c->model.nb, s);
+    c->wrench_pending = false;
+  } else launch_dynamics(c->model, c->d_model, c->st, s);
   if (timed) hipEventRecord(ev[1], s);
   if (c->model.np > 0) {
     hipLaunchKernelGGL(k_broadphase, dim3(N), dim3(64), 0, s, c->d_model, c->st);

@@ -306,6 +306,8 @@ class PhysxGpuSystem:
         self.cuda_articulation_qf = handle(N.BUF_ART_QF)
         self.cuda_articulation_target_qpos = handle(N.BUF_ART_TARGET_QPOS)
         self.cuda_articulation_target_qvel = handle(N.BUF_ART_TARGET_QVEL)
+        self.cuda_rigid_body_force = handle(N.BUF_RIGID_BODY_FORCE)      # (rows, 4): Actor.apply_force (structs/actor.py:316-322)
+        self.cuda_rigid_body_torque = handle(N.BUF_RIGID_BODY_TORQUE)
         self._initialized = True
         # publish the initial state so that the torch-visible buffers are valid
         self.gpu_update_articulation_kinematics()
@@ -326,6 +328,8 @@ class PhysxGpuSystem:
         self.lib.check(self.ctx, self.lib.fetch(self.ctx, mask, self._stream()), "fetch")
 
     def gpu_apply_rigid_dynamic_data(self): self._apply(N.APPLY_RIGID_DATA)
+    def gpu_apply_rigid_dynamic_force(self): self._apply(N.APPLY_RIGID_FORCE)     # acts during the next step() only
+    def gpu_apply_rigid_dynamic_torque(self): self._apply(N.APPLY_RIGID_TORQUE)
     def gpu_apply_articulation_root_pose(self): self._apply(N.APPLY_ART_ROOT_POSE)
     def gpu_apply_articulation_root_velocity(self): pass  # fixed-base articulations only
     def gpu_apply_articulation_qpos(self): self._apply(N.APPLY_ART_QPOS)
@@ -333,6 +337,13 @@ class PhysxGpuSystem:
     def gpu_apply_articulation_qf(self): self._apply(N.APPLY_ART_QF)
     def gpu_apply_articulation_target_position(self): self._apply(N.APPLY_ART_TARGET_QPOS)
     def gpu_apply_articulation_target_velocity(self): self._apply(N.APPLY_ART_TARGET_QVEL)
+
+    def apply_force(self, body: int, force):
+        """Actor.apply_force (structs/actor.py:316-322): world-frame force at the centre of mass of dynamic actor ``body`` in
+        every env, (N, 3) or (3,); committed at once, acts during the next step() only."""
+        F = self.cuda_rigid_body_force.torch().view(self.num_envs, self.bodies_per_env, 4)
+        F[:, body, :3] = torch.as_tensor(force, dtype=torch.float32, device=F.device)
+        self.gpu_apply_rigid_dynamic_force()
 
     def gpu_apply_all(self):
         """The eight calls of ManiSkillScene._gpu_apply_all (scene.py:950-966) in one launch."""

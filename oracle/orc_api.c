@@ -38,6 +38,7 @@ ORC_EXPORT void orc_destroy(orc_ctx* c) {
   free(c->xshape);
   free(c->xbody);
   for (int i = 0; i < MSK_BUF_COUNT; ++i) free(c->buf[i]);
+  free(c->wrench);
   for (int i = 0; i < c->nqueries; ++i) { free(c->queries[i].pairs); free(c->queries[i].out); }
   free(c);
 }
@@ -264,7 +265,11 @@ ORC_EXPORT int orc_finalize(orc_ctx* c, int num_envs) {
   size_t nrb = (size_t)num_envs * c->nb * 13;
   size_t nart = (size_t)num_envs * (c->na > 0 ? c->na : 1) * (c->max_dof > 0 ? c->max_dof : 1);
   c->buf[MSK_BUF_RIGID_BODY_DATA] = (float*)calloc(nrb, sizeof(float));
-  for (int b = MSK_BUF_ART_QPOS; b < MSK_BUF_COUNT; ++b) c->buf[b] = (float*)calloc(nart, sizeof(float));
+  for (int b = MSK_BUF_ART_QPOS; b <= MSK_BUF_ART_TARGET_QVEL; ++b) c->buf[b] = (float*)calloc(nart, sizeof(float));
+  c->buf[MSK_BUF_RIGID_BODY_FORCE] = (float*)calloc((size_t)num_envs * c->nb * 4, sizeof(float));
+  c->buf[MSK_BUF_RIGID_BODY_TORQUE] = (float*)calloc((size_t)num_envs * c->nb * 4, sizeof(float));
+  c->wrench = (float*)calloc((size_t)num_envs * c->nb * 8, sizeof(float));
+  c->wrench_pending = 0;
   c->finalized = 1;
   return MSK_OK;
 }
@@ -278,6 +283,7 @@ ORC_EXPORT int orc_set_scene_offsets(orc_ctx* c, const float* offsets) {
 ORC_EXPORT void* orc_buffer(orc_ctx* c, int id, int64_t shape[2]) {
   if (!c->finalized || id < 0 || id >= MSK_BUF_COUNT) return NULL;
   if (id == MSK_BUF_RIGID_BODY_DATA) { shape[0] = (int64_t)c->num_envs * c->nb; shape[1] = 13; }
+  else if (id == MSK_BUF_RIGID_BODY_FORCE || id == MSK_BUF_RIGID_BODY_TORQUE) { shape[0] = (int64_t)c->num_envs * c->nb; shape[1] = 4; }
   else { shape[0] = (int64_t)c->num_envs * c->na; shape[1] = c->max_dof; }
   return c->buf[id];
 }
@@ -289,6 +295,15 @@ static float* art_row(orc_ctx* c, int buf, int env, int art) {
 ORC_EXPORT int orc_apply(orc_ctx* c, uint32_t mask, void* stream) {
   (void)stream;
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "apply before finalize");
+  if (mask & (MSK_APPLY_RIGID_FORCE | MSK_APPLY_RIGID_TORQUE)) { /* external wrench of the next step */
+    const size_t rows = (size_t)c->num_envs * c->nb;
+    for (size_t r = 0; r < rows; ++r)
+      for (int k = 0; k < 3; ++k) {
+        if (mask & MSK_APPLY_RIGID_FORCE) c->wrench[r * 8 + k] = c->buf[MSK_BUF_RIGID_BODY_FORCE][r * 4 + k];
+        if (mask & MSK_APPLY_RIGID_TORQUE) c->wrench[r * 8 + 4 + k] = c->buf[MSK_BUF_RIGID_BODY_TORQUE][r * 4 + k];
+      }
+    c->wrench_pending = 1;
+  }
   for (int e = 0; e < c->num_envs; ++e) {
     orc_env* env = &c->envs[e];
     const float* off = c->offsets + 3 * e;
@@ -380,6 +395,10 @@ ORC_EXPORT int orc_step(orc_ctx* c, void* stream) {
   /* like the HIP library: contacts past the per-env capacity are dropped in (pair, point) order and the step goes on;
    * the sticky flag is read through msk_get_sizes()[7] */
   if (overflow) c->any_overflow = 1;
+  if (c->wrench_pending) { /* forces last one step */
+    memset(c->wrench, 0, sizeof(float) * 8 * (size_t)c->num_envs * c->nb);
+    c->wrench_pending = 0;
+  }
   return MSK_OK;
 }
 

@@ -272,6 +272,12 @@ static void dynamics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
     if (b->kind != MSK_BODY_DYNAMIC) continue;
     v3 v = e->blin[i], w = e->bang[i];
     if (!b->nograv) v = v3_madd(v, g, dt);
+    if (c->wrench_pending) { /* external force / torque at the centre of mass, this step only (msk_apply FORCE / TORQUE) */
+      const float* wr = c->wrench + ((size_t)(e - c->envs) * c->nb + i) * 8;
+      const float mass_i = (c->xb_slot[i] >= 0) ? c->xbody[((size_t)(e - c->envs) * c->nxb + c->xb_slot[i]) * 8] : b->mass;
+      v = v3_madd(v, v3_make(wr[0], wr[1], wr[2]), dt / mass_i);
+      w = v3_madd(w, sym6_mulv(s->Iwinv[i], v3_make(wr[4], wr[5], wr[6])), dt);
+    }
     float kl = fmaxf(0.0f, 1.0f - dt * b->lin_damp);
     float ka = fmaxf(0.0f, 1.0f - dt * b->ang_damp);
     v = v3_scale(v, kl);

@@ -106,6 +106,8 @@ typedef struct orc_ctx {
   /* per-env instance parameters (msk_declare_env_box / msk_declare_env_mass): slot per declared shape / body, -1 = template value */
   int xs_slot[MSK_MAX_SHAPES], nxs;
   int xb_slot[MSK_MAX_BODIES], nxb;
+  float* wrench;          /* [num_envs][nb][8]: external force (0..2) and torque (4..6) of the next step */
+  int wrench_pending;
   float* xshape;     /* [num_envs][nxs][8]: half sizes (3), pad, local position (3), pad */
   float* xbody;      /* [num_envs][nxb][8]: mass, inverse principal inertia (3), pad */
   int any_overflow;  /* some env dropped contacts past MSK_MAX_CONTACTS since finalize */

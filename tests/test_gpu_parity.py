@@ -344,3 +344,32 @@ def test_per_env_box_instances_match_oracle(oracle_factory):
     assert torch.equal(pg, pc) and torch.equal(cg, cc)
     z = rc[:, 1, 2]
     assert (z > 0.005).all() and z.std() > 0.01           # different sizes, different resting heights
+
+
+def test_external_wrench_matches_oracle(oracle_factory):
+    """cuda_rigid_body_force / _torque + gpu_apply_rigid_dynamic_force / _torque: random wrenches on the PickCube cube every
+    few substeps (it is kicked around the table top and into the arm), HIP state against the oracle's."""
+    n = 64
+    gen = torch.Generator().manual_seed(21)
+    forces = (torch.rand(25, n, 3, generator=gen) * 2 - 1) * 3.0
+    torques = (torch.rand(25, n, 3, generator=gen) * 2 - 1) * 2e-3
+    out = []
+    for dev, fac in ((DEV, None), (None, oracle_factory)):
+        env = PickCubeEnv(num_envs=n, device=dev, fused=False) if fac is None else PickCubeEnv(num_envs=n, px_factory=fac)
+        env.reset(seed=4)
+        px = env.px
+        F = px.cuda_rigid_body_force.torch().view(n, px.bodies_per_env, 4)
+        T = px.cuda_rigid_body_torque.torch().view(n, px.bodies_per_env, 4)
+        for k in range(25):
+            F[:, env._b_cube, :3] = forces[k].to(F.device)
+            px.gpu_apply_rigid_dynamic_force()
+            if k % 2 == 0:
+                T[:, env._b_cube, :3] = torques[k].to(T.device)
+                px.gpu_apply_rigid_dynamic_torque()
+            for _ in range(3):      # the wrench acts in the first of the three substeps only
+                px.step()
+        px.gpu_fetch_all()
+        out.append(px.cuda_rigid_body_data.torch().cpu().clone())
+    assert _close(out[0].numpy(), out[1].numpy())
+    moved = (out[1].view(n, -1, 13)[:, env._b_cube, :2] - out[1].view(n, -1, 13)[0, env._b_cube, :2]).abs().max()
+    assert moved > 1e-3

@@ -308,3 +308,65 @@ def test_per_env_box_sizes_and_masses(oracle_factory):
     imp = q.cuda_impulses.torch().view(n, 3)[:, 2]
     assert torch.allclose(imp, torch.tensor(mass) * 9.81 * px.timestep, rtol=3e-2)       # and weighs its own weight
     assert (rbd[:, cube, 7:13].abs() < 2e-2).all()
+
+
+def _free_cube_scene(factory, n, gravity=True):
+    """A cube floating far above the table (no contacts), optionally with gravity switched off through the config."""
+    from maniskill_amd.physx import SimConfig
+
+    tpl = SceneTemplate()
+    sb.add_table_scene(tpl)
+    cube = sb.add_cube(tpl, "cube", 0.02, (0, 0, 1.0))
+    cfg = SimConfig()
+    if not gravity:
+        cfg.scene_config.gravity = (0.0, 0.0, 0.0)
+    px = factory(tpl, n, cfg)
+    px.gpu_init()
+    px.set_scene_offsets(np.zeros((n, 3)))
+    rbd = px.cuda_rigid_body_data.torch().view(n, px.bodies_per_env, 13)
+    rbd[:, cube, :3] = torch.tensor([0.0, 0.0, 1.0], device=rbd.device)
+    rbd[:, cube, 3:7] = torch.tensor([1.0, 0, 0, 0], device=rbd.device)
+    rbd[:, cube, 7:13] = 0.0
+    px.gpu_apply_all()
+    return px, cube, rbd
+
+
+def test_external_force_and_torque_act_for_one_step(oracle_factory):
+    """cuda_rigid_body_force + gpu_apply_rigid_dynamic_force (Actor.apply_force, structs/actor.py:316-322) and the torque twin:
+    dv = F dt / m and dw = I^-1 tau dt in the step after the apply, nothing afterwards (forces are cleared by the step); a
+    second apply before the step replaces the wrench; kinematic rows are ignored."""
+    n = 3
+    px, cube, rbd = _free_cube_scene(oracle_factory, n, gravity=False)
+    m, dt = 0.064, px.timestep
+    I = m / 3 * (0.02 ** 2 + 0.02 ** 2)
+    F = px.cuda_rigid_body_force.torch().view(n, px.bodies_per_env, 4)
+    T = px.cuda_rigid_body_torque.torch().view(n, px.bodies_per_env, 4)
+    assert F.shape[-1] == 4 and T.shape == F.shape
+    F[:, cube, :3] = torch.tensor([[9.0, 9.0, 9.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0]], device=F.device)
+    px.gpu_apply_rigid_dynamic_force()
+    F[:, cube, :3] = torch.tensor([[0.64, 0.0, 0.0], [0.0, -1.28, 0.0], [0.0, 0.0, 0.0]], device=F.device)   # replaces, does not add
+    F[:, 0, :3] = 100.0                                                                   # the kinematic table: ignored
+    px.gpu_apply_rigid_dynamic_force()
+    T[2, cube, :3] = torch.tensor([0.0, 0.0, 2e-4], device=T.device)
+    px.gpu_apply_rigid_dynamic_torque()
+    px.step(); px.gpu_fetch_all()
+    v, w = rbd[:, cube, 7:10].clone(), rbd[:, cube, 10:13].clone()
+    want_v = torch.tensor([[0.64 * dt / m, 0, 0], [0, -1.28 * dt / m, 0], [0, 0, 0]], dtype=torch.float32)
+    assert torch.allclose(v.cpu(), want_v, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(w[2].cpu(), torch.tensor([0.0, 0.0, 2e-4 * dt / I * (1 - 0.05 * dt)]), rtol=1e-5, atol=1e-7) and w[:2].abs().max() == 0
+    assert rbd[:, 0, 7:13].abs().max() == 0
+    px.step(); px.gpu_fetch_all()                          # no force any more: v keeps, w only sees the default angular damping 0.05
+    assert torch.allclose(rbd[:, cube, 7:10], v, rtol=1e-6, atol=1e-8)
+    assert torch.allclose(rbd[:, cube, 10:13], w * (1 - 0.05 * dt), rtol=1e-6, atol=1e-8)
+
+
+def test_a_force_of_m_g_upwards_cancels_gravity(oracle_factory):
+    px, cube, rbd = _free_cube_scene(oracle_factory, 2)
+    F = px.cuda_rigid_body_force.torch().view(2, px.bodies_per_env, 4)
+    F[0, cube, 2] = 0.064 * 9.81
+    for _ in range(10):
+        px.gpu_apply_rigid_dynamic_force()      # every step, like a task that holds an object up
+        px.step()
+    px.gpu_fetch_all()
+    assert abs(float(rbd[0, cube, 9])) < 1e-5 and abs(float(rbd[0, cube, 2]) - 1.0) < 1e-5
+    assert abs(float(rbd[1, cube, 9]) + 9.81 * 10 * px.timestep) < 1e-4                  # its neighbour falls freely
