@@ -39,6 +39,8 @@ def _from_p(p):
 
 
 class PegInsertionSideEnv(PickCubeEnv):
+    state_actor_names = ("table-workspace", "peg", "box_with_hole")
+    state_articulation_name = "panda_wristcam"
     max_episode_steps = 100
     max_reward = 10.0
     obs_dim = 43

@@ -662,5 +662,37 @@ class PickCubeEnv:
         self.px.gpu_update_articulation_kinematics()
         self.px.gpu_fetch_all()
 
+    # names of the state-dict entries, in get_state order (scene.get_sim_state: actors in build order, then articulations)
+    state_actor_names = ("table-workspace", "cube", "goal_site")
+    state_articulation_name = "panda"
+
+    def state_layout(self):
+        """[(group, name, start, size)] of the flat state vector: 13 per actor, 13 + 2 * dof for the articulation."""
+        out, start = [], 0
+        for name in self.state_actor_names:
+            out.append(("actors", name, start, 13)); start += 13
+        ndof = self.get_state().shape[1] - start - 13
+        out.append(("articulations", self.state_articulation_name, start, 13 + ndof))
+        return out
+
+    def get_state_dict(self):
+        """BaseEnv.get_state_dict (sapien_env.py:1272-1283): {"actors": {name: (N, 13)}, "articulations": {name: (N, 13 + 2 dof)}}."""
+        flat = self.get_state()
+        out = {"actors": {}, "articulations": {}}
+        for group, name, start, size in self.state_layout():
+            out[group][name] = flat[:, start:start + size].clone()
+        return out
+
+    def set_state_dict(self, state: dict, env_idx=None):
+        """BaseEnv.set_state_dict (sapien_env.py:1293-1303); entries that are missing keep their current value."""
+        flat = self.get_state()
+        if env_idx is not None:
+            flat = flat[torch.as_tensor(env_idx, device=self.device, dtype=torch.long)]
+        for group, name, start, size in self.state_layout():
+            if group in state and name in state[group]:
+                v = torch.as_tensor(state[group][name], dtype=torch.float32, device=self.device)
+                flat[:, start:start + size] = v if v.ndim == 2 else v[None]
+        self.set_state(flat, env_idx)
+
     def close(self):
         self.px.close()

@@ -21,6 +21,7 @@ from .pick_cube import PickCubeEnv
 
 
 class PushCubeEnv(PickCubeEnv):
+    state_actor_names = ("table-workspace", "cube", "goal_region")
     max_episode_steps = 50
     max_reward = 4.0
     goal_radius = 0.1

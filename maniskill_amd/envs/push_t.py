@@ -382,5 +382,12 @@ class PushTEnv:
         self.px.gpu_fetch_all()
         self._buffers_stale = False
 
+    state_actor_names = ("table-workspace", "Tee", "goal_Tee", "goal_ee")
+    state_articulation_name = "panda_stick"
+    # the state-dict view of the flat state is the same code for every env of this package
+    from .pick_cube import PickCubeEnv as _P
+    state_layout, get_state_dict, set_state_dict = _P.state_layout, _P.get_state_dict, _P.set_state_dict
+    del _P
+
     def close(self):
         self.px.close()

@@ -16,6 +16,7 @@ from .pick_cube import PickCubeEnv
 
 
 class StackCubeEnv(PickCubeEnv):
+    state_actor_names = ("table-workspace", "cubeA", "cubeB")
     max_episode_steps = 50
     max_reward = 8.0
     obs_dim = 48

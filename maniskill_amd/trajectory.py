@@ -1,0 +1,327 @@
+"""Trajectory recording and replay.
+
+Mirrors the reference's ``RecordEpisode`` wrapper (mani_skill/utils/wrappers/record.py:216-720) and the GPU branch of
+``replay_trajectory`` (mani_skill/trajectory/replay_trajectory.py:112-241) on the envs of this package:
+
+* one group per episode, ``traj_<episode_id>``: ``actions (T, A) f32``, ``terminated / truncated / success (T,) bool``,
+  ``rewards (T,) f32``, ``env_states/{actors,articulations}/<name> (T + 1, D) f32`` (the state *before* the first action
+  first, record.py:161-186);
+* a JSON file next to it: ``env_info {env_id, env_kwargs, max_episode_steps}``, ``episodes [{episode_id, episode_seed,
+  control_mode, elapsed_steps, reset_kwargs, success}]``, ``source_type``, ``source_desc`` (record.py:275-287,642-707).
+
+Container: the reference writes HDF5 through h5py.  h5py is used here when it is importable and the path ends in ``.h5``;
+otherwise the same hierarchy is stored as an ``.npz`` archive whose member names are the HDF5 paths
+(``traj_0/env_states/actors/cube``).  Both are read back through the same ``open_arrays`` mapping, so a trajectory recorded
+by the reference replays here wherever h5py exists, and the golden traces of tests/golden travel without it.
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+try:   # optional: not part of this image
+    import h5py  # type: ignore
+except Exception:   # pragma: no cover
+    h5py = None
+
+
+# ------------------------------------------------------------------------------------------------ array container
+def _flatten(prefix: str, tree, out: Dict[str, np.ndarray]):
+    if isinstance(tree, dict):
+        for k, v in tree.items():
+            _flatten(f"{prefix}/{k}" if prefix else k, v, out)
+    else:
+        out[prefix] = np.asarray(tree)
+
+
+def _unflatten(flat: Dict[str, np.ndarray]) -> dict:
+    root: dict = {}
+    for path, arr in flat.items():
+        node = root
+        parts = path.split("/")
+        for p in parts[:-1]:
+            node = node.setdefault(p, {})
+        node[parts[-1]] = arr
+    return root
+
+
+def save_arrays(path: str, tree: dict):
+    flat: Dict[str, np.ndarray] = {}
+    _flatten("", tree, flat)
+    if path.endswith(".h5"):
+        if h5py is None:
+            raise RuntimeError("writing .h5 needs h5py; use a .npz path on this image")
+        with h5py.File(path, "w") as f:
+            for k, v in flat.items():
+                f.create_dataset(k, data=v)
+    else:
+        np.savez(path, **flat)
+
+
+def open_arrays(path: str) -> dict:
+    """The file as a nested dict of numpy arrays: ``tree["traj_0"]["env_states"]["actors"]["cube"]``."""
+    if path.endswith(".h5"):
+        if h5py is None:
+            raise RuntimeError("reading .h5 needs h5py, which is not installed here")
+        flat = {}
+        with h5py.File(path, "r") as f:
+            f.visititems(lambda name, obj: flat.__setitem__(name, np.asarray(obj)) if isinstance(obj, h5py.Dataset) else None)
+        return _unflatten(flat)
+    with np.load(path) as z:
+        return _unflatten({k: z[k] for k in z.files})
+
+
+def _to_np(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    if isinstance(x, dict):
+        return {k: _to_np(v) for k, v in x.items()}
+    return np.asarray(x)
+
+
+def _tree_index(tree, idx):
+    return {k: _tree_index(v, idx) for k, v in tree.items()} if isinstance(tree, dict) else tree[idx]
+
+
+def _tree_assign_rows(dst, src, idx):
+    if isinstance(dst, dict):
+        for k in dst:
+            _tree_assign_rows(dst[k], src[k], idx)
+    else:
+        dst[idx] = src[idx]
+
+
+def _tree_stack(trees: List[dict]):
+    first = trees[0]
+    if isinstance(first, dict):
+        return {k: _tree_stack([t[k] for t in trees]) for k in first}
+    return np.stack(trees, axis=0)
+
+
+# ------------------------------------------------------------------------------------------------ recording
+class RecordEpisode:
+    """Wraps an env of this package (or anything with its ``reset / step / get_state_dict`` surface) and keeps, per env,
+    the running episode: states, actions, rewards, flags.  ``flush_trajectory`` turns the episodes of the chosen envs into
+    ``traj_<id>`` groups; a full ``reset`` flushes everything, a partial one (``options["env_idx"]``) only those envs, which
+    is what ``ManiSkillVectorEnv``'s auto reset does on top of this wrapper."""
+
+    def __init__(self, env, output_dir: str, trajectory_name: str = "trajectory", save_trajectory: bool = True,
+                 record_env_state: bool = True, record_reward: bool = True, env_id: Optional[str] = None,
+                 source_type: Optional[str] = None, source_desc: Optional[str] = None, container: str = "npz"):
+        self.env = env
+        self.num_envs = env.num_envs
+        self.save_trajectory = save_trajectory
+        self.record_env_state = record_env_state
+        self.record_reward = record_reward
+        os.makedirs(output_dir, exist_ok=True)
+        self.path = os.path.join(output_dir, f"{trajectory_name}.{container}")
+        self.json_path = os.path.join(output_dir, f"{trajectory_name}.json")
+        self._episode_id = -1
+        self._groups: dict = {}
+        self._json = dict(
+            env_info=dict(env_id=env_id or type(env).__name__,
+                          env_kwargs=dict(obs_mode=getattr(env, "obs_mode", "state"), control_mode=getattr(env, "control_mode", None),
+                                          num_envs=self.num_envs, sim_backend="gpu"),
+                          max_episode_steps=int(getattr(env, "max_episode_steps", 0))),
+            episodes=[], source_type=source_type, source_desc=source_desc)
+        self._steps: List[dict] = []      # time-major buffer of batched frames; frame 0 of an episode has no action
+        self._start = np.zeros(self.num_envs, dtype=np.int64)
+        self._seeds = np.full(self.num_envs, -1, dtype=np.int64)
+
+    # gym surface -------------------------------------------------------------------------------------------------------
+    @property
+    def base_env(self):
+        return self.env
+
+    @property
+    def device(self):
+        return self.env.device
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    def _frame(self, action=None, reward=None, terminated=None, truncated=None, info=None):
+        n, a = self.num_envs, self.env.action_dim
+        f = dict(action=np.zeros((n, a), np.float32) if action is None else _to_np(action).astype(np.float32).reshape(n, a),
+                 reward=np.zeros(n, np.float32) if reward is None else _to_np(reward).astype(np.float32),
+                 terminated=np.zeros(n, bool) if terminated is None else _to_np(terminated).astype(bool),
+                 truncated=np.zeros(n, bool) if truncated is None else _to_np(truncated).astype(bool),
+                 success=np.zeros(n, bool) if info is None or "success" not in info else _to_np(info["success"]).astype(bool))
+        if self.record_env_state:
+            f["state"] = _to_np(self.env.get_state_dict())
+        return f
+
+    def reset(self, seed=None, options: Optional[dict] = None):
+        options = options or {}
+        partial = "env_idx" in options
+        idx = _to_np(options["env_idx"]).astype(np.int64).reshape(-1) if partial else np.arange(self.num_envs)
+        if self.save_trajectory and self._steps:
+            self.flush_trajectory(env_idxs_to_flush=idx)
+        obs, info = self.env.reset(seed=seed, options=options if options else None)
+        # the first frame of the new episodes.  A partial reset overwrites the rows of its envs in the newest frame (their old
+        # episodes were flushed above, record.py:420-445): the other envs' episodes go on through the same frame untouched
+        frame = self._frame()
+        if partial and self._steps:
+            if self.record_env_state:
+                _tree_assign_rows(self._steps[-1]["state"], frame["state"], idx)
+            self._start[idx] = len(self._steps) - 1
+        else:
+            self._steps = [frame]
+            self._start[:] = 0
+        main = getattr(self.env, "_main_seeds", None)
+        count = getattr(self.env, "_episode_count", None)
+        if main is not None and count is not None:   # reproducible by reset(seed=...) only for the first episode of a seed
+            first = np.asarray(count)[idx] == 1
+            self._seeds[idx] = np.where(first, np.asarray(main)[idx].astype(np.int64), -1)
+        return obs, info
+
+    def step(self, action):
+        out = self.env.step(action)
+        obs, rew, term, trunc, info = out
+        self._steps.append(self._frame(action, rew, term, trunc, info))
+        return out
+
+    # flushing ----------------------------------------------------------------------------------------------------------
+    def flush_trajectory(self, env_idxs_to_flush=None, ignore_empty_transition: bool = True, save: bool = True) -> int:
+        idxs = np.arange(self.num_envs) if env_idxs_to_flush is None else np.asarray(env_idxs_to_flush).reshape(-1)
+        end = len(self._steps)
+        count = 0
+        for e in idxs:
+            start = int(self._start[e])
+            if ignore_empty_transition and end - start <= 1:
+                continue
+            count += 1
+            if save and self.save_trajectory:
+                self._episode_id += 1
+                frames = self._steps[start:end]
+                grp = dict(actions=np.stack([f["action"][e] for f in frames[1:]]),
+                           terminated=np.array([f["terminated"][e] for f in frames[1:]]),
+                           truncated=np.array([f["truncated"][e] for f in frames[1:]]),
+                           success=np.array([f["success"][e] for f in frames[1:]]))
+                if self.record_reward:
+                    grp["rewards"] = np.array([f["reward"][e] for f in frames[1:]], dtype=np.float32)
+                if self.record_env_state:
+                    grp["env_states"] = _tree_stack([_tree_index(f["state"], e) for f in frames])
+                self._groups[f"traj_{self._episode_id}"] = grp
+                self._json["episodes"].append(dict(
+                    episode_id=self._episode_id, episode_seed=int(self._seeds[e]), env_index=int(e),
+                    control_mode=getattr(self.env, "control_mode", None), elapsed_steps=end - start - 1,
+                    reset_kwargs=dict(seed=int(self._seeds[e])) if self._seeds[e] >= 0 else dict(),
+                    success=bool(frames[-1]["success"][e])))
+            self._start[e] = end - 1 if end > 0 else 0
+        return count
+
+    def close(self):
+        if self.save_trajectory:
+            self.flush_trajectory()
+            save_arrays(self.path, self._groups)
+            with open(self.json_path, "w") as f:
+                json.dump(self._json, f, indent=2)
+
+
+# ------------------------------------------------------------------------------------------------ replay
+@dataclass
+class ReplayResult:
+    num_replays: int
+    successful_replays: int
+    max_state_error: float      # largest |replayed - recorded| over every state entry of every step (inf if no states)
+
+
+def load_trajectory(path: str):
+    """(json metadata, nested arrays) of a recorded trajectory; ``path`` is the array file (.npz / .h5)."""
+    with open(os.path.splitext(path)[0] + ".json") as f:
+        meta = json.load(f)
+    return meta, open_arrays(path)
+
+
+def replay_trajectory(env, path: str, use_env_states: bool = False, use_first_env_state: bool = False,
+                      count: Optional[int] = None) -> ReplayResult:
+    """replay_parallelized_sim (replay_trajectory.py:112-241): the episodes are replayed ``env.num_envs`` at a time, each
+    batch reset with its episode seeds, the first recorded state optionally restored, the recorded actions stepped (shorter
+    episodes padded with zero actions and their last state), and with ``use_env_states`` the recorded state re-imposed after
+    every step.  An episode counts as successful if ``info["success"]`` holds at its recorded last step.  Episodes keep the
+    env index they were recorded on when the batch allows it (per-env instances such as PegInsertionSide's peg sizes are a
+    property of the env index, not of the state)."""
+    meta, arrays = load_trajectory(path)
+    episodes = meta["episodes"][:count] if count else meta["episodes"]
+    n = env.num_envs
+    successes, err, seen_state = 0, 0.0, False
+    for b0 in range(0, len(episodes), n):
+        batch = episodes[b0:b0 + n]
+        pad = n - len(batch)
+        batch = batch + [batch[-1]] * pad
+        if len({ep["control_mode"] for ep in batch}) != 1:
+            raise NotImplementedError("replay of episodes with different control modes in one batch")
+        lens = np.array([ep["elapsed_steps"] for ep in batch])
+        T = int(lens.max())
+        trajs = [arrays[f"traj_{ep['episode_id']}"] for ep in batch]
+        seeds = [ep["episode_seed"] for ep in batch]
+        need_first = use_first_env_state or use_env_states or any(s < 0 for s in seeds)
+        env.reset(seed=[max(s, 0) for s in seeds])
+        has_states = all("env_states" in t for t in trajs)
+        if need_first and not has_states:
+            raise ValueError("the trajectory holds no env_states; it can only be replayed from seeds that were recorded")
+
+        def state_at(t):
+            rows = [_tree_index(tr["env_states"], min(t, ln)) for tr, ln in zip(trajs, lens)]
+            return _tree_stack(rows)
+        if need_first:
+            env.set_state_dict(state_at(0))
+        actions = np.zeros((T, n, trajs[0]["actions"].shape[1]), np.float32)
+        for i, (tr, ln) in enumerate(zip(trajs, lens)):
+            actions[:ln, i] = tr["actions"]
+        ok = np.zeros(n, bool)
+        for t in range(T):
+            _, _, _, _, info = env.step(torch.as_tensor(actions[t], device=env.device))
+            if has_states:
+                seen_state = True
+                now, want = _to_np(env.get_state_dict()), state_at(t + 1)
+                live = lens > t
+                for group in want:
+                    for name in want[group]:
+                        d = np.abs(now[group][name] - want[group][name])[live]
+                        err = max(err, float(d.max()) if d.size else 0.0)
+            if use_env_states:
+                env.set_state_dict(state_at(t + 1))
+            if "success" in info:
+                done_now = lens - 1 == t
+                ok[done_now] = _to_np(info["success"])[done_now]
+        real = n - pad
+        successes += int(ok[:real].sum())
+    return ReplayResult(len(episodes), successes, err if seen_state else float("inf"))
+
+
+def main(argv=None):
+    """``python -m maniskill_amd.trajectory --traj-path demo.npz -n 64`` (the reference's
+    ``python -m mani_skill.trajectory.replay_trajectory``, tyro Args at replay_trajectory.py:31-85)."""
+    import argparse
+
+    from .vector import _registry
+
+    ap = argparse.ArgumentParser(description="Replay a recorded trajectory on the MI355X backend")
+    ap.add_argument("--traj-path", required=True)
+    ap.add_argument("-n", "--num-envs", type=int, default=None, help="parallel envs per batch (default: one per episode, at most 1024)")
+    ap.add_argument("--use-env-states", action="store_true", help="re-impose the recorded state after every step")
+    ap.add_argument("--use-first-env-state", action="store_true", help="start every episode from its first recorded state")
+    ap.add_argument("--count", type=int, default=None, help="replay only the first COUNT episodes")
+    ap.add_argument("--device", default="cuda:0")
+    args = ap.parse_args(argv)
+    meta, _ = load_trajectory(args.traj_path)
+    env_id = meta["env_info"]["env_id"]
+    n = args.num_envs or min(len(meta["episodes"]), 1024)
+    kw = {k: v for k, v in meta["env_info"].get("env_kwargs", {}).items() if k in ("obs_mode", "control_mode") and v is not None}
+    env = _registry()[env_id](num_envs=n, device=args.device, **kw)
+    res = replay_trajectory(env, args.traj_path, use_env_states=args.use_env_states, use_first_env_state=args.use_first_env_state,
+                            count=args.count)
+    print(json.dumps(dict(env_id=env_id, num_replays=res.num_replays, successful_replays=res.successful_replays,
+                          max_state_error=res.max_state_error)))
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -41,7 +41,23 @@ def rollout(n=8, steps=40, seed=2022):
                 contact_ids_offsets=np.cumsum([0] + [len(c) for c in contact_ids]).astype(np.int64))
 
 
+def trace(n=8, steps=20, seed=31):
+    """A trajectory in the reference's recording layout (maniskill_amd/trajectory.py): pickcube_oracle_trace.{npz,json}."""
+    from maniskill_amd.trajectory import RecordEpisode
+
+    env = PickCubeEnv(num_envs=n, px_factory=lambda tpl, k, cfg: OraclePhysxSystem(tpl, k, cfg))
+    rec = RecordEpisode(env, HERE, trajectory_name="pickcube_oracle_trace", env_id="PickCube-v1", source_type="oracle",
+                        source_desc="uniform random actions in [-0.7, 0.7], CPU oracle (oracle/liborc.so), tests/golden/make_golden.py")
+    rec.reset(seed=seed)
+    gen = torch.Generator().manual_seed(1)
+    for _ in range(steps):
+        rec.step(0.7 * (2 * torch.rand(n, 8, generator=gen) - 1))
+    rec.close()
+
+
 if __name__ == "__main__":
+    trace()
+    print("wrote pickcube_oracle_trace.npz / .json")
     g = rollout()
     np.savez_compressed(os.path.join(HERE, "pickcube_oracle_rollout.npz"), **g)
     print("wrote pickcube_oracle_rollout.npz", {k: v.shape for k, v in g.items()})
