@@ -98,9 +98,13 @@ def main():
     env, gather, rank, world = make_sharded_env(args.env, args.envs, device_type="cuda", obs_mode=args.obs_mode,
                                                 sim_config=SimConfig(control_freq=args.control_freq))
     camera_mode = args.obs_mode != "state"
+    # one all-gather per control step, issued on RCCL's stream and waited for one step later (dist.py pipelined()): the
+    # next step's physics never waits for xGMI; flush() inside the timed region completes the last one
+    _gather = gather
     if camera_mode:   # image observations stay on their GPU; only the state part is gathered
-        _gather = gather
-        gather = lambda o, r, t, u: _gather(o["state"], r, t, u)
+        gather = lambda o, r, t, u: _gather.pipelined(o["state"], r, t, u)
+    else:
+        gather = _gather.pipelined
     dev = env.device
     n_local = env.num_envs
 
@@ -123,6 +127,7 @@ def main():
         for _ in range(args.warmup):
             out = env.step(2 * torch.rand(n_local, env.action_dim, device=dev) - 1)
             gather(*out[:4])
+        _gather.flush()
         substeps = env._sim_steps_per_control
         if not args.graph:
             env.px.timing_enable(args.steps * substeps)
@@ -134,6 +139,7 @@ def main():
             actions = 2 * torch.rand(n_local, env.action_dim, device=dev) - 1
             obs, rew, term, trunc, _ = env.step(actions)
             gather(obs, rew, term, trunc)
+        _gather.flush()
         sync()
         dt = time.perf_counter() - t0
         if args.graph:   # a graph replay records no events: time the kernels on eager steps of the same rollout

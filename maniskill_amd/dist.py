@@ -49,19 +49,55 @@ class ObservationGather:
         self.send = torch.empty(local_envs, self.width, dtype=torch.float32, device=device)
         self.recv = torch.empty(world * local_envs, self.width, dtype=torch.float32, device=device) if world > 1 else self.send
         assert equal_shards, "all_gather_into_tensor needs equal shard sizes (pad the env count to a multiple of world)"
+        # second buffer pair + the collective in flight, for pipelined()
+        self._send2 = torch.empty_like(self.send) if world > 1 else None
+        self._recv2 = torch.empty_like(self.recv) if world > 1 else None
+        self._inflight = None      # (work handle, recv buffer) of the newest collective
+        self._parity = 0
+        self._last = None          # world 1: the newest step's tensors
 
-    def __call__(self, obs, reward, terminated, truncated):
-        if self.world == 1:   # one shard: nothing to exchange, nothing to pack
-            return obs, reward, terminated, truncated
-        s = self.send
+    def _pack(self, s, obs, reward, terminated, truncated):
         s[:, : self.obs_dim] = obs
         s[:, self.obs_dim] = reward
         s[:, self.obs_dim + 1] = terminated.to(torch.float32)
         s[:, self.obs_dim + 2] = truncated.to(torch.float32)
-        if self.world > 1:
-            dist.all_gather_into_tensor(self.recv, s)
-        r = self.recv
+
+    def _unpack(self, r):
         return r[:, : self.obs_dim], r[:, self.obs_dim], r[:, self.obs_dim + 1] > 0.5, r[:, self.obs_dim + 2] > 0.5
+
+    def pipelined(self, obs, reward, terminated, truncated):
+        """One all-gather per control step, overlapped with the next step's physics: the collective of step k is issued
+        on RCCL's own stream as soon as the step's outputs exist and is only waited for when step k + 1 hands in its
+        outputs -- the call returns the gathered tensors of the PREVIOUS step (None the first time); ``flush()`` returns the
+        newest.  Nothing on the physics stream waits for xGMI; a rank that is ahead runs at most one step ahead."""
+        if self.world == 1:
+            prev, self._last = self._last, (obs, reward, terminated, truncated)
+            return prev
+        prev = self.flush()
+        send, recv = (self.send, self.recv) if self._parity == 0 else (self._send2, self._recv2)
+        self._parity ^= 1
+        self._pack(send, obs, reward, terminated, truncated)
+        self._inflight = (dist.all_gather_into_tensor(recv, send, async_op=True), recv)
+        return prev
+
+    def flush(self):
+        """Waits for the collective in flight and returns its tensors (None if there is none)."""
+        if self.world == 1:
+            last, self._last = self._last, None
+            return last
+        if self._inflight is None:
+            return None
+        work, recv = self._inflight
+        self._inflight = None
+        work.wait()
+        return self._unpack(recv)
+
+    def __call__(self, obs, reward, terminated, truncated):
+        if self.world == 1:   # one shard: nothing to exchange, nothing to pack
+            return obs, reward, terminated, truncated
+        self._pack(self.send, obs, reward, terminated, truncated)
+        dist.all_gather_into_tensor(self.recv, self.send)
+        return self._unpack(self.recv)
 
 
 def make_sharded_env(env_id: str, total_envs: int, device_type: str = "cuda", px_factory=None, **kw):

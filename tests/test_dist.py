@@ -31,12 +31,22 @@ def _worker(rank, world, port, total, steps, q):
                                                px_factory=lambda tpl, n, cfg: OraclePhysxSystem(tpl, n, cfg))
     obs, _ = env.reset(seed=2022)
     gen = torch.Generator().manual_seed(0)
-    out = None
+    from maniskill_amd.dist import ObservationGather
+    pipe = ObservationGather(env.num_envs, env.obs_dim, w, env.device)   # its own buffers: the two forms are not mixed on one object
+    out, piped = None, []
     for _ in range(steps):
         a = torch.rand(total, 8, generator=gen) * 2 - 1      # same global action stream on every rank
         n = env.num_envs
         o, rew, term, trunc, _ = env.step(a[r * n:(r + 1) * n])
         out = gather(o, rew, term, trunc)
+        prev = pipe.pipelined(o, rew, term, trunc)         # the overlapped form: hands back the previous step's gather
+        piped.append(None if prev is None else [t.clone() for t in prev])
+        piped_now = [t.clone() for t in out]
+        if len(piped) > 1:
+            assert all(torch.equal(x, y) for x, y in zip(piped[-1], last_sync))
+        last_sync = piped_now
+    final = pipe.flush()
+    assert piped[0] is None and all(torch.equal(x, y) for x, y in zip(final, out)) and pipe.flush() is None
     if rank == 0:
         q.put([t.clone().numpy() for t in out])
     dist.barrier()
