@@ -81,6 +81,20 @@ int msk_task_pusht_set_action(msk_ctx* ctx, const float* actions, void* stream);
 int msk_task_pusht_observe(msk_ctx* ctx, float* obs, int obs_dim, float* reward, uint8_t* flags, int32_t* elapsed, int advance,
                            void* stream);
 
+/* ---- PegInsertionSide-v1 (envs/tasks/tabletop/peg_insertion_side.py) ------------------------------------------------
+ * Sits on an initialised pickcube binding whose `cube` is the peg and whose `goal` is box_with_hole (max_angle_deg 20,
+ * max_episode_steps 100): the controller kernels and msk_control_step are shared, only evaluate / obs / reward differ.
+ * Host arrays, one row per env: peg half sizes [num_envs][3] (:106-109), hole centre in the box frame [num_envs][3]
+ * (:150-163), hole radius [num_envs] (peg radius + clearance, :165-167). */
+int msk_task_peg_init(msk_ctx* ctx, const float* peg_half_sizes, const float* hole_offsets, const float* hole_radii);
+/* elapsed_steps += 1; evaluate() = has_peg_inserted (:248-262): peg head within the hole's radius and at most 15 mm
+ * short of its centre plane; observation (:264-277) [num_envs][43] = qpos 9, qvel 9, tcp pose 7, peg pose 7, peg half
+ * sizes 3, hole pose 7, hole radius 1; normalized dense reward (:279-337): reaching + is_grasped (20 deg) +
+ * pre-insertion alignment + insertion, 10 on success, / 10; flags [num_envs][8] u8 = {success, 0, 0, is_grasped,
+ * terminated, truncated, 0, 0}; head_at_hole [num_envs][3] = info["peg_head_pos_at_hole"]. */
+int msk_task_peg_observe(msk_ctx* ctx, float* obs, float* reward, uint8_t* flags, int32_t* elapsed, float* head_at_hole, int advance,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

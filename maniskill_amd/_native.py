@@ -36,7 +36,7 @@ RENDER_EXPORTS = ["render_add_mesh", "render_set_base_color", "render_bind_env_b
                   "camera_obs_buffer", "camera_take_picture"]
 # include/msk_task.h — fused task kernels (HIP library only; the test-suite's CPU checker has no counterpart)
 TASK_EXPORTS = ["task_pickcube_init", "task_pickcube_set_action", "task_pickcube_set_action_ee", "control_step", "task_pickcube_observe",
-                "task_pusht_init", "task_pusht_set_action", "task_pusht_observe"]
+                "task_pusht_init", "task_pusht_set_action", "task_pusht_observe", "task_peg_init", "task_peg_observe"]
 K_DYNAMICS, K_COLLIDE, K_SOLVE = 0, 1, 2
 KERNEL_SLOTS = {"k_dynamics": K_DYNAMICS, "k_collide": K_COLLIDE, "k_solve": K_SOLVE}
 
@@ -158,6 +158,8 @@ class NativeLib:
             "task_pusht_init": (i32, [vp, C.POINTER(PushTDesc), C.POINTER(C.c_uint8)]),
             "task_pusht_set_action": (i32, [vp, vp, vp]),
             "task_pusht_observe": (i32, [vp, vp, i32, vp, vp, vp, i32, vp]),
+            "task_peg_init": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+            "task_peg_observe": (i32, [vp, vp, vp, vp, vp, vp, i32, vp]),
         }
         self.has_task_kernels = all(hasattr(self.dll, prefix + n) for n in task_sig)
         if self.has_task_kernels:

@@ -63,6 +63,8 @@ struct msk_ctx {
   msk_pusht_desc pusht;
   PushTTables pusht_tb;
   bool has_pusht = false;
+  PegTables peg_tb;
+  bool has_peg = false;
   bool kin_dirty;        /* link frames in st.bpose are older than (q, qd): run k_kinematics before reading them */
   uint32_t groups[MSK_MAX_SHAPES][4]; /* collision groups: only the static pair filter needs them */
   std::vector<void*> allocs;
@@ -932,6 +934,35 @@ MSK_API int msk_task_pusht_observe(msk_ctx* c, float* obs, int obs_dim, float* r
   }
   hipLaunchKernelGGL(k_pusht_observe, dim3(c->model.N), dim3(64), 0, (hipStream_t)stream, c->d_model, c->st, c->pusht, c->pusht_tb, obs,
                      obs_dim, reward, flags, elapsed, advance);
+  HIP_TRY(hipGetLastError());
+  return MSK_OK;
+}
+
+MSK_API int msk_task_peg_init(msk_ctx* c, const float* peg_half_sizes, const float* hole_offsets, const float* hole_radii) {
+  if (!c->has_pickcube) return fail(c, MSK_ERR_INVALID, "peg: bind the pickcube task first (its cube = the peg, its goal = box_with_hole)");
+  if (2 * (c->pickcube.arm_dofs + 2) + 25 != 43) return fail(c, MSK_ERR_INVALID, "peg: expects a 7+2 dof arm");
+  const size_t N = (size_t)c->model.N;
+  float *half = nullptr, *hole = nullptr, *radius = nullptr;
+  ALLOC(half, N * 3); ALLOC(hole, N * 3); ALLOC(radius, N);
+  HIP_TRY(hipMemcpy(half, peg_half_sizes, sizeof(float) * N * 3, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(hole, hole_offsets, sizeof(float) * N * 3, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(radius, hole_radii, sizeof(float) * N, hipMemcpyHostToDevice));
+  c->peg_tb.half = half; c->peg_tb.hole = hole; c->peg_tb.radius = radius;
+  c->has_peg = true;
+  return MSK_OK;
+}
+
+MSK_API int msk_task_peg_observe(msk_ctx* c, float* obs, float* reward, uint8_t* flags, int32_t* elapsed, float* head_at_hole,
+                                 int advance, void* stream) {
+  if (!c->has_peg) return fail(c, MSK_ERR_INVALID, "peg task not initialised");
+  const int N = c->model.N;
+  if (c->kin_dirty) {
+    launch_kinematics(c->model, c->d_model, c->st, (hipStream_t)stream);
+    c->kin_dirty = false;
+  }
+  const float cos_max = cosf(c->pickcube.max_angle_deg * 3.14159265358979323846f / 180.0f);
+  hipLaunchKernelGGL(k_peg_observe, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->pickcube, c->peg_tb,
+                     obs, reward, flags, elapsed, head_at_hole, advance, cos_max);
   HIP_TRY(hipGetLastError());
   return MSK_OK;
 }

@@ -197,6 +197,72 @@ __global__ void __launch_bounds__(256) k_pickcube_observe(const DModel* __restri
   f[6] = 0; f[7] = 0;
 }
 
+/* ---- PegInsertionSide-v1 ------------------------------------------------------------------------------------------- */
+struct PegTables { const float* half; const float* hole; const float* radius; };   /* [N][3], [N][3], [N] */
+
+MSK_DEV pose pose_from_p(float x, float y, float z) {
+  pose r;
+  r.p = v3_make(x, y, z);
+  r.q = quat_make(1.0f, 0.0f, 0.0f, 0.0f);
+  return r;
+}
+
+__global__ void __launch_bounds__(256) k_peg_observe(const DModel* __restrict__ m, DState st, msk_pickcube_desc d, PegTables tb,
+                                                     float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags,
+                                                     int* __restrict__ elapsed, float* __restrict__ head_at_hole, int advance,
+                                                     float cos_max_angle) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= m->N) return;
+  const float* E = EREC(st, m, e);
+  const int nq = d.arm_dofs + 2;
+  float* o = obs + (size_t)e * 43;
+  for (int j = 0; j < nq; ++j) {
+    o[j] = E[m->lay.q + j];
+    o[nq + j] = E[m->lay.qd + j];
+  }
+  const pose peg = load_pose(E, m->lay.bpose, d.cube), tcp = load_pose(E, m->lay.bpose, d.tcp), box = load_pose(E, m->lay.bpose, d.goal);
+  const pose lf = load_pose(E, m->lay.bpose, d.left_finger), rf = load_pose(E, m->lay.bpose, d.right_finger);
+  const float hl = tb.half[e * 3], hr1 = tb.half[e * 3 + 1], hr2 = tb.half[e * 3 + 2], rr = tb.radius[e];
+  const pose hole = pose_mul(box, pose_from_p(tb.hole[e * 3], tb.hole[e * 3 + 1], tb.hole[e * 3 + 2]));
+  const pose head = pose_mul(peg, pose_from_p(hl, 0.0f, 0.0f));
+  const v3 inside = pose_mul(pose_inv(hole), head).p;                       /* peg head in the hole's frame */
+  const bool success = -0.015f <= inside.x && -rr <= inside.y && inside.y <= rr && -rr <= inside.z && inside.z <= rr;
+  /* is_grasping(max_angle=20): contact forces = impulses of the last substep / dt */
+  const float inv_dt = 1.0f / m->cfg.timestep;
+  const v3 lforce = v3_scale(pair_impulse(m, st, e, d.left_finger, d.cube), inv_dt);
+  const v3 rforce = v3_scale(pair_impulse(m, st, e, d.right_finger, d.cube), inv_dt);
+  const m33 Rl = quat_to_m33(lf.q), Rr = quat_to_m33(rf.q);
+  const v3 ldir = m33_col(&Rl, 1), rdir = v3_neg(m33_col(&Rr, 1));
+  const bool grasped = finger_grasps(lforce, ldir, d.min_force, cos_max_angle) && finger_grasps(rforce, rdir, d.min_force, cos_max_angle);
+  int k = 2 * nq;
+  o[k++] = tcp.p.x; o[k++] = tcp.p.y; o[k++] = tcp.p.z; o[k++] = tcp.q.w; o[k++] = tcp.q.x; o[k++] = tcp.q.y; o[k++] = tcp.q.z;
+  o[k++] = peg.p.x; o[k++] = peg.p.y; o[k++] = peg.p.z; o[k++] = peg.q.w; o[k++] = peg.q.x; o[k++] = peg.q.y; o[k++] = peg.q.z;
+  o[k++] = hl; o[k++] = hr1; o[k++] = hr2;
+  o[k++] = hole.p.x; o[k++] = hole.p.y; o[k++] = hole.p.z; o[k++] = hole.q.w; o[k++] = hole.q.x; o[k++] = hole.q.y; o[k++] = hole.q.z;
+  o[k++] = rr;
+  /* compute_normalized_dense_reward (peg_insertion_side.py:279-337) */
+  const float g = grasped ? 1.0f : 0.0f;
+  const v3 grip_target = pose_mul(peg, pose_from_p(-0.06f, 0.0f, 0.0f)).p;
+  float r = 1.0f - tanhf(4.0f * v3_norm_plain(v3_sub(tcp.p, grip_target)));
+  r += g;
+  const pose ginv = pose_inv(pose_mul(hole, pose_from_p(-hl, 0.0f, 0.0f)));   /* goal pose of the peg: head at the hole's centre */
+  const v3 head_g = pose_mul(ginv, head).p, peg_g = pose_mul(ginv, peg).p;
+  const float head_yz = sqrtf(head_g.y * head_g.y + head_g.z * head_g.z), peg_yz = sqrtf(peg_g.y * peg_g.y + peg_g.z * peg_g.z);
+  r += 3.0f * (1.0f - tanhf(0.5f * (head_yz + peg_yz) + 4.5f * fmaxf(head_yz, peg_yz))) * g;
+  const bool pre_inserted = head_yz < 0.01f && peg_yz < 0.01f;
+  r += 5.0f * (1.0f - tanhf(5.0f * v3_norm_plain(inside))) * ((grasped && pre_inserted) ? 1.0f : 0.0f);
+  if (success) r = 10.0f;
+  reward[e] = r / 10.0f;
+  head_at_hole[e * 3] = inside.x; head_at_hole[e * 3 + 1] = inside.y; head_at_hole[e * 3 + 2] = inside.z;
+  const int el = elapsed[e] + (advance ? 1 : 0);
+  elapsed[e] = el;
+  uint8_t* f = flags + (size_t)e * 8;
+  f[0] = success; f[1] = 0; f[2] = 0; f[3] = grasped;
+  f[4] = success;                       /* terminated */
+  f[5] = el >= d.max_episode_steps;     /* truncated (TimeLimitWrapper) */
+  f[6] = 0; f[7] = 0;
+}
+
 /* ---- PushT-v1 ------------------------------------------------------------------------------------------------------ */
 struct PushTTables {
   const unsigned short* src;   /* [nsrc] masked source pixels of the T in its own frame: row << 8 | column (row-major order) */

@@ -48,9 +48,29 @@ class PegInsertionSideEnv(PickCubeEnv):
     camera_eye, camera_target = (0.0, -0.3, 0.2), (0.0, 0.0, 0.1)     # base_camera (:93-96)
     rest_qpos = np.array([0.0, np.pi / 8, 0, -np.pi * 5 / 8, 0, np.pi * 3 / 4, -np.pi / 4, 0.04, 0.04])   # :225-236
 
-    def __init__(self, *args, **kw):
-        kw["fused"] = False
-        super().__init__(*args, **kw)
+    grasp_max_angle = 20.0      # is_grasping(max_angle=20) in the reward (:289)
+
+    def _init_fused_task(self):
+        # the controller kernels and control_step are PickCube's (cube = peg); evaluate / obs / reward are the peg's
+        import ctypes as C
+        fp = C.POINTER(C.c_float)
+        arrs = [np.ascontiguousarray(t.cpu().numpy(), dtype=np.float32) for t in (self.peg_half_sizes, self._hole_offset, self.box_hole_radii)]
+        L = self.px.lib
+        L.check(self.px.ctx, L.task_peg_init(self.px.ctx, *[a.ctypes.data_as(fp) for a in arrs]), "task_peg_init")
+
+    def _fused_observe(self, advance: bool):
+        import ctypes as C
+        L, px = self.px.lib, self.px
+        N, dev = self.num_envs, self.device
+        obs = torch.empty(N, self.obs_dim, dtype=torch.float32, device=dev)
+        rew = torch.empty(N, dtype=torch.float32, device=dev)
+        fl = torch.empty(N, 8, dtype=torch.bool, device=dev)
+        head = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        L.check(px.ctx, L.task_peg_observe(px.ctx, C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()), C.c_void_p(fl.data_ptr()),
+                                           C.c_void_p(self._elapsed_steps.data_ptr()), C.c_void_p(head.data_ptr()),
+                                           1 if advance else 0, px._stream()), "task_peg_observe")
+        info = dict(elapsed_steps=self._elapsed_steps.clone(), success=fl[:, 0], peg_head_pos_at_hole=head)
+        return self._with_sensor_data(obs), rew, fl[:, 4], fl[:, 5], info
 
     # ---- scene -----------------------------------------------------------------------------------------------------------
     def _build_template(self, arm_stiffness=None):

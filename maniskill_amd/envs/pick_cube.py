@@ -94,6 +94,7 @@ class PickCubeEnv:
     camera_eye, camera_target = (0.3, 0.0, 0.6), (-0.1, 0.0, 0.1)   # base_camera (pick_cube.py:64-71)
     rest_qpos = sb.PANDA_REST_QPOS       # TableSceneBuilder.initialize keyframe (scene_builder/table/scene_builder.py:67-103)
     goal_thresh = 0.025
+    grasp_max_angle = 85.0    # is_grasping's max_angle in the task's reward (panda.py:237)
     cube_half_size = 0.02
     cube_spawn_half_size = 0.1
     cube_spawn_center = (0.0, 0.0)
@@ -183,9 +184,10 @@ class PickCubeEnv:
             d = NN.PickCubeDesc(cube=self._b_cube, goal=self._b_goal, tcp=self._b_tcp, left_finger=self._b_f1, right_finger=self._b_f2,
                                 arm_dofs=7, arm_delta=self.arm_delta, gripper_mid=0.5 * (self.gripper_high + self.gripper_low),
                                 gripper_half=0.5 * (self.gripper_high - self.gripper_low),
-                                goal_thresh=self.goal_thresh, min_force=0.5, max_angle_deg=85.0, static_thresh=0.2,
+                                goal_thresh=self.goal_thresh, min_force=0.5, max_angle_deg=self.grasp_max_angle, static_thresh=0.2,
                                 max_episode_steps=self.max_episode_steps)
             self.px.lib.check(self.px.ctx, self.px.lib.task_pickcube_init(self.px.ctx, C.byref(d)), "task_pickcube_init")
+            self._init_fused_task()
         # sensors: PickCube-v1's base_camera (pick_cube.py:64-71), 128 x 128, fov pi/2, depth + segmentation textures
         if obs_mode not in ("state", "depth+segmentation", "rgb", "rgbd", "rgb+depth+segmentation"):
             raise NotImplementedError(f"obs_mode {obs_mode!r}: this backend provides 'state', 'depth+segmentation', 'rgb', 'rgbd' "
@@ -337,6 +339,9 @@ class PickCubeEnv:
         g = 0.5 * (self.gripper_high + self.gripper_low) + 0.5 * (self.gripper_high - self.gripper_low) * a[:, 7:8]
         self._target_qpos[:, 7:9] = g
         self._target_qpos_buf[:, :9] = self._target_qpos
+
+    def _init_fused_task(self):
+        """Hook: a task with its own fused evaluate / obs / reward kernel binds it here (the pickcube binding is in place)."""
 
     def _build_template(self, arm_stiffness=None):
         return sb.build_pick_cube_template(self.cube_half_size, arm_stiffness=arm_stiffness)

@@ -67,7 +67,9 @@ class StepGraph:
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: API calls of other host threads (RCCL's watchdog polling its events, a data loader) must not
+        # invalidate this thread's capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = step_fn(self.action)
         self.replays = 0
 

@@ -52,14 +52,16 @@ def test_hip_matches_oracle_rollout(oracle_factory):
     gpu = PegInsertionSideEnv(num_envs=n, device="cuda:0", obs_mode="rgb+depth+segmentation")
     cpu = PegInsertionSideEnv(num_envs=n, px_factory=oracle_factory, obs_mode="rgb+depth+segmentation")
     og, _ = gpu.reset(seed=2022); oc, _ = cpu.reset(seed=2022)
-    assert torch.equal(og["state"].cpu(), oc["state"])
+    # the GPU env runs the fused task kernel (env-frame poses), the oracle env the torch task code (world poses minus the scene
+    # offset): the same physics bits, observations within fp32 rounding of that round trip
+    assert torch.allclose(og["state"].cpu(), oc["state"], atol=2e-6)
     gen = torch.Generator().manual_seed(0)
     for t in range(30):
         a = 2 * torch.rand(n, 8, generator=gen) - 1
         og, rg, tg, ug, _ = gpu.step(a.to("cuda:0"))
         oc, rc, tc, uc, _ = cpu.step(a)
         assert np.allclose(og["state"].cpu().numpy(), oc["state"].numpy(), rtol=1e-4, atol=1e-5), t
-        assert np.allclose(rg.cpu().numpy(), rc.numpy(), atol=1e-5) and torch.equal(tg.cpu(), tc)
+        assert np.allclose(rg.cpu().numpy(), rc.numpy(), atol=2e-5) and torch.equal(tg.cpu(), tc)
     cg, cc = og["sensor_data"]["base_camera"], oc["sensor_data"]["base_camera"]
     assert torch.equal(cg["rgb"].cpu(), cc["rgb"]) and torch.equal(cg["depth"].cpu(), cc["depth"])
     assert torch.equal(cg["segmentation"].cpu(), cc["segmentation"])
@@ -73,3 +75,37 @@ def test_hip_matches_oracle_rollout(oracle_factory):
     for _ in range(5):
         ig = gpu.step(None)[4]; ic = cpu.step(None)[4]
     assert ig["success"].all() and torch.equal(ig["success"].cpu(), ic["success"])
+
+
+@pytest.mark.gpu
+def test_fused_task_kernel_matches_torch_task_code():
+    """msk_task_peg_observe (include/msk_task.h) against the torch statement of evaluate / obs / reward on the same HIP
+    simulation: same physics bits, task arithmetic within fp32 rounding (the fused kernel works in the env frame, the torch code
+    on world poses minus the scene offset)."""
+    n = 128
+    fused = PegInsertionSideEnv(num_envs=n, device="cuda:0")
+    plain = PegInsertionSideEnv(num_envs=n, device="cuda:0", fused=False)
+    assert fused.fused and not plain.fused
+    of, _ = fused.reset(seed=7); op, _ = plain.reset(seed=7)
+    assert torch.allclose(of, op, atol=2e-6)
+    gen = torch.Generator().manual_seed(2)
+    for t in range(25):
+        a = (0.8 * (2 * torch.rand(n, 8, generator=gen) - 1)).to("cuda:0")
+        of, rf, tf, uf, inf_ = fused.step(a)
+        op, rp, tp, up, inp = plain.step(a)
+        assert torch.allclose(of, op, rtol=1e-5, atol=3e-6), t
+        assert torch.allclose(rf, rp, atol=2e-5) and torch.equal(tf, tp) and torch.equal(uf, up)
+        assert torch.allclose(inf_["peg_head_pos_at_hole"], inp["peg_head_pos_at_hole"], atol=3e-6)
+    assert torch.equal(fused.get_state(), plain.get_state())           # the simulations themselves are bit-identical
+    # success, reward 1 and termination for inserted pegs through the fused kernel as well
+    for env in (fused, plain):
+        goal = env.goal_pose
+        env._rbd[:, env._b_cube, :3] = goal[:, :3] + env._offsets
+        env._rbd[:, env._b_cube, 3:7] = goal[:, 3:7]
+        env._rbd[:, env._b_cube, 7:13] = 0.0
+        env.px.gpu_apply_all(); env.px.gpu_fetch_all()
+    for _ in range(3):
+        sf, sp = fused.step(None), plain.step(None)
+    ok = sf[4]["success"]                       # (an arm left in the way by the random rollout may knock a peg out again)
+    assert ok.float().mean() > 0.9 and torch.equal(ok, sp[4]["success"]) and torch.equal(sf[2], sp[2])
+    assert torch.allclose(sf[1][ok], torch.ones(int(ok.sum()), device="cuda:0")) and torch.allclose(sf[1], sp[1], atol=2e-5)

@@ -40,7 +40,7 @@ def _state(obs):
 @pytest.mark.gpu
 def test_graph_replay_equals_eager_torch_task_path():
     from maniskill_amd.envs.peg_insertion_side import PegInsertionSideEnv
-    eager, graphed, _, _ = _rollout_pair(lambda: PegInsertionSideEnv(num_envs=96, device="cuda:0"), steps=12)
+    eager, graphed, _, _ = _rollout_pair(lambda: PegInsertionSideEnv(num_envs=96, device="cuda:0", fused=False), steps=12)
     # a partial reset between replays is eager work on the same persistent state: no re-capture
     idx = torch.tensor([0, 5, 17, 95], device="cuda:0")
     eager.reset(seed=9, options=dict(env_idx=idx))
