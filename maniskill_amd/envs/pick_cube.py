@@ -114,7 +114,8 @@ class PickCubeEnv:
         self.reward_mode = reward_mode
         # control modes of Panda._controller_configs (panda.py:187-200): joint deltas (default) or end-effector deltas through IK
         dims = {"pd_joint_delta_pos": 8, "pd_joint_pos": 8, "pd_joint_target_delta_pos": 8, "pd_joint_vel": 8,
-                "pd_ee_delta_pos": 4, "pd_ee_delta_pose": 7, "pd_ee_target_delta_pos": 4, "pd_ee_target_delta_pose": 7}
+                "pd_joint_pos_vel": 15, "pd_joint_delta_pos_vel": 15,
+                "pd_ee_delta_pos": 4, "pd_ee_delta_pose": 7, "pd_ee_pose": 7, "pd_ee_target_delta_pos": 4, "pd_ee_target_delta_pose": 7}
         if control_mode not in dims:
             raise NotImplementedError(f"control_mode {control_mode!r}: this backend provides {sorted(dims)}")
         self.control_mode = control_mode
@@ -287,7 +288,7 @@ class PickCubeEnv:
         # controller.reset(): targets = current qpos (pd_joint_pos.py:54-69)
         self._target_qpos[env_idx] = self._qpos[env_idx, :9]
         self._target_qpos_buf[env_idx, :9] = self._qpos[env_idx, :9]
-        if self.control_mode == "pd_joint_vel":
+        if self.control_mode in ("pd_joint_vel", "pd_joint_pos_vel", "pd_joint_delta_pos_vel"):
             self._target_qvel_buf[env_idx] = 0.0
         self.px.gpu_apply_all()
         self.px.gpu_update_articulation_kinematics()
@@ -467,11 +468,23 @@ class PickCubeEnv:
             self._target_qvel_buf[:, :7] = torch.clip(action[:, :7], -1.0, 1.0)
             self._target_qpos[:, 7:9] = self._gripper_target(action[:, 7:8])
             self._target_qpos[:, :7] = self.qpos[:, :7]       # stiffness 0: the position target of the arm joints is inert
-        else:                                 # pd_ee_target_delta_pos / pose: virtual target pose in the root frame (pd_ee_pose.py:104-129,239-253)
-            delta = self._ee_delta(action)
-            prev = self._target_pose
-            q = self._qmul(self._euler_xyz_to_quat(delta[:, 3:6]), prev[:, 3:7])        # root_aligned_body_rotation
-            target = torch.cat([prev[:, :3] + delta[:, :3], q], dim=-1)                # root_translation
+        elif mode in ("pd_joint_pos_vel", "pd_joint_delta_pos_vel"):   # PDJointPosVelController (pd_joint_pos_vel.py:40-66): [pos 7 | vel 7 | gripper]
+            if mode == "pd_joint_pos_vel":        # absolute, not normalised
+                self._target_qpos[:, :7] = action[:, :7]
+                self._target_qvel_buf[:, :7] = action[:, 7:14]
+            else:                                 # normalised: position deltas in +-0.1 rad, velocities in +-1 rad/s
+                a = torch.clip(action[:, :14], -1.0, 1.0)
+                self._target_qpos[:, :7] = self.qpos[:, :7] + self.arm_delta * a[:, :7]
+                self._target_qvel_buf[:, :7] = a[:, 7:14]
+            self._target_qpos[:, 7:9] = self._gripper_target(action[:, 14:15])
+        else:                                 # virtual / absolute target pose in the root frame (pd_ee_pose.py:104-129,239-262)
+            if mode == "pd_ee_pose":              # use_delta=False, normalize_action=False: [xyz | XYZ euler] of the target itself
+                target = torch.cat([action[:, :3], self._euler_xyz_to_quat(action[:, 3:6])], dim=-1)
+            else:                                 # pd_ee_target_delta_pos / pose: the delta accumulates on the previous target
+                delta = self._ee_delta(action)
+                prev = self._target_pose
+                q = self._qmul(self._euler_xyz_to_quat(delta[:, 3:6]), prev[:, 3:7])    # root_aligned_body_rotation
+                target = torch.cat([prev[:, :3] + delta[:, :3], q], dim=-1)            # root_translation
             self._target_pose = target
             cur = self.ee_pose_at_base()
             qci = cur[:, 3:7] * const((1.0, -1.0, -1.0, -1.0), cur.device)
@@ -484,7 +497,7 @@ class PickCubeEnv:
             self._target_qpos[:, 7:9] = self._gripper_target(action[:, na - 1:na])
         self._target_qpos_buf[:, :9] = self._target_qpos
         self.px.gpu_apply_articulation_target_position()
-        if mode == "pd_joint_vel":
+        if mode in ("pd_joint_vel", "pd_joint_pos_vel", "pd_joint_delta_pos_vel"):
             self.px.gpu_apply_articulation_target_velocity()
 
     def _step_action(self, action):

@@ -144,3 +144,42 @@ def test_the_other_panda_control_modes(oracle_factory):
     # euler helpers invert each other
     r = torch.tensor([[0.3, -0.2, 0.5], [-1.0, 0.4, 0.1]])
     assert torch.allclose(PickCubeEnv._quat_to_euler_xyz(PickCubeEnv._euler_xyz_to_quat(r)), r, atol=1e-6)
+
+
+def test_absolute_ee_pose_and_pos_vel_modes(oracle_factory):
+    """pd_ee_pose (use_delta=False, normalize_action=False: panda.py:126-137, pd_ee_pose.py:254-262), pd_joint_pos_vel and
+    pd_joint_delta_pos_vel (pd_joint_pos_vel.py:40-66)."""
+    # absolute ee pose: the tcp converges on the commanded pose in the root frame (one LM step per control step)
+    env = PickCubeEnv(num_envs=2, px_factory=oracle_factory, control_mode="pd_ee_pose")
+    assert env.action_dim == 7
+    env.reset(seed=0)
+    start = env.ee_pose_at_base()
+    want_p = start[:, :3] + torch.tensor([[0.05, -0.04, 0.06], [-0.03, 0.05, 0.04]])
+    want_e = PickCubeEnv._quat_to_euler_xyz(start[:, 3:7])
+    act = torch.hstack([want_p, want_e, torch.ones(2, 1)])
+    for _ in range(40):
+        env.step(act)
+    cur = env.ee_pose_at_base()
+    assert (cur[:, :3] - want_p).norm(dim=1).max() < 5e-3
+    assert torch.allclose(env._target_pose[:, :3], want_p, atol=1e-6)
+    dq = env._qmul(cur[:, 3:7], start[:, 3:7] * torch.tensor([1.0, -1, -1, -1]))
+    assert (2 * torch.atan2(dq[:, 1:].norm(dim=1), dq[:, 0].abs())).max() < 2e-2          # orientation held
+    # position + velocity targets, absolute: joint 0 is driven to the target position; at rest there the velocity target only
+    # adds D * v_t to the drive force, i.e. a steady offset of D v_t / K = 0.02 rad
+    env = PickCubeEnv(num_envs=1, px_factory=oracle_factory, control_mode="pd_joint_pos_vel")
+    assert env.action_dim == 15
+    env.reset(seed=0)
+    tgt = env.qpos[:, :7].clone(); tgt[:, 0] += 0.2
+    vel = torch.zeros(1, 7); vel[0, 0] = 0.2
+    act = torch.hstack([tgt, vel, torch.ones(1, 1)])
+    for _ in range(40):
+        env.step(act)
+    assert abs(env.qpos[0, 0].item() - (tgt[0, 0].item() + 1e2 * 0.2 / 1e3)) < 5e-3 and abs(env.qvel[0, 0].item()) < 2e-2
+    # normalised deltas: position part scaled by 0.1 rad, velocity part in rad/s, both clipped to [-1, 1]
+    env = PickCubeEnv(num_envs=1, px_factory=oracle_factory, control_mode="pd_joint_delta_pos_vel")
+    env.reset(seed=0)
+    q0 = env.qpos[0, :7].clone()
+    a = torch.zeros(1, 15); a[0, 1] = 3.0; a[0, 7 + 2] = -5.0
+    env.step(a)
+    assert abs(env._target_qpos[0, 1].item() - (q0[1].item() + 0.1)) < 1e-6
+    assert env._target_qvel_buf[0, 2].item() == -1.0 and env._target_qvel_buf[0, 0].item() == 0.0
