@@ -136,7 +136,14 @@ enum msk_buffer_id {
   MSK_BUF_RIGID_BODY_FORCE = 7,  /* px.cuda_rigid_body_force (structs/actor.py:316-322): (num_envs*NB, 4) f32
                                   * [fx fy fz -], world frame, at the centre of mass; same rows as buffer 0 */
   MSK_BUF_RIGID_BODY_TORQUE = 8, /* px.cuda_rigid_body_torque: (num_envs*NB, 4) f32 [tx ty tz -]            */
-  MSK_BUF_COUNT = 9
+  MSK_BUF_ART_LINK_JOINT_FORCES = 9, /* px.cuda_articulation_link_incoming_joint_forces (structs/articulation.py:596-620):
+                                  * (num_envs*NA*max_links, 6) f32, row = (env*NA + articulation)*max_links + link index
+                                  * (links of an articulation in build order), [fx fy fz tx ty tz]: the wrench the parent
+                                  * transmits through the link's inbound joint, at the origin and in the axes of the
+                                  * joint's child frame (x = joint axis); root link: the wrench that holds the fixed base,
+                                  * in the root link's frame.  msk_get_sizes()[7] is not involved; max_links = shape[0] /
+                                  * (num_envs*NA). */
+  MSK_BUF_COUNT = 10
 };
 void* msk_buffer(msk_ctx* ctx, int buffer_id, int64_t shape[2]);
 
@@ -161,7 +168,9 @@ enum msk_fetch_mask {
   MSK_FETCH_ART_QPOS = 1 << 1,
   MSK_FETCH_ART_QVEL = 1 << 2,
   MSK_FETCH_ART_QACC = 1 << 3,
-  MSK_FETCH_ART_TARGETS = 1 << 4
+  MSK_FETCH_ART_TARGETS = 1 << 4,
+  MSK_FETCH_ART_LINK_FORCES = 1 << 5 /* gpu_fetch_articulation_link_incoming_joint_forces: inverse dynamics of the state the
+                                      * last msk_step left (qacc, contact impulses / dt); not part of gpu_fetch_all        */
 };
 int msk_apply(msk_ctx* ctx, uint32_t mask, void* stream);
 int msk_fetch(msk_ctx* ctx, uint32_t mask, void* stream);

@@ -18,11 +18,11 @@ JOINT_FIXED, JOINT_REVOLUTE, JOINT_PRISMATIC = 0, 1, 2
 BODY_KINEMATIC, BODY_DYNAMIC, BODY_LINK = 1, 2, 3
 SHAPE_PLANE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_CONVEX = 0, 1, 2, 3
 (BUF_RIGID_BODY_DATA, BUF_ART_QPOS, BUF_ART_QVEL, BUF_ART_QACC, BUF_ART_QF, BUF_ART_TARGET_QPOS,
- BUF_ART_TARGET_QVEL, BUF_RIGID_BODY_FORCE, BUF_RIGID_BODY_TORQUE) = range(9)
+ BUF_ART_TARGET_QVEL, BUF_RIGID_BODY_FORCE, BUF_RIGID_BODY_TORQUE, BUF_ART_LINK_JOINT_FORCES) = range(10)
 APPLY_RIGID_DATA, APPLY_ART_QPOS, APPLY_ART_QVEL, APPLY_ART_QF = 1, 2, 4, 8
 APPLY_ART_TARGET_QPOS, APPLY_ART_TARGET_QVEL, APPLY_ART_ROOT_POSE = 16, 32, 64
 APPLY_RIGID_FORCE, APPLY_RIGID_TORQUE = 128, 256
-FETCH_RIGID_DATA, FETCH_ART_QPOS, FETCH_ART_QVEL, FETCH_ART_QACC, FETCH_ART_TARGETS = 1, 2, 4, 8, 16
+FETCH_RIGID_DATA, FETCH_ART_QPOS, FETCH_ART_QVEL, FETCH_ART_QACC, FETCH_ART_TARGETS, FETCH_ART_LINK_FORCES = 1, 2, 4, 8, 16, 32
 
 EXPORTS = [
     "create", "destroy", "last_error", "add_articulation", "add_link", "set_drive", "add_tendon",

@@ -432,6 +432,121 @@ __global__ void __launch_bounds__(256) k_apply(const DModel* __restrict__ m, DSt
   }
 }
 
+/* gpu_fetch_articulation_link_incoming_joint_forces: inverse dynamics of the state the last step left (see the statement in
+ * oracle/orc_sim.c orc_link_joint_forces, mirrored here operation by operation).  On demand, not on the step path: one
+ * lane per env, serial over the tree, per-lane arrays in scratch.  out: [N][na][max_links][6]; link_slot[body] = row of a
+ * link within its articulation. */
+struct LinkSlots { signed char slot[MSK_MAX_BODIES]; int max_links; };
+
+__global__ void __launch_bounds__(64) k_link_forces(const DModel* __restrict__ m, DState st, LinkSlots ls, float* __restrict__ out) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= m->N) return;
+  const float* E = EREC(st, m, e);
+  const float inv_dt = 1.0f / m->cfg.timestep;
+  const v3 g = v3_make(m->cfg.gravity[0], m->cfg.gravity[1], m->cfg.gravity[2]);
+  pose T[MSK_MAX_BODIES];
+  sv6 V[MSK_MAX_BODIES], f[MSK_MAX_BODIES], acc[MSK_MAX_BODIES];
+  const int nb = m->nb;
+  for (int i = 0; i < nb; ++i) {
+    const DBody* b = &m->bodies[i];
+    T[i] = load_pose(E, m->lay.bpose, i);
+    V[i] = sv6_zero();
+    f[i] = sv6_zero();
+    acc[i] = sv6_zero();
+    if (b->kind != MSK_BODY_LINK) continue;
+    sv6 S = sv6_zero();
+    if (b->parent >= 0) {   /* the oracle's kinematics(): frame, joint subspace and spatial velocity from the parent's */
+      const pose Tj = pose_mul(T[b->parent], b->Xp);
+      const v3 axis = quat_rotate(Tj.q, v3_make(1, 0, 0));
+      pose Jq;
+      Jq.p = v3_make(0, 0, 0);
+      Jq.q = quat_make(1, 0, 0, 0);
+      if (b->jtype == MSK_JOINT_REVOLUTE) {
+        float sn, cs;
+        msk_sincos(0.5f * E[m->lay.q + b->dof], &sn, &cs);
+        Jq.q = quat_make(cs, sn, 0, 0);
+        S.a = axis;
+        S.l = v3_cross(Tj.p, axis);
+      } else if (b->jtype == MSK_JOINT_PRISMATIC) {
+        Jq.p = v3_make(E[m->lay.q + b->dof], 0, 0);
+        S.l = axis;
+      }
+      pose Ti = pose_mul(pose_mul(Tj, Jq), b->XcInv);
+      Ti.q = quat_normalize(Ti.q);
+      T[i] = Ti;
+      V[i] = V[b->parent];
+      if (b->dof >= 0) V[i] = sv6_madd(V[i], S, E[m->lay.qd + b->dof]);
+    }
+    const m33 R = quat_to_m33(T[i].q);
+    const v3 cw = v3_add(T[i].p, m33_mulv(&R, b->com));
+    float Iw[6];
+    sym6_rotate(&R, b->I6, Iw);
+    sinertia Isp;
+    const float mass = b->mass, cc = v3_dot(cw, cw);
+    Isp.m = mass;
+    Isp.h = v3_scale(cw, mass);
+    Isp.I[0] = Iw[0] + mass * (cc - cw.x * cw.x);
+    Isp.I[1] = Iw[1] + mass * (cc - cw.y * cw.y);
+    Isp.I[2] = Iw[2] + mass * (cc - cw.z * cw.z);
+    Isp.I[3] = Iw[3] - mass * (cw.x * cw.y);
+    Isp.I[4] = Iw[4] - mass * (cw.x * cw.z);
+    Isp.I[5] = Iw[5] - mass * (cw.y * cw.z);
+    if (b->parent >= 0) {
+      acc[i] = acc[b->parent];
+      if (b->dof >= 0) {
+        const float qd = E[m->lay.qd + b->dof];
+        const sv6 sq = {v3_scale(S.a, qd), v3_scale(S.l, qd)};
+        acc[i] = sv6_add(acc[i], sv6_crossm(V[b->parent], sq));
+        acc[i] = sv6_madd(acc[i], S, E[m->lay.qacc + b->dof]);
+      }
+    }
+    const sv6 Iv = sinertia_mul(&Isp, V[i]);
+    f[i] = sv6_add(sinertia_mul(&Isp, acc[i]), sv6_crossf(V[i], Iv));
+    if (!b->nograv) {
+      const v3 mg = v3_scale(g, mass);
+      f[i].a = v3_sub(f[i].a, v3_cross(cw, mg));
+      f[i].l = v3_sub(f[i].l, mg);
+    }
+  }
+  /* contact wrenches about the env origin: +F on body A, -F on body B (impulses of the last step / dt) */
+  const int* cnts = st.ct_cnt + (size_t)e * m->npp;
+  const float* recs = st.ct_rec + (size_t)e * m->npp * MSK_CT_REC;
+  for (int p = 0; p < m->np; ++p) {
+    const int cnt = cnts[p];
+    if (cnt == 0) continue;
+    const int ba = m->pinfo[p].ba, bb = m->pinfo[p].bb;
+    const bool la = ba >= 0 && m->bodies[ba].kind == MSK_BODY_LINK, lb = bb >= 0 && m->bodies[bb].kind == MSK_BODY_LINK;
+    if (!la && !lb) continue;
+    const float* rec = recs + (size_t)p * MSK_CT_REC;
+    const v3 n = v3_make(rec[0], rec[1], rec[2]);
+    v3 t1, t2;
+    msk_tangents(n, &t1, &t2);
+    for (int k = 0; k < cnt; ++k) {
+      const v3 pos = v3_make(rec[4 + k * 3 + 0], rec[4 + k * 3 + 1], rec[4 + k * 3 + 2]);
+      v3 F = v3_scale(n, rec[20 + k * 3 + 0]);
+      F = v3_madd(F, t1, rec[20 + k * 3 + 1]);
+      F = v3_madd(F, t2, rec[20 + k * 3 + 2]);
+      F = v3_scale(F, inv_dt);
+      const v3 Tq = v3_cross(pos, F);
+      if (la) { f[ba].a = v3_sub(f[ba].a, Tq); f[ba].l = v3_sub(f[ba].l, F); }
+      if (lb) { f[bb].a = v3_add(f[bb].a, Tq); f[bb].l = v3_add(f[bb].l, F); }
+    }
+  }
+  for (int i = nb - 1; i >= 0; --i) {
+    const DBody* b = &m->bodies[i];
+    if (b->kind == MSK_BODY_LINK && b->parent >= 0) f[b->parent] = sv6_add(f[b->parent], f[i]);
+  }
+  for (int i = 0; i < nb; ++i) {
+    const DBody* b = &m->bodies[i];
+    if (b->kind != MSK_BODY_LINK) continue;
+    const pose C = (b->parent >= 0) ? pose_mul(T[i], pose_inv(b->XcInv)) : T[i];
+    const v3 torque = v3_sub(f[i].a, v3_cross(C.p, f[i].l));   /* moved from the env origin to the frame's origin */
+    const v3 fl = quat_rotate(quat_conj(C.q), f[i].l), tl = quat_rotate(quat_conj(C.q), torque);
+    float* o = out + (((size_t)e * m->na + b->art) * ls.max_links + ls.slot[i]) * 6;
+    o[0] = fl.x; o[1] = fl.y; o[2] = fl.z; o[3] = tl.x; o[4] = tl.y; o[5] = tl.z;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_fetch(const DModel* __restrict__ m, DState st, DBuffers bf, unsigned mask, const int* __restrict__ art_dof0,
                                                const int* __restrict__ art_ndof) {
   const int N = m->N;

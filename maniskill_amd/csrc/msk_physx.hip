@@ -50,6 +50,7 @@ struct msk_ctx {
   int nverts_total;
   std::vector<float> h_xshape, h_xbody;   /* host mirrors of the per-env instance records [N][nxs | nxb][8] */
   float* d_wrench = nullptr;    /* [N][nb][8] external wrench of the next step (msk_apply FORCE / TORQUE) */
+  LinkSlots link_slots;         /* row of a link within its articulation (link incoming joint forces) */
   bool wrench_pending = false;
   size_t lds_solve = 0;  /* dynamic LDS of the solver launch */
   int solve_workers = 0; /* its one-env-per-wave workgroups */
@@ -493,6 +494,17 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   for (int b = MSK_BUF_ART_QPOS; b <= MSK_BUF_ART_TARGET_QVEL; ++b) ALLOC(c->bufs.buf[b], nart);
   ALLOC(c->bufs.buf[MSK_BUF_RIGID_BODY_FORCE], N * (size_t)m.nb * 4);
   ALLOC(c->bufs.buf[MSK_BUF_RIGID_BODY_TORQUE], N * (size_t)m.nb * 4);
+  {
+    int count[8] = {0};
+    c->link_slots.max_links = 0;
+    for (int i = 0; i < m.nb; ++i) {
+      c->link_slots.slot[i] = -1;
+      if (m.bodies[i].kind != MSK_BODY_LINK) continue;
+      c->link_slots.slot[i] = (signed char)count[m.bodies[i].art]++;
+      if (count[m.bodies[i].art] > c->link_slots.max_links) c->link_slots.max_links = count[m.bodies[i].art];
+    }
+  }
+  ALLOC(c->bufs.buf[MSK_BUF_ART_LINK_JOINT_FORCES], N * (size_t)(m.na > 0 ? m.na : 1) * (size_t)(c->link_slots.max_links > 0 ? c->link_slots.max_links : 1) * 6);
   ALLOC(c->d_wrench, N * (size_t)m.nb * 8);
   c->wrench_pending = false;
   c->bufs.max_dof = c->max_dof;
@@ -526,6 +538,7 @@ MSK_API void* msk_buffer(msk_ctx* c, int id, int64_t shape[2]) {
   if (!c->finalized || id < 0 || id >= MSK_BUF_COUNT) return nullptr;
   if (id == MSK_BUF_RIGID_BODY_DATA) { shape[0] = (int64_t)c->model.N * c->model.nb; shape[1] = 13; }
   else if (id == MSK_BUF_RIGID_BODY_FORCE || id == MSK_BUF_RIGID_BODY_TORQUE) { shape[0] = (int64_t)c->model.N * c->model.nb; shape[1] = 4; }
+  else if (id == MSK_BUF_ART_LINK_JOINT_FORCES) { shape[0] = (int64_t)c->model.N * c->model.na * c->link_slots.max_links; shape[1] = 6; }
   else { shape[0] = (int64_t)c->model.N * c->model.na; shape[1] = c->max_dof; }
   return c->bufs.buf[id];
 }
@@ -552,6 +565,11 @@ MSK_API int msk_fetch(msk_ctx* c, uint32_t mask, void* stream) {
   if (c->kin_dirty && (mask & MSK_FETCH_RIGID_DATA)) { /* link frames of the post-step (q, qd) */
     launch_kinematics(c->model, c->d_model, c->st, (hipStream_t)stream);
     c->kin_dirty = false;
+  }
+  if ((mask & MSK_FETCH_ART_LINK_FORCES) && c->model.na > 0) {
+    hipLaunchKernelGGL(k_link_forces, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, c->d_model, c->st, c->link_slots,
+                       c->bufs.buf[MSK_BUF_ART_LINK_JOINT_FORCES]);
+    if (!(mask & ~(uint32_t)MSK_FETCH_ART_LINK_FORCES)) { HIP_TRY(hipGetLastError()); return MSK_OK; }
   }
   hipLaunchKernelGGL(k_fetch, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->bufs, mask,
                      c->d_art_dof0, c->d_art_ndof);

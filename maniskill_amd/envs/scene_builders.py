@@ -63,12 +63,12 @@ def add_site(tpl: SceneTemplate, name, p=(0, 0, 0)):
 
 
 def add_panda(tpl: SceneTemplate, root_p=(-0.615, 0.0, 0.0), stiffness=1e3, damping=1e2, force_limit=100.0, arm_stiffness=None,
-              asset="panda_v2.json"):
+              asset="panda_v2.json", disable_gravity=True):
     """Panda with the drive properties of its controllers (panda.py:68-98,177-190); arm_stiffness = 0 is what
     PDJointVelController.set_drive_property sets on the arm joints (pd_joint_vel.py:25-38)."""
     model = load_model(asset)   # panda_v2.json; panda_v3.json = PandaWristCam (panda_wristcam.py:16-17)
     art = add_urdf_articulation(tpl, model, "panda", root_p=root_p, urdf_config=PANDA_URDF_CONFIG,
-                                disable_gravity=True)  # balance_passive_force (base_agent.py:263-282)
+                                disable_gravity=disable_gravity)  # True = balance_passive_force (base_agent.py:263-282)
     for k, bid in enumerate(tpl.art_active[art]):
         ks = stiffness if (arm_stiffness is None or k >= 7) else arm_stiffness
         tpl.set_drive(bid, ks, damping, force_limit, "force")

@@ -78,6 +78,7 @@ class SceneTemplate:
     def __init__(self):
         self.ops = []            # recorded C-ABI build calls
         self.body_names = []     # body id -> name
+        self.body_masses = []    # body id -> template mass (kinematic actors: 0)
         self.body_kind = []
         self.art_names = []
         self.art_links = []      # per articulation: list of body ids (link order)
@@ -105,6 +106,7 @@ class SceneTemplate:
                                       lo, hi, float(mass), list(map(float, com)), list(map(float, inertia6)),
                                       int(bool(disable_gravity)), float(armature), float(friction))))
         self.body_names.append(name)
+        self.body_masses.append(float(mass))
         self.body_kind.append(N.BODY_LINK)
         self.art_links[art].append(bid)
         self.joint_names[bid] = joint_name
@@ -129,6 +131,7 @@ class SceneTemplate:
                                        list(map(float, inertia6)), float(linear_damping), float(angular_damping),
                                        int(bool(disable_gravity)))))
         self.body_names.append(name)
+        self.body_masses.append(float(mass))
         self.body_kind.append(kind)
         return bid
 
@@ -308,6 +311,8 @@ class PhysxGpuSystem:
         self.cuda_articulation_target_qvel = handle(N.BUF_ART_TARGET_QVEL)
         self.cuda_rigid_body_force = handle(N.BUF_RIGID_BODY_FORCE)      # (rows, 4): Actor.apply_force (structs/actor.py:316-322)
         self.cuda_rigid_body_torque = handle(N.BUF_RIGID_BODY_TORQUE)
+        # (N * arts, max_links, 6) once viewed; Articulation.get_link_incoming_joint_forces (structs/articulation.py:596-620)
+        self.cuda_articulation_link_incoming_joint_forces = handle(N.BUF_ART_LINK_JOINT_FORCES)
         self._initialized = True
         # publish the initial state so that the torch-visible buffers are valid
         self.gpu_update_articulation_kinematics()
@@ -358,6 +363,13 @@ class PhysxGpuSystem:
     def gpu_fetch_articulation_qacc(self): self._fetch(N.FETCH_ART_QACC)
     def gpu_fetch_articulation_target_qpos(self): self._fetch(N.FETCH_ART_TARGETS)
     def gpu_fetch_articulation_target_qvel(self): self._fetch(N.FETCH_ART_TARGETS)
+    def gpu_fetch_articulation_link_incoming_joint_forces(self): self._fetch(N.FETCH_ART_LINK_FORCES)
+
+    def get_link_incoming_joint_forces(self) -> torch.Tensor:
+        """(num_envs * arts_per_env, max_links, 6) [fx fy fz tx ty tz] per link, fetched live like the reference does."""
+        self.gpu_fetch_articulation_link_incoming_joint_forces()
+        t = self.cuda_articulation_link_incoming_joint_forces.torch()
+        return t.view(self.num_envs * max(self.arts_per_env, 1), -1, 6)
 
     def gpu_fetch_all(self):
         """The eight calls of ManiSkillScene._gpu_fetch_all (scene.py:968-986) in one launch."""

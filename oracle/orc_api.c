@@ -232,6 +232,16 @@ ORC_EXPORT int orc_finalize(orc_ctx* c, int num_envs) {
     if (c->art_root[a] < 0) return fail(c, MSK_ERR_INVALID, "articulation without links");
     if (c->art_ndof[a] > c->max_dof) c->max_dof = c->art_ndof[a];
   }
+  c->max_links = 0;
+  {
+    int count[8] = {0};
+    for (int i = 0; i < c->nb; ++i) {
+      c->link_slot[i] = -1;
+      if (c->bodies[i].kind != MSK_BODY_LINK) continue;
+      c->link_slot[i] = count[c->bodies[i].art]++;
+      if (count[c->bodies[i].art] > c->max_links) c->max_links = count[c->bodies[i].art];
+    }
+  }
   c->npairs = 0;
   for (int i = 0; i < c->ns; ++i)
     for (int j = i + 1; j < c->ns; ++j)
@@ -267,6 +277,7 @@ ORC_EXPORT int orc_finalize(orc_ctx* c, int num_envs) {
   c->buf[MSK_BUF_RIGID_BODY_DATA] = (float*)calloc(nrb, sizeof(float));
   for (int b = MSK_BUF_ART_QPOS; b <= MSK_BUF_ART_TARGET_QVEL; ++b) c->buf[b] = (float*)calloc(nart, sizeof(float));
   c->buf[MSK_BUF_RIGID_BODY_FORCE] = (float*)calloc((size_t)num_envs * c->nb * 4, sizeof(float));
+  c->buf[MSK_BUF_ART_LINK_JOINT_FORCES] = (float*)calloc((size_t)num_envs * (c->na > 0 ? c->na : 1) * (c->max_links > 0 ? c->max_links : 1) * 6, sizeof(float));
   c->buf[MSK_BUF_RIGID_BODY_TORQUE] = (float*)calloc((size_t)num_envs * c->nb * 4, sizeof(float));
   c->wrench = (float*)calloc((size_t)num_envs * c->nb * 8, sizeof(float));
   c->wrench_pending = 0;
@@ -284,6 +295,7 @@ ORC_EXPORT void* orc_buffer(orc_ctx* c, int id, int64_t shape[2]) {
   if (!c->finalized || id < 0 || id >= MSK_BUF_COUNT) return NULL;
   if (id == MSK_BUF_RIGID_BODY_DATA) { shape[0] = (int64_t)c->num_envs * c->nb; shape[1] = 13; }
   else if (id == MSK_BUF_RIGID_BODY_FORCE || id == MSK_BUF_RIGID_BODY_TORQUE) { shape[0] = (int64_t)c->num_envs * c->nb; shape[1] = 4; }
+  else if (id == MSK_BUF_ART_LINK_JOINT_FORCES) { shape[0] = (int64_t)c->num_envs * c->na * c->max_links; shape[1] = 6; }
   else { shape[0] = (int64_t)c->num_envs * c->na; shape[1] = c->max_dof; }
   return c->buf[id];
 }
@@ -379,6 +391,14 @@ ORC_EXPORT int orc_fetch(orc_ctx* c, uint32_t mask, void* stream) {
           art_row(c, MSK_BUF_ART_TARGET_QVEL, e, a)[j] = env->qdt[d];
         }
       }
+    if (mask & MSK_FETCH_ART_LINK_FORCES) {
+      float w[MSK_MAX_BODIES * 6];
+      orc_link_joint_forces(c, &c->envs[e], w);
+      for (int i = 0; i < c->nb; ++i)
+        if (c->link_slot[i] >= 0)
+          memcpy(c->buf[MSK_BUF_ART_LINK_JOINT_FORCES] + (((size_t)e * c->na + c->bodies[i].art) * c->max_links + c->link_slot[i]) * 6,
+                 w + 6 * i, sizeof(float) * 6);
+    }
   }
   return MSK_OK;
 }

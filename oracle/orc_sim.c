@@ -287,6 +287,79 @@ static void dynamics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
   }
 }
 
+/* ---- link incoming joint forces (px.cuda_articulation_link_incoming_joint_forces, structs/articulation.py:596-620) ----
+ * Inverse dynamics of the state the last step left behind: with the link accelerations that go with qacc, the wrench a
+ * link's parent transmits through the link's inbound joint is
+ *     f_i = I_i a_i + v_i x* I_i v_i - (gravity + contact wrenches on link i) + sum over children f_c
+ * (Featherstone RNEA backward pass; contact forces = the last step's impulses / dt, so drives, limits and contacts are all
+ * accounted for).  Reported per link as [force | torque] at the origin of the joint's child frame, in that frame's axes
+ * (x = joint axis); the root link's row is the wrench the world applies to the fixed base, in the root link's frame.
+ * out: [nb][6], rows of bodies that are not links stay zero. */
+void orc_link_joint_forces(const orc_ctx* c, orc_env* e, float* out) {
+  orc_scratch s;
+  const float inv_dt = 1.0f / c->cfg.timestep;
+  const v3 g = v3_make(c->cfg.gravity[0], c->cfg.gravity[1], c->cfg.gravity[2]);
+  sv6 f[MSK_MAX_BODIES], acc[MSK_MAX_BODIES];
+  kinematics(c, e, &s);
+  memset(out, 0, sizeof(float) * 6 * (size_t)c->nb);
+  for (int i = 0; i < c->nb; ++i) {
+    const orc_body* b = &c->bodies[i];
+    if (b->kind != MSK_BODY_LINK) continue;
+    sinertia Isp;
+    const v3 cw = s.comw[i];
+    const float m = b->mass, cc = v3_dot(cw, cw);
+    Isp.m = m;
+    Isp.h = v3_scale(cw, m);
+    Isp.I[0] = s.Iw[i][0] + m * (cc - cw.x * cw.x);
+    Isp.I[1] = s.Iw[i][1] + m * (cc - cw.y * cw.y);
+    Isp.I[2] = s.Iw[i][2] + m * (cc - cw.z * cw.z);
+    Isp.I[3] = s.Iw[i][3] - m * (cw.x * cw.y);
+    Isp.I[4] = s.Iw[i][4] - m * (cw.x * cw.z);
+    Isp.I[5] = s.Iw[i][5] - m * (cw.y * cw.z);
+    if (b->parent < 0) {
+      acc[i] = sv6_zero();
+    } else {
+      acc[i] = acc[b->parent];
+      if (b->dof >= 0) {
+        sv6 sq = {v3_scale(s.S[i].a, e->qd[b->dof]), v3_scale(s.S[i].l, e->qd[b->dof])};
+        acc[i] = sv6_add(acc[i], sv6_crossm(s.V[b->parent], sq));
+        acc[i] = sv6_madd(acc[i], s.S[i], e->qacc[b->dof]);
+      }
+    }
+    sv6 Iv = sinertia_mul(&Isp, s.V[i]);
+    f[i] = sv6_add(sinertia_mul(&Isp, acc[i]), sv6_crossf(s.V[i], Iv));
+    if (!b->nograv) {
+      v3 mg = v3_scale(g, m);
+      f[i].a = v3_sub(f[i].a, v3_cross(cw, mg));
+      f[i].l = v3_sub(f[i].l, mg);
+    }
+  }
+  for (int k = 0; k < e->ncontacts; ++k) {   /* contact wrenches about the env origin: +F on body A, -F on body B */
+    const orc_contact* ct = &e->contacts[k];
+    v3 F = v3_scale(ct->n, ct->lam[0]);
+    F = v3_madd(F, ct->t1, ct->lam[1]);
+    F = v3_madd(F, ct->t2, ct->lam[2]);
+    F = v3_scale(F, inv_dt);
+    const v3 T = v3_cross(ct->pos, F);
+    if (ct->ba >= 0 && c->bodies[ct->ba].kind == MSK_BODY_LINK) { f[ct->ba].a = v3_sub(f[ct->ba].a, T); f[ct->ba].l = v3_sub(f[ct->ba].l, F); }
+    if (ct->bb >= 0 && c->bodies[ct->bb].kind == MSK_BODY_LINK) { f[ct->bb].a = v3_add(f[ct->bb].a, T); f[ct->bb].l = v3_add(f[ct->bb].l, F); }
+  }
+  for (int i = c->nb - 1; i >= 0; --i) {
+    const orc_body* b = &c->bodies[i];
+    if (b->kind != MSK_BODY_LINK) continue;
+    if (b->parent >= 0) f[b->parent] = sv6_add(f[b->parent], f[i]);
+  }
+  for (int i = 0; i < c->nb; ++i) {
+    const orc_body* b = &c->bodies[i];
+    if (b->kind != MSK_BODY_LINK) continue;
+    const pose C = (b->parent >= 0) ? pose_mul(e->bpose[i], pose_inv(b->XcInv)) : e->bpose[i];
+    const v3 torque = v3_sub(f[i].a, v3_cross(C.p, f[i].l));   /* moved from the env origin to the frame's origin */
+    const v3 fl = quat_rotate(quat_conj(C.q), f[i].l), tl = quat_rotate(quat_conj(C.q), torque);
+    float* o = out + 6 * i;
+    o[0] = fl.x; o[1] = fl.y; o[2] = fl.z; o[3] = tl.x; o[4] = tl.y; o[5] = tl.z;
+  }
+}
+
 /* ---- 3. collision ----------------------------------------------------------------- */
 static void collide(const orc_ctx* c, orc_env* e) {
   /* previous step's contacts, for warm starting: a new point inherits the impulses of the nearest

@@ -95,6 +95,8 @@ typedef struct orc_ctx {
   int ndisabled;
   int disabled[256][2];
   int max_dof;       /* per-articulation max dof (buffer width) */
+  int max_links;     /* per-articulation max link count */
+  int link_slot[MSK_MAX_BODIES]; /* index of a link within its articulation (build order), -1 for other bodies */
   int art_dof0[8], art_ndof[8];
   int num_envs;
   orc_env* envs;
@@ -120,5 +122,6 @@ int orc_collide_pair(const orc_ctx* c, const orc_env* e, int pair_index, orc_con
 /* orc_sim.c */
 void orc_forward_kinematics(const orc_ctx* c, orc_env* e);
 void orc_step_env(const orc_ctx* c, orc_env* e);
+void orc_link_joint_forces(const orc_ctx* c, orc_env* e, float* out);
 
 #endif

@@ -373,3 +373,35 @@ def test_external_wrench_matches_oracle(oracle_factory):
     assert _close(out[0].numpy(), out[1].numpy())
     moved = (out[1].view(n, -1, 13)[:, env._b_cube, :2] - out[1].view(n, -1, 13)[0, env._b_cube, :2]).abs().max()
     assert moved > 1e-3
+
+
+def test_link_incoming_joint_forces_match_oracle(oracle_factory):
+    """cuda_articulation_link_incoming_joint_forces: the inverse-dynamics kernel against the oracle's statement, on a Panda that
+    carries its own weight (known answers: tests/test_oracle_physics.py) and on PickCube rollouts where the arm is driven
+    around and pushes on the table and the cube (contact wrenches, accelerations, drive forces all present)."""
+    from test_oracle_physics import _panda_under_gravity
+
+    res = []
+    for fac in (lambda t, n, c: PhysxGpuSystem(torch.device(DEV), t, n, c), oracle_factory):
+        px, tpl = _panda_under_gravity(fac, 8)
+        tq = px.cuda_articulation_target_qpos.torch().view(8, -1)
+        tq[:, 1] += torch.linspace(-0.3, 0.3, 8).to(tq.device)      # every env swings to its own target
+        px.gpu_apply_articulation_target_position()
+        for _ in range(40):
+            px.step()
+        px.gpu_fetch_all()
+        res.append(px.get_link_incoming_joint_forces().cpu().clone())
+    assert res[0].shape == res[1].shape and res[1][:, 1, :3].norm(dim=-1).median() > 100.0   # (the last env's arm leans on the table)
+    assert np.allclose(res[0].numpy(), res[1].numpy(), rtol=1e-3, atol=2e-3)
+    n = 64
+    gen = torch.Generator().manual_seed(8)
+    acts = 2 * torch.rand(30, n, 8, generator=gen) - 1
+    out = []
+    for dev, fac in ((DEV, None), (None, oracle_factory)):
+        env = PickCubeEnv(num_envs=n, device=dev, fused=False) if fac is None else PickCubeEnv(num_envs=n, px_factory=fac)
+        env.reset(seed=11)
+        for k in range(30):
+            env.step(acts[k].to(env.device))
+        out.append(env.px.get_link_incoming_joint_forces().cpu().clone())
+    assert out[1].abs().max() > 1.0
+    assert np.allclose(out[0].numpy(), out[1].numpy(), rtol=1e-3, atol=2e-3)

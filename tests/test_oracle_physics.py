@@ -370,3 +370,65 @@ def test_a_force_of_m_g_upwards_cancels_gravity(oracle_factory):
     px.gpu_fetch_all()
     assert abs(float(rbd[0, cube, 9])) < 1e-5 and abs(float(rbd[0, cube, 2]) - 1.0) < 1e-5
     assert abs(float(rbd[1, cube, 9]) + 9.81 * 10 * px.timestep) < 1e-4                  # its neighbour falls freely
+
+
+def _panda_under_gravity(factory, n, gravity=True, dev=None):
+    """A Panda that has to carry itself (ManiSkill switches link gravity off -- balance_passive_force -- so the tasks' robots
+    have nothing to carry), held at its rest pose by its drives."""
+    from maniskill_amd.physx import SimConfig
+
+    tpl = SceneTemplate()
+    sb.add_panda(tpl, disable_gravity=not gravity)
+    sb.add_table_scene(tpl)
+    px = factory(tpl, n, SimConfig())
+    px.gpu_init()
+    px.set_scene_offsets(np.zeros((n, 3)))
+    rest = torch.tensor(sb.PANDA_REST_QPOS, dtype=torch.float32)
+    for buf in (px.cuda_articulation_qpos, px.cuda_articulation_target_qpos):
+        t = buf.torch().view(n, -1)
+        t[:, :9] = rest.to(t.device)
+    rbd = px.cuda_rigid_body_data.torch().view(n, px.bodies_per_env, 13)
+    rbd[:, tpl.body_id("panda_link0"), :7] = torch.tensor([-0.615, 0.0, 0.0, 1, 0, 0, 0], device=rbd.device)
+    rbd[:, tpl.body_id("table-workspace"), :7] = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)], device=rbd.device)
+    px.gpu_apply_all()
+    return px, tpl
+
+
+def test_link_incoming_joint_forces_carry_the_weight_above_them(oracle_factory):
+    """cuda_articulation_link_incoming_joint_forces + gpu_fetch_articulation_link_incoming_joint_forces
+    (structs/articulation.py:596-620): for an arm held still by its drives the wrench through a joint is the weight of
+    everything distal to it; a link with no children and no contacts carries its own weight; without gravity nothing."""
+    px, tpl = _panda_under_gravity(oracle_factory, 2)
+    for _ in range(150):
+        px.step()
+    px.gpu_fetch_all()
+    w = px.get_link_incoming_joint_forces()
+    names = tpl.body_names
+    order = [n for n in names if n.startswith("panda_")]
+    assert w.shape == (2, len(order), 6)
+    mass = dict(zip(names, tpl.body_masses))
+    g = 9.81
+    # the Panda is a chain with a two-finger fork at the hand: every link after X in build order hangs on X's joint
+    above = lambda first: sum(mass[n] for n in order[order.index(first):])
+    f = w[:, :, :3].norm(dim=-1)
+    for first in ("panda_link1", "panda_link4", "panda_hand"):
+        assert torch.allclose(f[:, order.index(first)], torch.full((2,), above(first) * g), rtol=2e-2), first
+    lf = order.index("panda_leftfinger")
+    assert torch.allclose(f[:, lf], torch.full((2,), mass["panda_leftfinger"] * g), rtol=3e-2)
+    # joint 1 turns about the vertical: the force along its axis (child-frame x) is the whole weight above it and its drive
+    # carries (almost) no torque
+    j1 = order.index("panda_link1")
+    assert torch.allclose(w[:, j1, 0].abs(), torch.full((2,), above("panda_link1") * g), rtol=2e-2) and w[:, j1, 3].abs().max() < 0.1
+    # joint 2 is horizontal: gravity loads its drive -- the torque about the joint axis is the drive force K (q_t - q) - D qd
+    j2 = order.index("panda_link2")
+    q = px.cuda_articulation_qpos.torch().view(2, -1)
+    qd = px.cuda_articulation_qvel.torch().view(2, -1)
+    qt = px.cuda_articulation_target_qpos.torch().view(2, -1)
+    drive = 1e3 * (qt[:, 1] - q[:, 1]) - 1e2 * qd[:, 1]
+    assert drive.abs().min() > 1.0 and torch.allclose(w[:, j2, 3].abs(), drive.abs(), rtol=5e-2)
+    # no gravity: nothing to carry
+    px0, _ = _panda_under_gravity(oracle_factory, 1, gravity=False)
+    for _ in range(30):
+        px0.step()
+    px0.gpu_fetch_all()
+    assert px0.get_link_incoming_joint_forces().abs().max() < 0.05
