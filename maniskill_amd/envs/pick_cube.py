@@ -661,7 +661,11 @@ class PickCubeEnv:
             s[:, :3] -= self._offsets
             return s
         root = actor(self._b_root)
-        return torch.hstack([actor(self._b_table), actor(self._b_cube), actor(self._b_goal), root, self.qpos, self.qvel])
+        return torch.hstack([actor(b) for b in self._state_actor_bodies()] + [root, self.qpos, self.qvel])
+
+    def _state_actor_bodies(self):
+        """Body ids behind ``state_actor_names`` (every non-static actor of the scene, in build order)."""
+        return [self._b_table, self._b_cube, self._b_goal]
 
     def set_state(self, state, env_idx=None):
         if env_idx is None:
@@ -670,12 +674,14 @@ class PickCubeEnv:
         if getattr(self, "fused", False) and getattr(self, "_buffers_stale", False):
             self.sync_buffers()
         off = self._offsets[env_idx]
-        for k, bid in enumerate([self._b_table, self._b_cube, self._b_goal, self._b_root]):
+        bodies = self._state_actor_bodies() + [self._b_root]
+        for k, bid in enumerate(bodies):
             s = state[:, 13 * k: 13 * (k + 1)].clone()
             s[:, :3] += off
             self._rbd[env_idx, bid, :] = s
-        self._qpos[env_idx, :9] = state[:, 52:61]
-        self._qvel[env_idx, :9] = state[:, 61:70]
+        o = 13 * len(bodies)
+        self._qpos[env_idx, :9] = state[:, o:o + 9]
+        self._qvel[env_idx, :9] = state[:, o + 9:o + 18]
         self.px.gpu_apply_all()
         self.px.gpu_update_articulation_kinematics()
         self.px.gpu_fetch_all()

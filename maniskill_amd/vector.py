@@ -24,8 +24,12 @@ def _registry():
         from .envs.push_cube import PushCubeEnv
         from .envs.push_t import PushTEnv
         from .envs.stack_cube import StackCubeEnv
+        from .envs.pull_cube import PullCubeEnv
+        from .envs.lift_peg_upright import LiftPegUprightEnv
+        from .envs.poke_cube import PokeCubeEnv
         ENVS.update({"PickCube-v1": PickCubeEnv, "PushCube-v1": PushCubeEnv, "StackCube-v1": StackCubeEnv, "PushT-v1": PushTEnv,
-                     "PegInsertionSide-v1": PegInsertionSideEnv})
+                     "PegInsertionSide-v1": PegInsertionSideEnv, "PullCube-v1": PullCubeEnv, "LiftPegUpright-v1": LiftPegUprightEnv,
+                     "PokeCube-v1": PokeCubeEnv})
     return ENVS
 
 
