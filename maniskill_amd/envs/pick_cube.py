@@ -158,6 +158,9 @@ class PickCubeEnv:
         self._q_lgrasp = self.px.gpu_create_contact_pair_impulse_query([(self._b_f1, self._b_cube)])
         self._q_rgrasp = self.px.gpu_create_contact_pair_impulse_query([(self._b_f2, self._b_cube)])
         self._offsets = self.px.scene_offsets  # (N, 3)
+        from ..structs import SceneView
+        self.scene = SceneView(self.px, fresh=self._fresh)   # Actor / Link / Articulation views (structs.py)
+        self.robot = self.scene.articulations[tpl.art_names[0]]
         dev = self.device
         self._rest_qpos = torch.tensor(sb.PANDA_REST_QPOS, dtype=torch.float32, device=dev)
         self._table_pose = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)],

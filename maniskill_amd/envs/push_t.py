@@ -69,6 +69,9 @@ class PushTEnv:
         self._qvel = self.px.cuda_articulation_qvel.torch().view(N, -1)
         self._target_qpos_buf = self.px.cuda_articulation_target_qpos.torch().view(N, -1)
         self._offsets = self.px.scene_offsets
+        from ..structs import SceneView
+        self.scene = SceneView(self.px, fresh=self._fresh)   # Actor / Link / Articulation views (structs.py)
+        self.robot = self.scene.articulations[tpl.art_names[0]]
         self._b_tee, self._b_goal, self._b_ee, self._b_table = ids["tee"], ids["goal_tee"], ids["goal_ee"], ids["table"]
         self._b_root, self._b_tcp = tpl.body_id("panda_link0"), tpl.body_id("panda_hand_tcp")
         self._table_pose = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)], dtype=torch.float32, device=dev)
