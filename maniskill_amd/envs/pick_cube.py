@@ -161,6 +161,12 @@ class PickCubeEnv:
         from ..structs import SceneView
         self.scene = SceneView(self.px, fresh=self._fresh)   # Actor / Link / Articulation views (structs.py)
         self.robot = self.scene.articulations[tpl.art_names[0]]
+        from .. import spaces
+        lim = np.array([tpl.joint_limits[b] for b in tpl.art_active[0]], dtype=np.float32)
+        self.single_action_space = spaces.panda_action_space(control_mode, lim)
+        self.action_space = spaces.batch_space(self.single_action_space, self.num_envs)
+        self.single_observation_space = spaces.Box(-np.inf, np.inf, (self.obs_dim,), np.float32)    # state part (obs_mode "state")
+        self.observation_space = spaces.batch_space(self.single_observation_space, self.num_envs)
         dev = self.device
         self._rest_qpos = torch.tensor(sb.PANDA_REST_QPOS, dtype=torch.float32, device=dev)
         self._table_pose = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)],

@@ -72,6 +72,9 @@ class PushTEnv:
         from ..structs import SceneView
         self.scene = SceneView(self.px, fresh=self._fresh)   # Actor / Link / Articulation views (structs.py)
         self.robot = self.scene.articulations[tpl.art_names[0]]
+        from .. import spaces
+        self.single_action_space = spaces.Box(-np.ones(7, np.float32), np.ones(7, np.float32), dtype=np.float32)   # pd_joint_delta_pos of PandaStick
+        self.action_space = spaces.batch_space(self.single_action_space, self.num_envs)
         self._b_tee, self._b_goal, self._b_ee, self._b_table = ids["tee"], ids["goal_tee"], ids["goal_ee"], ids["table"]
         self._b_root, self._b_tcp = tpl.body_id("panda_link0"), tpl.body_id("panda_hand_tcp")
         self._table_pose = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)], dtype=torch.float32, device=dev)

@@ -143,6 +143,8 @@ class RecordEpisode:
         return self.env.device
 
     def __getattr__(self, name):
+        if name == "env":   # not constructed yet (copy / pickle): no delegation target
+            raise AttributeError(name)
         return getattr(self.env, name)
 
     def _frame(self, action=None, reward=None, terminated=None, truncated=None, info=None):

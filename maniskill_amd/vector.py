@@ -49,6 +49,9 @@ class ManiSkillVectorEnv:
             env.enable_step_graph()
         self._env = env
         self.num_envs = env.num_envs
+        for name in ("single_action_space", "action_space", "single_observation_space", "observation_space"):
+            if hasattr(env, name):
+                setattr(self, name, getattr(env, name))
         self.auto_reset = auto_reset
         self.ignore_terminations = ignore_terminations
         self.record_metrics = record_metrics
