@@ -94,8 +94,10 @@ def test_registered_and_wrapped(oracle_factory):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cls", [PullCubeEnv, LiftPegUprightEnv, PokeCubeEnv])
-def test_hip_matches_oracle_rollout(oracle_factory, cls):
+@pytest.mark.parametrize("name", ["PullCube-v1", "LiftPegUpright-v1", "PokeCube-v1", "StackPyramid-v1"])
+def test_hip_matches_oracle_rollout(oracle_factory, name):
+    from maniskill_amd.vector import _registry
+    cls = _registry()[name]
     n = 48
     gpu, cpu = cls(num_envs=n, device="cuda:0"), cls(num_envs=n, px_factory=oracle_factory)
     og, _ = gpu.reset(seed=2022); oc, _ = cpu.reset(seed=2022)
@@ -107,3 +109,42 @@ def test_hip_matches_oracle_rollout(oracle_factory, cls):
         oc, rc, tc, uc, _ = cpu.step(a)
         assert np.allclose(og.cpu().numpy(), oc.numpy(), rtol=1e-4, atol=1e-5), t
         assert np.allclose(rg.cpu().numpy(), rc.numpy(), atol=1e-5) and torch.equal(tg.cpu(), tc)
+
+
+def test_stack_pyramid(oracle_factory):
+    """StackPyramid-v1 (stack_pyramid.py): placements keep their distance, the built pyramid is a success once the gripper is
+    away and it stands still, sparse reward."""
+    from maniskill_amd.envs.stack_pyramid import StackPyramidEnv
+
+    env = StackPyramidEnv(num_envs=6, px_factory=oracle_factory)
+    obs, info = env.reset(seed=0)
+    assert obs.shape == (6, 64) and not info["success"].any() and env.max_episode_steps == 250
+    P = [env._pose(b) for b in (env._b_cube, env._b_cubeB, env._b_cubeC)]
+    for i in range(3):
+        assert (P[i][:, 0].abs() <= 0.1 + 1e-6).all() and (P[i][:, 1].abs() <= 0.2 + 1e-6).all() and torch.allclose(P[i][:, 2], torch.full((6,), 0.02), atol=1e-6)
+        for j in range(i):
+            assert (torch.linalg.norm(P[i][:, :2] - P[j][:, :2], dim=1) > 2 * np.linalg.norm([0.02, 0.02]) - 1e-6).all()
+    tcp = env.tcp_pose
+    assert torch.allclose(obs[:, 18:25], tcp) and torch.allclose(obs[:, 25:32], P[0]) and torch.allclose(obs[:, 39:46], P[2])
+    assert torch.allclose(obs[:, 46:49], P[0][:, :3] - tcp[:, :3]) and torch.allclose(obs[:, 61:64], P[2][:, :3] - P[0][:, :3])
+    with pytest.raises(NotImplementedError):
+        StackPyramidEnv(num_envs=1, px_factory=oracle_factory, reward_mode="normalized_dense")
+    # build the pyramid by hand, away from the arm: A and B side by side (5 mm gap), C centred on top of both
+    base = torch.tensor([0.25, 0.3, 0.02])
+    ident = torch.tensor([1.0, 0, 0, 0])
+    for body, dp in ((env._b_cube, (-0.0225, 0.0, 0.0)), (env._b_cubeB, (0.0225, 0.0, 0.0)), (env._b_cubeC, (0.0, 0.0, 0.0405))):
+        env._rbd[:, body, :3] = base + torch.tensor(dp) + env._offsets
+        env._rbd[:, body, 3:7] = ident
+        env._rbd[:, body, 7:13] = 0.0
+    env.px.gpu_apply_all(); env.px.gpu_fetch_all()
+    for _ in range(20):
+        obs, rew, term, trunc, info = env.step(None)
+    assert info["success"].all() and term.all() and torch.equal(rew, torch.ones(6))
+    assert torch.allclose(env._pose(env._b_cubeC)[:, 2], torch.full((6,), 0.06), atol=2e-3)      # the top cube stays up there
+    # the top cube beside the others instead: no success, reward 0
+    env._rbd[:, env._b_cubeC, :3] = base + torch.tensor([0.0, 0.1, 0.0]) + env._offsets
+    env.px.gpu_apply_all(); env.px.gpu_fetch_all()
+    for _ in range(5):
+        obs, rew, term, trunc, info = env.step(None)
+    assert not info["success"].any() and torch.equal(rew, torch.zeros(6))
+    assert list(env.get_state_dict()["actors"]) == ["table-workspace", "cubeA", "cubeB", "cubeC"] and env.get_state().shape == (6, 13 * 4 + 13 + 18)
