@@ -388,8 +388,9 @@ class PickCubeEnv:
     def _qmul(a, b):
         w1, x1, y1, z1 = a.unbind(-1)
         w2, x2, y2, z2 = b.unbind(-1)
-        return torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
-                            w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], dim=-1)
+        q = torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                         w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], dim=-1)
+        return torch.where(q[..., :1] < 0, -q, q)   # quaternion_multiply standardises to a non-negative real part (rotation_conversions.py)
 
     def ee_jacobian(self) -> torch.Tensor:
         """(N, 6, 7) geometric Jacobian [linear; angular] of panda_hand_tcp in the root link's frame (what

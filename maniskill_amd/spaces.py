@@ -9,7 +9,8 @@ from __future__ import annotations
 import numpy as np
 
 try:   # optional
-    from gymnasium.spaces import Box as _GymBox  # type: ignore
+    import gymnasium as _gym  # type: ignore
+    _GymBox = _gym.spaces.Box if getattr(_gym, "__file__", None) else None    # a real installation, not a stand-in module
 except Exception:   # pragma: no cover
     _GymBox = None
 

@@ -24,8 +24,9 @@ from . import _native as N
 def _qmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     aw, ax, ay, az = a.unbind(-1)
     bw, bx, by, bz = b.unbind(-1)
-    return torch.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
-                        aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], dim=-1)
+    q = torch.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], dim=-1)
+    return torch.where(q[..., :1] < 0, -q, q)   # as quaternion_multiply of the reference: non-negative real part
 
 
 def _qrot(q: torch.Tensor, v: torch.Tensor) -> torch.Tensor:

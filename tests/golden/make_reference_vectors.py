@@ -1,0 +1,313 @@
+"""Golden vectors computed by the REFERENCE'S OWN CODE (run here, where /root/reference exists; the .npz travels).
+
+The physics of the reference lives in a binary wheel that cannot run here, but its task logic, controller action scaling, pose
+algebra and rotation conversions are plain torch code (tests/golden/_reference_stubs.py makes them importable).  This script
+  1. lets THIS package (CPU oracle backend) produce simulator states: random rollouts and the scripted pick-and-lift,
+  2. hands those states to the reference's unbound ``evaluate`` / ``_get_obs_extra`` / ``compute_normalized_dense_reward`` /
+     ``Panda.is_grasping`` / ``Panda.is_static`` / ``common.flatten_state_dict`` / controller ``_clip_and_scale_action`` / ``Pose`` /
+     ``rotation_conversions`` functions,
+  3. stores inputs and the reference's outputs in tests/golden/reference_vectors.npz.
+tests/test_reference_vectors.py replays the inputs through this package's host code and compares.
+
+Usage: python tests/golden/make_reference_vectors.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
+
+from _reference_stubs import Fake, install, ns  # noqa: E402
+
+install()
+
+from mani_skill.agents.controllers.pd_ee_pose import PDEEPoseController  # noqa: E402
+from mani_skill.agents.robots.panda.panda import Panda as RefPanda  # noqa: E402
+from mani_skill.envs.tasks import tabletop as ref_tasks  # noqa: E402
+from mani_skill.envs.tasks.tabletop.push_t import PushTEnv as RefPushT  # noqa: E402
+from mani_skill.utils import common as ref_common, gym_utils as ref_gym_utils  # noqa: E402
+from mani_skill.utils.geometry import rotation_conversions as rc  # noqa: E402
+from mani_skill.utils.structs.actor import Actor as RefActor  # noqa: E402
+from mani_skill.utils.structs.pose import Pose as RefPose  # noqa: E402
+
+from oracle_backend import OraclePhysxSystem  # noqa: E402
+from maniskill_amd.vector import _registry  # noqa: E402
+
+FAC = lambda tpl, n, cfg: OraclePhysxSystem(tpl, n, cfg)   # noqa: E731
+OUT = {}
+
+
+def put(prefix, **arrays):
+    for k, v in arrays.items():
+        OUT[f"{prefix}/{k}"] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+
+
+# ---------------------------------------------------------------------------------------------- pure functions
+def pure_functions():
+    g = torch.Generator().manual_seed(0)
+    e = (torch.rand(64, 3, generator=g) * 2 - 1) * torch.tensor([3.0, 1.4, 3.0])
+    q_from_e = rc.matrix_to_quaternion(rc.euler_angles_to_matrix(e, "XYZ"))
+    q = torch.randn(64, 4, generator=g); q = q / q.norm(dim=1, keepdim=True)
+    q2 = torch.randn(64, 4, generator=g); q2 = q2 / q2.norm(dim=1, keepdim=True)
+    v = torch.randn(64, 3, generator=g)
+    put("rot", euler=e, quat_from_euler=q_from_e, quat=q, euler_from_quat=rc.matrix_to_euler_angles(rc.quaternion_to_matrix(q), "XYZ"),
+        quat2=q2, quat_mul=rc.quaternion_multiply(q, q2), vec=v, quat_apply=rc.quaternion_apply(q, v))
+    p1, p2 = torch.randn(64, 3, generator=g), torch.randn(64, 3, generator=g)
+    a, b = RefPose.create_from_pq(p1, q), RefPose.create_from_pq(p2, q2)
+    put("pose", a=a.raw_pose, b=b.raw_pose, a_mul_b=(a * b).raw_pose, a_inv=a.inv().raw_pose, a_matrix=a.to_transformation_matrix())
+    act = torch.rand(64, 8, generator=g) * 4 - 2
+    put("clip_scale", action=act, arm=ref_gym_utils.clip_and_scale_action(act[:, :7], -0.1, 0.1),
+        gripper=ref_gym_utils.clip_and_scale_action(act[:, 7:], -0.01, 0.04))
+    # PDEEPoseController._clip_and_scale_action with Panda's pd_ee_delta_pose bounds (panda.py:111-123)
+    ctl = Fake(PDEEPoseController, config=ns(rot_lower=-0.1, rot_upper=0.1),
+               action_space_low=torch.tensor([-0.1] * 3 + [-0.1] * 3), action_space_high=torch.tensor([0.1] * 3 + [0.1] * 3))
+    act6 = torch.rand(64, 6, generator=g) * 3 - 1.5
+    put("ee_clip_scale", action=act6, out=PDEEPoseController._clip_and_scale_action(ctl, act6.clone()))
+    # flatten_state_dict: order of the nested keys, bools as floats
+    d = dict(agent=dict(qpos=torch.rand(5, 9, generator=g), qvel=torch.rand(5, 9, generator=g)),
+             extra=dict(is_grasped=torch.tensor([True, False, True, False, False]), tcp_pose=torch.rand(5, 7, generator=g), goal_pos=torch.rand(5, 3, generator=g)))
+    put("flatten", qpos=d["agent"]["qpos"], qvel=d["agent"]["qvel"], is_grasped=d["extra"]["is_grasped"], tcp_pose=d["extra"]["tcp_pose"],
+        goal_pos=d["extra"]["goal_pos"], out=ref_common.flatten_state_dict(d, use_torch=True))
+
+
+# ---------------------------------------------------------------------------------------------- task states from this package
+def rollout_states(name, n=6, steps=24, every=6, seed=3, **kw):
+    env = _registry()[name](num_envs=n, px_factory=FAC, **kw)
+    env.reset(seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    snaps = []
+    for t in range(steps):
+        env.step(0.8 * (2 * torch.rand(n, env.action_dim, generator=g) - 1))
+        if (t + 1) % every == 0:
+            snaps.append(env.get_state().clone())
+    return env, snaps
+
+
+def fake_agent(env, lforce, rforce):
+    """The reference's Panda with this package's link poses / joint state behind it."""
+    f1, f2 = ns(pose=RefPose.create(env._pose(env._b_f1))), ns(pose=RefPose.create(env._pose(env._b_f2)))
+    scene = ns(get_pairwise_contact_forces=lambda link, obj: lforce if link is f1 else rforce)
+    robot = ns(get_qvel=lambda: env.qvel, get_qpos=lambda: env.qpos,
+               get_qlimits=lambda: env.robot.qlimits)
+    return Fake(RefPanda, scene=scene, finger1_link=f1, finger2_link=f2, tcp=ns(pose=RefPose.create(env.tcp_pose)), robot=robot)
+
+
+def actor(env, body):
+    rows = env._rbd[:, body]
+    return Fake(RefActor, pose=RefPose.create(env._pose(body)), linear_velocity=rows[:, 7:10].clone(), angular_velocity=rows[:, 10:13].clone())
+
+
+def reference_outputs(ref_cls, fake, env):
+    info = ref_cls.evaluate(fake)
+    extra = ref_cls._get_obs_extra(fake, info)
+    obs = ref_common.flatten_state_dict(dict(agent=dict(qpos=env.qpos, qvel=env.qvel), extra=extra), use_torch=True)
+    if "sparse" in getattr(ref_cls, "SUPPORTED_REWARD_MODES", ("normalized_dense",)) and "normalized_dense" not in getattr(ref_cls, "SUPPORTED_REWARD_MODES", ("normalized_dense",)):
+        rew = info["success"].float()
+    else:
+        rew = ref_cls.compute_normalized_dense_reward(fake, obs=obs, action=None, info=info)
+    return info, obs, rew
+
+
+def synthetic_forces(n, g):
+    """Finger contact forces that exercise both sides of is_grasping's thresholds: |f| around 0.5 N, angles around the limits."""
+    mag = torch.rand(n, 1, generator=g) * 3.0 * (torch.rand(n, 1, generator=g) > 0.3)
+    d = torch.randn(n, 3, generator=g)
+    return mag * d / d.norm(dim=1, keepdim=True)
+
+
+def task_vectors(name, ref_cls, build_fake, solved=None, zero_forces=False, **kw):
+    env, snaps = rollout_states(name, **kw)
+    if solved is not None:   # states of the success branch: the last snapshot with the task solved by hand in the even envs
+        for variant in solved(env, snaps[-1].clone()):
+            keep = torch.arange(env.num_envs) % 2 == 1
+            variant[keep] = snaps[-1][keep]
+            snaps.append(variant)
+    g = torch.Generator().manual_seed(17)
+    rec = dict(state=[], lforce=[], rforce=[], obs=[], reward=[], success=[], grasp=[])
+    for st in snaps:
+        env.set_state(st)
+        lf, rf = synthetic_forces(env.num_envs, g), synthetic_forces(env.num_envs, g)
+        # pull the synthetic forces towards the fingers' opening directions in half of the envs so that grasps do occur
+        ydir = RefPose.create(env._pose(env._b_f1)).to_transformation_matrix()[:, :3, 1]
+        half = torch.arange(env.num_envs) % 2 == 0
+        lf[half] = ydir[half] * (0.3 + 2 * torch.rand(int(half.sum()), 1, generator=g))
+        rf[half] = -RefPose.create(env._pose(env._b_f2)).to_transformation_matrix()[half, :3, 1] * (0.3 + 2 * torch.rand(int(half.sum()), 1, generator=g))
+        if zero_forces:
+            lf, rf = torch.zeros_like(lf), torch.zeros_like(rf)
+        agent = fake_agent(env, lf, rf)
+        fake = build_fake(env, agent)
+        info, obs, rew = reference_outputs(ref_cls, fake, env)
+        rec["state"].append(st); rec["lforce"].append(lf); rec["rforce"].append(rf)
+        rec["obs"].append(obs); rec["reward"].append(rew); rec["success"].append(info["success"])
+        rec["grasp"].append(RefPanda.is_grasping(agent, None, max_angle=kw.get("grasp_angle", 85)) if False else RefPanda.is_grasping(agent, None))
+    put(name, num_envs=np.array(env.num_envs), **{k: torch.stack(v) for k, v in rec.items()})
+    print(name, "snapshots", len(snaps), "obs", tuple(rec["obs"][0].shape), "successes", int(torch.stack(rec["success"]).sum()),
+          "grasps", int(torch.stack(rec["grasp"]).sum()))
+
+
+def camera_vectors():
+    """RenderCamera.get_extrinsic_matrix / get_model_matrix (structs/render_camera.py:77-145) for random camera poses."""
+    from mani_skill.utils.structs.render_camera import RenderCamera as RefCam
+
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(16, 4, generator=g); q = q / q.norm(dim=1, keepdim=True)
+    pose = RefPose.create_from_pq(torch.randn(16, 3, generator=g), q)
+    cam = Fake(RefCam, scene=ns(gpu_sim_enabled=True, device=torch.device("cpu")), mount=None, global_pose=pose,
+               _cached_extrinsic_matrix=None, _cached_model_matrix=None)
+    put("camera", pose=pose.raw_pose, extrinsic=RefCam.get_extrinsic_matrix(cam), model=RefCam.get_model_matrix(cam))
+
+
+def vector_env_vectors():
+    """ManiSkillVectorEnv.step / reset of the reference (vector/wrappers/gymnasium.py:104-184) on a scripted env: same-step auto
+    reset with final_observation / final_info, ignore_terminations, episode metrics."""
+    from mani_skill.vector.wrappers.gymnasium import ManiSkillVectorEnv as RefVec
+    from scripted_env import ScriptedEnv
+
+    for tag, (auto, ignore) in dict(auto=(True, False), ignore=(True, True), manual=(False, False)).items():
+        env = ScriptedEnv()
+        w = Fake(RefVec, _env=env, num_envs=env.num_envs, auto_reset=auto, ignore_terminations=ignore, record_metrics=True,
+                 success_once=torch.zeros(4, dtype=torch.bool), fail_once=torch.zeros(4, dtype=torch.bool), returns=torch.zeros(4))
+        RefVec.reset(w, seed=0)
+        rec = {k: [] for k in ("obs", "rew", "term", "trunc", "success_once", "fail_once", "ret", "ep_len", "has_final", "final_obs", "final_mask",
+                               "final_success_once", "final_ret")}
+        g = torch.Generator().manual_seed(1)
+        for t in range(12):
+            a = torch.rand(4, 2, generator=g)
+            obs, rew, term, trunc, infos = RefVec.step(w, a)
+            ep = infos["episode"] if "episode" in infos else infos["final_info"]["episode"]
+            rec["obs"].append(obs); rec["rew"].append(rew); rec["term"].append(term.clone()); rec["trunc"].append(trunc.clone())
+            has = "final_info" in infos
+            rec["has_final"].append(torch.tensor(has))
+            fi = infos["final_info"]["episode"] if has else ep
+            rec["final_obs"].append(infos["final_observation"] if has else torch.zeros_like(obs))
+            rec["final_mask"].append(infos["_final_info"] if has else torch.zeros(4, dtype=torch.bool))
+            rec["final_success_once"].append(fi["success_once"]); rec["final_ret"].append(fi["return"])
+            rec["success_once"].append(w.success_once.clone()); rec["fail_once"].append(w.fail_once.clone()); rec["ret"].append(w.returns.clone())
+            rec["ep_len"].append(env.elapsed_steps.clone())
+        put(f"vector/{tag}", **{k: torch.stack(v) for k, v in rec.items()})
+
+
+def pusht_vectors():
+    """PushT-v1: the reference's own _load_scene builds the pseudo-render tables (sapien calls land in mocks), then evaluate
+    (pseudo_render_intersection), _get_obs_extra and the pose-based reward run on this package's states; the T is also put on and
+    near its goal for the success branch."""
+    from unittest.mock import MagicMock
+
+    env, snaps = rollout_states("PushT-v1", n=6, steps=24, every=6)
+    ref = Fake(RefPushT, device=torch.device("cpu"), robot_init_qpos_noise=0.02, scene=MagicMock(), agent=MagicMock(),
+               obs_mode="state", obs_mode_struct=ns(use_state=True))
+    RefPushT._load_scene(ref, {})
+    put("PushT-tables", tee_render=ref.tee_render, world_to_goal_trans=ref.world_to_goal_trans, uv_grid=ref.uv_grid)
+    # [table | Tee | goal_Tee | goal_ee | root | qpos 7 | qvel 7]: the T on its goal, 4 mm / 1.5 deg off, 2 cm off
+    goal = snaps[-1][:, 26:33]
+    for dxy, dang in ((0.0, 0.0), (0.004, 0.026), (0.02, 0.1)):
+        st = snaps[-1].clone()
+        ang = 2 * torch.atan2(goal[:, 6], goal[:, 3]) + dang
+        st[:, 13:15] = goal[:, :2] + dxy; st[:, 15] = 0.02
+        st[:, 16:20] = torch.stack([(ang / 2).cos(), torch.zeros(6), torch.zeros(6), (ang / 2).sin()], dim=1)
+        st[:, 20:26] = 0.0
+        snaps.append(st)
+    rec = dict(state=[], obs=[], reward=[], success=[], intersection=[])
+    for st in snaps:
+        env.set_state(st)
+        ref.tee, ref.goal_tee = actor(env, env._b_tee), actor(env, env._b_goal)
+        ref.agent = ns(tcp=ns(pose=RefPose.create(env.tcp_pose)))
+        info = RefPushT.evaluate(ref)
+        extra = RefPushT._get_obs_extra(ref, info)
+        obs = ref_common.flatten_state_dict(dict(agent=dict(qpos=env.qpos, qvel=env.qvel), extra=extra), use_torch=True)
+        rew = RefPushT.compute_normalized_dense_reward(ref, obs=obs, action=None, info=info)
+        rec["state"].append(st); rec["obs"].append(obs); rec["reward"].append(rew); rec["success"].append(info["success"])
+        rec["intersection"].append(RefPushT.pseudo_render_intersection(ref))
+    put("PushT-v1", num_envs=np.array(env.num_envs), **{k: torch.stack(v) for k, v in rec.items()})
+    print("PushT-v1 snapshots", len(snaps), "successes", int(torch.stack(rec["success"]).sum()), "max intersection",
+          float(torch.stack(rec["intersection"]).max()))
+
+
+def main():
+    pure_functions()
+    T = ref_tasks
+    common_kw = dict(obs_mode="state", obs_mode_struct=ns(use_state=True), robot_uids="panda", device=torch.device("cpu"))
+    # flat state of the PickCube family: [table 13 | object 13 | goal 13 | root 13 | qpos 9 | qvel 9]
+    def on_goal(env, st, dz=0.0):
+        st[:, 13:16] = st[:, 26:29]; st[:, 15] += dz; st[:, 20:26] = 0.0; st[:, -9:] = 0.0
+        moving = st.clone(); moving[:, -9] = 0.5                       # object placed but the robot still moving
+        return [st, moving]
+
+    def on_region(env, st):
+        st[:, 13:15] = st[:, 26:28]; st[:, 15] = 0.02; st[:, 16:20] = torch.tensor([1.0, 0, 0, 0]); st[:, 20:26] = 0.0; st[:, -9:] = 0.0
+        return [st]
+
+    def upright(env, st):   # [table 13 | peg 13 | root 13 | qpos | qvel]; tilted up about the world y axis, keeping its roll
+        q = env._qmul(torch.tensor([[np.cos(-np.pi / 4), 0.0, np.sin(-np.pi / 4), 0.0]], dtype=torch.float32),
+                      torch.tensor([[np.cos(np.pi / 4), np.sin(np.pi / 4), 0.0, 0.0]], dtype=torch.float32))
+        st[:, 13:16] = torch.tensor([0.3, 0.3, 0.12]); st[:, 16:20] = q; st[:, 20:26] = 0.0
+        tilted = st.clone(); tilted[:, 15] = 0.13                     # upright but 1 cm too high
+        return [st, tilted]
+
+    task_vectors("PickCube-v1", T.PickCubeEnv, lambda env, agent: Fake(T.PickCubeEnv, agent=agent, cube=actor(env, env._b_cube),
+                 goal_site=actor(env, env._b_goal), goal_thresh=0.025, **common_kw), solved=on_goal)
+    task_vectors("PushCube-v1", T.PushCubeEnv, lambda env, agent: Fake(T.PushCubeEnv, agent=agent, obj=actor(env, env._b_cube),
+                 goal_region=actor(env, env._b_goal), **common_kw), solved=on_region)
+    task_vectors("PullCube-v1", T.PullCubeEnv, lambda env, agent: Fake(T.PullCubeEnv, agent=agent, obj=actor(env, env._b_cube),
+                 goal_region=actor(env, env._b_goal), **common_kw), solved=on_region)
+    task_vectors("LiftPegUpright-v1", T.LiftPegUprightEnv, lambda env, agent: Fake(T.LiftPegUprightEnv, agent=agent, peg=actor(env, env._b_cube), **common_kw),
+                 solved=upright)
+    # StackCube: [table | cubeA | cubeB | root | qpos | qvel]
+    def stacked(env, st):
+        st[:, 13:16] = st[:, 26:29]; st[:, 15] += 0.04; st[:, 16:20] = st[:, 29:33]; st[:, 20:26] = 0.0; st[:, 33:39] = 0.0; st[:, -9:] = 0.0
+        off = st.clone(); off[:, 13] += 0.03                         # 3 cm off centre: not "on"
+        return [st, off]
+    task_vectors("StackCube-v1", T.StackCubeEnv, lambda env, agent: Fake(T.StackCubeEnv, agent=agent, cubeA=actor(env, env._b_cube),
+                 cubeB=actor(env, env._b_goal), cube_half_size=torch.tensor([0.02] * 3), **common_kw), solved=stacked)
+
+    # PokeCube: [table | cube | peg | goal | root | qpos | qvel]
+    def poked(env, st):
+        st[:, 13:15] = st[:, 39:41]; st[:, 15] = 0.02; st[:, 20:26] = 0.0; st[:, -9:] = 0.0
+        # peg head against the cube, aligned with it: the "fit" branch
+        fit = st.clone(); fit[:, 29:33] = fit[:, 16:20]; fit[:, 26] = fit[:, 13] - 0.12 - 0.02; fit[:, 27] = fit[:, 14]
+        return [st, fit]
+    task_vectors("PokeCube-v1", T.PokeCubeEnv, lambda env, agent: Fake(T.PokeCubeEnv, agent=agent, cube=actor(env, env._b_poked),
+                 peg=actor(env, env._b_cube), goal_region=actor(env, env._b_goal),
+                 peg_head_offsets=RefPose.create_from_pq(p=[0.12, 0, 0]), **common_kw), solved=poked)
+
+    # PegInsertionSide: [table | peg | box | root | qpos | qvel]; per-env sizes are a function of the env index
+    def inserted(env, st):
+        goal = env.goal_pose
+        st[:, 13:20] = goal; st[:, 20:26] = 0.0
+        near = st.clone(); near[:, 13:16] -= env._qrot(goal[:, 3:7], torch.tensor([[0.03, 0.0, 0.0]]).repeat(len(st), 1))   # 3 cm short
+        return [st, near]
+
+    def peg_fake(env, agent):
+        head = torch.zeros(env.num_envs, 3); head[:, 0] = env.peg_half_sizes[:, 0]
+        return Fake(T.PegInsertionSideEnv, agent=agent, peg=actor(env, env._b_cube), box=actor(env, env._b_goal), peg_half_sizes=env.peg_half_sizes,
+                    box_hole_radii=env.box_hole_radii, box_hole_offsets=RefPose.create_from_pq(p=env._hole_offset),
+                    peg_head_offsets=RefPose.create_from_pq(p=head), **common_kw)
+    task_vectors("PegInsertionSide-v1", T.PegInsertionSideEnv, peg_fake, solved=inserted)
+
+    # StackPyramid: [table | A | B | C | root | qpos | qvel]; sparse reward
+    def pyramid(env, st):
+        base = torch.tensor([0.25, 0.3, 0.02]); ident = torch.tensor([1.0, 0, 0, 0])
+        for k, dp in enumerate(((-0.0225, 0.0, 0.0), (0.0225, 0.0, 0.0), (0.0, 0.0, 0.0405))):
+            o = 13 * (k + 1)
+            st[:, o:o + 3] = base + torch.tensor(dp); st[:, o + 3:o + 7] = ident; st[:, o + 7:o + 13] = 0.0
+        moving = st.clone(); moving[:, 39 + 7] = 0.05                 # the top cube still sliding
+        return [st, moving]
+    task_vectors("StackPyramid-v1", T.StackPyramidEnv, lambda env, agent: Fake(T.StackPyramidEnv, agent=agent, cubeA=actor(env, env._b_cube),
+                 cubeB=actor(env, env._b_cubeB), cubeC=actor(env, env._b_cubeC), cube_half_size=torch.tensor([0.02] * 3), **common_kw),
+                 solved=pyramid, zero_forces=True)
+    pusht_vectors()
+    camera_vectors()
+    vector_env_vectors()
+    np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **OUT)
+    print("wrote reference_vectors.npz:", len(OUT), "arrays")
+
+
+if __name__ == "__main__":
+    main()

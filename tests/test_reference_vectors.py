@@ -1,0 +1,144 @@
+"""This package's host code against vectors computed by the reference's own code (tests/golden/reference_vectors.npz, written by
+tests/golden/make_reference_vectors.py where /root/reference is importable): rotation conversions, pose algebra, controller action
+scaling, flatten order, Panda.is_grasping / is_static and, per task, evaluate / observation / normalized dense reward on simulator
+states produced by this package.  The physics itself stays unpinned against PhysX; everything around it is pinned
+here against the reference's arithmetic."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from maniskill_amd.envs.pick_cube import PickCubeEnv
+from maniskill_amd.structs import Pose
+from maniskill_amd.vector import _registry
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "reference_vectors.npz"))
+T = lambda k: torch.from_numpy(G[k])   # noqa: E731
+
+
+def test_rotation_conversions():
+    """utils/geometry/rotation_conversions.py: euler XYZ <-> quaternion (sign-free comparison), multiply, apply."""
+    q = PickCubeEnv._euler_xyz_to_quat(T("rot/euler"))
+    want = T("rot/quat_from_euler")
+    assert torch.minimum((q - want).abs().max(dim=1)[0], (q + want).abs().max(dim=1)[0]).max() < 1e-6
+    e = PickCubeEnv._quat_to_euler_xyz(T("rot/quat"))
+    assert torch.allclose(e, T("rot/euler_from_quat"), atol=2e-5)
+    assert torch.allclose(PickCubeEnv._qmul(T("rot/quat"), T("rot/quat2")), T("rot/quat_mul"), atol=1e-6)
+    assert torch.allclose(PickCubeEnv._qrot(T("rot/quat"), T("rot/vec")), T("rot/quat_apply"), atol=1e-5)
+
+
+def test_pose_algebra():
+    a, b = Pose(T("pose/a")), Pose(T("pose/b"))
+    assert torch.allclose((a * b).raw_pose, T("pose/a_mul_b"), atol=1e-5)
+    assert torch.allclose(a.inv().raw_pose, T("pose/a_inv"), atol=1e-5)
+    assert torch.allclose(a.to_transformation_matrix(), T("pose/a_matrix"), atol=1e-6)
+
+
+def test_controller_action_scaling(oracle_factory):
+    """gym_utils.clip_and_scale_action through PDJointPos(use_delta) + PDJointPosMimic, and PDEEPoseController's rotation clip."""
+    act = T("clip_scale/action")
+    env = PickCubeEnv(num_envs=len(act), px_factory=oracle_factory)
+    env.reset(seed=0)
+    q0 = env.qpos.clone()
+    env._set_action(act)
+    assert torch.allclose(env._target_qpos[:, :7] - q0[:, :7], T("clip_scale/arm"), atol=1e-6)
+    assert torch.allclose(env._target_qpos[:, 7:8], T("clip_scale/gripper"), atol=1e-7) and torch.equal(env._target_qpos[:, 7], env._target_qpos[:, 8])
+    ee = PickCubeEnv(num_envs=len(act), px_factory=oracle_factory, control_mode="pd_ee_delta_pose")
+    a7 = torch.cat([T("ee_clip_scale/action"), torch.zeros(len(act), 1)], dim=1)
+    assert torch.allclose(ee._ee_delta(a7), T("ee_clip_scale/out"), atol=1e-6)
+
+
+def test_flatten_order():
+    """common.flatten_state_dict: agent (qpos, qvel) then extra in insertion order, bools as floats -- PickCube's obs layout."""
+    mine = torch.hstack([T("flatten/qpos"), T("flatten/qvel"), T("flatten/is_grasped")[:, None].float(), T("flatten/tcp_pose"), T("flatten/goal_pos")])
+    assert torch.equal(mine, T("flatten/out"))
+
+
+TASKS = ["PickCube-v1", "PushCube-v1", "PullCube-v1", "LiftPegUpright-v1", "StackCube-v1", "PokeCube-v1", "PegInsertionSide-v1", "StackPyramid-v1"]
+
+
+@pytest.mark.parametrize("name", TASKS)
+def test_task_logic_matches_the_reference(oracle_factory, name):
+    n = int(G[f"{name}/num_envs"])
+    env = _registry()[name](num_envs=n, px_factory=oracle_factory)
+    env.reset(seed=0)
+    states, lf, rf = T(f"{name}/state"), T(f"{name}/lforce"), T(f"{name}/rforce")
+    seen_success = seen_grasp = 0
+    for k in range(len(states)):
+        env.set_state(states[k])
+        forces = {id(env._q_lgrasp): lf[k], id(env._q_rgrasp): rf[k]}
+        zero = torch.zeros(n, 3)
+        env.get_pairwise_contact_forces = lambda q: forces.get(id(q), zero)   # the recorded finger forces instead of the simulator's
+        grasp = env.is_grasping()
+        assert torch.equal(grasp, T(f"{name}/grasp")[k])                   # Panda.is_grasping (panda.py:237-265)
+        info = env.get_info()
+        obs = env.get_obs(info)
+        rew = env.get_reward(obs, None, info)
+        assert torch.equal(info["success"], T(f"{name}/success")[k]), k
+        assert torch.allclose(obs, T(f"{name}/obs")[k], atol=1e-6), k
+        assert torch.allclose(rew, T(f"{name}/reward")[k], atol=2e-6), k
+        seen_success += int(info["success"].sum()); seen_grasp += int(grasp.sum())
+    assert seen_success > 0 and (seen_grasp > 0 or name == "StackPyramid-v1")   # the fixture exercises the success and grasp branches
+
+
+def test_pusht_matches_the_reference(oracle_factory):
+    """PushT-v1 (push_t.py:256-540): the pseudo-render tables, the intersection ratio of every state, evaluate, observation and the
+    pose-based reward, all computed by the reference's code on this package's states."""
+    from maniskill_amd.envs.push_t import PushTEnv
+
+    n = int(G["PushT-v1/num_envs"])
+    env = PushTEnv(num_envs=n, px_factory=oracle_factory)
+    env.reset(seed=0)
+    assert torch.equal(env.tee_render.float(), T("PushT-tables/tee_render")) and torch.allclose(env.world_to_goal_trans, T("PushT-tables/world_to_goal_trans"), atol=1e-6)
+    states = T("PushT-v1/state")
+    for k in range(len(states)):
+        env.set_state(states[k])
+        assert torch.allclose(env.pseudo_render_intersection(), T("PushT-v1/intersection")[k], atol=1e-6), k
+        info = env.get_info()
+        assert torch.equal(info["success"], T("PushT-v1/success")[k])
+        assert torch.allclose(env.get_obs(info), T("PushT-v1/obs")[k], atol=1e-6)
+        assert torch.allclose(env.compute_normalized_dense_reward(info), T("PushT-v1/reward")[k], atol=2e-6)
+    assert T("PushT-v1/success").any() and not T("PushT-v1/success").all()
+
+
+def test_camera_matrices(oracle_factory):
+    """RenderCamera.get_extrinsic_matrix (OpenCV, ros2opencv @ inv(pose)) and get_model_matrix (pose * POSE_GL_TO_ROS) of the
+    reference for random camera poses (structs/render_camera.py:77-145)."""
+    poses = T("camera/pose")
+    env = PickCubeEnv(num_envs=len(poses), px_factory=oracle_factory, obs_mode="depth+segmentation")
+    cam = env.camera
+    cam.get_global_pose = lambda: poses
+    cam._cached_extrinsic = cam._cached_model = None
+    assert torch.allclose(cam.get_extrinsic_matrix(), T("camera/extrinsic"), atol=2e-6)
+    assert torch.allclose(cam.get_model_matrix(), T("camera/model"), atol=2e-6)
+
+
+@pytest.mark.parametrize("tag,auto,ignore", [("auto", True, False), ("ignore", True, True), ("manual", False, False)])
+def test_vector_env_wrapper_matches_the_reference(tag, auto, ignore):
+    """ManiSkillVectorEnv (vector/wrappers/gymnasium.py:104-184) on a scripted env: same-step auto reset, final_observation /
+    final_info, ignore_terminations, episode metrics -- step by step against the reference wrapper's recorded outputs."""
+    from maniskill_amd.vector import ManiSkillVectorEnv
+    from scripted_env import ScriptedEnv
+
+    env = ScriptedEnv()
+    w = ManiSkillVectorEnv(env, auto_reset=auto, ignore_terminations=ignore, record_metrics=True)
+    w.reset(seed=0)
+    R = lambda k: T(f"vector/{tag}/{k}")   # noqa: E731
+    g = torch.Generator().manual_seed(1)
+    saw_final = False
+    for t in range(12):
+        obs, rew, term, trunc, infos = w.step(torch.rand(4, 2, generator=g))
+        assert torch.equal(obs, R("obs")[t]) and torch.allclose(rew, R("rew")[t]) and torch.equal(term, R("term")[t]) and torch.equal(trunc, R("trunc")[t]), t
+        assert torch.equal(w.success_once, R("success_once")[t]) and torch.equal(w.fail_once, R("fail_once")[t]) and torch.allclose(w.returns, R("ret")[t])
+        assert torch.equal(env.elapsed_steps, R("ep_len")[t])
+        has = "final_info" in infos
+        assert has == bool(R("has_final")[t])
+        if has:
+            saw_final = True
+            assert torch.equal(infos["final_observation"], R("final_obs")[t]) and torch.equal(infos["_final_info"], R("final_mask")[t])
+            assert torch.equal(infos["_final_observation"], R("final_mask")[t])
+            ep = infos["final_info"]["episode"]
+            assert torch.equal(ep["success_once"], R("final_success_once")[t]) and torch.allclose(ep["return"], R("final_ret")[t])
+    assert saw_final == auto
