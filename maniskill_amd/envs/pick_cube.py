@@ -414,7 +414,7 @@ class PickCubeEnv:
     def _ee_delta(self, action: torch.Tensor) -> torch.Tensor:
         """_clip_and_scale_action of PDEEPos / PDEEPoseController (pd_ee_pose.py:224-237): (N, 6) delta pose in the root frame."""
         pos = self.ee_pos_bound * torch.clip(action[:, :3], -1.0, 1.0)
-        if self.control_mode == "pd_ee_delta_pos":
+        if self.control_mode in ("pd_ee_delta_pos", "pd_ee_target_delta_pos"):   # PDEEPosController: translation only
             return torch.hstack([pos, torch.zeros_like(pos)])
         rot = action[:, 3:6].clone()
         nrm = torch.linalg.norm(rot, dim=1)

@@ -194,6 +194,59 @@ def vector_env_vectors():
         put(f"vector/{tag}", **{k: torch.stack(v) for k, v in rec.items()})
 
 
+def ee_controller_vectors():
+    """PDEEPos / PDEEPoseController.set_action (pd_ee_pose.py:104-129) + Kinematics.compute_ik's GPU branch (kinematics.py:185-245)
+    for the five end-effector control modes of the Panda: the reference's code gets this package's Jacobian, joint state and link
+    poses (its own come from pytorch_kinematics / sapien) and produces the arm's joint targets."""
+    from mani_skill.agents.controllers.pd_ee_pose import PDEEPosController, PDEEPosControllerConfig, PDEEPoseControllerConfig
+    from mani_skill.agents.controllers.utils.kinematics import Kinematics
+
+    cfgs = {"pd_ee_delta_pos": (PDEEPosController, PDEEPosControllerConfig, dict(use_delta=True, use_target=False, normalize_action=True)),
+            "pd_ee_delta_pose": (PDEEPoseController, PDEEPoseControllerConfig, dict(use_delta=True, use_target=False, normalize_action=True)),
+            "pd_ee_target_delta_pos": (PDEEPosController, PDEEPosControllerConfig, dict(use_delta=True, use_target=True, normalize_action=True)),
+            "pd_ee_target_delta_pose": (PDEEPoseController, PDEEPoseControllerConfig, dict(use_delta=True, use_target=True, normalize_action=True)),
+            "pd_ee_pose": (PDEEPoseController, PDEEPoseControllerConfig, dict(use_delta=False, use_target=False, normalize_action=False))}
+    g = torch.Generator().manual_seed(9)
+    for mode, (ctl_cls, cfg_cls, flags) in cfgs.items():
+        env = _registry()["PickCube-v1"](num_envs=5, px_factory=FAC, control_mode=mode)
+        env.reset(seed=4)
+        pos_only = ctl_cls is PDEEPosController
+        adim = 3 if pos_only else 6
+        b = 0.1 if mode != "pd_ee_pose" else 2.0
+        extra = {} if pos_only else dict(rot_lower=-0.1, rot_upper=0.1)
+        cfg = cfg_cls(joint_names=[f"panda_joint{k}" for k in range(1, 8)], pos_lower=-b, pos_upper=b, stiffness=1e3, damping=1e2, force_limit=100,
+                      ee_link="panda_hand_tcp", urdf_path=None, **extra, **flags)      # the real config record (panda.py:101-137)
+        rec = dict(action=[], state=[], target=[])
+        target_pose = None
+        for step in range(4):
+            if mode == "pd_ee_pose":      # absolute targets near the current pose
+                cur = env.ee_pose_at_base()
+                arm = torch.cat([cur[:, :3] + 0.05 * (2 * torch.rand(5, 3, generator=g) - 1),
+                                 env._quat_to_euler_xyz(cur[:, 3:7]) + 0.1 * (2 * torch.rand(5, 3, generator=g) - 1)], dim=1)
+            else:
+                arm = 1.6 * (2 * torch.rand(5, adim, generator=g) - 1)
+            act = torch.cat([arm, 2 * torch.rand(5, 1, generator=g) - 1], dim=1)
+            J = env.ee_jacobian()
+            kin = Fake(Kinematics, use_gpu_ik=True, active_ancestor_joint_idxs=list(range(7)), qmask=torch.ones(7, dtype=torch.bool),
+                       pk_chain=ns(jacobian=lambda q, J=J: J), device=torch.device("cpu"))
+            sent = {}
+            ctl = Fake(ctl_cls, config=cfg, scene=ns(gpu_sim_enabled=True, num_envs=5), kinematics=kin, device=torch.device("cpu"),
+                       articulation=ns(get_qpos=lambda: env.qpos), active_joint_indices=torch.arange(7),
+                       ee_link=ns(pose=RefPose.create(env._rbd[:, env._b_tcp, :7].clone())), root_link=ns(pose=RefPose.create(env._rbd[:, env._b_root, :7].clone())),
+                       _target_pose=None if target_pose is None else RefPose.create(target_pose), _normalize_action=flags["normalize_action"],
+                       action_space=ns(shape=(5, adim)), action_space_low=torch.tensor([-b] * 3 + [-0.1] * 3)[:adim], action_space_high=torch.tensor([b] * 3 + [0.1] * 3)[:adim],
+                       set_drive_targets=lambda t: sent.__setitem__("t", t.clone()), _sim_steps=5)
+            if flags["use_target"] and target_pose is None:
+                ctl_cls.reset.__wrapped__(ctl) if hasattr(ctl_cls.reset, "__wrapped__") else object.__setattr__(ctl, "_target_pose", ctl.ee_pose_at_base)
+            ctl_cls.set_action(ctl, arm.clone())
+            if flags["use_target"]:
+                target_pose = ctl._target_pose.raw_pose.clone()
+            rec["action"].append(act); rec["state"].append(env.get_state().clone()); rec["target"].append(sent["t"])
+            env.step(act)
+        put(f"ee/{mode}", **{k: torch.stack(v) for k, v in rec.items()})
+        print("ee", mode, "targets", tuple(rec["target"][0].shape))
+
+
 def pusht_vectors():
     """PushT-v1: the reference's own _load_scene builds the pseudo-render tables (sapien calls land in mocks), then evaluate
     (pseudo_render_intersection), _get_obs_extra and the pose-based reward run on this package's states; the T is also put on and
@@ -305,6 +358,7 @@ def main():
     pusht_vectors()
     camera_vectors()
     vector_env_vectors()
+    ee_controller_vectors()
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **OUT)
     print("wrote reference_vectors.npz:", len(OUT), "arrays")
 

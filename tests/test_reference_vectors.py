@@ -142,3 +142,20 @@ def test_vector_env_wrapper_matches_the_reference(tag, auto, ignore):
             ep = infos["final_info"]["episode"]
             assert torch.equal(ep["success_once"], R("final_success_once")[t]) and torch.allclose(ep["return"], R("final_ret")[t])
     assert saw_final == auto
+
+
+@pytest.mark.parametrize("mode", ["pd_ee_delta_pos", "pd_ee_delta_pose", "pd_ee_target_delta_pos", "pd_ee_target_delta_pose", "pd_ee_pose"])
+def test_ee_controllers_match_the_reference(oracle_factory, mode):
+    """PDEEPos / PDEEPoseController.set_action + Kinematics.compute_ik (GPU branch) of the reference, fed with this package's
+    Jacobian and link poses, against this package's controller: the arm joint targets of four consecutive control steps (the
+    virtual-target modes carry their target pose from step to step)."""
+    acts, states, want = T(f"ee/{mode}/action"), T(f"ee/{mode}/state"), T(f"ee/{mode}/target")
+    env = PickCubeEnv(num_envs=acts.shape[1], px_factory=oracle_factory, control_mode=mode)
+    env.reset(seed=4)
+    for k in range(len(acts)):
+        assert torch.equal(env.get_state(), states[k])                       # the same rollout as when the vectors were made
+        env.step(acts[k])
+        # the LM system (7 joints, 6 task dimensions, lambda 1e-4) is ill-conditioned, so fp32 rounding of the Euler-angle round
+        # trips shows up at the 1e-4 level in the joint targets (measured: <= 9.5e-5 rad; 0 for the position-only delta mode)
+        got, ref = env._target_qpos[:, :7], want[k]
+        assert torch.allclose(got, ref, atol=3e-4), (k, (got - ref).abs().max())
