@@ -247,6 +247,73 @@ def ee_controller_vectors():
         print("ee", mode, "targets", tuple(rec["target"][0].shape))
 
 
+def joint_controller_vectors():
+    """PDJointPos / PDJointPosMimic / PDJointVel / PDJointPosVelController.set_action (agents/controllers/*.py) for the six joint-space
+    control modes of the Panda, three consecutive control steps each (use_target modes carry their targets)."""
+    from mani_skill.agents.controllers.pd_joint_pos import PDJointPosController, PDJointPosMimicController
+    from mani_skill.agents.controllers.pd_joint_pos_vel import PDJointPosVelController
+    from mani_skill.agents.controllers.pd_joint_vel import PDJointVelController
+
+    dev = torch.device("cpu")
+    arm = dict(pd_joint_delta_pos=(PDJointPosController, dict(use_delta=True, use_target=False), True, (-0.1, 0.1)),
+               pd_joint_target_delta_pos=(PDJointPosController, dict(use_delta=True, use_target=True), True, (-0.1, 0.1)),
+               pd_joint_pos=(PDJointPosController, dict(use_delta=False, use_target=False), False, None),
+               pd_joint_vel=(PDJointVelController, dict(), True, (-1.0, 1.0)),
+               pd_joint_pos_vel=(PDJointPosVelController, dict(use_delta=False, use_target=False), False, None),
+               pd_joint_delta_pos_vel=(PDJointPosVelController, dict(use_delta=True, use_target=False), True, (-0.1, 0.1)))
+    g = torch.Generator().manual_seed(12)
+    for mode, (cls, flags, normalize, bound) in arm.items():
+        env = _registry()["PickCube-v1"](num_envs=4, px_factory=FAC, control_mode=mode)
+        env.reset(seed=6)
+        n, adim = 4, env.action_dim - 1
+        tq_arm, tq_grip = env.qpos[:, :7].clone(), env.qpos[:, 7:9].clone()
+        rec = dict(action=[], qpos_target=[], qvel_target=[])
+        for step in range(3):
+            if mode in ("pd_joint_pos", "pd_joint_pos_vel"):
+                a_arm = torch.cat([env.qpos[:, :7] + 0.1 * (2 * torch.rand(n, 7, generator=g) - 1)] +
+                                  ([0.5 * (2 * torch.rand(n, 7, generator=g) - 1)] if adim == 14 else []), dim=1)
+            else:
+                a_arm = 1.5 * (2 * torch.rand(n, adim, generator=g) - 1)
+            a_grip = 1.5 * (2 * torch.rand(n, 1, generator=g) - 1)
+            sent = dict(vel=torch.zeros(n, 7))
+            art = ns(get_qpos=lambda: env.qpos, set_joint_drive_targets=lambda t, joints, idx: sent.__setitem__("pos" if len(idx) == 7 else "grip", t.clone()),
+                     set_joint_drive_velocity_targets=lambda t, joints, idx: sent.__setitem__("vel", t.clone()))
+            lo = None if bound is None else torch.tensor(([bound[0]] * 7 + ([-1.0] * 7 if adim == 14 else []))[:adim])
+            hi = None if bound is None else torch.tensor(([bound[1]] * 7 + ([1.0] * 7 if adim == 14 else []))[:adim])
+            ctl = Fake(cls, config=ns(interpolate=False, **flags), scene=ns(num_envs=n), articulation=art, joints=None, active_joint_indices=torch.arange(7),
+                       _target_qpos=tq_arm, _target_qvel=None, _normalize_action=normalize, action_space=ns(shape=(n, adim)), action_space_low=lo, action_space_high=hi, device=dev, _sim_steps=5)
+            cls.set_action(ctl, a_arm.clone())
+            if cls is not PDJointVelController:
+                tq_arm = ctl._target_qpos.clone()
+            grip = Fake(PDJointPosMimicController, config=ns(interpolate=False, use_delta=False, use_target=False), scene=ns(num_envs=n), articulation=art, joints=None,
+                        active_joint_indices=torch.tensor([7, 8]), control_joint_indices=torch.tensor([0]), mimic_joint_indices=torch.tensor([1]),
+                        mimic_control_joint_indices=torch.tensor([0]), _multiplier=torch.ones(1), _offset=torch.zeros(1), _target_qpos=tq_grip.clone(),
+                        _normalize_action=True, action_space=ns(shape=(n, 1)), action_space_low=torch.tensor([-0.01]), action_space_high=torch.tensor([0.04]), device=dev, _sim_steps=5)
+            PDJointPosMimicController.set_action(grip, a_grip.clone())
+            tq_grip = grip._target_qpos.clone()
+            act = torch.cat([a_arm, a_grip], dim=1)
+            rec["action"].append(act)
+            rec["qpos_target"].append(torch.cat([sent.get("pos", torch.full((n, 7), float("nan"))), sent["grip"]], dim=1))
+            rec["qvel_target"].append(sent["vel"])
+            env.step(act)
+        put(f"joint/{mode}", **{k: torch.stack(v) for k, v in rec.items()})
+        print("joint", mode, "action dim", adim + 1)
+
+
+def shader_vectors():
+    """render/shaders.py:66-84: the minimal pack's texture transforms on this package's rasterised textures."""
+    from mani_skill.render.shaders import PREBUILT_SHADER_CONFIGS
+
+    env = _registry()["PickCube-v1"](num_envs=2, px_factory=FAC, obs_mode="rgb+depth+segmentation")
+    env.reset(seed=0)
+    env.camera.take_picture()
+    pos = env.camera.get_picture_cuda().torch().clone()
+    col = env.camera.get_picture_cuda("Color").torch().clone()
+    tr = PREBUILT_SHADER_CONFIGS["minimal"].texture_transforms
+    out = dict(tr["PositionSegmentation"](pos)); out.update(tr["Color"](col))
+    put("shader", position_segmentation=pos, color=col, **out)
+
+
 def pusht_vectors():
     """PushT-v1: the reference's own _load_scene builds the pseudo-render tables (sapien calls land in mocks), then evaluate
     (pseudo_render_intersection), _get_obs_extra and the pose-based reward run on this package's states; the T is also put on and
@@ -359,6 +426,8 @@ def main():
     camera_vectors()
     vector_env_vectors()
     ee_controller_vectors()
+    joint_controller_vectors()
+    shader_vectors()
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **OUT)
     print("wrote reference_vectors.npz:", len(OUT), "arrays")
 

@@ -159,3 +159,31 @@ def test_ee_controllers_match_the_reference(oracle_factory, mode):
         # trips shows up at the 1e-4 level in the joint targets (measured: <= 9.5e-5 rad; 0 for the position-only delta mode)
         got, ref = env._target_qpos[:, :7], want[k]
         assert torch.allclose(got, ref, atol=3e-4), (k, (got - ref).abs().max())
+
+
+@pytest.mark.parametrize("mode", ["pd_joint_delta_pos", "pd_joint_target_delta_pos", "pd_joint_pos", "pd_joint_vel", "pd_joint_pos_vel", "pd_joint_delta_pos_vel"])
+def test_joint_controllers_match_the_reference(oracle_factory, mode):
+    """PDJointPos / PDJointPosMimic / PDJointVel / PDJointPosVelController.set_action of the reference over three consecutive control
+    steps: position targets of the arm and of the mimic gripper, velocity targets."""
+    acts, qt, vt = T(f"joint/{mode}/action"), T(f"joint/{mode}/qpos_target"), T(f"joint/{mode}/qvel_target")
+    env = PickCubeEnv(num_envs=acts.shape[1], px_factory=oracle_factory, control_mode=mode)
+    env.reset(seed=6)
+    for k in range(len(acts)):
+        env.step(acts[k])
+        if not torch.isnan(qt[k][:, 0]).any():          # the velocity controller sets no arm position target
+            assert torch.allclose(env._target_qpos[:, :7], qt[k][:, :7], atol=1e-6), k
+        assert torch.allclose(env._target_qpos[:, 7:9], qt[k][:, 7:9], atol=1e-7)
+        if mode in ("pd_joint_vel", "pd_joint_pos_vel", "pd_joint_delta_pos_vel"):
+            assert torch.allclose(env._target_qvel_buf[:, :7], vt[k], atol=1e-6)
+
+
+def test_shader_texture_transforms(oracle_factory):
+    """The minimal pack's texture transforms (render/shaders.py:66-84) applied by the reference to this package's textures ==
+    what Camera.get_obs hands out here."""
+    env = PickCubeEnv(num_envs=2, px_factory=oracle_factory, obs_mode="rgb+depth+segmentation")
+    env.reset(seed=0)
+    env.camera.take_picture()
+    assert torch.equal(env.camera.get_picture_cuda().torch(), T("shader/position_segmentation"))      # the same picture as when recorded
+    out = env.camera.get_obs(depth=True, segmentation=True, position=True, rgb=True)
+    for k in ("depth", "segmentation", "position", "rgb"):
+        assert torch.equal(out[k], T(f"shader/{k}")), k
