@@ -314,6 +314,38 @@ def shader_vectors():
     put("shader", position_segmentation=pos, color=col, **out)
 
 
+def constants_vectors():
+    """Numbers the reference fixes in Python: registered episode lengths, task constants, and what TableSceneBuilder.initialize (with
+    the noise switched off) hands to the robot and the table."""
+    from unittest.mock import MagicMock
+
+    from mani_skill.envs.tasks.tabletop.pick_cube_cfgs import PICK_CUBE_CONFIGS
+    from mani_skill.utils.registration import REGISTERED_ENVS
+    from mani_skill.utils.scene_builder.table import TableSceneBuilder
+
+    names = ["PickCube-v1", "PushCube-v1", "PullCube-v1", "StackCube-v1", "LiftPegUpright-v1", "PokeCube-v1", "PegInsertionSide-v1", "StackPyramid-v1", "PushT-v1"]
+    put("const", max_episode_steps=np.array([REGISTERED_ENVS[n].max_episode_steps for n in names]))
+    OUT["const/names"] = np.array(names)
+    c = PICK_CUBE_CONFIGS["panda"]
+    put("const/pickcube", values=np.array([c["cube_half_size"], c["goal_thresh"], c["cube_spawn_half_size"], c["max_goal_height"], *c["cube_spawn_center"],
+                                           *c["sensor_cam_eye_pos"], *c["sensor_cam_target_pos"]], dtype=np.float64))
+    T = ref_tasks
+    put("const/tasks", push_goal_radius=np.array(T.PushCubeEnv.goal_radius), pull_goal_radius=np.array(T.PullCubeEnv.goal_radius),
+        poke=np.array([T.PokeCubeEnv.cube_half_size, T.PokeCubeEnv.peg_half_width, T.PokeCubeEnv.peg_half_length, T.PokeCubeEnv.goal_radius]),
+        liftpeg=np.array([T.LiftPegUprightEnv.peg_half_width, T.LiftPegUprightEnv.peg_half_length]),
+        pusht=np.array([RefPushT.intersection_thresh, RefPushT.goal_z_rot, *RefPushT.goal_offset.tolist(), RefPushT.tee_spawnbox_xlength,
+                        RefPushT.tee_spawnbox_ylength, RefPushT.tee_spawnbox_xoffset, RefPushT.tee_spawnbox_yoffset], dtype=np.float64))
+    zero_rng = ns(normal=lambda mean, std, shape: np.zeros(shape))
+    for uid in ("panda", "panda_wristcam"):
+        agent = MagicMock()
+        env = ns(robot_uids=uid, _enhanced_determinism=False, _episode_rng=zero_rng, agent=agent)
+        b = Fake(TableSceneBuilder, env=env, table=MagicMock(), robot_init_qpos_noise=0.02)
+        TableSceneBuilder.initialize(b, torch.arange(3))
+        pose = agent.robot.set_pose.call_args[0][0]
+        table_pose = b.table.set_pose.call_args[0][0]
+        put(f"const/{uid}", rest_qpos=np.asarray(agent.reset.call_args[0][0])[0], root_p=np.asarray(pose.p), table_p=np.asarray(table_pose.p))
+
+
 def pusht_vectors():
     """PushT-v1: the reference's own _load_scene builds the pseudo-render tables (sapien calls land in mocks), then evaluate
     (pseudo_render_intersection), _get_obs_extra and the pose-based reward run on this package's states; the T is also put on and
@@ -428,6 +460,7 @@ def main():
     ee_controller_vectors()
     joint_controller_vectors()
     shader_vectors()
+    constants_vectors()
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **OUT)
     print("wrote reference_vectors.npz:", len(OUT), "arrays")
 

@@ -187,3 +187,31 @@ def test_shader_texture_transforms(oracle_factory):
     out = env.camera.get_obs(depth=True, segmentation=True, position=True, rgb=True)
     for k in ("depth", "segmentation", "position", "rgb"):
         assert torch.equal(out[k], T(f"shader/{k}")), k
+
+
+def test_constants_and_scene_initialisation():
+    """Registered episode lengths, task constants, the robots' rest keyframes and base / table placement as the reference's Python
+    states them (registration.py, pick_cube_cfgs.py, the task classes, TableSceneBuilder.initialize with its noise switched off)."""
+    from maniskill_amd.envs import scene_builders as sb
+    from maniskill_amd.envs.lift_peg_upright import LiftPegUprightEnv
+    from maniskill_amd.envs.peg_insertion_side import PegInsertionSideEnv
+    from maniskill_amd.envs.poke_cube import PokeCubeEnv
+    from maniskill_amd.envs.pull_cube import PullCubeEnv
+    from maniskill_amd.envs.push_cube import PushCubeEnv
+    from maniskill_amd.envs.push_t import PushTEnv
+
+    reg = _registry()
+    for name, steps in zip(G["const/names"].tolist(), G["const/max_episode_steps"].tolist()):
+        assert reg[name].max_episode_steps == steps, name
+    P = PickCubeEnv
+    mine = [P.cube_half_size, P.goal_thresh, P.cube_spawn_half_size, P.max_goal_height, *P.cube_spawn_center, *P.camera_eye, *P.camera_target]
+    assert np.allclose(mine, G["const/pickcube/values"])
+    assert PushCubeEnv.goal_radius == float(G["const/tasks/push_goal_radius"]) and PullCubeEnv.goal_radius == float(G["const/tasks/pull_goal_radius"])
+    K = PokeCubeEnv
+    assert np.allclose([K.cube_half_size, K.peg_half_width, K.peg_half_length, K.goal_radius], G["const/tasks/poke"])
+    assert np.allclose([LiftPegUprightEnv.peg_half_width, LiftPegUprightEnv.peg_half_length], G["const/tasks/liftpeg"])
+    S = PushTEnv
+    assert np.allclose([S.intersection_thresh, S.goal_z_rot, *S.goal_offset, S.tee_spawnbox_xlength, S.tee_spawnbox_ylength, S.tee_spawnbox_xoffset,
+                        S.tee_spawnbox_yoffset], G["const/tasks/pusht"], atol=1e-7)
+    assert np.allclose(sb.PANDA_REST_QPOS, G["const/panda/rest_qpos"]) and np.allclose(PegInsertionSideEnv.rest_qpos, G["const/panda_wristcam/rest_qpos"])
+    assert np.allclose(G["const/panda/root_p"], [-0.615, 0, 0]) and np.allclose(G["const/panda/table_p"], [-0.12, 0, -sb.TABLE_HEIGHT])
