@@ -8,7 +8,10 @@ Harness = the reference's ``mani_skill/examples/benchmarking/gpu_sim.py:90-108``
 over ranks.  Task-default frequencies (sim 100 Hz / control 20 Hz => 5 physics substeps per step,
 15 position + 1 velocity TGS iterations).  The 4096 envs are split over the ranks (strong
 scaling, BASELINE.json: "4096 parallel PickCube-v1 envs at 1/2/4/8 MI355X"); the only
-collective is one all-gather of (obs | reward | terminated | truncated) per step (dist.py).
+collective is one all-gather of (obs | reward | terminated | truncated) per step (dist.py), issued on
+RCCL's stream and waited for one step later, so it overlaps the next step's physics.  A control
+step (controller, 5 substeps, link frames, task kernel) is replayed as ONE captured HIP graph
+(maniskill_amd/graph.py; --no-graph launches kernel by kernel): same kernels, same order.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
