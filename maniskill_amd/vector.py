@@ -28,9 +28,10 @@ def _registry():
         from .envs.lift_peg_upright import LiftPegUprightEnv
         from .envs.poke_cube import PokeCubeEnv
         from .envs.stack_pyramid import StackPyramidEnv
+        from .envs.pull_cube_tool import PullCubeToolEnv
         ENVS.update({"PickCube-v1": PickCubeEnv, "PushCube-v1": PushCubeEnv, "StackCube-v1": StackCubeEnv, "PushT-v1": PushTEnv,
                      "PegInsertionSide-v1": PegInsertionSideEnv, "PullCube-v1": PullCubeEnv, "LiftPegUpright-v1": LiftPegUprightEnv,
-                     "PokeCube-v1": PokeCubeEnv, "StackPyramid-v1": StackPyramidEnv})
+                     "PokeCube-v1": PokeCubeEnv, "StackPyramid-v1": StackPyramidEnv, "PullCubeTool-v1": PullCubeToolEnv})
     return ENVS
 
 

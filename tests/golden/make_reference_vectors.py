@@ -95,7 +95,7 @@ def fake_agent(env, lforce, rforce):
     f1, f2 = ns(pose=RefPose.create(env._pose(env._b_f1))), ns(pose=RefPose.create(env._pose(env._b_f2)))
     scene = ns(get_pairwise_contact_forces=lambda link, obj: lforce if link is f1 else rforce)
     robot = ns(get_qvel=lambda: env.qvel, get_qpos=lambda: env.qpos,
-               get_qlimits=lambda: env.robot.qlimits)
+               get_qlimits=lambda: env.robot.qlimits, get_links=lambda: [ns(pose=RefPose.create(env._pose(env._b_root)))])
     return Fake(RefPanda, scene=scene, finger1_link=f1, finger2_link=f2, tcp=ns(pose=RefPose.create(env.tcp_pose)), robot=robot)
 
 
@@ -323,7 +323,8 @@ def constants_vectors():
     from mani_skill.utils.registration import REGISTERED_ENVS
     from mani_skill.utils.scene_builder.table import TableSceneBuilder
 
-    names = ["PickCube-v1", "PushCube-v1", "PullCube-v1", "StackCube-v1", "LiftPegUpright-v1", "PokeCube-v1", "PegInsertionSide-v1", "StackPyramid-v1", "PushT-v1"]
+    names = ["PickCube-v1", "PushCube-v1", "PullCube-v1", "StackCube-v1", "LiftPegUpright-v1", "PokeCube-v1", "PegInsertionSide-v1", "StackPyramid-v1", "PushT-v1",
+             "PullCubeTool-v1"]
     put("const", max_episode_steps=np.array([REGISTERED_ENVS[n].max_episode_steps for n in names]))
     OUT["const/names"] = np.array(names)
     c = PICK_CUBE_CONFIGS["panda"]
@@ -454,6 +455,14 @@ def main():
     task_vectors("StackPyramid-v1", T.StackPyramidEnv, lambda env, agent: Fake(T.StackPyramidEnv, agent=agent, cubeA=actor(env, env._b_cube),
                  cubeB=actor(env, env._b_cubeB), cubeC=actor(env, env._b_cubeC), cube_half_size=torch.tensor([0.02] * 3), **common_kw),
                  solved=pyramid, zero_forces=True)
+    # PullCubeTool: [table | cube | tool | root | qpos | qvel]
+    def pulled(env, st):
+        near = st.clone(); near[:, 13:15] = torch.tensor([-0.2, 0.05]); near[:, 15] = 0.02; near[:, 20:26] = 0.0          # within 0.6 m of the base
+        away = st.clone(); away[:, 13] = 0.55                                                                            # pushed out of reach: -2
+        hooked = st.clone(); hooked[:, 26:29] = hooked[:, 13:16] + torch.tensor([-(0.05 + 0.02), -0.067, 0.005]); hooked[:, 29:33] = torch.tensor([1.0, 0, 0, 0])
+        return [near, away, hooked]
+    task_vectors("PullCubeTool-v1", T.PullCubeToolEnv, lambda env, agent: Fake(T.PullCubeToolEnv, agent=agent, cube=actor(env, env._b_pulled),
+                 l_shape_tool=actor(env, env._b_cube), **common_kw), solved=pulled)
     pusht_vectors()
     camera_vectors()
     vector_env_vectors()

@@ -85,6 +85,29 @@ def test_poke_cube(oracle_factory):
     assert list(env.get_state_dict()["actors"]) == ["table-workspace", "cube", "peg", "goal_region"] and env.get_state().shape == (4, 83)
 
 
+def test_pull_cube_tool(oracle_factory):
+    """PullCubeTool-v1 (pull_cube_tool.py): the L-shaped tool is one actor of two boxes with the reference's densities (0.25 kg each,
+    centre of mass between them); layout, observation slices, success once the cube is near the base."""
+    from maniskill_amd.envs.pull_cube_tool import PullCubeToolEnv, _compound_box_mass
+
+    m, com, I = _compound_box_mass([((0.1, 0, 0), (0.1, 0.025, 0.025), 500.0), ((0.175, 0.05, 0), (0.025, 0.05, 0.025), 1000.0)])
+    assert abs(m - 0.5) < 1e-9 and np.allclose(com, (0.1375, 0.025, 0.0)) and I[2] > I[1] > I[0] > 0 and abs(I[3]) > 0   # xy product of inertia of an L
+    env = PullCubeToolEnv(num_envs=4, px_factory=oracle_factory)
+    obs, info = env.reset(seed=0)
+    assert obs.shape == (4, 39) and not info["success"].any() and env.max_episode_steps == 100
+    for _ in range(10):
+        obs, rew, term, trunc, info = env.step(None)
+    tool, cube = env.tool_pose, env.pulled_cube_pose
+    assert ((tool[:, :2] <= -0.1 + 1e-3) & (tool[:, :2] >= -0.3 - 1e-3)).all() and torch.allclose(tool[:, 2], torch.full((4,), 0.025), atol=1.5e-3)
+    assert ((cube[:, 0] >= 0.05 - 1e-3) & (cube[:, 0] <= 0.25 + 1e-3)).all() and torch.allclose(cube[:, 2], torch.full((4,), 0.02), atol=1.5e-3)
+    assert torch.allclose(obs[:, 25:32], cube) and torch.allclose(obs[:, 32:39], tool) and env.px.get_overflow() == 0
+    assert (tool[:, 3] > 0.9999).all()                                   # the L lies flat and does not tip about its offset centre of mass
+    _teleport(env, env._b_pulled, p=torch.tensor([[-0.2, 0.05, 0.02]]).repeat(4, 1))
+    obs, rew, term, trunc, info = env.step(None)
+    assert info["success"].all() and term.all() and (rew > 1.0).all()    # 5 (success) + reaching, / 5
+    assert list(env.get_state_dict()["actors"]) == ["table-workspace", "cube", "l_shape_tool"]
+
+
 def test_registered_and_wrapped(oracle_factory):
     for name, dim in (("PullCube-v1", 35), ("LiftPegUpright-v1", 32), ("PokeCube-v1", 54)):
         venv = ManiSkillVectorEnv(name, num_envs=2, px_factory=oracle_factory)
@@ -94,7 +117,7 @@ def test_registered_and_wrapped(oracle_factory):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["PullCube-v1", "LiftPegUpright-v1", "PokeCube-v1", "StackPyramid-v1"])
+@pytest.mark.parametrize("name", ["PullCube-v1", "LiftPegUpright-v1", "PokeCube-v1", "StackPyramid-v1", "PullCubeTool-v1"])
 def test_hip_matches_oracle_rollout(oracle_factory, name):
     from maniskill_amd.vector import _registry
     cls = _registry()[name]

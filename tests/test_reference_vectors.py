@@ -56,7 +56,7 @@ def test_flatten_order():
     assert torch.equal(mine, T("flatten/out"))
 
 
-TASKS = ["PickCube-v1", "PushCube-v1", "PullCube-v1", "LiftPegUpright-v1", "StackCube-v1", "PokeCube-v1", "PegInsertionSide-v1", "StackPyramid-v1"]
+TASKS = ["PickCube-v1", "PushCube-v1", "PullCube-v1", "LiftPegUpright-v1", "StackCube-v1", "PokeCube-v1", "PegInsertionSide-v1", "StackPyramid-v1", "PullCubeTool-v1"]
 
 
 @pytest.mark.parametrize("name", TASKS)
