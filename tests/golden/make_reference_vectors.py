@@ -347,6 +347,47 @@ def constants_vectors():
         put(f"const/{uid}", rest_qpos=np.asarray(agent.reset.call_args[0][0])[0], root_p=np.asarray(pose.p), table_p=np.asarray(table_pose.p))
 
 
+def episode_init_vectors():
+    """The reference's _initialize_episode of every task, 4000 sub-scenes at once on a fake env whose actors only record the poses
+    they are given: support (min / max) and mean of every placed actor's position and yaw -- the layout statistics this package's own
+    samplers (different RNG) have to reproduce."""
+    class Rec:
+        def __init__(self):
+            self.raw = None
+
+        def set_pose(self, pose):
+            self.raw = RefPose.create(pose).raw_pose.clone()
+
+    B = 4000
+    T = ref_tasks
+    base = dict(device=torch.device("cpu"), num_envs=B, table_scene=ns(initialize=lambda idx: None), scene_builder=ns(initialize=lambda idx: None))
+    jobs = {
+        "PickCube-v1": (T.PickCubeEnv, dict(cube="cube", goal_site="goal_site"), dict(cube_half_size=0.02, cube_spawn_half_size=0.1, cube_spawn_center=(0, 0), max_goal_height=0.3)),
+        "PushCube-v1": (T.PushCubeEnv, dict(obj="cube", goal_region="goal_region"), {}),
+        "PullCube-v1": (T.PullCubeEnv, dict(obj="cube", goal_region="goal_region"), {}),
+        "StackCube-v1": (T.StackCubeEnv, dict(cubeA="cubeA", cubeB="cubeB"), dict(cube_half_size=torch.tensor([0.02] * 3))),
+        "LiftPegUpright-v1": (T.LiftPegUprightEnv, dict(peg="peg"), {}),
+        "PokeCube-v1": (T.PokeCubeEnv, dict(peg="peg", cube="cube", goal_region="goal_region"), {}),
+        "PullCubeTool-v1": (T.PullCubeToolEnv, dict(l_shape_tool="l_shape_tool", cube="cube"), {}),
+        "StackPyramid-v1": (T.StackPyramidEnv, dict(cubeA="cubeA", cubeB="cubeB", cubeC="cubeC"), dict(cube_half_size=torch.tensor([0.02] * 3))),
+    }
+    for name, (cls, actors, extra) in jobs.items():
+        recs = {attr: Rec() for attr in actors}
+        fake = Fake(cls, **base, **recs, **extra)
+        torch.manual_seed(0)
+        cls._initialize_episode(fake, torch.arange(B), {})
+        for attr, mine in actors.items():
+            raw = recs[attr].raw
+            if raw.shape[1] < 7:   # the orientation came from transforms3d (a stand-in here): position statistics only
+                raw = torch.cat([raw[:, :3], torch.tensor([[1.0, 0, 0, 0]]).expand(len(raw), 4)], dim=1)
+            raw = raw.expand(B, 7) if raw.shape[0] == 1 else raw
+            yaw = 2 * torch.atan2(raw[:, 6], raw[:, 3])
+            yaw = torch.remainder(yaw + np.pi, 2 * np.pi) - np.pi
+            put(f"init/{name}/{mine}", pmin=raw[:, :3].min(0)[0], pmax=raw[:, :3].max(0)[0], pmean=raw[:, :3].mean(0),
+                yaw_min=yaw.min(), yaw_max=yaw.max(), qxy_absmax=raw[:, 4:6].abs().max())
+        print("init", name, {a: tuple(np.round(recs[a].raw[:, :3].mean(0).numpy(), 3)) for a in actors})
+
+
 def pusht_vectors():
     """PushT-v1: the reference's own _load_scene builds the pseudo-render tables (sapien calls land in mocks), then evaluate
     (pseudo_render_intersection), _get_obs_extra and the pose-based reward run on this package's states; the T is also put on and
@@ -470,6 +511,7 @@ def main():
     joint_controller_vectors()
     shader_vectors()
     constants_vectors()
+    episode_init_vectors()
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **OUT)
     print("wrote reference_vectors.npz:", len(OUT), "arrays")
 

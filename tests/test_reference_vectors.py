@@ -215,3 +215,32 @@ def test_constants_and_scene_initialisation():
                         S.tee_spawnbox_yoffset], G["const/tasks/pusht"], atol=1e-7)
     assert np.allclose(sb.PANDA_REST_QPOS, G["const/panda/rest_qpos"]) and np.allclose(PegInsertionSideEnv.rest_qpos, G["const/panda_wristcam/rest_qpos"])
     assert np.allclose(G["const/panda/root_p"], [-0.615, 0, 0]) and np.allclose(G["const/panda/table_p"], [-0.12, 0, -sb.TABLE_HEIGHT])
+
+
+INIT = {"PickCube-v1": dict(cube="_b_cube", goal_site="_b_goal"), "PushCube-v1": dict(cube="_b_cube", goal_region="_b_goal"),
+        "PullCube-v1": dict(cube="_b_cube", goal_region="_b_goal"), "StackCube-v1": dict(cubeA="_b_cube", cubeB="_b_goal"),
+        "LiftPegUpright-v1": dict(peg="_b_cube"), "PokeCube-v1": dict(peg="_b_cube", cube="_b_poked", goal_region="_b_goal"),
+        "PullCubeTool-v1": dict(l_shape_tool="_b_cube", cube="_b_pulled"), "StackPyramid-v1": dict(cubeA="_b_cube", cubeB="_b_cubeB", cubeC="_b_cubeC")}
+
+
+@pytest.mark.parametrize("name", sorted(INIT))
+def test_episode_layout_statistics(oracle_factory, name):
+    """Support and mean of every placed actor's position and yaw over 1500 fresh episodes against the reference's own
+    _initialize_episode (4000 sub-scenes on a recording fake): this package draws from its own per-env RNG streams, so the samples
+    differ but the distributions must not."""
+    n = 1500
+    env = _registry()[name](num_envs=n, px_factory=oracle_factory)
+    env.reset(seed=123)
+    for actor, attr in INIT[name].items():
+        raw = env._pose(getattr(env, attr))
+        R = lambda k: torch.from_numpy(np.atleast_1d(G[f"init/{name}/{actor}/{k}"]))   # noqa: E731
+        span = (R("pmax") - R("pmin")).clamp(min=1e-3)
+        tol = 0.03 * span + 1e-4
+        assert ((raw[:, :3].min(0)[0] - R("pmin")).abs() <= tol).all(), (actor, raw[:, :3].min(0)[0], R("pmin"))
+        assert ((raw[:, :3].max(0)[0] - R("pmax")).abs() <= tol).all(), (actor, raw[:, :3].max(0)[0], R("pmax"))
+        assert ((raw[:, :3].mean(0) - R("pmean")).abs() <= 0.05 * span + 1e-4).all(), (actor, raw[:, :3].mean(0), R("pmean"))
+        yaw = torch.remainder(2 * torch.atan2(raw[:, 6], raw[:, 3]) + np.pi, 2 * np.pi) - np.pi
+        ys = float(R("yaw_max") - R("yaw_min"))
+        if ys > 1e-3 and float(R("qxy_absmax")) < 1e-6:          # a yaw-only randomisation in the reference
+            assert abs(float(yaw.min() - R("yaw_min"))) <= 0.03 * ys + 1e-3 and abs(float(yaw.max() - R("yaw_max"))) <= 0.03 * ys + 1e-3, actor
+            assert raw[:, 4:6].abs().max() < 1e-6
