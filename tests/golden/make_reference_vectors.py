@@ -370,6 +370,14 @@ def episode_init_vectors():
         "PokeCube-v1": (T.PokeCubeEnv, dict(peg="peg", cube="cube", goal_region="goal_region"), {}),
         "PullCubeTool-v1": (T.PullCubeToolEnv, dict(l_shape_tool="l_shape_tool", cube="cube"), {}),
         "StackPyramid-v1": (T.StackPyramidEnv, dict(cubeA="cubeA", cubeB="cubeB", cubeC="cubeC"), dict(cube_half_size=torch.tensor([0.02] * 3))),
+        "PushT-v1": (RefPushT, dict(tee="Tee", goal_tee="goal_Tee", ee_goal_pos="goal_ee"), {}),
+        # per-env peg sizes drawn from the reference's ranges (peg_insertion_side.py:97-98): lengths U(0.085, 0.125), radii U(0.015, 0.025)
+        "PegInsertionSide-v1": (T.PegInsertionSideEnv, dict(peg="peg", box="box_with_hole"),
+                                dict(peg_half_sizes=torch.stack([torch.rand(B, generator=torch.Generator().manual_seed(1)) * 0.04 + 0.085,
+                                                                 torch.rand(B, generator=torch.Generator().manual_seed(2)) * 0.01 + 0.015,
+                                                                 torch.rand(B, generator=torch.Generator().manual_seed(2)) * 0.01 + 0.015], dim=1),
+                                     agent=__import__("unittest.mock").mock.MagicMock(), _enhanced_determinism=False, robot_init_qpos_noise=0.02,
+                                     _episode_rng=ns(normal=lambda m, sd, shape: np.zeros(shape)))),
     }
     for name, (cls, actors, extra) in jobs.items():
         recs = {attr: Rec() for attr in actors}

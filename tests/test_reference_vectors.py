@@ -220,7 +220,8 @@ def test_constants_and_scene_initialisation():
 INIT = {"PickCube-v1": dict(cube="_b_cube", goal_site="_b_goal"), "PushCube-v1": dict(cube="_b_cube", goal_region="_b_goal"),
         "PullCube-v1": dict(cube="_b_cube", goal_region="_b_goal"), "StackCube-v1": dict(cubeA="_b_cube", cubeB="_b_goal"),
         "LiftPegUpright-v1": dict(peg="_b_cube"), "PokeCube-v1": dict(peg="_b_cube", cube="_b_poked", goal_region="_b_goal"),
-        "PullCubeTool-v1": dict(l_shape_tool="_b_cube", cube="_b_pulled"), "StackPyramid-v1": dict(cubeA="_b_cube", cubeB="_b_cubeB", cubeC="_b_cubeC")}
+        "PullCubeTool-v1": dict(l_shape_tool="_b_cube", cube="_b_pulled"), "StackPyramid-v1": dict(cubeA="_b_cube", cubeB="_b_cubeB", cubeC="_b_cubeC"),
+        "PushT-v1": dict(Tee="_b_tee", goal_Tee="_b_goal", goal_ee="_b_ee"), "PegInsertionSide-v1": dict(peg="_b_cube", box_with_hole="_b_goal")}
 
 
 @pytest.mark.parametrize("name", sorted(INIT))
