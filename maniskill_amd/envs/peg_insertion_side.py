@@ -70,7 +70,7 @@ class PegInsertionSideEnv(PickCubeEnv):
                                            C.c_void_p(self._elapsed_steps.data_ptr()), C.c_void_p(head.data_ptr()),
                                            1 if advance else 0, px._stream()), "task_peg_observe")
         info = dict(elapsed_steps=self._elapsed_steps.clone(), success=fl[:, 0], peg_head_pos_at_hole=head)
-        return self._with_sensor_data(obs), rew, fl[:, 4], fl[:, 5], info
+        return self._with_sensor_data(obs), self._fused_reward(rew, info), fl[:, 4], fl[:, 5], info
 
     # ---- scene -----------------------------------------------------------------------------------------------------------
     def _build_template(self, arm_stiffness=None):

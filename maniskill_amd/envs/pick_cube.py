@@ -111,6 +111,8 @@ class PickCubeEnv:
         self.num_envs = int(num_envs)
         self.sim_config = sim_config or SimConfig()
         self.robot_init_qpos_noise = robot_init_qpos_noise
+        if reward_mode not in ("normalized_dense", "dense", "sparse", "none"):
+            raise NotImplementedError(f"reward_mode {reward_mode!r}: one of 'normalized_dense', 'dense', 'sparse', 'none' (sapien_env.py:648-670)")
         self.reward_mode = reward_mode
         # control modes of Panda._controller_configs (panda.py:187-200): joint deltas (default) or end-effector deltas through IK
         dims = {"pd_joint_delta_pos": 8, "pd_joint_pos": 8, "pd_joint_target_delta_pos": 8, "pd_joint_vel": 8,
@@ -537,7 +539,7 @@ class PickCubeEnv:
                                                 1 if advance else 0, px._stream()), "task_pickcube_observe")
         info = dict(elapsed_steps=self._elapsed_steps.clone(), success=fl[:, 0], is_obj_placed=fl[:, 1], is_robot_static=fl[:, 2],
                     is_grasped=fl[:, 3])
-        return self._with_sensor_data(obs), rew, fl[:, 4], fl[:, 5], info
+        return self._with_sensor_data(obs), self._fused_reward(rew, info), fl[:, 4], fl[:, 5], info
 
     def _fused_step(self, action):
         """BaseEnv.step on the fused kernels: controller, substeps + link frames, evaluate/obs/reward."""
@@ -656,8 +658,31 @@ class PickCubeEnv:
         return reward
 
     def get_reward(self, obs, action, info):
+        """BaseEnv.get_reward (sapien_env.py:648-670): 'normalized_dense' (default), 'dense', 'sparse' (success - fail as float;
+        compute_sparse_reward :672-697) or 'none'."""
+        mode = self.reward_mode
+        if mode == "none":
+            return torch.zeros(self.num_envs, dtype=torch.float32, device=self.device)
+        if mode == "sparse":
+            r = info["success"].float() if "success" in info else torch.zeros(self.num_envs, device=self.device)
+            return r - info["fail"].float() if "fail" in info else r
+        if mode not in ("dense", "normalized_dense"):
+            raise NotImplementedError(mode)
         r = self.compute_dense_reward(obs, action, info)
-        return r / self.max_reward if self.reward_mode == "normalized_dense" else r
+        return r / self.max_reward if mode == "normalized_dense" else r
+
+    def _fused_reward(self, rew, info):
+        """The fused task kernels pay the normalized dense reward; the other modes follow from it and the success flag."""
+        mode = self.reward_mode
+        if mode == "normalized_dense":
+            return rew
+        if mode == "dense":
+            return rew * self.max_reward
+        if mode == "sparse":
+            return info["success"].float()
+        if mode == "none":
+            return torch.zeros_like(rew)
+        raise NotImplementedError(mode)
 
     # ---------------------------------------------------------------- state (sapien_env.py:1272-1325)
     def get_state(self):

@@ -396,6 +396,22 @@ def episode_init_vectors():
         print("init", name, {a: tuple(np.round(recs[a].raw[:, :3].mean(0).numpy(), 3)) for a in actors})
 
 
+def reward_mode_vectors():
+    """BaseEnv.get_reward / compute_sparse_reward (sapien_env.py:648-697) for the four reward modes, with and without a fail flag."""
+    from mani_skill.envs.sapien_env import BaseEnv as RefBase
+
+    g = torch.Generator().manual_seed(3)
+    dense = torch.rand(8, generator=g) * 5
+    success = torch.tensor([True, False, False, True, False, False, True, False])
+    fail = torch.tensor([False, True, False, False, False, True, False, False])
+    put("reward_mode", dense=dense, success=success, fail=fail)
+    for mode in ("sparse", "dense", "normalized_dense", "none"):
+        for tag, info in (("s", dict(success=success)), ("sf", dict(success=success, fail=fail))):
+            fake = Fake(RefBase, _reward_mode=mode, num_envs=8, device=torch.device("cpu"), compute_dense_reward=lambda obs, action, info: dense.clone(),
+                        compute_normalized_dense_reward=lambda obs, action, info: dense / 5.0)
+            put(f"reward_mode/{mode}_{tag}", out=RefBase.get_reward(fake, obs=None, action=None, info=info).to(torch.float32))
+
+
 def pusht_vectors():
     """PushT-v1: the reference's own _load_scene builds the pseudo-render tables (sapien calls land in mocks), then evaluate
     (pseudo_render_intersection), _get_obs_extra and the pose-based reward run on this package's states; the T is also put on and
@@ -520,6 +536,7 @@ def main():
     shader_vectors()
     constants_vectors()
     episode_init_vectors()
+    reward_mode_vectors()
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **OUT)
     print("wrote reference_vectors.npz:", len(OUT), "arrays")
 

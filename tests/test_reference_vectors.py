@@ -245,3 +245,16 @@ def test_episode_layout_statistics(oracle_factory, name):
         if ys > 1e-3 and float(R("qxy_absmax")) < 1e-6:          # a yaw-only randomisation in the reference
             assert abs(float(yaw.min() - R("yaw_min"))) <= 0.03 * ys + 1e-3 and abs(float(yaw.max() - R("yaw_max"))) <= 0.03 * ys + 1e-3, actor
             assert raw[:, 4:6].abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["sparse", "dense", "normalized_dense", "none"])
+def test_reward_modes(oracle_factory, mode):
+    """BaseEnv.get_reward / compute_sparse_reward (sapien_env.py:648-697): the four reward modes, with and without a fail flag (the
+    reference's sparse reward of a task without a fail flag is the bool success tensor itself; here it is its float value)."""
+    env = PickCubeEnv(num_envs=8, px_factory=oracle_factory, reward_mode=mode)
+    env.compute_dense_reward = lambda obs, action, info: T("reward_mode/dense").clone()
+    for tag, info in (("s", dict(success=T("reward_mode/success"))), ("sf", dict(success=T("reward_mode/success"), fail=T("reward_mode/fail")))):
+        got = env.get_reward(None, None, info)
+        assert got.dtype == torch.float32 and torch.allclose(got, T(f"reward_mode/{mode}_{tag}/out"), atol=1e-7), (mode, tag)
+    with pytest.raises(NotImplementedError):
+        PickCubeEnv(num_envs=1, px_factory=oracle_factory, reward_mode="shaped")
