@@ -151,3 +151,21 @@ def test_action_and_observation_spaces(oracle_factory):
     assert env.single_observation_space.shape == (42,) and env.observation_space.shape == (2, 42)
     venv = ManiSkillVectorEnv("PushT-v1", num_envs=2, px_factory=oracle_factory)
     assert venv.single_action_space.shape == (7,) and venv.action_space.shape == (2, 7)
+
+
+def test_edge_cases(oracle_factory):
+    """Empty partial reset, single env with a flat action, numpy actions, unknown modes."""
+    env = _env(oracle_factory, n=3)
+    env.reset(seed=0)
+    s0 = env.get_state().clone()
+    env.reset(options=dict(env_idx=torch.tensor([], dtype=torch.long)))            # nobody is reset: nothing moves
+    assert torch.equal(env.get_state(), s0)
+    assert env.step(np.zeros((3, 8), dtype=np.float32))[1].shape == (3,)
+    one = _env(oracle_factory, n=1)
+    one.reset(seed=0)
+    assert one.step(torch.zeros(8))[0].shape == (1, 42)
+    for kw in (dict(obs_mode="pointcloud"), dict(control_mode="pd_base_vel"), dict(reward_mode="shaped")):
+        with pytest.raises(NotImplementedError):
+            _env(oracle_factory, n=1, **kw)
+    with pytest.raises(RuntimeError):
+        PickCubeEnv(num_envs=1, device="cpu")                                       # the product path has no CPU backend
