@@ -41,7 +41,10 @@ class PushTEnv:
 
     def __init__(self, num_envs: int = 1, device: Optional[str] = None, sim_config: Optional[SimConfig] = None,
                  robot_init_qpos_noise: float = 0.02, obs_mode: str = "state", env_index_offset: int = 0,
-                 total_envs: Optional[int] = None, px_factory=None, fused: Optional[bool] = None):
+                 total_envs: Optional[int] = None, px_factory=None, fused: Optional[bool] = None, reward_mode: str = "normalized_dense"):
+        if reward_mode not in ("normalized_dense", "dense", "sparse", "none"):
+            raise NotImplementedError(f"reward_mode {reward_mode!r}: one of 'normalized_dense', 'dense', 'sparse', 'none' (sapien_env.py:648-670)")
+        self.reward_mode = reward_mode
         self.num_envs = int(num_envs)
         self.sim_config = sim_config or SimConfig()
         self.robot_init_qpos_noise = robot_init_qpos_noise
@@ -272,7 +275,18 @@ class PushTEnv:
             self.camera.take_picture()
             obs = dict(state=obs, sensor_data=dict(base_camera=self.camera.get_obs(**self._textures)),
                        sensor_param=dict(base_camera=self.camera.get_params()))
-        return obs, rew, fl[:, 4], fl[:, 5], info
+        return obs, self._mode_reward(rew, info), fl[:, 4], fl[:, 5], info
+
+    def _mode_reward(self, normalized, info):
+        """BaseEnv.get_reward (sapien_env.py:648-670) from the normalized dense reward (max 3) and the success flag."""
+        mode = self.reward_mode
+        if mode == "normalized_dense":
+            return normalized
+        if mode == "dense":
+            return normalized * 3.0
+        if mode == "sparse":
+            return info["success"].float()
+        return torch.zeros_like(normalized)
 
     def _fused_step(self, action):
         import ctypes as C
@@ -326,7 +340,7 @@ class PushTEnv:
         self._elapsed_steps += 1
         info = self.get_info()
         obs = self.get_obs(info)
-        reward = self.compute_normalized_dense_reward(info)
+        reward = self._mode_reward(self.compute_normalized_dense_reward(info), info)
         terminated = info["success"].clone()
         truncated = self._elapsed_steps >= self.max_episode_steps
         return obs, reward, terminated, truncated, info

@@ -164,3 +164,16 @@ def test_fused_task_kernels_match_the_torch_path():
     near = (ratio - th.intersection_thresh).abs() < 3.0 / 795.0     # a pixel or two of the 64 x 64 mask: rounding of the transform
     assert torch.equal(sf[~near], st[~near])
     assert (sf != st).float().mean() < 0.01
+
+
+def test_reward_modes(oracle_factory):
+    """BaseEnv.get_reward's modes on PushT (sapien_env.py:648-670)."""
+    outs = {}
+    for mode in ("normalized_dense", "dense", "sparse", "none"):
+        env = PushTEnv(num_envs=3, px_factory=oracle_factory, reward_mode=mode)
+        env.reset(seed=0)
+        outs[mode] = env.step(torch.full((3, 7), 0.2))
+    nd, info = outs["normalized_dense"][1], outs["normalized_dense"][4]
+    assert torch.allclose(outs["dense"][1], nd * 3.0) and torch.equal(outs["sparse"][1], info["success"].float()) and torch.equal(outs["none"][1], torch.zeros(3))
+    with pytest.raises(NotImplementedError):
+        PushTEnv(num_envs=1, px_factory=oracle_factory, reward_mode="shaped")
