@@ -30,6 +30,7 @@ class PushTEnv:
     """PushT-v1, ``pd_joint_delta_pos`` control, PandaStick; obs_mode 'state' or 'depth+segmentation'."""
 
     max_episode_steps = 100
+    camera_eye, camera_target = (0.3, 0.0, 0.6), (-0.1, 0.0, 0.1)      # base_camera (push_t.py:133-145)
     tee_spawnbox_xlength, tee_spawnbox_ylength = 0.2, 0.3
     tee_spawnbox_xoffset, tee_spawnbox_yoffset = -0.1, -0.1
     goal_offset = (-0.156, -0.1)
@@ -99,7 +100,7 @@ class PushTEnv:
         if obs_mode != "state":
             from ..render import CameraConfig, RenderCameraGroup, attach_template_visuals, look_at
             attach_template_visuals(self.px, tpl)
-            p, q = look_at(eye=[0.3, 0, 0.6], target=[-0.1, 0, 0.1])
+            p, q = look_at(eye=list(self.camera_eye), target=list(self.camera_target))
             self.camera = RenderCameraGroup(self.px, CameraConfig("base_camera", p, q, 128, 128, np.pi / 2, 0.01, 100.0))
             if self._want_color:
                 self.camera.enable_color()

@@ -412,6 +412,39 @@ def reward_mode_vectors():
             put(f"reward_mode/{mode}_{tag}", out=RefBase.get_reward(fake, obs=None, action=None, info=info).to(torch.float32))
 
 
+def sensor_config_vectors():
+    """Every task's _default_sensor_configs (base_camera): eye / target handed to sapien_utils.look_at, resolution, fov, near, far."""
+    import importlib
+    su = importlib.import_module("mani_skill.utils.sapien_utils")
+
+    names = ["PickCube-v1", "PushCube-v1", "PullCube-v1", "StackCube-v1", "LiftPegUpright-v1", "PokeCube-v1", "PegInsertionSide-v1", "StackPyramid-v1", "PushT-v1",
+             "PullCubeTool-v1"]
+    from mani_skill.utils.registration import REGISTERED_ENVS
+    real = su.look_at
+    rows = []
+    for n in names:
+        cls = REGISTERED_ENVS[n].cls
+        mod = sys.modules[cls.__module__]
+        def rec(eye, target, up=(0, 0, 1)):   # stands in for look_at (transforms3d is not here): a pose that remembers what it was built from
+            return RefPose.create_from_pq(torch.tensor([float(x) for x in eye]), torch.tensor([7.0] + [float(x) for x in target]))   # q = (tag, target)
+        su.look_at = rec
+        had = getattr(mod, "look_at", None)
+        if had is not None:
+            mod.look_at = rec
+        extra = dict(sensor_cam_eye_pos=[0.3, 0, 0.6], sensor_cam_target_pos=[-0.1, 0, 0.1]) if n == "PickCube-v1" else {}
+        cfgs = cls._default_sensor_configs.fget(Fake(cls, **extra))
+        if had is not None:
+            mod.look_at = had
+        cam = [c for c in cfgs if c.uid == "base_camera"][0]
+        raw = cam.pose.raw_pose[0]
+        assert float(raw[3]) == 7.0, (n, "builds its camera pose without look_at")
+        eye, target = raw[:3].tolist(), raw[4:7].tolist()
+        rows.append([*eye, *target, cam.width, cam.height, cam.fov, cam.near, cam.far])
+    su.look_at = real
+    OUT["sensor/names"] = np.array(names)
+    put("sensor", rows=np.array(rows, dtype=np.float64))
+
+
 def pusht_vectors():
     """PushT-v1: the reference's own _load_scene builds the pseudo-render tables (sapien calls land in mocks), then evaluate
     (pseudo_render_intersection), _get_obs_extra and the pose-based reward run on this package's states; the T is also put on and
@@ -537,6 +570,7 @@ def main():
     constants_vectors()
     episode_init_vectors()
     reward_mode_vectors()
+    sensor_config_vectors()
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **OUT)
     print("wrote reference_vectors.npz:", len(OUT), "arrays")
 

@@ -199,7 +199,6 @@ def test_constants_and_scene_initialisation():
     from maniskill_amd.envs.pull_cube import PullCubeEnv
     from maniskill_amd.envs.push_cube import PushCubeEnv
     from maniskill_amd.envs.push_t import PushTEnv
-
     reg = _registry()
     for name, steps in zip(G["const/names"].tolist(), G["const/max_episode_steps"].tolist()):
         assert reg[name].max_episode_steps == steps, name
@@ -258,3 +257,13 @@ def test_reward_modes(oracle_factory, mode):
         assert got.dtype == torch.float32 and torch.allclose(got, T(f"reward_mode/{mode}_{tag}/out"), atol=1e-7), (mode, tag)
     with pytest.raises(NotImplementedError):
         PickCubeEnv(num_envs=1, px_factory=oracle_factory, reward_mode="shaped")
+
+
+def test_base_camera_configs():
+    """Every task's base_camera as its _default_sensor_configs states it in the reference: look_at eye / target, 128 x 128, fov pi/2,
+    near 0.01, far 100."""
+    reg = _registry()
+    for name, row in zip(G["sensor/names"].tolist(), G["sensor/rows"]):
+        cls = reg[name]
+        assert np.allclose(cls.camera_eye, row[0:3], atol=1e-6) and np.allclose(cls.camera_target, row[3:6], atol=1e-6), name
+        assert tuple(row[6:8]) == (128, 128) and abs(row[8] - np.pi / 2) < 1e-6 and row[9] == 0.01 and row[10] == 100, name
