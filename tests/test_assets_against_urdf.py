@@ -88,3 +88,38 @@ def test_cooked_model_matches_the_urdf(name):
     mine = {frozenset((names[a], names[b]) if isinstance(a, int) else (a, b)) for a, b in model["disable_collisions"]}
     assert mine == pairs
     assert n_boxes > 0 or name == "panda_stick"
+
+
+def _read_stl(path):
+    import struct
+    data = open(path, "rb").read()
+    if data[:5] == b"solid" and b"facet" in data[:400]:
+        return np.array([[float(x) for x in line.split()[1:4]] for line in data.decode(errors="ignore").splitlines() if line.strip().startswith("vertex")])
+    n = struct.unpack("<I", data[80:84])[0]
+    tri = np.frombuffer(data, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]), count=n, offset=84)
+    return tri["v"].reshape(-1, 3).astype(np.float64)
+
+
+@pytest.mark.parametrize("name", ["panda_v2", "panda_stick"])
+def test_cooked_hulls_stay_inside_and_close_to_the_collision_meshes(name):
+    """Hull vertices are capped at 64 per shape (GPU PhysX cooks convex meshes to <= 64 vertices): the capped hull must be a subset of
+    the mesh's vertices, lie inside its convex hull, and keep >= 93 % of its volume."""
+    from scipy.spatial import ConvexHull, Delaunay
+
+    model = json.load(open(os.path.join(HERE, "..", "maniskill_amd", "assets", f"{name}.json")))
+    checked = 0
+    for link in model["links"]:
+        for col in link["collisions"]:
+            if col["type"] != "convex" or "source" not in col or not col["source"].endswith(".stl"):
+                continue
+            path = os.path.join(REF, col["source"])
+            if not os.path.exists(path):
+                continue
+            mesh = _read_stl(path) * np.asarray(col.get("scale", [1.0, 1.0, 1.0]))
+            verts = np.asarray(col["verts"])
+            assert len(verts) <= 64
+            assert Delaunay(mesh[ConvexHull(mesh).vertices]).find_simplex(verts * 0.999 + mesh.mean(0) * 0.001).min() >= 0, (link["name"], "outside")
+            ratio = ConvexHull(verts).volume / ConvexHull(mesh).volume
+            assert 0.93 <= ratio <= 1.0 + 1e-6, (link["name"], ratio)
+            checked += 1
+    assert checked >= 1
