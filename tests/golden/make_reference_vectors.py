@@ -571,8 +571,9 @@ def main():
     episode_init_vectors()
     reward_mode_vectors()
     sensor_config_vectors()
-    np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **OUT)
-    print("wrote reference_vectors.npz:", len(OUT), "arrays")
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "reference_vectors.npz")
+    np.savez_compressed(out_path, **OUT)
+    print("wrote", os.path.basename(out_path) + ":", len(OUT), "arrays")
 
 
 if __name__ == "__main__":

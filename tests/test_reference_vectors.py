@@ -267,3 +267,21 @@ def test_base_camera_configs():
         cls = reg[name]
         assert np.allclose(cls.camera_eye, row[0:3], atol=1e-6) and np.allclose(cls.camera_target, row[3:6], atol=1e-6), name
         assert tuple(row[6:8]) == (128, 128) and abs(row[8] - np.pi / 2) < 1e-6 and row[9] == 0.01 and row[10] == 100, name
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/mani_skill"), reason="needs the reference tree (present in the build container only)")
+def test_committed_vectors_are_what_the_generator_writes(tmp_path):
+    """tests/golden/reference_vectors.npz is exactly what tests/golden/make_reference_vectors.py produces today: neither the fixture nor
+    the states this package feeds the reference's code have drifted."""
+    import subprocess
+    import sys
+
+    out = str(tmp_path / "fresh.npz")
+    subprocess.check_call([sys.executable, os.path.join(HERE, "golden", "make_reference_vectors.py"), out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                          timeout=600)
+    fresh = np.load(out)
+    assert sorted(fresh.files) == sorted(G.files)
+    for k in G.files:
+        a, b = G[k], fresh[k]
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+        assert np.array_equal(a, b, equal_nan=True) if a.dtype.kind in "fc" else np.array_equal(a, b), k
