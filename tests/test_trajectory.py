@@ -124,3 +124,28 @@ def test_oracle_reproduces_its_committed_trace(oracle_factory):
 def test_hip_replays_the_committed_trace():
     res = replay_trajectory(PickCubeEnv(num_envs=8, device="cuda:0"), os.path.join(HERE, "golden", "pickcube_oracle_trace.npz"))
     assert res.num_replays == 8 and res.max_state_error < 1e-4
+
+
+def test_recording_under_the_auto_resetting_vector_env(oracle_factory, tmp_path):
+    """ManiSkillVectorEnv(RecordEpisode(env)): the wrapper's same-step partial resets cut the recorded episodes; every recorded
+    episode is at most max_episode_steps long and replays exactly."""
+    from maniskill_amd.vector import ManiSkillVectorEnv
+
+    env = PickCubeEnv(num_envs=3, px_factory=oracle_factory)
+    env.max_episode_steps = 6                                   # short episodes: several truncations within the rollout
+    rec = RecordEpisode(env, str(tmp_path), env_id="PickCube-v1")
+    venv = ManiSkillVectorEnv(rec, auto_reset=True)
+    venv.reset(seed=9)
+    gen = torch.Generator().manual_seed(2)
+    finals = 0
+    for _ in range(15):
+        _, _, _, _, infos = venv.step(0.4 * (2 * torch.rand(3, 8, generator=gen) - 1))
+        finals += int("final_info" in infos)
+    rec.close()
+    meta, arrays = load_trajectory(str(tmp_path / "trajectory.npz"))
+    lens = [ep["elapsed_steps"] for ep in meta["episodes"]]
+    assert finals == 2 and sorted(lens) == [3, 3, 3, 6, 6, 6, 6, 6, 6]          # 15 steps = 6 + 6 + 3 per env
+    assert all(arrays[f"traj_{ep['episode_id']}"]["truncated"][-1] == (ep["elapsed_steps"] == 6) for ep in meta["episodes"])
+    fresh = PickCubeEnv(num_envs=3, px_factory=oracle_factory)
+    res = replay_trajectory(fresh, str(tmp_path / "trajectory.npz"))
+    assert res.num_replays == 9 and res.max_state_error < 1e-5
