@@ -19,6 +19,20 @@
 #include <string.h>
 
 #define ORC_FEAT_EPS 2.5e-3f
+/* Optional work counters (cc -DORC_STATS, tools/oracle_np_stats.py): how many GJK / EPA iterations the narrowphase spends per
+ * hull pair -- the dependent chain the HIP lane-group kernels walk through.  Not compiled into liborc.so. */
+#ifdef ORC_STATS
+long long orc_stats[16]; /* 0 gjk calls, 1 gjk iterations, 2 culled by margin, 3 epa calls, 4 epa iterations, 5 epa degenerate, 6 obb culled,
+                         * 7 obb tested, 8 plane pairs past the AABB test, 9 box-box pairs past the AABB test, 10 box-box SAT hits,
+                         * 11 manifolds built, 12 contact points, 13 candidate pairs visited */
+#define STAT(k, n) __atomic_fetch_add(&orc_stats[k], (long long)(n), __ATOMIC_RELAXED)
+__attribute__((visibility("default"))) void orc_stats_read(long long out[16], int reset) {
+  for (int i = 0; i < 16; ++i) { out[i] = orc_stats[i]; if (reset) orc_stats[i] = 0; }
+}
+#else
+#define STAT(k, n) ((void)0)
+#endif
+
 #define ORC_GJK_ITERS 32
 #define ORC_EPA_ITERS 32
 #define ORC_EPA_MAXV 40
@@ -518,6 +532,7 @@ static int epa(const orc_shape* A, const pose* TA, const orc_shape* B, const pos
   }
   int bestf = 0;
   for (int it = 0; it < ORC_EPA_ITERS; ++it) {
+    STAT(4, 1);
     bestf = -1;
     float bd = 3.0e38f;
     for (int f = 0; f < nf; ++f)
@@ -585,11 +600,13 @@ static int gjk_epa(const orc_shape* A, const pose* TA, const orc_shape* B, const
   v3 v = s[0].w;
   float vv = v3_len2(v);
   int hit = 0;
+  STAT(0, 1);
   for (int it = 0; it < ORC_GJK_ITERS; ++it) {
     if (vv < 1e-10f) { hit = 1; break; }
+    STAT(1, 1);
     mvert w = msupport(A, TA, B, TB, v3_neg(v));
     float vw = v3_dot(v, w.w);
-    if (vw > 0.0f && vw * vw > margin * margin * vv) return 0; /* separated by more than margin */
+    if (vw > 0.0f && vw * vw > margin * margin * vv) { STAT(2, 1); return 0; } /* separated by more than margin */
     if (vv - vw <= 1e-6f * vv) break;                          /* converged */
     int dupl = 0;
     for (int i = 0; i < n; ++i) if (v3_len2(v3_sub(s[i].w, w.w)) < 1e-14f) dupl = 1;
@@ -615,7 +632,9 @@ static int gjk_epa(const orc_shape* A, const pose* TA, const orc_shape* B, const
     }
   }
   float depth;
+  STAT(3, 1);
   if (!epa(A, TA, B, TB, s, n, n_out, &depth, wa, wb)) {
+    STAT(5, 1);
     /* degenerate: fall back to the centre direction with zero separation */
     *n_out = v3_normalize(d0);
     *sep_out = 0.0f;
@@ -674,6 +693,7 @@ int orc_collide_pair(const orc_ctx* c, const orc_env* e, int pi, orc_contact* ou
   pose TA = shape_pose(c, e, A), TB = shape_pose(c, e, B);
   const float margin = 2.0f * c->cfg.contact_offset;
   int n = 0;
+  STAT(13, 1);
   if (A->type == MSK_SHAPE_PLANE || B->type == MSK_SHAPE_PLANE) {
     const int pa = A->type == MSK_SHAPE_PLANE;
     const orc_shape* P = pa ? A : B;
@@ -686,6 +706,7 @@ int orc_collide_pair(const orc_ctx* c, const orc_env* e, int pi, orc_contact* ou
     v3 pn = quat_rotate(TP->q, v3_make(1, 0, 0));
     float lo = v3_dot(pn, cc) - v3_dot(pn, TP->p) - (fabsf(pn.x) * ch.x + fabsf(pn.y) * ch.y + fabsf(pn.z) * ch.z);
     if (lo > margin) return 0;
+    STAT(8, 1);
     n = plane_convex(P, TP, C, TC, margin, pa, out);
   } else {
     v3 ca, ha, cb, hb;
@@ -697,15 +718,20 @@ int orc_collide_pair(const orc_ctx* c, const orc_env* e, int pi, orc_contact* ou
     v3 nrm, wa, wb;
     float sep;
     if (A->type == MSK_SHAPE_BOX && B->type == MSK_SHAPE_BOX) {
+      STAT(9, 1);
       if (!sat_box_box(A, &TA, B, &TB, margin, &nrm, &sep)) return 0;
+      STAT(10, 1);
       wa = support(A, &TA, v3_neg(nrm));
       wb = support(B, &TB, nrm);
     } else {
-      if (obb_separated(A, &TA, B, &TB, ca, cb, margin)) return 0;
+      STAT(7, 1);
+      if (obb_separated(A, &TA, B, &TB, ca, cb, margin)) { STAT(6, 1); return 0; }
       if (!gjk_epa(A, &TA, B, &TB, ca, cb, margin, &nrm, &sep, &wa, &wb)) return 0;
     }
+    STAT(11, 1);
     n = build_manifold(A, &TA, B, &TB, nrm, margin, wa, wb, sep, out);
   }
+  STAT(12, n);
   float mu = 0.5f * (A->df + B->df);
   for (int i = 0; i < n; ++i) {
     out[i].sa = c->pairs[pi].sa; out[i].sb = c->pairs[pi].sb;
