@@ -834,6 +834,9 @@ MSK_DEV int gjk_epa(const CCtx& m, const CShape* A, const pose* TA, const CShape
   int ok = 0;
   for (int g = 0; g < 64 / NPG; ++g) /* one EPA workspace per wave: the groups that got here take turns */
     if (g == m.grp) ok = epa(m, A, TA, B, TB, S, n, n_out, &depth, wa, wb);
+  /* a polytope whose faces are all slivers hands back a null normal: a contact row without direction would poison the solver
+   * (J = 0, 1 / (J W J^T) = inf) -- treat it like the other degenerate cases (the group's lanes hold the same normal) */
+  if (ok && !(v3_len2(*n_out) > 0.25f)) ok = 0;
   if (!ok) {
     /* degenerate: fall back to the centre direction with zero separation */
     *n_out = v3_normalize(d0);

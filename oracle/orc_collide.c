@@ -16,6 +16,8 @@
  * (sapien wheel absent): parity unpinned.
  */
 #include "orc_sim.h"
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define ORC_FEAT_EPS 2.5e-3f
@@ -633,8 +635,19 @@ static int gjk_epa(const orc_shape* A, const pose* TA, const orc_shape* B, const
   }
   float depth;
   STAT(3, 1);
-  if (!epa(A, TA, B, TB, s, n, n_out, &depth, wa, wb)) {
+  int ok = epa(A, TA, B, TB, s, n, n_out, &depth, wa, wb);
+  /* a polytope whose faces are all slivers hands back a null normal: a contact row without direction would poison the solver
+   * (J = 0, 1 / (J W J^T) = inf) -- treat it like the other degenerate cases */
+  if (ok && !(v3_len2(*n_out) > 0.25f)) ok = 0;
+  if (!ok) {
     STAT(5, 1);
+#ifdef ORC_STATS
+    if (getenv("ORC_STATS_VERBOSE")) {
+      static int shown = 0;
+      if (shown++ < 12) fprintf(stderr, "epa degenerate: A type %d nverts %d body %d | B type %d nverts %d body %d | simplex %d, |d0| %g, TA.p %g %g %g TB.p %g %g %g\n", A->type, A->nverts, A->body,
+                                B->type, B->nverts, B->body, n, sqrtf(v3_len2(d0)), TA->p.x, TA->p.y, TA->p.z, TB->p.x, TB->p.y, TB->p.z);
+    }
+#endif
     /* degenerate: fall back to the centre direction with zero separation */
     *n_out = v3_normalize(d0);
     *sep_out = 0.0f;

@@ -109,3 +109,16 @@ def test_fused_task_kernel_matches_torch_task_code():
     ok = sf[4]["success"]                       # (an arm left in the way by the random rollout may knock a peg out again)
     assert ok.float().mean() > 0.9 and torch.equal(ok, sp[4]["success"]) and torch.equal(sf[2], sp[2])
     assert torch.allclose(sf[1][ok], torch.ones(int(ok.sum()), device="cuda:0")) and torch.allclose(sf[1], sp[1], atol=2e-5)
+
+
+def test_long_random_rollout_stays_finite(oracle_factory):
+    """Regression: at control step 84 of this rollout env 16's arm hits the box so that EPA ends on a polytope of slivers and used to hand
+    back a null normal; the contact row without a direction (J = 0) turned the env into NaNs.  Such polytopes now take the degenerate
+    fallback (oracle/orc_collide.c and msk_collide.h gjk_epa)."""
+    env = PegInsertionSideEnv(num_envs=64, px_factory=oracle_factory)
+    env.reset(seed=2022)
+    gen = torch.Generator().manual_seed(0)
+    for k in range(100):
+        obs, rew, term, trunc, info = env.step(2 * torch.rand(64, 8, generator=gen) - 1)
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all(), k
+    assert torch.isfinite(env.get_state()).all() and env.qvel.abs().max() < 20.0
