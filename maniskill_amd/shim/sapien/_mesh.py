@@ -1,0 +1,406 @@
+"""Mesh files, convex hulls and mass properties for the shim's builders (host only, cold path).
+
+What SAPIEN does natively behind ``PhysxCollisionShapeConvexMesh(filename, scale, material)`` /
+``add_visual_from_file`` (mani_skill/utils/building/actor_builder.py:114-143; SURVEY §7.2 "Meshes without trimesh"):
+binary + ASCII STL, OBJ and GLB (positions + indices) readers, convex hull cooking capped at 64 vertices per hull (the cap
+GPU PhysX cooks with [ext]), mass / centre of mass / inertia of boxes, spheres, capsules, cylinders and hulls from a density
+(``shape.set_density``, actor_builder.py:152).
+"""
+from __future__ import annotations
+
+import json
+import os
+import struct
+
+import numpy as np
+
+MAX_HULL_VERTS = 64
+_cache: dict = {}
+
+
+# ------------------------------------------------------------------------------------------------ readers
+def read_stl(path):
+    """-> (vertices [n,3] float64, faces [m,3] int64); vertices are not merged."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:5] == b"solid" and b"facet" in data[:400]:
+        verts = []
+        for line in data.decode("ascii", "ignore").splitlines():
+            t = line.split()
+            if len(t) == 4 and t[0] == "vertex":
+                verts.append([float(t[1]), float(t[2]), float(t[3])])
+        v = np.asarray(verts, dtype=np.float64).reshape(-1, 3)
+    else:
+        (ntri,) = struct.unpack_from("<I", data, 80)
+        rec = np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("attr", "<u2")])
+        tris = np.frombuffer(data, dtype=rec, count=ntri, offset=84)
+        v = tris["v"].reshape(-1, 3).astype(np.float64)
+    return v, np.arange(len(v), dtype=np.int64).reshape(-1, 3)
+
+
+def read_obj(path):
+    """-> list of (vertices, faces), one per ``o`` / ``g`` group that has faces (polygons are fan-triangulated)."""
+    verts, groups, cur = [], [], []
+    with open(path, "r", errors="ignore") as f:
+        for line in f:
+            t = line.split()
+            if not t:
+                continue
+            if t[0] == "v" and len(t) >= 4:
+                verts.append([float(t[1]), float(t[2]), float(t[3])])
+            elif t[0] == "f":
+                idx = [int(w.split("/")[0]) for w in t[1:]]
+                idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
+                for k in range(1, len(idx) - 1):
+                    cur.append([idx[0], idx[k], idx[k + 1]])
+            elif t[0] in ("o", "g") and cur:
+                groups.append(cur)
+                cur = []
+    if cur:
+        groups.append(cur)
+    V = np.asarray(verts, dtype=np.float64).reshape(-1, 3)
+    out = []
+    for g in groups:
+        F = np.asarray(g, dtype=np.int64)
+        used = np.unique(F)
+        remap = -np.ones(len(V), dtype=np.int64)
+        remap[used] = np.arange(len(used))
+        out.append((V[used], remap[F]))
+    return out
+
+
+_GLTF_DTYPE = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
+_GLTF_NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
+
+
+def read_glb(path):
+    """Binary glTF 2.0 -> list of parts dict(vertices [n,3], faces [m,3], base_color rgba, name), node transforms applied.
+    Positions, indices and the material's baseColorFactor only (no textures, normals, skins)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    magic, version, _ = struct.unpack_from("<III", data, 0)
+    if magic != 0x46546C67:
+        raise RuntimeError(f"{path}: not a GLB file")
+    off, doc, blob = 12, None, b""
+    while off < len(data):
+        clen, ctype = struct.unpack_from("<II", data, off)
+        chunk = data[off + 8: off + 8 + clen]
+        if ctype == 0x4E4F534A:
+            doc = json.loads(chunk.decode("utf-8"))
+        elif ctype == 0x004E4942:
+            blob = chunk
+        off += 8 + clen
+    return _gltf_parts(doc, [blob], os.path.dirname(path))
+
+
+def _gltf_parts(doc, blobs, base_dir):
+    def accessor(i):
+        a = doc["accessors"][i]
+        bv = doc["bufferViews"][a["bufferView"]]
+        dt, nc = np.dtype(_GLTF_DTYPE[a["componentType"]]), _GLTF_NCOMP[a["type"]]
+        buf = blobs[bv.get("buffer", 0)]
+        start = bv.get("byteOffset", 0) + a.get("byteOffset", 0)
+        stride = bv.get("byteStride", 0) or dt.itemsize * nc
+        if stride == dt.itemsize * nc:
+            arr = np.frombuffer(buf, dtype=dt, count=a["count"] * nc, offset=start).reshape(a["count"], nc)
+        else:
+            raw = np.frombuffer(buf, dtype=np.uint8, count=stride * (a["count"] - 1) + dt.itemsize * nc, offset=start)
+            arr = np.lib.stride_tricks.as_strided(raw, (a["count"], dt.itemsize * nc), (stride, 1)).copy().view(dt).reshape(a["count"], nc)
+        return arr
+
+    def node_matrix(n):
+        if "matrix" in n:
+            return np.asarray(n["matrix"], dtype=np.float64).reshape(4, 4).T
+        M = np.eye(4)
+        if "scale" in n:
+            M = np.diag(list(n["scale"]) + [1.0]) @ M
+        if "rotation" in n:
+            x, y, z, w = n["rotation"]
+            from ._pose import _quat2mat
+            R = np.eye(4)
+            R[:3, :3] = _quat2mat([w, x, y, z])
+            M = R @ M
+        if "translation" in n:
+            T = np.eye(4)
+            T[:3, 3] = n["translation"]
+            M = T @ M
+        return M
+
+    parts = []
+
+    def visit(ni, parent):
+        n = doc["nodes"][ni]
+        M = parent @ node_matrix(n)
+        if "mesh" in n:
+            mesh = doc["meshes"][n["mesh"]]
+            for prim in mesh["primitives"]:
+                if prim.get("mode", 4) != 4 or "POSITION" not in prim["attributes"]:
+                    continue
+                v = accessor(prim["attributes"]["POSITION"]).astype(np.float64)
+                f = (accessor(prim["indices"]).astype(np.int64).reshape(-1, 3) if "indices" in prim
+                     else np.arange(len(v), dtype=np.int64).reshape(-1, 3))
+                v = v @ M[:3, :3].T + M[:3, 3]
+                if np.linalg.det(M[:3, :3]) < 0:
+                    f = f[:, ::-1]
+                color = [0.8, 0.8, 0.8, 1.0]
+                if "material" in prim:
+                    mat = doc["materials"][prim["material"]]
+                    color = list(mat.get("pbrMetallicRoughness", {}).get("baseColorFactor", color))
+                parts.append(dict(vertices=v, faces=f, base_color=color, name=mesh.get("name", n.get("name", ""))))
+        for c in n.get("children", []):
+            visit(c, M)
+
+    scenes = doc.get("scenes") or [dict(nodes=list(range(len(doc.get("nodes", [])))))]
+    for ni in scenes[doc.get("scene", 0)]["nodes"]:
+        visit(ni, np.eye(4))
+    return parts
+
+
+def load_mesh_parts(path):
+    """Any supported mesh file -> list of dict(vertices, faces, base_color, name) in the file's own frame and units."""
+    key = ("parts", os.path.abspath(path), os.path.getmtime(path))
+    if key in _cache:
+        return _cache[key]
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".stl":
+        v, f = read_stl(path)
+        parts = [dict(vertices=v, faces=f, base_color=[0.8, 0.8, 0.8, 1.0], name=os.path.basename(path))]
+    elif ext == ".obj":
+        parts = [dict(vertices=v, faces=f, base_color=[0.8, 0.8, 0.8, 1.0], name=os.path.basename(path)) for v, f in read_obj(path)]
+    elif ext == ".glb":
+        parts = read_glb(path)
+        # glTF is y-up; SAPIEN loads GLB through assimp into its z-up world: (x, y, z)_gltf -> (x, -z, y)
+        for p in parts:
+            v = p["vertices"]
+            p["vertices"] = np.stack([v[:, 0], -v[:, 2], v[:, 1]], axis=1)
+    elif ext == ".dae":
+        parts = read_dae(path)
+    else:
+        raise RuntimeError(f"unsupported mesh format: {path}")
+    if not parts:
+        raise RuntimeError(f"no triangles in {path}")
+    _cache[key] = parts
+    return parts
+
+
+def read_dae(path):
+    """COLLADA: <triangles>/<polylist> of every geometry, positions only, <up_axis> honoured, node transforms ignored
+    except the unit scale."""
+    import xml.etree.ElementTree as ET
+    root = ET.parse(path).getroot()
+    ns = {"c": root.tag[1:root.tag.index("}")]} if root.tag.startswith("{") else {}
+    q = (lambda s: "/".join("c:" + t if t not in (".", "..", "") else t for t in s.split("/"))) if ns else (lambda s: s)
+    unit = root.find(q("asset/unit"), ns)
+    scale = float(unit.get("meter", "1")) if unit is not None else 1.0
+    up = root.find(q("asset/up_axis"), ns)
+    up = up.text.strip() if up is not None and up.text else "Y_UP"
+    parts = []
+    for geom in root.iter(("{%s}geometry" % ns["c"]) if ns else "geometry"):
+        mesh = geom.find(q("mesh"), ns)
+        if mesh is None:
+            continue
+        sources = {}
+        for src in mesh.findall(q("source"), ns):
+            fa = src.find(q("float_array"), ns)
+            if fa is not None and fa.text:
+                sources["#" + src.get("id")] = np.array(fa.text.split(), dtype=np.float64)
+        vmap = {}
+        for vs in mesh.findall(q("vertices"), ns):
+            for inp in vs.findall(q("input"), ns):
+                if inp.get("semantic") == "POSITION":
+                    vmap["#" + vs.get("id")] = inp.get("source")
+        for tag in ("triangles", "polylist"):
+            for prim in mesh.findall(q(tag), ns):
+                inputs = prim.findall(q("input"), ns)
+                stride = max(int(i.get("offset", "0")) for i in inputs) + 1
+                vin = next((i for i in inputs if i.get("semantic") == "VERTEX"), None)
+                pel = prim.find(q("p"), ns)
+                if vin is None or pel is None or not pel.text:
+                    continue
+                V = sources[vmap[vin.get("source")]].reshape(-1, 3) * scale
+                idx = np.array(pel.text.split(), dtype=np.int64).reshape(-1, stride)[:, int(vin.get("offset", "0"))]
+                if tag == "polylist":
+                    vc = prim.find(q("vcount"), ns)
+                    counts = np.array(vc.text.split(), dtype=np.int64)
+                    faces, o = [], 0
+                    for n in counts:
+                        for k in range(1, n - 1):
+                            faces.append([idx[o], idx[o + k], idx[o + k + 1]])
+                        o += n
+                    F = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+                else:
+                    F = idx.reshape(-1, 3)
+                if up == "Y_UP":
+                    V = np.stack([V[:, 0], -V[:, 2], V[:, 1]], axis=1)
+                parts.append(dict(vertices=V, faces=F, base_color=[0.8, 0.8, 0.8, 1.0], name=geom.get("name", "")))
+    return parts
+
+
+# ------------------------------------------------------------------------------------------------ hulls
+def reduce_hull(points, max_verts=MAX_HULL_VERTS):
+    """Convex hull of `points`, greedily limited to `max_verts` vertices: start from the axis-extreme points and repeatedly
+    add the input vertex that lies farthest outside the current hull (progressive hull).  Deterministic."""
+    from scipy.spatial import ConvexHull
+    pts = np.unique(np.round(np.asarray(points, dtype=np.float64), 7), axis=0)
+    full = ConvexHull(pts)
+    hv = pts[full.vertices]
+    if len(hv) <= max_verts:
+        return hv
+    sel = set()
+    for ax in range(3):
+        sel.add(int(np.argmin(hv[:, ax])))
+        sel.add(int(np.argmax(hv[:, ax])))
+    sel = sorted(sel)
+    k = 0
+    while True:   # make sure the seed is full-dimensional
+        try:
+            ConvexHull(hv[sel])
+            break
+        except Exception:
+            if k not in sel:
+                sel.append(k)
+            k += 1
+    while len(sel) < max_verts:
+        h = ConvexHull(hv[sel])
+        d = hv @ h.equations[:, :3].T + h.equations[:, 3]   # signed distance of every vertex to every facet
+        out = d.max(axis=1)
+        out[sel] = -1.0
+        j = int(np.argmax(out))
+        if out[j] < 1e-5:
+            break
+        sel.append(j)
+    h = ConvexHull(hv[sel])
+    return hv[sel][h.vertices]
+
+
+def hull_faces(verts):
+    """Triangles of the convex hull of `verts` (indices into verts), counter-clockwise seen from outside."""
+    from scipy.spatial import ConvexHull
+    v = np.asarray(verts, dtype=np.float64)
+    h = ConvexHull(v)
+    tris = h.simplices.copy()
+    c = v.mean(axis=0)
+    n = np.cross(v[tris[:, 1]] - v[tris[:, 0]], v[tris[:, 2]] - v[tris[:, 0]])
+    flip = np.einsum("ij,ij->i", n, v[tris[:, 0]] - c) < 0
+    tris[flip] = tris[flip][:, ::-1]
+    return tris.astype(np.int64)
+
+
+def cook_convex(path, scale=(1, 1, 1)):
+    """One hull (<= 64 vertices) of everything in the file, scaled.  -> (vertices float32 [n,3], faces)"""
+    sc = np.asarray(scale, dtype=np.float64).reshape(-1)
+    sc = np.full(3, sc[0]) if sc.size == 1 else sc
+    key = ("hull", os.path.abspath(path), os.path.getmtime(path))
+    if key not in _cache:
+        pts = np.concatenate([p["vertices"] for p in load_mesh_parts(path)])
+        _cache[key] = np.round(reduce_hull(pts), 6)
+    v = (_cache[key] * sc).astype(np.float32)
+    return v, hull_faces(v)
+
+
+def cook_multiple_convex(path, scale=(1, 1, 1)):
+    """PhysxCollisionShapeConvexMesh.load_multiple: one hull per part / connected group of the file."""
+    sc = np.asarray(scale, dtype=np.float64).reshape(-1)
+    sc = np.full(3, sc[0]) if sc.size == 1 else sc
+    out = []
+    for p in load_mesh_parts(path):
+        try:
+            v = (np.round(reduce_hull(p["vertices"]), 6) * sc).astype(np.float32)
+        except Exception:
+            continue
+        out.append((v, hull_faces(v)))
+    if not out:
+        raise RuntimeError(f"failed to cook any convex mesh from {path}")
+    return out
+
+
+def prism(radius, half_length, sides=16, axis=0):
+    """Cylinder stand-in: `sides`-gon prism along `axis` (SAPIEN / PhysX cylinders and capsules lie along local x)."""
+    ang = np.arange(sides) * (2 * np.pi / sides)
+    ring = np.stack([radius * np.cos(ang), radius * np.sin(ang)], axis=1)
+    v = np.concatenate([np.c_[np.full(sides, -half_length), ring], np.c_[np.full(sides, half_length), ring]])
+    if axis != 0:
+        v = np.roll(v, axis, axis=1)
+    return np.round(v, 6).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------ mass properties
+def _sym(ixx, iyy, izz, ixy=0.0, ixz=0.0, iyz=0.0):
+    return np.array([[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]], dtype=np.float64)
+
+
+def box_mass(half, density):
+    hx, hy, hz = [float(h) for h in half]
+    m = density * 8 * hx * hy * hz
+    return m, np.zeros(3), _sym(m / 3 * (hy * hy + hz * hz), m / 3 * (hx * hx + hz * hz), m / 3 * (hx * hx + hy * hy))
+
+
+def sphere_mass(r, density):
+    m = density * 4.0 / 3.0 * np.pi * r ** 3
+    i = 0.4 * m * r * r
+    return m, np.zeros(3), _sym(i, i, i)
+
+
+def cylinder_mass(r, half_length, density):
+    """axis = local x"""
+    h = 2 * half_length
+    m = density * np.pi * r * r * h
+    return m, np.zeros(3), _sym(0.5 * m * r * r, m * (3 * r * r + h * h) / 12, m * (3 * r * r + h * h) / 12)
+
+
+def capsule_mass(r, half_length, density):
+    """axis = local x: cylinder of length 2*half_length + two hemispheres"""
+    h = 2 * half_length
+    mc = density * np.pi * r * r * h
+    ms = density * 4.0 / 3.0 * np.pi * r ** 3
+    ixx = 0.5 * mc * r * r + 0.4 * ms * r * r
+    # hemisphere pair about a transverse axis through the capsule centre
+    iyy = mc * (3 * r * r + h * h) / 12 + ms * (0.4 * r * r + 0.375 * r * h + 0.25 * h * h)
+    return mc + ms, np.zeros(3), _sym(ixx, iyy, iyy)
+
+
+def mesh_mass(verts, faces, density):
+    """Closed triangle mesh (outward faces): signed tetrahedra against the origin."""
+    v = np.asarray(verts, dtype=np.float64)
+    t = v[np.asarray(faces, dtype=np.int64)]
+    a, b, c = t[:, 0], t[:, 1], t[:, 2]
+    vol6 = np.einsum("ij,ij->i", a, np.cross(b, c))
+    vol = vol6.sum() / 6.0
+    if abs(vol) < 1e-18:
+        return 0.0, np.zeros(3), np.zeros((3, 3))
+    com = ((a + b + c) * vol6[:, None]).sum(0) / (24.0 * vol)
+    # second moments: integral of x_i x_j over each tetrahedron
+    S = np.zeros((3, 3))
+    for P, Q in ((a, a), (b, b), (c, c)):
+        S += np.einsum("n,ni,nj->ij", vol6, P, Q) * 2
+    for P, Q in ((a, b), (a, c), (b, c)):
+        S += np.einsum("n,ni,nj->ij", vol6, P, Q) + np.einsum("n,ni,nj->ij", vol6, Q, P)
+    S /= 120.0
+    if vol < 0:
+        vol, S = -vol, -S
+    m = density * vol
+    C = density * S - m * np.outer(com, com)          # covariance about the centre of mass
+    I = np.trace(C) * np.eye(3) - C
+    return m, com, I
+
+
+def combine(parts):
+    """parts: list of (mass, com_in_body [3], inertia_about_com_in_body_axes [3,3]) -> total (mass, com, inertia about com)."""
+    M = sum(p[0] for p in parts)
+    if M <= 0:
+        return 0.0, np.zeros(3), np.zeros((3, 3))
+    com = sum(p[0] * np.asarray(p[1]) for p in parts) / M
+    I = np.zeros((3, 3))
+    for m, c, Ic in parts:
+        d = np.asarray(c) - com
+        I += Ic + m * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+    return M, com, I
+
+
+def principal(I):
+    """Symmetric inertia -> (principal moments [3], quaternion wxyz of the principal frame in the original axes)."""
+    from ._pose import _mat2quat
+    w, V = np.linalg.eigh(np.asarray(I, dtype=np.float64))
+    if np.linalg.det(V) < 0:
+        V[:, 2] = -V[:, 2]
+    return w, _mat2quat(V)

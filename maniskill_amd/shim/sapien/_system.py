@@ -1,0 +1,678 @@
+"""PhysxGpuSystem / PhysxCpuSystem of the shim and the scene compiler behind ``gpu_init()``.
+
+ManiSkill builds every sub-scene separately in Python (``for scene_idx in scene_idxs: ... sub_scene.add_entity(entity)``,
+mani_skill/utils/building/actor_builder.py:234-245, articulation_builder.py:143-205).  The C-ABI library wants ONE scene template
+plus per-sub-scene instance records (include/msk_physx.h), so ``gpu_init()`` (envs/scene.py:902-948) compiles the object graph:
+sub-scene 0 becomes the template, every other sub-scene is checked against it (same bodies, joints, shapes, materials,
+collision groups); boxes whose sizes and bodies whose masses differ between sub-scenes become ``msk_declare_env_box`` /
+``msk_declare_env_mass`` instances (PegInsertionSide-v1, envs/tasks/tabletop/peg_insertion_side.py:133-187).
+
+Buffers: rows of ``cuda_rigid_body_data`` are sub-scene-major (row = env * bodies_per_env + template body id), positions are
+relative to the sub-scene (docs/source/user_guide/concepts/gpu_simulation.md:9); ``gpu_pose_index`` / ``gpu_index`` hand those
+rows out, which is all the reference relies on (utils/structs/base.py:103-109, articulation.py:266-270).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ._pose import Pose
+
+_JOINT = {"fixed": 0, "revolute": 1, "revolute_unwrapped": 1, "prismatic": 2}
+_SYNC_FETCH = 1 | 2 | 4 | 8 | 16
+
+
+def _pose7(pose: Pose):
+    return tuple(float(x) for x in pose._p) + tuple(float(x) for x in pose._q)
+
+
+class _Handle3D:
+    """cuda_articulation_link_incoming_joint_forces: (num_articulations, max_links, 6) view of the library's 2-D buffer."""
+
+    def __init__(self, handle, shape):
+        self._h, self._shape = handle, shape
+
+    def torch(self):
+        return self._h.torch().view(*self._shape)
+
+
+class _GatherQuery:
+    """A contact query whose listed rows are not the library's own order: gathered on demand."""
+
+    def __init__(self, qid, engine_handle, index: Optional[torch.Tensor]):
+        self.id = qid
+        self._engine_handle = engine_handle
+        self._index = index
+        self.cuda_impulses = self if index is not None else engine_handle
+
+    def torch(self):
+        return self._engine_handle.torch().index_select(0, self._index)
+
+
+class PhysxSystem:
+    def __init__(self):
+        from . import physx as P
+        self._P = P
+        self._scenes = []
+        self._scene_idx = {}
+        self._offsets = {}
+        self._initialized = False
+        self._components = []           # every PhysxRigidBaseComponent in registration order
+        self._timestep = 0.01
+        # snapshot of the module-level configuration, as SAPIEN takes it when the system is created
+        self._cfg = dict(scene=dict(P._config["scene"]), body=dict(P._config["body"]), shape=dict(P._config["shape"]))
+        self._engine = None
+        self._body_rows = None
+
+    # -- scenes ---------------------------------------------------------------------------------------------------
+    def _register_scene(self, scene):
+        self._scene_idx[id(scene)] = len(self._scenes)
+        self._scenes.append(scene)
+
+    def _scene_index(self, scene) -> int:
+        return self._scene_idx[id(scene)]
+
+    def set_scene_offset(self, scene, offset):
+        self._offsets[id(scene)] = np.array(offset, dtype=np.float32).reshape(3)
+
+    def get_scene_offset(self, scene):
+        return self._offsets.get(id(scene), np.zeros(3, dtype=np.float32)).copy()
+
+    def _register_component(self, comp):
+        if self._initialized:
+            raise RuntimeError("cannot add physical components after the simulation was initialised")
+        self._components.append(comp)
+
+    def _unregister_component(self, comp):
+        if self._initialized:
+            raise RuntimeError("cannot remove physical components after the simulation was initialised")
+        self._components.remove(comp)
+
+    @property
+    def rigid_dynamic_components(self):
+        return [c for c in self._components if isinstance(c, self._P.PhysxRigidDynamicComponent)]
+
+    @property
+    def rigid_static_components(self):
+        return [c for c in self._components if isinstance(c, self._P.PhysxRigidStaticComponent)]
+
+    @property
+    def articulation_link_components(self):
+        return [c for c in self._components if isinstance(c, self._P.PhysxArticulationLinkComponent)]
+
+    def get_rigid_dynamic_components(self):
+        return self.rigid_dynamic_components
+
+    def get_rigid_static_components(self):
+        return self.rigid_static_components
+
+    def get_articulation_link_components(self):
+        return self.articulation_link_components
+
+    @property
+    def timestep(self):
+        return self._timestep
+
+    @timestep.setter
+    def timestep(self, dt):
+        if self._initialized and abs(float(dt) - self._timestep) > 1e-12:
+            raise RuntimeError("timestep cannot be changed after the simulation was initialised")
+        self._timestep = float(dt)
+
+    def get_timestep(self):
+        return self._timestep
+
+    def set_timestep(self, dt):
+        self.timestep = dt
+
+    def get_config(self):
+        return self._cfg
+
+    # =============================================================================================================
+    # compiler
+    # =============================================================================================================
+    def _shape_sig(self, s, fold: Optional[Pose], relaxed: bool):
+        P = self._P
+        lp = s._local_pose if fold is None else fold * s._local_pose
+        mat = s.physical_material
+        base = (s._kind, tuple(s._groups), mat.static_friction, mat.dynamic_friction, mat.restitution, s.patch_radius,
+                s.min_patch_radius, s.contact_offset, s.rest_offset)
+        if isinstance(s, P.PhysxCollisionShapeBox):
+            if relaxed:
+                return base + (tuple(float(x) for x in lp._q),)
+            return base + (_pose7(lp), tuple(float(x) for x in s.half_size))
+        if isinstance(s, P.PhysxCollisionShapeConvexMesh):
+            h = getattr(s, "_vhash", None)
+            if h is None:
+                h = s._vhash = hash(s._scaled_vertices.tobytes())
+            return base + (_pose7(lp), h)
+        if isinstance(s, P.PhysxCollisionShapeSphere):
+            return base + (_pose7(lp), s.radius)
+        if isinstance(s, (P.PhysxCollisionShapeCapsule, P.PhysxCollisionShapeCylinder)):
+            return base + (_pose7(lp), s.radius, s.half_length)
+        if isinstance(s, P.PhysxCollisionShapePlane):
+            return base + (_pose7(lp),)
+        if isinstance(s, P.PhysxCollisionShapeTriangleMesh):
+            return base + (_pose7(lp), s.filename, tuple(float(x) for x in s.scale))
+        raise TypeError(type(s))
+
+    def _comp_sig(self, c, relaxed: bool):
+        P = self._P
+        if isinstance(c, P.PhysxRigidStaticComponent):
+            fold = c.entity._pose
+            shapes = tuple(self._shape_sig(s, fold, relaxed) for s in c.collision_shapes
+                           if not isinstance(s, P.PhysxCollisionShapePlane))     # planes are global, see _compile
+            return ("static", shapes)
+        shapes = tuple(self._shape_sig(s, None, relaxed) for s in c.collision_shapes)
+        if relaxed:
+            massp = ()
+        else:
+            m, com, I6 = c._mass_tensor()
+            massp = (m, tuple(com), tuple(I6))
+        common = (massp, c.linear_damping, c.angular_damping, bool(c.disable_gravity), shapes)
+        if isinstance(c, P.PhysxArticulationLinkComponent):
+            j = c.joint
+            return ("link", c.index, -1 if c.parent is None else c.parent.index, j._type, _pose7(j.pose_in_parent),
+                    _pose7(j.pose_in_child), tuple(j._limits.reshape(-1).tolist()), j.stiffness, j.damping, j.force_limit,
+                    j.drive_mode, j.friction, j._armature) + common
+        return ("kinematic" if c.kinematic else "dynamic", tuple(c.locked_motion_axes)) + common
+
+    def _compile(self):
+        """-> (SceneTemplate, per-env instance data); sets _body_id / _art_id on every component / articulation."""
+        from maniskill_amd import _native as N
+        from maniskill_amd.physx import SceneTemplate
+        P = self._P
+        n_env = len(self._scenes)
+        per_env = [[] for _ in range(n_env)]
+        for c in self._components:
+            per_env[c._env].append(c)
+        env0 = per_env[0]
+
+        # ---- homogeneity check ------------------------------------------------------------------------------------
+        sig0 = tuple(self._comp_sig(c, False) for c in env0)
+        hetero = []
+        for e in range(1, n_env):
+            comps = per_env[e]
+            if len(comps) != len(env0) or tuple(self._comp_sig(c, False) for c in comps) != sig0:
+                hetero.append(e)
+        if hetero:
+            rel0 = tuple(self._comp_sig(c, True) for c in env0)
+            for e in hetero:
+                comps = per_env[e]
+                if len(comps) != len(env0) or tuple(self._comp_sig(c, True) for c in comps) != rel0:
+                    raise RuntimeError(
+                        f"sub-scene {e} differs structurally from sub-scene 0 (other bodies, joints, meshes, materials or collision "
+                        "groups): this backend simulates one scene template with per-sub-scene box sizes and masses; fully "
+                        "heterogeneous sub-scenes are not supported yet")
+
+        # ---- global planes (a plane on a static actor of ANY sub-scene is one infinite plane of the whole PhysX scene;
+        #      the reference therefore attaches it in the first sub-scene only, actor_builder.py:76-90) ---------------------
+        planes = {}
+        for c in self._components:
+            if isinstance(c, P.PhysxRigidStaticComponent):
+                off = self._offsets.get(id(self._scenes[c._env]), np.zeros(3))
+                for s in c.collision_shapes:
+                    if isinstance(s, P.PhysxCollisionShapePlane):
+                        gp = c.entity._pose * s._local_pose
+                        n = gp.to_transformation_matrix()[:3, 0]
+                        d = float(np.dot(n, gp.p + off))          # plane: n . x = d in world coordinates
+                        # in a sub-scene frame x_local = x - offset: d_local = d - n . offset; identical for all sub-scenes only
+                        # if the offsets lie in the plane (ManiSkill's grid is horizontal, the ground normal is +z)
+                        key = (tuple(np.round(n, 6)), round(d, 6))
+                        planes.setdefault(key, (gp, s, n, d, off))
+        tpl = SceneTemplate()
+        self._static_shape_owner = []
+        for key, (gp, s, n, d, off) in planes.items():
+            for sc in self._scenes:
+                o = self._offsets.get(id(sc), np.zeros(3))
+                if abs(float(np.dot(n, o - off))) > 1e-6:
+                    raise RuntimeError("a static plane is not parallel to the sub-scene grid: cannot be shared by all sub-scenes")
+            lp = gp                                     # offsets are in-plane: the plane is the same in every sub-scene frame
+            mat = s.physical_material
+            tpl.add_shape(-1, N.SHAPE_PLANE, lp._p, lp._q, (0, 0, 0), None, mat.static_friction, mat.dynamic_friction, mat.restitution,
+                          s._groups, s.patch_radius, s.min_patch_radius)
+            self._static_shape_owner.append(s)
+
+        # ---- template from sub-scene 0 ----------------------------------------------------------------------------------
+        arts0, art_ids = [], {}
+        body_ids = {}
+        shape_ids = {}       # id(shape of env 0) -> template shape index
+
+        def add_shapes(comp, body, fold):
+            for s in comp.collision_shapes:
+                if isinstance(s, P.PhysxCollisionShapePlane):
+                    if body >= 0:
+                        raise RuntimeError("plane collision shapes must belong to static actors")
+                    continue
+                lp = s._local_pose if fold is None else fold * s._local_pose
+                mat = s.physical_material
+                kw = dict(static_friction=mat.static_friction, dynamic_friction=mat.dynamic_friction, restitution=mat.restitution,
+                          groups=s._groups, patch_radius=s.patch_radius, min_patch_radius=s.min_patch_radius)
+                subs = [s]
+                if isinstance(s, P.PhysxCollisionShapeTriangleMesh):
+                    subs = s._hulls
+                for sub in subs:
+                    if isinstance(sub, P.PhysxCollisionShapeBox):
+                        sid = tpl.add_shape(body, N.SHAPE_BOX, lp._p, lp._q, sub.half_size, None, **kw)
+                    elif isinstance(sub, P.PhysxCollisionShapeConvexMesh):
+                        sid = tpl.add_shape(body, N.SHAPE_CONVEX, lp._p, lp._q, (0, 0, 0), sub._scaled_vertices, **kw)
+                    elif isinstance(sub, P.PhysxCollisionShapeSphere):
+                        sid = tpl.add_shape(body, N.SHAPE_SPHERE, lp._p, lp._q, (sub.radius, 0, 0), None, **kw)
+                    elif isinstance(sub, P.PhysxCollisionShapeCapsule):
+                        sid = tpl.add_shape(body, N.SHAPE_CAPSULE, lp._p, lp._q, (sub.radius, sub.half_length, 0), None, **kw)
+                    elif isinstance(sub, P.PhysxCollisionShapeCylinder):
+                        sid = tpl.add_shape(body, N.SHAPE_CYLINDER, lp._p, lp._q, (sub.radius, sub.half_length, 0), None, **kw)
+                    else:
+                        raise RuntimeError(f"collision shape {type(sub).__name__} is not supported")
+                    shape_ids.setdefault(id(s), sid)
+
+        for c in env0:
+            if isinstance(c, P.PhysxRigidStaticComponent):
+                add_shapes(c, -1, c.entity._pose)
+                body_ids[id(c)] = -1
+            elif isinstance(c, P.PhysxArticulationLinkComponent):
+                art = c.articulation
+                if id(art) not in art_ids:
+                    if art.root.joint._type != "fixed":
+                        raise RuntimeError(f"articulation {art.name!r}: only fixed-base articulations are supported "
+                                           "(fix_root_link=True); free roots are not")
+                    rp = art.root.entity._pose
+                    art_ids[id(art)] = tpl.add_articulation(art.name, rp._p, rp._q)
+                    arts0.append(art)
+                a = art_ids[id(art)]
+                j = c.joint
+                if c.parent is not None and j._type not in _JOINT:
+                    raise RuntimeError(f"joint {j.name!r}: type {j._type!r} is not supported")
+                m, com, I6 = c._mass_tensor()
+                lim = j._limits.reshape(-1) if j.dof else (-np.inf, np.inf)
+                if j._type == "revolute_unwrapped":
+                    lim = (-np.inf, np.inf)
+                bid = tpl.add_link(a, c.name, -1 if c.parent is None else body_ids[id(c.parent)],
+                                   _JOINT.get(j._type, 0) if c.parent is not None else 0, j.name, list(_pose7(j.pose_in_parent)),
+                                   list(_pose7(j.pose_in_child)), (lim[0], lim[1]), m, com, I6, c.disable_gravity, j._armature, j.friction)
+                body_ids[id(c)] = bid
+                if j.dof:
+                    tpl.set_drive(bid, j.stiffness, j.damping, j.force_limit, j.drive_mode)
+                add_shapes(c, bid, None)
+            else:
+                m, com, I6 = c._mass_tensor()
+                ep = c.entity._pose
+                kind = N.BODY_KINEMATIC if c.kinematic else N.BODY_DYNAMIC
+                if any(c.locked_motion_axes):
+                    raise RuntimeError("locked motion axes are not supported")
+                bid = tpl.add_actor(c.entity.name, kind, ep._p, ep._q, 0.0 if c.kinematic else m, com, I6, c.linear_damping,
+                                    c.angular_damping, c.disable_gravity)
+                body_ids[id(c)] = bid
+                add_shapes(c, bid, None)
+        for art in arts0:
+            for t in art._tendons:
+                chain, coef = t["chain"], t["coef"]
+                act = [(l, k) for l, k in zip(chain, coef) if k != 0.0]
+                if len(act) != 2:
+                    raise RuntimeError("fixed tendons are supported over exactly two driven joints (URDF mimic joints)")
+                (la, ka), (lb, kb) = act
+                tpl.add_tendon(body_ids[id(la)], body_ids[id(lb)], ka, kb, t["rest_length"], t["stiffness"], t["damping"])
+            by_name = {l.entity.name: l for l in art.links if l.entity is not None}
+            for l in art.links:
+                for other in sorted(getattr(l, "_srdf_disabled", ())):
+                    if other in by_name:
+                        tpl.disable_collision(body_ids[id(l)], body_ids[id(by_name[other])])
+
+        # ---- per-env instances ---------------------------------------------------------------------------------------------
+        inst = dict(boxes={}, masses={})
+        if hetero:
+            for k, c0 in enumerate(env0):
+                if isinstance(c0, P.PhysxRigidStaticComponent):
+                    fold = lambda comp: comp.entity._pose          # noqa: E731
+                else:
+                    fold = lambda comp: None                       # noqa: E731
+                for si, s0 in enumerate(c0.collision_shapes):
+                    if not isinstance(s0, P.PhysxCollisionShapeBox):
+                        continue
+                    hs = np.stack([per_env[e][k].collision_shapes[si].half_size for e in range(n_env)])
+                    lps = []
+                    for e in range(n_env):
+                        comp = per_env[e][k]
+                        f = fold(comp)
+                        lp = comp.collision_shapes[si]._local_pose
+                        lps.append((lp if f is None else f * lp)._p)
+                    lps = np.stack(lps)
+                    if np.ptp(hs, axis=0).max() > 0 or np.ptp(lps, axis=0).max() > 0:
+                        sid = shape_ids[id(s0)]
+                        tpl.declare_env_box(sid)
+                        inst["boxes"][sid] = (hs.astype(np.float32), lps.astype(np.float32))
+                if isinstance(c0, P.PhysxRigidDynamicComponent) and not c0.kinematic:
+                    mt = [per_env[e][k]._mass_tensor() for e in range(n_env)]
+                    ms = np.array([t[0] for t in mt], dtype=np.float32)
+                    I6 = np.array([t[2] for t in mt], dtype=np.float32)
+                    coms = np.array([t[1] for t in mt], dtype=np.float32)
+                    if np.ptp(ms) > 0 or np.ptp(I6, axis=0).max() > 0:
+                        if np.abs(coms).max() > 1e-7 or np.abs(I6[:, 3:]).max() > 1e-9 * max(float(np.abs(I6[:, :3]).max()), 1e-30):
+                            raise RuntimeError("per-sub-scene masses need the centre of mass at the body origin and a diagonal inertia")
+                        bid = body_ids[id(c0)]
+                        tpl.declare_env_mass(bid)
+                        inst["masses"][bid] = (ms, I6[:, :3].copy())
+
+        # ---- ids on every component -------------------------------------------------------------------------------------------
+        for e in range(n_env):
+            for k, c in enumerate(per_env[e]):
+                c._body_id = body_ids[id(env0[k])]
+                if isinstance(c, P.PhysxArticulationLinkComponent):
+                    c.articulation._art_id = art_ids[id(env0[k].articulation)]
+        self._per_env = per_env
+        self._n_env = n_env
+        return tpl, inst
+
+    # =============================================================================================================
+    # engine
+    # =============================================================================================================
+    def _start_engine(self, torch_device, lib, host_memory):
+        from maniskill_amd import physx as E
+        tpl, inst = self._compile()
+        sc, bc, shc = self._cfg["scene"], self._cfg["body"], self._cfg["shape"]
+        cfg = E.SimConfig(sim_freq=1.0 / self._timestep, control_freq=1.0 / self._timestep, scene_config=E.SceneConfig(
+            gravity=[float(g) for g in sc["gravity"]], bounce_threshold=sc["bounce_threshold"], sleep_threshold=bc["sleep_threshold"],
+            contact_offset=shc["contact_offset"], rest_offset=shc["rest_offset"],
+            solver_position_iterations=int(bc["solver_position_iterations"]), solver_velocity_iterations=int(bc["solver_velocity_iterations"]),
+            enable_pcm=bool(sc["enable_pcm"]), enable_tgs=bool(sc["enable_tgs"])))
+        cls = E.PhysxGpuSystem
+        if host_memory:
+            cls = type("HostMemorySystem", (E.PhysxGpuSystem,), dict(host_memory=True))
+        eng = cls(torch_device, tpl, self._n_env, cfg, lib=lib)
+        eng.gpu_init()
+        for sid, (hs, lp) in inst["boxes"].items():
+            eng.set_env_boxes(sid, hs, lp)
+        for bid, (m, I) in inst["masses"].items():
+            eng.set_env_masses(bid, m, I)
+        self._engine, self._template = eng, tpl
+        self._nb, self._na, self._max_dof = eng.bodies_per_env, eng.arts_per_env, eng.max_dof
+        self.cuda_rigid_body_data = eng.cuda_rigid_body_data
+        self.cuda_rigid_body_force = eng.cuda_rigid_body_force
+        self.cuda_rigid_body_torque = eng.cuda_rigid_body_torque
+        self.cuda_articulation_qpos = eng.cuda_articulation_qpos
+        self.cuda_articulation_qvel = eng.cuda_articulation_qvel
+        self.cuda_articulation_qacc = eng.cuda_articulation_qacc
+        self.cuda_articulation_qf = eng.cuda_articulation_qf
+        self.cuda_articulation_target_qpos = eng.cuda_articulation_target_qpos
+        self.cuda_articulation_target_qvel = eng.cuda_articulation_target_qvel
+        lf = eng.cuda_articulation_link_incoming_joint_forces
+        rows = self._n_env * max(self._na, 1)
+        self.cuda_articulation_link_incoming_joint_forces = _Handle3D(lf, (rows, max(lf.shape[0] // max(rows, 1), 1), 6))
+        self._initialized = True
+
+    # indices ------------------------------------------------------------------------------------------------------------
+    def _pose_index(self, comp) -> int:
+        if comp._body_id < 0:
+            raise RuntimeError("static bodies have no row in cuda_rigid_body_data")
+        return comp._env * self._nb + comp._body_id
+
+    def _art_index(self, art) -> int:
+        return art._env * self._na + art._art_id
+
+    # CPU-style accessors (synchronous; off the hot path) ---------------------------------------------------------------
+    def _sync_in(self):
+        self._engine._fetch(_SYNC_FETCH)
+
+    def _read_body_row(self, comp):
+        self._sync_in()
+        return self.cuda_rigid_body_data.torch()[self._pose_index(comp)].detach().cpu().numpy().copy()
+
+    def _read_body_pose(self, comp) -> Pose:
+        if comp._body_id < 0:
+            return comp.entity._pose
+        r = self._read_body_row(comp)
+        return Pose(r[:3], r[3:7])
+
+    def _write_body_pose(self, comp, pose: Pose):
+        if comp._body_id < 0:
+            raise RuntimeError("static bodies cannot be moved after the simulation was initialised")
+        self._sync_in()
+        row = self.cuda_rigid_body_data.torch()[self._pose_index(comp)]
+        row[:7] = torch.as_tensor(np.concatenate([pose._p, pose._q]), device=row.device)
+        P = self._P
+        if isinstance(comp, P.PhysxArticulationLinkComponent):
+            if not comp.is_root:
+                raise RuntimeError("only the root link of an articulation can be moved")
+            self._engine.gpu_apply_articulation_root_pose()
+            self._engine.gpu_update_articulation_kinematics()
+        else:
+            self._engine.gpu_apply_rigid_dynamic_data()
+
+    def _write_body_cols(self, comp, col0, vals):
+        self._sync_in()
+        row = self.cuda_rigid_body_data.torch()[self._pose_index(comp)]
+        row[col0:col0 + 3] = torch.as_tensor(vals.reshape(3), device=row.device)
+        self._engine.gpu_apply_rigid_dynamic_data()
+
+    def _art_buf(self, name):
+        return getattr(self, "cuda_articulation_" + name).torch()
+
+    def _read_art_vec(self, art, name):
+        self._sync_in()
+        return self._art_buf(name)[self._art_index(art), :art.dof].detach().cpu().numpy().copy()
+
+    def _write_art_vec(self, art, name, v):
+        self._sync_in()
+        buf = self._art_buf(name)
+        buf[self._art_index(art), :art.dof] = torch.as_tensor(v, device=buf.device)
+        getattr(self._engine, {"qpos": "gpu_apply_articulation_qpos", "qvel": "gpu_apply_articulation_qvel",
+                               "qf": "gpu_apply_articulation_qf", "target_qpos": "gpu_apply_articulation_target_position",
+                               "target_qvel": "gpu_apply_articulation_target_velocity"}[name])()
+        if name == "qpos":
+            self._engine.gpu_update_articulation_kinematics()
+
+    def _dof_index(self, art, joint):
+        return art.active_joints.index(joint)
+
+    def _read_dof(self, art, name, joint):
+        return float(self._read_art_vec(art, name)[self._dof_index(art, joint)])
+
+    def _write_dof(self, art, name, joint, v):
+        vec = self._read_art_vec(art, name)
+        vec[self._dof_index(art, joint)] = v
+        self._write_art_vec(art, name, vec)
+
+    def _read_link_joint_forces(self, art):
+        self._engine.gpu_fetch_articulation_link_incoming_joint_forces()
+        t = self.cuda_articulation_link_incoming_joint_forces.torch()
+        return t[self._art_index(art), :len(art.links)].detach().cpu().numpy().copy()
+
+    def _add_force_torque(self, comp, force, torque):
+        F = self.cuda_rigid_body_force.torch()
+        T = self.cuda_rigid_body_torque.torch()
+        i = self._pose_index(comp)
+        F[i, :3] += torch.as_tensor(force, device=F.device)
+        T[i, :3] += torch.as_tensor(torque, device=T.device)
+        self._engine.gpu_apply_rigid_dynamic_force()
+        self._engine.gpu_apply_rigid_dynamic_torque()
+
+    def _add_force_at_point(self, comp, force, point):
+        pose = self._read_body_pose(comp)
+        com = (pose * comp.cmass_local_pose).p
+        self._add_force_torque(comp, force, np.cross(point - com, force))
+
+    def _drive_changed(self, joint):
+        raise RuntimeError("drive properties cannot be changed after the simulation was initialised (choose the control mode at "
+                           "construction)")
+
+    def step(self):
+        self._engine.step()
+
+
+class PhysxGpuSystem(PhysxSystem):
+    """``physx.PhysxGpuSystem(device)`` (sapien_env.py:1187): every sub-scene of this process on one GPU."""
+
+    def __init__(self, device=None):
+        super().__init__()
+        from . import physx as P
+        from ._core import Device
+        self.device = device if (isinstance(device, Device) or hasattr(device, "is_cuda")) else Device(device if device is not None else "cuda")
+        self._backend = P._backend
+
+    def _torch_device(self):
+        if self._backend is not None and self._backend[1]:
+            return torch.device("cpu")
+        return torch.device("cuda", max(int(getattr(self.device, "cuda_id", 0)), 0))
+
+    def gpu_init(self):
+        if self._initialized:
+            raise RuntimeError("gpu_init() was already called")
+        if not self._scenes:
+            raise RuntimeError("gpu_init() without sub-scenes")
+        if self._backend is not None:
+            lib, host = self._backend
+        else:
+            from maniskill_amd import _native as N
+            lib, host = N.default_lib(), False          # raises if libmsk_physx.so is missing: no CPU fallback
+        self._start_engine(self._torch_device(), lib, host)
+
+    # apply / fetch ------------------------------------------------------------------------------------------------------
+    def gpu_apply_rigid_dynamic_data(self): self._engine.gpu_apply_rigid_dynamic_data()
+    def gpu_apply_rigid_dynamic_force(self): self._engine.gpu_apply_rigid_dynamic_force()
+    def gpu_apply_rigid_dynamic_torque(self): self._engine.gpu_apply_rigid_dynamic_torque()
+    def gpu_apply_articulation_root_pose(self): self._engine.gpu_apply_articulation_root_pose()
+    def gpu_apply_articulation_root_velocity(self): self._engine.gpu_apply_articulation_root_velocity()
+    def gpu_apply_articulation_qpos(self): self._engine.gpu_apply_articulation_qpos()
+    def gpu_apply_articulation_qvel(self): self._engine.gpu_apply_articulation_qvel()
+    def gpu_apply_articulation_qf(self): self._engine.gpu_apply_articulation_qf()
+    def gpu_apply_articulation_target_position(self): self._engine.gpu_apply_articulation_target_position()
+    def gpu_apply_articulation_target_velocity(self): self._engine.gpu_apply_articulation_target_velocity()
+    def gpu_fetch_rigid_dynamic_data(self): self._engine.gpu_fetch_rigid_dynamic_data()
+    def gpu_fetch_articulation_link_pose(self): self._engine.gpu_fetch_articulation_link_pose()
+    def gpu_fetch_articulation_link_velocity(self): pass   # same rows as link_pose: fetched together
+    def gpu_fetch_articulation_qpos(self): self._engine.gpu_fetch_articulation_qpos()
+    def gpu_fetch_articulation_qvel(self): self._engine.gpu_fetch_articulation_qvel()
+    def gpu_fetch_articulation_qacc(self): self._engine.gpu_fetch_articulation_qacc()
+    def gpu_fetch_articulation_target_qpos(self): self._engine.gpu_fetch_articulation_target_qpos()
+    def gpu_fetch_articulation_target_qvel(self): pass     # written together with target_qpos
+    def gpu_fetch_articulation_link_incoming_joint_forces(self): self._engine.gpu_fetch_articulation_link_incoming_joint_forces()
+    def gpu_update_articulation_kinematics(self): self._engine.gpu_update_articulation_kinematics()
+
+    def sync_poses_gpu_to_cpu(self):
+        self._sync_in()
+        rows = self.cuda_rigid_body_data.torch().detach().cpu().numpy()
+        for c in self._components:
+            if c._body_id >= 0 and c.entity is not None:
+                r = rows[self._pose_index(c)]
+                c.entity._pose = Pose(r[:3], r[3:7])
+
+    # contact queries (envs/scene.py:741-801; utils/structs/base.py:116-136; articulation.py:447-462) ---------------------------
+    def _gather(self, listed_keys, listed_envs):
+        """listed row j asks for engine key listed_keys[j] in sub-scene listed_envs[j] -> (unique keys, index tensor or None)."""
+        uniq = []
+        pos = {}
+        for k in listed_keys:
+            if k not in pos:
+                pos[k] = len(uniq)
+                uniq.append(k)
+        U = len(uniq)
+        idx = np.array([e * U + pos[k] for k, e in zip(listed_keys, listed_envs)], dtype=np.int64)
+        identity = len(idx) == self._n_env * U and np.array_equal(idx, np.arange(len(idx)))
+        return uniq, (None if identity else idx)
+
+    def gpu_create_contact_pair_impulse_query(self, body_pairs):
+        keys, envs = [], []
+        for a, b in body_pairs:
+            if a._env != b._env:
+                raise RuntimeError("a contact pair must live in one sub-scene")
+            keys.append((a._body_id, b._body_id))
+            envs.append(a._env)
+        uniq, idx = self._gather(keys, envs)
+        q = self._engine.gpu_create_contact_pair_impulse_query(uniq)
+        dev = q.cuda_impulses.torch().device
+        return _GatherQuery(q.id, q.cuda_impulses, None if idx is None else torch.as_tensor(idx, device=dev))
+
+    def gpu_create_contact_body_impulse_query(self, bodies):
+        keys = [b._body_id for b in bodies]
+        envs = [b._env for b in bodies]
+        uniq, idx = self._gather(keys, envs)
+        q = self._engine.gpu_create_contact_body_impulse_query(uniq)
+        dev = q.cuda_impulses.torch().device
+        return _GatherQuery(q.id, q.cuda_impulses, None if idx is None else torch.as_tensor(idx, device=dev))
+
+    def gpu_query_contact_pair_impulses(self, query):
+        self._engine.gpu_query_contact_pair_impulses(query)
+
+    def gpu_query_contact_body_impulses(self, query):
+        self._engine.gpu_query_contact_body_impulses(query)
+
+
+class PhysxCpuSystem(PhysxSystem):
+    """``physx.PhysxCpuSystem()`` (sapien_env.py:1212): one sub-scene with SAPIEN's per-object API.  The same C-ABI library
+    simulates it (a single-env context on the GPU, or the test-suite's injected checker); component getters / setters
+    read and write the state buffers synchronously."""
+
+    def __init__(self):
+        super().__init__()
+        from . import physx as P
+        self._backend = P._backend
+        self._lazy_failed = None
+
+    def _ensure(self):
+        if self._initialized:
+            return
+        if len(self._scenes) != 1:
+            raise RuntimeError("PhysxCpuSystem simulates exactly one scene")
+        if self._backend is not None:
+            lib, host = self._backend
+            dev = torch.device("cpu") if host else torch.device("cuda", 0)
+        else:
+            from maniskill_amd import _native as N
+            lib, host, dev = N.default_lib(), False, torch.device("cuda", 0)
+        self._start_engine(dev, lib, host)
+        # host-side initial state recorded before the first step
+        for c in self._components:
+            if c._body_id < 0:
+                continue
+            if isinstance(c, self._P.PhysxArticulationLinkComponent):
+                continue
+            self._write_body_pose(c, c.entity._pose)
+        seen = set()
+        for c in self._components:
+            if isinstance(c, self._P.PhysxArticulationLinkComponent) and id(c.articulation) not in seen:
+                art = c.articulation
+                seen.add(id(art))
+                self._write_body_pose(art.root, art.root.entity._pose)
+                if art._qpos0 is not None:
+                    self._write_art_vec(art, "qpos", art._qpos0)
+                tq = np.array([j._drive_target for j in art.active_joints], dtype=np.float32)
+                tv = np.array([j._drive_velocity_target for j in art.active_joints], dtype=np.float32)
+                self._write_art_vec(art, "target_qpos", tq)
+                self._write_art_vec(art, "target_qvel", tv)
+
+    def step(self):
+        self._ensure()
+        self._engine.step()
+
+    def get_contacts(self):
+        self._ensure()
+        P = self._P
+        ids, vals = self._engine.get_contacts(0, 256)
+        if len(ids) == 0:
+            return []
+        shape_owner = {}
+        si = len(self._static_shape_owner)
+        owners = list(self._static_shape_owner)
+        for c in self._per_env[0]:
+            for s in c.collision_shapes:
+                if isinstance(s, P.PhysxCollisionShapePlane):
+                    continue
+                subs = s._hulls if isinstance(s, P.PhysxCollisionShapeTriangleMesh) else [s]
+                owners.extend([s] * len(subs))
+        from ._pose import _qrot  # noqa: F401
+        by_pair = {}
+        for (sa, sb, _), v in zip(ids, vals):
+            by_pair.setdefault((int(sa), int(sb)), []).append(v)
+        out = []
+        for (sa, sb), pts in by_pair.items():
+            A, B = owners[sa], owners[sb]
+            points = []
+            for v in pts:
+                n = v[3:6]
+                points.append(P.PhysxContactPoint(position=v[:3].copy(), normal=n.copy(), impulse=(n * v[7]).astype(np.float32),
+                                                  separation=float(v[6])))
+            out.append(P.PhysxContact([A._body, B._body], [A, B], points))
+        return out

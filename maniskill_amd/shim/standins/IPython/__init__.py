@@ -1,0 +1,2 @@
+"""Stand-in so that ``from IPython.display import HTML, display`` (mani_skill/utils/visualization/jupyter_utils.py:3) imports."""
+from . import display  # noqa: F401

@@ -1,0 +1,8 @@
+class HTML:
+    def __init__(self, data=None, **kw):
+        self.data = data
+
+
+def display(*objs, **kw):
+    for o in objs:
+        print(o)

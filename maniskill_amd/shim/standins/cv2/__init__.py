@@ -1,0 +1,5 @@
+"""Stand-in so that module-level ``import cv2`` statements succeed; any use raises."""
+
+
+def __getattr__(name):
+    raise ImportError(f"cv2 is not installed (stand-in module): cv2.{name} is unavailable")

@@ -1,0 +1,65 @@
+"""Stand-in for ``dacite`` (only ``from_dict`` + ``Config(strict=...)``), used when the real package is not installed.
+The reference builds its SimConfig with it (mani_skill/envs/sapien_env.py:265)."""
+from __future__ import annotations
+
+import dataclasses
+import typing
+from dataclasses import dataclass, field
+
+
+@dataclass
+class Config:
+    strict: bool = False
+    check_types: bool = True
+    type_hooks: dict = field(default_factory=dict)
+    cast: list = field(default_factory=list)
+
+
+class DaciteError(Exception):
+    pass
+
+
+class UnexpectedDataError(DaciteError):
+    pass
+
+
+class MissingValueError(DaciteError):
+    pass
+
+
+def _build(tp, value, config):
+    origin = typing.get_origin(tp)
+    if dataclasses.is_dataclass(tp) and isinstance(value, dict):
+        return from_dict(tp, value, config)
+    if origin is typing.Union:
+        for arg in typing.get_args(tp):
+            if dataclasses.is_dataclass(arg) and isinstance(value, dict):
+                return from_dict(arg, value, config)
+        return value
+    if origin in (list, tuple) and isinstance(value, (list, tuple)):
+        args = typing.get_args(tp)
+        if args and dataclasses.is_dataclass(args[0]):
+            return type(value)(_build(args[0], v, config) for v in value)
+        return value
+    if origin is dict and isinstance(value, dict):
+        args = typing.get_args(tp)
+        if len(args) == 2 and dataclasses.is_dataclass(args[1]):
+            return {k: _build(args[1], v, config) for k, v in value.items()}
+    return value
+
+
+def from_dict(data_class, data, config: Config = None):
+    config = config or Config()
+    hints = typing.get_type_hints(data_class)
+    names = {f.name for f in dataclasses.fields(data_class)}
+    if config.strict:
+        extra = set(data.keys()) - names
+        if extra:
+            raise UnexpectedDataError(f'can not match {extra} to any data class field')
+    kwargs = {}
+    for f in dataclasses.fields(data_class):
+        if f.name in data:
+            kwargs[f.name] = _build(hints.get(f.name, typing.Any), data[f.name], config)
+        elif f.default is dataclasses.MISSING and f.default_factory is dataclasses.MISSING:
+            raise MissingValueError(f'missing value for field "{f.name}"')
+    return data_class(**kwargs)

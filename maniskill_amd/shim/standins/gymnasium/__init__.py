@@ -1,0 +1,30 @@
+"""Minimal stand-in for the ``gymnasium`` package (API of 0.29.1), used only when the real one is not installed.
+
+ManiSkill's host Python (mani_skill/envs/sapien_env.py:8, utils/registration.py:9-12, agents/controllers/base_controller.py:10-11,
+vector/wrappers/gymnasium.py:5-7) needs Env / Wrapper / spaces / register / make / VectorEnv / batch_space; this image has no
+network to install gymnasium, so maniskill_amd.shim.install() puts this directory on sys.path *behind* site-packages: a real
+gymnasium always wins.  Written from the documented gymnasium API; nothing here is on the simulation hot path.
+"""
+__version__ = "0.29.1"
+
+from . import envs, spaces, vector, wrappers  # noqa: E402,F401
+from .core import ActionWrapper, Env, ObservationWrapper, RewardWrapper, Wrapper  # noqa: E402,F401
+from .envs.registration import EnvSpec, make, make_vec, register, registry, spec  # noqa: E402,F401
+from .spaces import Space  # noqa: E402,F401
+
+
+class error:  # namespace, as gymnasium.error
+    class Error(Exception):
+        pass
+
+    class ResetNeeded(Error):
+        pass
+
+
+class logger:  # namespace, as gymnasium.logger
+    @staticmethod
+    def warn(msg, *args):
+        import warnings
+        warnings.warn(msg % args if args else msg)
+
+    info = debug = staticmethod(lambda *a, **k: None)

@@ -1,0 +1,185 @@
+"""Env / Wrapper of the gymnasium stand-in (0.29-era API: 5-tuple step, (obs, info) reset, get_wrapper_attr)."""
+from __future__ import annotations
+
+from typing import Any, Generic, Optional, TypeVar
+
+import numpy as np
+
+ObsType = TypeVar("ObsType")
+ActType = TypeVar("ActType")
+
+
+class Env(Generic[ObsType, ActType]):
+    metadata: dict = {"render_modes": []}
+    render_mode: Optional[str] = None
+    spec = None
+    action_space = None
+    observation_space = None
+    _np_random = None
+
+    def step(self, action):
+        raise NotImplementedError
+
+    def reset(self, *, seed=None, options=None):
+        if seed is not None:
+            self._np_random = np.random.default_rng(seed)
+        return None, {}
+
+    def render(self):
+        raise NotImplementedError
+
+    def close(self):
+        pass
+
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def np_random(self):
+        if self._np_random is None:
+            self._np_random = np.random.default_rng()
+        return self._np_random
+
+    @np_random.setter
+    def np_random(self, value):
+        self._np_random = value
+
+    def has_wrapper_attr(self, name: str) -> bool:
+        return hasattr(self, name)
+
+    def get_wrapper_attr(self, name: str):
+        return getattr(self, name)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *args):
+        self.close()
+        return False
+
+    def __str__(self):
+        return f"<{type(self).__name__} instance>" if self.spec is None else f"<{type(self).__name__}<{self.spec.id}>>"
+
+
+class Wrapper(Env):
+    """Forwards everything to ``self.env``; spaces / metadata can be overridden per wrapper."""
+
+    def __init__(self, env: Env):
+        self.env = env
+        self._action_space = None
+        self._observation_space = None
+        self._metadata = None
+
+    def __getattr__(self, name):
+        if name.startswith("_") or name == "env":
+            raise AttributeError(f"accessing private attribute '{name}' is prohibited")
+        return getattr(self.env, name)
+
+    def get_wrapper_attr(self, name: str):
+        if name in self.__dict__ or any(name in c.__dict__ for c in type(self).__mro__ if c not in (Wrapper, Env, object, Generic)):
+            return getattr(self, name)
+        if name in ("action_space", "observation_space", "metadata", "spec", "render_mode", "unwrapped", "np_random"):
+            return getattr(self, name)
+        try:
+            return self.env.get_wrapper_attr(name)
+        except AttributeError as e:
+            raise AttributeError(f"wrapper {type(self).__name__} has no attribute {name!r}") from e
+
+    def has_wrapper_attr(self, name: str) -> bool:
+        try:
+            self.get_wrapper_attr(name)
+            return True
+        except AttributeError:
+            return False
+
+    @property
+    def spec(self):
+        return self.env.spec
+
+    @property
+    def action_space(self):
+        return self.env.action_space if self._action_space is None else self._action_space
+
+    @action_space.setter
+    def action_space(self, space):
+        self._action_space = space
+
+    @property
+    def observation_space(self):
+        return self.env.observation_space if self._observation_space is None else self._observation_space
+
+    @observation_space.setter
+    def observation_space(self, space):
+        self._observation_space = space
+
+    @property
+    def metadata(self):
+        return self.env.metadata if self._metadata is None else self._metadata
+
+    @metadata.setter
+    def metadata(self, value):
+        self._metadata = value
+
+    @property
+    def render_mode(self):
+        return self.env.render_mode
+
+    @property
+    def np_random(self):
+        return self.env.np_random
+
+    @np_random.setter
+    def np_random(self, value):
+        self.env.np_random = value
+
+    @property
+    def unwrapped(self):
+        return self.env.unwrapped
+
+    def step(self, action):
+        return self.env.step(action)
+
+    def reset(self, *, seed=None, options=None):
+        return self.env.reset(seed=seed, options=options)
+
+    def render(self):
+        return self.env.render()
+
+    def close(self):
+        return self.env.close()
+
+    def __str__(self):
+        return f"<{type(self).__name__}{self.env}>"
+
+    __repr__ = __str__
+
+
+class ObservationWrapper(Wrapper):
+    def reset(self, *, seed=None, options=None):
+        obs, info = self.env.reset(seed=seed, options=options)
+        return self.observation(obs), info
+
+    def step(self, action):
+        obs, reward, terminated, truncated, info = self.env.step(action)
+        return self.observation(obs), reward, terminated, truncated, info
+
+    def observation(self, observation):
+        raise NotImplementedError
+
+
+class RewardWrapper(Wrapper):
+    def step(self, action):
+        obs, reward, terminated, truncated, info = self.env.step(action)
+        return obs, self.reward(reward), terminated, truncated, info
+
+    def reward(self, reward):
+        raise NotImplementedError
+
+
+class ActionWrapper(Wrapper):
+    def step(self, action):
+        return self.env.step(self.action(action))
+
+    def action(self, action):
+        raise NotImplementedError

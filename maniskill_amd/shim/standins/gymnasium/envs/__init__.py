@@ -1,0 +1,2 @@
+from . import registration  # noqa: F401
+from .registration import make, register, registry, spec  # noqa: F401

@@ -1,0 +1,105 @@
+"""register / make of the gymnasium stand-in.
+
+The reference registers every task with ``gym.register(uid, entry_point=partial(make, env_id=uid), max_episode_steps=...,
+additional_wrappers=[WrapperSpec("MSTimeLimit", ...)])`` (utils/registration.py:236-257) and its MSTimeLimit wrapper inspects the
+calling frame for a function called ``make`` with a local ``max_episode_steps`` (:131-136): so ``make`` below applies the
+additional wrappers inline and keeps that local name.
+"""
+from __future__ import annotations
+
+import copy
+import importlib
+from dataclasses import dataclass, field
+from typing import Any, Callable, Optional, Union
+
+
+@dataclass
+class WrapperSpec:
+    name: str
+    entry_point: str
+    kwargs: Optional[dict]
+
+
+@dataclass
+class EnvSpec:
+    id: str
+    entry_point: Union[Callable, str, None] = None
+    reward_threshold: Optional[float] = None
+    nondeterministic: bool = False
+    max_episode_steps: Optional[int] = None
+    order_enforce: bool = True
+    autoreset: bool = False
+    disable_env_checker: bool = False
+    apply_api_compatibility: bool = False
+    kwargs: dict = field(default_factory=dict)
+    additional_wrappers: tuple = field(default_factory=tuple)
+    vector_entry_point: Union[Callable, str, None] = None
+    namespace: Optional[str] = None
+    name: Optional[str] = None
+    version: Optional[int] = None
+
+    def __post_init__(self):
+        self.name = self.id
+
+    def make(self, **kwargs):
+        return make(self, **kwargs)
+
+
+registry: dict[str, EnvSpec] = {}
+
+
+def _load(entry_point):
+    if callable(entry_point):
+        return entry_point
+    mod, attr = entry_point.split(":")
+    obj = importlib.import_module(mod)
+    for part in attr.split("."):
+        obj = getattr(obj, part)
+    return obj
+
+
+def register(id: str, entry_point=None, reward_threshold=None, nondeterministic=False, max_episode_steps=None, order_enforce=True,
+             autoreset=False, disable_env_checker=False, apply_api_compatibility=False, additional_wrappers=(), vector_entry_point=None,
+             kwargs: Optional[dict] = None, **extra):
+    registry[id] = EnvSpec(id=id, entry_point=entry_point, reward_threshold=reward_threshold, nondeterministic=nondeterministic,
+                           max_episode_steps=max_episode_steps, order_enforce=order_enforce, autoreset=autoreset,
+                           disable_env_checker=disable_env_checker, apply_api_compatibility=apply_api_compatibility,
+                           kwargs=dict(kwargs or {}), additional_wrappers=tuple(additional_wrappers), vector_entry_point=vector_entry_point)
+
+
+def spec(env_id: str) -> EnvSpec:
+    if env_id not in registry:
+        raise KeyError(f"No registered env with id: {env_id}")
+    return registry[env_id]
+
+
+def make(id, max_episode_steps: Optional[int] = None, autoreset: Optional[bool] = None, apply_api_compatibility: Optional[bool] = None,
+         disable_env_checker: Optional[bool] = None, **kwargs):
+    from ..wrappers import OrderEnforcing, TimeLimit
+
+    env_spec = id if isinstance(id, EnvSpec) else spec(id)
+    env_spec_kwargs = copy.deepcopy(env_spec.kwargs)
+    env_spec_kwargs.update(kwargs)
+    env_creator = _load(env_spec.entry_point)
+    env = env_creator(**env_spec_kwargs)
+    made_spec = copy.copy(env_spec)
+    made_spec.kwargs = env_spec_kwargs
+    if max_episode_steps is not None:
+        made_spec.max_episode_steps = max_episode_steps
+    env.unwrapped.spec = made_spec
+    if env_spec.order_enforce:
+        env = OrderEnforcing(env)
+    if max_episode_steps is not None:
+        env = TimeLimit(env, max_episode_steps)
+    elif env_spec.max_episode_steps is not None:
+        env = TimeLimit(env, env_spec.max_episode_steps)
+    for wrapper_spec in env_spec.additional_wrappers:
+        env = _load(wrapper_spec.entry_point)(env=env, **(wrapper_spec.kwargs or {}))
+    return env
+
+
+def make_vec(id, num_envs: int = 1, **kwargs):
+    env_spec = spec(id)
+    if env_spec.vector_entry_point is None:
+        raise ValueError(f"{id} has no vector_entry_point")
+    return _load(env_spec.vector_entry_point)(num_envs=num_envs, **kwargs)

@@ -1,0 +1,222 @@
+"""Spaces of the gymnasium stand-in (see gymnasium/__init__.py of this directory for why it exists)."""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Any, Iterable, Mapping, Optional, Sequence
+
+import numpy as np
+
+
+class Space:
+    def __init__(self, shape=None, dtype=None, seed=None):
+        self._shape = None if shape is None else tuple(int(s) for s in shape)
+        self.dtype = None if dtype is None else np.dtype(dtype)
+        self._np_random = None
+        self._seed = seed
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def np_random(self) -> np.random.Generator:
+        if self._np_random is None:
+            self.seed(self._seed)
+        return self._np_random
+
+    def seed(self, seed=None):
+        self._np_random = np.random.default_rng(seed)
+        return [seed]
+
+    @property
+    def is_np_flattenable(self):
+        return False
+
+    def sample(self, mask=None):
+        raise NotImplementedError
+
+    def contains(self, x) -> bool:
+        raise NotImplementedError
+
+    def __contains__(self, x):
+        return self.contains(x)
+
+
+class Box(Space):
+    def __init__(self, low, high, shape: Optional[Sequence[int]] = None, dtype=np.float32, seed=None):
+        dtype = np.dtype(dtype)
+        if shape is not None:
+            shape = tuple(int(s) for s in shape)
+        elif isinstance(low, np.ndarray):
+            shape = low.shape
+        elif isinstance(high, np.ndarray):
+            shape = high.shape
+        elif np.isscalar(low) and np.isscalar(high):
+            shape = (1,)
+        else:
+            raise ValueError("Box shape cannot be inferred from low / high")
+        super().__init__(shape, dtype, seed)
+
+        def full(v):
+            # float bounds into an integer box: +-inf become the dtype's range (as gymnasium does)
+            a = np.asarray(v)
+            if dtype.kind in "iu" and a.dtype.kind == "f":
+                info = np.iinfo(dtype)
+                finite = np.isfinite(a)
+                out = np.where(finite, np.where(finite, a, 0).astype(dtype), np.where(a > 0, info.max, info.min)).astype(dtype)
+                a = out
+            else:
+                a = a.astype(dtype)
+            return np.full(shape, a, dtype=dtype) if a.shape == () else np.broadcast_to(a, shape).copy()
+
+        self.low, self.high = full(low), full(high)
+        self.bounded_below = np.asarray(-np.inf < np.asarray(low, dtype=np.float64)) & np.ones(shape, bool)
+        self.bounded_above = np.asarray(np.inf > np.asarray(high, dtype=np.float64)) & np.ones(shape, bool)
+
+    @property
+    def is_np_flattenable(self):
+        return True
+
+    def is_bounded(self, manner="both"):
+        below, above = bool(np.all(self.bounded_below)), bool(np.all(self.bounded_above))
+        return {"both": below and above, "below": below, "above": above}[manner]
+
+    def sample(self, mask=None):
+        rng = self.np_random
+        if self.dtype.kind == "f":
+            out = np.empty(self.shape, dtype=np.float64)
+            unb = ~self.bounded_below & ~self.bounded_above
+            upp = ~self.bounded_below & self.bounded_above
+            low = self.bounded_below & ~self.bounded_above
+            bnd = self.bounded_below & self.bounded_above
+            out[unb] = rng.normal(size=unb[unb].shape)
+            out[low] = rng.exponential(size=low[low].shape) + self.low[low]
+            out[upp] = -rng.exponential(size=upp[upp].shape) + self.high[upp]
+            out[bnd] = rng.uniform(low=self.low[bnd], high=self.high[bnd], size=bnd[bnd].shape)
+            return out.astype(self.dtype)
+        if self.dtype.kind == "b":
+            return rng.integers(0, 2, size=self.shape).astype(self.dtype)
+        return rng.integers(self.low.astype(np.int64), self.high.astype(np.int64) + 1, size=self.shape).astype(self.dtype)
+
+    def contains(self, x) -> bool:
+        x = np.asarray(x)
+        return bool(x.shape == self.shape and np.all(x >= self.low) and np.all(x <= self.high))
+
+    def __repr__(self):
+        return f"Box({self.low.min() if self.low.size else 0}, {self.high.max() if self.high.size else 0}, {self.shape}, {self.dtype})"
+
+    def __eq__(self, other):
+        return isinstance(other, Box) and self.shape == other.shape and self.dtype == other.dtype \
+            and np.array_equal(self.low, other.low) and np.array_equal(self.high, other.high)
+
+
+class Discrete(Space):
+    def __init__(self, n: int, seed=None, start: int = 0):
+        super().__init__((), np.int64, seed)
+        self.n, self.start = int(n), int(start)
+
+    @property
+    def is_np_flattenable(self):
+        return True
+
+    def sample(self, mask=None):
+        return np.int64(self.start + self.np_random.integers(self.n))
+
+    def contains(self, x) -> bool:
+        return self.start <= int(x) < self.start + self.n
+
+    def __repr__(self):
+        return f"Discrete({self.n})"
+
+    def __eq__(self, other):
+        return isinstance(other, Discrete) and (self.n, self.start) == (other.n, other.start)
+
+
+class MultiDiscrete(Space):
+    def __init__(self, nvec, dtype=np.int64, seed=None):
+        self.nvec = np.asarray(nvec, dtype=dtype)
+        super().__init__(self.nvec.shape, dtype, seed)
+
+    def sample(self, mask=None):
+        return (self.np_random.random(self.nvec.shape) * self.nvec).astype(self.dtype)
+
+    def contains(self, x) -> bool:
+        x = np.asarray(x)
+        return bool(x.shape == self.shape and np.all(x >= 0) and np.all(x < self.nvec))
+
+
+class Dict(Space, Mapping):
+    """Keeps the order of a list of (key, space) pairs; sorts the keys of a plain dict (as gymnasium does)."""
+
+    def __init__(self, spaces=None, seed=None, **kw):
+        if isinstance(spaces, Mapping) and not isinstance(spaces, OrderedDict):
+            try:
+                spaces = OrderedDict(sorted(spaces.items()))
+            except TypeError:
+                spaces = OrderedDict(spaces.items())
+        elif isinstance(spaces, (list, tuple)) or isinstance(spaces, OrderedDict):
+            spaces = OrderedDict(spaces)
+        elif spaces is None:
+            spaces = OrderedDict()
+        for k, v in kw.items():
+            spaces[k] = v
+        self.spaces = spaces
+        Space.__init__(self, None, None, seed)
+
+    @property
+    def is_np_flattenable(self):
+        return all(s.is_np_flattenable for s in self.spaces.values())
+
+    def seed(self, seed=None):
+        super().seed(seed)
+        for i, s in enumerate(self.spaces.values()):
+            s.seed(None if seed is None else int(seed) + i + 1)
+        return [seed]
+
+    def sample(self, mask=None):
+        return OrderedDict((k, s.sample()) for k, s in self.spaces.items())
+
+    def contains(self, x) -> bool:
+        return isinstance(x, Mapping) and x.keys() == self.spaces.keys() and all(self.spaces[k].contains(x[k]) for k in self.spaces)
+
+    def __getitem__(self, key):
+        return self.spaces[key]
+
+    def __setitem__(self, key, value):
+        self.spaces[key] = value
+
+    def __iter__(self):
+        return iter(self.spaces)
+
+    def __len__(self):
+        return len(self.spaces)
+
+    def __repr__(self):
+        return "Dict(" + ", ".join(f"{k!r}: {s}" for k, s in self.spaces.items()) + ")"
+
+    def __eq__(self, other):
+        return isinstance(other, Dict) and list(self.spaces.items()) == list(other.spaces.items())
+
+
+class Tuple(Space, Sequence):
+    def __init__(self, spaces: Iterable[Space], seed=None):
+        self.spaces = tuple(spaces)
+        Space.__init__(self, None, None, seed)
+
+    def sample(self, mask=None):
+        return tuple(s.sample() for s in self.spaces)
+
+    def contains(self, x) -> bool:
+        return isinstance(x, (tuple, list)) and len(x) == len(self.spaces) and all(s.contains(v) for s, v in zip(self.spaces, x))
+
+    def __getitem__(self, i):
+        return self.spaces[i]
+
+    def __len__(self):
+        return len(self.spaces)
+
+
+from . import utils  # noqa: E402,F401
+from .utils import flatdim, flatten, flatten_space, unflatten  # noqa: E402,F401
+
+__all__ = ["Space", "Box", "Discrete", "MultiDiscrete", "Dict", "Tuple", "flatten_space", "flatten", "flatdim", "unflatten", "utils"]

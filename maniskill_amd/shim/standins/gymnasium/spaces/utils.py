@@ -1,0 +1,64 @@
+"""flatten helpers of the gymnasium stand-in (Box / Discrete / Dict / Tuple only)."""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+
+
+def flatdim(space) -> int:
+    from . import Box, Dict, Discrete, Tuple
+    if isinstance(space, Box):
+        return int(np.prod(space.shape))
+    if isinstance(space, Discrete):
+        return space.n
+    if isinstance(space, Dict):
+        return sum(flatdim(s) for s in space.spaces.values())
+    if isinstance(space, Tuple):
+        return sum(flatdim(s) for s in space.spaces)
+    raise NotImplementedError(type(space))
+
+
+def flatten_space(space):
+    from . import Box, Dict, Discrete, Tuple
+    if isinstance(space, Box):
+        return Box(space.low.reshape(-1), space.high.reshape(-1), dtype=space.dtype)
+    if isinstance(space, Discrete):
+        return Box(0, 1, shape=(space.n,), dtype=np.int64)
+    if isinstance(space, (Dict, Tuple)):
+        subs = [flatten_space(s) for s in (space.spaces.values() if isinstance(space, Dict) else space.spaces)]
+        return Box(np.concatenate([s.low for s in subs]), np.concatenate([s.high for s in subs]),
+                   dtype=np.result_type(*[s.dtype for s in subs]))
+    raise NotImplementedError(type(space))
+
+
+def flatten(space, x):
+    from . import Box, Dict, Discrete, Tuple
+    if isinstance(space, Box):
+        return np.asarray(x, dtype=space.dtype).reshape(-1)
+    if isinstance(space, Discrete):
+        out = np.zeros(space.n, dtype=np.int64)
+        out[int(x) - space.start] = 1
+        return out
+    if isinstance(space, Dict):
+        return np.concatenate([np.asarray(flatten(s, x[k])) for k, s in space.spaces.items()])
+    if isinstance(space, Tuple):
+        return np.concatenate([np.asarray(flatten(s, v)) for s, v in zip(space.spaces, x)])
+    raise NotImplementedError(type(space))
+
+
+def unflatten(space, x):
+    from . import Box, Dict, Discrete, Tuple
+    if isinstance(space, Box):
+        return np.asarray(x, dtype=space.dtype).reshape(space.shape)
+    if isinstance(space, Discrete):
+        return np.int64(space.start + int(np.nonzero(x)[0][0]))
+    if isinstance(space, (Dict, Tuple)):
+        items = list(space.spaces.items()) if isinstance(space, Dict) else list(enumerate(space.spaces))
+        out, o = [], 0
+        for k, s in items:
+            n = flatdim(s)
+            out.append((k, unflatten(s, x[o:o + n])))
+            o += n
+        return OrderedDict(out) if isinstance(space, Dict) else tuple(v for _, v in out)
+    raise NotImplementedError(type(space))

@@ -1,0 +1,15 @@
+import numpy as np
+
+
+def batch_space(space, n: int = 1):
+    from ..spaces import Box, Dict, Discrete, MultiDiscrete, Tuple
+    if isinstance(space, Box):
+        rep = (n,) + (1,) * len(space.shape)
+        return Box(np.tile(space.low, rep), np.tile(space.high, rep), dtype=space.dtype)
+    if isinstance(space, Discrete):
+        return MultiDiscrete(np.full((n,), space.n, dtype=np.int64))
+    if isinstance(space, Dict):
+        return Dict([(k, batch_space(s, n)) for k, s in space.spaces.items()])
+    if isinstance(space, Tuple):
+        return Tuple([batch_space(s, n) for s in space.spaces])
+    raise NotImplementedError(type(space))

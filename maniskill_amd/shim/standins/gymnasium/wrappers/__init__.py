@@ -1,0 +1,35 @@
+"""The two wrappers gymnasium.make applies that the reference looks for (utils/registration.py:137-153)."""
+from ..core import Wrapper
+
+
+class OrderEnforcing(Wrapper):
+    def __init__(self, env, disable_render_order_enforcing: bool = False):
+        super().__init__(env)
+        self._has_reset = False
+
+    def step(self, action):
+        if not self._has_reset:
+            raise RuntimeError("Cannot call env.step() before calling env.reset()")
+        return self.env.step(action)
+
+    def reset(self, **kwargs):
+        self._has_reset = True
+        return self.env.reset(**kwargs)
+
+
+class TimeLimit(Wrapper):
+    def __init__(self, env, max_episode_steps: int):
+        super().__init__(env)
+        self._max_episode_steps = max_episode_steps
+        self._elapsed_steps = None
+
+    def step(self, action):
+        obs, reward, terminated, truncated, info = self.env.step(action)
+        self._elapsed_steps += 1
+        if self._elapsed_steps >= self._max_episode_steps:
+            truncated = True
+        return obs, reward, terminated, truncated, info
+
+    def reset(self, **kwargs):
+        self._elapsed_steps = 0
+        return self.env.reset(**kwargs)

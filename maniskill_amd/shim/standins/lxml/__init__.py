@@ -1,0 +1,3 @@
+"""Stand-in for ``lxml`` (only ``lxml.etree`` as a thin alias of the standard library's ElementTree), used when lxml is absent.
+The reference reads URDF joint / link names with it (mani_skill/agents/controllers/utils/kinematics.py:18,75-82)."""
+from . import etree  # noqa: F401

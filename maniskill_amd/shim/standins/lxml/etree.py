@@ -1,0 +1,2 @@
+from xml.etree.ElementTree import *  # noqa: F401,F403
+from xml.etree.ElementTree import Element, ElementTree, fromstring, parse, tostring  # noqa: F401

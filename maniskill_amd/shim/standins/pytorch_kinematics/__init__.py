@@ -1,0 +1,132 @@
+"""Stand-in for ``pytorch_kinematics`` (the subset ManiSkill's batched IK uses: mani_skill/agents/controllers/utils/kinematics.py
+:158-170 ``build_serial_chain_from_urdf(...).to(device)``, ``get_joint_limits``, ``PseudoInverseIK(...)`` construction,
+:204 ``forward_kinematics(q).get_matrix()``, :240 ``jacobian(q)``), used only when the real package is not installed.
+Batched torch code: forward kinematics as a product of homogeneous transforms, the geometric Jacobian in the base frame with
+rows [linear; angular] (pytorch_kinematics' convention)."""
+from __future__ import annotations
+
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import torch
+
+
+def _rpy_matrix(r, p, y):
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                     [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                     [-sp, cp * sr, cp * cr]])
+
+
+class Transform3d:
+    def __init__(self, matrix: torch.Tensor):
+        self._m = matrix
+
+    def get_matrix(self):
+        return self._m
+
+
+class SerialChain:
+    def __init__(self, joints, device="cpu", dtype=torch.float32):
+        # joints: list of dict(name, type, origin 4x4 (numpy), axis [3], lower, upper)
+        self._joints = joints
+        self.device, self.dtype = torch.device(device), dtype
+        self._origins = [torch.tensor(j["origin"], dtype=dtype, device=self.device) for j in joints]
+        self._axes = [torch.tensor(j["axis"], dtype=dtype, device=self.device) for j in joints]
+        self._movable = [i for i, j in enumerate(joints) if j["type"] != "fixed"]
+        self.n_joints = len(self._movable)
+
+    def to(self, device=None, dtype=None):
+        return SerialChain(self._joints, device if device is not None else self.device, dtype or self.dtype)
+
+    def get_joint_parameter_names(self, exclude_fixed=True):
+        return [self._joints[i]["name"] for i in self._movable]
+
+    def get_joint_limits(self):
+        return ([self._joints[i]["lower"] for i in self._movable], [self._joints[i]["upper"] for i in self._movable])
+
+    def _frames(self, th: torch.Tensor):
+        """-> (end transform (B,4,4), list of (axis_world (B,3), origin_world (B,3), type) per movable joint)"""
+        th = torch.as_tensor(th, dtype=self.dtype, device=self.device)
+        if th.dim() == 1:
+            th = th[None]
+        B = th.shape[0]
+        T = torch.eye(4, dtype=self.dtype, device=self.device)[None].repeat(B, 1, 1)
+        info, k = [], 0
+        for i, j in enumerate(self._joints):
+            T = T @ self._origins[i]
+            if j["type"] == "fixed":
+                continue
+            a = self._axes[i]
+            axis_w = T[:, :3, :3] @ a
+            info.append((axis_w, T[:, :3, 3].clone(), j["type"]))
+            q = th[:, k]
+            k += 1
+            J = torch.eye(4, dtype=self.dtype, device=self.device)[None].repeat(B, 1, 1)
+            if j["type"] == "prismatic":
+                J[:, :3, 3] = q[:, None] * a
+            else:    # Rodrigues
+                K = torch.tensor([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]], dtype=self.dtype, device=self.device)
+                s, c = torch.sin(q)[:, None, None], torch.cos(q)[:, None, None]
+                J[:, :3, :3] = torch.eye(3, dtype=self.dtype, device=self.device) + s * K + (1 - c) * (K @ K)
+            T = T @ J
+        return T, info
+
+    def forward_kinematics(self, th, end_only=True):
+        T, _ = self._frames(th)
+        return Transform3d(T)
+
+    def jacobian(self, th):
+        T, info = self._frames(th)
+        pe = T[:, :3, 3]
+        cols = []
+        for axis_w, origin_w, typ in info:
+            if typ == "prismatic":
+                cols.append(torch.cat([axis_w, torch.zeros_like(axis_w)], dim=1))
+            else:
+                cols.append(torch.cat([torch.cross(axis_w, pe - origin_w, dim=1), axis_w], dim=1))
+        return torch.stack(cols, dim=2)
+
+
+def build_serial_chain_from_urdf(data, end_link_name, root_link_name=""):
+    root = ET.fromstring(data if isinstance(data, (bytes, str)) else bytes(data))
+    child_joint = {}
+    for je in root.findall("joint"):
+        child_joint[je.find("child").get("link")] = je
+    chain = []
+    link = end_link_name
+    while link in child_joint and link != root_link_name:
+        je = child_joint[link]
+        o = je.find("origin")
+        xyz = [float(x) for x in (o.get("xyz", "0 0 0") if o is not None else "0 0 0").split()]
+        rpy = [float(x) for x in (o.get("rpy", "0 0 0") if o is not None else "0 0 0").split()]
+        M = np.eye(4)
+        M[:3, :3] = _rpy_matrix(*rpy)
+        M[:3, 3] = xyz
+        ax = je.find("axis")
+        axis = np.array([float(x) for x in ax.get("xyz").split()]) if ax is not None else np.array([1.0, 0, 0])
+        n = np.linalg.norm(axis)
+        axis = axis / n if n > 0 else axis
+        jt = je.get("type")
+        lim = je.find("limit")
+        lo = float(lim.get("lower", "-inf")) if lim is not None else -np.inf
+        hi = float(lim.get("upper", "inf")) if lim is not None else np.inf
+        if jt == "continuous":
+            jt, lo, hi = "revolute", -np.inf, np.inf
+        chain.append(dict(name=je.get("name"), type=jt if jt in ("revolute", "prismatic") else "fixed", origin=M, axis=axis, lower=lo, upper=hi))
+        link = je.find("parent").get("link")
+    chain.reverse()
+    return SerialChain(chain)
+
+
+build_serial_chain_from_mjcf = None
+
+
+class PseudoInverseIK:
+    """Constructed by ManiSkill but its solve() is not on the batched path (compute_ik uses the chain's Jacobian directly)."""
+
+    def __init__(self, chain, **kwargs):
+        self.chain, self.kwargs = chain, kwargs
+
+    def solve(self, *a, **k):
+        raise NotImplementedError("PseudoInverseIK.solve is not provided by the stand-in")

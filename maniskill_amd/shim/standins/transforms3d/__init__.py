@@ -1,0 +1,4 @@
+"""Stand-in for ``transforms3d`` (euler / quaternions subset ManiSkill imports), used when the real package is not installed.
+Conventions are those documented by transforms3d: quaternions are [w, x, y, z]; an axes string is 's' (static frame) or 'r'
+(rotating frame) followed by the three axis letters; default 'sxyz'."""
+from . import euler, quaternions, axangles  # noqa: F401

@@ -1,0 +1,9 @@
+from .quaternions import axangle2quat, quat2mat, mat2quat, quat2axangle
+
+
+def axangle2mat(axis, angle, is_normalized=False):
+    return quat2mat(axangle2quat(axis, angle, is_normalized))
+
+
+def mat2axangle(mat):
+    return quat2axangle(mat2quat(mat))

@@ -1,0 +1,49 @@
+import math
+
+import numpy as np
+
+from . import quaternions as _q
+
+_AXIS = {"x": 0, "y": 1, "z": 2}
+
+
+def _axis_quat(axis: int, angle: float):
+    q = np.zeros(4)
+    q[0] = math.cos(angle / 2.0)
+    q[1 + axis] = math.sin(angle / 2.0)
+    return q
+
+
+def euler2quat(ai, aj, ak, axes="sxyz"):
+    """Static frame: rotate about fixed i, then fixed j, then fixed k => q = q_k q_j q_i.  Rotating frame: q = q_i q_j q_k."""
+    i, j, k = (_AXIS[c] for c in axes[1:])
+    qi, qj, qk = _axis_quat(i, ai), _axis_quat(j, aj), _axis_quat(k, ak)
+    if axes[0] == "s":
+        return _q.qmult(qk, _q.qmult(qj, qi))
+    return _q.qmult(qi, _q.qmult(qj, qk))
+
+
+def euler2mat(ai, aj, ak, axes="sxyz"):
+    return _q.quat2mat(euler2quat(ai, aj, ak, axes))
+
+
+def mat2euler(mat, axes="sxyz"):
+    from scipy.spatial.transform import Rotation as R
+    seq = axes[1:]
+    rot = R.from_matrix(np.asarray(mat, dtype=np.float64)[:3, :3])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ang = rot.as_euler(seq.lower() if axes[0] == "s" else seq.upper())
+    return float(ang[0]), float(ang[1]), float(ang[2])
+
+
+def quat2euler(quaternion, axes="sxyz"):
+    return mat2euler(_q.quat2mat(quaternion), axes)
+
+
+def euler2axangle(ai, aj, ak, axes="sxyz"):
+    return _q.quat2axangle(euler2quat(ai, aj, ak, axes))
+
+# transforms3d.euler re-exports these through its own imports (robocasa's object loader takes them from here)
+from .quaternions import mat2quat, quat2axangle, quat2mat  # noqa: E402,F401

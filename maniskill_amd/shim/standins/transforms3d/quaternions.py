@@ -1,0 +1,81 @@
+import math
+
+import numpy as np
+
+
+def qmult(q1, q2):
+    w1, x1, y1, z1 = q1
+    w2, x2, y2, z2 = q2
+    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2,
+                     w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                     w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
+
+
+def qconjugate(q):
+    return np.array(q) * np.array([1.0, -1, -1, -1])
+
+
+def qnorm(q):
+    return math.sqrt(float(np.dot(q, q)))
+
+
+def qinverse(q):
+    return qconjugate(q) / float(np.dot(q, q))
+
+
+def quat2mat(q):
+    w, x, y, z = [float(v) for v in q]
+    n = w * w + x * x + y * y + z * z
+    if n < np.finfo(np.float64).eps:
+        return np.eye(3)
+    s = 2.0 / n
+    X, Y, Z = x * s, y * s, z * s
+    wX, wY, wZ = w * X, w * Y, w * Z
+    xX, xY, xZ = x * X, x * Y, x * Z
+    yY, yZ, zZ = y * Y, y * Z, z * Z
+    return np.array([[1.0 - (yY + zZ), xY - wZ, xZ + wY],
+                     [xY + wZ, 1.0 - (xX + zZ), yZ - wX],
+                     [xZ - wY, yZ + wX, 1.0 - (xX + yY)]])
+
+
+def mat2quat(M):
+    """Largest-eigenvector method (Bar-Itzhack), result with w >= 0."""
+    Qxx, Qyx, Qzx, Qxy, Qyy, Qzy, Qxz, Qyz, Qzz = np.asarray(M, dtype=np.float64).flat
+    K = np.array([[Qxx - Qyy - Qzz, 0, 0, 0],
+                  [Qyx + Qxy, Qyy - Qxx - Qzz, 0, 0],
+                  [Qzx + Qxz, Qzy + Qyz, Qzz - Qxx - Qyy, 0],
+                  [Qyz - Qzy, Qzx - Qxz, Qxy - Qyx, Qxx + Qyy + Qzz]]) / 3.0
+    vals, vecs = np.linalg.eigh(K)
+    q = vecs[[3, 0, 1, 2], np.argmax(vals)]
+    if q[0] < 0:
+        q = -q
+    return q
+
+
+def axangle2quat(vector, theta, is_normalized=False):
+    v = np.asarray(vector, dtype=np.float64)
+    if not is_normalized:
+        v = v / math.sqrt(float(np.dot(v, v)))
+    t2 = theta / 2.0
+    return np.concatenate(([math.cos(t2)], v * math.sin(t2)))
+
+
+def quat2axangle(quat, identity_thresh=None):
+    w, x, y, z = [float(v) for v in quat]
+    n2 = x * x + y * y + z * z
+    if identity_thresh is None:
+        identity_thresh = np.finfo(np.float64).eps * 3
+    if n2 < identity_thresh ** 2:
+        return np.array([1.0, 0, 0]), 0.0
+    n = math.sqrt(n2)
+    return np.array([x, y, z]) / n, 2 * math.atan2(n, w)
+
+
+def rotate_vector(v, q):
+    return quat2mat(q) @ np.asarray(v, dtype=np.float64)
+
+
+def nearly_equivalent(q1, q2, rtol=1e-5, atol=1e-8):
+    q1, q2 = np.asarray(q1), np.asarray(q2)
+    return bool(np.allclose(q1, q2, rtol, atol) or np.allclose(q1, -q2, rtol, atol))

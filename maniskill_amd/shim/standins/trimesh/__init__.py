@@ -1,0 +1,100 @@
+"""Stand-in for ``trimesh`` (the few mesh containers / primitives ManiSkill's geometry helpers touch:
+mani_skill/utils/geometry/trimesh_utils.py, utils/structs/{actor,link,articulation}.py), used when trimesh is not installed."""
+from __future__ import annotations
+
+import numpy as np
+
+
+class _Box:
+    """Axis-aligned bounding box primitive: bounds, extents, centre (== centre of mass of a uniform box)."""
+
+    def __init__(self, bounds):
+        self.bounds = np.asarray(bounds, dtype=np.float64)
+
+    @property
+    def extents(self):
+        return self.bounds[1] - self.bounds[0]
+
+    @property
+    def center_mass(self):
+        return 0.5 * (self.bounds[0] + self.bounds[1])
+
+    centroid = center_mass
+
+    @property
+    def vertices(self):
+        lo, hi = self.bounds
+        return np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])])
+
+
+class Trimesh:
+    def __init__(self, vertices=None, faces=None, **kw):
+        self.vertices = np.zeros((0, 3)) if vertices is None else np.array(vertices, dtype=np.float64).reshape(-1, 3)
+        self.faces = np.zeros((0, 3), dtype=np.int64) if faces is None else np.array(faces, dtype=np.int64).reshape(-1, 3)
+
+    def apply_transform(self, matrix):
+        M = np.asarray(matrix, dtype=np.float64)
+        self.vertices = self.vertices @ M[:3, :3].T + M[:3, 3]
+        return self
+
+    def apply_scale(self, scale):
+        self.vertices = self.vertices * np.asarray(scale, dtype=np.float64)
+        return self
+
+    def apply_translation(self, t):
+        self.vertices = self.vertices + np.asarray(t, dtype=np.float64)
+        return self
+
+    def copy(self):
+        return Trimesh(self.vertices.copy(), self.faces.copy())
+
+    @property
+    def bounds(self):
+        return np.stack([self.vertices.min(0), self.vertices.max(0)])
+
+    @property
+    def extents(self):
+        b = self.bounds
+        return b[1] - b[0]
+
+    @property
+    def bounding_box(self):
+        return _Box(self.bounds)
+
+    @property
+    def centroid(self):
+        return self.vertices.mean(0)
+
+    @property
+    def convex_hull(self):
+        from scipy.spatial import ConvexHull
+        h = ConvexHull(self.vertices)
+        remap = -np.ones(len(self.vertices), dtype=np.int64)
+        remap[h.vertices] = np.arange(len(h.vertices))
+        return Trimesh(self.vertices[h.vertices], remap[h.simplices])
+
+    @property
+    def triangles(self):
+        return self.vertices[self.faces]
+
+    @property
+    def area_faces(self):
+        t = self.triangles
+        return 0.5 * np.linalg.norm(np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]), axis=1)
+
+    @property
+    def area(self):
+        return float(self.area_faces.sum())
+
+    def sample(self, count, seed=None):
+        rng = np.random.default_rng(seed)
+        a = self.area_faces
+        idx = rng.choice(len(a), size=count, p=a / a.sum())
+        t = self.triangles[idx]
+        u, v = rng.random((2, count, 1))
+        flip = (u + v) > 1
+        u, v = np.where(flip, 1 - u, u), np.where(flip, 1 - v, v)
+        return t[:, 0] + u * (t[:, 1] - t[:, 0]) + v * (t[:, 2] - t[:, 0])
+
+
+from . import creation  # noqa: E402,F401

@@ -1,0 +1,81 @@
+import numpy as np
+
+from . import Trimesh
+
+
+def box(extents=(1, 1, 1), transform=None, **kw):
+    h = 0.5 * np.asarray(extents, dtype=np.float64)
+    v = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], dtype=np.float64) * h
+    f = np.array([[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7], [2, 7, 6], [0, 2, 6], [0, 6, 4],
+                  [1, 5, 7], [1, 7, 3]])
+    m = Trimesh(v, f)
+    return m.apply_transform(transform) if transform is not None else m
+
+
+def _revolve(profile_r, profile_z, sections):
+    """Surface of revolution about z of the polyline (r_i, z_i); the first / last point may sit on the axis."""
+    ang = np.linspace(0, 2 * np.pi, sections, endpoint=False)
+    rings, verts = [], []
+    for r, z in zip(profile_r, profile_z):
+        if r < 1e-12:
+            rings.append([len(verts)])
+            verts.append([0.0, 0.0, z])
+        else:
+            rings.append(list(range(len(verts), len(verts) + sections)))
+            verts.extend([[r * np.cos(a), r * np.sin(a), z] for a in ang])
+    faces = []
+    for a, b in zip(rings[:-1], rings[1:]):
+        for k in range(sections):
+            k2 = (k + 1) % sections
+            if len(a) == 1 and len(b) > 1:
+                faces.append([a[0], b[k2], b[k]])
+            elif len(b) == 1 and len(a) > 1:
+                faces.append([a[k], a[k2], b[0]])
+            elif len(a) > 1 and len(b) > 1:
+                faces.append([a[k], a[k2], b[k2]])
+                faces.append([a[k], b[k2], b[k]])
+    return Trimesh(np.array(verts), np.array(faces))
+
+
+def cylinder(radius, height=None, sections=32, transform=None, **kw):
+    h = 0.5 * float(height)
+    m = _revolve([0, radius, radius, 0], [-h, -h, h, h], sections)
+    return m.apply_transform(transform) if transform is not None else m
+
+
+def capsule(height=1.0, radius=1.0, count=(16, 16), transform=None, **kw):
+    """Capsule along z, cylinder part of length `height` centred at the origin."""
+    h, n = 0.5 * float(height), max(int(count[0]) // 2, 2)
+    th = np.linspace(0, np.pi / 2, n + 1)
+    r = np.concatenate([radius * np.sin(th), radius * np.sin(th[::-1])])
+    z = np.concatenate([-h - radius * np.cos(th), h + radius * np.cos(th[::-1])])
+    m = _revolve(r, z, int(count[1]) * 2)
+    return m.apply_transform(transform) if transform is not None else m
+
+
+def icosphere(subdivisions=3, radius=1.0, **kw):
+    t = (1.0 + 5 ** 0.5) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], dtype=np.float64)
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6],
+                  [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10], [8, 6, 7],
+                  [9, 8, 1]])
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    for _ in range(int(subdivisions)):
+        cache, verts, nf = {}, list(v), []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = verts[a] + verts[b]
+                verts.append(m / np.linalg.norm(m))
+                cache[key] = len(verts) - 1
+            return cache[key]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
+        v, f = np.array(verts), np.array(nf)
+    return Trimesh(v * radius, f)
+
+
+uv_sphere = lambda radius=1.0, **kw: icosphere(radius=radius)  # noqa: E731

@@ -1,0 +1,73 @@
+"""Runs the REFERENCE's own, unmodified ``mani_skill`` package on this repository's backend through the ``sapien`` shim.
+
+Test infrastructure.  Two modes:
+  * ``setup(backend="hip")``     the product: libmsk_physx.so on cuda:0 (``-m gpu`` tests on the GPU box),
+  * ``setup(backend="oracle")``  the CPU checker (oracle/liborc.so, same C ABI, host memory) behind the same shim, so that the
+    host logic (builders -> scene compiler -> buffers -> ManiSkill structs) is exercised in this GPU-less container.  The
+    reference picks its torch device from the backend string (mani_skill/envs/utils/system/backend.py:60-91: "physx_cuda" ->
+    torch.device("cuda")); for the oracle mode that one function is wrapped so that the "GPU" code path (PhysxGpuSystem, batched
+    buffers) runs with cpu tensors.  Nothing in the reference is edited.
+
+The reference lives at /root/reference in the build container and nowhere on the GPU box unless a checkout is staged next to
+the repo (MANISKILL_ROOT); tests that need it skip when it is absent.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def find_reference():
+    for cand in (os.environ.get("MANISKILL_ROOT"), "/root/reference", os.path.join(ROOT, "_ref_stage")):
+        if cand and os.path.isdir(os.path.join(cand, "mani_skill")):
+            return cand
+    return None
+
+
+_done = {}
+
+
+def setup(backend="oracle"):
+    """-> the imported ``gymnasium`` module with every ManiSkill task registered, or None if no reference checkout exists."""
+    ref = find_reference()
+    if ref is None:
+        return None
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import maniskill_amd.shim as shim
+    shim.install(ref)
+    import sapien.physx as physx
+    if backend == "oracle":
+        from oracle_backend import oracle_lib
+        physx._set_backend(oracle_lib(), host_memory=True)
+    else:
+        physx._set_backend(None, False)
+    import gymnasium as gym
+    import mani_skill.envs  # noqa: F401  (registers the tasks)
+    import mani_skill.envs.sapien_env as se
+    import mani_skill.envs.utils.system.backend as be
+    if "orig_parse" not in _done:
+        _done["orig_parse"] = be.parse_sim_and_render_backend
+    orig = _done["orig_parse"]
+    if backend == "oracle":
+        import torch
+
+        class _HostCudaDevice:
+            """What sapien.Device("cuda") is to the reference (``is_cuda()``), for a system that keeps its buffers in host memory."""
+            name, cuda_id = "cuda", 0
+
+            def is_cuda(self): return True
+            def is_cpu(self): return False
+            def can_render(self): return True
+
+        def parse(sim_backend, render_backend):
+            sb = sim_backend.split(":")[0]
+            if be.sim_backend_name_mapping.get(sb, sb) != "physx_cuda":
+                return orig(sim_backend, render_backend)
+            rd = None if render_backend in (None, "none") else _HostCudaDevice()
+            return be.BackendInfo(device=torch.device("cpu"), sim_device=_HostCudaDevice(), sim_backend="physx_cuda", render_device=rd,
+                                  render_backend="none" if rd is None else "sapien_cuda")
+        se.parse_sim_and_render_backend = parse
+    else:
+        se.parse_sim_and_render_backend = orig
+    return gym
