@@ -118,7 +118,7 @@ class Entity:
     @property
     def pose(self) -> Pose:
         px = self._physx_body()
-        if px is not None and px._system is not None and px._system._initialized:
+        if px is not None and px._system is not None and px._system._live():
             return px._system._read_body_pose(px)
         return self._pose
 
@@ -126,7 +126,7 @@ class Entity:
     def pose(self, pose: Pose):
         self._pose = Pose(pose.p, pose.q)
         px = self._physx_body()
-        if px is not None and px._system is not None and px._system._initialized:
+        if px is not None and px._system is not None and px._system._live():
             px._system._write_body_pose(px, self._pose)
 
     def get_pose(self):

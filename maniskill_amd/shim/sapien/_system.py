@@ -131,6 +131,10 @@ class PhysxSystem:
     def get_config(self):
         return self._cfg
 
+    def _live(self) -> bool:
+        """True once component accessors must go to the simulator's state (the CPU-style system starts lazily, see there)."""
+        return self._initialized
+
     # =============================================================================================================
     # compiler
     # =============================================================================================================
@@ -221,14 +225,14 @@ class PhysxSystem:
                         d = float(np.dot(n, gp.p + off))          # plane: n . x = d in world coordinates
                         # in a sub-scene frame x_local = x - offset: d_local = d - n . offset; identical for all sub-scenes only
                         # if the offsets lie in the plane (ManiSkill's grid is horizontal, the ground normal is +z)
-                        key = (tuple(np.round(n, 6)), round(d, 6))
+                        key = (tuple(np.round(n, 4)), round(d, 4))
                         planes.setdefault(key, (gp, s, n, d, off))
         tpl = SceneTemplate()
         self._static_shape_owner = []
         for key, (gp, s, n, d, off) in planes.items():
             for sc in self._scenes:
                 o = self._offsets.get(id(sc), np.zeros(3))
-                if abs(float(np.dot(n, o - off))) > 1e-6:
+                if abs(float(np.dot(n, o - off))) > 1e-4:
                     raise RuntimeError("a static plane is not parallel to the sub-scene grid: cannot be shared by all sub-scenes")
             lp = gp                                     # offsets are in-plane: the plane is the same in every sub-scene frame
             mat = s.physical_material
@@ -609,11 +613,24 @@ class PhysxCpuSystem(PhysxSystem):
         super().__init__()
         from . import physx as P
         self._backend = P._backend
-        self._lazy_failed = None
+        self._starting = False
+
+    def _live(self) -> bool:
+        # SAPIEN's CPU system is live from the start; here the template is frozen at the first state access after building
+        if not self._initialized and not self._starting:
+            self._ensure()
+        return self._initialized
 
     def _ensure(self):
-        if self._initialized:
+        if self._initialized or self._starting:
             return
+        self._starting = True
+        try:
+            self._ensure_inner()
+        finally:
+            self._starting = False
+
+    def _ensure_inner(self):
         if len(self._scenes) != 1:
             raise RuntimeError("PhysxCpuSystem simulates exactly one scene")
         if self._backend is not None:

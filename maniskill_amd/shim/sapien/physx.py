@@ -568,13 +568,13 @@ class PhysxRigidBodyComponent(PhysxRigidBaseComponent):
     # -- velocities (CPU-style access; on the batched system they read / write the state buffers) ---------------------
     @property
     def linear_velocity(self):
-        if self._system is not None and self._system._initialized:
+        if self._system is not None and self._system._live():
             return self._system._read_body_row(self)[7:10]
         return self._lin_vel.copy()
 
     @property
     def angular_velocity(self):
-        if self._system is not None and self._system._initialized:
+        if self._system is not None and self._system._live():
             return self._system._read_body_row(self)[10:13]
         return self._ang_vel.copy()
 
@@ -585,7 +585,7 @@ class PhysxRigidBodyComponent(PhysxRigidBaseComponent):
         return self.angular_velocity
 
     def add_force_at_point(self, force, point, mode="force"):
-        if self._system is None or not self._system._initialized:
+        if self._system is None or not self._system._live():
             raise RuntimeError("add_force_at_point before the simulation was initialised")
         self._system._add_force_at_point(self, np.asarray(force, dtype=np.float32), np.asarray(point, dtype=np.float32))
 
@@ -610,7 +610,7 @@ class PhysxRigidDynamicComponent(PhysxRigidBodyComponent):
 
     def _gpu_pose_index(self):
         if self._system is None or not self._system._initialized:
-            raise RuntimeError("gpu_pose_index is available after gpu_init()")
+            return -1       # as SAPIEN: meaningful after gpu_init() only
         return self._system._pose_index(self)
 
     def get_gpu_index(self):
@@ -646,14 +646,14 @@ class PhysxRigidDynamicComponent(PhysxRigidBodyComponent):
     # velocity setters (dynamic bodies only)
     @PhysxRigidBodyComponent.linear_velocity.setter
     def linear_velocity(self, v):
-        if self._system is not None and self._system._initialized:
+        if self._system is not None and self._system._live():
             self._system._write_body_cols(self, 7, np.asarray(v, dtype=np.float32))
         else:
             self._lin_vel = np.array(v, dtype=np.float32).reshape(3)
 
     @PhysxRigidBodyComponent.angular_velocity.setter
     def angular_velocity(self, v):
-        if self._system is not None and self._system._initialized:
+        if self._system is not None and self._system._live():
             self._system._write_body_cols(self, 10, np.asarray(v, dtype=np.float32))
         else:
             self._ang_vel = np.array(v, dtype=np.float32).reshape(3)
@@ -793,7 +793,7 @@ class PhysxArticulationJoint:
     @property
     def drive_target(self):
         art = self.child_link.articulation
-        if art._system is not None and art._system._initialized and self.dof:
+        if art._system is not None and art._system._live() and self.dof:
             return np.array([art._system._read_dof(art, "target_qpos", self)], dtype=np.float32)
         return np.array([self._drive_target] * self.dof, dtype=np.float32)
 
@@ -802,13 +802,13 @@ class PhysxArticulationJoint:
         v = float(np.asarray(v, dtype=np.float32).reshape(-1)[0])
         self._drive_target = v
         art = self.child_link.articulation
-        if art._system is not None and art._system._initialized and self.dof:
+        if art._system is not None and art._system._live() and self.dof:
             art._system._write_dof(art, "target_qpos", self, v)
 
     @property
     def drive_velocity_target(self):
         art = self.child_link.articulation
-        if art._system is not None and art._system._initialized and self.dof:
+        if art._system is not None and art._system._live() and self.dof:
             return np.array([art._system._read_dof(art, "target_qvel", self)], dtype=np.float32)
         return np.array([self._drive_velocity_target] * self.dof, dtype=np.float32)
 
@@ -817,7 +817,7 @@ class PhysxArticulationJoint:
         v = float(np.asarray(v, dtype=np.float32).reshape(-1)[0])
         self._drive_velocity_target = v
         art = self.child_link.articulation
-        if art._system is not None and art._system._initialized and self.dof:
+        if art._system is not None and art._system._live() and self.dof:
             art._system._write_dof(art, "target_qvel", self, v)
 
     def get_drive_target(self):
@@ -951,7 +951,7 @@ class PhysxArticulation:
     @property
     def gpu_index(self):
         if self._system is None or not self._system._initialized:
-            raise RuntimeError("gpu_index is available after gpu_init()")
+            return -1
         return self._system._art_index(self)
 
     def get_gpu_index(self):
@@ -979,7 +979,7 @@ class PhysxArticulation:
     get_root_pose, set_root_pose = get_pose, set_pose
 
     def _vec(self, name):
-        if self._system is not None and self._system._initialized:
+        if self._system is not None and self._system._live():
             return self._system._read_art_vec(self, name)
         if name == "qpos" and self._qpos0 is not None:
             return np.asarray(self._qpos0, dtype=np.float32)
@@ -987,7 +987,7 @@ class PhysxArticulation:
 
     def _set_vec(self, name, v):
         v = np.asarray(v, dtype=np.float32).reshape(-1)
-        if self._system is not None and self._system._initialized:
+        if self._system is not None and self._system._live():
             self._system._write_art_vec(self, name, v)
         elif name == "qpos":
             self._qpos0 = v.copy()
@@ -1078,7 +1078,7 @@ class PhysxArticulationLinkComponent(PhysxRigidBodyComponent):
     @property
     def gpu_pose_index(self):
         if self._system is None or not self._system._initialized:
-            raise RuntimeError("gpu_pose_index is available after gpu_init()")
+            return -1
         return self._system._pose_index(self)
 
     def get_gpu_pose_index(self):

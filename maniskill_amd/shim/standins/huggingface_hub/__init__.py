@@ -1,0 +1,9 @@
+"""Stand-in so that ``from huggingface_hub import snapshot_download`` (mani_skill/utils/download_asset.py:11, a module-level
+import) succeeds where the package is absent; there is no network in this environment, so downloading raises."""
+
+
+def snapshot_download(*a, **k):
+    raise RuntimeError("huggingface_hub is not installed (stand-in): asset downloads are unavailable")
+
+
+hf_hub_download = snapshot_download

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Build recipe for oracle/_ref/maniskill: a byte-compiled (source-less) build of the reference's Python package.
+
+The reference for this path is Python (``/root/reference/mani_skill``); its task / wrapper / struct code is what defines the
+boundary's behaviour and its own test files (``/root/reference/tests``) are the T0 conformance suite.
+/root/reference does not exist on the GPU box, so — like a C reference compiled into oracle/_ref/*.so — the package is COMPILED
+where it lies (py_compile, same interpreter on both machines) and only the outputs are written under oracle/_ref/ (git-ignored,
+travels with the snapshot): ``*.pyc`` files for ``mani_skill`` and ``tests``, plus the data files the package reads at run time
+(URDF / SRDF / STL / GLB / JSON of the Panda and Fetch robots, the table scene, task configs).  No reference source file is
+copied.  Test infrastructure only: tests/ref_harness.py puts it on sys.path behind the sapien shim; the product never imports it.
+
+Usage: python oracle/build_ref.py [--ref /root/reference] [--robots panda fetch]
+"""
+import argparse
+import os
+import py_compile
+import shutil
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "_ref", "maniskill")
+DATA_SKIP_EXT = {".py", ".pyc", ".md", ".png", ".gif", ".jpg", ".mp4", ".sh", ".ipynb"}
+
+
+def build(ref="/root/reference", robots=("panda", "fetch"), quiet=True):
+    if not os.path.isdir(os.path.join(ref, "mani_skill")):
+        return None
+    stamp = os.path.join(OUT, ".built")
+    if os.path.exists(stamp):
+        return OUT
+    if os.path.isdir(OUT):
+        shutil.rmtree(OUT)
+    n_py = n_data = 0
+    for pkg in ("mani_skill", "tests"):
+        src_root = os.path.join(ref, pkg)
+        for dirpath, dirnames, filenames in os.walk(src_root):
+            dirnames[:] = [d for d in dirnames if d != "__pycache__"]
+            rel = os.path.relpath(dirpath, ref)
+            parts = rel.split(os.sep)
+            if parts[:3] == ["mani_skill", "assets", "robots"] and len(parts) > 3 and parts[3] not in robots:
+                dirnames[:] = []
+                continue
+            if parts[:2] == ["mani_skill", "examples"]:
+                # keep only the benchmarking harness (examples/benchmarking/gpu_sim.py is the measurement protocol)
+                if len(parts) > 2 and parts[2] != "benchmarking":
+                    dirnames[:] = []
+                    continue
+            out_dir = os.path.join(OUT, rel)
+            os.makedirs(out_dir, exist_ok=True)
+            for fn in filenames:
+                src = os.path.join(dirpath, fn)
+                ext = os.path.splitext(fn)[1].lower()
+                if ext == ".py":
+                    py_compile.compile(src, cfile=os.path.join(out_dir, fn + "c"), dfile=os.path.join(rel, fn), doraise=True,
+                                       invalidation_mode=py_compile.PycInvalidationMode.UNCHECKED_HASH)
+                    n_py += 1
+                elif ext not in DATA_SKIP_EXT and pkg == "mani_skill":
+                    shutil.copyfile(src, os.path.join(out_dir, fn))
+                    n_data += 1
+    with open(stamp, "w") as f:
+        f.write(f"{n_py} modules compiled, {n_data} data files, python {sys.version.split()[0]}\n")
+    if not quiet:
+        print(f"oracle/_ref/maniskill: {n_py} modules compiled, {n_data} data files")
+    return OUT
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--robots", nargs="*", default=["panda", "fetch"])
+    ap.add_argument("--force", action="store_true")
+    a = ap.parse_args()
+    if a.force and os.path.isdir(OUT):
+        shutil.rmtree(OUT)
+    r = build(a.ref, tuple(a.robots), quiet=False)
+    print(r or "reference not present: nothing built")

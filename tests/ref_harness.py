@@ -8,8 +8,8 @@ Test infrastructure.  Two modes:
     torch.device("cuda")); for the oracle mode that one function is wrapped so that the "GPU" code path (PhysxGpuSystem, batched
     buffers) runs with cpu tensors.  Nothing in the reference is edited.
 
-The reference lives at /root/reference in the build container and nowhere on the GPU box unless a checkout is staged next to
-the repo (MANISKILL_ROOT); tests that need it skip when it is absent.
+The reference lives at /root/reference in the build container; on the GPU box its byte-compiled build oracle/_ref/maniskill
+(oracle/build_ref.py; outputs only, no sources) is what travels.  Tests that need it skip when neither is present.
 """
 import os
 import sys
@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def find_reference():
-    for cand in (os.environ.get("MANISKILL_ROOT"), "/root/reference", os.path.join(ROOT, "_ref_stage")):
+    for cand in (os.environ.get("MANISKILL_ROOT"), "/root/reference", os.path.join(ROOT, "oracle", "_ref", "maniskill")):
         if cand and os.path.isdir(os.path.join(cand, "mani_skill")):
             return cand
     return None

@@ -1,0 +1,53 @@
+"""T0 parity: the reference's OWN API-conformance tests, run unmodified on this backend through the sapien shim.
+
+The reference's test files (``/root/reference/tests``) are executed by pytest in a subprocess with tests/ref_pytest_plugin.py
+loaded; nothing of the reference is copied or edited.  Here (no GPU) the CPU checker sits behind the shim, so what is verified is
+the host path: builders -> scene compiler -> C ABI -> buffers -> ManiSkill's structs / BaseEnv / ManiSkillVectorEnv.  With
+``-m gpu`` the same node ids run on libmsk_physx.so.  The reference checkout is not on the GPU box unless staged (see
+tests/ref_harness.py): the tests skip when it is absent.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import ref_harness
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = ref_harness.find_reference()
+needs_ref = pytest.mark.skipif(REF is None, reason="no ManiSkill checkout (reference) available")
+
+# node ids of the reference's suite that pin this boundary (VERDICT r1 "What's missing" 2)
+STATE_NODES = [
+    "tests/test_gpu_envs.py::test_partial_resets",
+    "tests/test_gpu_envs.py::test_timelimits",
+    "tests/test_gpu_envs.py::test_hidden_objs",
+    "tests/test_sim_state.py::test_raw_sim_states",
+    "tests/structs/test_pose.py",
+    "tests/structs/test_actor.py",
+    "tests/structs/test_link.py",
+    "tests/structs/test_obs_mode_struct.py",
+]
+
+
+def run_reference_tests(nodes, backend, extra=()):
+    env = dict(os.environ, MSK_REF_BACKEND=backend, PYTHONPATH=os.pathsep.join([HERE, os.environ.get("PYTHONPATH", "")]))
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-p", "ref_pytest_plugin", "-p", "no:cacheprovider", "--rootdir", REF, *extra, *nodes]
+    r = subprocess.run(cmd, cwd=REF, env=env, capture_output=True, text=True, timeout=3000)
+    return r.returncode, (r.stdout[-6000:] + r.stderr[-3000:])
+
+
+@needs_ref
+@pytest.mark.parametrize("node", STATE_NODES)
+def test_reference_suite_on_cpu_checker(built, node):
+    rc, out = run_reference_tests([node], "oracle")
+    assert rc == 0, out
+
+
+@needs_ref
+@pytest.mark.gpu
+@pytest.mark.parametrize("node", STATE_NODES)
+def test_reference_suite_on_hip(built, node):
+    rc, out = run_reference_tests([node], "hip")
+    assert rc == 0, out
