@@ -53,28 +53,29 @@ class Pose:
     def __init__(self, p=None, q=None):
         if p is not None and q is None and np.ndim(p) == 2:      # Pose(4x4 matrix)
             M = np.asarray(p, dtype=np.float64)
-            self._p = M[:3, 3].astype(np.float32)
-            self._q = _mat2quat(M[:3, :3]).astype(np.float32)
+            self._p = M[:3, 3].copy()
+            self._q = _mat2quat(M[:3, :3])
             return
-        self._p = np.zeros(3, dtype=np.float32) if p is None else np.array(p, dtype=np.float32).reshape(3)
-        self._q = np.array([1, 0, 0, 0], dtype=np.float32) if q is None else np.array(q, dtype=np.float32).reshape(4)
+        # kept in float64 (compositions of build-time frames stay exact to the last fp32 bit); .p / .q hand out float32 like SAPIEN
+        self._p = np.zeros(3, dtype=np.float64) if p is None else np.array(p, dtype=np.float64).reshape(3)
+        self._q = np.array([1, 0, 0, 0], dtype=np.float64) if q is None else np.array(q, dtype=np.float64).reshape(4)
 
     # -- accessors ----------------------------------------------------------------------------------------------
     @property
     def p(self):
-        return self._p.copy()
+        return self._p.astype(np.float32)
 
     @p.setter
     def p(self, v):
-        self._p = np.array(v, dtype=np.float32).reshape(3)
+        self._p = np.array(v, dtype=np.float64).reshape(3)
 
     @property
     def q(self):
-        return self._q.copy()
+        return self._q.astype(np.float32)
 
     @q.setter
     def q(self, v):
-        self._q = np.array(v, dtype=np.float32).reshape(4)
+        self._q = np.array(v, dtype=np.float64).reshape(4)
 
     def get_p(self):
         return self.p
@@ -102,7 +103,7 @@ class Pose:
     def set_rpy(self, rpy):
         from scipy.spatial.transform import Rotation as R
         x, y, z, w = R.from_euler("xyz", np.asarray(rpy, dtype=np.float64)).as_quat()
-        self._q = np.array([w, x, y, z], dtype=np.float32)
+        self._q = np.array([w, x, y, z], dtype=np.float64)
         return self
 
     # -- algebra ------------------------------------------------------------------------------------------------
@@ -116,7 +117,13 @@ class Pose:
         return Pose(-_qrot(qi, self._p), qi)
 
     def to_transformation_matrix(self):
-        M = np.eye(4, dtype=np.float32)
+        M = np.eye(4, dtype=np.float64)
+        M[:3, :3] = _quat2mat(self._q)
+        M[:3, 3] = self._p
+        return M.astype(np.float32)
+
+    def _matrix64(self):
+        M = np.eye(4, dtype=np.float64)
         M[:3, :3] = _quat2mat(self._q)
         M[:3, 3] = self._p
         return M
@@ -128,7 +135,7 @@ class Pose:
         return (self._p.tolist(), self._q.tolist())
 
     def __setstate__(self, s):
-        self._p, self._q = np.array(s[0], dtype=np.float32), np.array(s[1], dtype=np.float32)
+        self._p, self._q = np.array(s[0], dtype=np.float64), np.array(s[1], dtype=np.float64)
 
     def __eq__(self, other):
         return isinstance(other, Pose) and np.array_equal(self._p, other._p) and np.array_equal(self._q, other._q)

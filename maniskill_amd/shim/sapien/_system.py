@@ -147,7 +147,7 @@ class PhysxSystem:
         if isinstance(s, P.PhysxCollisionShapeBox):
             if relaxed:
                 return base + (tuple(float(x) for x in lp._q),)
-            return base + (_pose7(lp), tuple(float(x) for x in s.half_size))
+            return base + (_pose7(lp), tuple(float(x) for x in s._half))
         if isinstance(s, P.PhysxCollisionShapeConvexMesh):
             h = getattr(s, "_vhash", None)
             if h is None:
@@ -228,17 +228,27 @@ class PhysxSystem:
                         key = (tuple(np.round(n, 4)), round(d, 4))
                         planes.setdefault(key, (gp, s, n, d, off))
         tpl = SceneTemplate()
-        self._static_shape_owner = []
         for key, (gp, s, n, d, off) in planes.items():
             for sc in self._scenes:
                 o = self._offsets.get(id(sc), np.zeros(3))
                 if abs(float(np.dot(n, o - off))) > 1e-4:
                     raise RuntimeError("a static plane is not parallel to the sub-scene grid: cannot be shared by all sub-scenes")
-            lp = gp                                     # offsets are in-plane: the plane is the same in every sub-scene frame
-            mat = s.physical_material
-            tpl.add_shape(-1, N.SHAPE_PLANE, lp._p, lp._q, (0, 0, 0), None, mat.static_friction, mat.dynamic_friction, mat.restitution,
+        self._shape_owner = []       # template shape index -> the PhysxCollisionShape of sub-scene 0 (or the global plane) behind it
+        placed_planes = set()
+
+        def add_plane(key):
+            gp, s, n, d, off = planes[key]
+            mat = s.physical_material     # offsets are in-plane: the plane is the same in every sub-scene frame
+            tpl.add_shape(-1, N.SHAPE_PLANE, gp._p, gp._q, (0, 0, 0), None, mat.static_friction, mat.dynamic_friction, mat.restitution,
                           s._groups, s.patch_radius, s.min_patch_radius)
-            self._static_shape_owner.append(s)
+            self._shape_owner.append(s)
+            placed_planes.add(key)
+
+        def plane_key(comp, s):
+            off = self._offsets.get(id(self._scenes[comp._env]), np.zeros(3))
+            gp = comp.entity._pose * s._local_pose
+            n = gp.to_transformation_matrix()[:3, 0]
+            return (tuple(np.round(n, 4)), round(float(np.dot(n, gp.p + off)), 4))
 
         # ---- template from sub-scene 0 ----------------------------------------------------------------------------------
         arts0, art_ids = [], {}
@@ -250,6 +260,9 @@ class PhysxSystem:
                 if isinstance(s, P.PhysxCollisionShapePlane):
                     if body >= 0:
                         raise RuntimeError("plane collision shapes must belong to static actors")
+                    k = plane_key(comp, s)
+                    if k not in placed_planes:
+                        add_plane(k)
                     continue
                 lp = s._local_pose if fold is None else fold * s._local_pose
                 mat = s.physical_material
@@ -260,7 +273,7 @@ class PhysxSystem:
                     subs = s._hulls
                 for sub in subs:
                     if isinstance(sub, P.PhysxCollisionShapeBox):
-                        sid = tpl.add_shape(body, N.SHAPE_BOX, lp._p, lp._q, sub.half_size, None, **kw)
+                        sid = tpl.add_shape(body, N.SHAPE_BOX, lp._p, lp._q, sub._half, None, **kw)
                     elif isinstance(sub, P.PhysxCollisionShapeConvexMesh):
                         sid = tpl.add_shape(body, N.SHAPE_CONVEX, lp._p, lp._q, (0, 0, 0), sub._scaled_vertices, **kw)
                     elif isinstance(sub, P.PhysxCollisionShapeSphere):
@@ -272,6 +285,7 @@ class PhysxSystem:
                     else:
                         raise RuntimeError(f"collision shape {type(sub).__name__} is not supported")
                     shape_ids.setdefault(id(s), sid)
+                    self._shape_owner.append(s)
 
         for c in env0:
             if isinstance(c, P.PhysxRigidStaticComponent):
@@ -311,6 +325,9 @@ class PhysxSystem:
                                     c.angular_damping, c.disable_gravity)
                 body_ids[id(c)] = bid
                 add_shapes(c, bid, None)
+        for key in planes:
+            if key not in placed_planes:
+                add_plane(key)
         for art in arts0:
             for t in art._tendons:
                 chain, coef = t["chain"], t["coef"]
@@ -336,7 +353,7 @@ class PhysxSystem:
                 for si, s0 in enumerate(c0.collision_shapes):
                     if not isinstance(s0, P.PhysxCollisionShapeBox):
                         continue
-                    hs = np.stack([per_env[e][k].collision_shapes[si].half_size for e in range(n_env)])
+                    hs = np.stack([per_env[e][k].collision_shapes[si]._half for e in range(n_env)])
                     lps = []
                     for e in range(n_env):
                         comp = per_env[e][k]
@@ -670,16 +687,7 @@ class PhysxCpuSystem(PhysxSystem):
         ids, vals = self._engine.get_contacts(0, 256)
         if len(ids) == 0:
             return []
-        shape_owner = {}
-        si = len(self._static_shape_owner)
-        owners = list(self._static_shape_owner)
-        for c in self._per_env[0]:
-            for s in c.collision_shapes:
-                if isinstance(s, P.PhysxCollisionShapePlane):
-                    continue
-                subs = s._hulls if isinstance(s, P.PhysxCollisionShapeTriangleMesh) else [s]
-                owners.extend([s] * len(subs))
-        from ._pose import _qrot  # noqa: F401
+        owners = self._shape_owner
         by_pair = {}
         for (sa, sb, _), v in zip(ids, vals):
             by_pair.setdefault((int(sa), int(sb)), []).append(v)

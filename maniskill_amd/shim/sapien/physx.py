@@ -231,13 +231,17 @@ class PhysxCollisionShapeBox(PhysxCollisionShape):
 
     def __init__(self, half_size, material=None):
         super().__init__(material)
-        self.half_size = np.array(half_size, dtype=np.float32).reshape(3)
+        self._half = np.array(half_size, dtype=np.float64).reshape(3)
+
+    @property
+    def half_size(self):
+        return self._half.astype(np.float32)
 
     def get_half_size(self):
         return self.half_size
 
     def _mass_props(self):
-        return _mesh.box_mass(self.half_size, self.density)
+        return _mesh.box_mass(self._half, self.density)
 
 
 class PhysxCollisionShapeSphere(PhysxCollisionShape):
@@ -461,7 +465,7 @@ class PhysxRigidBodyComponent(PhysxRigidBaseComponent):
             m, c, I = s._mass_props()
             if m <= 0:
                 continue
-            M = s.local_pose.to_transformation_matrix().astype(np.float64)
+            M = s.local_pose._matrix64()
             R = M[:3, :3]
             parts.append((m, R @ c + M[:3, 3], R @ I @ R.T))
         if not parts:
@@ -480,9 +484,9 @@ class PhysxRigidBodyComponent(PhysxRigidBaseComponent):
         else:
             m = float(self._mass)
             cp = self._cmass_local_pose if self._cmass_local_pose is not None else Pose()
-            R = cp.to_transformation_matrix()[:3, :3].astype(np.float64)
+            R = cp._matrix64()[:3, :3]
             I = R @ np.diag(np.asarray(self._inertia if self._inertia is not None else [1, 1, 1], dtype=np.float64)) @ R.T
-            c = cp.p.astype(np.float64)
+            c = cp._p.copy()
         return float(m), np.asarray(c, dtype=np.float64), [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
 
     @property

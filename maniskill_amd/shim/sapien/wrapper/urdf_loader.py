@@ -160,7 +160,7 @@ class URDFLoader:
                 ax = je.find("axis")
                 axis = _floats(ax.get("xyz"), (1, 0, 0)) if ax is not None else [1.0, 0, 0]
                 jo = _origin(je)
-                jo = Pose(jo.p * S, jo.q)
+                jo = Pose(jo._p * S, jo._q)
                 axis_pose = Pose([0, 0, 0], shortest_rotation([1, 0, 0], axis))
                 lim = je.find("limit")
                 dyn = je.find("dynamics")
@@ -184,7 +184,10 @@ class URDFLoader:
                     raise RuntimeError(f"{urdf_file}: joint type {jt!r} of {je.get('name')!r} is not supported")
                 mim = je.find("mimic")
                 if mim is not None:
-                    builder.mimic_joint_records.append(MimicJointRecord(je.get("name"), mim.get("joint"), float(mim.get("multiplier", "1")),
+                    # q(this joint) = multiplier * q(mimicked joint) + offset.  ManiSkill turns a record into the tendon
+                    # -multiplier * q(record.joint) + q(record.mimic) = offset (articulation_builder.py:161-200), so record.joint is
+                    # the mimicked joint and record.mimic the one carrying the <mimic> tag
+                    builder.mimic_joint_records.append(MimicJointRecord(mim.get("joint"), je.get("name"), float(mim.get("multiplier", "1")),
                                                                         float(mim.get("offset", "0"))))
             # ---- inertial ----
             ine = le.find("inertial")
@@ -196,9 +199,9 @@ class URDFLoader:
                 T = np.array([[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]], dtype=np.float64)
                 from .._mesh import principal
                 w, q = principal(T)
-                lb.set_mass_and_inertia(mass * S ** 3, Pose(io.p * S, io.q) * Pose([0, 0, 0], q), np.maximum(w, 0) * S ** 5)
-                R = io.to_transformation_matrix()[:3, :3].astype(np.float64)
-                lb._exact_inertial = (mass * S ** 3, io.p.astype(np.float64) * S, (R @ T @ R.T) * S ** 5)
+                lb.set_mass_and_inertia(mass * S ** 3, Pose(io._p * S, io._q) * Pose([0, 0, 0], q), np.maximum(w, 0) * S ** 5)
+                R = io._matrix64()[:3, :3]
+                lb._exact_inertial = (mass * S ** 3, io._p * S, (R @ T @ R.T) * S ** 5)
             # ---- collisions ----
             mat = self._link_material.get(name, self._material)
             density = self._link_density.get(name, self._density)
@@ -208,7 +211,7 @@ class URDFLoader:
             for ce in le.findall("collision"):
                 g = ce.find("geometry")
                 co = _origin(ce)
-                co = Pose(co.p * S, co.q)
+                co = Pose(co._p * S, co._q)
                 if g.find("box") is not None:
                     size = _floats(g.find("box").get("size"), (1, 1, 1))
                     lb.add_box_collision(co, [s * S / 2 for s in size], **kw)
@@ -235,7 +238,7 @@ class URDFLoader:
             for ve in le.findall("visual"):
                 g = ve.find("geometry")
                 vo = _origin(ve)
-                vo = Pose(vo.p * S, vo.q)
+                vo = Pose(vo._p * S, vo._q)
                 vm = self._visual_material(ve, named)
                 vname = ve.get("name", "")
                 if g is None:
