@@ -437,10 +437,17 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
       mass_i = x[0];
       sym6_rotate(&R, Ii, Iinv);
     } else sym6_rotate(&R, b->Iinv6, Iinv);
-    if (st.ext_wrench) { /* external force / torque at the centre of mass, this step only (msk_apply FORCE / TORQUE) */
-      const float* wr = st.ext_wrench + ((size_t)e * m->nb + i) * 8;
-      v = v3_madd(v, v3_make(wr[0], wr[1], wr[2]), dt / mass_i);
-      w = v3_madd(w, sym6_mulv(Iinv, v3_make(wr[4], wr[5], wr[6])), dt);
+    { /* external force / torque at the centre of mass, this step only (msk_apply FORCE / TORQUE).  Data-driven so that a captured
+       * step graph sees forces applied between replays: the rows are always read (32 bytes per dynamic body), a non-zero row is
+       * consumed and cleared here */
+      float* wr = st.ext_wrench + ((size_t)e * m->nb + i) * 8;
+      const float4 wf = *(const float4*)wr, wt = *(const float4*)(wr + 4);
+      if (wf.x != 0.0f || wf.y != 0.0f || wf.z != 0.0f || wt.x != 0.0f || wt.y != 0.0f || wt.z != 0.0f) {
+        v = v3_madd(v, v3_make(wf.x, wf.y, wf.z), dt / mass_i);
+        w = v3_madd(w, sym6_mulv(Iinv, v3_make(wt.x, wt.y, wt.z)), dt);
+        *(float4*)wr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        *(float4*)(wr + 4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
     }
     const float kl = fmaxf(0.0f, 1.0f - dt * b->lin_damp);
     const float ka = fmaxf(0.0f, 1.0f - dt * b->ang_damp);

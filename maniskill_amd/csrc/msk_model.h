@@ -101,7 +101,7 @@ struct DState {
   /* narrowphase work lists per env and type (plane / box-box / GJK): surviving pair indices in pair order */
   int *np_count;                               /* [N][4] */
   int *np_items;                               /* [N][3][np] */
-  const float *ext_wrench;                     /* [N][nb][8] external force (0..2) / torque (4..6) of this step, or nullptr */
+  float *ext_wrench;                           /* [N][nb][8] external force (0..2) / torque (4..6) of the next step; consumed and cleared by k_dynamics */
   long long *dbg;                              /* [N][8] phase time stamps (MSK_PROFILE_PHASES builds only) */
   int *env_ncontacts;                          /* [N] */
   int *env_overflow;                           /* [1] */

@@ -51,7 +51,6 @@ struct msk_ctx {
   std::vector<float> h_xshape, h_xbody;   /* host mirrors of the per-env instance records [N][nxs | nxb][8] */
   float* d_wrench = nullptr;    /* [N][nb][8] external wrench of the next step (msk_apply FORCE / TORQUE) */
   LinkSlots link_slots;         /* row of a link within its articulation (link incoming joint forces) */
-  bool wrench_pending = false;
   size_t lds_solve = 0;  /* dynamic LDS of the solver launch */
   int solve_workers = 0; /* its one-env-per-wave workgroups */
   RModel* rmodel;            /* host copy of the render geometry (include/msk_render.h) */
@@ -506,7 +505,7 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   }
   ALLOC(c->bufs.buf[MSK_BUF_ART_LINK_JOINT_FORCES], N * (size_t)(m.na > 0 ? m.na : 1) * (size_t)(c->link_slots.max_links > 0 ? c->link_slots.max_links : 1) * 6);
   ALLOC(c->d_wrench, N * (size_t)m.nb * 8);
-  c->wrench_pending = false;
+  c->st.ext_wrench = c->d_wrench;
   c->bufs.max_dof = c->max_dof;
   /* initial poses (template replicated) */
   std::vector<float> h(N * (size_t)m.lay.stride, 0.0f);
@@ -550,7 +549,6 @@ MSK_API int msk_apply(msk_ctx* c, uint32_t mask, void* stream) {
     const int rows = N * c->model.nb;
     hipLaunchKernelGGL(k_apply_wrench, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_wrench,
                        c->bufs.buf[MSK_BUF_RIGID_BODY_FORCE], c->bufs.buf[MSK_BUF_RIGID_BODY_TORQUE], rows, mask);
-    c->wrench_pending = true;
     if (!(mask & ~(uint32_t)(MSK_APPLY_RIGID_FORCE | MSK_APPLY_RIGID_TORQUE))) { HIP_TRY(hipGetLastError()); return MSK_OK; }
   }
   hipLaunchKernelGGL(k_apply, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->bufs, mask,
@@ -594,13 +592,7 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
   const bool timed = c->t_n < c->t_cap;
   hipEvent_t* ev = timed ? &c->tev[(size_t)c->t_n * (MSK_K_SLOTS + 1)] : nullptr;
   if (timed) hipEventRecord(ev[0], s);
-  if (c->wrench_pending) { /* forces act for this step only */
-    DState stw = c->st;
-    stw.ext_wrench = c->d_wrench;
-    launch_dynamics(c->model, c->d_model, stw, s);
-    hipMemsetAsync(c->d_wrench, 0, sizeof(float) * 8 * (size_t)N * c->model.nb, s);
-    c->wrench_pending = false;
-  } else launch_dynamics(c->model, c->d_model, c->st, s);
+  launch_dynamics(c->model, c->d_model, c->st, s);   /* consumes and clears pending external wrenches (data-driven, graph-safe) */
   if (timed) hipEventRecord(ev[1], s);
   if (c->model.np > 0) {
     hipLaunchKernelGGL(k_broadphase, dim3(N), dim3(64), 0, s, c->d_model, c->st);

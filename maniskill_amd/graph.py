@@ -11,7 +11,7 @@ Contract of a captured env step:
   * no host synchronisation and no host->device copy inside ``step`` (all the envs of this package comply for the
     control modes documented in DESIGN.md §6),
   * the action tensor is copied into a static input; the outputs are static tensors that the *next* replay
-    overwrites, so ``__call__`` hands out clones of (obs, reward, terminated, truncated) and the static ``info``,
+    overwrites, so ``__call__`` hands out clones of everything: obs (camera textures included), reward, flags and ``info``,
   * anything outside ``step`` (reset, set_state, per-env instance updates) stays eager and needs no re-capture: the
     graph holds pointers into the simulator's persistent state, not copies of it.
 """
@@ -37,14 +37,15 @@ def const(values, device, dtype=torch.float32):
 
 
 def _clone_tree(x):
-    """Snapshots of the small per-step outputs; the camera textures under ``sensor_data`` are already a snapshot taken
-    inside the step (render.py get_obs copy=True) and are handed out as they are."""
-    if isinstance(x, dict) and "sensor_data" in x:
-        return {k: (v if k in ("sensor_data", "sensor_param") else _clone_tree(v)) for k, v in x.items()}
+    """Snapshots of every tensor a replay hands out.  Everything produced inside the capture — the camera planes under
+    ``sensor_data`` included: their ``.clone()`` in render.get_obs runs inside the graph and lands in a fixed pool allocation —
+    lives in memory the next replay overwrites, so callers get copies made after the replay."""
     if isinstance(x, torch.Tensor):
         return x.clone()
     if isinstance(x, dict):
         return {k: _clone_tree(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_clone_tree(v) for v in x)
     return x
 
 
@@ -84,4 +85,4 @@ class StepGraph:
         self.graph.replay()
         self.replays += 1
         obs, rew, term, trunc, info = self.out
-        return _clone_tree(obs), rew.clone(), term.clone(), trunc.clone(), dict(info)
+        return _clone_tree(obs), rew.clone(), term.clone(), trunc.clone(), _clone_tree(info)

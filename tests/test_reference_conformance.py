@@ -1,7 +1,7 @@
 """T0 parity: the reference's OWN API-conformance tests, run unmodified on this backend through the sapien shim.
 
-The reference's test files (``/root/reference/tests``) are executed by pytest in a subprocess with tests/ref_pytest_plugin.py
-loaded; nothing of the reference is copied or edited.  Here (no GPU) the CPU checker sits behind the shim, so what is verified is
+The reference's test functions (``/root/reference/tests``, or its byte-compiled build oracle/_ref/maniskill on the GPU box) are
+imported and called by tests/ref_run_node.py in a subprocess; nothing of the reference is copied or edited.  Here (no GPU) the CPU checker sits behind the shim, so what is verified is
 the host path: builders -> scene compiler -> C ABI -> buffers -> ManiSkill's structs / BaseEnv / ManiSkillVectorEnv.  With
 ``-m gpu`` the same node ids run on libmsk_physx.so.  The reference checkout is not on the GPU box unless staged (see
 tests/ref_harness.py): the tests skip when it is absent.
@@ -31,10 +31,10 @@ STATE_NODES = [
 ]
 
 
-def run_reference_tests(nodes, backend, extra=()):
-    env = dict(os.environ, MSK_REF_BACKEND=backend, PYTHONPATH=os.pathsep.join([HERE, os.environ.get("PYTHONPATH", "")]))
-    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-p", "ref_pytest_plugin", "-p", "no:cacheprovider", "--rootdir", REF, *extra, *nodes]
-    r = subprocess.run(cmd, cwd=REF, env=env, capture_output=True, text=True, timeout=3000)
+def run_reference_tests(nodes, backend):
+    """tests/ref_run_node.py in a subprocess (fresh interpreter: the shim / backend selection is process-global)."""
+    cmd = [sys.executable, os.path.join(HERE, "ref_run_node.py"), backend, *nodes]
+    r = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True, timeout=3000)
     return r.returncode, (r.stdout[-6000:] + r.stderr[-3000:])
 
 
