@@ -43,7 +43,8 @@ enum msk_status {
 
 enum msk_joint_type { MSK_JOINT_FIXED = 0, MSK_JOINT_REVOLUTE = 1, MSK_JOINT_PRISMATIC = 2 };
 enum msk_body_kind { MSK_BODY_KINEMATIC = 1, MSK_BODY_DYNAMIC = 2, MSK_BODY_LINK = 3 };
-enum msk_shape_type { MSK_SHAPE_PLANE = 0, MSK_SHAPE_BOX = 1, MSK_SHAPE_SPHERE = 2, MSK_SHAPE_CONVEX = 3 };
+enum msk_shape_type { MSK_SHAPE_PLANE = 0, MSK_SHAPE_BOX = 1, MSK_SHAPE_SPHERE = 2, MSK_SHAPE_CONVEX = 3, MSK_SHAPE_CAPSULE = 4,
+                      MSK_SHAPE_CYLINDER = 5 };
 
 /* Capacities of one env template (compile-time, shared by oracle and HIP library). */
 #define MSK_MAX_BODIES 48
@@ -107,9 +108,13 @@ int msk_add_actor(msk_ctx* ctx, int kind, const float pose[7], float mass,
                   float angular_damping, int disable_gravity);
 /* PhysxCollisionShape* + body.attach(shape) (actor_builder.py:57-164).  body = -1
  * attaches to the static world (PhysxRigidStaticComponent).  params: box half sizes /
- * sphere radius / unused.  verts (convex only): nverts*3 floats in shape-local
- * coordinates, scale already applied, nverts <= MSK_MAX_HULL_VERTS.  Plane normal is
- * +x of the shape frame (SAPIEN convention, building/ground.py:38-40). */
+ * sphere {radius} / capsule and cylinder {radius, half length} (axis = +x of the shape frame, as in
+ * SAPIEN / PhysX) / convex {rounding radius, normally 0}.  verts (convex only): nverts*3 floats in
+ * shape-local coordinates, scale already applied, nverts <= MSK_MAX_HULL_VERTS.  Plane normal is
+ * +x of the shape frame (SAPIEN convention, building/ground.py:38-40).
+ * Internally every non-box, non-plane shape is a "rounded hull": a convex vertex set swept by a ball.
+ * Sphere = 1 vertex + radius, capsule = 2 vertices + radius (exact); a cylinder is cooked to a 16-sided
+ * prism hull (PhysX has no cylinder primitive either: SAPIEN hands it a cooked convex mesh [ext]). */
 int msk_add_shape(msk_ctx* ctx, int body, int type, const float local_pose[7],
                   const float params[3], const float* verts, int nverts,
                   float static_friction, float dynamic_friction, float restitution,

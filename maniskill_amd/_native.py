@@ -16,7 +16,7 @@ DEFAULT_LIB = os.path.join(_HERE, "csrc", "libmsk_physx.so")
 # enums of include/msk_physx.h
 JOINT_FIXED, JOINT_REVOLUTE, JOINT_PRISMATIC = 0, 1, 2
 BODY_KINEMATIC, BODY_DYNAMIC, BODY_LINK = 1, 2, 3
-SHAPE_PLANE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_CONVEX = 0, 1, 2, 3
+SHAPE_PLANE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_CONVEX, SHAPE_CAPSULE, SHAPE_CYLINDER = 0, 1, 2, 3, 4, 5
 (BUF_RIGID_BODY_DATA, BUF_ART_QPOS, BUF_ART_QVEL, BUF_ART_QACC, BUF_ART_QF, BUF_ART_TARGET_QPOS,
  BUF_ART_TARGET_QVEL, BUF_RIGID_BODY_FORCE, BUF_RIGID_BODY_TORQUE, BUF_ART_LINK_JOINT_FORCES) = range(10)
 APPLY_RIGID_DATA, APPLY_ART_QPOS, APPLY_ART_QVEL, APPLY_ART_QF = 1, 2, 4, 8

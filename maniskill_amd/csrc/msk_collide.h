@@ -106,6 +106,9 @@ MSK_DEV void grp_sync() {
 #define NO_INDEX 0x7fffffff
 
 MSK_DEV int shape_nverts(const CShape* sh) { return sh->type == MSK_SHAPE_BOX ? 8 : sh->nverts; }
+/* rounding radius of a hull (sphere = 1 vertex, capsule = 2 vertices, swept by a ball: include/msk_physx.h); the scans, GJK and
+ * EPA work on the core, the radius is added to heights and separations -- the oracle's shape_rad() */
+MSK_DEV float shape_rad(const CShape* sh) { return sh->type == MSK_SHAPE_CONVEX ? sh->par[0] : 0.0f; }
 MSK_DEV v3 shape_vert(const CCtx& m, const CShape* sh, int i) {
   if (sh->type == MSK_SHAPE_BOX)
     return v3_make((i & 1) ? sh->par[0] : -sh->par[0], (i & 2) ? sh->par[1] : -sh->par[1],
@@ -192,7 +195,7 @@ MSK_DEV int select_feature(const CCtx& m, const CShape* sh, const pose* T, v3 n,
     if (m.gl == 0) {
       out[cnt].u = PU[sk] + o1;
       out[cnt].v = PV[sk] + o2;
-      out[cnt].h = H[sk] + on;
+      out[cnt].h = fmaf(sign, shape_rad(sh), H[sk] + on);
     }
     cnt++;
   }
@@ -789,6 +792,8 @@ MSK_DEV int gjk_epa(const CCtx& m, const CShape* A, const pose* TA, const CShape
   Simplex S;
   float bary[4] = {1, 0, 0, 0};
   int n = 0;
+  const float ra = shape_rad(A), rb = shape_rad(B), rsum = ra + rb;
+  margin += rsum;   /* distances below are between the cores */
   v3 d0 = v3_sub(ca, cb);
   if (v3_len2(d0) < 1e-12f) d0 = v3_make(1, 0, 0);
   S.s0 = msupport(m, A, TA, B, TB, v3_neg(d0));
@@ -825,8 +830,8 @@ MSK_DEV int gjk_epa(const CCtx& m, const CShape* A, const pose* TA, const CShape
       for (int i = 0; i < 4; ++i)
         if (i < n) { const mvert s = simplex_get(S, i); pa = v3_madd(pa, s.a, bary[i]); pb = v3_madd(pb, s.b, bary[i]); }
       *n_out = v3_scale(v, 1.0f / dist);
-      *sep_out = dist;
-      *wa = pa; *wb = pb;
+      *sep_out = dist - rsum;
+      *wa = v3_madd(pa, *n_out, -ra); *wb = v3_madd(pb, *n_out, rb);
       return 1;
     }
   }
@@ -840,12 +845,13 @@ MSK_DEV int gjk_epa(const CCtx& m, const CShape* A, const pose* TA, const CShape
   if (!ok) {
     /* degenerate: fall back to the centre direction with zero separation */
     *n_out = v3_normalize(d0);
-    *sep_out = 0.0f;
-    *wa = support(m, A, TA, v3_neg(*n_out));
-    *wb = support(m, B, TB, *n_out);
+    *sep_out = 0.0f - rsum;
+    *wa = v3_madd(support(m, A, TA, v3_neg(*n_out)), *n_out, -ra);
+    *wb = v3_madd(support(m, B, TB, *n_out), *n_out, rb);
     return 1;
   }
-  *sep_out = -depth;
+  *sep_out = -depth - rsum;
+  *wa = v3_madd(*wa, *n_out, -ra); *wb = v3_madd(*wb, *n_out, rb);
   return 1;
 }
 
@@ -867,7 +873,7 @@ MSK_DEV int plane_convex(const CCtx& m, const CShape* P, const pose* TP, const C
     c.u = c.v = c.hm = c.sep = 0.0f;
     if (i < nv) {
       v3 w = pose_apply(*TC, shape_vert(m, C, i));
-      float sep = v3_dot(pn, w) - pd;
+      float sep = v3_dot(pn, w) - pd - shape_rad(C);
       if (!(sep > margin)) { keep = true; c.u = v3_dot(w, t1); c.v = v3_dot(w, t2); c.hm = pd + 0.5f * sep; c.sep = sep; }
     }
     const unsigned bk = grp_ballot(keep);

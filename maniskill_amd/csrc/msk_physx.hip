@@ -277,9 +277,36 @@ MSK_API int msk_add_shape(msk_ctx* c, int body, int type, const float local_pose
   s->local = pose_from7(local_pose);
   s->par[0] = params[0]; s->par[1] = params[1]; s->par[2] = params[2];
   s->df = df;
-  if (type == MSK_SHAPE_CONVEX) {
+  /* sphere / capsule / cylinder become rounded hulls (include/msk_physx.h): core vertices + rounding radius in par[0] */
+  float gen[32 * 3];
+  if (type == MSK_SHAPE_SPHERE) {
+    if (!(params[0] > 0.0f)) return fail(c, MSK_ERR_INVALID, "sphere: radius must be positive");
+    gen[0] = gen[1] = gen[2] = 0.0f;
+    verts = gen; nverts = 1;
+    s->type = type = MSK_SHAPE_CONVEX;
+    s->par[0] = params[0]; s->par[1] = s->par[2] = 0.0f;
+  } else if (type == MSK_SHAPE_CAPSULE) {
+    if (!(params[0] > 0.0f) || !(params[1] >= 0.0f)) return fail(c, MSK_ERR_INVALID, "capsule: radius > 0, half length >= 0");
+    gen[0] = -params[1]; gen[1] = gen[2] = 0.0f; gen[3] = params[1]; gen[4] = gen[5] = 0.0f;
+    verts = gen; nverts = 2;
+    s->type = type = MSK_SHAPE_CONVEX;
+    s->par[0] = params[0]; s->par[1] = s->par[2] = 0.0f;
+  } else if (type == MSK_SHAPE_CYLINDER) {
+    if (!(params[0] > 0.0f) || !(params[1] > 0.0f)) return fail(c, MSK_ERR_INVALID, "cylinder: radius and half length must be positive");
+    for (int k = 0; k < 16; ++k) {
+      const float a = (float)k * (6.28318530717958647692f / 16.0f);
+      const float y = params[0] * cosf(a), z = params[0] * sinf(a);
+      gen[3 * k] = -params[1]; gen[3 * k + 1] = y; gen[3 * k + 2] = z;
+      gen[3 * (16 + k)] = params[1]; gen[3 * (16 + k) + 1] = y; gen[3 * (16 + k) + 2] = z;
+    }
+    verts = gen; nverts = 32;
+    s->type = type = MSK_SHAPE_CONVEX;
+    s->par[0] = s->par[1] = s->par[2] = 0.0f;
+  } else if (type == MSK_SHAPE_CONVEX) {
     if (nverts < 4 || nverts > MSK_MAX_HULL_VERTS) return fail(c, MSK_ERR_CAPACITY, "convex: 4..64 vertices");
-    if (c->nverts_total + nverts > MSK_MAX_SHAPES * 16) return fail(c, MSK_ERR_CAPACITY, "hull vertex pool exhausted");
+    if (!(params[0] >= 0.0f)) return fail(c, MSK_ERR_INVALID, "convex: negative rounding radius");
+  }
+  if (type == MSK_SHAPE_CONVEX) {
     s->nverts = nverts;
     s->vbase = c->nverts_total;
     v3 lo = {3e38f, 3e38f, 3e38f}, hi = {-3e38f, -3e38f, -3e38f};
@@ -291,7 +318,8 @@ MSK_API int msk_add_shape(msk_ctx* c, int body, int type, const float local_pose
     }
     c->nverts_total += nverts;
     s->aabb_c.x = (lo.x + hi.x) * 0.5f; s->aabb_c.y = (lo.y + hi.y) * 0.5f; s->aabb_c.z = (lo.z + hi.z) * 0.5f;
-    s->aabb_h.x = (hi.x - lo.x) * 0.5f; s->aabb_h.y = (hi.y - lo.y) * 0.5f; s->aabb_h.z = (hi.z - lo.z) * 0.5f;
+    s->aabb_h.x = (hi.x - lo.x) * 0.5f + s->par[0]; s->aabb_h.y = (hi.y - lo.y) * 0.5f + s->par[0];   /* core box + rounding radius */
+    s->aabb_h.z = (hi.z - lo.z) * 0.5f + s->par[0];
   } else if (type == MSK_SHAPE_BOX) {
     s->aabb_h.x = params[0]; s->aabb_h.y = params[1]; s->aabb_h.z = params[2];
   } else if (type == MSK_SHAPE_PLANE) {

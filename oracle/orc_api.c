@@ -161,8 +161,36 @@ ORC_EXPORT int orc_add_shape(orc_ctx* c, int body, int type, const float local_p
   s->sf = sf; s->df = df; s->rest = rest;
   memcpy(s->g, groups, sizeof(s->g));
   s->patch_r = patch_radius;
-  if (type == MSK_SHAPE_CONVEX) {
+  /* sphere / capsule / cylinder become rounded hulls (include/msk_physx.h): core vertices + rounding radius in par[0] */
+  float gen[32 * 3];
+  if (type == MSK_SHAPE_SPHERE) {
+    if (!(params[0] > 0.0f)) return fail(c, MSK_ERR_INVALID, "sphere: radius must be positive");
+    gen[0] = gen[1] = gen[2] = 0.0f;
+    verts = gen; nverts = 1;
+    s->type = type = MSK_SHAPE_CONVEX;
+    s->par[0] = params[0]; s->par[1] = s->par[2] = 0.0f;
+  } else if (type == MSK_SHAPE_CAPSULE) {
+    if (!(params[0] > 0.0f) || !(params[1] >= 0.0f)) return fail(c, MSK_ERR_INVALID, "capsule: radius > 0, half length >= 0");
+    gen[0] = -params[1]; gen[1] = gen[2] = 0.0f; gen[3] = params[1]; gen[4] = gen[5] = 0.0f;
+    verts = gen; nverts = 2;
+    s->type = type = MSK_SHAPE_CONVEX;
+    s->par[0] = params[0]; s->par[1] = s->par[2] = 0.0f;
+  } else if (type == MSK_SHAPE_CYLINDER) {
+    if (!(params[0] > 0.0f) || !(params[1] > 0.0f)) return fail(c, MSK_ERR_INVALID, "cylinder: radius and half length must be positive");
+    for (int k = 0; k < 16; ++k) {
+      const float a = (float)k * (6.28318530717958647692f / 16.0f);
+      const float y = params[0] * cosf(a), z = params[0] * sinf(a);
+      gen[3 * k] = -params[1]; gen[3 * k + 1] = y; gen[3 * k + 2] = z;
+      gen[3 * (16 + k)] = params[1]; gen[3 * (16 + k) + 1] = y; gen[3 * (16 + k) + 2] = z;
+    }
+    verts = gen; nverts = 32;
+    s->type = type = MSK_SHAPE_CONVEX;
+    s->par[0] = s->par[1] = s->par[2] = 0.0f;
+  } else if (type == MSK_SHAPE_CONVEX) {
     if (nverts < 4 || nverts > MSK_MAX_HULL_VERTS) return fail(c, MSK_ERR_CAPACITY, "convex: 4..64 vertices");
+    if (!(params[0] >= 0.0f)) return fail(c, MSK_ERR_INVALID, "convex: negative rounding radius");
+  }
+  if (type == MSK_SHAPE_CONVEX) {
     s->nverts = nverts;
     v3 lo = v3_make(3e38f, 3e38f, 3e38f), hi = v3_make(-3e38f, -3e38f, -3e38f);
     for (int i = 0; i < nverts; ++i) {
@@ -171,7 +199,7 @@ ORC_EXPORT int orc_add_shape(orc_ctx* c, int body, int type, const float local_p
       hi = v3_make(fmaxf(hi.x, s->verts[i].x), fmaxf(hi.y, s->verts[i].y), fmaxf(hi.z, s->verts[i].z));
     }
     s->aabb_c = v3_scale(v3_add(lo, hi), 0.5f);
-    s->aabb_h = v3_scale(v3_sub(hi, lo), 0.5f);
+    s->aabb_h = v3_add(v3_scale(v3_sub(hi, lo), 0.5f), v3_make(s->par[0], s->par[0], s->par[0]));   /* core box + rounding radius */
   } else if (type == MSK_SHAPE_BOX) {
     s->aabb_c = v3_make(0, 0, 0);
     s->aabb_h = v3_make(params[0], params[1], params[2]);

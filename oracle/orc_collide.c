@@ -48,6 +48,9 @@ static pose shape_pose(const orc_ctx* c, const orc_env* e, const orc_shape* sh) 
 }
 
 static int shape_nverts(const orc_shape* sh) { return sh->type == MSK_SHAPE_BOX ? 8 : sh->nverts; }
+/* rounding radius of a hull: a sphere is a one-vertex hull, a capsule a two-vertex hull, swept by a ball of this radius
+ * (msk_add_shape); GJK / EPA / the feature scans work on the core, the radius is added to heights and separations */
+static float shape_rad(const orc_shape* sh) { return sh->type == MSK_SHAPE_CONVEX ? sh->par[0] : 0.0f; }
 static v3 shape_vert(const orc_shape* sh, int i) {
   if (sh->type == MSK_SHAPE_BOX)
     return v3_make((i & 1) ? sh->par[0] : -sh->par[0], (i & 2) ? sh->par[1] : -sh->par[1],
@@ -139,7 +142,7 @@ static int select_feature(const orc_shape* sh, const pose* T, v3 n, v3 t1, v3 t2
     v3 p = shape_vert(sh, kept[k]);
     out[k].u = v3_dot(p, t1l) + o1;
     out[k].v = v3_dot(p, t2l) + o2;
-    out[k].h = hh[kept[k]] + on;
+    out[k].h = fmaf(sign, shape_rad(sh), hh[kept[k]] + on);   /* the surface lies a radius beyond the core, towards the other shape */
   }
   return cnt;
 }
@@ -595,6 +598,8 @@ static int gjk_epa(const orc_shape* A, const pose* TA, const orc_shape* B, const
   mvert s[4];
   float bary[4] = {1, 0, 0, 0};
   int n = 0;
+  const float ra = shape_rad(A), rb = shape_rad(B), rsum = ra + rb;
+  margin += rsum;   /* distances below are between the cores */
   v3 d0 = v3_sub(ca, cb);
   if (v3_len2(d0) < 1e-12f) d0 = v3_make(1, 0, 0);
   s[0] = msupport(A, TA, B, TB, v3_neg(d0));
@@ -628,8 +633,8 @@ static int gjk_epa(const orc_shape* A, const pose* TA, const orc_shape* B, const
       v3 pa = v3_make(0, 0, 0), pb = v3_make(0, 0, 0);
       for (int i = 0; i < n; ++i) { pa = v3_madd(pa, s[i].a, bary[i]); pb = v3_madd(pb, s[i].b, bary[i]); }
       *n_out = v3_scale(v, 1.0f / dist);
-      *sep_out = dist;
-      *wa = pa; *wb = pb;
+      *sep_out = dist - rsum;
+      *wa = v3_madd(pa, *n_out, -ra); *wb = v3_madd(pb, *n_out, rb);
       return 1;
     }
   }
@@ -650,12 +655,13 @@ static int gjk_epa(const orc_shape* A, const pose* TA, const orc_shape* B, const
 #endif
     /* degenerate: fall back to the centre direction with zero separation */
     *n_out = v3_normalize(d0);
-    *sep_out = 0.0f;
-    *wa = support(A, TA, v3_neg(*n_out));
-    *wb = support(B, TB, *n_out);
+    *sep_out = 0.0f - rsum;
+    *wa = v3_madd(support(A, TA, v3_neg(*n_out)), *n_out, -ra);
+    *wb = v3_madd(support(B, TB, *n_out), *n_out, rb);
     return 1;
   }
-  *sep_out = -depth;
+  *sep_out = -depth - rsum;
+  *wa = v3_madd(*wa, *n_out, -ra); *wb = v3_madd(*wb, *n_out, rb);
   return 1;
 }
 
@@ -671,7 +677,7 @@ static int plane_convex(const orc_shape* P, const pose* TP, const orc_shape* C, 
   int nv = shape_nverts(C);
   for (int i = 0; i < nv; ++i) {
     v3 w = pose_apply(*TC, shape_vert(C, i));
-    float sep = v3_dot(pn, w) - pd;
+    float sep = v3_dot(pn, w) - pd - shape_rad(C);
     if (sep > margin) continue;
     cs[nc].u = v3_dot(w, t1); cs[nc].v = v3_dot(w, t2); cs[nc].hm = pd + 0.5f * sep; cs[nc].sep = sep;
     nc++;

@@ -1,0 +1,146 @@
+"""Sphere / capsule / cylinder collision shapes (mani_skill/utils/building/actor_builder.py:73-155): known answers on the CPU
+oracle, HIP == oracle on the GPU.  Inside the library they are "rounded hulls" (include/msk_physx.h): a vertex core swept by a
+ball, so a sphere rolls on ONE contact point and a lying capsule rests on TWO."""
+import numpy as np
+import pytest
+import torch
+
+from maniskill_amd import _native as N
+from maniskill_amd.envs import scene_builders as sb
+from maniskill_amd.physx import SceneTemplate, SimConfig
+
+
+def _world(factory, n, shape, params, z, q=(1, 0, 0, 0), mass=0.5, inertia=(1e-3, 1e-3, 1e-3), gravity=(0, 0, -9.81), friction=0.5, v0=None, w0=None):
+    tpl = SceneTemplate()
+    sb.add_table_scene(tpl)
+    b = tpl.add_actor("obj", N.BODY_DYNAMIC, p=(0, 0, z), q=q, mass=mass, inertia6=tuple(inertia) + (0, 0, 0), angular_damping=0.0)
+    tpl.add_shape(b, shape, params=params, static_friction=friction, dynamic_friction=friction)
+    cfg = SimConfig()
+    cfg.scene_config.gravity = tuple(gravity)
+    px = factory(tpl, n, cfg)
+    px.gpu_init()
+    px.set_scene_offsets(np.zeros((n, 3)))
+    rbd = px.cuda_rigid_body_data.torch().view(n, px.bodies_per_env, 13)
+    rbd[:, tpl.body_id("table-workspace"), :7] = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)])
+    rbd[:, b, :3] = torch.tensor([0.0, 0.0, z])
+    rbd[:, b, 3:7] = torch.tensor(q, dtype=torch.float32)
+    rbd[:, b, 7:13] = 0.0
+    if v0 is not None:
+        rbd[:, b, 7:10] = torch.tensor(v0, dtype=torch.float32)
+    if w0 is not None:
+        rbd[:, b, 10:13] = torch.tensor(w0, dtype=torch.float32)
+    px.gpu_apply_all()
+    return px, b, rbd
+
+
+def _settle(px, steps):
+    for _ in range(steps):
+        px.step()
+    px.gpu_fetch_all()
+
+
+def test_sphere_rests_on_one_contact_point_carrying_its_weight(oracle_factory):
+    r, m = 0.03, 0.5
+    px, b, rbd = _world(oracle_factory, 1, N.SHAPE_SPHERE, (r, 0, 0), z=r + 0.01, mass=m, inertia=(0.4 * m * r * r,) * 3)
+    _settle(px, 60)
+    assert abs(rbd[0, b, 2].item() - r) < 1e-3 and rbd[0, b, 7:13].abs().max() < 1e-2
+    ids, vals = px.get_contacts(0)
+    assert len(ids) == 1                                        # one point, straight below the centre
+    assert np.allclose(vals[0, :3], [0, 0, 0], atol=2e-3) and abs(abs(vals[0, 5]) - 1.0) < 1e-5
+    assert abs(vals[0, 7] - m * 9.81 * px.timestep) < 0.03 * m * 9.81 * px.timestep    # normal impulse = weight * dt
+
+
+def test_sphere_rolls_without_slipping(oracle_factory):
+    """A ball pushed along x on a rough table ends up rolling: v = omega x r (v_x = omega_y * r), and keeps (5/7 of) its speed."""
+    r, m = 0.03, 0.5
+    px, b, rbd = _world(oracle_factory, 1, N.SHAPE_SPHERE, (r, 0, 0), z=r, mass=m, inertia=(0.4 * m * r * r,) * 3, friction=1.0,
+                        v0=(0.2, 0, 0))
+    _settle(px, 40)
+    vx, wy = rbd[0, b, 7].item(), rbd[0, b, 11].item()
+    assert abs(vx - wy * r) < 0.02 * abs(vx)                    # rolling contact
+    assert abs(vx - 0.2 * 5.0 / 7.0) < 0.03 * 0.2               # sliding -> rolling keeps 5/7 of the speed of a solid ball
+    x0 = rbd[0, b, 0].item()
+    _settle(px, 20)
+    assert abs((rbd[0, b, 0].item() - x0) - vx * 20 * px.timestep) < 0.05 * vx * 20 * px.timestep   # and keeps going
+
+
+def test_lying_capsule_rests_on_two_points(oracle_factory):
+    r, hl, m = 0.02, 0.05, 0.3
+    px, b, rbd = _world(oracle_factory, 1, N.SHAPE_CAPSULE, (r, hl, 0), z=r + 0.005, mass=m, inertia=(1e-4, 4e-4, 4e-4))
+    _settle(px, 60)
+    assert abs(rbd[0, b, 2].item() - r) < 1e-3 and rbd[0, b, 7:13].abs().max() < 1e-2
+    ids, vals = px.get_contacts(0)
+    assert len(ids) == 2
+    xs = sorted(vals[:, 0].tolist())
+    assert abs(xs[0] + hl) < 2e-3 and abs(xs[1] - hl) < 2e-3    # under the two end centres (axis = local x)
+    assert abs(vals[:, 7].sum() - m * 9.81 * px.timestep) < 0.03 * m * 9.81 * px.timestep
+
+
+def test_standing_capsule_on_its_cap_is_one_point(oracle_factory):
+    r, hl, m = 0.02, 0.05, 0.3
+    q = (np.cos(np.pi / 4), 0, -np.sin(np.pi / 4), 0)            # local x -> world z
+    px, b, rbd = _world(oracle_factory, 1, N.SHAPE_CAPSULE, (r, hl, 0), z=hl + r, q=q, mass=m, inertia=(1e-4, 4e-4, 4e-4))
+    _settle(px, 3)
+    ids, vals = px.get_contacts(0)
+    assert len(ids) == 1 and abs(rbd[0, b, 2].item() - (hl + r)) < 1e-3
+
+
+def test_cylinder_rests_on_its_flat_face_and_sphere_on_box(oracle_factory):
+    r, hl, m = 0.03, 0.02, 0.4
+    q = (np.cos(np.pi / 4), 0, -np.sin(np.pi / 4), 0)            # axis (local x) up
+    px, b, rbd = _world(oracle_factory, 1, N.SHAPE_CYLINDER, (r, hl, 0), z=hl + 0.004, q=q, mass=m, inertia=(2e-4, 1.5e-4, 1.5e-4))
+    _settle(px, 60)
+    assert abs(rbd[0, b, 2].item() - hl) < 1e-3 and rbd[0, b, 7:13].abs().max() < 1e-2
+    ids, vals = px.get_contacts(0)
+    assert 3 <= len(ids) <= 4                                    # a face manifold
+
+
+def _stack(factory, n):
+    """A ball resting on a cube resting on the table: sphere-box goes through GJK on the sphere's core."""
+    tpl = SceneTemplate()
+    sb.add_table_scene(tpl)
+    cube = sb.add_cube(tpl, "cube", 0.03, (0, 0, 0.03))
+    r, m = 0.02, 0.1
+    ball = tpl.add_actor("ball", N.BODY_DYNAMIC, p=(0, 0, 0.06 + r), mass=m, inertia6=(0.4 * m * r * r,) * 3 + (0, 0, 0))
+    tpl.add_shape(ball, N.SHAPE_SPHERE, params=(r, 0, 0))
+    px = factory(tpl, n, SimConfig())
+    px.gpu_init()
+    px.set_scene_offsets(np.zeros((n, 3)))
+    rbd = px.cuda_rigid_body_data.torch().view(n, px.bodies_per_env, 13)
+    rbd[:, tpl.body_id("table-workspace"), :7] = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)])
+    px.gpu_apply_all()
+    return px, cube, ball, rbd, r, m
+
+
+def test_ball_on_cube_on_table(oracle_factory):
+    px, cube, ball, rbd, r, m = _stack(oracle_factory, 1)
+    _settle(px, 80)
+    assert abs(rbd[0, ball, 2].item() - (0.06 + r)) < 1.5e-3 and abs(rbd[0, cube, 2].item() - 0.03) < 1e-3
+    assert rbd[0, ball, 7:13].abs().max() < 2e-2
+
+
+@pytest.mark.gpu
+def test_rounded_shapes_hip_equals_oracle(built, oracle_factory):
+    from maniskill_amd.physx import PhysxGpuSystem
+    hip = lambda tpl, n, cfg: PhysxGpuSystem("cuda:0", tpl, n, cfg)   # noqa: E731
+    cases = [
+        (N.SHAPE_SPHERE, (0.03, 0, 0), 0.05, (1, 0, 0, 0), dict(v0=(0.3, 0.1, 0), friction=1.0)),
+        (N.SHAPE_CAPSULE, (0.02, 0.05, 0), 0.04, (0.9659258, 0, 0.2588190, 0), dict(w0=(0, 0, 2.0))),
+        (N.SHAPE_CYLINDER, (0.03, 0.02, 0), 0.05, (0.8660254, 0.5, 0, 0), dict(v0=(0.1, 0, 0))),
+    ]
+    for shape, params, z, q, kw in cases:
+        a = _world(hip, 8, shape, params, z, q=q, **kw)
+        b = _world(oracle_factory, 8, shape, params, z, q=q, **kw)
+        for k in range(60):
+            a[0].step(); b[0].step()
+            if k % 10 == 9:
+                a[0].gpu_fetch_all(); b[0].gpu_fetch_all()
+                ra, rb = a[2].cpu(), b[2]
+                assert torch.isfinite(ra).all() and torch.isfinite(rb).all()
+                assert torch.allclose(ra, rb, rtol=1e-4, atol=1e-5), (shape, k, float((ra - rb).abs().max()))
+    pa = _stack(hip, 8)
+    pb = _stack(oracle_factory, 8)
+    for k in range(60):
+        pa[0].step(); pb[0].step()
+    pa[0].gpu_fetch_all(); pb[0].gpu_fetch_all()
+    assert torch.allclose(pa[3].cpu(), pb[3], rtol=1e-4, atol=1e-5)
