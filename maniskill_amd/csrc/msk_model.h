@@ -41,7 +41,7 @@ struct DShape {
 
 struct DTendon { int dof_a, dof_b; float ca, cb, rest, K, D; };
 struct DPair { int sa, sb; };
-struct DPairInfo { int ba, bb; float mu; int pad; }; /* bodies of the two shapes, friction of the pair */
+struct DPairInfo { int ba, bb; float mu; float rest; }; /* bodies of the two shapes, friction and restitution of the pair (averages) */
 
 #define MSK_SOLVE_CLASSES 4
 #define MSK_LIMIT_DISTANCE 0.1f   /* a joint closer than this to a limit gets a limit block (solver and classifier) */

@@ -67,6 +67,7 @@ struct msk_ctx {
   bool has_peg = false;
   bool kin_dirty;        /* link frames in st.bpose are older than (q, qd): run k_kinematics before reading them */
   uint32_t groups[MSK_MAX_SHAPES][4]; /* collision groups: only the static pair filter needs them */
+  float rest[MSK_MAX_SHAPES];         /* restitution per shape (pair value = average, DPairInfo::rest) */
   std::vector<void*> allocs;
   std::vector<HostQuery> queries;
   /* per-kernel event timing (msk_timing_*): MSK_K_SLOTS + 1 events per armed step */
@@ -266,7 +267,7 @@ MSK_API int msk_add_actor(msk_ctx* c, int kind, const float pose7[7], float mass
 MSK_API int msk_add_shape(msk_ctx* c, int body, int type, const float local_pose[7], const float params[3],
                           const float* verts, int nverts, float sf, float df, float rest, const uint32_t groups[4],
                           float patch_radius, float min_patch_radius) {
-  (void)sf; (void)rest; (void)patch_radius; (void)min_patch_radius;
+  (void)sf; (void)patch_radius; (void)min_patch_radius;
   DModel& m = c->model;
   if (c->finalized) return fail(c, MSK_ERR_INVALID, "add_shape after finalize");
   if (m.ns >= MSK_MAX_SHAPES) return fail(c, MSK_ERR_CAPACITY, "too many shapes");
@@ -328,6 +329,7 @@ MSK_API int msk_add_shape(msk_ctx* c, int body, int type, const float local_pose
     return fail(c, MSK_ERR_INVALID, "shape type not supported");
   }
   memcpy(c->groups[m.ns], groups, 4 * sizeof(uint32_t));
+  c->rest[m.ns] = rest;
   return m.ns++;
 }
 
@@ -446,7 +448,7 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
     const DShape* B = &m.shapes[m.pairs[p].sb];
     m.pinfo[p].ba = A->body; m.pinfo[p].bb = B->body;
     m.pinfo[p].mu = 0.5f * (A->df + B->df);
-    m.pinfo[p].pad = 0;
+    m.pinfo[p].rest = 0.5f * (c->rest[m.pairs[p].sa] + c->rest[m.pairs[p].sb]);
   }
   {
     EnvLayout& L = m.lay;

@@ -104,12 +104,18 @@ struct CsLds {
  * recovery or approach speed from c0 + J.dq) or of a friction row (drift J.dq).  b = J.dq only changes
  * between sweeps, so every lane evaluates this once per sweep for its own rows, off the serial chain. */
 template <bool POSIT, bool FRICTION>
-MSK_DEV float bias_over_arr(float b, float c0, float rinv, float inv_h, float inv_dt, float beta_dt) {
+MSK_DEV float bias_over_arr(float b, float c0, float rinv, float inv_h, float inv_dt, float beta_dt, float rest = 0.0f, float vclose = 0.0f) {
   float bias;
   if (!FRICTION) {
     const float cur = c0 + b;
     if (POSIT) bias = (cur > 0.0f) ? cur * inv_h : fmaxf(cur * beta_dt, -MSK_MAX_DEPEN_VEL);
     else bias = (cur > 0.0f) ? cur * inv_dt : 0.0f;
+    /* restitution: a normal row that came in faster than bounce_threshold aims at the rebound speed (rest = e * J.v* < 0) once the gap
+     * is closed (position sweeps) or would be eaten by the approach allowance of the next step (velocity sweep) */
+    if (rest < 0.0f) {
+      if (POSIT) { if (!(cur > 0.0f)) bias = fminf(bias, rest); }
+      else if (cur < vclose) bias = rest;
+    }
   } else {
     bias = POSIT ? b * inv_h : 0.0f;
   }
@@ -238,7 +244,7 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   float J[3][NVP];
   float c0[3] = {0.0f, 0.0f, 0.0f}, lam[3] = {0.0f, 0.0f, 0.0f};
   bool valid[3] = {false, false, false};
-  float mu = 0.0f;
+  float mu = 0.0f, erest = 0.0f;
   int code = -1; /* contact blocks: pair * 4 + point */
 #pragma unroll
   for (int s = 0; s < 3; ++s)
@@ -269,6 +275,7 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
     const v3 pt = v3_make(rec[4 + 3 * kk], rec[4 + 3 * kk + 1], rec[4 + 3 * kk + 2]);
     const float sep = rec[16 + kk];
     mu = pi.mu;
+    erest = pi.rest;
     /* coordinates that move the two bodies (bit k) */
     const unsigned coordsA = pi.ba >= 0 ? m->body_coords[pi.ba] : 0u, coordsB = pi.bb >= 0 ? m->body_coords[pi.bb] : 0u;
     const v3 dirs[3] = {n, t1, t2};
@@ -330,6 +337,9 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
     for (int k = 0; k < NVP; ++k) acc = fmaf(J[s][k], Lvf[k], acc);
     av[s] = acc;
   }
+  /* restitution bias of my normal row (the oracle's rows[i].rest): e * J.v* if the approach beats bounce_threshold */
+  const bool bounces = is_contact && erest > 0.0f && av[0] < -m->cfg.bounce_threshold;
+  const float rest0 = bounces ? erest * av[0] : 0.0f, vclose0 = bounces ? -av[0] * dt : 0.0f;
   for (int blk = 0; blk < nblk; ++blk) { /* per-group trip count: the groups of a wave diverge here, no cross-lane ops inside */
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -402,7 +412,7 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   auto sweep = [&](auto posit_tag) {
     constexpr bool POSIT = decltype(posit_tag)::value;
     /* sweep-invariant bias terms of my rows */
-    const float t0 = bias_over_arr<POSIT, false>(bv[0], c0[0], rinv[0], inv_h, inv_dt, beta_dt);
+    const float t0 = bias_over_arr<POSIT, false>(bv[0], c0[0], rinv[0], inv_h, inv_dt, beta_dt, rest0, vclose0);
     const float t1f = bias_over_arr<POSIT, true>(bv[1], c0[1], rinv[1], inv_h, inv_dt, beta_dt);
     const float t1n = bias_over_arr<POSIT, false>(bv[1], c0[1], rinv[1], inv_h, inv_dt, beta_dt);
     const float t1 = is_contact ? t1f : t1n;

@@ -752,10 +752,12 @@ int orc_collide_pair(const orc_ctx* c, const orc_env* e, int pi, orc_contact* ou
   }
   STAT(12, n);
   float mu = 0.5f * (A->df + B->df);
+  float rest = 0.5f * (A->rest + B->rest);
   for (int i = 0; i < n; ++i) {
     out[i].sa = c->pairs[pi].sa; out[i].sb = c->pairs[pi].sb;
     out[i].ba = A->body; out[i].bb = B->body;
     out[i].mu = mu;
+    out[i].rest = rest;
     out[i].sep -= c->cfg.rest_offset * 2.0f;
   }
   return n;

@@ -44,6 +44,8 @@ typedef struct {
   float c0;     /* position-level error at the start of the step (separation / distance to the limit) */
   float rinv;   /* 1 / (J . Y) */
   float mu;
+  float rest;   /* normal rows: restitution bias e * (J . v*) when the approach is faster than bounce_threshold, else 0 */
+  float vclose; /* ... and the distance that approach covers in one step */
   float lam;    /* accumulated impulse */
   float a, b;   /* J . v and J . dq, carried in constraint space */
   float lsum;   /* sum of lam over the position iterations */
@@ -504,6 +506,12 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
     for (int r = 0; r < nr; ++r) A[i][r] = dot_seq(rows[i].J, rows[r].Y, nv, s.npad);
     rows[i].rinv = 1.0f / A[i][i];
     float a = dot_seq(rows[i].J, s.vfree, nv, s.npad);
+    /* restitution (PhysxMaterial.restitution, scene bounce_threshold: structs/types.py:35-67): a normal row approaching faster
+     * than the threshold aims at the rebound speed -e * (approach speed) instead of zero */
+    if (rows[i].kind == ROW_CN) {
+      const float er = e->contacts[rows[i].idx].rest;
+      if (er > 0.0f && a < -c->cfg.bounce_threshold) { rows[i].rest = er * a; rows[i].vclose = -a * dt; }
+    }
     for (int r = 0; r < nr; ++r) a = fmaf(A[i][r], rows[r].lam, a);
     rows[i].a = a;
   }
@@ -519,6 +527,11 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
         const float cur = r->c0 + r->b;
         if (posit) bias = (cur > 0.0f) ? cur * inv_h : fmaxf(cur * beta_dt, -ORC_MAX_DEPEN_VEL);
         else bias = (cur > 0.0f) ? cur * inv_dt : 0.0f;
+        /* bounce: once the gap is closed (position sweeps) or would be eaten by the approach allowance of the next step (velocity sweep) */
+        if (r->rest < 0.0f) {
+          if (posit) { if (!(cur > 0.0f)) bias = fminf(bias, r->rest); }
+          else if (cur < r->vclose) bias = r->rest;
+        }
         lo = 0.0f; hi = INFINITY;
       } else { /* friction */
         bias = posit ? r->b * inv_h : 0.0f;

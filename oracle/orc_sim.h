@@ -64,6 +64,7 @@ typedef struct {
   v3 n;              /* unit normal, from B towards A */
   float sep;         /* signed separation along n (negative = penetration) */
   float mu;
+  float rest;        /* restitution of the pair: average of the two shapes' (PhysX's default combine mode) */
   float lam[3];      /* accumulated impulses: normal, t1, t2 */
   v3 t1, t2;
 } orc_contact;

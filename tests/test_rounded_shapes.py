@@ -144,3 +144,66 @@ def test_rounded_shapes_hip_equals_oracle(built, oracle_factory):
         pa[0].step(); pb[0].step()
     pa[0].gpu_fetch_all(); pb[0].gpu_fetch_all()
     assert torch.allclose(pa[3].cpu(), pb[3], rtol=1e-4, atol=1e-5)
+
+
+def _bouncer(factory, n, e, drop=0.3, r=0.03):
+    tpl = SceneTemplate()
+    q = (float(np.cos(np.pi / 4)), 0.0, 0.0, float(np.sin(np.pi / 4)))
+    table = tpl.add_actor("table-workspace", N.BODY_KINEMATIC, p=(-0.12, 0.0, -sb.TABLE_HEIGHT), q=q)
+    tpl.add_shape(table, N.SHAPE_BOX, p=(0, 0, sb.TABLE_HEIGHT / 2), params=(1.2, 0.6, sb.TABLE_HEIGHT / 2), restitution=e)
+    m = 0.2
+    ball = tpl.add_actor("ball", N.BODY_DYNAMIC, p=(0, 0, r + drop), mass=m, inertia6=(0.4 * m * r * r,) * 3 + (0, 0, 0))
+    tpl.add_shape(ball, N.SHAPE_SPHERE, params=(r, 0, 0), restitution=e)
+    cfg = SimConfig(sim_freq=500, control_freq=100)
+    px = factory(tpl, n, cfg)
+    px.gpu_init()
+    px.set_scene_offsets(np.zeros((n, 3)))
+    rbd = px.cuda_rigid_body_data.torch().view(n, px.bodies_per_env, 13)
+    return px, ball, rbd, r
+
+
+def _first_apex(px, ball, rbd, r, max_steps=600):
+    """height of the ball's lowest point at the first apex after the first impact"""
+    hit, best, prev_v = False, 0.0, 0.0
+    for k in range(max_steps):
+        px.step()
+        px.gpu_fetch_all()
+        vz = rbd[0, ball, 9].item()
+        if not hit and vz > 0:
+            hit = True
+        if hit:
+            best = max(best, rbd[0, ball, 2].item() - r)
+            if vz < 0 and prev_v >= 0:
+                return best
+        prev_v = vz
+    return best
+
+
+@pytest.mark.parametrize("e", [0.0, 0.5, 0.8])
+def test_bounce_height_is_e_squared_times_the_drop(oracle_factory, e):
+    """PhysxMaterial.restitution + bounce_threshold (structs/types.py:35-67): rebound speed = e * impact speed -> apex e^2 * drop."""
+    drop = 0.3
+    px, ball, rbd, r = _bouncer(oracle_factory, 1, e, drop)
+    apex = _first_apex(px, ball, rbd, r)
+    if e == 0.0:
+        assert apex < 2e-3
+    else:
+        assert abs(apex - e * e * drop) < 0.06 * e * e * drop + 2e-3
+
+
+def test_slow_contacts_do_not_bounce(oracle_factory):
+    """below bounce_threshold (2 m/s: a 0.05 m drop arrives at 1 m/s) restitution is ignored"""
+    px, ball, rbd, r = _bouncer(oracle_factory, 1, 0.8, drop=0.05)
+    assert _first_apex(px, ball, rbd, r) < 2e-3
+
+
+@pytest.mark.gpu
+def test_bounce_hip_equals_oracle(built, oracle_factory):
+    from maniskill_amd.physx import PhysxGpuSystem
+    a = _bouncer(lambda tpl, n, cfg: PhysxGpuSystem("cuda:0", tpl, n, cfg), 4, 0.8)
+    b = _bouncer(oracle_factory, 4, 0.8)
+    for k in range(300):
+        a[0].step(); b[0].step()
+    a[0].gpu_fetch_all(); b[0].gpu_fetch_all()
+    assert torch.allclose(a[2].cpu(), b[2], rtol=1e-4, atol=1e-5)
+    assert b[2][0, b[1], 9].abs() > 0.1      # still bouncing
