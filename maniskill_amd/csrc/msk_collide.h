@@ -855,6 +855,32 @@ MSK_DEV int gjk_epa(const CCtx& m, const CShape* A, const pose* TA, const CShape
   return 1;
 }
 
+/* ---- vertex cull (before GJK) ----------------------------------------------------------------- */
+/* Are the vertices of V (a box or a rounded hull) farther than `margin` from the oriented box (centre c, half extents h, in the
+ * frame TO) along one of that box's face normals?  The box contains the other shape, so a gap along any of the three axes is
+ * a gap between the shapes: GJK would find a distance above the margin and report nothing.  The broadphase asks the same
+ * question of V's own local box; asking it of V's vertices (the scan is one pass over the group's lanes, all LDS) answers it
+ * for the hull itself — what is left of the "link hovering over the table" pairs goes away here.  Conservative by 1e-4 m: a
+ * pair this test drops is one the oracle's GJK rejects, so the contact sets stay identical. */
+MSK_DEV bool verts_beyond_obb(const CCtx& m, const CShape* V, const pose* TV, const pose* TO, v3 c, v3 h, float margin) {
+  /* V's vertices in the box frame: x_o = R_o^T (R_v x + p_v - p_o) - c */
+  const quat qrel = quat_mul(quat_conj(TO->q), TV->q);
+  const v3 prel = v3_sub(quat_rotate_inv(TO->q, v3_sub(TV->p, TO->p)), c);
+  v3 lo = v3_make(3.0e38f, 3.0e38f, 3.0e38f), hi = v3_make(-3.0e38f, -3.0e38f, -3.0e38f);
+  const int nv = shape_nverts(V);
+#pragma unroll 1
+  for (int i = m.gl; i < nv; i += NPG) {
+    const v3 w = v3_add(quat_rotate(qrel, shape_vert(m, V, i)), prel);
+    lo = v3_make(fminf(lo.x, w.x), fminf(lo.y, w.y), fminf(lo.z, w.z));
+    hi = v3_make(fmaxf(hi.x, w.x), fmaxf(hi.y, w.y), fmaxf(hi.z, w.z));
+  }
+  const float r = shape_rad(V) + margin + 1.0e-4f;
+  const float gx = fmaxf(-grp_max(-lo.x) - h.x, -h.x - grp_max(hi.x));   /* gap along x: min vertex above +h or max vertex below -h */
+  const float gy = fmaxf(-grp_max(-lo.y) - h.y, -h.y - grp_max(hi.y));
+  const float gz = fmaxf(-grp_max(-lo.z) - h.z, -h.z - grp_max(hi.z));
+  return fmaxf(gx, fmaxf(gy, gz)) > r;
+}
+
 /* ---- plane ----------------------------------------------------------------------------- */
 MSK_DEV int plane_convex(const CCtx& m, const CShape* P, const pose* TP, const CShape* C, const pose* TC, float margin,
                         int plane_is_a, DContactOut* out) {

@@ -139,17 +139,29 @@ __global__ void __launch_bounds__(64) k_broadphase(const DModel* __restrict__ m,
 
 /* Solver capacity class of env e: constraint blocks = joints within MSK_LIMIT_DISTANCE of a limit + contact points
  * (the same count solve_env makes), against the per-template class capacities. */
-MSK_DEV int solver_class(const DModel* __restrict__ m, const DState& st, const int e) {
+/* contact points of env e: its row of pair counts (npp ints, a multiple of 16, zero past np) summed with 16-byte loads, eight in
+ * flight: a lane per env walks a strided row, so the number of dependent memory round trips is what costs */
+MSK_DEV int env_contact_total(const DModel* __restrict__ m, const DState& st, const int e) {
+  const int4* c4 = (const int4*)(st.ct_cnt + (size_t)e * m->npp);
+  const int n4 = m->npp >> 2;
+  int s0 = 0, s1 = 0;
+#pragma unroll 8
+  for (int i = 0; i < n4; ++i) {
+    const int4 v = c4[i];
+    s0 += v.x + v.y;
+    s1 += v.z + v.w;
+  }
+  return s0 + s1;
+}
+
+MSK_DEV int solver_class_of(const DModel* __restrict__ m, const DState& st, const int e, const int contacts) {
   const float* E = EREC(st, m, e);
   int nblk = 0;
   for (int d = 0; d < m->nd; ++d) {
     const float lo = m->dof_lo[d], hi = m->dof_hi[d], q = E[m->lay.q + d];
     if (!(lo < -1e30f && hi > 1e30f) && (q - lo < MSK_LIMIT_DISTANCE || hi - q < MSK_LIMIT_DISTANCE)) nblk++;
   }
-  const int* cnts = st.ct_cnt + (size_t)e * m->npp;
-  int base = 0;
-  for (int p = 0; p < m->np; ++p) base += cnts[p];
-  nblk += base < MSK_MAX_CONTACTS ? base : MSK_MAX_CONTACTS;
+  nblk += contacts < MSK_MAX_CONTACTS ? contacts : MSK_MAX_CONTACTS;
   return nblk <= m->cls_cap[0] ? 0 : (nblk <= m->cls_cap[1] ? 1 : (nblk <= m->cls_cap[2] ? 2 : 3));
 }
 
@@ -157,7 +169,7 @@ MSK_DEV int solver_class(const DModel* __restrict__ m, const DState& st, const i
 MSK_DEV void classify_envs(const DModel* __restrict__ m, const DState& st, const int e0, const int n) {
   const int lane = threadIdx.x & 63;
   const bool mine = lane < n && e0 + lane < m->N;
-  const int cls = mine ? solver_class(m, st, e0 + lane) : -1;
+  const int cls = mine ? solver_class_of(m, st, e0 + lane, env_contact_total(m, st, e0 + lane)) : -1;
 #pragma unroll
   for (int c = 0; c < MSK_SOLVE_CLASSES; ++c) {
     const unsigned long long mask = __ballot(cls == c);
@@ -183,7 +195,7 @@ __global__ void __launch_bounds__(64) k_classify(const DModel* __restrict__ m, D
  * `group` = 16 at 4096 envs, fewer when there are few envs (then the launch is bound by its slowest wave). */
 template <int TYPE, int LPI>   /* LPI = lanes per item: 1 or NPG */
 MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, const int e0, const int group, const int part,
-                              const int nparts, int* pref, float* s_ws, float* s_we) {
+                              const int nparts, int* pref, float* s_ws, float* s_we, const v3* verts) {
   constexpr int type = TYPE;
   const int lane = threadIdx.x;
   const float margin = 2.0f * m->cfg.contact_offset;
@@ -226,7 +238,7 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
   bool writer = true;
   if constexpr (LPI == 1) { /* box-box: one lane per pair, its polygon arrays interleaved in LDS */
     CCtx cx;
-    cx.verts = m->verts; cx.ws = nullptr; cx.we = nullptr; cx.gl = 0; cx.grp = 0; cx.dbg = nullptr;
+    cx.verts = verts; cx.ws = nullptr; cx.we = nullptr; cx.gl = 0; cx.grp = 0; cx.dbg = nullptr;
     perlane::DContactOut out[4];
     v3 nrm;
     float sep;
@@ -242,7 +254,7 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
     onrm = out[0].n;
   } else {
     CCtx cx;
-    cx.verts = m->verts;
+    cx.verts = verts;
     cx.ws = s_ws + (lane / NPG) * WS_TOTAL;
     cx.we = s_we;
     cx.gl = lane % NPG;
@@ -264,9 +276,12 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
         }
       } else {
         v3 ca, ha, cb, hb;
-        world_aabb(dA->aabb_c, shape_half_dev(m, E, dA), &TA, &ca, &ha);
-        world_aabb(dB->aabb_c, shape_half_dev(m, E, dB), &TB, &cb, &hb);
-        hit = gjk_epa(cx, A, &TA, B, &TB, ca, cb, margin, &nrm, &sep, &wa, &wb);
+        const v3 hla = shape_half_dev(m, E, dA), hlb = shape_half_dev(m, E, dB);
+        world_aabb(dA->aabb_c, hla, &TA, &ca, &ha);
+        world_aabb(dB->aabb_c, hlb, &TB, &cb, &hb);
+        /* third cull stage: each shape's vertices against the other's oriented local box (msk_collide.h verts_beyond_obb) */
+        hit = !(verts_beyond_obb(cx, A, &TA, &TB, dB->aabb_c, hlb, margin) || verts_beyond_obb(cx, B, &TB, &TA, dA->aabb_c, hla, margin));
+        if (hit) hit = gjk_epa(cx, A, &TA, B, &TB, ca, cb, margin, &nrm, &sep, &wa, &wb);
       }
 #ifdef MSK_PROFILE_PHASES
       tq[1] = (long long)__builtin_readcyclecounter();
@@ -335,8 +350,8 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
  * blocks of one kind share the group's list of that kind.
  * Per 64 consecutive envs, the block that finishes last sorts them into the solver lists (one wave, one env per lane:
  * a handful of same-address atomics per 64 envs). */
-struct NpCfg { int nplane, nbox, nhull; };
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_narrowphase(const DModel* __restrict__ m, DState st, const int group, const NpCfg cfg) {
+struct NpCfg { int nplane, nbox, nhull, skip; };   /* skip: timing experiments only (bit 0 plane, 1 box-box, 2 hull lists not processed) */
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_narrowphase(const DModel* __restrict__ m, DState st, const int group, const NpCfg cfg) {
   __shared__ int pref[NP_GROUP_MAX + 1];
   /* one LDS image for both kinds of block: 32 lanes x 208 words of per-pair arrays (box-box), or four group workspaces
    * and the wave's EPA workspace (plane, hull) */
@@ -346,9 +361,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   float* s_we = s_lds + (64 / NPG) * WS_TOTAL;
   const int e0 = blockIdx.x * group;
   int y = blockIdx.y;
-  if (y < cfg.nplane) narrowphase_body<NP_PLANE, NPG>(m, st, e0, group, y, cfg.nplane, pref, s_ws, s_we);
-  else if ((y -= cfg.nplane) < cfg.nbox) narrowphase_body<NP_BOXBOX, 1>(m, st, e0, group, y, cfg.nbox, pref, s_ws, s_we);
-  else narrowphase_body<NP_GJK, NPG>(m, st, e0, group, y - cfg.nbox, cfg.nhull, pref, s_ws, s_we);
+  const bool lane_kind = (y >= cfg.nplane) && (y - cfg.nplane < cfg.nbox);   /* box-box, one lane per pair: boxes only */
+  /* plane and hull blocks scan hull vertices over and over (support points, features): the template's vertex pool (<= 12 KB) is
+   * staged in the part of the LDS image that only the lane-per-pair kind uses, so every scan is an LDS read instead of an L2 hit */
+  const v3* verts = m->verts;
+  if (!lane_kind) {
+    float* s_verts = s_lds + (64 / NPG) * WS_TOTAL + WE_TOTAL;
+    const int nw = m->nverts_total * 3;
+    if (nw <= LDS_WORDS - ((64 / NPG) * WS_TOTAL + WE_TOTAL)) {
+      const float* src = (const float*)m->verts;
+      for (int i = threadIdx.x; i < nw; i += 64) s_verts[i] = src[i];
+      verts = (const v3*)s_verts;
+    }
+  }
+  if (y < cfg.nplane) { if (!(cfg.skip & 1)) narrowphase_body<NP_PLANE, NPG>(m, st, e0, group, y, cfg.nplane, pref, s_ws, s_we, verts); }
+  else if ((y -= cfg.nplane) < cfg.nbox) {
+    if (!(cfg.skip & 2)) narrowphase_body<NP_BOXBOX, 1>(m, st, e0, group, y, cfg.nbox, pref, s_ws, s_we, verts);
+  }
+  else if (!(cfg.skip & 4)) narrowphase_body<NP_GJK, NPG>(m, st, e0, group, y - cfg.nbox, cfg.nhull, pref, s_ws, s_we, verts);
   __threadfence();
   const int chunk = e0 / 64;
   const int first_blk = (chunk * 64 + group - 1) / group, end_env = min(chunk * 64 + 64, m->N);

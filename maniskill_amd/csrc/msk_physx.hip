@@ -66,6 +66,7 @@ struct msk_ctx {
   PegTables peg_tb;
   bool has_peg = false;
   bool kin_dirty;        /* link frames in st.bpose are older than (q, qd): run k_kinematics before reading them */
+  PairSel pick_lsel, pick_rsel;   /* pickcube task: shape pairs finger <-> object */
   uint32_t groups[MSK_MAX_SHAPES][4]; /* collision groups: only the static pair filter needs them */
   float rest[MSK_MAX_SHAPES];         /* restitution per shape (pair value = average, DPairInfo::rest) */
   std::vector<void*> allocs;
@@ -635,6 +636,8 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
     cfg.nplane = 1;
     cfg.nbox = e_nbox;
     cfg.nhull = e_nhull;
+    static const int e_skip = getenv("MSK_NP_SKIP") ? atoi(getenv("MSK_NP_SKIP")) : 0;
+    cfg.skip = e_skip;
     hipLaunchKernelGGL(k_narrowphase, dim3((N + group - 1) / group, cfg.nplane + cfg.nbox + cfg.nhull), dim3(64), 0, s, c->d_model,
                        c->st, group, cfg);
   } else {
@@ -896,6 +899,21 @@ MSK_API int msk_task_pickcube_init(msk_ctx* c, const msk_pickcube_desc* d) {
   if (d->arm_dofs + 2 != c->model.nd || 2 * (d->arm_dofs + 2) + 24 != 42) return fail(c, MSK_ERR_INVALID, "pickcube: expects a 7+2 dof arm");
   c->pickcube = *d;
   c->has_pickcube = true;
+  /* candidate pairs between each finger and the object, ascending: what the observe kernel sums contact impulses over */
+  for (int side = 0; side < 2; ++side) {
+    PairSel* ps = side ? &c->pick_rsel : &c->pick_lsel;
+    const int x = side ? d->right_finger : d->left_finger, y = d->cube;
+    ps->n = 0;
+    for (int p = 0; p < c->model.np; ++p) {
+      const int ba = c->model.pinfo[p].ba, bb = c->model.pinfo[p].bb;
+      float sgn;
+      if (ba == x && bb == y) sgn = 1.0f;
+      else if (ba == y && bb == x) sgn = -1.0f;
+      else continue;
+      if (ps->n >= 14) return fail(c, MSK_ERR_CAPACITY, "pickcube: too many shape pairs between a finger and the object");
+      ps->idx[ps->n] = p; ps->sgn[ps->n] = sgn; ps->n++;
+    }
+  }
   return MSK_OK;
 }
 
@@ -1027,8 +1045,8 @@ MSK_API int msk_task_pickcube_observe(msk_ctx* c, float* obs, float* reward, uin
     c->kin_dirty = false;
   }
   const float cos_max = cosf(c->pickcube.max_angle_deg * 3.14159265358979323846f / 180.0f);
-  hipLaunchKernelGGL(k_pickcube_observe, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->pickcube, obs,
-                     reward, flags, elapsed, advance, cos_max);
+  hipLaunchKernelGGL(k_pickcube_observe, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, c->d_model, c->st, c->pickcube, c->pick_lsel,
+                     c->pick_rsel, obs, reward, flags, elapsed, advance, cos_max);
   HIP_TRY(hipGetLastError());
   return MSK_OK;
 }

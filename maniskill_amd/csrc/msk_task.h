@@ -131,6 +131,30 @@ MSK_DEV v3 pair_impulse(const DModel* m, const DState& st, int e, int x, int y) 
   return sum;
 }
 
+/* the same sum over a pair list prepared on the host (the candidate pairs between two bodies, ascending: the order of the scan
+ * above): the observe kernels ask for finger-object impulses every step and need not walk the whole pair table for them */
+struct PairSel { int n; int idx[14]; float sgn[14]; };
+MSK_DEV v3 pair_impulse_sel(const DModel* m, const DState& st, int e, const PairSel& ps) {
+  const int* cnts = st.ct_cnt + (size_t)e * m->npp;
+  const float* recs = st.ct_rec + (size_t)e * m->npp * MSK_CT_REC;
+  v3 sum = v3_make(0, 0, 0);
+  for (int i = 0; i < ps.n; ++i) {
+    const int p = ps.idx[i];
+    const int cnt = cnts[p];
+    if (cnt == 0) continue;
+    const float* rec = recs + (size_t)p * MSK_CT_REC;
+    const v3 n = v3_make(rec[0], rec[1], rec[2]);
+    v3 t1, t2;
+    msk_tangents(n, &t1, &t2);
+    for (int k = 0; k < cnt; ++k) {
+      const float l0 = rec[20 + k * 3 + 0], l1 = rec[20 + k * 3 + 1], l2 = rec[20 + k * 3 + 2];
+      const v3 imp = v3_madd(v3_madd(v3_scale(n, l0), t1, l1), t2, l2);
+      sum = v3_madd(sum, imp, ps.sgn[i]);
+    }
+  }
+  return sum;
+}
+
 MSK_DEV float v3_norm_plain(v3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
 
 /* Panda.is_grasping for one finger: force >= min_force and angle(finger opening direction, force) <= max_angle */
@@ -143,10 +167,10 @@ MSK_DEV bool finger_grasps(v3 force, v3 dir, float min_force, float cos_max_angl
   return fn >= min_force && c >= cos_max_angle;
 }
 
-__global__ void __launch_bounds__(256) k_pickcube_observe(const DModel* __restrict__ m, DState st, msk_pickcube_desc d, float* __restrict__ obs,
-                                                          float* __restrict__ reward, uint8_t* __restrict__ flags,
-                                                          int* __restrict__ elapsed, int advance, float cos_max_angle) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(64) k_pickcube_observe(const DModel* __restrict__ m, DState st, msk_pickcube_desc d, PairSel lsel, PairSel rsel,
+                                                         float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags,
+                                                         int* __restrict__ elapsed, int advance, float cos_max_angle) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
   if (e >= m->N) return;
   const float* E = EREC(st, m, e);
   const int nq = d.arm_dofs + 2;
@@ -163,8 +187,8 @@ __global__ void __launch_bounds__(256) k_pickcube_observe(const DModel* __restri
   const pose lf = load_pose(E, m->lay.bpose, d.left_finger), rf = load_pose(E, m->lay.bpose, d.right_finger);
   /* is_grasping: contact forces = impulses of the last substep / dt */
   const float inv_dt = 1.0f / m->cfg.timestep;
-  const v3 lforce = v3_scale(pair_impulse(m, st, e, d.left_finger, d.cube), inv_dt);
-  const v3 rforce = v3_scale(pair_impulse(m, st, e, d.right_finger, d.cube), inv_dt);
+  const v3 lforce = v3_scale(pair_impulse_sel(m, st, e, lsel), inv_dt);
+  const v3 rforce = v3_scale(pair_impulse_sel(m, st, e, rsel), inv_dt);
   const m33 Rl = quat_to_m33(lf.q), Rr = quat_to_m33(rf.q);
   const v3 ldir = m33_col(&Rl, 1), rdir = v3_neg(m33_col(&Rr, 1));
   const bool grasped = finger_grasps(lforce, ldir, d.min_force, cos_max_angle) && finger_grasps(rforce, rdir, d.min_force, cos_max_angle);
