@@ -14,9 +14,9 @@ __version__ = "0.1.0"
 
 def make(env_id: str, **kwargs):
     """gym.make-style constructor of a batched env: ``maniskill_amd.make("PickCube-v1", num_envs=4096, device="cuda:0")``
-    (mani_skill/utils/registration.py:176-196); wrap it in ``maniskill_amd.vector.ManiSkillVectorEnv`` for auto resets and metrics."""
-    from .vector import _registry
-    reg = _registry()
+    (mani_skill/utils/registration.py:176-196).  Auto resets / metrics: the reference's own ManiSkillVectorEnv over the sapien shim."""
+    from .envs import registered
+    reg = registered()
     if env_id not in reg:
         raise KeyError(f"{env_id!r} is not built on this backend; available: {sorted(reg)}")
     return reg[env_id](**kwargs)

@@ -183,7 +183,6 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
   float* vec = lds + ly.vec;
   const int LD = MSK_MAX_DOF + 1;
 
-  if (blockIdx.x == 0 && threadIdx.x < MSK_SOLVE_CLASSES) st.cls_count[threadIdx.x] = 0; /* this substep's solver lists */
 #ifdef MSK_PROFILE_PHASES
   long long* dstamp = st.dbg + (size_t)m->N * 8 + 64 + (size_t)e * 8;
   int dsi = 0;

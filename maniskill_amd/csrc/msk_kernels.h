@@ -58,6 +58,7 @@ __global__ void __launch_bounds__(64) k_broadphase(const DModel* __restrict__ m,
   const int e = blockIdx.x, lane = threadIdx.x;
   const float* E = EREC(st, m, e);
   const float margin = 2.0f * m->cfg.contact_offset;
+  if (blockIdx.x == 0 && lane < MSK_SOLVE_CLASSES) st.cls_count[lane] = 0;   /* this substep's solver lists (filled by the narrowphase) */
   if (lane < m->ns) {
     const DShape* sh = &m->shapes[lane];
     if (sh->type != MSK_SHAPE_PLANE) {

@@ -96,7 +96,7 @@ struct DState {
    * room for cls_cap[] blocks; built by the last narrowphase launch (classify_envs) */
   int *cls_list;                               /* [MSK_SOLVE_CLASSES][N] */
   int *np_done;                                /* [N]: narrowphase blocks of an env group that have finished (self-resetting) */
-  int *cls_count;                              /* [MSK_SOLVE_CLASSES]; zeroed by k_dynamics of the same substep */
+  int *cls_count;                              /* [MSK_SOLVE_CLASSES]; zeroed by k_broadphase of the same substep */
   float *a_scratch;                            /* [solver workers][9 * 64 * 64]: A images of class-3 envs */
   /* narrowphase work lists per env and type (plane / box-box / GJK): surviving pair indices in pair order */
   int *np_count;                               /* [N][4] */

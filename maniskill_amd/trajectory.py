@@ -303,7 +303,7 @@ def main(argv=None):
     ``python -m mani_skill.trajectory.replay_trajectory``, tyro Args at replay_trajectory.py:31-85)."""
     import argparse
 
-    from .vector import _registry
+    from .envs import registered as _registry
 
     ap = argparse.ArgumentParser(description="Replay a recorded trajectory on the MI355X backend")
     ap.add_argument("--traj-path", required=True)

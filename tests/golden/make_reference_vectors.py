@@ -38,7 +38,7 @@ from mani_skill.utils.structs.actor import Actor as RefActor  # noqa: E402
 from mani_skill.utils.structs.pose import Pose as RefPose  # noqa: E402
 
 from oracle_backend import OraclePhysxSystem  # noqa: E402
-from maniskill_amd.vector import _registry  # noqa: E402
+from maniskill_amd.envs import registered as _registry  # noqa: E402
 
 FAC = lambda tpl, n, cfg: OraclePhysxSystem(tpl, n, cfg)   # noqa: E731
 OUT = {}

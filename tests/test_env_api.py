@@ -136,7 +136,7 @@ def test_env_results_do_not_depend_on_batch_composition(oracle_factory):
 
 def test_action_and_observation_spaces(oracle_factory):
     """single_action_space / action_space per control mode (Panda._controller_configs, panda.py:77-211)."""
-    from maniskill_amd.vector import ManiSkillVectorEnv
+    import maniskill_amd
 
     for mode, dim in (("pd_joint_delta_pos", 8), ("pd_ee_delta_pose", 7), ("pd_joint_pos_vel", 15), ("pd_ee_pose", 7), ("pd_joint_pos", 8)):
         env = PickCubeEnv(num_envs=3, px_factory=oracle_factory, control_mode=mode)
@@ -149,7 +149,7 @@ def test_action_and_observation_spaces(oracle_factory):
     env = PickCubeEnv(num_envs=2, px_factory=oracle_factory, control_mode="pd_joint_pos")
     assert np.allclose(env.single_action_space.low[:7], env.robot.qlimits[0, :7, 0].numpy()) and env.single_action_space.high[3] < 0   # joint 4's range is negative
     assert env.single_observation_space.shape == (42,) and env.observation_space.shape == (2, 42)
-    venv = ManiSkillVectorEnv("PushT-v1", num_envs=2, px_factory=oracle_factory)
+    venv = maniskill_amd.make("PushT-v1", num_envs=2, px_factory=oracle_factory)
     assert venv.single_action_space.shape == (7,) and venv.action_space.shape == (2, 7)
 
 

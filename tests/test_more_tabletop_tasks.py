@@ -7,7 +7,7 @@ import torch
 from maniskill_amd.envs.lift_peg_upright import LiftPegUprightEnv
 from maniskill_amd.envs.poke_cube import PokeCubeEnv
 from maniskill_amd.envs.pull_cube import PullCubeEnv
-from maniskill_amd.vector import ManiSkillVectorEnv
+import maniskill_amd
 
 
 def _teleport(env, body, p=None, q=None):
@@ -108,9 +108,9 @@ def test_pull_cube_tool(oracle_factory):
     assert list(env.get_state_dict()["actors"]) == ["table-workspace", "cube", "l_shape_tool"]
 
 
-def test_registered_and_wrapped(oracle_factory):
+def test_registered(oracle_factory):
     for name, dim in (("PullCube-v1", 35), ("LiftPegUpright-v1", 32), ("PokeCube-v1", 54)):
-        venv = ManiSkillVectorEnv(name, num_envs=2, px_factory=oracle_factory)
+        venv = maniskill_amd.make(name, num_envs=2, px_factory=oracle_factory)
         obs, _ = venv.reset(seed=1)
         obs, rew, term, trunc, info = venv.step(torch.zeros(2, 8))
         assert obs.shape == (2, dim) and rew.shape == (2,)
@@ -119,7 +119,7 @@ def test_registered_and_wrapped(oracle_factory):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["PullCube-v1", "LiftPegUpright-v1", "PokeCube-v1", "StackPyramid-v1", "PullCubeTool-v1"])
 def test_hip_matches_oracle_rollout(oracle_factory, name):
-    from maniskill_amd.vector import _registry
+    from maniskill_amd.envs import registered as _registry
     cls = _registry()[name]
     n = 48
     gpu, cpu = cls(num_envs=n, device="cuda:0"), cls(num_envs=n, px_factory=oracle_factory)

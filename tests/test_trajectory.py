@@ -127,20 +127,20 @@ def test_hip_replays_the_committed_trace():
 
 
 def test_recording_under_the_auto_resetting_vector_env(oracle_factory, tmp_path):
-    """ManiSkillVectorEnv(RecordEpisode(env)): the wrapper's same-step partial resets cut the recorded episodes; every recorded
-    episode is at most max_episode_steps long and replays exactly."""
-    from maniskill_amd.vector import ManiSkillVectorEnv
-
+    """RecordEpisode(env) under same-step partial resets (what ManiSkillVectorEnv does, vector/wrappers/gymnasium.py:150-176): the
+    resets cut the recorded episodes; every recorded episode is at most max_episode_steps long and replays exactly."""
     env = PickCubeEnv(num_envs=3, px_factory=oracle_factory)
     env.max_episode_steps = 6                                   # short episodes: several truncations within the rollout
     rec = RecordEpisode(env, str(tmp_path), env_id="PickCube-v1")
-    venv = ManiSkillVectorEnv(rec, auto_reset=True)
-    venv.reset(seed=9)
+    rec.reset(seed=9)
     gen = torch.Generator().manual_seed(2)
     finals = 0
     for _ in range(15):
-        _, _, _, _, infos = venv.step(0.4 * (2 * torch.rand(3, 8, generator=gen) - 1))
-        finals += int("final_info" in infos)
+        _, _, term, trunc, _ = rec.step(0.4 * (2 * torch.rand(3, 8, generator=gen) - 1))
+        done = term | trunc
+        if done.any():
+            finals += 1
+            rec.reset(options=dict(env_idx=torch.nonzero(done).flatten()))
     rec.close()
     meta, arrays = load_trajectory(str(tmp_path / "trajectory.npz"))
     lens = [ep["elapsed_steps"] for ep in meta["episodes"]]
