@@ -405,3 +405,29 @@ def test_link_incoming_joint_forces_match_oracle(oracle_factory):
         out.append(env.px.get_link_incoming_joint_forces().cpu().clone())
     assert out[1].abs().max() > 1.0
     assert np.allclose(out[0].numpy(), out[1].numpy(), rtol=1e-3, atol=2e-3)
+
+
+@pytest.mark.gpu
+def test_hip_vs_oracle_at_the_metrics_env_count(oracle_factory):
+    """the oracle comparison at BASELINE.json's env count, 4096 PickCube envs x 20 control steps (100 substeps):
+    contact-pair sets bit-exact, states within 1e-4 relative."""
+    n = 4096
+    gpu = PickCubeEnv(num_envs=n, device="cuda:0", fused=False)
+    cpu = PickCubeEnv(num_envs=n, px_factory=oracle_factory)
+    og, _ = gpu.reset(seed=2022); oc, _ = cpu.reset(seed=2022)
+    assert torch.allclose(og.cpu(), oc, atol=2e-6)
+    gen = torch.Generator().manual_seed(5)
+    for t in range(20):
+        a = 2 * torch.rand(n, 8, generator=gen) - 1
+        og, rg, tg, *_ = gpu.step(a.to("cuda:0"))
+        oc, rc, tc, *_ = cpu.step(a)
+        assert torch.isfinite(og).all() and torch.isfinite(oc).all()
+        assert torch.allclose(og.cpu(), oc, rtol=1e-4, atol=1e-5), (t, float((og.cpu() - oc).abs().max()))
+        assert torch.equal(tg.cpu(), tc)
+    assert np.array_equal(gpu.px.get_env_contact_counts(), cpu.px.get_env_contact_counts())
+    for e in (0, 1, 777, 2048, 4095):
+        ig, _ = gpu.px.get_contacts(e)
+        ic, _ = cpu.px.get_contacts(e)
+        assert np.array_equal(ig, ic), e          # shape-pair ids of every contact point, in order
+    sg, sc = gpu.get_state().cpu(), cpu.get_state()
+    assert torch.allclose(sg, sc, rtol=1e-4, atol=1e-5)

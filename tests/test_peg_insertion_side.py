@@ -122,3 +122,25 @@ def test_long_random_rollout_stays_finite(oracle_factory):
         obs, rew, term, trunc, info = env.step(2 * torch.rand(64, 8, generator=gen) - 1)
         assert torch.isfinite(obs).all() and torch.isfinite(rew).all(), k
     assert torch.isfinite(env.get_state()).all() and env.qvel.abs().max() < 20.0
+
+
+@pytest.mark.gpu
+def test_epa_null_normal_reproducer_hip_vs_oracle(oracle_factory):
+    """the sliver-polytope rollout (seed 2022, 64 envs, 100 control steps; the old failure sat at step 84) on HIP
+    against the oracle -- finiteness on BOTH sides first (a shared NaN compares equal to nothing and used to go unnoticed), then
+    the states."""
+    n = 64
+    gpu = PegInsertionSideEnv(num_envs=n, device="cuda:0", fused=False)
+    cpu = PegInsertionSideEnv(num_envs=n, px_factory=oracle_factory)
+    gpu.reset(seed=2022); cpu.reset(seed=2022)
+    gen = torch.Generator().manual_seed(0)
+    for k in range(100):
+        a = 2 * torch.rand(n, 8, generator=gen) - 1
+        og, rg, *_ = gpu.step(a.to("cuda:0"))
+        oc, rc, *_ = cpu.step(a)
+        assert torch.isfinite(og).all() and torch.isfinite(rg).all(), f"HIP not finite at step {k}"
+        assert torch.isfinite(oc).all() and torch.isfinite(rc).all(), f"oracle not finite at step {k}"
+        if k % 10 == 9 or 80 <= k <= 90:
+            sg, sc = gpu.get_state().cpu(), cpu.get_state()
+            assert torch.isfinite(sg).all() and torch.isfinite(sc).all()
+            assert torch.allclose(sg, sc, rtol=1e-4, atol=1e-5), (k, float((sg - sc).abs().max()))
