@@ -259,6 +259,10 @@ class RenderShapeTriangleMesh(RenderShape):
         else:
             self.filename = str(filename)
             self._parts = []
+            if not os.path.exists(self.filename):     # a visual that cannot be loaded is skipped, as a renderer does: the body stays
+                import warnings
+                warnings.warn(f"visual mesh not found, skipped: {self.filename}")
+                return
             for p in _mesh.load_mesh_parts(self.filename):
                 mat = material if material is not None else RenderMaterial(base_color=p["base_color"])
                 self._parts.append(RenderShapeTriangleMeshPart(p["vertices"], p["faces"], mat))
@@ -276,6 +280,24 @@ class RenderShapeTriangleMesh(RenderShape):
                 f = np.concatenate([f, f[:, ::-1]])
             out.append((v, f, p.material._flat_color()))
         return out
+
+
+def _simplify(v, f):
+    """Dense mesh -> something the template holds: a planar sheet becomes the fan of its 2-D convex outline (both windings, as
+    sheets are drawn double sided), anything else its <= 64-vertex convex hull."""
+    from scipy.spatial import ConvexHull
+    v = np.asarray(v, dtype=np.float64)
+    c = v.mean(0)
+    u, sv, vt = np.linalg.svd(v - c, full_matrices=False)
+    if sv[2] < 1e-9 * max(sv[0], 1e-30):
+        uv = (v - c) @ vt[:2].T
+        h = ConvexHull(uv)
+        ring = h.vertices                      # counter-clockwise in the (vt[0], vt[1]) plane
+        pts = v[ring]
+        fan = np.array([[0, k, k + 1] for k in range(1, len(ring) - 1)], dtype=np.int64)
+        return pts, np.concatenate([fan, fan[:, ::-1]])
+    hv = _mesh.reduce_hull(v)
+    return hv, _mesh.hull_faces(hv)
 
 
 def _icosphere(subdiv):
@@ -674,9 +696,9 @@ class RenderSystemGroup:
                         v = v / np.maximum(shape.half_size.astype(np.float64), 1e-12)
                     if len(f) > MAX_TRIS_PER_PART:
                         # the rasteriser's template is small (include/msk_render.h capacities): dense visual meshes are drawn as
-                        # their <= 64-vertex hull until the micro-triangle path exists
-                        hv = _mesh.reduce_hull(v)
-                        v, f = hv, _mesh.hull_faces(hv)
+                        # their <= 64-vertex hull until the micro-triangle path exists; flat sheets (the ground grid,
+                        # building/ground.py:46-119: 20 000 coplanar triangles) as their outline polygon, which is exact
+                        v, f = _simplify(v, f)
                     v32 = np.ascontiguousarray(v, dtype=np.float32)
                     f32 = np.ascontiguousarray(f, dtype=np.int32)
                     rsid = L.render_add_mesh(ctx, int(body), N._fa(list(lp._p) + list(lp._q), 7), v32.ctypes.data_as(C.POINTER(C.c_float)),

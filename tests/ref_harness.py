@@ -68,6 +68,8 @@ def setup(backend="oracle"):
             return be.BackendInfo(device=torch.device("cpu"), sim_device=_HostCudaDevice(), sim_backend="physx_cuda", render_device=rd,
                                   render_backend="none" if rd is None else "sapien_cuda")
         se.parse_sim_and_render_backend = parse
+        if not torch.cuda.is_available():      # the reference synchronises the device after taking pictures (sapien_env.py:624)
+            torch.cuda.synchronize = lambda *a, **k: None
     else:
         se.parse_sim_and_render_backend = orig
     return gym

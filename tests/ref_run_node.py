@@ -1,7 +1,8 @@
 """Runs test functions of the REFERENCE's own test modules (by node id) on this backend, in this process.
 
 ``python tests/ref_run_node.py <backend> <node id> [<node id> ...]`` with node ids as pytest writes them
-(``tests/test_gpu_envs.py::test_partial_resets`` or a whole file ``tests/structs/test_pose.py``).  The modules are imported by
+(``tests/test_gpu_envs.py::test_partial_resets`` or a whole file ``tests/structs/test_pose.py``); a trailing
+``[name=value,...]`` keeps only the parametrisations with those values.  The modules are imported by
 name, so the byte-compiled build of the reference (oracle/_ref/maniskill, no sources: what travels to the GPU box) works the same
 as a checkout; ``pytest.mark.parametrize`` marks are expanded here.  Exit code 0 = every selected test passed.
 """
@@ -38,12 +39,18 @@ def main():
         return 3
     failed = ran = 0
     for node in nodes:
+        sel = {}
+        if node.endswith("]") and "[" in node:          # tests/x.py::test_y[env_id=PickCube-v1,obs_mode=rgb]: only these parameter values
+            node, _, flt = node[:-1].partition("[")
+            sel = dict(kv.split("=", 1) for kv in flt.split(","))
         path, _, func = node.partition("::")
         mod = importlib.import_module(path[:-3].replace("/", ".") if path.endswith(".py") else path.replace("/", "."))
         names = [func] if func else [n for n in dir(mod) if n.startswith("test_") and callable(getattr(mod, n))]
         for name in names:
             fn = getattr(mod, name)
             for kw in _cases(fn):
+                if any(str(kw.get(k)) != v for k, v in sel.items()):
+                    continue
                 ran += 1
                 label = f"{path}::{name}" + (f"[{'-'.join(str(v) for v in kw.values())}]" if kw else "")
                 try:

@@ -24,10 +24,23 @@ STATE_NODES = [
     "tests/test_gpu_envs.py::test_timelimits",
     "tests/test_gpu_envs.py::test_hidden_objs",
     "tests/test_sim_state.py::test_raw_sim_states",
+    "tests/test_sim_state.py::test_raw_heterogeneous_actor_sim_states",
     "tests/structs/test_pose.py",
     "tests/structs/test_actor.py",
     "tests/structs/test_link.py",
     "tests/structs/test_obs_mode_struct.py",
+]
+
+
+# camera observation modes of the reference's own suite (tests/test_gpu_envs.py:44-104 asserts cuda tensors: GPU only)
+GPU_ONLY_NODES = [
+    "tests/test_gpu_envs.py::test_envs_obs_modes[env_id=PickCube-v1,obs_mode=state_dict]",
+    "tests/test_gpu_envs.py::test_envs_obs_modes[env_id=PickCube-v1,obs_mode=state]",
+    "tests/test_gpu_envs.py::test_envs_obs_modes[env_id=PickCube-v1,obs_mode=rgb]",
+    "tests/test_gpu_envs.py::test_envs_obs_modes[env_id=PickCube-v1,obs_mode=rgb+depth+segmentation]",
+    "tests/test_gpu_envs.py::test_envs_obs_modes[env_id=PickCube-v1,obs_mode=depth+state]",
+    "tests/test_gpu_envs.py::test_envs_obs_modes[env_id=StackCube-v1,obs_mode=state]",
+    "tests/test_gpu_envs.py::test_envs_obs_modes[env_id=PegInsertionSide-v1,obs_mode=state]",
 ]
 
 
@@ -47,7 +60,7 @@ def test_reference_suite_on_cpu_checker(built, node):
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.parametrize("node", STATE_NODES)
+@pytest.mark.parametrize("node", STATE_NODES + GPU_ONLY_NODES)
 def test_reference_suite_on_hip(built, node):
     rc, out = run_reference_tests([node], "hip")
     assert rc == 0, out
