@@ -40,16 +40,107 @@ class _Handle3D:
 
 
 class _GatherQuery:
-    """A contact query whose listed rows are not the library's own order: gathered on demand."""
+    """A contact-impulse query: one engine query per structural group, the listed rows gathered on demand."""
 
-    def __init__(self, qid, engine_handle, index: Optional[torch.Tensor]):
-        self.id = qid
-        self._engine_handle = engine_handle
-        self._index = index
-        self.cuda_impulses = self if index is not None else engine_handle
+    def __init__(self, parts, direct_handle, nrows, device):
+        self._parts, self._direct = parts, direct_handle
+        self._out = None if direct_handle is not None else torch.zeros(nrows, 3, dtype=torch.float32, device=device)
+        self.cuda_impulses = direct_handle if direct_handle is not None else self
+
+    def _run(self):
+        for g, q, rows, idx in self._parts:
+            g.engine.gpu_query_contact_pair_impulses(q)
+            if rows is not None:
+                self._out[rows] = q.cuda_impulses.torch().index_select(0, idx)
 
     def torch(self):
-        return self._engine_handle.torch().index_select(0, self._index)
+        return self._out
+
+
+class _Group:
+    """Sub-scenes that share one scene template: one context of the C-ABI library."""
+
+    def __init__(self, envs, engine, template):
+        self.envs, self.engine, self.template = list(envs), engine, template
+        self.n, self.nb, self.na, self.max_dof = len(envs), engine.bodies_per_env, engine.arts_per_env, engine.max_dof
+        self.base = self.abase = 0        # first row of the group in the unified body / articulation buffers (_MultiBuffers)
+
+
+class _Tensor:
+    def __init__(self, t):
+        self._t = t
+
+    def torch(self):
+        return self._t
+
+
+class _MultiBuffers:
+    """Structurally different sub-scenes (other articulations, meshes, body counts per sub-scene: e.g. a different cabinet in every
+    sub-scene of OpenCabinetDrawer-v1, envs/tasks/mobile_manipulation/open_cabinet_drawer.py:128-177) run as one library context
+    per structural group.  ManiSkill still sees ONE ``cuda_rigid_body_data`` / ``cuda_articulation_*`` set: unified torch buffers in
+    which every group owns a contiguous row range (articulation rows padded to the largest dof count, as SAPIEN pads them);
+    ``gpu_fetch_*`` copies the groups' buffers in, ``gpu_apply_*`` copies them out before the group's own apply."""
+
+    BODY = ("rigid_body_data", "rigid_body_force", "rigid_body_torque")
+    ART = ("qpos", "qvel", "qacc", "qf", "target_qpos", "target_qvel")
+
+    def __init__(self, px, device):
+        self.px = px
+        gs = px._groups
+        rows = arows = 0
+        for g in gs:
+            g.base, g.abase = rows, arows
+            rows += g.n * g.nb
+            arows += g.n * max(g.na, 0)
+        self.max_dof = max(g.max_dof for g in gs)
+        self.max_links = 1
+        for g in gs:
+            lf = g.engine.cuda_articulation_link_incoming_joint_forces
+            self.max_links = max(self.max_links, lf.shape[0] // max(g.n * max(g.na, 1), 1))
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=device)   # noqa: E731
+        self.t = dict(rigid_body_data=z(rows, 13), rigid_body_force=z(rows, 4), rigid_body_torque=z(rows, 4),
+                      link_forces=z(max(arows, 1), self.max_links, 6))
+        for name in self.ART:
+            self.t[name] = z(max(arows, 1), max(self.max_dof, 1))
+        px.cuda_rigid_body_data = _Tensor(self.t["rigid_body_data"])
+        px.cuda_rigid_body_force = _Tensor(self.t["rigid_body_force"])
+        px.cuda_rigid_body_torque = _Tensor(self.t["rigid_body_torque"])
+        for name in self.ART:
+            setattr(px, "cuda_articulation_" + name, _Tensor(self.t[name]))
+        px.cuda_articulation_link_incoming_joint_forces = _Tensor(self.t["link_forces"])
+        self.fetch_all()
+
+    def _eng(self, g, name):
+        return getattr(g.engine, "cuda_" + name if name in self.BODY else "cuda_articulation_" + name).torch()
+
+    def pull(self, names):      # engine buffers -> unified
+        for g in self.px._groups:
+            for name in names:
+                if name in self.BODY:
+                    self.t[name][g.base:g.base + g.n * g.nb] = self._eng(g, name)
+                elif g.na > 0:
+                    self.t[name][g.abase:g.abase + g.n * g.na, :g.max_dof] = self._eng(g, name)
+
+    def push(self, names):      # unified -> engine buffers
+        for g in self.px._groups:
+            for name in names:
+                if name in self.BODY:
+                    self._eng(g, name).copy_(self.t[name][g.base:g.base + g.n * g.nb])
+                elif g.na > 0:
+                    self._eng(g, name).copy_(self.t[name][g.abase:g.abase + g.n * g.na, :g.max_dof])
+
+    def fetch_all(self):
+        for g in self.px._groups:
+            g.engine.gpu_fetch_all()
+        self.pull(("rigid_body_data",) + self.ART)
+
+    def pull_link_forces(self):
+        for g in self.px._groups:
+            if g.na == 0:
+                continue
+            g.engine.gpu_fetch_articulation_link_incoming_joint_forces()
+            lf = g.engine.cuda_articulation_link_incoming_joint_forces.torch().view(g.n * g.na, -1, 6)
+            self.t["link_forces"][g.abase:g.abase + g.n * g.na, :lf.shape[1]] = lf
 
 
 class PhysxSystem:
@@ -185,32 +276,38 @@ class PhysxSystem:
         return ("kinematic" if c.kinematic else "dynamic", tuple(c.locked_motion_axes)) + common
 
     def _compile(self):
-        """-> (SceneTemplate, per-env instance data); sets _body_id / _art_id on every component / articulation."""
-        from maniskill_amd import _native as N
-        from maniskill_amd.physx import SceneTemplate
-        P = self._P
+        """Partition the sub-scenes into structural groups (same bodies, joints, meshes, materials, collision groups; box sizes and
+        masses may differ inside a group) and compile one scene template per group.  -> list of (envs, SceneTemplate, instances)."""
         n_env = len(self._scenes)
         per_env = [[] for _ in range(n_env)]
         for c in self._components:
             per_env[c._env].append(c)
-        env0 = per_env[0]
+        self._per_env, self._n_env = per_env, n_env
+        groups, order = {}, []
+        for e in range(n_env):
+            key = tuple(self._comp_sig(c, True) for c in per_env[e])
+            if key not in groups:
+                groups[key] = []
+                order.append(key)
+            groups[key].append(e)
+        self._shape_owner_of_group = []
+        out = []
+        for gi, key in enumerate(order):
+            envs = groups[key]
+            tpl, inst = self._compile_group(envs, gi)
+            out.append((envs, tpl, inst))
+        return out
 
-        # ---- homogeneity check ------------------------------------------------------------------------------------
+    def _compile_group(self, envs, gi):
+        """-> (SceneTemplate, per-env instance data) of the sub-scenes `envs`; sets _body_id / _art_id / _group / _lenv."""
+        from maniskill_amd import _native as N
+        from maniskill_amd.physx import SceneTemplate
+        P = self._P
+        per_env = [self._per_env[e] for e in envs]
+        n_env = len(envs)
+        env0 = per_env[0]
         sig0 = tuple(self._comp_sig(c, False) for c in env0)
-        hetero = []
-        for e in range(1, n_env):
-            comps = per_env[e]
-            if len(comps) != len(env0) or tuple(self._comp_sig(c, False) for c in comps) != sig0:
-                hetero.append(e)
-        if hetero:
-            rel0 = tuple(self._comp_sig(c, True) for c in env0)
-            for e in hetero:
-                comps = per_env[e]
-                if len(comps) != len(env0) or tuple(self._comp_sig(c, True) for c in comps) != rel0:
-                    raise RuntimeError(
-                        f"sub-scene {e} differs structurally from sub-scene 0 (other bodies, joints, meshes, materials or collision "
-                        "groups): this backend simulates one scene template with per-sub-scene box sizes and masses; fully "
-                        "heterogeneous sub-scenes are not supported yet")
+        hetero = [e for e in range(1, n_env) if tuple(self._comp_sig(c, False) for c in per_env[e]) != sig0]
 
         # ---- global planes (a plane on a static actor of ANY sub-scene is one infinite plane of the whole PhysX scene;
         #      the reference therefore attaches it in the first sub-scene only, actor_builder.py:76-90) ---------------------
@@ -233,7 +330,8 @@ class PhysxSystem:
                 o = self._offsets.get(id(sc), np.zeros(3))
                 if abs(float(np.dot(n, o - off))) > 1e-4:
                     raise RuntimeError("a static plane is not parallel to the sub-scene grid: cannot be shared by all sub-scenes")
-        self._shape_owner = []       # template shape index -> the PhysxCollisionShape of sub-scene 0 (or the global plane) behind it
+        self._shape_owner = []       # template shape index -> the PhysxCollisionShape of the group's first sub-scene (or the global plane)
+        self._shape_owner_of_group.append(self._shape_owner)
         placed_planes = set()
 
         def add_plane(key):
@@ -381,10 +479,19 @@ class PhysxSystem:
         for e in range(n_env):
             for k, c in enumerate(per_env[e]):
                 c._body_id = body_ids[id(env0[k])]
+                c._group, c._lenv = gi, e
                 if isinstance(c, P.PhysxArticulationLinkComponent):
-                    c.articulation._art_id = art_ids[id(env0[k].articulation)]
-        self._per_env = per_env
-        self._n_env = n_env
+                    art = c.articulation
+                    art._art_id = art_ids[id(env0[k].articulation)]
+                    art._group, art._lenv = gi, e
+        self._env_box_shapes_of_group = getattr(self, "_env_box_shapes_of_group", {})
+        boxes = {}
+        for c0 in env0:
+            for s0 in c0.collision_shapes:
+                sid = shape_ids.get(id(s0))
+                if sid is not None and sid in inst["boxes"]:
+                    boxes.setdefault(body_ids[id(c0)], []).append((sid, np.asarray(s0._half, dtype=np.float32)))
+        self._env_box_shapes_of_group[gi] = boxes
         return tpl, inst
 
     # =============================================================================================================
@@ -392,7 +499,7 @@ class PhysxSystem:
     # =============================================================================================================
     def _start_engine(self, torch_device, lib, host_memory):
         from maniskill_amd import physx as E
-        tpl, inst = self._compile()
+        compiled = self._compile()
         sc, bc, shc = self._cfg["scene"], self._cfg["body"], self._cfg["shape"]
         cfg = E.SimConfig(sim_freq=1.0 / self._timestep, control_freq=1.0 / self._timestep, scene_config=E.SceneConfig(
             gravity=[float(g) for g in sc["gravity"]], bounce_threshold=sc["bounce_threshold"], sleep_threshold=bc["sleep_threshold"],
@@ -402,40 +509,55 @@ class PhysxSystem:
         cls = E.PhysxGpuSystem
         if host_memory:
             cls = type("HostMemorySystem", (E.PhysxGpuSystem,), dict(host_memory=True))
-        eng = cls(torch_device, tpl, self._n_env, cfg, lib=lib)
-        eng.gpu_init()
-        for sid, (hs, lp) in inst["boxes"].items():
-            eng.set_env_boxes(sid, hs, lp)
-        for bid, (m, I) in inst["masses"].items():
-            eng.set_env_masses(bid, m, I)
-        self._engine, self._template = eng, tpl
-        self._nb, self._na, self._max_dof = eng.bodies_per_env, eng.arts_per_env, eng.max_dof
-        self.cuda_rigid_body_data = eng.cuda_rigid_body_data
-        self.cuda_rigid_body_force = eng.cuda_rigid_body_force
-        self.cuda_rigid_body_torque = eng.cuda_rigid_body_torque
-        self.cuda_articulation_qpos = eng.cuda_articulation_qpos
-        self.cuda_articulation_qvel = eng.cuda_articulation_qvel
-        self.cuda_articulation_qacc = eng.cuda_articulation_qacc
-        self.cuda_articulation_qf = eng.cuda_articulation_qf
-        self.cuda_articulation_target_qpos = eng.cuda_articulation_target_qpos
-        self.cuda_articulation_target_qvel = eng.cuda_articulation_target_qvel
-        lf = eng.cuda_articulation_link_incoming_joint_forces
-        rows = self._n_env * max(self._na, 1)
-        self.cuda_articulation_link_incoming_joint_forces = _Handle3D(lf, (rows, max(lf.shape[0] // max(rows, 1), 1), 6))
+        self._groups = []
+        for envs, tpl, inst in compiled:
+            eng = cls(torch_device, tpl, len(envs), cfg, lib=lib)
+            eng.gpu_init()
+            for sid, (hs, lp) in inst["boxes"].items():
+                eng.set_env_boxes(sid, hs, lp)
+            for bid, (m, I) in inst["masses"].items():
+                eng.set_env_masses(bid, m, I)
+            self._groups.append(_Group(envs, eng, tpl))
+        g0 = self._groups[0]
+        self._engine, self._template = g0.engine, g0.template      # single-group scenes: the zero-copy fast path
+        self._nb, self._na, self._max_dof = g0.nb, g0.na, g0.max_dof
+        self._env_box_shapes = self._env_box_shapes_of_group.get(0, {})
+        if len(self._groups) == 1:
+            eng = g0.engine
+            self._multi = None
+            self.cuda_rigid_body_data = eng.cuda_rigid_body_data
+            self.cuda_rigid_body_force = eng.cuda_rigid_body_force
+            self.cuda_rigid_body_torque = eng.cuda_rigid_body_torque
+            self.cuda_articulation_qpos = eng.cuda_articulation_qpos
+            self.cuda_articulation_qvel = eng.cuda_articulation_qvel
+            self.cuda_articulation_qacc = eng.cuda_articulation_qacc
+            self.cuda_articulation_qf = eng.cuda_articulation_qf
+            self.cuda_articulation_target_qpos = eng.cuda_articulation_target_qpos
+            self.cuda_articulation_target_qvel = eng.cuda_articulation_target_qvel
+            lf = eng.cuda_articulation_link_incoming_joint_forces
+            rows = g0.n * max(g0.na, 1)
+            self.cuda_articulation_link_incoming_joint_forces = _Handle3D(lf, (rows, max(lf.shape[0] // max(rows, 1), 1), 6))
+        else:
+            self._multi = _MultiBuffers(self, torch_device)
         self._initialized = True
 
     # indices ------------------------------------------------------------------------------------------------------------
     def _pose_index(self, comp) -> int:
         if comp._body_id < 0:
             raise RuntimeError("static bodies have no row in cuda_rigid_body_data")
-        return comp._env * self._nb + comp._body_id
+        g = self._groups[comp._group]
+        return g.base + comp._lenv * g.nb + comp._body_id
 
     def _art_index(self, art) -> int:
-        return art._env * self._na + art._art_id
+        g = self._groups[art._group]
+        return g.abase + art._lenv * g.na + art._art_id
 
     # CPU-style accessors (synchronous; off the hot path) ---------------------------------------------------------------
     def _sync_in(self):
-        self._engine._fetch(_SYNC_FETCH)
+        if self._multi is not None:
+            self._multi.fetch_all()
+        else:
+            self._engine._fetch(_SYNC_FETCH)
 
     def _read_body_row(self, comp):
         self._sync_in()
@@ -457,16 +579,16 @@ class PhysxSystem:
         if isinstance(comp, P.PhysxArticulationLinkComponent):
             if not comp.is_root:
                 raise RuntimeError("only the root link of an articulation can be moved")
-            self._engine.gpu_apply_articulation_root_pose()
-            self._engine.gpu_update_articulation_kinematics()
+            self._do("apply", "gpu_apply_articulation_root_pose", ("rigid_body_data",))
+            self._do("call", "gpu_update_articulation_kinematics")
         else:
-            self._engine.gpu_apply_rigid_dynamic_data()
+            self._do("apply", "gpu_apply_rigid_dynamic_data", ("rigid_body_data",))
 
     def _write_body_cols(self, comp, col0, vals):
         self._sync_in()
         row = self.cuda_rigid_body_data.torch()[self._pose_index(comp)]
         row[col0:col0 + 3] = torch.as_tensor(vals.reshape(3), device=row.device)
-        self._engine.gpu_apply_rigid_dynamic_data()
+        self._do("apply", "gpu_apply_rigid_dynamic_data", ("rigid_body_data",))
 
     def _art_buf(self, name):
         return getattr(self, "cuda_articulation_" + name).torch()
@@ -479,11 +601,11 @@ class PhysxSystem:
         self._sync_in()
         buf = self._art_buf(name)
         buf[self._art_index(art), :art.dof] = torch.as_tensor(v, device=buf.device)
-        getattr(self._engine, {"qpos": "gpu_apply_articulation_qpos", "qvel": "gpu_apply_articulation_qvel",
-                               "qf": "gpu_apply_articulation_qf", "target_qpos": "gpu_apply_articulation_target_position",
-                               "target_qvel": "gpu_apply_articulation_target_velocity"}[name])()
+        self._do("apply", {"qpos": "gpu_apply_articulation_qpos", "qvel": "gpu_apply_articulation_qvel",
+                           "qf": "gpu_apply_articulation_qf", "target_qpos": "gpu_apply_articulation_target_position",
+                           "target_qvel": "gpu_apply_articulation_target_velocity"}[name], (name,))
         if name == "qpos":
-            self._engine.gpu_update_articulation_kinematics()
+            self._do("call", "gpu_update_articulation_kinematics")
 
     def _dof_index(self, art, joint):
         return art.active_joints.index(joint)
@@ -497,7 +619,10 @@ class PhysxSystem:
         self._write_art_vec(art, name, vec)
 
     def _read_link_joint_forces(self, art):
-        self._engine.gpu_fetch_articulation_link_incoming_joint_forces()
+        if self._multi is not None:
+            self._multi.pull_link_forces()
+        else:
+            self._engine.gpu_fetch_articulation_link_incoming_joint_forces()
         t = self.cuda_articulation_link_incoming_joint_forces.torch()
         return t[self._art_index(art), :len(art.links)].detach().cpu().numpy().copy()
 
@@ -507,8 +632,8 @@ class PhysxSystem:
         i = self._pose_index(comp)
         F[i, :3] += torch.as_tensor(force, device=F.device)
         T[i, :3] += torch.as_tensor(torque, device=T.device)
-        self._engine.gpu_apply_rigid_dynamic_force()
-        self._engine.gpu_apply_rigid_dynamic_torque()
+        self._do("apply", "gpu_apply_rigid_dynamic_force", ("rigid_body_force",))
+        self._do("apply", "gpu_apply_rigid_dynamic_torque", ("rigid_body_torque",))
 
     def _add_force_at_point(self, comp, force, point):
         pose = self._read_body_pose(comp)
@@ -519,8 +644,21 @@ class PhysxSystem:
         raise RuntimeError("drive properties cannot be changed after the simulation was initialised (choose the control mode at "
                            "construction)")
 
+    def _do(self, kind, method, names=()):
+        """One boundary call on every group: 'apply' copies the unified rows out first, 'fetch' copies the groups' rows in after."""
+        if self._multi is None:
+            getattr(self._engine, method)()
+            return
+        if kind == "apply":
+            self._multi.push(names)
+        for g in self._groups:
+            getattr(g.engine, method)()
+        if kind == "fetch":
+            self._multi.pull(names)
+
     def step(self):
-        self._engine.step()
+        for g in self._groups:
+            g.engine.step()
 
 
 class PhysxGpuSystem(PhysxSystem):
@@ -551,26 +689,31 @@ class PhysxGpuSystem(PhysxSystem):
         self._start_engine(self._torch_device(), lib, host)
 
     # apply / fetch ------------------------------------------------------------------------------------------------------
-    def gpu_apply_rigid_dynamic_data(self): self._engine.gpu_apply_rigid_dynamic_data()
-    def gpu_apply_rigid_dynamic_force(self): self._engine.gpu_apply_rigid_dynamic_force()
-    def gpu_apply_rigid_dynamic_torque(self): self._engine.gpu_apply_rigid_dynamic_torque()
-    def gpu_apply_articulation_root_pose(self): self._engine.gpu_apply_articulation_root_pose()
-    def gpu_apply_articulation_root_velocity(self): self._engine.gpu_apply_articulation_root_velocity()
-    def gpu_apply_articulation_qpos(self): self._engine.gpu_apply_articulation_qpos()
-    def gpu_apply_articulation_qvel(self): self._engine.gpu_apply_articulation_qvel()
-    def gpu_apply_articulation_qf(self): self._engine.gpu_apply_articulation_qf()
-    def gpu_apply_articulation_target_position(self): self._engine.gpu_apply_articulation_target_position()
-    def gpu_apply_articulation_target_velocity(self): self._engine.gpu_apply_articulation_target_velocity()
-    def gpu_fetch_rigid_dynamic_data(self): self._engine.gpu_fetch_rigid_dynamic_data()
-    def gpu_fetch_articulation_link_pose(self): self._engine.gpu_fetch_articulation_link_pose()
+    def gpu_apply_rigid_dynamic_data(self): self._do("apply", "gpu_apply_rigid_dynamic_data", ("rigid_body_data",))
+    def gpu_apply_rigid_dynamic_force(self): self._do("apply", "gpu_apply_rigid_dynamic_force", ("rigid_body_force",))
+    def gpu_apply_rigid_dynamic_torque(self): self._do("apply", "gpu_apply_rigid_dynamic_torque", ("rigid_body_torque",))
+    def gpu_apply_articulation_root_pose(self): self._do("apply", "gpu_apply_articulation_root_pose", ("rigid_body_data",))
+    def gpu_apply_articulation_root_velocity(self): self._do("apply", "gpu_apply_articulation_root_velocity", ())
+    def gpu_apply_articulation_qpos(self): self._do("apply", "gpu_apply_articulation_qpos", ("qpos",))
+    def gpu_apply_articulation_qvel(self): self._do("apply", "gpu_apply_articulation_qvel", ("qvel",))
+    def gpu_apply_articulation_qf(self): self._do("apply", "gpu_apply_articulation_qf", ("qf",))
+    def gpu_apply_articulation_target_position(self): self._do("apply", "gpu_apply_articulation_target_position", ("target_qpos",))
+    def gpu_apply_articulation_target_velocity(self): self._do("apply", "gpu_apply_articulation_target_velocity", ("target_qvel",))
+    def gpu_fetch_rigid_dynamic_data(self): self._do("fetch", "gpu_fetch_rigid_dynamic_data", ("rigid_body_data",))
+    def gpu_fetch_articulation_link_pose(self): self._do("fetch", "gpu_fetch_articulation_link_pose", ("rigid_body_data",))
     def gpu_fetch_articulation_link_velocity(self): pass   # same rows as link_pose: fetched together
-    def gpu_fetch_articulation_qpos(self): self._engine.gpu_fetch_articulation_qpos()
-    def gpu_fetch_articulation_qvel(self): self._engine.gpu_fetch_articulation_qvel()
-    def gpu_fetch_articulation_qacc(self): self._engine.gpu_fetch_articulation_qacc()
-    def gpu_fetch_articulation_target_qpos(self): self._engine.gpu_fetch_articulation_target_qpos()
+    def gpu_fetch_articulation_qpos(self): self._do("fetch", "gpu_fetch_articulation_qpos", ("qpos",))
+    def gpu_fetch_articulation_qvel(self): self._do("fetch", "gpu_fetch_articulation_qvel", ("qvel",))
+    def gpu_fetch_articulation_qacc(self): self._do("fetch", "gpu_fetch_articulation_qacc", ("qacc",))
+    def gpu_fetch_articulation_target_qpos(self): self._do("fetch", "gpu_fetch_articulation_target_qpos", ("target_qpos", "target_qvel"))
     def gpu_fetch_articulation_target_qvel(self): pass     # written together with target_qpos
-    def gpu_fetch_articulation_link_incoming_joint_forces(self): self._engine.gpu_fetch_articulation_link_incoming_joint_forces()
-    def gpu_update_articulation_kinematics(self): self._engine.gpu_update_articulation_kinematics()
+    def gpu_update_articulation_kinematics(self): self._do("call", "gpu_update_articulation_kinematics")
+
+    def gpu_fetch_articulation_link_incoming_joint_forces(self):
+        if self._multi is not None:
+            self._multi.pull_link_forces()
+        else:
+            self._engine.gpu_fetch_articulation_link_incoming_joint_forces()
 
     def sync_poses_gpu_to_cpu(self):
         self._sync_in()
@@ -581,44 +724,51 @@ class PhysxGpuSystem(PhysxSystem):
                 c.entity._pose = Pose(r[:3], r[3:7])
 
     # contact queries (envs/scene.py:741-801; utils/structs/base.py:116-136; articulation.py:447-462) ---------------------------
-    def _gather(self, listed_keys, listed_envs):
-        """listed row j asks for engine key listed_keys[j] in sub-scene listed_envs[j] -> (unique keys, index tensor or None)."""
-        uniq = []
-        pos = {}
-        for k in listed_keys:
-            if k not in pos:
-                pos[k] = len(uniq)
-                uniq.append(k)
-        U = len(uniq)
-        idx = np.array([e * U + pos[k] for k, e in zip(listed_keys, listed_envs)], dtype=np.int64)
-        identity = len(idx) == self._n_env * U and np.array_equal(idx, np.arange(len(idx)))
-        return uniq, (None if identity else idx)
+    def _make_query(self, keys, groups, lenvs, create):
+        """Listed row j asks for engine key keys[j] of local sub-scene lenvs[j] of group groups[j].  Per group: one engine query over
+        the group's unique keys; the listed rows are gathered from the engines' results (identity for the usual one-pair-per-env
+        list of a single-group scene: then the engine's own buffer is handed out)."""
+        parts = []
+        for gi, g in enumerate(self._groups):
+            rows = [j for j in range(len(keys)) if groups[j] == gi]
+            if not rows:
+                continue
+            uniq, pos = [], {}
+            for j in rows:
+                if keys[j] not in pos:
+                    pos[keys[j]] = len(uniq)
+                    uniq.append(keys[j])
+            U = len(uniq)
+            idx = np.array([lenvs[j] * U + pos[keys[j]] for j in rows], dtype=np.int64)
+            q = create(g.engine, uniq)
+            parts.append((g, q, np.asarray(rows, dtype=np.int64), idx))
+        dev = self.cuda_rigid_body_data.torch().device
+        if len(parts) == 1 and len(self._groups) == 1:
+            g, q, rows, idx = parts[0]
+            if len(idx) == g.n * (len(idx) // max(g.n, 1)) and np.array_equal(idx, np.arange(len(idx))) and np.array_equal(rows, np.arange(len(rows))):
+                return _GatherQuery([(g, q, None, None)], q.cuda_impulses, len(keys), dev)
+        return _GatherQuery([(g, q, torch.as_tensor(rows, device=dev), torch.as_tensor(idx, device=dev)) for g, q, rows, idx in parts],
+                            None, len(keys), dev)
 
     def gpu_create_contact_pair_impulse_query(self, body_pairs):
-        keys, envs = [], []
+        keys, groups, lenvs = [], [], []
         for a, b in body_pairs:
             if a._env != b._env:
                 raise RuntimeError("a contact pair must live in one sub-scene")
             keys.append((a._body_id, b._body_id))
-            envs.append(a._env)
-        uniq, idx = self._gather(keys, envs)
-        q = self._engine.gpu_create_contact_pair_impulse_query(uniq)
-        dev = q.cuda_impulses.torch().device
-        return _GatherQuery(q.id, q.cuda_impulses, None if idx is None else torch.as_tensor(idx, device=dev))
+            groups.append(a._group)
+            lenvs.append(a._lenv)
+        return self._make_query(keys, groups, lenvs, lambda eng, uniq: eng.gpu_create_contact_pair_impulse_query(uniq))
 
     def gpu_create_contact_body_impulse_query(self, bodies):
-        keys = [b._body_id for b in bodies]
-        envs = [b._env for b in bodies]
-        uniq, idx = self._gather(keys, envs)
-        q = self._engine.gpu_create_contact_body_impulse_query(uniq)
-        dev = q.cuda_impulses.torch().device
-        return _GatherQuery(q.id, q.cuda_impulses, None if idx is None else torch.as_tensor(idx, device=dev))
+        return self._make_query([b._body_id for b in bodies], [b._group for b in bodies], [b._lenv for b in bodies],
+                                lambda eng, uniq: eng.gpu_create_contact_body_impulse_query(uniq))
 
     def gpu_query_contact_pair_impulses(self, query):
-        self._engine.gpu_query_contact_pair_impulses(query)
+        query._run()
 
     def gpu_query_contact_body_impulses(self, query):
-        self._engine.gpu_query_contact_body_impulses(query)
+        query._run()
 
 
 class PhysxCpuSystem(PhysxSystem):
@@ -687,7 +837,7 @@ class PhysxCpuSystem(PhysxSystem):
         ids, vals = self._engine.get_contacts(0, 256)
         if len(ids) == 0:
             return []
-        owners = self._shape_owner
+        owners = self._shape_owner_of_group[0]
         by_pair = {}
         for (sa, sb, _), v in zip(ids, vals):
             by_pair.setdefault((int(sa), int(sb)), []).append(v)
