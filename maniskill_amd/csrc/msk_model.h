@@ -53,7 +53,7 @@ struct DModel {
   DShape shapes[MSK_MAX_SHAPES];
   DTendon tendons[MSK_MAX_TENDONS];
   DPair pairs[MSK_MAX_PAIRS];
-  v3 verts[MSK_MAX_SHAPES * 16]; /* hull vertex pool (<= 1024 vertices per template) */
+  v3 verts[MSK_MAX_SHAPES * 48]; /* hull vertex pool (<= 3072 vertices per template) */
   int nverts_total;
   EnvLayout lay;
   /* tree tables for the wave-per-env dynamics (msk_dynamics.h) */

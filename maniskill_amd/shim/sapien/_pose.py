@@ -148,7 +148,10 @@ def shortest_rotation(source, target):
     """sapien.math.shortest_rotation: quaternion (wxyz) of the smallest rotation taking direction `source` to `target`."""
     a = np.asarray(source, dtype=np.float64)
     b = np.asarray(target, dtype=np.float64)
-    a, b = a / np.linalg.norm(a), b / np.linalg.norm(b)
+    na, nb = np.linalg.norm(a), np.linalg.norm(b)
+    if na < 1e-12 or nb < 1e-12:          # no direction (the "0 0 0" axis of a fixed URDF joint): identity
+        return np.array([1.0, 0, 0, 0], dtype=np.float32)
+    a, b = a / na, b / nb
     d = float(np.dot(a, b))
     if d < -1.0 + 1e-9:       # opposite: any axis perpendicular to a
         axis = np.cross(a, [1.0, 0, 0])
