@@ -1,7 +1,8 @@
 /*
  * msk_dynamics.h — kinematics + articulation dynamics, one wavefront per env (gfx950, wave64).
  *
- * (two envs share a wavefront, 32 lanes each, when the template has <= 32 bodies and <= 15 dofs)
+ * (two envs share a wavefront, 32 lanes each, when the template has <= 32 bodies and <= 15 dofs; the per-lane rows of the
+ *  joint-space matrices are register arrays of MD = 16 entries then, of MD = 32 for up to 31 dofs with a wavefront per env)
  *
  *   lane i  <-> body i   link frames / velocities / RNEA, level-synchronous over the tree depth
  *                        (a lane reads its parent's pose, V, acc from LDS; parents gather the
@@ -31,16 +32,16 @@ MSK_DEV void dyn_sync() {
 /* dynamic LDS carve (floats) for a template with nb bodies */
 struct DynLds {
   int pose, S, V, acc, Ic, M, L, vec, total;
-  __host__ __device__ explicit DynLds(int nb) {
+  __host__ __device__ DynLds(int nb, int md) {
     int o = 0;
     pose = o; o += nb * 8;
     S = o; o += nb * 6;
     V = o; o += nb * 6;
     acc = o; o += nb * 6;            /* acc on the way down, f on the way back */
     Ic = o; o += nb * 10;
-    M = o; o += MSK_MAX_DOF * (MSK_MAX_DOF + 1);
-    L = o; o += MSK_MAX_DOF * (MSK_MAX_DOF + 1);
-    vec = o; o += 8 * MSK_MAX_DOF;   /* qd | bias | Kd | Dd | fconst | err | rhs | vfree */
+    M = o; o += md * (md + 1);
+    L = o; o += md * (md + 1);
+    vec = o; o += 8 * md;            /* qd | bias | Kd | Dd | fconst | err | rhs | vfree */
     total = o;
   }
 };
@@ -144,7 +145,7 @@ MSK_DEV void publish_body(const DModel* m, float* E, int i, const DBody* b, pose
 template <int LPE>
 __global__ void __launch_bounds__(64) k_kinematics(const DModel* __restrict__ m, DState st) {
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
-  const DynLds ly(m->nb);
+  const DynLds ly(m->nb, 0);
   const int sub = threadIdx.x / LPE, i = threadIdx.x % LPE;
   const int e_raw = blockIdx.x * (64 / LPE) + sub;
   const bool live = e_raw < m->N;
@@ -161,10 +162,10 @@ __global__ void __launch_bounds__(64) k_kinematics(const DModel* __restrict__ m,
   publish_body(m, E, i, b, T, V, comw);
 }
 
-template <int LPE>
+template <int LPE, int MD>   /* MD: capacity of the per-lane joint-space rows (16 or 32 dofs) */
 __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, DState st) {
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
-  const DynLds ly(m->nb);
+  const DynLds ly(m->nb, MD);
   const int sub = threadIdx.x / LPE, i = threadIdx.x % LPE;
   const int e_raw = blockIdx.x * (64 / LPE) + sub;
   const bool live = e_raw < m->N;      /* a surplus half-wave shadows the last env and stores nothing */
@@ -181,7 +182,7 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
   float* Lm = lds + ly.M;
   float* Ll = lds + ly.L;
   float* vec = lds + ly.vec;
-  const int LD = MSK_MAX_DOF + 1;
+  const int LD = MD + 1;
 
 #ifdef MSK_PROFILE_PHASES
   long long* dstamp = st.dbg + (size_t)m->N * 8 + 64 + (size_t)e * 8;
@@ -206,8 +207,8 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
     publish_body(m, E, i, b, T, V, comw);
   }
   /* zero M while the forward results settle */
-  for (int k = i; k < MSK_MAX_DOF * LD; k += LPE) Lm[k] = 0.0f;
-  if (i < nd) vec[DV_QD * MSK_MAX_DOF + i] = E[m->lay.qd + i];
+  for (int k = i; k < MD * LD; k += LPE) Lm[k] = 0.0f;
+  if (i < nd) vec[DV_QD * MD + i] = E[m->lay.qd + i];
   DPHASE();
   /* ---- 2. RNEA body forces, spatial inertias about the env origin ---------------------------------------- */
   if (link) {
@@ -273,7 +274,7 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
   /* ---- 4. bias torques and CRBA rows (lane = body with a dof) ------------------------------------------------ */
   if (link && b->dof >= 0) {
     const int di = b->dof;
-    vec[DV_BIAS * MSK_MAX_DOF + di] = sv6_dot(S, f);
+    vec[DV_BIAS * MD + di] = sv6_dot(S, f);
     const sv6 F = sinertia_mul(&Ic, S);
     Lm[di * LD + di] = sv6_dot(S, F) + b->armature;
     int j = b->parent;
@@ -289,10 +290,10 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
     float* sc = Senv + di * 8;   /* motion subspace column of coordinate di, for the row assembly */
     sc[0] = S.a.x; sc[1] = S.a.y; sc[2] = S.a.z; sc[3] = S.l.x; sc[4] = S.l.y; sc[5] = S.l.z;
     /* drive of this joint */
-    vec[DV_KD * MSK_MAX_DOF + di] = b->K;
-    vec[DV_DD * MSK_MAX_DOF + di] = b->D;
-    vec[DV_FC * MSK_MAX_DOF + di] = 0.0f;
-    vec[DV_ERR * MSK_MAX_DOF + di] = E[m->lay.q + di] - E[m->lay.qt + di];
+    vec[DV_KD * MD + di] = b->K;
+    vec[DV_DD * MD + di] = b->D;
+    vec[DV_FC * MD + di] = 0.0f;
+    vec[DV_ERR * MD + di] = E[m->lay.q + di] - E[m->lay.qt + di];
   }
   dyn_sync();
 
@@ -302,23 +303,23 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
   const float fmax_i = rowlane ? m->bodies[m->dof_body[i]].fmax : 0.0f;
   const float qdt_i = rowlane ? E[m->lay.qdt + i] : 0.0f;
   const float qf_i = rowlane ? E[m->lay.qf + i] : 0.0f;
-  const float bias_i = rowlane ? vec[DV_BIAS * MSK_MAX_DOF + i] : 0.0f;
-  float Kd = rowlane ? vec[DV_KD * MSK_MAX_DOF + i] : 0.0f, Dd = rowlane ? vec[DV_DD * MSK_MAX_DOF + i] : 0.0f;
-  float fconst = 0.0f, err = rowlane ? vec[DV_ERR * MSK_MAX_DOF + i] : 0.0f;
+  const float bias_i = rowlane ? vec[DV_BIAS * MD + i] : 0.0f;
+  float Kd = rowlane ? vec[DV_KD * MD + i] : 0.0f, Dd = rowlane ? vec[DV_DD * MD + i] : 0.0f;
+  float fconst = 0.0f, err = rowlane ? vec[DV_ERR * MD + i] : 0.0f;
   for (int pass = 0; pass < 2; ++pass) {
-    float Arow[MSK_MAX_DOF];
+    float Arow[MD];
     float rhs = 0.0f;
     if (rowlane) {
       float mv = 0.0f;
 #pragma unroll
-      for (int k = 0; k < MSK_MAX_DOF; ++k) {
+      for (int k = 0; k < MD; ++k) {
         const float mk = (k < nd) ? Lm[i * LD + k] : 0.0f;
         Arow[k] = mk;
-        if (k < nd) mv = fmaf(mk, vec[DV_QD * MSK_MAX_DOF + k], mv);
+        if (k < nd) mv = fmaf(mk, vec[DV_QD * MD + k], mv);
       }
       const float dadd = dt * fmaf(dt, Kd, Dd);
 #pragma unroll
-      for (int k = 0; k < MSK_MAX_DOF; ++k)
+      for (int k = 0; k < MD; ++k)
         if (k == i) Arow[k] += dadd;
       const float tau = qf_i - bias_i - Kd * err + Dd * qdt_i + fconst;
       rhs = fmaf(dt, tau, mv);
@@ -328,7 +329,7 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
         const float te = fmaf(tn->ca, E[m->lay.q + tn->dof_a], tn->cb * E[m->lay.q + tn->dof_b]) - tn->rest;
         if (i == tn->dof_a) {
 #pragma unroll
-          for (int k = 0; k < MSK_MAX_DOF; ++k) {
+          for (int k = 0; k < MD; ++k) {
             if (k == tn->dof_a) Arow[k] += g2 * tn->ca * tn->ca;
             if (k == tn->dof_b) Arow[k] += g2 * tn->ca * tn->cb;
           }
@@ -336,21 +337,21 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
         }
         if (i == tn->dof_b) {
 #pragma unroll
-          for (int k = 0; k < MSK_MAX_DOF; ++k) {
+          for (int k = 0; k < MD; ++k) {
             if (k == tn->dof_b) Arow[k] += g2 * tn->cb * tn->cb;
             if (k == tn->dof_a) Arow[k] += g2 * tn->ca * tn->cb;
           }
           rhs -= dt * tn->K * te * tn->cb;
         }
       }
-      vec[DV_RHS * MSK_MAX_DOF + i] = rhs;
+      vec[DV_RHS * MD + i] = rhs;
     }
     /* Cholesky A = L L^T, lane i owns row i; column j is finished at step j */
-    float Lrow[MSK_MAX_DOF];
+    float Lrow[MD];
 #pragma unroll
-    for (int k = 0; k < MSK_MAX_DOF; ++k) Lrow[k] = 0.0f;
+    for (int k = 0; k < MD; ++k) Lrow[k] = 0.0f;
 #pragma unroll
-    for (int j = 0; j < MSK_MAX_DOF; ++j) {
+    for (int j = 0; j < MD; ++j) {
       if (j < nd) {
         float sum = 0.0f;
         if (rowlane && i >= j) {
@@ -370,38 +371,38 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
         dyn_sync();
       }
     }
-    /* triangular solves: lane c < nd -> column c of A^-1, lane MSK_MAX_DOF -> vfree = A^-1 rhs */
-    const bool col = i < nd, vf = i == MSK_MAX_DOF;
-    float y[MSK_MAX_DOF], x[MSK_MAX_DOF];
+    /* triangular solves: lane c < nd -> column c of A^-1, lane MD -> vfree = A^-1 rhs */
+    const bool col = i < nd, vf = i == MD;
+    float y[MD], x[MD];
     if (col || vf) {
 #pragma unroll
-      for (int r = 0; r < MSK_MAX_DOF; ++r) {
+      for (int r = 0; r < MD; ++r) {
         y[r] = 0.0f;
         if (r < nd) {
-          float sum = vf ? vec[DV_RHS * MSK_MAX_DOF + r] : ((r == i) ? 1.0f : 0.0f);
+          float sum = vf ? vec[DV_RHS * MD + r] : ((r == i) ? 1.0f : 0.0f);
 #pragma unroll
           for (int k = 0; k < r; ++k) sum = fmaf(-Ll[r * LD + k], y[k], sum);
           y[r] = sum / Ll[r * LD + r];
         }
       }
 #pragma unroll
-      for (int r = MSK_MAX_DOF - 1; r >= 0; --r) {
+      for (int r = MD - 1; r >= 0; --r) {
         x[r] = 0.0f;
         if (r < nd) {
           float sum = y[r];
 #pragma unroll
-          for (int k = r + 1; k < MSK_MAX_DOF; ++k)
+          for (int k = r + 1; k < MD; ++k)
             if (k < nd) sum = fmaf(-Ll[k * LD + r], x[k], sum);
           x[r] = sum / Ll[r * LD + r];
         }
       }
       if (vf) {
 #pragma unroll
-        for (int r = 0; r < MSK_MAX_DOF; ++r)
-          if (r < nd) { vec[DV_VF * MSK_MAX_DOF + r] = x[r]; if (live) vfenv[r] = x[r]; }
+        for (int r = 0; r < MD; ++r)
+          if (r < nd) { vec[DV_VF * MD + r] = x[r]; if (live) vfenv[r] = x[r]; }
       } else if (live) {
 #pragma unroll
-        for (int r = 0; r < MSK_MAX_DOF; ++r)
+        for (int r = 0; r < MD; ++r)
           if (r < nd) Wenv[r * G + i] = x[r];
       }
     }
@@ -410,7 +411,7 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
     /* drive force limits: predict the PD force at v*, saturate where it exceeds the limit */
     bool sat = false;
     if (rowlane && !(Kd == 0.0f && Dd == 0.0f)) {
-      const float vfi = vec[DV_VF * MSK_MAX_DOF + i];
+      const float vfi = vec[DV_VF * MD + i];
       const float F = -Kd * fmaf(dt, vfi, err) - Dd * (vfi - qdt_i);
       if (fabsf(F) > fmax_i) {
         fconst = (F > 0.0f) ? fmax_i : -fmax_i;

@@ -19,18 +19,22 @@
 struct HostQuery { int npairs; int* d_pairs; float* d_out; };
 
 /* wave-per-env kernels: two envs share a wavefront when the template is small enough */
-static int lanes_per_env(const DModel& m) { return (m.nb <= 32 && m.nd < MSK_MAX_DOF) ? 32 : 64; }
+static int lanes_per_env(const DModel& m) { return (m.nb <= 32 && m.nd < 16) ? 32 : 64; }
+/* capacity of k_dynamics' per-lane joint-space rows: lane md computes the unconstrained velocity, so nd <= md (and md < lanes) */
+static int dyn_md(const DModel& m) { return m.nd <= 16 ? 16 : 32; }
 static void launch_kinematics(const DModel& m, const DModel* d_model, const DState& st, hipStream_t s) {
   const int lpe = lanes_per_env(m), epb = 64 / lpe;
-  const size_t lds = (size_t)DynLds(m.nb).total * sizeof(float) * epb;
+  const size_t lds = (size_t)DynLds(m.nb, 0).total * sizeof(float) * epb;
   if (lpe == 32) hipLaunchKernelGGL(k_kinematics<32>, dim3((m.N + 1) / 2), dim3(64), lds, s, d_model, st);
   else hipLaunchKernelGGL(k_kinematics<64>, dim3(m.N), dim3(64), lds, s, d_model, st);
 }
 static void launch_dynamics(const DModel& m, const DModel* d_model, const DState& st, hipStream_t s) {
   const int lpe = lanes_per_env(m), epb = 64 / lpe;
-  const size_t lds = (size_t)DynLds(m.nb).total * sizeof(float) * epb;
-  if (lpe == 32) hipLaunchKernelGGL(k_dynamics<32>, dim3((m.N + 1) / 2), dim3(64), lds, s, d_model, st);
-  else hipLaunchKernelGGL(k_dynamics<64>, dim3(m.N), dim3(64), lds, s, d_model, st);
+  const int md = dyn_md(m);
+  const size_t lds = (size_t)DynLds(m.nb, md).total * sizeof(float) * epb;
+  if (lpe == 32) hipLaunchKernelGGL((k_dynamics<32, 16>), dim3((m.N + 1) / 2), dim3(64), lds, s, d_model, st);
+  else if (md == 16) hipLaunchKernelGGL((k_dynamics<64, 16>), dim3(m.N), dim3(64), lds, s, d_model, st);
+  else hipLaunchKernelGGL((k_dynamics<64, 32>), dim3(m.N), dim3(64), lds, s, d_model, st);
 }
 
 struct msk_ctx {
@@ -203,7 +207,7 @@ MSK_API int msk_add_link(msk_ctx* c, int art, int parent_body, int joint_type, c
   } else {
     if (parent_body >= m.nb || m.bodies[parent_body].art != art) return fail(c, MSK_ERR_INVALID, "bad parent link");
     if (b->jtype != MSK_JOINT_FIXED) {
-      if (m.nd >= MSK_MAX_DOF) return fail(c, MSK_ERR_CAPACITY, "too many dofs");
+      if (m.nd >= MSK_MAX_DOF - 1) return fail(c, MSK_ERR_CAPACITY, "too many dofs (31 per sub-scene)");
       b->dof = m.nd++;
       c->art_ndof[art]++;
     }
@@ -457,8 +461,9 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   {
     EnvLayout& L = m.lay;
     int o = 0;
-    L.q = o; o += MSK_MAX_DOF; L.qd = o; o += MSK_MAX_DOF; L.qacc = o; o += MSK_MAX_DOF;
-    L.qf = o; o += MSK_MAX_DOF; L.qt = o; o += MSK_MAX_DOF; L.qdt = o; o += MSK_MAX_DOF;
+    const int dpad = m.nd <= 16 ? 16 : 32;   /* the six joint vectors: 16 floats each as long as that holds the template's dofs */
+    L.q = o; o += dpad; L.qd = o; o += dpad; L.qacc = o; o += dpad;
+    L.qf = o; o += dpad; L.qt = o; o += dpad; L.qdt = o; o += dpad;
     L.off = o; o += 4;
     L.bpose = o; o += m.nb * 8;
     L.blin = o; o += m.nb * 4; L.bang = o; o += m.nb * 4; L.comw = o; o += m.nb * 4;

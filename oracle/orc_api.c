@@ -86,7 +86,7 @@ ORC_EXPORT int orc_add_link(orc_ctx* c, int art, int parent_body, int joint_type
   } else {
     if (parent_body >= c->nb || c->bodies[parent_body].art != art) return fail(c, MSK_ERR_INVALID, "bad parent link");
     if (b->jtype != MSK_JOINT_FIXED) {
-      if (c->ndof >= MSK_MAX_DOF) return fail(c, MSK_ERR_CAPACITY, "too many dofs");
+      if (c->ndof >= MSK_MAX_DOF - 1) return fail(c, MSK_ERR_CAPACITY, "too many dofs (31 per sub-scene)");
       b->dof = c->ndof++;
       c->art_ndof[art]++;
     }
