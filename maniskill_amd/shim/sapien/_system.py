@@ -113,25 +113,31 @@ class _MultiBuffers:
     def _eng(self, g, name):
         return getattr(g.engine, "cuda_" + name if name in self.BODY else "cuda_articulation_" + name).torch()
 
-    def pull(self, names):      # engine buffers -> unified
+    def _pairs(self, names):
+        """(unified view, engine tensor) for every group and buffer name"""
+        uni, eng = [], []
         for g in self.px._groups:
             for name in names:
                 if name in self.BODY:
-                    self.t[name][g.base:g.base + g.n * g.nb] = self._eng(g, name)
+                    uni.append(self.t[name][g.base:g.base + g.n * g.nb])
+                    eng.append(self._eng(g, name))
                 elif g.na > 0:
-                    self.t[name][g.abase:g.abase + g.n * g.na, :g.max_dof] = self._eng(g, name)
+                    uni.append(self.t[name][g.abase:g.abase + g.n * g.na, :g.max_dof])
+                    eng.append(self._eng(g, name))
+        return uni, eng
+
+    def pull(self, names):      # engine buffers -> unified (one batched copy for all groups)
+        uni, eng = self._pairs(tuple(names))
+        if uni:
+            torch._foreach_copy_(uni, eng)
 
     def push(self, names):      # unified -> engine buffers
-        for g in self.px._groups:
-            for name in names:
-                if name in self.BODY:
-                    self._eng(g, name).copy_(self.t[name][g.base:g.base + g.n * g.nb])
-                elif g.na > 0:
-                    self._eng(g, name).copy_(self.t[name][g.abase:g.abase + g.n * g.na, :g.max_dof])
+        uni, eng = self._pairs(tuple(names))
+        if uni:
+            torch._foreach_copy_(eng, uni)
 
     def fetch_all(self):
-        for g in self.px._groups:
-            g.engine.gpu_fetch_all()
+        self.px._each_group("gpu_fetch_all")
         self.pull(("rigid_body_data",) + self.ART)
 
     def pull_link_forces(self):
@@ -651,14 +657,35 @@ class PhysxSystem:
             return
         if kind == "apply":
             self._multi.push(names)
-        for g in self._groups:
-            getattr(g.engine, method)()
+        self._each_group(method)
         if kind == "fetch":
             self._multi.pull(names)
 
+    def _each_group(self, method):
+        """The same call on every group's context.  On the GPU the groups' kernels are independent and small (a few dozen sub-scenes
+        each), so they are issued on a handful of side streams and overlap; the current stream forks before and joins after."""
+        gs = self._groups
+        dev = self.cuda_rigid_body_data.torch().device
+        if dev.type != "cuda" or len(gs) < 3:
+            for g in gs:
+                getattr(g.engine, method)()
+            return
+        if not hasattr(self, "_side_streams"):
+            self._side_streams = [torch.cuda.Stream(dev) for _ in range(min(8, len(gs)))]
+        main = torch.cuda.current_stream(dev)
+        for st in self._side_streams:
+            st.wait_stream(main)
+        for k, g in enumerate(gs):
+            with torch.cuda.stream(self._side_streams[k % len(self._side_streams)]):
+                getattr(g.engine, method)()
+        for st in self._side_streams:
+            main.wait_stream(st)
+
     def step(self):
-        for g in self._groups:
-            g.engine.step()
+        if self._multi is None:
+            self._engine.step()
+        else:
+            self._each_group("step")
 
 
 class PhysxGpuSystem(PhysxSystem):
