@@ -16,9 +16,16 @@ step (controller, 5 substeps, link frames, task kernel) is replayed as ONE captu
     python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Defaults follow the reference's protocol: 1000 steps after a seeded reset; the harness's second pass (a full reset every 200 steps,
+``gpu_sim.py:166-178``) is timed right after and reported as ``step_reset``.
+
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      dominant kernel of the substep, algorithmic bytes / HIP-event duration
-  cpu_baseline  the CPU oracle (oracle/liborc.so, OpenMP over envs) on a bounded sample, N=1 only
+  roofline        dominant kernel of the substep, algorithmic bytes / HIP-event duration; ``traffic`` = PMC bytes of that
+                  kernel from the rocprofv3 passes committed for this round (profiles/r02_pmc_counters_4096.json carries the commit it
+                  was taken at), ``substep_traffic`` the sum over the substep's kernels
+  step_reset      the same rollout with a full reset every 200 steps
+  cpu_baseline    the CPU oracle's physics loop (oracle/liborc.so orc_step, OpenMP over envs, no Python per env) on a bounded sample,
+                  N=1 only: kind "port" -- it is NOT PhysX
 """
 from __future__ import annotations
 
@@ -43,7 +50,8 @@ ALG_BYTES_PER_ENV_SUBSTEP = 3056.0
 
 
 def cpu_baseline(sample_envs: int, sample_steps: int):
-    """Times the CPU oracle (test infrastructure, 'port' of the same algorithm) on the host cores."""
+    """Times the CPU oracle's physics on the host cores: the same PickCube scene, ``sample_steps`` control steps' worth of substeps
+    through liborc's orc_step (one ctypes call per substep for ALL envs, OpenMP inside): physics only, no per-env Python."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_backend import OraclePhysxSystem
     from maniskill_amd.envs.pick_cube import PickCubeEnv
@@ -53,26 +61,30 @@ def cpu_baseline(sample_envs: int, sample_steps: int):
     env = PickCubeEnv(num_envs=sample_envs, px_factory=lambda tpl, n, cfg: OraclePhysxSystem(tpl, n, cfg))
     env.reset(seed=2022)
     gen = torch.Generator().manual_seed(0)
-    env.step(2 * torch.rand(sample_envs, 8, generator=gen) - 1)
-    t0 = time.perf_counter()
-    for _ in range(sample_steps):
+    for _ in range(3):     # a few control steps so that arms and cubes are in contact-rich states, targets set
         env.step(2 * torch.rand(sample_envs, 8, generator=gen) - 1)
+    sub = env._sim_steps_per_control
+    t0 = time.perf_counter()
+    for _ in range(sample_steps * sub):
+        env.px.step()
     dt = time.perf_counter() - t0
     env.close()
     return {
         "value": sample_envs * sample_steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-        "sample": f"{sample_envs} PickCube-v1 envs x {sample_steps} control steps (5 substeps each), "
-                  f"oracle/liborc.so scalar C, OpenMP over envs on {cores} host threads, {dt:.1f} s",
+        "sample": f"{sample_envs} PickCube-v1 envs x {sample_steps} control steps ({sub} physics substeps each, physics only: one orc_step "
+                  f"call per substep for all envs), oracle/liborc.so scalar C, OpenMP over envs on {cores} host threads, {dt:.1f} s; "
+                  "the in-repo CPU restatement, not PhysX",
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--envs", type=int, default=4096, help="total env count over all ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the step+reset pass (profiling runs)")
     ap.add_argument("--env", default="PickCube-v1", choices=["PickCube-v1", "PushT-v1", "PegInsertionSide-v1"],
                     help="PickCube-v1 (BASELINE.json's metric, default), PushT-v1 (its camera config) or "
                          "PegInsertionSide-v1 (its contact-rich config)")
@@ -145,6 +157,21 @@ def main():
         _gather.flush()
         sync()
         dt = time.perf_counter() - t0
+        # second pass of the reference's harness (gpu_sim.py:166-178): the same stepping with a full reset every 200 steps
+        dt_reset = None
+        if not args.no_extras and not args.reset_every:
+            n2 = min(args.steps, 400)
+            env.reset(seed=2022)
+            sync()
+            t1 = time.perf_counter()
+            for k in range(n2):
+                if k and k % 200 == 0:
+                    env.reset()
+                out = env.step(2 * torch.rand(n_local, env.action_dim, device=dev) - 1)
+                gather(*out[:4])
+            _gather.flush()
+            sync()
+            dt_reset = (time.perf_counter() - t1, n2)
         if args.graph:   # a graph replay records no events: time the kernels on eager steps of the same rollout
             env.disable_step_graph()
             env.px.timing_enable(20 * substeps)
@@ -164,10 +191,12 @@ def main():
             torch.cuda.synchronize(dev)
             cam_us = ev[0].elapsed_time(ev[1]) / 20 * 1e3
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, dt_reset[0] if dt_reset else 0.0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = float(t[0].item())
+    if dt_reset:
+        dt_reset = (float(t[1].item()), dt_reset[1])
 
     if rank == 0:
         dom = max(kernels, key=lambda k: kernels[k][0])
@@ -177,11 +206,14 @@ def main():
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         # HBM traffic of the dominant kernel: PMC FETCH_SIZE / WRITE_SIZE cannot be read from inside this process; the
         # value below comes from the committed rocprofv3 --pmc passes of this same command (profiles/, see its "source")
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_counters_4096.json")
+        traffic = substep_traffic = pmc_commit = None
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_counters_4096.json")
         if args.envs == 4096 and world == 1 and args.env == "PickCube-v1" and os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f)["substep_groups"].get(dom, {}).get("hbm_bytes_per_launch")
+                doc = json.load(f)
+            traffic = doc["substep_groups"].get(dom, {}).get("hbm_bytes_per_launch")
+            substep_traffic = sum(g["hbm_bytes_per_launch"] for k, g in doc["substep_groups"].items() if k in kernels)
+            pmc_commit = doc.get("commit")
         result = {
             "metric": f"env steps/sec (whole node), {args.envs} parallel {args.env} envs",
             "value": args.envs * args.steps / dt,
@@ -193,7 +225,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (uniform random actions in [-1,1], seed-2022 resets)",
-            "config": {"workload": f"{args.env}, num_envs={args.envs}, state obs, pd_joint_delta_pos, "
+            "config": {"workload": f"{args.env}, num_envs={args.envs}, {'state' if not camera_mode else args.obs_mode + ' camera'} obs, pd_joint_delta_pos, "
                                    f"sim 100 Hz / control {args.control_freq} Hz ({substeps} substeps, 15+1 TGS iterations)"
                                    + (f", full reset every {args.reset_every} steps" if args.reset_every else ""),
                        "envs_per_gpu": n_local, "parallelism": f"env-shard x{world}",
@@ -201,8 +233,9 @@ def main():
                                   "timed region") if args.graph else "eager launches; kernel_us from HIP events over the timed region"},
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_counters_4096.json (rocprofv3 --pmc, (2*FETCH_SIZE + WRITE_SIZE) KiB)" if traffic else None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "substep_traffic": substep_traffic,
+                "traffic_source": (f"profiles/r02_pmc_counters_4096.json (rocprofv3 --pmc passes of this command at commit {pmc_commit}, "
+                                   "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch)") if traffic else None,
                 "avg_kernel_us": avg_s * 1e6, "launches": launches,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_us": {k: v[0] / max(v[1], 1) * 1e3 for k, v in kernels.items()},
@@ -216,8 +249,11 @@ def main():
                                 "bound": "hbm", "algorithmic_bytes_per_frame": img_bytes,
                                 "achieved": img_bytes / (cam_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": img_bytes / (cam_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+        if dt_reset:
+            result["step_reset"] = {"value": args.envs * dt_reset[1] / dt_reset[0], "unit": "env-steps/s", "steps": dt_reset[1],
+                                    "ms_per_step": dt_reset[0] / dt_reset[1] * 1e3, "what": "full reset every 200 steps inside the timed region"}
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(4096, 25)   # the metric's own env count: 16 envs per host thread on a 256-thread box
+            result["cpu_baseline"] = cpu_baseline(4096, 20)   # the metric's own env count: 16 envs per host thread on a 256-thread box
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""env-steps/s of the REFERENCE'S OWN host Python (mani_skill's BaseEnv, controllers, structs, task code, unmodified) on this
+backend through the sapien shim -- the drop-in path, next to bench.py's number for the hand-written fused host.  Needs a reference
+build (a checkout, or oracle/_ref/maniskill from oracle/build_ref.py); prints one JSON line.
+
+    python tools/bench_reference_host.py [--env PickCube-v1] [--envs 4096] [--steps 200]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+import ref_harness  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--env", default="PickCube-v1")
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--obs-mode", default="state")
+    a = ap.parse_args()
+    if ref_harness.find_reference() is None:
+        print(json.dumps({"error": "no reference build present"}))
+        return
+    gym = ref_harness.setup("hip")
+    t0 = time.perf_counter()
+    kw = dict(render_backend="none") if a.obs_mode == "state" else {}
+    env = gym.make(a.env, num_envs=a.envs, obs_mode=a.obs_mode, **kw)
+    obs, _ = env.reset(seed=2022)
+    build_s = time.perf_counter() - t0
+    dev = env.unwrapped.device
+    torch.manual_seed(0)
+    with torch.inference_mode():
+        for _ in range(5):
+            env.step(2 * torch.rand(env.action_space.shape, device=dev) - 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            env.step(2 * torch.rand(env.action_space.shape, device=dev) - 1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print(json.dumps({"metric": f"env steps/sec, {a.envs} parallel {a.env} envs, reference host Python over the sapien shim", "value": a.envs * a.steps / dt,
+                      "unit": "env-steps/s", "ms_per_step": dt / a.steps * 1e3, "steps": a.steps, "obs_mode": a.obs_mode, "build_s": round(build_s, 1),
+                      "host": "mani_skill (unmodified): BaseEnv.step, controllers, structs, task evaluate / obs / reward as eager torch ops",
+                      "backend": "libmsk_physx.so (HIP, gfx950) through maniskill_amd/shim/sapien"}))
+
+
+if __name__ == "__main__":
+    main()

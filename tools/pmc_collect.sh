@@ -7,5 +7,5 @@ cd /tmp && export TMPDIR=/tmp
 OUT=${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/pmc
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/$ctr -- \
-    python ${GRAFT_REPO_ROOT:-/root/repo}/bench.py --steps 20 --warmup 40 --no-cpu-baseline "$@" > $OUT.$ctr.log 2>&1
+    python ${GRAFT_REPO_ROOT:-/root/repo}/bench.py --steps 20 --warmup 40 --no-cpu-baseline --no-extras "$@" > $OUT.$ctr.log 2>&1
 done

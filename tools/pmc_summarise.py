@@ -6,8 +6,9 @@ from collections import defaultdict
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "pmc")
-out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles", "r01_pmc_counters_4096.json")
-command = sys.argv[3] if len(sys.argv) > 3 else "python bench.py --steps 20 --warmup 40 --no-cpu-baseline"
+out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles", "r02_pmc_counters_4096.json")
+command = sys.argv[3] if len(sys.argv) > 3 else "python bench.py --steps 20 --warmup 40 --no-cpu-baseline --no-extras"
+commit = sys.argv[4] if len(sys.argv) > 4 else os.popen(f"git -C {root} rev-parse --short HEAD 2>/dev/null").read().strip()
 LAST = 100
 
 
@@ -39,6 +40,7 @@ for slot, names in slots.items():
     if present:
         groups[slot] = {"kernels": present, "hbm_bytes_per_launch": sum(kernels[n]["hbm_bytes_per_launch"] for n in present)}
 doc = {
+    "commit": commit,
     "source": f"rocprofv3 --pmc <counter> --kernel-trace -- {command} (tools/pmc_collect.sh: one pass per counter, MI355X); "
               f"mean over the last {LAST} launches of each kernel",
     "units": "FETCH_SIZE / WRITE_SIZE in KiB per launch as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE doubled "
