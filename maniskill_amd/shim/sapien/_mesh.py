@@ -168,11 +168,9 @@ def load_mesh_parts(path):
     elif ext == ".obj":
         parts = [dict(vertices=v, faces=f, base_color=[0.8, 0.8, 0.8, 1.0], name=os.path.basename(path)) for v, f in read_obj(path)]
     elif ext == ".glb":
+        # node transforms applied, nothing else: ManiSkill's GLB assets come out in their link frames that way (checked against the
+        # collision STLs of the same links: identical bounds), i.e. the files carry their own y-up -> z-up root rotation
         parts = read_glb(path)
-        # glTF is y-up; SAPIEN loads GLB through assimp into its z-up world: (x, y, z)_gltf -> (x, -z, y)
-        for p in parts:
-            v = p["vertices"]
-            p["vertices"] = np.stack([v[:, 0], -v[:, 2], v[:, 1]], axis=1)
     elif ext == ".dae":
         parts = read_dae(path)
     else:
@@ -322,6 +320,49 @@ def prism(radius, half_length, sides=16, axis=0):
     if axis != 0:
         v = np.roll(v, axis, axis=1)
     return np.round(v, 6).astype(np.float32)
+
+
+def cluster_simplify(verts, faces, max_tris):
+    """Vertex-clustering simplification of a triangle mesh to at most `max_tris` triangles: vertices are merged per cell of a
+    uniform grid (representative = the cell's mean), collapsed triangles dropped; the cell size is bisected to the finest grid that
+    meets the budget.  -> (vertices, faces, moved) where `moved` is the largest distance between an input vertex and the vertex
+    that replaces it: the measured error quoted for visual meshes that are too dense for the rasteriser's scene template
+    (SURVEY.md §7.2)."""
+    v = np.asarray(verts, dtype=np.float64)
+    f = np.asarray(faces, dtype=np.int64)
+    if len(f) <= max_tris:
+        return v, f, 0.0
+    lo, hi = v.min(0), v.max(0)
+    ext = float(np.max(hi - lo))
+
+    def at(cell):
+        key = np.floor((v - lo) / cell).astype(np.int64)
+        uniq, inv = np.unique(key, axis=0, return_inverse=True)
+        inv = inv.reshape(-1)
+        nf = inv[f]
+        keep = (nf[:, 0] != nf[:, 1]) & (nf[:, 1] != nf[:, 2]) & (nf[:, 0] != nf[:, 2])
+        nf = nf[keep]
+        if len(nf):
+            srt = np.sort(nf, axis=1)
+            _, first = np.unique(srt, axis=0, return_index=True)
+            nf = nf[np.sort(first)]
+        return uniq, inv, nf
+
+    a, b = ext / 512.0, ext            # too fine .. certainly coarse enough
+    for _ in range(18):
+        mid = 0.5 * (a + b)
+        if len(at(mid)[2]) <= max_tris:
+            b = mid
+        else:
+            a = mid
+    uniq, inv, nf = at(b)
+    cnt = np.bincount(inv, minlength=len(uniq)).astype(np.float64)
+    nv = np.stack([np.bincount(inv, weights=v[:, k], minlength=len(uniq)) / np.maximum(cnt, 1) for k in range(3)], axis=1)
+    used = np.unique(nf)
+    remap = -np.ones(len(uniq), dtype=np.int64)
+    remap[used] = np.arange(len(used))
+    moved = float(np.linalg.norm(v - nv[inv], axis=1).max())      # measured: the farthest any input vertex moved (<= cell diagonal)
+    return nv[used], remap[nf], moved
 
 
 # ------------------------------------------------------------------------------------------------ mass properties

@@ -282,9 +282,10 @@ class RenderShapeTriangleMesh(RenderShape):
         return out
 
 
-def _simplify(v, f):
+def _simplify(v, f, max_tris=256):
     """Dense mesh -> something the template holds: a planar sheet becomes the fan of its 2-D convex outline (both windings, as
-    sheets are drawn double sided), anything else its <= 64-vertex convex hull."""
+    sheets are drawn double sided, exact); anything else is simplified by vertex clustering to `max_tris` triangles (the surface
+    moves by at most the returned bound, recorded in RenderSystemGroup.simplification)."""
     from scipy.spatial import ConvexHull
     v = np.asarray(v, dtype=np.float64)
     c = v.mean(0)
@@ -296,8 +297,9 @@ def _simplify(v, f):
         pts = v[ring]
         fan = np.array([[0, k, k + 1] for k in range(1, len(ring) - 1)], dtype=np.int64)
         return pts, np.concatenate([fan, fan[:, ::-1]])
-    hv = _mesh.reduce_hull(v)
-    return hv, _mesh.hull_faces(hv)
+    nv, nf, bound = _mesh.cluster_simplify(v, f, max_tris)
+    _simplify.last_bound = bound
+    return nv, nf
 
 
 def _icosphere(subdiv):
@@ -676,7 +678,14 @@ class RenderSystemGroup:
         eng = self._engine
         L, ctx = eng.lib, eng.ctx
         rs0 = self.systems[0]
-        MAX_TRIS_PER_PART = 256
+        # triangle budget of the rasteriser's scene template (include/msk_render.h: 8192 triangles, 4096 vertices): parts above their
+        # share are simplified; the largest surface displacement is kept for the record
+        counts = [len(f) for rb in rs0.render_bodies for sh in rb.render_shapes for (_, f, _) in sh._triangles()]
+        KEEP = 400                                              # parts up to this size are drawn as they are (table.glb's four meshes)
+        small = sum(n for n in counts if n <= KEEP)
+        dense = sum(1 for n in counts if n > KEEP)
+        MAX_TRIS_PER_PART = KEEP if not dense else max(64, min(KEEP, (5200 - small) // dense))   # template: 8192 triangles, 4096 vertices
+        self.simplification = dict(parts=0, max_surface_error=0.0, tris_before=0, tris_after=0)
         declared = dict(getattr(self._px, "_env_box_shapes", {}))
         for rb in rs0.render_bodies:
             if rb.visibility <= 0:
@@ -694,11 +703,21 @@ class RenderSystemGroup:
                 for v, f, rgba in shape._triangles():
                     if follows is not None:
                         v = v / np.maximum(shape.half_size.astype(np.float64), 1e-12)
-                    if len(f) > MAX_TRIS_PER_PART:
+                    if len(v) > len(f):     # exporters write three vertices per triangle: weld identical positions (exact)
+                        uq, inv = np.unique(np.round(np.asarray(v, dtype=np.float64), 7), axis=0, return_inverse=True)
+                        v, f = uq, inv.reshape(-1)[np.asarray(f, dtype=np.int64)]
+                    if len(f) > KEEP:
                         # the rasteriser's template is small (include/msk_render.h capacities): dense visual meshes are drawn as
                         # their <= 64-vertex hull until the micro-triangle path exists; flat sheets (the ground grid,
                         # building/ground.py:46-119: 20 000 coplanar triangles) as their outline polygon, which is exact
-                        v, f = _simplify(v, f)
+                        n0 = len(f)
+                        _simplify.last_bound = 0.0
+                        v, f = _simplify(v, f, MAX_TRIS_PER_PART)
+                        sm = self.simplification
+                        sm["parts"] += 1
+                        sm["max_surface_error"] = max(sm["max_surface_error"], _simplify.last_bound)
+                        sm["tris_before"] += n0
+                        sm["tris_after"] += len(f)
                     v32 = np.ascontiguousarray(v, dtype=np.float32)
                     f32 = np.ascontiguousarray(f, dtype=np.int32)
                     rsid = L.render_add_mesh(ctx, int(body), N._fa(list(lp._p) + list(lp._q), 7), v32.ctypes.data_as(C.POINTER(C.c_float)),
