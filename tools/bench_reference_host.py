@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--obs-mode", default="state")
+    ap.add_argument("--cprofile", type=int, default=0, help="print the N most expensive host functions (cumulative) of the timed loop to stderr")
     a = ap.parse_args()
     if ref_harness.find_reference() is None:
         print(json.dumps({"error": "no reference build present"}))
@@ -40,11 +41,21 @@ def main():
         for _ in range(5):
             env.step(2 * torch.rand(env.action_space.shape, device=dev) - 1)
         torch.cuda.synchronize()
+        prof = None
+        if a.cprofile:
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             env.step(2 * torch.rand(env.action_space.shape, device=dev) - 1)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(a.cprofile)
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(a.cprofile // 2)
     print(json.dumps({"metric": f"env steps/sec, {a.envs} parallel {a.env} envs, reference host Python over the sapien shim", "value": a.envs * a.steps / dt,
                       "unit": "env-steps/s", "ms_per_step": dt / a.steps * 1e3, "steps": a.steps, "obs_mode": a.obs_mode, "build_s": round(build_s, 1),
                       "host": "mani_skill (unmodified): BaseEnv.step, controllers, structs, task evaluate / obs / reward as eager torch ops",
