@@ -23,6 +23,7 @@
 #define MSK_DYNAMICS_H
 
 #include "msk_model.h"
+#include "msk_broadphase.h"
 
 MSK_DEV void dyn_sync() {
   asm volatile("" ::: "memory");
@@ -472,6 +473,21 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
   }
   DPHASE();
 #undef DPHASE
+  /* ---- broadphase of this block's envs (msk_broadphase.h), the whole wavefront on one env at a time.  It reads the body poses
+   * in the env record (this kernel rewrites the link frames with the bits they already hold) and nothing else of the above. */
+  if (m->np > 0) {
+    __shared__ float bp_aabb[MSK_MAX_SHAPES][6];
+    __shared__ float bp_obb[MSK_MAX_SHAPES][13];   /* rotation columns (9), local half extents (3); odd stride: no bank conflicts */
+    if (blockIdx.x == 0 && threadIdx.x < MSK_SOLVE_CLASSES) st.cls_count[threadIdx.x] = 0;   /* this substep's solver lists (filled by the narrowphase) */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   /* the other half-wave's stores to its env record */
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll 1
+    for (int k = 0; k < 64 / LPE; ++k) {
+      const int eb = blockIdx.x * (64 / LPE) + k;
+      if (eb < m->N) broadphase_env(m, st, eb, bp_aabb, bp_obb);
+    }
+  }
 }
 
 #endif

@@ -2,8 +2,8 @@
  * msk_kernels.h — collision, layout-converter and query kernels of one physics substep (gfx950, wave64).
  *
  * Launches of a substep (N envs):
- *   k_dynamics    <<<N/2, 64>>>                half a wavefront per env, lane = body / dof / A^-1 column: msk_dynamics.h
- *   k_broadphase  <<<N, 64>>>                  one wavefront per env: shape AABBs and oriented boxes, pair culling, work lists
+ *   k_dynamics    <<<N/2, 64>>>                half a wavefront per env, lane = body / dof / A^-1 column: msk_dynamics.h; its tail is
+ *                                              the broadphase of the block's envs (msk_broadphase.h): AABBs, oriented boxes, pair culling, work lists
  *   k_narrowphase <<<(N/16, 1 + 1 + 4), 64>>>  per 16-env group: plane list, box-box list, four blocks sharing the hull list;
  *                                              the last block of a 64-env chunk sorts its envs into the solver lists
  *   k_csolve      <<<768 + N/4, 64>>>          constraint-space TGS, every capacity class in one launch: msk_solve.h
@@ -17,144 +17,14 @@
 #include "msk_collide.h"
 #include "msk_collide_lane.h"
 #include "msk_solve.h"
+#include "msk_broadphase.h"
 #include "msk_dynamics.h"
 
 #define MSK_WARM_DIST 5.0e-3f
 #define MSK_WARM_FACTOR 0.9f
 
-/* ---- collision -------------------------------------------------------------------------- */
-/* half sizes / local position of a shape as this env instantiates it (declared boxes: from the env record) */
-MSK_DEV v3 shape_half_dev(const DModel* m, const float* E, const DShape* sh) {
-  const int xs = m->xs_slot[sh - m->shapes];
-  if (xs < 0) return sh->aabb_h;
-  const float* x = E + m->lay.xshape + xs * 8;
-  return v3_make(x[0], x[1], x[2]);
-}
-MSK_DEV pose shape_pose_dev(const DModel* m, const float* E, const DShape* sh) {
-  pose L = sh->local;
-  const int xs = m->xs_slot[sh - m->shapes];
-  if (xs >= 0) { const float* x = E + m->lay.xshape + xs * 8; L.p = v3_make(x[4], x[5], x[6]); }
-  if (sh->body < 0) return L;
-  return pose_mul(load_pose(E, m->lay.bpose, sh->body), L);
-}
-MSK_DEV CShape cshape_env(const DModel* m, const float* E, const DShape* sh) {
-  CShape c = cshape_of(sh);
-  if (m->xs_slot[sh - m->shapes] >= 0) { const v3 h = shape_half_dev(m, E, sh); c.par[0] = h.x; c.par[1] = h.y; c.par[2] = h.z; }
-  return c;
-}
-
-/* Collision runs in two kernels.
- *   k_broadphase  one wavefront per env: lane s computes the world AABB and the oriented box of shape s (LDS), lane p
- *                 tests candidate pair p (AABBs; for hull pairs also the six face normals of the two oriented boxes);
- *                 survivors are appended to the env's three work lists (one per narrowphase type) by ballot rank — no
- *                 atomics, deterministic order —, culled pairs get their contact slot emptied.
- *   k_narrowphase contact generation + warm-start matching, see the comment at the kernel.
- * The cull tests are the oracle's, so the set of pairs that reach the narrowphase is identical. */
-enum { NP_PLANE = 0, NP_BOXBOX = 1, NP_GJK = 2, NP_TYPES = 3 };
-
-__global__ void __launch_bounds__(64) k_broadphase(const DModel* __restrict__ m, DState st) {
-  __shared__ float aabb[MSK_MAX_SHAPES][6];
-  __shared__ float obb[MSK_MAX_SHAPES][13];   /* rotation columns (9), local half extents (3); odd stride: no bank conflicts */
-  const int e = blockIdx.x, lane = threadIdx.x;
-  const float* E = EREC(st, m, e);
-  const float margin = 2.0f * m->cfg.contact_offset;
-  if (blockIdx.x == 0 && lane < MSK_SOLVE_CLASSES) st.cls_count[lane] = 0;   /* this substep's solver lists (filled by the narrowphase) */
-  if (lane < m->ns) {
-    const DShape* sh = &m->shapes[lane];
-    if (sh->type != MSK_SHAPE_PLANE) {
-      const pose T = shape_pose_dev(m, E, sh);
-      v3 c, h;
-      const v3 hl = shape_half_dev(m, E, sh);
-      world_aabb(sh->aabb_c, hl, &T, &c, &h);
-      aabb[lane][0] = c.x; aabb[lane][1] = c.y; aabb[lane][2] = c.z;
-      aabb[lane][3] = h.x; aabb[lane][4] = h.y; aabb[lane][5] = h.z;
-      const m33 R = quat_to_m33(T.q);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) { obb[lane][j * 3] = R.m[0][j]; obb[lane][j * 3 + 1] = R.m[1][j]; obb[lane][j * 3 + 2] = R.m[2][j]; }
-      obb[lane][9] = hl.x; obb[lane][10] = hl.y; obb[lane][11] = hl.z;
-    }
-  }
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  int* cnts = st.ct_cnt + (size_t)e * m->npp;
-  int base[NP_TYPES] = {0, 0, 0};
-  for (int p0 = 0; p0 < m->np; p0 += 64) {   /* uniform trip count: the ballots below need the whole wave */
-    const int pi = p0 + lane;
-    const bool valid = pi < m->np;
-    const int sa = m->pairs[valid ? pi : 0].sa, sb = m->pairs[valid ? pi : 0].sb;
-    const DShape* A = &m->shapes[sa];
-    const DShape* B = &m->shapes[sb];
-    bool keep = false;
-    int type;
-    if (A->type == MSK_SHAPE_PLANE || B->type == MSK_SHAPE_PLANE) {
-      type = NP_PLANE;
-      const int pa = A->type == MSK_SHAPE_PLANE;
-      const DShape* P = pa ? A : B;
-      const int sc = pa ? sb : sa;
-      if (m->shapes[sc].type != MSK_SHAPE_PLANE) {
-        const pose TP = shape_pose_dev(m, E, P);
-        const v3 cc = v3_make(aabb[sc][0], aabb[sc][1], aabb[sc][2]), ch = v3_make(aabb[sc][3], aabb[sc][4], aabb[sc][5]);
-        const v3 pn = quat_rotate(TP.q, v3_make(1, 0, 0));
-        const float lo = v3_dot(pn, cc) - v3_dot(pn, TP.p) - (fabsf(pn.x) * ch.x + fabsf(pn.y) * ch.y + fabsf(pn.z) * ch.z);
-        keep = valid && !(lo > margin);
-      }
-    } else {
-      type = (A->type == MSK_SHAPE_BOX && B->type == MSK_SHAPE_BOX) ? NP_BOXBOX : NP_GJK;
-      keep = valid && !(fabsf(aabb[sa][0] - aabb[sb][0]) > aabb[sa][3] + aabb[sb][3] + margin) &&
-             !(fabsf(aabb[sa][1] - aabb[sb][1]) > aabb[sa][4] + aabb[sb][4] + margin) &&
-             !(fabsf(aabb[sa][2] - aabb[sb][2]) > aabb[sa][5] + aabb[sb][5] + margin);
-      if (keep && type == NP_GJK) { /* second stage (oracle: obb_separated): the two oriented boxes along their six face normals */
-        const v3 d = v3_make(aabb[sa][0] - aabb[sb][0], aabb[sa][1] - aabb[sb][1], aabb[sa][2] - aabb[sb][2]);
-        v3 au[3], bu[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          au[j] = v3_make(obb[sa][j * 3], obb[sa][j * 3 + 1], obb[sa][j * 3 + 2]);
-          bu[j] = v3_make(obb[sb][j * 3], obb[sb][j * 3 + 1], obb[sb][j * 3 + 2]);
-        }
-        const float hax = obb[sa][9], hay = obb[sa][10], haz = obb[sa][11], hbx = obb[sb][9], hby = obb[sb][10], hbz = obb[sb][11];
-        bool sep = false;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          const v3 L = (k < 3) ? au[k] : bu[k - 3];
-          const float ra = fmaf(hax, fabsf(v3_dot(au[0], L)), fmaf(hay, fabsf(v3_dot(au[1], L)), haz * fabsf(v3_dot(au[2], L))));
-          const float rb = fmaf(hbx, fabsf(v3_dot(bu[0], L)), fmaf(hby, fabsf(v3_dot(bu[1], L)), hbz * fabsf(v3_dot(bu[2], L))));
-          if (fabsf(v3_dot(d, L)) > ra + rb + margin) sep = true;
-        }
-        keep = !sep;
-      }
-    }
-    /* append to this env's per-type list, in pair order (ballot ranks: no atomics, deterministic) */
-#pragma unroll
-    for (int t = 0; t < NP_TYPES; ++t) {
-      const unsigned long long mask = __ballot(keep && type == t);
-      if (keep && type == t) {
-        const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-        st.np_items[((size_t)e * NP_TYPES + t) * m->np + base[t] + rank] = pi;
-      }
-      base[t] += __popcll(mask);
-    }
-    if (!keep && pi < m->np && cnts[pi] != 0) cnts[pi] = 0;
-  }
-  if (lane < NP_TYPES) st.np_count[(size_t)e * 4 + lane] = (lane == 0) ? base[0] : ((lane == 1) ? base[1] : base[2]);
-}
-
 /* Solver capacity class of env e: constraint blocks = joints within MSK_LIMIT_DISTANCE of a limit + contact points
  * (the same count solve_env makes), against the per-template class capacities. */
-/* contact points of env e: its row of pair counts (npp ints, a multiple of 16, zero past np) summed with 16-byte loads, eight in
- * flight: a lane per env walks a strided row, so the number of dependent memory round trips is what costs */
-MSK_DEV int env_contact_total(const DModel* __restrict__ m, const DState& st, const int e) {
-  const int4* c4 = (const int4*)(st.ct_cnt + (size_t)e * m->npp);
-  const int n4 = m->npp >> 2;
-  int s0 = 0, s1 = 0;
-#pragma unroll 8
-  for (int i = 0; i < n4; ++i) {
-    const int4 v = c4[i];
-    s0 += v.x + v.y;
-    s1 += v.z + v.w;
-  }
-  return s0 + s1;
-}
-
 MSK_DEV int solver_class_of(const DModel* __restrict__ m, const DState& st, const int e, const int contacts) {
   const float* E = EREC(st, m, e);
   int nblk = 0;
@@ -170,7 +40,9 @@ MSK_DEV int solver_class_of(const DModel* __restrict__ m, const DState& st, cons
 MSK_DEV void classify_envs(const DModel* __restrict__ m, const DState& st, const int e0, const int n) {
   const int lane = threadIdx.x & 63;
   const bool mine = lane < n && e0 + lane < m->N;
-  const int cls = mine ? solver_class_of(m, st, e0 + lane, env_contact_total(m, st, e0 + lane)) : -1;
+  /* the contact total is kept current by device-scope atomics (narrowphase writers): an atomic load sees what every block of this
+   * launch has added before it signed off, without the L2 write-back / invalidate a fence across the XCDs would cost */
+  const int cls = mine ? solver_class_of(m, st, e0 + lane, __hip_atomic_load(&st.ct_total[e0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : -1;
 #pragma unroll
   for (int c = 0; c < MSK_SOLVE_CLASSES; ++c) {
     const unsigned long long mask = __ballot(cls == c);
@@ -194,13 +66,23 @@ __global__ void __launch_bounds__(64) k_classify(const DModel* __restrict__ m, D
  *   hull list (blockIdx.y = 2 ..): a 16-lane group per pair (msk_collide.h), four pairs in flight, four blocks sharing
  *     the group's list — few pairs, each a long chain of support scans over up to 64 vertices.
  * `group` = 16 at 4096 envs, fewer when there are few envs (then the launch is bound by its slowest wave). */
+/* number of plane / box-box blocks whose sign-off a 64-env chunk waits for */
+MSK_DEV int chunk_fixed_blocks(const DModel* __restrict__ m, const int chunk, const int group, const int per_group) {
+  const int first_blk = (chunk * 64 + group - 1) / group, end_env = min(chunk * 64 + 64, m->N);
+  return ((end_env + group - 1) / group - first_blk) * per_group;
+}
+
 template <int TYPE, int LPI>   /* LPI = lanes per item: 1 or NPG */
 MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, const int e0, const int group, const int part,
-                              const int nparts, int* pref, float* s_ws, float* s_we, const v3* verts) {
+                              const int nparts, int* pref, float* s_ws, float* s_we, const v3* verts, const int fixed_per_group) {
   constexpr int type = TYPE;
+  constexpr bool GLOBALQ = TYPE == NP_GJK;   /* hull items: one queue for the whole launch (part / nparts count over all hull blocks) */
   const int lane = threadIdx.x;
   const float margin = 2.0f * m->cfg.contact_offset;
-  { /* exclusive prefix of the group's list lengths: one load per lane, a 16-lane scan */
+  int count;
+  if constexpr (GLOBALQ) {
+    count = *st.hq_count;
+  } else { /* exclusive prefix of the group's list lengths: one load per lane, a 16-lane scan */
     int c = (lane < group && e0 + lane < m->N) ? st.np_count[(size_t)(e0 + lane) * 4 + type] : 0;
     int incl = c;
 #pragma unroll
@@ -210,18 +92,31 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
     }
     if (lane < NP_GROUP_MAX) pref[lane] = incl - c;
     if (lane == NP_GROUP_MAX - 1) pref[NP_GROUP_MAX] = incl;
+    __syncthreads();
+    count = pref[NP_GROUP_MAX];
   }
-  __syncthreads();
-  const int count = pref[NP_GROUP_MAX];
-  /* the group's list is dealt out pass by pass to the `nparts` blocks that share it (part = which one I am): the blocks
-   * stay balanced even when one env of the group owns most of the pairs (an arm lying on the table) */
+  /* the list is dealt out pass by pass to the `nparts` blocks that share it (part = which one I am): the blocks stay balanced
+   * even when one env owns most of the pairs (an arm lying on the table).  Uniform trip count: the sign-off below needs the wave. */
   constexpr int STEP = (LPI == 1) ? PL_LANES : 64 / LPI;   /* pairs per pass */
-  for (int idx = part * STEP + ((LPI == 1) ? (lane < PL_LANES ? lane : count) : lane / LPI); idx < count; idx += STEP * nparts) {
-  int j = 0;
+  for (int it = GLOBALQ ? 0 : part * STEP; it < count; it += STEP * nparts) {
+  /* hull queue: item i goes to block i % nparts, so up to nparts items get a wave each (no divergence between the four lane groups of
+   * a wave, no taking turns at the wave's EPA workspace) and only a longer queue doubles up */
+  const int idx = GLOBALQ ? it + (lane / LPI) * nparts + part : it + ((LPI == 1) ? (lane < PL_LANES ? lane : count) : lane / LPI);
+  const bool act = idx < count;
+  int e = 0;
+  if (act) do {
+  int pi;
+  if constexpr (GLOBALQ) {
+    const int item = st.hq_items[idx];
+    e = item / m->np;
+    pi = item - e * m->np;
+  } else {
+    int j = 0;
 #pragma unroll
-  for (int k = 1; k < NP_GROUP_MAX; ++k) j += (k < group && idx >= pref[k]) ? 1 : 0;
-  const int e = e0 + j;
-  const int pi = st.np_items[((size_t)e * NP_TYPES + type) * m->np + (idx - pref[j])];
+    for (int k = 1; k < NP_GROUP_MAX; ++k) j += (k < group && idx >= pref[k]) ? 1 : 0;
+    e = e0 + j;
+    pi = st.np_items[((size_t)e * NP_TYPES + type) * m->np + (idx - pref[j])];
+  }
   float* E = EREC(st, m, e);
   const DShape* dA = &m->shapes[m->pairs[pi].sa];
   const DShape* dB = &m->shapes[m->pairs[pi].sb];
@@ -304,7 +199,7 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
     if (n > 0) atomicAdd(&d[5], 1ull);
   }
 #endif
-  if (!writer) continue;
+  if (!writer) break;
   /* warm start from the previous contents of this pair's slot, then overwrite it */
   int* cntp = st.ct_cnt + (size_t)e * m->npp + pi;
   float* rec = st.ct_rec + ((size_t)e * m->npp + pi) * MSK_CT_REC;
@@ -319,8 +214,9 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
       for (int a = 0; a < 3; ++a) plam[jj][a] = rec[20 + jj * 3 + a];
     }
   }
-  if (n == 0 && nprev == 0) continue;
+  if (n == 0 && nprev == 0) break;
   *cntp = n;
+  if (n != nprev) atomicAdd(&st.ct_total[e], n - nprev);   /* device scope: read by whichever block classifies the env's chunk */
   if (n > 0) { rec[0] = onrm.x; rec[1] = onrm.y; rec[2] = onrm.z; }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -344,6 +240,22 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
 #pragma unroll
     for (int a = 0; a < 3; ++a) rec[20 + k * 3 + a] = lam[a];
   }
+  } while (0);
+  if constexpr (GLOBALQ) { /* sign the pass's items off with their chunks (see k_narrowphase); a wave may finish several chunks */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   /* the writer's atomic on the contact total has been performed */
+    const int chunk = e / 64;
+    const bool signer = act && (lane % LPI) == 0;
+    int old = -1;
+    if (signer) old = atomicAdd(&st.np_done[chunk], 1);
+    unsigned long long fin = __ballot(signer && old == chunk_fixed_blocks(m, chunk, group, fixed_per_group) - 1);
+    while (fin != 0ull) {
+      const int L = __ffsll((long long)fin) - 1;
+      fin &= fin - 1ull;
+      const int ch = __builtin_amdgcn_readlane(chunk, L);
+      if (lane == 0) st.np_done[ch] = 0;
+      classify_envs(m, st, ch * 64, 64);
+    }
+  }
   }
 }
 
@@ -351,7 +263,7 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
  * blocks of one kind share the group's list of that kind.
  * Per 64 consecutive envs, the block that finishes last sorts them into the solver lists (one wave, one env per lane:
  * a handful of same-address atomics per 64 envs). */
-struct NpCfg { int nplane, nbox, nhull, skip; };   /* skip: timing experiments only (bit 0 plane, 1 box-box, 2 hull lists not processed) */
+struct NpCfg { int nplane, nbox, nhull; };
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_narrowphase(const DModel* __restrict__ m, DState st, const int group, const NpCfg cfg) {
   __shared__ int pref[NP_GROUP_MAX + 1];
   /* one LDS image for both kinds of block: 32 lanes x 208 words of per-pair arrays (box-box), or four group workspaces
@@ -362,6 +274,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
   float* s_we = s_lds + (64 / NPG) * WS_TOTAL;
   const int e0 = blockIdx.x * group;
   int y = blockIdx.y;
+  const int fixed_per_group = cfg.nplane + cfg.nbox;
   const bool lane_kind = (y >= cfg.nplane) && (y - cfg.nplane < cfg.nbox);   /* box-box, one lane per pair: boxes only */
   /* plane and hull blocks scan hull vertices over and over (support points, features): the template's vertex pool (<= 12 KB) is
    * staged in the part of the LDS image that only the lane-per-pair kind uses, so every scan is an LDS read instead of an L2 hit */
@@ -375,20 +288,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
       verts = (const v3*)s_verts;
     }
   }
-  if (y < cfg.nplane) { if (!(cfg.skip & 1)) narrowphase_body<NP_PLANE, NPG>(m, st, e0, group, y, cfg.nplane, pref, s_ws, s_we, verts); }
-  else if ((y -= cfg.nplane) < cfg.nbox) {
-    if (!(cfg.skip & 2)) narrowphase_body<NP_BOXBOX, 1>(m, st, e0, group, y, cfg.nbox, pref, s_ws, s_we, verts);
+  if (y >= fixed_per_group) { /* hull blocks: the launch-wide queue; their items sign off one by one */
+    narrowphase_body<NP_GJK, NPG>(m, st, e0, group, (y - fixed_per_group) * (int)gridDim.x + (int)blockIdx.x, cfg.nhull * (int)gridDim.x, pref, s_ws, s_we,
+                                  verts, fixed_per_group);
+    return;
   }
-  else if (!(cfg.skip & 4)) narrowphase_body<NP_GJK, NPG>(m, st, e0, group, y - cfg.nbox, cfg.nhull, pref, s_ws, s_we, verts);
-  __threadfence();
+  if (y < cfg.nplane) narrowphase_body<NP_PLANE, NPG>(m, st, e0, group, y, cfg.nplane, pref, s_ws, s_we, verts, fixed_per_group);
+  else narrowphase_body<NP_BOXBOX, 1>(m, st, e0, group, y - cfg.nplane, cfg.nbox, pref, s_ws, s_we, verts, fixed_per_group);
+  /* Sign-off.  The only data of this launch the classifying wave reads are the contact totals, and those are device-scope
+   * atomics; so all that is needed is that this wave's atomics have been performed before its sign-off is (a wait on the
+   * memory counters: the workgroup-scope release), not __threadfence(): on this part an agent-scope fence writes back and
+   * invalidates the XCD's L2 (an empty launch of these 1536 blocks took 25 us with it, 4 us without: profiles/r02_np_floor.md).
+   * np_done[chunk] starts at minus the chunk's hull items (broadphase); plane / box-box blocks and hull items add one each. */
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   const int chunk = e0 / 64;
-  const int first_blk = (chunk * 64 + group - 1) / group, end_env = min(chunk * 64 + 64, m->N);
-  const int nblk_chunk = (end_env + group - 1) / group - first_blk;
   int done = 0;
   if (threadIdx.x == 0) done = atomicAdd(&st.np_done[chunk], 1);
   done = __builtin_amdgcn_readfirstlane(done);
-  if (done == nblk_chunk * (int)gridDim.y - 1) {
-    __threadfence();
+  if (done == chunk_fixed_blocks(m, chunk, group, fixed_per_group) - 1) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (threadIdx.x == 0) st.np_done[chunk] = 0;
     classify_envs(m, st, chunk * 64, 64);
   }
@@ -460,6 +378,7 @@ __global__ void __launch_bounds__(256) k_apply(const DModel* __restrict__ m, DSt
   if (teleported) { /* no warm start across a teleport: replays from a state are reproducible */
     int* cnts = st.ct_cnt + (size_t)e * m->npp;
     for (int p = 0; p < m->np; ++p) cnts[p] = 0;
+    st.ct_total[e] = 0;
   }
 }
 

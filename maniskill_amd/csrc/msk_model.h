@@ -95,15 +95,22 @@ struct DState {
   /* solver work lists by LDS capacity class (msk_solve.h): class 0 = packed small launch, 1..3 = one wave per env with
    * room for cls_cap[] blocks; built by the last narrowphase launch (classify_envs) */
   int *cls_list;                               /* [MSK_SOLVE_CLASSES][N] */
-  int *np_done;                                /* [N]: narrowphase blocks of an env group that have finished (self-resetting) */
-  int *cls_count;                              /* [MSK_SOLVE_CLASSES]; zeroed by k_broadphase of the same substep */
+  int *np_done;                                /* [N/64]: per 64-env chunk, sign-offs of the narrowphase: the broadphase subtracts the chunk's hull items, every
+                                                * plane / box-box block and every hull item adds one; whoever brings it to the number of plane / box-box
+                                                * blocks classifies the chunk and resets it */
+  int *cls_count;                              /* [MSK_SOLVE_CLASSES]; zeroed by k_dynamics (its broadphase tail) of the same substep */
   float *a_scratch;                            /* [solver workers][9 * 64 * 64]: A images of class-3 envs */
   /* narrowphase work lists per env and type (plane / box-box / GJK): surviving pair indices in pair order */
   int *np_count;                               /* [N][4] */
   int *np_items;                               /* [N][3][np] */
+  int *hq_items;                               /* [N * np] the launch's hull (GJK) items of ALL envs, env * np + pair: one queue, dealt out to the hull
+                                                * blocks of the narrowphase whatever env group they come from */
+  int *hq_count;                               /* [1] filled by the broadphase (atomics), zeroed by the solver launch */
   float *ext_wrench;                           /* [N][nb][8] external force (0..2) / torque (4..6) of the next step; consumed and cleared by k_dynamics */
   long long *dbg;                              /* [N][8] phase time stamps (MSK_PROFILE_PHASES builds only) */
   int *env_ncontacts;                          /* [N] */
+  int *ct_total;                               /* [N] sum of the env's ct_cnt row, kept in step with every write to it (device-scope atomics in the
+                                                * narrowphase): what the classification reads instead of the row */
   int *env_overflow;                           /* [1] */
 };
 

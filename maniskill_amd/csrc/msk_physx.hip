@@ -70,8 +70,6 @@ struct msk_ctx {
   PegTables peg_tb;
   bool has_peg = false;
   bool kin_dirty;        /* link frames in st.bpose are older than (q, qd): run k_kinematics before reading them */
-  hipStream_t side_stream = nullptr;   /* second branch of a captured substep (msk_step) */
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   PairSel pick_lsel, pick_rsel;   /* pickcube task: shape pairs finger <-> object */
   uint32_t groups[MSK_MAX_SHAPES][4]; /* collision groups: only the static pair filter needs them */
   float rest[MSK_MAX_SHAPES];         /* restitution per shape (pair value = average, DPairInfo::rest) */
@@ -158,7 +156,6 @@ MSK_API void msk_destroy(msk_ctx* c) {
   hipDeviceSynchronize();
   for (void* p : c->allocs) hipFree(p);
   for (hipEvent_t e : c->tev) hipEventDestroy(e);
-  if (c->side_stream) { hipStreamDestroy(c->side_stream); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
   delete c->rmodel;
   delete c;
 }
@@ -520,8 +517,9 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
     c->lds_solve = CsLds<32, 32, 32>::TOTAL * sizeof(float);
     HIP_TRY(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_solve));
   }
-  ALLOC(st.env_ncontacts, N); ALLOC(st.env_overflow, 1);
+  ALLOC(st.env_ncontacts, N); ALLOC(st.env_overflow, 1); ALLOC(st.ct_total, N);
   ALLOC(st.np_count, N * 4); ALLOC(st.np_items, N * NP_TYPES * (size_t)(m.np > 0 ? m.np : 1));
+  ALLOC(st.hq_items, N * (size_t)(m.np > 0 ? m.np : 1)); ALLOC(st.hq_count, 1);
   ALLOC(c->d_art_dof0, 8); ALLOC(c->d_art_ndof, 8);
   HIP_TRY(hipMemcpy(c->d_art_dof0, c->art_dof0, sizeof(int) * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->d_art_ndof, c->art_ndof, sizeof(int) * 8, hipMemcpyHostToDevice));
@@ -631,34 +629,12 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
   const bool timed = c->t_n < c->t_cap;
   hipEvent_t* ev = timed ? &c->tev[(size_t)c->t_n * (MSK_K_SLOTS + 1)] : nullptr;
   if (timed) hipEventRecord(ev[0], s);
-  /* k_dynamics (joint-space inertia, drives, unconstrained velocities) and the collision kernels are independent once the link frames
-   * of the current q are published, so a captured substep can run them as two branches of the graph: k_kinematics, then
-   * [k_dynamics | k_broadphase + k_narrowphase], then the solver (both kernels write the same bits to the link frames).
-   * Measured (4096 PickCube envs, graph replay, 1000 steps): 1.64 ms per control step with the branches, 1.58 ms without -- the
-   * extra k_kinematics per substep and the fork / join cost more than the 46 us of k_dynamics they hide.  Off unless MSK_OVERLAP=1. */
-  bool overlap = false;
-  {
-    static const int e_overlap = getenv("MSK_OVERLAP") ? atoi(getenv("MSK_OVERLAP")) : -1;
-    overlap = e_overlap > 0 && !timed && c->model.np > 0;
-  }
-  if (overlap) {
-    if (!c->side_stream) {
-      HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    }
-    /* always: a replayed graph cannot know whether the host changed q since the frames were last published */
-    launch_kinematics(c->model, c->d_model, c->st, s);
-    HIP_TRY(hipEventRecord(c->ev_fork, s));
-    HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-    launch_dynamics(c->model, c->d_model, c->st, c->side_stream);
-    HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
-  } else {
-    launch_dynamics(c->model, c->d_model, c->st, s);   /* consumes and clears pending external wrenches (data-driven, graph-safe) */
-  }
+  /* k_dynamics: joint-space inertia, drives, unconstrained velocities; consumes and clears pending external wrenches (data-driven,
+   * graph-safe); its tail is the broadphase of the same envs.  (Running it as a second branch of the captured graph next to the
+   * collision kernels was measured slower than the serial order: 1.64 against 1.58 ms per control step -- removed.) */
+  launch_dynamics(c->model, c->d_model, c->st, s);
   if (timed) hipEventRecord(ev[1], s);
   if (c->model.np > 0) {
-    hipLaunchKernelGGL(k_broadphase, dim3(N), dim3(64), 0, s, c->d_model, c->st);
     int group = N / 256;   /* ~256 x 6 waves whatever the env count */
     group = group < 1 ? 1 : (group > NP_GROUP_MAX ? NP_GROUP_MAX : group);
     while (group & (group - 1)) group &= group - 1;   /* a power of two: groups never straddle the 64-env classification chunks */
@@ -668,15 +644,12 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
     cfg.nplane = 1;
     cfg.nbox = e_nbox;
     cfg.nhull = e_nhull;
-    static const int e_skip = getenv("MSK_NP_SKIP") ? atoi(getenv("MSK_NP_SKIP")) : 0;
-    cfg.skip = e_skip;
     hipLaunchKernelGGL(k_narrowphase, dim3((N + group - 1) / group, cfg.nplane + cfg.nbox + cfg.nhull), dim3(64), 0, s, c->d_model,
                        c->st, group, cfg);
   } else {
     hipMemsetAsync(c->st.cls_count, 0, sizeof(int) * MSK_SOLVE_CLASSES, s);
     hipLaunchKernelGGL(k_classify, dim3(nblk), dim3(64), 0, s, c->d_model, c->st);
   }
-  if (overlap) HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
   if (timed) hipEventRecord(ev[2], s);
   {
     const int gm = c->solve_workers;

@@ -192,6 +192,10 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
     base += tot;
   }
   bool overflow = base > MSK_MAX_CONTACTS;
+  if (in_range && lane == 0) { /* the running total the classification read (msk_kernels.h) must be this row's sum; trimmed rows follow */
+    if (st.ct_total[e] != base) atomicOr(st.env_overflow, 4);
+    if (overflow) st.ct_total[e] = MSK_MAX_CONTACTS;
+  }
   int ncont = overflow ? MSK_MAX_CONTACTS : base;
   if (GL == 64 && nlim + ncont > LY::MAXBLK) { /* LDS image of the last class exhausted (NVP = 32 only): trailing points ignored */
     ncont = LY::MAXBLK - nlim;
@@ -569,6 +573,7 @@ __global__ void __launch_bounds__(64) k_csolve(const DModel* __restrict__ m, DSt
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(CsLds<NVP, GL, GL>::TOTAL == CsLds<NVP, 64, MSK_CLASS2_BLOCKS>::TOTAL, "one LDS size for both kinds of workgroup");
   static_assert(MSK_CLASS3_BLOCKS * 3 * NVP <= CsLds<NVP, 64, MSK_CLASS2_BLOCKS>::POOL, "Y of the largest env fits the pool");
+  if (blockIdx.x == 0 && threadIdx.x == 0) *st.hq_count = 0;   /* the narrowphase has consumed the hull queue; the next broadphase refills it */
   if ((int)blockIdx.x < gm) {
     const int n3 = st.cls_count[3], n2 = st.cls_count[2], n1 = st.cls_count[1];
     const size_t N = (size_t)m->N;
