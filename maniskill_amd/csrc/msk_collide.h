@@ -58,7 +58,11 @@ MSK_DEV CShape cshape_of(const DShape* sh) {
 /* what the narrowphase functions need besides the two shapes: the hull vertex pool (the template's table in global
  * memory: 12 KB, L1-resident), the group's workspace, the wave's EPA workspace, the lane's index in its group and
  * the group's index in its wave */
-struct CCtx { const v3* verts; float* ws; float* we; int gl, grp; unsigned long long* dbg; };
+struct CCtx { const v3* verts; float* ws; float* we; int gl, grp; unsigned long long* dbg;
+#ifdef MSK_PROFILE_PHASES
+  mutable int gjk_iters; mutable long long epa_cycles;   /* work counters of the profiling build (tools/gpu_phase_probe.py) */
+#endif
+};
 
 /* ---- group primitives (a group = one DPP row of 16 lanes) ------------------------------------------------ */
 template <int CTRL>
@@ -804,6 +808,9 @@ MSK_DEV int gjk_epa(const CCtx& m, const CShape* A, const pose* TA, const CShape
   int hit = 0;
   for (int it = 0; it < ORC_GJK_ITERS; ++it) {
     if (vv < 1e-10f) { hit = 1; break; }
+#ifdef MSK_PROFILE_PHASES
+    m.gjk_iters++;
+#endif
     mvert w = msupport(m, A, TA, B, TB, v3_neg(v));
     float vw = v3_dot(v, w.w);
     if (vw > 0.0f && vw * vw > margin * margin * vv) return 0; /* separated by more than margin */
@@ -837,8 +844,14 @@ MSK_DEV int gjk_epa(const CCtx& m, const CShape* A, const pose* TA, const CShape
   }
   float depth = 0.0f;
   int ok = 0;
+#ifdef MSK_PROFILE_PHASES
+  const long long t_epa = (long long)__builtin_readcyclecounter();
+#endif
   for (int g = 0; g < 64 / NPG; ++g) /* one EPA workspace per wave: the groups that got here take turns */
     if (g == m.grp) ok = epa(m, A, TA, B, TB, S, n, n_out, &depth, wa, wb);
+#ifdef MSK_PROFILE_PHASES
+  m.epa_cycles = (long long)__builtin_readcyclecounter() - t_epa;
+#endif
   /* a polytope whose faces are all slivers hands back a null normal: a contact row without direction would poison the solver
    * (J = 0, 1 / (J W J^T) = inf) -- treat it like the other degenerate cases (the group's lanes hold the same normal) */
   if (ok && !(v3_len2(*n_out) > 0.25f)) ok = 0;

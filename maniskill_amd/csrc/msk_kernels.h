@@ -126,7 +126,7 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
   const CShape* A = &cA;
   const CShape* B = &cB;
 #ifdef MSK_PROFILE_PHASES
-  long long tq[5]; tq[0] = (long long)__builtin_readcyclecounter(); tq[1] = tq[2] = tq[0];
+  long long tq[5]; tq[0] = (long long)__builtin_readcyclecounter(); tq[1] = tq[2] = tq[0]; tq[3] = tq[4] = 0;
 #endif
   v3 opos[4], onrm = v3_make(0, 0, 1);
   float osep[4];
@@ -156,6 +156,9 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
     cx.gl = lane % NPG;
     cx.grp = lane / NPG;
     cx.dbg = nullptr;
+#ifdef MSK_PROFILE_PHASES
+    cx.gjk_iters = 0; cx.epa_cycles = 0;
+#endif
     DContactOut out[4];
     if (type == NP_PLANE) {
       const int pa = A->type == MSK_SHAPE_PLANE;
@@ -188,6 +191,9 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
     for (int k = 0; k < 4; ++k) { opos[k] = out[k].pos; osep[k] = out[k].sep; }
     onrm = out[0].n;
     writer = cx.gl == 0;   /* the group's first lane owns the contact slot */
+#ifdef MSK_PROFILE_PHASES
+    tq[3] = cx.epa_cycles; tq[4] = cx.gjk_iters;
+#endif
   }
 #ifdef MSK_PROFILE_PHASES
   tq[2] = (long long)__builtin_readcyclecounter();
@@ -197,6 +203,14 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
     atomicAdd(&d[1], (unsigned long long)(tq[1] - tq[0])); atomicMax(&d[2], (unsigned long long)(tq[1] - tq[0]));
     atomicAdd(&d[3], (unsigned long long)(tq[2] - tq[1])); atomicMax(&d[4], (unsigned long long)(tq[2] - tq[1]));
     if (n > 0) atomicAdd(&d[5], 1ull);
+    if (type == NP_GJK) { /* row 3: [0] items through EPA, [1] sum / [2] max EPA cycles, [3] sum / [4] max GJK iterations; row 4: histogram of primary */
+      unsigned long long* x = (unsigned long long*)st.dbg + (size_t)m->N * 8 + 3 * 8;
+      if (tq[3] > 0) { atomicAdd(&x[0], 1ull); atomicAdd(&x[1], (unsigned long long)tq[3]); atomicMax(&x[2], (unsigned long long)tq[3]); }
+      atomicAdd(&x[3], (unsigned long long)tq[4]); atomicMax(&x[4], (unsigned long long)tq[4]);
+      const long long pc = tq[1] - tq[0];
+      const int bk = pc < 25000 ? 0 : (pc < 50000 ? 1 : (pc < 100000 ? 2 : (pc < 150000 ? 3 : (pc < 200000 ? 4 : (pc < 300000 ? 5 : (pc < 400000 ? 6 : 7))))));
+      atomicAdd(&x[8 + bk], 1ull);
+    }
   }
 #endif
   if (!writer) break;

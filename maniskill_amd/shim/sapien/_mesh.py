@@ -38,6 +38,81 @@ def read_stl(path):
     return v, np.arange(len(v), dtype=np.int64).reshape(-1, 3)
 
 
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2",
+              "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+
+def read_ply(path):
+    """Stanford PLY (ascii, binary little / big endian): vertex x y z and the face lists, polygons fanned into triangles."""
+    with open(path, "rb") as f:
+        data = f.read()
+    end = data.find(b"end_header")
+    if not data.startswith(b"ply") or end < 0:
+        raise RuntimeError(f"not a PLY file: {path}")
+    body = end + len(b"end_header")
+    body = data.index(b"\n", body) + 1
+    fmt, elements = None, []
+    for line in data[:end].decode("ascii", "replace").splitlines():
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "format":
+            fmt = t[1]
+        elif t[0] == "element":
+            elements.append(dict(name=t[1], count=int(t[2]), props=[]))
+        elif t[0] == "property" and elements:
+            if t[1] == "list":
+                elements[-1]["props"].append(("list", t[2], t[3], t[4]))
+            else:
+                elements[-1]["props"].append(("scalar", t[1], t[2]))
+    verts, faces = None, []
+    if fmt == "ascii":
+        tok = data[body:].split()
+        pos = 0
+        for el in elements:
+            rows = []
+            for _ in range(el["count"]):
+                row = {}
+                for pr in el["props"]:
+                    if pr[0] == "scalar":
+                        row[pr[2]] = float(tok[pos]); pos += 1
+                    else:
+                        n = int(tok[pos]); pos += 1
+                        row[pr[3]] = [int(x) for x in tok[pos:pos + n]]; pos += n
+                rows.append(row)
+            if el["name"] == "vertex":
+                verts = np.array([[r["x"], r["y"], r["z"]] for r in rows], dtype=np.float64)
+            elif el["name"] == "face":
+                key = "vertex_indices" if rows and "vertex_indices" in rows[0] else "vertex_index"
+                for r in rows:
+                    idx = r[key]
+                    faces.extend([idx[0], idx[k], idx[k + 1]] for k in range(1, len(idx) - 1))
+    else:
+        en = "<" if fmt == "binary_little_endian" else ">"
+        pos = body
+        for el in elements:
+            if all(pr[0] == "scalar" for pr in el["props"]):
+                dt = np.dtype([(pr[2], en + _PLY_TYPES[pr[1]]) for pr in el["props"]])
+                arr = np.frombuffer(data, dtype=dt, count=el["count"], offset=pos)
+                pos += dt.itemsize * el["count"]
+                if el["name"] == "vertex":
+                    verts = np.stack([arr["x"], arr["y"], arr["z"]], axis=1).astype(np.float64)
+            else:
+                for _ in range(el["count"]):
+                    for pr in el["props"]:
+                        if pr[0] == "scalar":
+                            pos += np.dtype(_PLY_TYPES[pr[1]]).itemsize
+                        else:
+                            ct, it = np.dtype(en + _PLY_TYPES[pr[1]]), np.dtype(en + _PLY_TYPES[pr[2]])
+                            n = int(np.frombuffer(data, dtype=ct, count=1, offset=pos)[0]); pos += ct.itemsize
+                            idx = np.frombuffer(data, dtype=it, count=n, offset=pos).astype(np.int64); pos += it.itemsize * n
+                            if el["name"] == "face" and pr[3] in ("vertex_indices", "vertex_index"):
+                                faces.extend([idx[0], idx[k], idx[k + 1]] for k in range(1, n - 1))
+    if verts is None:
+        raise RuntimeError(f"no vertex element in {path}")
+    return verts, np.array(faces, dtype=np.int64).reshape(-1, 3)
+
+
 def read_obj(path):
     """-> list of (vertices, faces), one per ``o`` / ``g`` group that has faces (polygons are fan-triangulated)."""
     verts, groups, cur = [], [], []
@@ -173,6 +248,9 @@ def load_mesh_parts(path):
         parts = read_glb(path)
     elif ext == ".dae":
         parts = read_dae(path)
+    elif ext == ".ply":
+        v, f = read_ply(path)
+        parts = [dict(vertices=v, faces=f, base_color=[0.8, 0.8, 0.8, 1.0], name=os.path.basename(path))]
     else:
         raise RuntimeError(f"unsupported mesh format: {path}")
     if not parts:

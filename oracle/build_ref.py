@@ -9,7 +9,7 @@ travels with the snapshot): ``*.pyc`` files for ``mani_skill`` and ``tests``, pl
 (URDF / SRDF / STL / GLB / JSON of the Panda and Fetch robots, the table scene, task configs).  No reference source file is
 copied.  Test infrastructure only: tests/ref_harness.py puts it on sys.path behind the sapien shim; the product never imports it.
 
-Usage: python oracle/build_ref.py [--ref /root/reference] [--robots panda fetch]
+Usage: python oracle/build_ref.py [--ref /root/reference] [--robots panda fetch ...]
 """
 import argparse
 import os
@@ -19,10 +19,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "_ref", "maniskill")
+# robot description folders the conformance tests load (tests/ref_env_zoo.py); the other robots only come with downloaded tasks
+ZOO_ROBOTS = ("panda", "fetch", "so100", "allegro", "dclaw", "trifinger", "g1_humanoid", "humanoid")
 DATA_SKIP_EXT = {".py", ".pyc", ".md", ".png", ".gif", ".jpg", ".mp4", ".sh", ".ipynb"}
 
 
-def build(ref="/root/reference", robots=("panda", "fetch"), quiet=True):
+def build(ref="/root/reference", robots=ZOO_ROBOTS, quiet=True):
     if not os.path.isdir(os.path.join(ref, "mani_skill")):
         return None
     stamp = os.path.join(OUT, ".built")
@@ -67,7 +69,7 @@ def build(ref="/root/reference", robots=("panda", "fetch"), quiet=True):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--robots", nargs="*", default=["panda", "fetch"])
+    ap.add_argument("--robots", nargs="*", default=list(ZOO_ROBOTS))
     ap.add_argument("--force", action="store_true")
     a = ap.parse_args()
     if a.force and os.path.isdir(OUT):

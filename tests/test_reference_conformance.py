@@ -64,3 +64,30 @@ def test_reference_suite_on_cpu_checker(built, node):
 def test_reference_suite_on_hip(built, node):
     rc, out = run_reference_tests([node], "hip")
     assert rc == 0, out
+
+
+def _run_zoo(backend):
+    import json
+    r = subprocess.run([sys.executable, os.path.join(HERE, "ref_env_zoo.py"), backend, "3"], cwd=HERE, capture_output=True, text=True, timeout=3000)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("ZOO ")]
+    assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
+    return json.loads(line[-1][4:])
+
+
+@needs_ref
+def test_reference_env_zoo_on_cpu_checker(built):
+    """Every task of the reference's registry that needs no downloaded asset (35 of 74: tests/ref_env_zoo.py) is built by the reference's own
+    code over the shim -- Panda, Fetch-free tabletop tasks, two-robot tasks, SO100, the MJCF control tasks, D'Claw valves with a different
+    valve per sub-scene, Allegro hand, TriFinger, Unitree G1 (fixed base) -- reset and stepped; observations, rewards and the raw
+    simulation buffers stay finite."""
+    res = _run_zoo("oracle")
+    bad = {k: v for k, v in res.items() if v != "ok"}
+    assert not bad and len(res) >= 35, bad
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_reference_env_zoo_on_hip(built):
+    res = _run_zoo("hip")
+    bad = {k: v for k, v in res.items() if v != "ok"}
+    assert not bad and len(res) >= 35, bad

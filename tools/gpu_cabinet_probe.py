@@ -64,6 +64,26 @@ if mode == "parity":
     sys.exit(0 if worst < 1e-3 else 1)
 
 gym = ref_harness.setup("hip")
+if mode == "profile":   # where a control step of the multi-group scene spends its host time
+    import cProfile, pstats
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    env = gym.make("OpenCabinetDrawer-v1", num_envs=n)
+    obs, _ = env.reset(seed=0)
+    for _ in range(3):
+        env.step(2 * torch.rand(env.action_space.shape, device=obs.device) - 1)
+    torch.cuda.synchronize()
+    prof = cProfile.Profile(); prof.enable()
+    t0 = time.time()
+    for _ in range(20):
+        env.step(2 * torch.rand(env.action_space.shape, device=obs.device) - 1)
+    t_launch = time.time() - t0
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    prof.disable()
+    print(f"{n} envs: {1e3 * dt / 20:.2f} ms per step, host returns after {1e3 * t_launch / 20:.2f} ms per step")
+    pstats.Stats(prof).sort_stats("cumulative").print_stats(45)
+    pstats.Stats(prof).sort_stats("tottime").print_stats(25)
+    sys.exit(0)
 res = {}
 for n in [int(x) for x in sys.argv[2:]] or [256, 1024]:
     t0 = time.time()
