@@ -184,6 +184,24 @@ int msk_update_kinematics(msk_ctx* ctx, void* stream);
 /* PhysxGpuSystem.step() (envs/scene.py:379-380): one substep of `timestep` for all envs. */
 int msk_step(msk_ctx* ctx, void* stream);
 
+/* ---- several contexts behind one set of sapien tensors ------------------------------------------------------------ */
+/* ManiSkill sees ONE px.cuda_rigid_body_data / px.cuda_articulation_* per process, over all sub-scenes (utils/structs/actor.py:352,
+ * articulation.py:726-797), also when the sub-scenes differ in structure (a different cabinet per sub-scene:
+ * envs/tasks/mobile_manipulation/open_cabinet_drawer.py:128-177) and therefore run as one context per structural group.
+ * msk_bind_buffers: the caller owns the storage of the nine apply / fetch buffers (ids MSK_BUF_RIGID_BODY_DATA ..
+ * MSK_BUF_RIGID_BODY_TORQUE, ptrs[id]) and hands each context ITS ROW RANGE of the shared tensors: no copies between a context's
+ * buffers and the tensor ManiSkill reads.  Articulation rows are `art_pitch` floats apart (>= the context's max_dof: SAPIEN pads
+ * every articulation to the largest one of the scene).  Contents: whatever the memory holds (fetch to fill the outputs; qf / force
+ * / torque are inputs).  msk_buffer reports the bound pointers afterwards, shape[1] = art_pitch for the articulation buffers.
+ * The memory must outlive the context. */
+int msk_bind_buffers(msk_ctx* ctx, void* const ptrs[9], int64_t art_pitch);
+/* The same boundary call on n contexts of one device, in one native call: op 0 = msk_step, 1 = msk_apply(mask), 2 = msk_fetch(mask),
+ * 3 = msk_update_kinematics.  The contexts are independent, so their kernels are issued round-robin on internal streams forked
+ * from and joined into `stream` (what a host loop over the contexts with per-call stream switches would do, without its cost:
+ * 25 groups x 28 calls per control step were 23 ms of Python in OpenCabinetDrawer-v1). */
+enum msk_batch_op { MSK_BATCH_STEP = 0, MSK_BATCH_APPLY = 1, MSK_BATCH_FETCH = 2, MSK_BATCH_UPDATE_KINEMATICS = 3 };
+int msk_batch(msk_ctx* const* ctxs, int n, int op, uint32_t mask, void* stream);
+
 /* ---- per-env instances of the template (heterogeneous sub-scenes) -------------------------------------------- */
 /* ManiSkill builds some tasks with a different actor per sub-scene and merges them (Actor.merge: e.g. PegInsertionSide-v1's
  * peg and box-with-hole, one size per env, envs/tasks/tabletop/peg_insertion_side.py:133-187).  Here the template stays one

@@ -30,6 +30,7 @@ EXPORTS = [
     "fetch", "update_kinematics", "step", "query_create_pairs", "query_create_bodies", "query_buffer", "query_run",
     "get_sizes", "get_contacts", "get_env_contact_counts", "timing_enable", "timing_read",
     "set_solver_classes", "get_solver_class_counts", "declare_env_box", "declare_env_mass", "set_env_boxes", "set_env_masses",
+    "bind_buffers", "batch",
 ]
 # include/msk_render.h — camera pipeline (both libraries)
 RENDER_EXPORTS = ["render_add_mesh", "render_set_base_color", "render_bind_env_box", "render_set_lights", "render_finalize", "camera_create", "camera_buffer",
@@ -37,6 +38,7 @@ RENDER_EXPORTS = ["render_add_mesh", "render_set_base_color", "render_bind_env_b
 # include/msk_task.h — fused task kernels (HIP library only; the test-suite's CPU checker has no counterpart)
 TASK_EXPORTS = ["task_pickcube_init", "task_pickcube_set_action", "task_pickcube_set_action_ee", "control_step", "task_pickcube_observe",
                 "task_pusht_init", "task_pusht_set_action", "task_pusht_observe", "task_peg_init", "task_peg_observe"]
+BATCH_STEP, BATCH_APPLY, BATCH_FETCH, BATCH_UPDATE_KINEMATICS = 0, 1, 2, 3
 K_DYNAMICS, K_COLLIDE, K_SOLVE = 0, 1, 2
 KERNEL_SLOTS = {"k_dynamics": K_DYNAMICS, "k_collide": K_COLLIDE, "k_solve": K_SOLVE}
 
@@ -127,6 +129,8 @@ class NativeLib:
             "set_env_masses": (i32, [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
             "set_solver_classes": (i32, [vp, C.POINTER(C.c_int32)]),
             "get_solver_class_counts": (i32, [vp, C.POINTER(C.c_int32)]),
+            "bind_buffers": (i32, [vp, C.POINTER(C.c_void_p), C.c_int64]),
+            "batch": (i32, [C.POINTER(C.c_void_p), i32, i32, u32, vp]),
             "timing_enable": (i32, [vp, i32]),
             "timing_read": (i32, [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
         }

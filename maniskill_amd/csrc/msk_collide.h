@@ -504,15 +504,35 @@ MSK_DEV int sat_box_box(const CShape* A, const pose* TA, const CShape* B, const 
 /* ---- GJK / EPA ------------------------------------------------------------------------ */
 typedef struct { v3 w, a, b; } mvert;
 
+/* Support point of the Minkowski difference A - B in direction d.  The two support scans are independent chains: written out side
+ * by side and branch-free (a box enters its scan with zero vertices and takes the sign formula), so the scheduler interleaves them --
+ * a wave that carries one hull pair is bound by the latency of its dependent instructions, not by issue slots.  Per shape the
+ * arithmetic is support()'s: ascending strided scan with `>`, arg-max butterfly keeping the lower index. */
 MSK_DEV mvert msupport(const CCtx& m, const CShape* A, const pose* TA, const CShape* B, const pose* TB, v3 d) {
-  mvert r;
-#pragma unroll 1
-  for (int side = 0; side < 2; ++side) { /* one copy of the support code for both shapes */
-    const CShape sh = side ? *B : *A;
-    const pose T = side ? *TB : *TA;
-    const v3 p = support(m, &sh, &T, side ? v3_neg(d) : d);
-    if (side) r.b = p; else r.a = p;
+  const v3 dla = quat_rotate_inv(TA->q, d), dlb = quat_rotate_inv(TB->q, v3_neg(d));
+  const bool boxa = A->type == MSK_SHAPE_BOX, boxb = B->type == MSK_SHAPE_BOX;
+  const int na = boxa ? 0 : A->nverts, nb = boxb ? 0 : B->nverts;
+  int ia = NO_INDEX, ib = NO_INDEX;
+  float da = -3.0e38f, db = -3.0e38f;
+#pragma unroll
+  for (int k = 0; k < MSK_MAX_HULL_VERTS / NPG; ++k) {
+    const int i = m.gl + k * NPG;
+    const bool va = i < na, vb = i < nb;
+    const float xa = v3_dot(m.verts[A->vbase + (va ? i : 0)], dla), xb = v3_dot(m.verts[B->vbase + (vb ? i : 0)], dlb);
+    const bool ta = va && (xa > da || ia == NO_INDEX), tb = vb && (xb > db || ib == NO_INDEX);
+    da = ta ? xa : da; ia = ta ? i : ia;
+    db = tb ? xb : db; ib = tb ? i : ib;
   }
+  argmax_step<ROW_XOR1>(da, ia); argmax_step<ROW_XOR1>(db, ib);
+  argmax_step<ROW_XOR2>(da, ia); argmax_step<ROW_XOR2>(db, ib);
+  argmax_step<ROW_HALF_MIRROR>(da, ia); argmax_step<ROW_HALF_MIRROR>(db, ib);
+  argmax_step<ROW_MIRROR>(da, ia); argmax_step<ROW_MIRROR>(db, ib);
+  const v3 ha = m.verts[A->vbase + (boxa ? 0 : ia)], hb = m.verts[B->vbase + (boxb ? 0 : ib)];
+  const v3 pa = boxa ? v3_make(dla.x >= 0.0f ? A->par[0] : -A->par[0], dla.y >= 0.0f ? A->par[1] : -A->par[1], dla.z >= 0.0f ? A->par[2] : -A->par[2]) : ha;
+  const v3 pb = boxb ? v3_make(dlb.x >= 0.0f ? B->par[0] : -B->par[0], dlb.y >= 0.0f ? B->par[1] : -B->par[1], dlb.z >= 0.0f ? B->par[2] : -B->par[2]) : hb;
+  mvert r;
+  r.a = pose_apply(*TA, pa);
+  r.b = pose_apply(*TB, pb);
   r.w = v3_sub(r.a, r.b);
   return r;
 }
@@ -571,7 +591,7 @@ MSK_DEV void bary_set(float* bary, int i, float x) {
 }
 
 /* reduce the simplex to the sub-simplex closest to the origin; returns 1 if the origin is enclosed */
-MSK_DEV int simplex_closest(Simplex& S, int* n, v3* v, float* bary) {
+MSK_DEV int simplex_closest(Simplex& S, int* n, v3* v, float* bary, const int gl) {
   if (*n == 1) { *v = S.s0.w; bary[0] = 1; return 0; }
   if (*n == 2) {
     v3 ab = v3_sub(S.s1.w, S.s0.w);
@@ -595,29 +615,40 @@ MSK_DEV int simplex_closest(Simplex& S, int* n, v3* v, float* bary) {
     *n = mm;
     return 0;
   }
-  /* tetrahedron: test the four faces */
+  /* tetrahedron: the four faces {0,1,2|3}, {0,1,3|2}, {0,2,3|1}, {1,2,3|0} side by side, lane (gl & 3) of every quad takes one; then
+   * the serial scan's choice (first face with the smallest distance among the faces the origin is outside of) from quad broadcasts */
+  const int f = gl & 3;
+  const int f0 = (f == 3) ? 1 : 0, f1 = (f < 2) ? 1 : 2, f2 = (f == 0) ? 2 : 3, f3 = 3 - f;
+  const v3 a = simplex_get(S, f0).w, b = simplex_get(S, f1).w, c = simplex_get(S, f2).w, d = simplex_get(S, f3).w;
+  const v3 nrm = v3_cross(v3_sub(b, a), v3_sub(c, a));
+  const float sd = v3_dot(nrm, v3_sub(d, a));  /* side of the opposite vertex */
+  const float so = v3_dot(nrm, v3_neg(a));     /* side of the origin */
+  int outside = (sd > 0.0f) ? (so < 0.0f) : (so > 0.0f);
+  if (fabsf(sd) < 1e-20f) outside = 1; /* degenerate tetrahedron: treat as a face */
+  float bc[3] = {0.0f, 0.0f, 0.0f};
+  int mask = 0;
+  v3 p = v3_make(0, 0, 0);
+  if (outside) p = closest_tri(a, b, c, bc, &mask);
+  const float d2 = outside ? v3_len2(p) : 3.0e38f;
   float bestd = 3.0e38f;
-  int bestf = -1, bestmask = 0;
-  float bestb[3] = {0.0f, 0.0f, 0.0f};
-  v3 bestv = v3_make(0, 0, 0);
-  const mvert q[4] = {S.s0, S.s1, S.s2, S.s3};
-#pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    /* faces {0,1,2|3}, {0,1,3|2}, {0,2,3|1}, {1,2,3|0} */
-    const int f0 = (f == 3) ? 1 : 0, f1 = (f < 2) ? 1 : 2, f2 = (f == 0) ? 2 : 3, f3 = 3 - f;
-    v3 a = q[f0].w, b = q[f1].w, c = q[f2].w, d = q[f3].w;
-    v3 nrm = v3_cross(v3_sub(b, a), v3_sub(c, a));
-    float sd = v3_dot(nrm, v3_sub(d, a));  /* side of the opposite vertex */
-    float so = v3_dot(nrm, v3_neg(a));     /* side of the origin */
-    int outside = (sd > 0.0f) ? (so < 0.0f) : (so > 0.0f);
-    if (fabsf(sd) < 1e-20f) outside = 1; /* degenerate tetrahedron: treat as a face */
-    if (!outside) continue;
-    float bc[3]; int mask;
-    v3 p = closest_tri(a, b, c, bc, &mask);
-    float d2 = v3_len2(p);
-    if (d2 < bestd) { bestd = d2; bestf = f; bestmask = mask; bestv = p; bestb[0] = bc[0]; bestb[1] = bc[1]; bestb[2] = bc[2]; }
+  int bestf = -1;
+  {
+    const float e0 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(d2), __float_as_int(d2), 0x00, 0xF, 0xF, false));
+    const float e1 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(d2), __float_as_int(d2), 0x55, 0xF, 0xF, false));
+    const float e2 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(d2), __float_as_int(d2), 0xAA, 0xF, 0xF, false));
+    const float e3 = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(d2), __float_as_int(d2), 0xFF, 0xF, 0xF, false));
+    const int o0 = __builtin_amdgcn_update_dpp(outside, outside, 0x00, 0xF, 0xF, false), o1 = __builtin_amdgcn_update_dpp(outside, outside, 0x55, 0xF, 0xF, false);
+    const int o2 = __builtin_amdgcn_update_dpp(outside, outside, 0xAA, 0xF, 0xF, false), o3 = __builtin_amdgcn_update_dpp(outside, outside, 0xFF, 0xF, 0xF, false);
+    if (o0 && e0 < bestd) { bestd = e0; bestf = 0; }
+    if (o1 && e1 < bestd) { bestd = e1; bestf = 1; }
+    if (o2 && e2 < bestd) { bestd = e2; bestf = 2; }
+    if (o3 && e3 < bestd) { bestd = e3; bestf = 3; }
   }
   if (bestf < 0) return 1;
+  const int src = (threadIdx.x & ~3) | bestf;   /* the lane of my quad that holds the chosen face */
+  const int bestmask = __shfl(mask, src);
+  const v3 bestv = v3_make(__shfl(p.x, src), __shfl(p.y, src), __shfl(p.z, src));
+  const float bestb[3] = {__shfl(bc[0], src), __shfl(bc[1], src), __shfl(bc[2], src)};
   const int g0 = (bestf == 3) ? 1 : 0, g1 = (bestf < 2) ? 1 : 2, g2 = (bestf == 0) ? 2 : 3;
   const mvert t[3] = {simplex_get(S, g0), simplex_get(S, g1), simplex_get(S, g2)};
   int mm = 0;
@@ -822,7 +853,7 @@ MSK_DEV int gjk_epa(const CCtx& m, const CShape* A, const pose* TA, const CShape
     simplex_set(S, n, w);
     n++;
     v3 nvv;
-    if (simplex_closest(S, &n, &nvv, bary)) { hit = 1; break; }
+    if (simplex_closest(S, &n, &nvv, bary, m.gl)) { hit = 1; break; }
     float nvl = v3_len2(nvv);
     if (nvl >= vv) break; /* no progress (numerical) */
     v = nvv;

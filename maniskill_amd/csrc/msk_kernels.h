@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
 }
 
 /* ---- AoS <-> SoA converters ------------------------------------------------------------------ */
-struct DBuffers { float* buf[MSK_BUF_COUNT]; int max_dof; };
+struct DBuffers { float* buf[MSK_BUF_COUNT]; int max_dof; int pitch; /* floats between articulation rows (>= max_dof) */ };
 
 /* gpu_apply_rigid_dynamic_force / _torque: the buffer rows become the pending wrench of the next substep */
 __global__ void k_apply_wrench(float* __restrict__ wrench, const float* __restrict__ force, const float* __restrict__ torque,
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(256) k_apply(const DModel* __restrict__ m, DSt
   for (int a = 0; a < m->na; ++a)
     for (int j = 0; j < art_ndof[a]; ++j) {
       const int d = art_dof0[a] + j;
-      const size_t row = ((size_t)e * m->na + a) * bf.max_dof + j;
+      const size_t row = ((size_t)e * m->na + a) * bf.pitch + j;
       if (mask & MSK_APPLY_ART_QPOS) {
         const float nq = bf.buf[MSK_BUF_ART_QPOS][row];
         if (nq != E[m->lay.q + (d)]) teleported = true;
@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(256) k_fetch(const DModel* __restrict__ m, DSt
   for (int a = 0; a < m->na; ++a)
     for (int j = 0; j < art_ndof[a]; ++j) {
       const int d = art_dof0[a] + j;
-      const size_t row = ((size_t)e * m->na + a) * bf.max_dof + j;
+      const size_t row = ((size_t)e * m->na + a) * bf.pitch + j;
       if (mask & MSK_FETCH_ART_QPOS) bf.buf[MSK_BUF_ART_QPOS][row] = E[m->lay.q + (d)];
       if (mask & MSK_FETCH_ART_QVEL) bf.buf[MSK_BUF_ART_QVEL][row] = E[m->lay.qd + (d)];
       if (mask & MSK_FETCH_ART_QACC) bf.buf[MSK_BUF_ART_QACC][row] = E[m->lay.qacc + (d)];

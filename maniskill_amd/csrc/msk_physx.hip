@@ -544,6 +544,7 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   ALLOC(c->d_wrench, N * (size_t)m.nb * 8);
   c->st.ext_wrench = c->d_wrench;
   c->bufs.max_dof = c->max_dof;
+  c->bufs.pitch = c->max_dof > 0 ? c->max_dof : 1;
   /* initial poses (template replicated) */
   std::vector<float> h(N * (size_t)m.lay.stride, 0.0f);
   for (size_t e = 0; e < N; ++e)
@@ -575,8 +576,20 @@ MSK_API void* msk_buffer(msk_ctx* c, int id, int64_t shape[2]) {
   if (id == MSK_BUF_RIGID_BODY_DATA) { shape[0] = (int64_t)c->model.N * c->model.nb; shape[1] = 13; }
   else if (id == MSK_BUF_RIGID_BODY_FORCE || id == MSK_BUF_RIGID_BODY_TORQUE) { shape[0] = (int64_t)c->model.N * c->model.nb; shape[1] = 4; }
   else if (id == MSK_BUF_ART_LINK_JOINT_FORCES) { shape[0] = (int64_t)c->model.N * c->model.na * c->link_slots.max_links; shape[1] = 6; }
-  else { shape[0] = (int64_t)c->model.N * c->model.na; shape[1] = c->max_dof; }
+  else { shape[0] = (int64_t)c->model.N * c->model.na; shape[1] = c->bufs.pitch; }
   return c->bufs.buf[id];
+}
+
+MSK_API int msk_bind_buffers(msk_ctx* c, void* const ptrs[9], int64_t art_pitch) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "bind_buffers before finalize");
+  if (art_pitch < (c->max_dof > 0 ? c->max_dof : 1)) return fail(c, MSK_ERR_INVALID, "bind_buffers: art_pitch below max_dof");
+  for (int id = 0; id <= MSK_BUF_RIGID_BODY_TORQUE; ++id)
+    if (!ptrs[id]) return fail(c, MSK_ERR_INVALID, "bind_buffers: null pointer");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());   /* nothing in flight may still use the old storage (which stays allocated until msk_destroy) */
+  for (int id = 0; id <= MSK_BUF_RIGID_BODY_TORQUE; ++id) c->bufs.buf[id] = (float*)ptrs[id];
+  c->bufs.pitch = (int)art_pitch;
+  return MSK_OK;
 }
 
 MSK_API int msk_apply(msk_ctx* c, uint32_t mask, void* stream) {
@@ -665,6 +678,52 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
   if (timed) { hipEventRecord(ev[3], s); c->t_n++; }
   HIP_TRY(hipGetLastError());
   return MSK_OK;
+}
+
+/* fork / join streams of msk_batch, per process (the contexts of a batch live on one device) */
+#define MSK_BATCH_STREAMS 32
+static hipStream_t g_side[MSK_BATCH_STREAMS];
+static hipEvent_t g_fork, g_join[MSK_BATCH_STREAMS];
+static int g_side_dev = -1;
+
+MSK_API int msk_batch(msk_ctx* const* ctxs, int n, int op, uint32_t mask, void* stream) {
+  if (n <= 0) return MSK_OK;
+  msk_ctx* c = ctxs[0];   /* errors of the fork / join are reported on the first context */
+  hipStream_t s = (hipStream_t)stream;
+  auto one = [&](msk_ctx* c, void* st) -> int {
+    switch (op) {
+      case MSK_BATCH_STEP: return msk_step(c, st);
+      case MSK_BATCH_APPLY: return msk_apply(c, mask, st);
+      case MSK_BATCH_FETCH: return msk_fetch(c, mask, st);
+      case MSK_BATCH_UPDATE_KINEMATICS: return msk_update_kinematics(c, st);
+      default: return fail(c, MSK_ERR_INVALID, "batch: unknown op");
+    }
+  };
+  if (n < 3) { /* not worth a fork */
+    for (int i = 0; i < n; ++i) { const int r = one(ctxs[i], stream); if (r < 0) return r; }
+    return MSK_OK;
+  }
+  if (g_side_dev != c->device) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventCreateWithFlags(&g_fork, hipEventDisableTiming));
+    for (int k = 0; k < MSK_BATCH_STREAMS; ++k) {
+      HIP_TRY(hipStreamCreateWithFlags(&g_side[k], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&g_join[k], hipEventDisableTiming));
+    }
+    g_side_dev = c->device;
+  }
+  static const int e_ns = getenv("MSK_BATCH_STREAMS") ? atoi(getenv("MSK_BATCH_STREAMS")) : 8;   /* tuning aid */
+  const int cap = e_ns < 1 ? 1 : (e_ns > MSK_BATCH_STREAMS ? MSK_BATCH_STREAMS : e_ns);
+  const int ns = n < cap ? n : cap;
+  HIP_TRY(hipEventRecord(g_fork, s));
+  for (int k = 0; k < ns; ++k) HIP_TRY(hipStreamWaitEvent(g_side[k], g_fork, 0));
+  int rc = MSK_OK;
+  for (int i = 0; i < n && rc >= 0; ++i) rc = one(ctxs[i], (void*)g_side[i % ns]);
+  for (int k = 0; k < ns; ++k) {
+    HIP_TRY(hipEventRecord(g_join[k], g_side[k]));
+    HIP_TRY(hipStreamWaitEvent(s, g_join[k], 0));
+  }
+  return rc;
 }
 
 MSK_API int msk_timing_enable(msk_ctx* c, int max_steps) {

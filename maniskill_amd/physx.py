@@ -215,6 +215,26 @@ class ContactPairImpulseQuery:
 # --------------------------------------------------------------------------------------
 # the system
 # --------------------------------------------------------------------------------------
+class _TensorHandle:
+    """``.torch()`` over a slice of a caller-owned tensor (bind_buffers)"""
+
+    def __init__(self, t):
+        self._t = t
+        self.shape = tuple(t.shape)
+
+    def torch(self):
+        return self._t
+
+
+def batch_call(engines, op: int, mask: int = 0):
+    """``msk_batch``: one native call for the same boundary call on several contexts (structural groups of one scene)."""
+    e0 = engines[0]
+    arr = getattr(e0, "_batch_arr", None)
+    if arr is None or arr[1] != len(engines):
+        arr = e0._batch_arr = ((C.c_void_p * len(engines))(*[e.ctx for e in engines]), len(engines))
+    e0.lib.check(e0.ctx, e0.lib.batch(arr[0], arr[1], op, mask, e0._stream()), "batch")
+
+
 class PhysxGpuSystem:
     """All sub-scenes of one process / one GPU (reference: one ``physx.PhysxGpuSystem``)."""
 
@@ -317,6 +337,27 @@ class PhysxGpuSystem:
         # publish the initial state so that the torch-visible buffers are valid
         self.gpu_update_articulation_kinematics()
         self._fetch(N.FETCH_RIGID_DATA | N.FETCH_ART_QPOS | N.FETCH_ART_QVEL | N.FETCH_ART_QACC | N.FETCH_ART_TARGETS)
+
+    def bind_buffers(self, tensors, row0: int, art_row0: int):
+        """``msk_bind_buffers``: this context's nine apply / fetch buffers become row ranges of caller-owned tensors (``tensors``: name ->
+        2-D float32 tensor shared by several contexts; body rows start at ``row0``, articulation rows at ``art_row0``).  The handles
+        ``cuda_*`` are rebuilt over the bound memory."""
+        names = ["rigid_body_data", "articulation_qpos", "articulation_qvel", "articulation_qacc", "articulation_qf",
+                 "articulation_target_qpos", "articulation_target_qvel", "rigid_body_force", "rigid_body_torque"]
+        pitch = int(tensors["articulation_qpos"].shape[1])
+        ptrs = (C.c_void_p * 9)()
+        for i, nm in enumerate(names):
+            t = tensors[nm]
+            assert t.dtype == torch.float32 and t.is_contiguous()
+            r0 = art_row0 if nm.startswith("articulation") else row0
+            ptrs[i] = t.data_ptr() + 4 * r0 * int(t.shape[1])
+        self.lib.check(self.ctx, self.lib.bind_buffers(self.ctx, ptrs, pitch), "bind_buffers")
+        self._bound = tensors     # keeps the storage alive
+        nb, na = self.num_envs * self.bodies_per_env, self.num_envs * max(self.arts_per_env, 0)
+        for nm in names:
+            t = tensors[nm]
+            r0, n = (art_row0, max(na, 1)) if nm.startswith("articulation") else (row0, nb)
+            setattr(self, "cuda_" + nm, _TensorHandle(t[r0:r0 + n]))
 
     def set_scene_offsets(self, offsets):
         """``px.set_scene_offset`` for every sub-scene at once (sapien_env.py:1202)."""

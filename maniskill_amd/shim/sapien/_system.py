@@ -108,37 +108,14 @@ class _MultiBuffers:
         for name in self.ART:
             setattr(px, "cuda_articulation_" + name, _Tensor(self.t[name]))
         px.cuda_articulation_link_incoming_joint_forces = _Tensor(self.t["link_forces"])
+        # every group's context reads and writes ITS ROWS of these tensors directly (msk_bind_buffers): no copies on apply / fetch
+        shared = {("" if name in self.BODY else "articulation_") + name: self.t[name] for name in self.BODY + self.ART}
+        for g in gs:
+            g.engine.bind_buffers(shared, g.base, g.abase)
         self.fetch_all()
 
-    def _eng(self, g, name):
-        return getattr(g.engine, "cuda_" + name if name in self.BODY else "cuda_articulation_" + name).torch()
-
-    def _pairs(self, names):
-        """(unified view, engine tensor) for every group and buffer name"""
-        uni, eng = [], []
-        for g in self.px._groups:
-            for name in names:
-                if name in self.BODY:
-                    uni.append(self.t[name][g.base:g.base + g.n * g.nb])
-                    eng.append(self._eng(g, name))
-                elif g.na > 0:
-                    uni.append(self.t[name][g.abase:g.abase + g.n * g.na, :g.max_dof])
-                    eng.append(self._eng(g, name))
-        return uni, eng
-
-    def pull(self, names):      # engine buffers -> unified (one batched copy for all groups)
-        uni, eng = self._pairs(tuple(names))
-        if uni:
-            torch._foreach_copy_(uni, eng)
-
-    def push(self, names):      # unified -> engine buffers
-        uni, eng = self._pairs(tuple(names))
-        if uni:
-            torch._foreach_copy_(eng, uni)
-
     def fetch_all(self):
-        self.px._each_group("gpu_fetch_all")
-        self.pull(("rigid_body_data",) + self.ART)
+        self.px._batch("gpu_fetch_all")
 
     def pull_link_forces(self):
         for g in self.px._groups:
@@ -544,6 +521,7 @@ class PhysxSystem:
             rows = g0.n * max(g0.na, 1)
             self.cuda_articulation_link_incoming_joint_forces = _Handle3D(lf, (rows, max(lf.shape[0] // max(rows, 1), 1), 6))
         else:
+            self._engines = [g.engine for g in self._groups]
             self._multi = _MultiBuffers(self, torch_device)
         self._initialized = True
 
@@ -650,42 +628,54 @@ class PhysxSystem:
         raise RuntimeError("drive properties cannot be changed after the simulation was initialised (choose the control mode at "
                            "construction)")
 
+    # sapien call -> (msk_batch op, mask) for a scene of several groups
+    _BATCH = None
+
+    @classmethod
+    def _batch_table(cls):
+        if cls._BATCH is None:
+            from maniskill_amd import _native as N
+            A, F = N.BATCH_APPLY, N.BATCH_FETCH
+            cls._BATCH = {
+                "gpu_apply_rigid_dynamic_data": (A, N.APPLY_RIGID_DATA), "gpu_apply_rigid_dynamic_force": (A, N.APPLY_RIGID_FORCE),
+                "gpu_apply_rigid_dynamic_torque": (A, N.APPLY_RIGID_TORQUE), "gpu_apply_articulation_root_pose": (A, N.APPLY_ART_ROOT_POSE),
+                "gpu_apply_articulation_root_velocity": None, "gpu_apply_articulation_qpos": (A, N.APPLY_ART_QPOS),
+                "gpu_apply_articulation_qvel": (A, N.APPLY_ART_QVEL), "gpu_apply_articulation_qf": (A, N.APPLY_ART_QF),
+                "gpu_apply_articulation_target_position": (A, N.APPLY_ART_TARGET_QPOS),
+                "gpu_apply_articulation_target_velocity": (A, N.APPLY_ART_TARGET_QVEL),
+                "gpu_fetch_rigid_dynamic_data": (F, N.FETCH_RIGID_DATA), "gpu_fetch_articulation_link_pose": (F, N.FETCH_RIGID_DATA),
+                "gpu_fetch_articulation_qpos": (F, N.FETCH_ART_QPOS), "gpu_fetch_articulation_qvel": (F, N.FETCH_ART_QVEL),
+                "gpu_fetch_articulation_qacc": (F, N.FETCH_ART_QACC), "gpu_fetch_articulation_target_qpos": (F, N.FETCH_ART_TARGETS),
+                "gpu_fetch_all": (F, N.FETCH_RIGID_DATA | N.FETCH_ART_QPOS | N.FETCH_ART_QVEL | N.FETCH_ART_QACC | N.FETCH_ART_TARGETS),
+                "gpu_update_articulation_kinematics": (N.BATCH_UPDATE_KINEMATICS, 0), "step": (N.BATCH_STEP, 0),
+            }
+        return cls._BATCH
+
+    def _batch(self, method):
+        """One boundary call on every group's context, in one native call (msk_batch: the groups' kernels are independent and small, so
+        the library issues them on a handful of side streams forked from / joined into the current one)."""
+        from maniskill_amd.physx import batch_call
+        ent = self._batch_table()[method]
+        if ent is not None:
+            batch_call(self._engines, ent[0], ent[1])
+
     def _do(self, kind, method, names=()):
-        """One boundary call on every group: 'apply' copies the unified rows out first, 'fetch' copies the groups' rows in after."""
+        """One boundary call.  With several groups the contexts are bound to their rows of the unified tensors (msk_bind_buffers), so
+        'apply' / 'fetch' move nothing on the host side."""
         if self._multi is None:
             getattr(self._engine, method)()
-            return
-        if kind == "apply":
-            self._multi.push(names)
-        self._each_group(method)
-        if kind == "fetch":
-            self._multi.pull(names)
+        else:
+            self._batch(method)
 
     def _each_group(self, method):
-        """The same call on every group's context.  On the GPU the groups' kernels are independent and small (a few dozen sub-scenes
-        each), so they are issued on a handful of side streams and overlap; the current stream forks before and joins after."""
-        gs = self._groups
-        dev = self.cuda_rigid_body_data.torch().device
-        if dev.type != "cuda" or len(gs) < 3:
-            for g in gs:
-                getattr(g.engine, method)()
-            return
-        if not hasattr(self, "_side_streams"):
-            self._side_streams = [torch.cuda.Stream(dev) for _ in range(min(8, len(gs)))]
-        main = torch.cuda.current_stream(dev)
-        for st in self._side_streams:
-            st.wait_stream(main)
-        for k, g in enumerate(gs):
-            with torch.cuda.stream(self._side_streams[k % len(self._side_streams)]):
-                getattr(g.engine, method)()
-        for st in self._side_streams:
-            main.wait_stream(st)
+        for g in self._groups:
+            getattr(g.engine, method)()
 
     def step(self):
         if self._multi is None:
             self._engine.step()
         else:
-            self._each_group("step")
+            self._batch("step")
 
 
 class PhysxGpuSystem(PhysxSystem):

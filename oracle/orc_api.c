@@ -37,7 +37,7 @@ ORC_EXPORT void orc_destroy(orc_ctx* c) {
   free(c->offsets);
   free(c->xshape);
   free(c->xbody);
-  for (int i = 0; i < MSK_BUF_COUNT; ++i) free(c->buf[i]);
+  for (int i = 0; i < MSK_BUF_COUNT; ++i) free((c->buf_bound && i <= MSK_BUF_RIGID_BODY_TORQUE) ? c->buf_own[i] : c->buf[i]);
   free(c->wrench);
   for (int i = 0; i < c->nqueries; ++i) { free(c->queries[i].pairs); free(c->queries[i].out); }
   free(c);
@@ -260,6 +260,7 @@ ORC_EXPORT int orc_finalize(orc_ctx* c, int num_envs) {
     if (c->art_root[a] < 0) return fail(c, MSK_ERR_INVALID, "articulation without links");
     if (c->art_ndof[a] > c->max_dof) c->max_dof = c->art_ndof[a];
   }
+  c->art_pitch = c->max_dof > 0 ? c->max_dof : 1;
   c->max_links = 0;
   {
     int count[8] = {0};
@@ -324,12 +325,27 @@ ORC_EXPORT void* orc_buffer(orc_ctx* c, int id, int64_t shape[2]) {
   if (id == MSK_BUF_RIGID_BODY_DATA) { shape[0] = (int64_t)c->num_envs * c->nb; shape[1] = 13; }
   else if (id == MSK_BUF_RIGID_BODY_FORCE || id == MSK_BUF_RIGID_BODY_TORQUE) { shape[0] = (int64_t)c->num_envs * c->nb; shape[1] = 4; }
   else if (id == MSK_BUF_ART_LINK_JOINT_FORCES) { shape[0] = (int64_t)c->num_envs * c->na * c->max_links; shape[1] = 6; }
-  else { shape[0] = (int64_t)c->num_envs * c->na; shape[1] = c->max_dof; }
+  else { shape[0] = (int64_t)c->num_envs * c->na; shape[1] = c->art_pitch; }
   return c->buf[id];
 }
 
 static float* art_row(orc_ctx* c, int buf, int env, int art) {
-  return c->buf[buf] + ((size_t)env * c->na + art) * c->max_dof;
+  return c->buf[buf] + ((size_t)env * c->na + art) * c->art_pitch;
+}
+
+/* msk_bind_buffers / msk_batch of include/msk_physx.h (host memory here; the batch is a loop) */
+ORC_EXPORT int orc_bind_buffers(orc_ctx* c, void* const ptrs[9], int64_t art_pitch) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "bind_buffers before finalize");
+  if (art_pitch < (c->max_dof > 0 ? c->max_dof : 1)) return fail(c, MSK_ERR_INVALID, "bind_buffers: art_pitch below max_dof");
+  for (int id = 0; id <= MSK_BUF_RIGID_BODY_TORQUE; ++id)
+    if (!ptrs[id]) return fail(c, MSK_ERR_INVALID, "bind_buffers: null pointer");
+  for (int id = 0; id <= MSK_BUF_RIGID_BODY_TORQUE; ++id) {
+    if (!c->buf_bound) c->buf_own[id] = c->buf[id];   /* freed by orc_destroy */
+    c->buf[id] = (float*)ptrs[id];
+  }
+  c->buf_bound = 1;
+  c->art_pitch = (int)art_pitch;
+  return MSK_OK;
 }
 
 ORC_EXPORT int orc_apply(orc_ctx* c, uint32_t mask, void* stream) {
@@ -446,6 +462,21 @@ ORC_EXPORT int orc_step(orc_ctx* c, void* stream) {
   if (c->wrench_pending) { /* forces last one step */
     memset(c->wrench, 0, sizeof(float) * 8 * (size_t)c->num_envs * c->nb);
     c->wrench_pending = 0;
+  }
+  return MSK_OK;
+}
+
+ORC_EXPORT int orc_batch(orc_ctx* const* ctxs, int n, int op, uint32_t mask, void* stream) {
+  for (int i = 0; i < n; ++i) {
+    int r;
+    switch (op) {
+      case MSK_BATCH_STEP: r = orc_step(ctxs[i], stream); break;
+      case MSK_BATCH_APPLY: r = orc_apply(ctxs[i], mask, stream); break;
+      case MSK_BATCH_FETCH: r = orc_fetch(ctxs[i], mask, stream); break;
+      case MSK_BATCH_UPDATE_KINEMATICS: r = orc_update_kinematics(ctxs[i], stream); break;
+      default: return fail(ctxs[i], MSK_ERR_INVALID, "batch: unknown op");
+    }
+    if (r < 0) return r;
   }
   return MSK_OK;
 }

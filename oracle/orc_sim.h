@@ -96,6 +96,9 @@ typedef struct orc_ctx {
   int ndisabled;
   int disabled[256][2];
   int max_dof;       /* per-articulation max dof (buffer width) */
+  int art_pitch;     /* floats between articulation rows of the buffers (= max_dof unless bound: msk_bind_buffers) */
+  int buf_bound;     /* the nine apply / fetch buffers live in caller memory; buf_own keeps the allocations to free */
+  float* buf_own[MSK_BUF_COUNT];
   int max_links;     /* per-articulation max link count */
   int link_slot[MSK_MAX_BODIES]; /* index of a link within its articulation (build order), -1 for other bodies */
   int art_dof0[8], art_ndof[8];
