@@ -144,11 +144,10 @@ MSK_DEV void publish_body(const DModel* m, float* E, int i, const DBody* b, pose
 
 /* PhysxGpuSystem.gpu_update_articulation_kinematics: frames and velocities only */
 template <int LPE>
-__global__ void __launch_bounds__(64) k_kinematics(const DModel* __restrict__ m, DState st) {
-  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+MSK_DEV void kinematics_block(const DModel* __restrict__ m, const DState& st, float* lds_all, const int blk) {
   const DynLds ly(m->nb, 0);
   const int sub = threadIdx.x / LPE, i = threadIdx.x % LPE;
-  const int e_raw = blockIdx.x * (64 / LPE) + sub;
+  const int e_raw = blk * (64 / LPE) + sub;
   const bool live = e_raw < m->N;
   const int e = live ? e_raw : m->N - 1;
   float* lds = lds_all + sub * ly.total;
@@ -162,13 +161,19 @@ __global__ void __launch_bounds__(64) k_kinematics(const DModel* __restrict__ m,
   v3 comw = v3_add(T.p, m33_mulv(&R, b->com));
   publish_body(m, E, i, b, T, V, comw);
 }
+template <int LPE>
+__global__ void __launch_bounds__(64) k_kinematics(const DModel* __restrict__ m, DState st) {
+  extern __shared__ __attribute__((aligned(16))) float lds_kin[];
+  kinematics_block<LPE>(m, st, lds_kin, blockIdx.x);
+}
 
+/* blk: which block of the env range this workgroup is (its blockIdx.x when the launch serves one context: k_dynamics; its index inside
+ * the context's share of a launch over several contexts: k_multi_dynamics, msk_kernels.h) */
 template <int LPE, int MD>   /* MD: capacity of the per-lane joint-space rows (16 or 32 dofs) */
-__global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, DState st) {
-  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, float* lds_all, const int blk) {
   const DynLds ly(m->nb, MD);
   const int sub = threadIdx.x / LPE, i = threadIdx.x % LPE;
-  const int e_raw = blockIdx.x * (64 / LPE) + sub;
+  const int e_raw = blk * (64 / LPE) + sub;
   const bool live = e_raw < m->N;      /* a surplus half-wave shadows the last env and stores nothing */
   const int e = live ? e_raw : m->N - 1;
   float* lds = lds_all + sub * ly.total;
@@ -478,16 +483,21 @@ __global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, D
   if (m->np > 0) {
     __shared__ float bp_aabb[MSK_MAX_SHAPES][6];
     __shared__ float bp_obb[MSK_MAX_SHAPES][13];   /* rotation columns (9), local half extents (3); odd stride: no bank conflicts */
-    if (blockIdx.x == 0 && threadIdx.x < MSK_SOLVE_CLASSES) st.cls_count[threadIdx.x] = 0;   /* this substep's solver lists (filled by the narrowphase) */
+    if (blk == 0 && threadIdx.x < MSK_SOLVE_CLASSES) st.cls_count[threadIdx.x] = 0;   /* this substep's solver lists (filled by the narrowphase) */
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   /* the other half-wave's stores to its env record */
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll 1
     for (int k = 0; k < 64 / LPE; ++k) {
-      const int eb = blockIdx.x * (64 / LPE) + k;
+      const int eb = blk * (64 / LPE) + k;
       if (eb < m->N) broadphase_env(m, st, eb, bp_aabb, bp_obb);
     }
   }
+}
+template <int LPE, int MD>
+__global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, DState st) {
+  extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  dynamics_block<LPE, MD>(m, st, lds_dyn, blockIdx.x);
 }
 
 #endif

@@ -278,16 +278,18 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
  * Per 64 consecutive envs, the block that finishes last sorts them into the solver lists (one wave, one env per lane:
  * a handful of same-address atomics per 64 envs). */
 struct NpCfg { int nplane, nbox, nhull; };
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_narrowphase(const DModel* __restrict__ m, DState st, const int group, const NpCfg cfg) {
+MSK_DEV void narrowphase_block(const DModel* __restrict__ m, const DState& st, const int group, const NpCfg cfg, const int bx, const int by, const int gx,
+                               const int gy) {
   __shared__ int pref[NP_GROUP_MAX + 1];
   /* one LDS image for both kinds of block: 32 lanes x 208 words of per-pair arrays (box-box), or four group workspaces
    * and the wave's EPA workspace (plane, hull) */
-  constexpr int LDS_WORDS = PL_WORDS * PL_LANES > (64 / NPG) * WS_TOTAL + WE_TOTAL ? PL_WORDS * PL_LANES : (64 / NPG) * WS_TOTAL + WE_TOTAL;
+  constexpr int GROUP_WORDS = (64 / NPG) * WS_TOTAL + WE_TOTAL + 3 * MSK_MAX_SHAPES * 20;   /* workspaces + room for 1280 staged hull vertices */
+  constexpr int LDS_WORDS = PL_WORDS * PL_LANES > GROUP_WORDS ? PL_WORDS * PL_LANES : GROUP_WORDS;
   __shared__ float s_lds[LDS_WORDS];
   float* s_ws = s_lds;
   float* s_we = s_lds + (64 / NPG) * WS_TOTAL;
-  const int e0 = blockIdx.x * group;
-  int y = blockIdx.y;
+  const int e0 = bx * group;
+  int y = by;
   const int fixed_per_group = cfg.nplane + cfg.nbox;
   const bool lane_kind = (y >= cfg.nplane) && (y - cfg.nplane < cfg.nbox);   /* box-box, one lane per pair: boxes only */
   /* plane and hull blocks scan hull vertices over and over (support points, features): the template's vertex pool (<= 12 KB) is
@@ -303,7 +305,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
     }
   }
   if (y >= fixed_per_group) { /* hull blocks: the launch-wide queue; their items sign off one by one */
-    narrowphase_body<NP_GJK, NPG>(m, st, e0, group, (y - fixed_per_group) * (int)gridDim.x + (int)blockIdx.x, cfg.nhull * (int)gridDim.x, pref, s_ws, s_we,
+    narrowphase_body<NP_GJK, NPG>(m, st, e0, group, (y - fixed_per_group) * gx + bx, cfg.nhull * gx, pref, s_ws, s_we,
                                   verts, fixed_per_group);
     return;
   }
@@ -326,6 +328,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
   }
 }
 
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_narrowphase(const DModel* __restrict__ m, DState st, const int group, const NpCfg cfg) {
+  narrowphase_block(m, st, group, cfg, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+}
+
 /* ---- AoS <-> SoA converters ------------------------------------------------------------------ */
 struct DBuffers { float* buf[MSK_BUF_COUNT]; int max_dof; int pitch; /* floats between articulation rows (>= max_dof) */ };
 
@@ -344,10 +350,10 @@ __global__ void k_apply_wrench(float* __restrict__ wrench, const float* __restri
   }
 }
 
-__global__ void __launch_bounds__(256) k_apply(const DModel* __restrict__ m, DState st, DBuffers bf, unsigned mask, const int* __restrict__ art_dof0,
-                                               const int* __restrict__ art_ndof) {
+MSK_DEV void apply_block(const DModel* __restrict__ m, const DState& st, const DBuffers& bf, unsigned mask, const int* __restrict__ art_dof0,
+                         const int* __restrict__ art_ndof, const int blk) {
   const int N = m->N;
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blk * 256 + threadIdx.x;
   if (e >= N) return;
   float* E = EREC(st, m, e);
   const float ox = E[m->lay.off + 0], oy = E[m->lay.off + 1], oz = E[m->lay.off + 2];
@@ -394,6 +400,11 @@ __global__ void __launch_bounds__(256) k_apply(const DModel* __restrict__ m, DSt
     for (int p = 0; p < m->np; ++p) cnts[p] = 0;
     st.ct_total[e] = 0;
   }
+}
+
+__global__ void __launch_bounds__(256) k_apply(const DModel* __restrict__ m, DState st, DBuffers bf, unsigned mask, const int* __restrict__ art_dof0,
+                                               const int* __restrict__ art_ndof) {
+  apply_block(m, st, bf, mask, art_dof0, art_ndof, blockIdx.x);
 }
 
 /* gpu_fetch_articulation_link_incoming_joint_forces: inverse dynamics of the state the last step left (see the statement in
@@ -511,10 +522,10 @@ __global__ void __launch_bounds__(64) k_link_forces(const DModel* __restrict__ m
   }
 }
 
-__global__ void __launch_bounds__(256) k_fetch(const DModel* __restrict__ m, DState st, DBuffers bf, unsigned mask, const int* __restrict__ art_dof0,
-                                               const int* __restrict__ art_ndof) {
+MSK_DEV void fetch_block(const DModel* __restrict__ m, const DState& st, const DBuffers& bf, unsigned mask, const int* __restrict__ art_dof0,
+                         const int* __restrict__ art_ndof, const int blk) {
   const int N = m->N;
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blk * 256 + threadIdx.x;
   if (e >= N) return;
   float* E = EREC(st, m, e);
   const float ox = E[m->lay.off + 0], oy = E[m->lay.off + 1], oz = E[m->lay.off + 2];
@@ -539,6 +550,78 @@ __global__ void __launch_bounds__(256) k_fetch(const DModel* __restrict__ m, DSt
         bf.buf[MSK_BUF_ART_TARGET_QVEL][row] = E[m->lay.qdt + (d)];
       }
     }
+}
+
+__global__ void __launch_bounds__(256) k_fetch(const DModel* __restrict__ m, DState st, DBuffers bf, unsigned mask, const int* __restrict__ art_dof0,
+                                               const int* __restrict__ art_ndof) {
+  fetch_block(m, st, bf, mask, art_dof0, art_ndof, blockIdx.x);
+}
+
+/* ---- one launch over several contexts (msk_batch) -------------------------------------------------------------------------------
+ * A scene whose sub-scenes differ in structure runs as one context per structural group (a few dozen envs each): per group the
+ * kernels above are latency chains on a handful of workgroups, and 25 groups x 15 launches per control step, spread over streams,
+ * still run four at a time.  Here the groups of one template variant share each launch: a workgroup finds its group from the
+ * table (first workgroup of every group in this launch), then runs the same block function on that group's model and state. */
+struct GroupRef {
+  const DModel* m;
+  DState st;
+  DBuffers bufs;
+  const int* art_dof0;
+  const int* art_ndof;
+  int b_dyn, b_np, b_cs, b_af;   /* first workgroup of this group in the dynamics (= kinematics) / narrowphase / solver / apply-fetch launches */
+  int np_group, np_gx, np_gy, gm;
+  NpCfg np_cfg;
+};
+enum { MG_DYN = 0, MG_NP = 1, MG_CS = 2, MG_AF = 3 };
+template <int WHICH>
+MSK_DEV int multi_find(const GroupRef* __restrict__ refs, const int n, const int blk, int* local) {
+  int g = 0;
+  for (int k = 1; k < n; ++k) {
+    const int b = WHICH == MG_DYN ? refs[k].b_dyn : (WHICH == MG_NP ? refs[k].b_np : (WHICH == MG_CS ? refs[k].b_cs : refs[k].b_af));
+    if (blk >= b) g = k;
+  }
+  const int b0 = WHICH == MG_DYN ? refs[g].b_dyn : (WHICH == MG_NP ? refs[g].b_np : (WHICH == MG_CS ? refs[g].b_cs : refs[g].b_af));
+  *local = blk - b0;
+  return g;
+}
+template <int LPE, int MD>
+__global__ void __launch_bounds__(64) k_multi_dynamics(const GroupRef* __restrict__ refs, const int n) {
+  extern __shared__ __attribute__((aligned(16))) float lds_md[];
+  int blk;
+  const GroupRef& r = refs[multi_find<MG_DYN>(refs, n, blockIdx.x, &blk)];
+  if (blk * (64 / LPE) >= r.m->N) return;
+  dynamics_block<LPE, MD>(r.m, r.st, lds_md, blk);
+}
+template <int LPE>
+__global__ void __launch_bounds__(64) k_multi_kinematics(const GroupRef* __restrict__ refs, const int n) {
+  extern __shared__ __attribute__((aligned(16))) float lds_mk[];
+  int blk;
+  const GroupRef& r = refs[multi_find<MG_DYN>(refs, n, blockIdx.x, &blk)];
+  if (blk * (64 / LPE) >= r.m->N) return;
+  kinematics_block<LPE>(r.m, r.st, lds_mk, blk);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_multi_narrowphase(const GroupRef* __restrict__ refs, const int n) {
+  int blk;
+  const GroupRef& r = refs[multi_find<MG_NP>(refs, n, blockIdx.x, &blk)];
+  if (blk >= r.np_gx * r.np_gy) return;
+  narrowphase_block(r.m, r.st, r.np_group, r.np_cfg, blk % r.np_gx, blk / r.np_gx, r.np_gx, r.np_gy);
+}
+template <int NVP, int GL>
+__global__ void __launch_bounds__(64) k_multi_csolve(const GroupRef* __restrict__ refs, const int n) {
+  extern __shared__ __attribute__((aligned(16))) float lds_mc[];
+  int blk;
+  const GroupRef& r = refs[multi_find<MG_CS>(refs, n, blockIdx.x, &blk)];
+  csolve_block<NVP, GL>(r.m, r.st, r.gm, blk, lds_mc);
+}
+__global__ void __launch_bounds__(256) k_multi_apply(const GroupRef* __restrict__ refs, const int n, const unsigned mask) {
+  int blk;
+  const GroupRef& r = refs[multi_find<MG_AF>(refs, n, blockIdx.x, &blk)];
+  apply_block(r.m, r.st, r.bufs, mask, r.art_dof0, r.art_ndof, blk);
+}
+__global__ void __launch_bounds__(256) k_multi_fetch(const GroupRef* __restrict__ refs, const int n, const unsigned mask) {
+  int blk;
+  const GroupRef& r = refs[multi_find<MG_AF>(refs, n, blockIdx.x, &blk)];
+  fetch_block(r.m, r.st, r.bufs, mask, r.art_dof0, r.art_ndof, blk);
 }
 
 /* sum of contact impulses applied on body x by body y, per env, per queried pair */

@@ -13,8 +13,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 
 #define MSK_API extern "C" __attribute__((visibility("default")))
+
+static unsigned long long g_bind_epoch = 1;   /* msk_bind_buffers calls so far: invalidates the merged-batch table */
 
 struct HostQuery { int npairs; int* d_pairs; float* d_out; };
 
@@ -152,6 +155,7 @@ MSK_API msk_ctx* msk_create(int hip_device, const msk_config* cfg) {
 
 MSK_API void msk_destroy(msk_ctx* c) {
   if (!c) return;
+  g_bind_epoch++;   /* a merged-batch table may hold this context's pointers */
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   for (void* p : c->allocs) hipFree(p);
@@ -510,12 +514,16 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   ALLOC(st.a_scratch, (size_t)c->solve_workers * 9 * MSK_CLASS3_BLOCKS * (MSK_CLASS3_BLOCKS + 4));   /* + prefetch slack */
   if (m.G == 16) {
     auto k0 = k_csolve<16, 16>;
+    auto k1 = k_multi_csolve<16, 16>;
     c->lds_solve = CsLds<16, 16, 16>::TOTAL * sizeof(float);
     HIP_TRY(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_solve));
+    HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_solve));
   } else {
     auto k0 = k_csolve<32, 32>;
+    auto k1 = k_multi_csolve<32, 32>;
     c->lds_solve = CsLds<32, 32, 32>::TOTAL * sizeof(float);
     HIP_TRY(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_solve));
+    HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_solve));
   }
   ALLOC(st.env_ncontacts, N); ALLOC(st.env_overflow, 1); ALLOC(st.ct_total, N);
   ALLOC(st.np_count, N * 4); ALLOC(st.np_items, N * NP_TYPES * (size_t)(m.np > 0 ? m.np : 1));
@@ -589,6 +597,7 @@ MSK_API int msk_bind_buffers(msk_ctx* c, void* const ptrs[9], int64_t art_pitch)
   HIP_TRY(hipDeviceSynchronize());   /* nothing in flight may still use the old storage (which stays allocated until msk_destroy) */
   for (int id = 0; id <= MSK_BUF_RIGID_BODY_TORQUE; ++id) c->bufs.buf[id] = (float*)ptrs[id];
   c->bufs.pitch = (int)art_pitch;
+  g_bind_epoch++;
   return MSK_OK;
 }
 
@@ -634,6 +643,19 @@ MSK_API int msk_update_kinematics(msk_ctx* c, void* stream) {
   return MSK_OK;
 }
 
+/* env-group size and block kinds of the narrowphase launch for N envs */
+static void np_launch_shape(int N, int* group_out, NpCfg* cfg) {
+  int group = N / 256;   /* ~256 x 6 waves whatever the env count */
+  group = group < 1 ? 1 : (group > NP_GROUP_MAX ? NP_GROUP_MAX : group);
+  while (group & (group - 1)) group &= group - 1;   /* a power of two: groups never straddle the 64-env classification chunks */
+  static const int e_nbox = getenv("MSK_NP_NBOX") ? atoi(getenv("MSK_NP_NBOX")) : 1;       /* tuning aids */
+  static const int e_nhull = getenv("MSK_NP_NHULL") ? atoi(getenv("MSK_NP_NHULL")) : 4;
+  cfg->nplane = 1;
+  cfg->nbox = e_nbox;
+  cfg->nhull = e_nhull;
+  *group_out = group;
+}
+
 MSK_API int msk_step(msk_ctx* c, void* stream) {
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "step before finalize");
   const int N = c->model.N;
@@ -648,15 +670,9 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
   launch_dynamics(c->model, c->d_model, c->st, s);
   if (timed) hipEventRecord(ev[1], s);
   if (c->model.np > 0) {
-    int group = N / 256;   /* ~256 x 6 waves whatever the env count */
-    group = group < 1 ? 1 : (group > NP_GROUP_MAX ? NP_GROUP_MAX : group);
-    while (group & (group - 1)) group &= group - 1;   /* a power of two: groups never straddle the 64-env classification chunks */
-    static const int e_nbox = getenv("MSK_NP_NBOX") ? atoi(getenv("MSK_NP_NBOX")) : 1;       /* tuning aids */
-    static const int e_nhull = getenv("MSK_NP_NHULL") ? atoi(getenv("MSK_NP_NHULL")) : 4;
+    int group;
     NpCfg cfg;
-    cfg.nplane = 1;
-    cfg.nbox = e_nbox;
-    cfg.nhull = e_nhull;
+    np_launch_shape(N, &group, &cfg);
     hipLaunchKernelGGL(k_narrowphase, dim3((N + group - 1) / group, cfg.nplane + cfg.nbox + cfg.nhull), dim3(64), 0, s, c->d_model,
                        c->st, group, cfg);
   } else {
@@ -680,6 +696,104 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
   return MSK_OK;
 }
 
+/* msk_batch, merged form: the contexts share every launch (k_multi_*, msk_kernels.h).  Possible when they are instances of the same
+ * kernel variants (lanes per env, dof padding, solver padding) and nothing per-context is armed (kernel timing).  The table of the
+ * contexts (GroupRef) lives in device memory and is rebuilt when the list of contexts or a buffer binding changes. */
+struct MergedCache {
+  std::vector<msk_ctx*> key;
+  unsigned long long epoch = 0;
+  GroupRef* d_refs = nullptr;
+  int t_dyn = 0, t_np = 0, t_cs = 0, t_af = 0;
+  size_t lds_dyn = 0, lds_kin = 0;
+  bool any_np = false;
+};
+static MergedCache g_merged;
+
+static int batch_merged(msk_ctx* const* ctxs, int n, int op, uint32_t mask, hipStream_t s) {
+  msk_ctx* c = ctxs[0];
+  if (n < 2) return 1;
+  static const int e_off = getenv("MSK_BATCH_MERGED") ? atoi(getenv("MSK_BATCH_MERGED")) : 1;
+  if (!e_off) return 1;
+  const int lpe = lanes_per_env(c->model), md = dyn_md(c->model), G = c->model.G;
+  for (int i = 0; i < n; ++i) {
+    msk_ctx* x = ctxs[i];
+    if (!x->finalized || x->device != c->device || x->t_n < x->t_cap) return 1;
+    if (lanes_per_env(x->model) != lpe || dyn_md(x->model) != md || x->model.G != G || x->lds_solve != c->lds_solve) return 1;
+  }
+  if (op == MSK_BATCH_APPLY && (mask & (MSK_APPLY_RIGID_FORCE | MSK_APPLY_RIGID_TORQUE))) return 1;   /* wrench staging: per context */
+  if (op == MSK_BATCH_FETCH && (mask & MSK_FETCH_ART_LINK_FORCES)) return 1;
+  MergedCache& mc = g_merged;
+  bool same = mc.epoch == g_bind_epoch && (int)mc.key.size() == n;
+  for (int i = 0; same && i < n; ++i) same = mc.key[i] == ctxs[i];
+  if (!same) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (mc.d_refs) { hipFree(mc.d_refs); mc.d_refs = nullptr; }
+    std::vector<GroupRef> refs((size_t)n);
+    mc.t_dyn = mc.t_np = mc.t_cs = mc.t_af = 0;
+    mc.lds_dyn = mc.lds_kin = 0;
+    mc.any_np = false;
+    const int epb = 64 / lpe, epw = (G == 16) ? 4 : 2;
+    for (int i = 0; i < n; ++i) {
+      msk_ctx* x = ctxs[i];
+      GroupRef& r = refs[(size_t)i];
+      const int N = x->model.N;
+      r.m = x->d_model; r.st = x->st; r.bufs = x->bufs; r.art_dof0 = x->d_art_dof0; r.art_ndof = x->d_art_ndof;
+      r.b_dyn = mc.t_dyn; mc.t_dyn += (N + epb - 1) / epb;
+      r.b_af = mc.t_af; mc.t_af += (N + 255) / 256;
+      r.gm = x->solve_workers;
+      r.b_cs = mc.t_cs; mc.t_cs += r.gm + (N + epw - 1) / epw;
+      np_launch_shape(N, &r.np_group, &r.np_cfg);
+      r.np_gx = (N + r.np_group - 1) / r.np_group;
+      r.np_gy = r.np_cfg.nplane + r.np_cfg.nbox + r.np_cfg.nhull;
+      r.b_np = mc.t_np;
+      if (x->model.np > 0) { mc.t_np += r.np_gx * r.np_gy; mc.any_np = true; } else { r.np_gx = 0; }
+      mc.lds_dyn = std::max(mc.lds_dyn, (size_t)DynLds(x->model.nb, md).total * sizeof(float) * epb);
+      mc.lds_kin = std::max(mc.lds_kin, (size_t)DynLds(x->model.nb, 0).total * sizeof(float) * epb);
+      if ((x->model.np > 0) != (c->model.np > 0)) return 1;   /* mixed: the pair-less contexts classify in a kernel of their own */
+    }
+    HIP_TRY(hipMalloc(&mc.d_refs, sizeof(GroupRef) * (size_t)n));
+    HIP_TRY(hipMemcpy(mc.d_refs, refs.data(), sizeof(GroupRef) * (size_t)n, hipMemcpyHostToDevice));
+    mc.key.assign(ctxs, ctxs + n);
+    mc.epoch = g_bind_epoch;
+  }
+  auto kinematics = [&]() {
+    if (lpe == 32) hipLaunchKernelGGL(k_multi_kinematics<32>, dim3(mc.t_dyn), dim3(64), mc.lds_kin, s, mc.d_refs, n);
+    else hipLaunchKernelGGL(k_multi_kinematics<64>, dim3(mc.t_dyn), dim3(64), mc.lds_kin, s, mc.d_refs, n);
+    for (int i = 0; i < n; ++i) ctxs[i]->kin_dirty = false;
+  };
+  switch (op) {
+    case MSK_BATCH_STEP: {
+      if (!mc.any_np) return 1;
+      if (lpe == 32) hipLaunchKernelGGL((k_multi_dynamics<32, 16>), dim3(mc.t_dyn), dim3(64), mc.lds_dyn, s, mc.d_refs, n);
+      else if (md == 16) hipLaunchKernelGGL((k_multi_dynamics<64, 16>), dim3(mc.t_dyn), dim3(64), mc.lds_dyn, s, mc.d_refs, n);
+      else hipLaunchKernelGGL((k_multi_dynamics<64, 32>), dim3(mc.t_dyn), dim3(64), mc.lds_dyn, s, mc.d_refs, n);
+      hipLaunchKernelGGL(k_multi_narrowphase, dim3(mc.t_np), dim3(64), 0, s, mc.d_refs, n);
+      if (G == 16) { auto k0 = k_multi_csolve<16, 16>; hipLaunchKernelGGL(k0, dim3(mc.t_cs), dim3(64), c->lds_solve, s, mc.d_refs, n); }
+      else { auto k0 = k_multi_csolve<32, 32>; hipLaunchKernelGGL(k0, dim3(mc.t_cs), dim3(64), c->lds_solve, s, mc.d_refs, n); }
+      for (int i = 0; i < n; ++i) ctxs[i]->kin_dirty = true;
+      break;
+    }
+    case MSK_BATCH_APPLY:
+      hipLaunchKernelGGL(k_multi_apply, dim3(mc.t_af), dim3(256), 0, s, mc.d_refs, n, mask);
+      break;
+    case MSK_BATCH_FETCH: {
+      bool dirty = false;
+      for (int i = 0; i < n; ++i) dirty = dirty || ctxs[i]->kin_dirty;
+      if (dirty && (mask & MSK_FETCH_RIGID_DATA)) kinematics();
+      hipLaunchKernelGGL(k_multi_fetch, dim3(mc.t_af), dim3(256), 0, s, mc.d_refs, n, mask);
+      break;
+    }
+    case MSK_BATCH_UPDATE_KINEMATICS:
+      kinematics();
+      break;
+    default:
+      return fail(c, MSK_ERR_INVALID, "batch: unknown op");
+  }
+  HIP_TRY(hipGetLastError());
+  return MSK_OK;
+}
+
 /* fork / join streams of msk_batch, per process (the contexts of a batch live on one device) */
 #define MSK_BATCH_STREAMS 32
 static hipStream_t g_side[MSK_BATCH_STREAMS];
@@ -699,6 +813,7 @@ MSK_API int msk_batch(msk_ctx* const* ctxs, int n, int op, uint32_t mask, void* 
       default: return fail(c, MSK_ERR_INVALID, "batch: unknown op");
     }
   };
+  { const int r = batch_merged(ctxs, n, op, mask, s); if (r != 1) return r; }   /* 1: not mergeable, go on below */
   if (n < 3) { /* not worth a fork */
     for (int i = 0; i < n; ++i) { const int r = one(ctxs[i], stream); if (r < 0) return r; }
     return MSK_OK;

@@ -127,7 +127,7 @@ MSK_DEV float bias_over_arr(float b, float c0, float rinv, float inv_h, float in
  * lane reads back only what it wrote itself, and the sweeps prefetch four blocks ahead to cover the L2 round trip. */
 template <int NVP, int GL, int CAP, bool AGLOB>
 MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int* __restrict__ list, const int first, const int count,
-                       float* lds_all) {
+                       float* lds_all, const int wg) {   /* wg: this workgroup's index among the context's solver workgroups */
   typedef CsLds<NVP, GL, CAP> LY;
   const int g = threadIdx.x / GL, lane = threadIdx.x % GL;   /* `lane` = my block / coordinate inside the env */
   const int gshift = g * GL;
@@ -229,7 +229,7 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   if (nbmax == 0 && __ballot(active) == 0ull) return;
   float* Ly = pool + pbase;
   float* La;
-  if constexpr (AGLOB) La = st.a_scratch + (size_t)blockIdx.x * (9 * CAP * (CAP + 4));
+  if constexpr (AGLOB) La = st.a_scratch + (size_t)wg * (9 * CAP * (CAP + 4));
   else La = Ly + nblk * 3 * NVP;
   const int nb = nblk > 0 ? nblk : 1; /* row stride of my A image */
 
@@ -569,25 +569,29 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
  * class-0 envs each.  All kinds use the same LDS bytes; class 3 (more than MSK_CLASS2_BLOCKS blocks: rare) keeps its
  * A image in global memory. */
 template <int NVP, int GL>
-__global__ void __launch_bounds__(64) k_csolve(const DModel* __restrict__ m, DState st, const int gm) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+MSK_DEV void csolve_block(const DModel* __restrict__ m, const DState& st, const int gm, const int blk, float* lds) {
   static_assert(CsLds<NVP, GL, GL>::TOTAL == CsLds<NVP, 64, MSK_CLASS2_BLOCKS>::TOTAL, "one LDS size for both kinds of workgroup");
   static_assert(MSK_CLASS3_BLOCKS * 3 * NVP <= CsLds<NVP, 64, MSK_CLASS2_BLOCKS>::POOL, "Y of the largest env fits the pool");
-  if (blockIdx.x == 0 && threadIdx.x == 0) *st.hq_count = 0;   /* the narrowphase has consumed the hull queue; the next broadphase refills it */
-  if ((int)blockIdx.x < gm) {
+  if (blk == 0 && threadIdx.x == 0) *st.hq_count = 0;   /* the narrowphase has consumed the hull queue; the next broadphase refills it */
+  if (blk < gm) {
     const int n3 = st.cls_count[3], n2 = st.cls_count[2], n1 = st.cls_count[1];
     const size_t N = (size_t)m->N;
-    for (int i = blockIdx.x; i < n3 + n2 + n1; i += gm) {
-      if (i < n3) solve_env<NVP, 64, MSK_CLASS3_BLOCKS, true>(m, st, st.cls_list + 3 * N, i, n3, lds);
-      else if (i < n3 + n2) solve_env<NVP, 64, MSK_CLASS2_BLOCKS, false>(m, st, st.cls_list + 2 * N, i - n3, n2, lds);
-      else solve_env<NVP, 64, MSK_CLASS2_BLOCKS, false>(m, st, st.cls_list + N, i - n3 - n2, n1, lds);
+    for (int i = blk; i < n3 + n2 + n1; i += gm) {
+      if (i < n3) solve_env<NVP, 64, MSK_CLASS3_BLOCKS, true>(m, st, st.cls_list + 3 * N, i, n3, lds, blk);
+      else if (i < n3 + n2) solve_env<NVP, 64, MSK_CLASS2_BLOCKS, false>(m, st, st.cls_list + 2 * N, i - n3, n2, lds, blk);
+      else solve_env<NVP, 64, MSK_CLASS2_BLOCKS, false>(m, st, st.cls_list + N, i - n3 - n2, n1, lds, blk);
       wave_sync();
     }
   } else {
-    const int count = st.cls_count[0], first = ((int)blockIdx.x - gm) * (64 / GL);
+    const int count = st.cls_count[0], first = (blk - gm) * (64 / GL);
     if (first >= count) return;
-    solve_env<NVP, GL, GL, false>(m, st, st.cls_list, first, count, lds);
+    solve_env<NVP, GL, GL, false>(m, st, st.cls_list, first, count, lds, blk);
   }
+}
+template <int NVP, int GL>
+__global__ void __launch_bounds__(64) k_csolve(const DModel* __restrict__ m, DState st, const int gm) {
+  extern __shared__ __attribute__((aligned(16))) float lds_cs[];
+  csolve_block<NVP, GL>(m, st, gm, blockIdx.x, lds_cs);
 }
 
 #endif
