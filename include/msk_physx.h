@@ -47,7 +47,7 @@ enum msk_shape_type { MSK_SHAPE_PLANE = 0, MSK_SHAPE_BOX = 1, MSK_SHAPE_SPHERE =
                       MSK_SHAPE_CYLINDER = 5 };
 
 /* Capacities of one env template (compile-time, shared by oracle and HIP library). */
-#define MSK_MAX_BODIES 48
+#define MSK_MAX_BODIES 64
 #define MSK_MAX_SHAPES 64
 #define MSK_MAX_DOF 32        /* articulation DoF per env (all articulations); dofs + 6 per free body <= MSK_MAX_NV */
 #define MSK_MAX_NV 32         /* generalized velocity size: art DoF + 6 per free body */

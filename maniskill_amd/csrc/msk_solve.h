@@ -37,6 +37,14 @@
 
 #define MSK_PEN_BETA 0.8f
 #define MSK_MAX_DEPEN_VEL 3.0f
+/* a row whose own response J W J^T is below this cannot be moved by an impulse (two links with no relative freedom along the normal:
+ * fixed-jointed siblings whose hulls overlap; round-off leaves ~1e-8, 1 / that turned one env of UnitreeG1TransportBox-v1 into NaNs):
+ * it takes no impulse -- PhysX's minimal-response test (recipResponse = 0).  Lightest response a real body gives: 1 / (1e6 kg). */
+#define MSK_MIN_RESPONSE 1.0e-6f
+/* and a limit / normal row hands over at most this per sweep (N s): overlapping hulls of links that can barely move relative to each
+ * other (response 1e-5: fingers of a hand at their zero pose) asked for 3e5 and more, and that momentum came back through the other
+ * rows.  Three orders of magnitude above anything a manipulation task produces (a 100 kg body stopped from 5 m/s: 500). */
+#define MSK_MAX_ROW_IMPULSE 1.0e3f
 #define MSK_SMALL_BLOCKS 16
 
 /* LDS hand-off inside a wavefront: DS instructions of one wave execute in issue order, so only the compiler has to be
@@ -370,9 +378,9 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
         a[0] = d0; a[1] = d1; a[2] = d2;
       }
       if (lane == blk) { /* my own diagonal */
-        if (s == 0) rinv[0] = 1.0f / d0;
-        if (s == 1) rinv[1] = 1.0f / d1;
-        if (s == 2) rinv[2] = 1.0f / d2;
+        if (s == 0) rinv[0] = d0 > MSK_MIN_RESPONSE ? 1.0f / d0 : 0.0f;
+        if (s == 1) rinv[1] = d1 > MSK_MIN_RESPONSE ? 1.0f / d1 : 0.0f;
+        if (s == 2) rinv[2] = d2 > MSK_MIN_RESPONSE ? 1.0f / d2 : 0.0f;
       }
       /* warm start: a += A[:, col] * lambda_0[col] (rows ascending == columns ascending) */
       const float l0 = Llamf[col];
@@ -410,9 +418,9 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
     }
   }
   /* clamp bounds without selects: hi = fma(flim, lam_n, hi_c), lo = fma(-flim, lam_n, 0)
-   *   contact block: flim = mu, hi_c = 0 -> +-mu*lam_n ; limit block (slot 1 = upper limit row): flim = 0, hi_c = inf -> [0, inf) */
+   *   contact block: flim = mu, hi_c = 0 -> +-mu*lam_n ; limit block (slot 1 = upper limit row): flim = 0, hi_c = cap -> [0, cap] */
   const float flim = is_contact ? mu : 0.0f;
-  const float hi_c = is_contact ? 0.0f : INFINITY;
+  const float hi_c = is_contact ? 0.0f : MSK_MAX_ROW_IMPULSE;
   auto sweep = [&](auto posit_tag) {
     constexpr bool POSIT = decltype(posit_tag)::value;
     /* sweep-invariant bias terms of my rows */
@@ -429,7 +437,7 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
                                             : (unsigned)((wrows >> (blk * 3)) & 7ull);
       /* new impulse = clamp(lam - (J.v + bias) / A_rr); a row that does not exist has rinv = lam = 0 -> stays 0 */
       if (rowbits & 1u) {
-        const float nl = fminf(fmaxf(fmaf(-av[0], rinv[0], lam[0] - t0), 0.0f), INFINITY);
+        const float nl = fminf(fmaxf(fmaf(-av[0], rinv[0], lam[0] - t0), 0.0f), MSK_MAX_ROW_IMPULSE);
         const float dl = group_bcast<GL>(nl - lam[0], blk);
         if (owner) lam[0] = nl;
         av[0] = fmaf(Ac[0], dl, av[0]); av[1] = fmaf(Ac[1], dl, av[1]); av[2] = fmaf(Ac[2], dl, av[2]);

@@ -32,6 +32,8 @@
 
 #define ORC_PEN_BETA 0.8f        /* penetration recovery rate: bias = beta * depth / dt   */
 #define ORC_MAX_DEPEN_VEL 3.0f   /* m/s cap on the penetration-recovery bias            */
+#define ORC_MAX_ROW_IMPULSE 1.0e3f /* N s per sweep on a limit / normal row (msk_solve.h MSK_MAX_ROW_IMPULSE) */
+#define ORC_MIN_RESPONSE 1.0e-6f /* J W J^T below this: the row takes no impulse (msk_solve.h MSK_MIN_RESPONSE) */
 #define ORC_WARM_DIST 5.0e-3f    /* contact matching radius for warm starting             */
 #define ORC_WARM_FACTOR 0.9f     /* fraction of last step's impulses applied up front     */
 #define ORC_LIMIT_DISTANCE 0.1f  /* a joint-limit row exists while q is within this of the limit */
@@ -504,7 +506,9 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
   /* constraint-space operator and initial state: a = J (v* + Y^T lambda_0) */
   for (int i = 0; i < nr; ++i) {
     for (int r = 0; r < nr; ++r) A[i][r] = dot_seq(rows[i].J, rows[r].Y, nv, s.npad);
-    rows[i].rinv = 1.0f / A[i][i];
+    /* a row without response of its own (two links with no relative freedom along the direction: PhysX's minimal-response test) takes
+     * no impulse: rinv = 0 keeps lambda at its clamp of 0 */
+    rows[i].rinv = A[i][i] > ORC_MIN_RESPONSE ? 1.0f / A[i][i] : 0.0f;
     float a = dot_seq(rows[i].J, s.vfree, nv, s.npad);
     /* restitution (PhysxMaterial.restitution, scene bounce_threshold: structs/types.py:35-67): a normal row approaching faster
      * than the threshold aims at the rebound speed -e * (approach speed) instead of zero */
@@ -532,7 +536,7 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
           if (posit) { if (!(cur > 0.0f)) bias = fminf(bias, r->rest); }
           else if (cur < r->vclose) bias = r->rest;
         }
-        lo = 0.0f; hi = INFINITY;
+        lo = 0.0f; hi = ORC_MAX_ROW_IMPULSE;
       } else { /* friction */
         bias = posit ? r->b * inv_h : 0.0f;
         hi = r->mu * lam_n; lo = -hi; /* == fma(+-mu, lam_n, 0) on the device */

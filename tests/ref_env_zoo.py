@@ -1,7 +1,7 @@
 """Runs inside a fresh interpreter (tests/test_reference_conformance.py): every listed env id of the REFERENCE's registry is built by the
 reference's own code over the sapien shim, reset and stepped with sampled actions; prints one JSON object {env_id: "ok" | reason}.
 
-    python tests/ref_env_zoo.py <oracle|hip> [steps] [env ids ...]
+    python tests/ref_env_zoo.py <oracle|hip> [steps] [env ids ...]      (ZOO_ENVS=<n> sub-scenes per task, default 2)
 """
 import json
 import sys
@@ -16,7 +16,9 @@ ENV_IDS = [
     "MS-HopperStand-v1", "RotateValveLevel0-v1", "RotateValveLevel1-v1", "RotateValveLevel2-v1", "RotateValveLevel3-v1", "RotateValveLevel4-v1",
     "RotateSingleObjectInHandLevel0-v1", "RotateSingleObjectInHandLevel1-v1", "TriFingerRotateCubeLevel0-v1", "TriFingerRotateCubeLevel1-v1",
     "TriFingerRotateCubeLevel2-v1", "TriFingerRotateCubeLevel3-v1", "TriFingerRotateCubeLevel4-v1", "UnitreeG1TransportBox-v1",
+    "UnitreeG1PlaceAppleInBowl-v1",
 ]
+NUM_ENVS = int(__import__("os").environ.get("ZOO_ENVS", "2"))
 NEEDS_RENDER_BODIES = {"PushT-v1"}   # its scene builder reads the render shapes it has just attached (push_t.py:53)
 
 
@@ -37,7 +39,7 @@ def main():
     for eid in ids:
         try:
             kw = {} if eid in NEEDS_RENDER_BODIES else dict(render_backend="none")
-            env = gym.make(eid, num_envs=2, **kw)
+            env = gym.make(eid, num_envs=NUM_ENVS, **kw)
             dev = env.unwrapped.device
             obs, _ = env.reset(seed=0)
             for _ in range(steps):

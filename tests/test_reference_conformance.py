@@ -66,9 +66,10 @@ def test_reference_suite_on_hip(built, node):
     assert rc == 0, out
 
 
-def _run_zoo(backend):
+def _run_zoo(backend, steps="3", ids=(), envs="2"):
     import json
-    r = subprocess.run([sys.executable, os.path.join(HERE, "ref_env_zoo.py"), backend, "3"], cwd=HERE, capture_output=True, text=True, timeout=3000)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "ref_env_zoo.py"), backend, steps, *ids], cwd=HERE, capture_output=True, text=True, timeout=3000,
+                       env=dict(os.environ, ZOO_ENVS=envs))
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("ZOO ")]
     assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
     return json.loads(line[-1][4:])
@@ -76,7 +77,7 @@ def _run_zoo(backend):
 
 @needs_ref
 def test_reference_env_zoo_on_cpu_checker(built):
-    """Every task of the reference's registry that needs no downloaded asset (35 of 74: tests/ref_env_zoo.py) is built by the reference's own
+    """Every task of the reference's registry that needs no downloaded asset (36 of 74: tests/ref_env_zoo.py) is built by the reference's own
     code over the shim -- Panda, Fetch-free tabletop tasks, two-robot tasks, SO100, the MJCF control tasks, D'Claw valves with a different
     valve per sub-scene, Allegro hand, TriFinger, Unitree G1 (fixed base) -- reset and stepped; observations, rewards and the raw
     simulation buffers stay finite."""
@@ -86,8 +87,17 @@ def test_reference_env_zoo_on_cpu_checker(built):
 
 
 @needs_ref
+def test_overlapping_link_hulls_stay_finite(built):
+    """UnitreeG1TransportBox-v1: the hand's finger links start with their convex hulls 2 cm inside each other and can barely move relative to each
+    other (row response 1e-5 .. 1e-9).  Rows below the minimal response take no impulse, the others at most MSK_MAX_ROW_IMPULSE per sweep
+    (msk_solve.h); before, the first control steps asked for 1e6 N s and the env went to NaN within five steps."""
+    res = _run_zoo("oracle", "40", ("UnitreeG1TransportBox-v1",), "4")
+    assert res == {"UnitreeG1TransportBox-v1": "ok"}, res
+
+
+@needs_ref
 @pytest.mark.gpu
 def test_reference_env_zoo_on_hip(built):
-    res = _run_zoo("hip")
+    res = _run_zoo("hip", "30", (), "8")
     bad = {k: v for k, v in res.items() if v != "ok"}
-    assert not bad and len(res) >= 35, bad
+    assert not bad and len(res) >= 36, bad
