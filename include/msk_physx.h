@@ -93,6 +93,13 @@ int msk_add_link(msk_ctx* ctx, int art, int parent_body, int joint_type,
                  float limit_lo, float limit_hi, float mass, const float com[3],
                  const float inertia6[6], int disable_gravity, float armature,
                  float joint_friction);
+/* fix_root_link = False (utils/building/articulation_builder.py:212; agents with a free base: mani_skill/agents/robots/anymal, unitree_*,
+ * the MJCF ant / humanoid of envs/tasks/control): the articulation's root link is not held by the world.  It gets six coordinates of
+ * its own -- the root's spatial velocity about the sub-scene origin (angular, then linear: Pluecker) -- that enter the joint-space
+ * inertia, the solver and the integration like joint coordinates do; qpos / qvel keep SAPIEN's layout (joints only), the root's pose
+ * and velocity travel in its row of rigid_body_data (msk_apply with MSK_APPLY_ART_ROOT_POSE / MSK_APPLY_ART_ROOT_VELOCITY).
+ * Call before msk_finalize; joint dofs + 6 per floating root <= MSK_MAX_DOF - 1. */
+int msk_set_articulation_floating(msk_ctx* ctx, int articulation);
 /* PhysxArticulationJoint.set_drive_properties (agents/controllers/pd_joint_pos.py:38-52) */
 int msk_set_drive(msk_ctx* ctx, int link_body, float stiffness, float damping,
                   float force_limit, int mode_acceleration);
@@ -166,7 +173,9 @@ enum msk_apply_mask {
    * a second apply before that step replaces the rows, it does not add.  Rows of kinematic actors and of
    * articulation links are ignored. */
   MSK_APPLY_RIGID_FORCE = 1 << 7,
-  MSK_APPLY_RIGID_TORQUE = 1 << 8
+  MSK_APPLY_RIGID_TORQUE = 1 << 8,
+  MSK_APPLY_ART_ROOT_VELOCITY = 1 << 9 /* gpu_apply_articulation_root_velocity: linear (centre of mass) and angular velocity of a floating root,
+                                        * columns 7..12 of its rigid_body_data row */
 };
 enum msk_fetch_mask {
   MSK_FETCH_RIGID_DATA = 1 << 0,   /* gpu_fetch_rigid_dynamic_data + link_pose/velocity  */

@@ -21,7 +21,7 @@ SHAPE_PLANE, SHAPE_BOX, SHAPE_SPHERE, SHAPE_CONVEX, SHAPE_CAPSULE, SHAPE_CYLINDE
  BUF_ART_TARGET_QVEL, BUF_RIGID_BODY_FORCE, BUF_RIGID_BODY_TORQUE, BUF_ART_LINK_JOINT_FORCES) = range(10)
 APPLY_RIGID_DATA, APPLY_ART_QPOS, APPLY_ART_QVEL, APPLY_ART_QF = 1, 2, 4, 8
 APPLY_ART_TARGET_QPOS, APPLY_ART_TARGET_QVEL, APPLY_ART_ROOT_POSE = 16, 32, 64
-APPLY_RIGID_FORCE, APPLY_RIGID_TORQUE = 128, 256
+APPLY_RIGID_FORCE, APPLY_RIGID_TORQUE, APPLY_ART_ROOT_VELOCITY = 128, 256, 512
 FETCH_RIGID_DATA, FETCH_ART_QPOS, FETCH_ART_QVEL, FETCH_ART_QACC, FETCH_ART_TARGETS, FETCH_ART_LINK_FORCES = 1, 2, 4, 8, 16, 32
 
 EXPORTS = [
@@ -30,7 +30,7 @@ EXPORTS = [
     "fetch", "update_kinematics", "step", "query_create_pairs", "query_create_bodies", "query_buffer", "query_run",
     "get_sizes", "get_contacts", "get_env_contact_counts", "timing_enable", "timing_read",
     "set_solver_classes", "get_solver_class_counts", "declare_env_box", "declare_env_mass", "set_env_boxes", "set_env_masses",
-    "bind_buffers", "batch",
+    "bind_buffers", "batch", "set_articulation_floating",
 ]
 # include/msk_render.h — camera pipeline (both libraries)
 RENDER_EXPORTS = ["render_add_mesh", "render_set_base_color", "render_bind_env_box", "render_set_lights", "render_finalize", "camera_create", "camera_buffer",
@@ -129,6 +129,7 @@ class NativeLib:
             "set_env_masses": (i32, [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
             "set_solver_classes": (i32, [vp, C.POINTER(C.c_int32)]),
             "get_solver_class_counts": (i32, [vp, C.POINTER(C.c_int32)]),
+            "set_articulation_floating": (i32, [vp, i32]),
             "bind_buffers": (i32, [vp, C.POINTER(C.c_void_p), C.c_int64]),
             "batch": (i32, [C.POINTER(C.c_void_p), i32, i32, u32, vp]),
             "timing_enable": (i32, [vp, i32]),

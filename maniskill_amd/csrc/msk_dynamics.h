@@ -51,6 +51,21 @@ enum { DV_QD = 0, DV_BIAS = 1, DV_KD = 2, DV_DD = 3, DV_FC = 4, DV_ERR = 5, DV_R
 MSK_DEV sv6 lds_sv6(const float* p) { sv6 r = {v3_make(p[0], p[1], p[2]), v3_make(p[3], p[4], p[5])}; return r; }
 MSK_DEV void lds_put_sv6(float* p, sv6 v) { p[0] = v.a.x; p[1] = v.a.y; p[2] = v.a.z; p[3] = v.l.x; p[4] = v.l.y; p[5] = v.l.z; }
 
+/* The six coordinates of a floating root are those of a free body: velocity of its centre of mass c (0..2), angular velocity (3..5).
+ * Unit motion a as a spatial vector about the env origin: translation (0; e), rotation about the axis through c (e; c x e);
+ * S_a . F for a spatial force F = (moment about the origin; force): the force component, the moment about c.  (oracle: root_unit / root_project) */
+MSK_DEV sv6 root_unit(int a, v3 c) {
+  sv6 u = sv6_zero();
+  const v3 ex = v3_make(a % 3 == 0 ? 1.0f : 0.0f, a % 3 == 1 ? 1.0f : 0.0f, a % 3 == 2 ? 1.0f : 0.0f);
+  if (a < 3) u.l = ex;
+  else { u.a = ex; u.l = v3_cross(c, ex); }
+  return u;
+}
+MSK_DEV void root_project(sv6 F, v3 c, float out[6]) {
+  const v3 mc = v3_add(F.a, v3_cross(F.l, c));
+  out[0] = F.l.x; out[1] = F.l.y; out[2] = F.l.z; out[3] = mc.x; out[4] = mc.y; out[5] = mc.z;
+}
+
 /* Forward pass shared by k_dynamics and k_kinematics: link frames, joint subspaces, spatial
  * velocities (and accelerations with zero joint acceleration), level by level.
  * Returns this lane's body frame; S/V/acc of every body are in LDS afterwards. */
@@ -64,6 +79,15 @@ MSK_DEV pose forward_pass(const DModel* m, const float* E, float* lds, const Dyn
   sv6 S = sv6_zero(), V = sv6_zero(), A = sv6_zero();
   if (has) {
     T = load_pose(E, m->lay.bpose, i);
+    if (b->kind == MSK_BODY_LINK && b->parent < 0 && b->root_dof >= 0) { /* floating root: (v of its centre of mass, omega) is state, as for a free body */
+      const float* qr = E + m->lay.qd + b->root_dof;
+      const v3 vc = v3_make(qr[0], qr[1], qr[2]), w = v3_make(qr[3], qr[4], qr[5]);
+      const m33 Rr = quat_to_m33(T.q);
+      const v3 cr = v3_add(T.p, m33_mulv(&Rr, b->com));
+      V.a = w;
+      V.l = v3_add(vc, v3_cross(cr, w));   /* Pluecker: velocity of the point at the env origin */
+      if (WITH_ACC) A.l = v3_cross(vc, w);  /* the angular unit motions turn about the moving centre of mass: d/dt (c x e) = v_c x e */
+    }
     float* pp = lds + ly.pose + i * 8;
     pp[0] = T.p.x; pp[1] = T.p.y; pp[2] = T.p.z; pp[3] = T.q.w; pp[4] = T.q.x; pp[5] = T.q.y; pp[6] = T.q.z;
     lds_put_sv6(lds + ly.S + i * 6, S);
@@ -291,6 +315,14 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
         Lm[di * LD + bj->dof] = v;
         Lm[bj->dof * LD + di] = v;
       }
+      if (bj->root_dof >= 0) { /* coupling with the floating root's six unit motions */
+        float Fc[6];
+        const float* pj = lds + ly.pose + j * 8;
+        const m33 Rj = quat_to_m33(quat_make(pj[3], pj[4], pj[5], pj[6]));
+        root_project(F, v3_add(v3_make(pj[0], pj[1], pj[2]), m33_mulv(&Rj, bj->com)), Fc);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { Lm[di * LD + bj->root_dof + a] = Fc[a]; Lm[(bj->root_dof + a) * LD + di] = Fc[a]; }
+      }
       j = bj->parent;
     }
     float* sc = Senv + di * 8;   /* motion subspace column of coordinate di, for the row assembly */
@@ -300,6 +332,28 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
     vec[DV_DD * MD + di] = b->D;
     vec[DV_FC * MD + di] = 0.0f;
     vec[DV_ERR * MD + di] = E[m->lay.q + di] - E[m->lay.qt + di];
+  }
+  if (link && b->root_dof >= 0) { /* floating root: bias = the accumulated wrench, root block = the tree's composite inertia column by column */
+    const int rd = b->root_dof;
+    if (live) store_v3(E, m->lay.comw, i, comw);   /* the solver integrates the root like a free body: about its centre of mass */
+    float fc[6];
+    root_project(f, comw, fc);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const sv6 u = root_unit(a, comw);
+      const sv6 F = sinertia_mul(&Ic, u);
+      float Fc[6];
+      root_project(F, comw, Fc);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) Lm[(rd + r) * LD + rd + a] = Fc[r];
+      vec[DV_BIAS * MD + rd + a] = fc[a];
+      vec[DV_KD * MD + rd + a] = 0.0f;
+      vec[DV_DD * MD + rd + a] = 0.0f;
+      vec[DV_FC * MD + rd + a] = 0.0f;
+      vec[DV_ERR * MD + rd + a] = 0.0f;
+      float* sc = Senv + (rd + a) * 8;
+      sc[0] = u.a.x; sc[1] = u.a.y; sc[2] = u.a.z; sc[3] = u.l.x; sc[4] = u.l.y; sc[5] = u.l.z;
+    }
   }
   dyn_sync();
 

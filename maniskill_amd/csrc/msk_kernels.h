@@ -380,6 +380,11 @@ MSK_DEV void apply_block(const DModel* __restrict__ m, const DState& st, const D
         store_v3(E, m->lay.bang, i, v3_make(r[10], r[11], r[12]));
       }
     }
+    if (is_root && b->root_dof >= 0 && (mask & MSK_APPLY_ART_ROOT_VELOCITY)) { /* the root's six coordinates ARE (v_com, omega) */
+      float* qd = E + m->lay.qd + b->root_dof;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) qd[k] = r[7 + k];
+    }
   }
   for (int a = 0; a < m->na; ++a)
     for (int j = 0; j < art_ndof[a]; ++j) {

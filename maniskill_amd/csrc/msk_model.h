@@ -24,6 +24,7 @@ struct EnvLayout { int q, qd, qacc, qf, qt, qdt, off, bpose, blin, bang, comw, x
 
 struct DBody {
   int kind, art, parent, jtype, dof, vofs, nograv, movable;
+  int root_dof;   /* root link of a floating articulation: first of its six coordinates (angular 3, linear 3: Pluecker about the env origin), else -1 */
   pose Xp, XcInv;
   float lim_lo, lim_hi, mass;
   v3 com;
@@ -67,6 +68,8 @@ struct DModel {
   int npp;                             /* np padded to a multiple of G (contact slot stride)     */
   unsigned long long coord_moves[MSK_MAX_NV]; /* bit b: coordinate k moves body b                */
   int coord_body[MSK_MAX_NV];          /* free body whose first coordinate is k, else -1         */
+  int coord_root[MSK_MAX_NV];          /* floating root link whose first coordinate is k, else -1 */
+  unsigned char dof_body_is_root[MSK_MAX_DOF]; /* dof d is one of a floating root's six coordinates */
   unsigned body_coords[MSK_MAX_BODIES]; /* bit k: coordinate k moves body b (transpose of coord_moves) */
   float dof_lo[MSK_MAX_DOF], dof_hi[MSK_MAX_DOF];
   DPairInfo pinfo[MSK_MAX_PAIRS];

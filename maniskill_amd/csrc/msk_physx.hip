@@ -47,7 +47,7 @@ struct msk_ctx {
   DModel* d_model;
   DState st;
   DBuffers bufs;
-  int art_root[8], art_dof0[8], art_ndof[8];
+  int art_root[8], art_dof0[8], art_ndof[8], art_floating[8];
   int *d_art_dof0, *d_art_ndof;
   int max_dof;
   int ndisabled;
@@ -173,8 +173,16 @@ MSK_API int msk_add_articulation(msk_ctx* c, const float root_pose[7]) {
   c->art_root[m.na] = -1;
   c->art_dof0[m.na] = m.nd;
   c->art_ndof[m.na] = 0;
+  c->art_floating[m.na] = 0;
   c->pending_root = pose_from7(root_pose);
   return m.na++;
+}
+
+MSK_API int msk_set_articulation_floating(msk_ctx* c, int art) {
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "set_articulation_floating after finalize");
+  if (art < 0 || art >= c->model.na) return fail(c, MSK_ERR_INVALID, "set_articulation_floating: no such articulation");
+  c->art_floating[art] = 1;
+  return MSK_OK;
 }
 
 MSK_API int msk_add_link(msk_ctx* c, int art, int parent_body, int joint_type, const float pose_in_parent[7],
@@ -199,7 +207,7 @@ MSK_API int msk_add_link(msk_ctx* c, int art, int parent_body, int joint_type, c
   memcpy(b->I6, inertia6, sizeof(b->I6));
   b->nograv = disable_gravity;
   b->armature = armature;
-  b->dof = -1; b->vofs = -1;
+  b->dof = -1; b->vofs = -1; b->root_dof = -1;
   memset(&c->init_pose[m.nb], 0, sizeof(pose));
   c->init_pose[m.nb].q.w = 1.0f;
   if (parent_body < 0) {
@@ -259,7 +267,7 @@ MSK_API int msk_add_actor(msk_ctx* c, int kind, const float pose7[7], float mass
   if (kind != MSK_BODY_KINEMATIC && kind != MSK_BODY_DYNAMIC) return fail(c, MSK_ERR_INVALID, "bad actor kind");
   DBody* b = &m.bodies[m.nb];
   memset(b, 0, sizeof(*b));
-  b->kind = kind; b->art = -1; b->parent = -1; b->dof = -1; b->vofs = -1;
+  b->kind = kind; b->art = -1; b->parent = -1; b->dof = -1; b->vofs = -1; b->root_dof = -1;
   c->init_pose[m.nb] = pose_from7(pose7);
   b->mass = mass;
   b->com.x = com[0]; b->com.y = com[1]; b->com.z = com[2];
@@ -396,6 +404,19 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   if (!m.cfg.enable_tgs) return fail(c, MSK_ERR_INVALID, "only the TGS solver is implemented");
   if (num_envs <= 0) return fail(c, MSK_ERR_INVALID, "num_envs must be positive");
   HIP_TRY(hipSetDevice(c->device));
+  /* floating roots: six coordinates each, behind the joint dofs (qpos / qvel keep the joints-only layout) */
+  for (int a = 0; a < m.na; ++a) {
+    if (!c->art_floating[a] || c->art_root[a] < 0) continue;
+    if (m.nd + 6 > MSK_MAX_DOF - 1) return fail(c, MSK_ERR_CAPACITY, "too many dofs (31 per sub-scene, 6 per floating root)");
+    m.bodies[c->art_root[a]].root_dof = m.nd;
+    m.nd += 6;
+  }
+  for (int i = 0; i < m.nb; ++i) { /* links below a floating root move even behind fixed joints */
+    DBody* b = &m.bodies[i];
+    if (b->kind != MSK_BODY_LINK) continue;
+    if (b->parent < 0) b->movable = b->root_dof >= 0;
+    else b->movable = (b->dof >= 0) || m.bodies[b->parent].movable;
+  }
   m.nv = m.nd;
   for (int i = 0; i < m.nb; ++i)
     if (m.bodies[i].kind == MSK_BODY_DYNAMIC) { m.bodies[i].vofs = m.nv; m.nv += 6; }
@@ -419,13 +440,21 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   m.G = (m.nv <= 16) ? 16 : 32;
   m.npp = ((m.np + m.G - 1) / m.G) * m.G;
   if (m.npp == 0) m.npp = m.G;
-  for (int k = 0; k < MSK_MAX_NV; ++k) { m.coord_moves[k] = 0; m.coord_body[k] = -1; }
+  for (int k = 0; k < MSK_MAX_NV; ++k) { m.coord_moves[k] = 0; m.coord_body[k] = -1; m.coord_root[k] = -1; }
+  for (int k = 0; k < MSK_MAX_DOF; ++k) m.dof_body_is_root[k] = 0;
   for (int i = 0; i < m.nb; ++i) {
     const DBody* b = &m.bodies[i];
     if (b->kind == MSK_BODY_LINK) {
       if (b->dof >= 0) { m.dof_lo[b->dof] = b->lim_lo; m.dof_hi[b->dof] = b->lim_hi; }
-      for (int j = i; j >= 0; j = m.bodies[j].parent)
+      if (b->root_dof >= 0) {
+        m.coord_root[b->root_dof] = i;
+        for (int a = 0; a < 6; ++a) { m.dof_lo[b->root_dof + a] = -3.0e38f; m.dof_hi[b->root_dof + a] = 3.0e38f; m.dof_body[b->root_dof + a] = i; m.dof_body_is_root[b->root_dof + a] = 1; }
+      }
+      for (int j = i; j >= 0; j = m.bodies[j].parent) {
         if (m.bodies[j].dof >= 0) m.coord_moves[m.bodies[j].dof] |= 1ull << i;
+        if (m.bodies[j].root_dof >= 0)
+          for (int a = 0; a < 6; ++a) m.coord_moves[m.bodies[j].root_dof + a] |= 1ull << i;
+      }
     } else if (b->kind == MSK_BODY_DYNAMIC) {
       for (int a = 0; a < 6; ++a) m.coord_moves[b->vofs + a] = 1ull << i;
       m.coord_body[b->vofs] = i;

@@ -546,8 +546,20 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   if (active && lane < nd) {
     const float q = E[m->lay.q + lane], qd = E[m->lay.qd + lane];
     E[m->lay.qacc + lane] = (v - qd) / dt;
-    E[m->lay.q + lane] = q + dq;
+    E[m->lay.q + lane] = m->dof_body_is_root[lane] ? 0.0f : q + dq;   /* a floating root's six slots carry no position: its pose does */
     E[m->lay.qd + lane] = v;
+  }
+  const int fr = (active && lane < nd) ? m->coord_root[lane] : -1;
+  if (fr >= 0) { /* floating root: integrated like the free bodies below (its six coordinates are v of its centre of mass, omega) */
+    const int k = lane;
+    const v3 dx = v3_make(Lvd[NVP + k], Lvd[NVP + k + 1], Lvd[NVP + k + 2]);
+    const v3 dr = v3_make(Lvd[NVP + k + 3], Lvd[NVP + k + 4], Lvd[NVP + k + 5]);
+    const v3 cw = v3_add(load_v3(E, m->lay.comw, fr), dx);
+    pose T = load_pose(E, m->lay.bpose, fr);
+    const quat qn = quat_normalize(quat_mul(quat_from_rotvec(dr), T.q));
+    T.q = qn;
+    T.p = v3_sub(cw, quat_rotate(qn, m->bodies[fr].com));
+    store_pose(E, m->lay.bpose, fr, T);
   }
   const int fb = (active && lane < nv) ? m->coord_body[lane] : -1;
   if (fb >= 0) {

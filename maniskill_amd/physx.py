@@ -88,8 +88,11 @@ class SceneTemplate:
         self.nshapes = 0
 
     # -- articulations ----------------------------------------------------------------
-    def add_articulation(self, name, root_p=(0, 0, 0), root_q=(1, 0, 0, 0)) -> int:
+    def add_articulation(self, name, root_p=(0, 0, 0), root_q=(1, 0, 0, 0), floating=False) -> int:
+        """floating: fix_root_link = False -- the root link gets six coordinates of its own (msk_set_articulation_floating)."""
         self.ops.append(("add_articulation", (_pose7(root_p, root_q),)))
+        if floating:
+            self.ops.append(("set_articulation_floating", (len(self.art_names),)))
         self.art_names.append(name)
         self.art_links.append([])
         self.art_active.append([])
@@ -274,6 +277,8 @@ class PhysxGpuSystem:
             elif op == "add_link":
                 L.check(ctx, L.add_link(ctx, a[0], a[1], a[2], N._fa(a[3], 7), N._fa(a[4], 7), a[5], a[6], a[7],
                                         N._fa(a[8], 3), N._fa(a[9], 6), a[10], a[11], a[12]), op)
+            elif op == "set_articulation_floating":
+                L.check(ctx, L.set_articulation_floating(ctx, a[0]), op)
             elif op == "set_drive":
                 L.check(ctx, L.set_drive(ctx, *a), op)
             elif op == "add_tendon":
@@ -377,7 +382,7 @@ class PhysxGpuSystem:
     def gpu_apply_rigid_dynamic_force(self): self._apply(N.APPLY_RIGID_FORCE)     # acts during the next step() only
     def gpu_apply_rigid_dynamic_torque(self): self._apply(N.APPLY_RIGID_TORQUE)
     def gpu_apply_articulation_root_pose(self): self._apply(N.APPLY_ART_ROOT_POSE)
-    def gpu_apply_articulation_root_velocity(self): pass  # fixed-base articulations only
+    def gpu_apply_articulation_root_velocity(self): self._apply(N.APPLY_ART_ROOT_VELOCITY)   # floating roots; ignored by fixed ones
     def gpu_apply_articulation_qpos(self): self._apply(N.APPLY_ART_QPOS)
     def gpu_apply_articulation_qvel(self): self._apply(N.APPLY_ART_QVEL)
     def gpu_apply_articulation_qf(self): self._apply(N.APPLY_ART_QF)

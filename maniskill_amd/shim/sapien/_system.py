@@ -375,11 +375,9 @@ class PhysxSystem:
             elif isinstance(c, P.PhysxArticulationLinkComponent):
                 art = c.articulation
                 if id(art) not in art_ids:
-                    if art.root.joint._type != "fixed":
-                        raise RuntimeError(f"articulation {art.name!r}: only fixed-base articulations are supported "
-                                           "(fix_root_link=True); free roots are not")
                     rp = art.root.entity._pose
-                    art_ids[id(art)] = tpl.add_articulation(art.name, rp._p, rp._q)
+                    # fix_root_link = False (articulation_builder.py:212): the root link gets six coordinates of its own (msk_set_articulation_floating)
+                    art_ids[id(art)] = tpl.add_articulation(art.name, rp._p, rp._q, floating=art.root.joint._type != "fixed")
                     arts0.append(art)
                 a = art_ids[id(art)]
                 j = c.joint
@@ -574,6 +572,12 @@ class PhysxSystem:
         row[col0:col0 + 3] = torch.as_tensor(vals.reshape(3), device=row.device)
         self._do("apply", "gpu_apply_rigid_dynamic_data", ("rigid_body_data",))
 
+    def _write_root_velocity(self, comp, col0, vals):
+        self._sync_in()
+        row = self.cuda_rigid_body_data.torch()[self._pose_index(comp)]
+        row[col0:col0 + 3] = torch.as_tensor(vals.reshape(3), device=row.device)
+        self._do("apply", "gpu_apply_articulation_root_velocity", ())
+
     def _art_buf(self, name):
         return getattr(self, "cuda_articulation_" + name).torch()
 
@@ -639,7 +643,7 @@ class PhysxSystem:
             cls._BATCH = {
                 "gpu_apply_rigid_dynamic_data": (A, N.APPLY_RIGID_DATA), "gpu_apply_rigid_dynamic_force": (A, N.APPLY_RIGID_FORCE),
                 "gpu_apply_rigid_dynamic_torque": (A, N.APPLY_RIGID_TORQUE), "gpu_apply_articulation_root_pose": (A, N.APPLY_ART_ROOT_POSE),
-                "gpu_apply_articulation_root_velocity": None, "gpu_apply_articulation_qpos": (A, N.APPLY_ART_QPOS),
+                "gpu_apply_articulation_root_velocity": (A, N.APPLY_ART_ROOT_VELOCITY), "gpu_apply_articulation_qpos": (A, N.APPLY_ART_QPOS),
                 "gpu_apply_articulation_qvel": (A, N.APPLY_ART_QVEL), "gpu_apply_articulation_qf": (A, N.APPLY_ART_QF),
                 "gpu_apply_articulation_target_position": (A, N.APPLY_ART_TARGET_QPOS),
                 "gpu_apply_articulation_target_velocity": (A, N.APPLY_ART_TARGET_QVEL),

@@ -1022,16 +1022,25 @@ class PhysxArticulation:
     def get_qacc(self):
         return self.qacc
 
+    def _root_floating(self):
+        return self.root.joint._type != "fixed"
+
     def set_root_linear_velocity(self, v):
-        pass     # fixed-base articulations only
+        if self._root_floating() and self._system is not None and self._system._initialized:
+            self._system._write_root_velocity(self.root, 7, np.asarray(v, dtype=np.float32))
 
     def set_root_angular_velocity(self, v):
-        pass
+        if self._root_floating() and self._system is not None and self._system._initialized:
+            self._system._write_root_velocity(self.root, 10, np.asarray(v, dtype=np.float32))
 
     def get_root_linear_velocity(self):
+        if self._root_floating() and self._system is not None and self._system._initialized:
+            return self._system._read_body_row(self.root)[7:10]
         return np.zeros(3, dtype=np.float32)
 
     def get_root_angular_velocity(self):
+        if self._root_floating() and self._system is not None and self._system._initialized:
+            return self._system._read_body_row(self.root)[10:13]
         return np.zeros(3, dtype=np.float32)
 
     def get_link_incoming_joint_forces(self):

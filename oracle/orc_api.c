@@ -51,6 +51,7 @@ ORC_EXPORT int orc_add_articulation(orc_ctx* c, const float root_pose[7]) {
   c->art_root[c->na] = -1;
   c->art_dof0[c->na] = c->ndof;
   c->art_ndof[c->na] = 0;
+  c->art_floating[c->na] = 0;
   /* root pose is attached to the root link when it is added */
   orc_body* tmp = &c->bodies[MSK_MAX_BODIES - 1];
   tmp->init_pose = pose_from7(root_pose);
@@ -79,7 +80,7 @@ ORC_EXPORT int orc_add_link(orc_ctx* c, int art, int parent_body, int joint_type
   memcpy(b->I6, inertia6, sizeof(b->I6));
   b->nograv = disable_gravity;
   b->armature = armature; b->jfriction = joint_friction;
-  b->dof = -1; b->vofs = -1;
+  b->dof = -1; b->vofs = -1; b->root_dof = -1;
   if (parent_body < 0) {
     b->init_pose = root;
     c->art_root[art] = c->nb;
@@ -93,6 +94,13 @@ ORC_EXPORT int orc_add_link(orc_ctx* c, int art, int parent_body, int joint_type
     b->movable = (b->dof >= 0) || c->bodies[parent_body].movable;
   }
   return c->nb++;
+}
+
+ORC_EXPORT int orc_set_articulation_floating(orc_ctx* c, int art) {
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "set_articulation_floating after finalize");
+  if (art < 0 || art >= c->na) return fail(c, MSK_ERR_INVALID, "set_articulation_floating: no such articulation");
+  c->art_floating[art] = 1;
+  return MSK_OK;
 }
 
 ORC_EXPORT int orc_set_drive(orc_ctx* c, int link_body, float K, float D, float force_limit, int mode_acc) {
@@ -251,6 +259,19 @@ static void env_reset(const orc_ctx* c, orc_env* e) {
 ORC_EXPORT int orc_finalize(orc_ctx* c, int num_envs) {
   if (c->finalized) return fail(c, MSK_ERR_INVALID, "finalize twice");
   if (!c->cfg.enable_tgs) return fail(c, MSK_ERR_INVALID, "only the TGS solver is implemented");
+  /* floating roots: six coordinates each, behind the joint dofs (qpos / qvel keep the joints-only layout) */
+  for (int a = 0; a < c->na; ++a) {
+    if (!c->art_floating[a] || c->art_root[a] < 0) continue;
+    if (c->ndof + 6 > MSK_MAX_DOF - 1) return fail(c, MSK_ERR_CAPACITY, "too many dofs (31 per sub-scene, 6 per floating root)");
+    c->bodies[c->art_root[a]].root_dof = c->ndof;
+    c->ndof += 6;
+  }
+  for (int i = 0; i < c->nb; ++i) { /* links below a floating root move even behind fixed joints */
+    orc_body* b = &c->bodies[i];
+    if (b->kind != MSK_BODY_LINK) continue;
+    if (b->parent < 0) b->movable = b->root_dof >= 0;
+    else b->movable = (b->dof >= 0) || c->bodies[b->parent].movable;
+  }
   c->nv = c->ndof;
   for (int i = 0; i < c->nb; ++i)
     if (c->bodies[i].kind == MSK_BODY_DYNAMIC) { c->bodies[i].vofs = c->nv; c->nv += 6; }
@@ -383,6 +404,10 @@ ORC_EXPORT int orc_apply(orc_ctx* c, uint32_t mask, void* stream) {
           env->blin[i] = v3_make(r[7], r[8], r[9]);
           env->bang[i] = v3_make(r[10], r[11], r[12]);
         }
+      }
+      if (is_root && b->root_dof >= 0 && (mask & MSK_APPLY_ART_ROOT_VELOCITY)) { /* the root's six coordinates ARE (v_com, omega) */
+        float* qd = env->qd + b->root_dof;
+        for (int k = 0; k < 6; ++k) qd[k] = r[7 + k];
       }
     }
     for (int a = 0; a < c->na; ++a)

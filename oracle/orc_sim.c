@@ -99,6 +99,12 @@ static void kinematics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
     }
     m33 R = quat_to_m33(e->bpose[i].q);
     s->comw[i] = v3_add(e->bpose[i].p, m33_mulv(&R, b->com));
+    if (b->kind == MSK_BODY_LINK && b->parent < 0 && b->root_dof >= 0) { /* floating root: (v of its centre of mass, omega) is state, as for a free body */
+      const float* qr = e->qd + b->root_dof;
+      const v3 vc = v3_make(qr[0], qr[1], qr[2]), w = v3_make(qr[3], qr[4], qr[5]);
+      s->V[i].a = w;
+      s->V[i].l = v3_add(vc, v3_cross(s->comw[i], w));   /* Pluecker: velocity of the point at the env origin */
+    }
     sym6_rotate(&R, b->I6, s->Iw[i]);
     if (b->kind == MSK_BODY_LINK) {
       /* published velocities: angular, and linear velocity of the COM */
@@ -120,6 +126,21 @@ static void kinematics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
 void orc_forward_kinematics(const orc_ctx* c, orc_env* e) {
   orc_scratch s;
   kinematics(c, e, &s);
+}
+
+/* The six coordinates of a floating root are those of a free body: velocity of its centre of mass c (0..2), angular velocity (3..5).
+ * Unit motion a as a spatial vector about the env origin: translation (0; e), rotation about the axis through c (e; c x e);
+ * S_a . F for a spatial force F = (moment about the origin; force): the force component, the moment about c. */
+static sv6 root_unit(int a, v3 c) {
+  sv6 u = sv6_zero();
+  const v3 ex = v3_make(a % 3 == 0 ? 1.0f : 0.0f, a % 3 == 1 ? 1.0f : 0.0f, a % 3 == 2 ? 1.0f : 0.0f);
+  if (a < 3) u.l = ex;
+  else { u.a = ex; u.l = v3_cross(c, ex); }
+  return u;
+}
+static void root_project(sv6 F, v3 c, float out[6]) {
+  const v3 mc = v3_add(F.a, v3_cross(F.l, c));
+  out[0] = F.l.x; out[1] = F.l.y; out[2] = F.l.z; out[3] = mc.x; out[4] = mc.y; out[5] = mc.z;
 }
 
 /* ---- 2. dynamics ------------------------------------------------------------------ */
@@ -151,6 +172,10 @@ static void dynamics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
     Ic[i] = Isp[i];
     if (b->parent < 0) {
       acc[i] = sv6_zero();
+      if (b->root_dof >= 0) { /* the angular unit motions turn about the moving centre of mass: d/dt (c x e) = v_c x e */
+        const float* qr = e->qd + b->root_dof;
+        acc[i].l = v3_cross(v3_make(qr[0], qr[1], qr[2]), v3_make(qr[3], qr[4], qr[5]));
+      }
     } else {
       acc[i] = acc[b->parent];
       if (b->dof >= 0) {
@@ -171,6 +196,7 @@ static void dynamics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
     const orc_body* b = &c->bodies[i];
     if (b->kind != MSK_BODY_LINK) continue;
     if (b->dof >= 0) bias[b->dof] = sv6_dot(s->S[i], f[i]);
+    if (b->root_dof >= 0) root_project(f[i], s->comw[i], bias + b->root_dof);   /* the accumulated wrench: force, moment about the root's centre of mass */
     if (b->parent >= 0) {
       f[b->parent] = sv6_add(f[b->parent], f[i]);
       sinertia_acc(&Ic[b->parent], &Ic[i]);
@@ -190,11 +216,27 @@ static void dynamics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
         M[b->dof][bj->dof] = v;
         M[bj->dof][b->dof] = v;
       }
+      if (bj->root_dof >= 0) { /* coupling with the floating root's six unit motions */
+        float Fc[6];
+        root_project(F, s->comw[j], Fc);
+        for (int a = 0; a < 6; ++a) { M[b->dof][bj->root_dof + a] = Fc[a]; M[bj->root_dof + a][b->dof] = Fc[a]; }
+      }
       j = bj->parent;
+    }
+  }
+  for (int i = 0; i < c->nb; ++i) { /* root blocks: the composite spatial inertia of the whole tree, column by column */
+    const orc_body* b = &c->bodies[i];
+    if (b->kind != MSK_BODY_LINK || b->root_dof < 0) continue;
+    for (int a = 0; a < 6; ++a) {
+      const sv6 F = sinertia_mul(&Ic[i], root_unit(a, s->comw[i]));
+      float Fc[6];
+      root_project(F, s->comw[i], Fc);
+      for (int r = 0; r < 6; ++r) M[b->root_dof + r][b->root_dof + a] = Fc[r];
     }
   }
   /* implicit PD drives / tendons: A = M + dt*D + dt^2*K; saturated drives become constant forces */
   float Kd[MSK_MAX_DOF], Dd[MSK_MAX_DOF], fconst[MSK_MAX_DOF], fmaxd[MSK_MAX_DOF], err[MSK_MAX_DOF];
+  for (int i = 0; i < nd; ++i) { Kd[i] = 0.0f; Dd[i] = 0.0f; fconst[i] = 0.0f; fmaxd[i] = 0.0f; err[i] = 0.0f; }   /* root coordinates: no drive */
   for (int i = 0; i < c->nb; ++i) {
     const orc_body* b = &c->bodies[i];
     if (b->kind != MSK_BODY_LINK || b->dof < 0) continue;
@@ -414,8 +456,13 @@ static void coordinate_tables(const orc_ctx* c, const orc_env* e, orc_scratch* s
     const orc_body* b = &c->bodies[i];
     if (b->kind == MSK_BODY_LINK) {
       if (b->dof >= 0) s->Scol[b->dof] = s->S[i];
-      for (int j = i; j >= 0; j = c->bodies[j].parent)
+      if (b->root_dof >= 0)
+        for (int a = 0; a < 6; ++a) s->Scol[b->root_dof + a] = root_unit(a, s->comw[i]);
+      for (int j = i; j >= 0; j = c->bodies[j].parent) {
         if (c->bodies[j].dof >= 0) s->moves[c->bodies[j].dof] |= (uint64_t)1 << i;
+        if (c->bodies[j].root_dof >= 0)
+          for (int a = 0; a < 6; ++a) s->moves[c->bodies[j].root_dof + a] |= (uint64_t)1 << i;
+      }
     } else if (b->kind == MSK_BODY_DYNAMIC) {
       const v3 ex[3] = {v3_make(1, 0, 0), v3_make(0, 1, 0), v3_make(0, 0, 1)};
       const float mass_i = (c->xb_slot[i] >= 0) ? c->xbody[((size_t)(e - c->envs) * c->nxb + c->xb_slot[i]) * 8] : b->mass;
@@ -575,6 +622,17 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
     e->qacc[i] = (v[i] - e->qd[i]) / dt;
     e->q[i] += dq[i];
     e->qd[i] = v[i];
+  }
+  for (int i = 0; i < c->nb; ++i) { /* floating roots: integrated like the free bodies below */
+    const orc_body* b = &c->bodies[i];
+    if (b->kind != MSK_BODY_LINK || b->root_dof < 0) continue;
+    const int rd = b->root_dof;
+    const v3 dx = v3_make(dq[rd + 0], dq[rd + 1], dq[rd + 2]), dr = v3_make(dq[rd + 3], dq[rd + 4], dq[rd + 5]);
+    const v3 cw = v3_add(s.comw[i], dx);
+    const quat qn = quat_normalize(quat_mul(quat_from_rotvec(dr), e->bpose[i].q));
+    e->bpose[i].q = qn;
+    e->bpose[i].p = v3_sub(cw, quat_rotate(qn, b->com));
+    for (int a = 0; a < 6; ++a) e->q[rd + a] = 0.0f;   /* these slots carry no position: the pose does */
   }
   for (int i = 0; i < c->nb; ++i) {
     const orc_body* b = &c->bodies[i];

@@ -33,6 +33,7 @@ typedef struct {
   int nograv;
   float armature, jfriction;
   int dof;           /* index into q (articulation dof) or -1 */
+  int root_dof;      /* root link of a floating articulation: first of its six coordinates (angular 3, linear 3), else -1 */
   int vofs;          /* offset into the generalized velocity vector (free bodies), or -1 */
   float K, D, fmax;  /* drive */
   int drive_accel;
@@ -102,6 +103,7 @@ typedef struct orc_ctx {
   int max_links;     /* per-articulation max link count */
   int link_slot[MSK_MAX_BODIES]; /* index of a link within its articulation (build order), -1 for other bodies */
   int art_dof0[8], art_ndof[8];
+  int art_floating[8];
   int num_envs;
   orc_env* envs;
   float* offsets;    /* num_envs*3 */

@@ -17,6 +17,8 @@ ENV_IDS = [
     "RotateSingleObjectInHandLevel0-v1", "RotateSingleObjectInHandLevel1-v1", "TriFingerRotateCubeLevel0-v1", "TriFingerRotateCubeLevel1-v1",
     "TriFingerRotateCubeLevel2-v1", "TriFingerRotateCubeLevel3-v1", "TriFingerRotateCubeLevel4-v1", "UnitreeG1TransportBox-v1",
     "UnitreeG1PlaceAppleInBowl-v1",
+    # free-floating roots (fix_root_link = False: msk_set_articulation_floating)
+    "MS-AntWalk-v1", "MS-AntRun-v1", "MS-HumanoidStand-v1", "MS-HumanoidWalk-v1", "MS-HumanoidRun-v1",
 ]
 NUM_ENVS = int(__import__("os").environ.get("ZOO_ENVS", "2"))
 NEEDS_RENDER_BODIES = {"PushT-v1"}   # its scene builder reads the render shapes it has just attached (push_t.py:53)

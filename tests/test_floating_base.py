@@ -1,0 +1,160 @@
+"""Floating-base articulations (msk_set_articulation_floating; fix_root_link = False in utils/building/articulation_builder.py:212): the root
+link owns six coordinates -- its spatial velocity about the sub-scene origin.  Known answers for the CPU checker: a one-link floating
+articulation IS a free rigid body (same trajectory as the same box as a dynamic actor, thrown with spin onto the table), momentum of a
+free-flying two-link chain whose joint is driven, the parabola of its centre of mass under gravity; then HIP == checker."""
+import numpy as np
+import pytest
+import torch
+
+from maniskill_amd import _native as N
+from maniskill_amd.envs import scene_builders as sb
+from maniskill_amd.physx import SceneTemplate, SimConfig
+
+HALF = (0.03, 0.02, 0.015)
+MASS = 0.4
+I6 = tuple(MASS / 3 * (HALF[(k + 1) % 3] ** 2 + HALF[(k + 2) % 3] ** 2) for k in range(3)) + (0, 0, 0)
+
+
+ISO = (1.2e-4, 1.2e-4, 1.2e-4, 0, 0, 0)
+
+
+def _box_world(factory, n, as_articulation, gravity=(0, 0, -9.81), I6=ISO):
+    tpl = SceneTemplate()
+    sb.add_table_scene(tpl)
+    if as_articulation:
+        art = tpl.add_articulation("box", floating=True)
+        body = tpl.add_link(art, "base", -1, N.JOINT_FIXED, mass=MASS, inertia6=I6)
+    else:
+        body = tpl.add_actor("box", N.BODY_DYNAMIC, mass=MASS, inertia6=I6, angular_damping=0.0)
+    tpl.add_shape(body, N.SHAPE_BOX, params=HALF)
+    cfg = SimConfig()
+    cfg.scene_config.gravity = tuple(gravity)
+    px = factory(tpl, n, cfg)
+    px.gpu_init()
+    px.set_scene_offsets(np.zeros((n, 3)))
+    rbd = px.cuda_rigid_body_data.torch().view(n, px.bodies_per_env, 13)
+    rbd[:, tpl.body_id("table-workspace"), :7] = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)]).to(rbd.device)
+    q = np.array([0.9, 0.1, 0.3, -0.2]); q /= np.linalg.norm(q)
+    rbd[:, body, :3] = torch.tensor([0.05, -0.02, 0.25]).to(rbd.device)
+    rbd[:, body, 3:7] = torch.tensor(q, dtype=torch.float32).to(rbd.device)
+    rbd[:, body, 7:10] = torch.tensor([0.3, -0.2, 0.5]).to(rbd.device)
+    rbd[:, body, 10:13] = torch.tensor([2.0, -3.0, 1.5]).to(rbd.device)
+    if as_articulation:
+        px.gpu_apply_rigid_dynamic_data()
+        px.gpu_apply_articulation_root_pose()
+        px.gpu_apply_articulation_root_velocity()
+    else:
+        px.gpu_apply_all()
+    return px, body, rbd
+
+
+def _rollout(px, body, rbd, steps):
+    out = []
+    for _ in range(steps):
+        px.step()
+        px.gpu_fetch_all()
+        out.append(rbd[0, body].clone().cpu())
+    return torch.stack(out)
+
+
+def test_one_link_floating_articulation_is_a_free_rigid_body(oracle_factory):
+    """isotropic inertia (no gyroscopic torque, which rigid actors leave out as PhysX does): thrown with spin, flight, impacts on the
+    table, tumbling to rest -- the same trajectory as the same box as a dynamic actor"""
+    a = _rollout(*_box_world(oracle_factory, 1, True), 400)
+    b = _rollout(*_box_world(oracle_factory, 1, False), 400)
+    assert (a[:, :3] - b[:, :3]).abs().max() < 1e-4 and (a[:, 7:] - b[:, 7:]).abs().max() < 2e-3
+    dq = torch.minimum((a[:, 3:7] - b[:, 3:7]).abs().max(1).values, (a[:, 3:7] + b[:, 3:7]).abs().max(1).values)   # quaternions up to sign
+    assert dq.max() < 1e-3
+    assert 0.01 < a[-1, 2] < 0.04 and a[-1, 7:].abs().max() < 2e-2      # at rest on the table
+
+
+def test_torque_free_tumbling_keeps_angular_momentum(oracle_factory):
+    """anisotropic inertia in free flight: omega precesses (Euler's equations: the articulation keeps the gyroscopic term), the angular
+    momentum R I R^T omega stays where it was, the centre of mass flies straight"""
+    px, body, rbd = _box_world(oracle_factory, 1, True, gravity=(0, 0, 0), I6=I6)
+    tr = _rollout(px, body, rbd, 150).double().numpy()
+
+    def L(row):
+        w, x, y, z = row[3:7]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        return R @ np.diag(I6[:3]) @ R.T @ row[10:13]
+    L0, L1 = L(tr[0]), L(tr[-1])
+    assert np.abs(tr[-1, 10:13] - tr[0, 10:13]).max() > 0.3                      # it does precess
+    assert np.linalg.norm(L1 - L0) < 0.02 * np.linalg.norm(L0)
+    assert np.abs(tr[-1, 7:10] - tr[0, 7:10]).max() < 1e-5
+
+
+def _chain(factory, n, gravity):
+    """two boxes joined by a revolute joint with a position drive, floating, no ground contact"""
+    tpl = SceneTemplate()
+    art = tpl.add_articulation("chain", floating=True)
+    base = tpl.add_link(art, "base", -1, N.JOINT_FIXED, mass=1.0, inertia6=(2e-3, 3e-3, 4e-3, 0, 0, 0))
+    arm = tpl.add_link(art, "arm", base, N.JOINT_REVOLUTE, "j", pose_in_parent=(0.1, 0, 0, np.cos(0.3), 0, np.sin(0.3), 0),
+                       pose_in_child=(-0.15, 0, 0, 1, 0, 0, 0), mass=0.5, com=(0.02, 0.01, 0), inertia6=(1e-3, 2e-3, 2.5e-3, 0, 0, 0))
+    tpl.set_drive(arm, 50.0, 2.0)
+    cfg = SimConfig()
+    cfg.scene_config.gravity = tuple(gravity)
+    px = factory(tpl, n, cfg)
+    px.gpu_init()
+    px.set_scene_offsets(np.zeros((n, 3)))
+    rbd = px.cuda_rigid_body_data.torch().view(n, px.bodies_per_env, 13)
+    rbd[:, base, :3] = torch.tensor([0.0, 0.0, 1.0]).to(rbd.device)
+    rbd[:, base, 7:10] = torch.tensor([0.2, 0.1, 0.0]).to(rbd.device)
+    rbd[:, base, 10:13] = torch.tensor([0.5, -0.4, 0.8]).to(rbd.device)
+    px.gpu_apply_articulation_root_pose()
+    px.gpu_apply_articulation_root_velocity()
+    px.cuda_articulation_target_qpos.torch()[:, 0] = 1.2
+    px.gpu_apply_articulation_target_position()
+    px.gpu_update_articulation_kinematics()
+    px.gpu_fetch_all()
+    return px, (base, arm), rbd, np.array([1.0, 0.5])
+
+
+def _momentum(rbd, bodies, masses):
+    p = sum(m * rbd[0, b, 7:10].cpu().numpy().astype(np.float64) for b, m in zip(bodies, masses))
+    com = sum(m * rbd[0, b, 0:3].cpu().numpy().astype(np.float64) for b, m in zip(bodies, masses)) / masses.sum()
+    return p, com
+
+
+def test_driven_joint_in_free_flight_keeps_linear_momentum(oracle_factory):
+    px, bodies, rbd, masses = _chain(oracle_factory, 1, (0, 0, 0))
+    # rigid_body_data carries link-frame positions and COM velocities: the bodies' coms are offset, so only velocities enter p
+    p0, _ = _momentum(rbd, bodies, masses)
+    q0 = px.cuda_articulation_qpos.torch()[0, 0].item()
+    for _ in range(150):
+        px.step()
+    px.gpu_fetch_all()
+    p1, _ = _momentum(rbd, bodies, masses)
+    assert abs(px.cuda_articulation_qpos.torch()[0, 0].item() - 1.2) < 0.05 and abs(q0) < 1e-6      # the drive moved the joint
+    # semi-implicit Euler: the links' velocities follow from a finite joint / root rotation, so momentum holds to O(dt) of the internal motion
+    assert np.abs(p1 - p0).max() < 1e-2 * np.abs(p0).max()
+
+
+def test_centre_of_mass_of_a_floating_chain_falls_on_the_parabola(oracle_factory):
+    px, bodies, rbd, masses = _chain(oracle_factory, 1, (0, 0, -9.81))
+    p0, _ = _momentum(rbd, bodies, masses)
+    n, dt = 100, px.timestep
+    for _ in range(n):
+        px.step()
+    px.gpu_fetch_all()
+    p1, _ = _momentum(rbd, bodies, masses)
+    assert np.abs(p1[:2] - p0[:2]).max() < 1e-2 * np.abs(p0).max()
+    assert abs((p1[2] - p0[2]) / masses.sum() + 9.81 * n * dt) < 1e-2
+
+
+@pytest.mark.gpu
+def test_floating_base_hip_equals_oracle(built, oracle_factory):
+    from maniskill_amd.physx import PhysxGpuSystem
+    hip = lambda tpl, n, cfg: PhysxGpuSystem("cuda:0", tpl, n, cfg)   # noqa: E731
+    a = _rollout(*_box_world(hip, 4, True), 300)
+    b = _rollout(*_box_world(oracle_factory, 4, True), 300)
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+    pa, ba, ra, _ = _chain(hip, 4, (0, 0, -9.81))
+    pb, bb, rb, _ = _chain(oracle_factory, 4, (0, 0, -9.81))
+    for _ in range(200):
+        pa.step(); pb.step()
+    pa.gpu_fetch_all(); pb.gpu_fetch_all()
+    assert torch.allclose(ra.cpu(), rb, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(pa.cuda_articulation_qpos.torch().cpu(), pb.cuda_articulation_qpos.torch(), rtol=1e-4, atol=1e-5)

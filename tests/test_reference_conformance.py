@@ -77,13 +77,13 @@ def _run_zoo(backend, steps="3", ids=(), envs="2"):
 
 @needs_ref
 def test_reference_env_zoo_on_cpu_checker(built):
-    """Every task of the reference's registry that needs no downloaded asset (36 of 74: tests/ref_env_zoo.py) is built by the reference's own
+    """Every task of the reference's registry that needs no downloaded asset (41 of 74: tests/ref_env_zoo.py) is built by the reference's own
     code over the shim -- Panda, Fetch-free tabletop tasks, two-robot tasks, SO100, the MJCF control tasks, D'Claw valves with a different
     valve per sub-scene, Allegro hand, TriFinger, Unitree G1 (fixed base) -- reset and stepped; observations, rewards and the raw
     simulation buffers stay finite."""
     res = _run_zoo("oracle")
     bad = {k: v for k, v in res.items() if v != "ok"}
-    assert not bad and len(res) >= 35, bad
+    assert not bad and len(res) >= 41, bad
 
 
 @needs_ref
@@ -100,4 +100,4 @@ def test_overlapping_link_hulls_stay_finite(built):
 def test_reference_env_zoo_on_hip(built):
     res = _run_zoo("hip", "30", (), "8")
     bad = {k: v for k, v in res.items() if v != "ok"}
-    assert not bad and len(res) >= 36, bad
+    assert not bad and len(res) >= 41, bad
