@@ -575,41 +575,52 @@ class RenderSystem:
 
 
 class RenderCameraGroup:
-    """``camera_group.take_picture()`` / ``get_picture_cuda(name).torch()`` for one camera across all sub-scenes."""
+    """``camera_group.take_picture()`` / ``get_picture_cuda(name).torch()`` for one camera across all sub-scenes.  With several
+    structural groups every group renders its own sub-scenes (its own rasteriser template and camera); the textures are handed out
+    in sub-scene order."""
 
     def __init__(self, group: "RenderSystemGroup", cameras, texture_names):
         self._g = group
         self.cameras = list(cameras)
         self.texture_names = list(texture_names)
-        eng = group._engine
-        L, ctx = eng.lib, eng.ctx
         cam = self.cameras[0]
         for c in self.cameras:
             if (c.width, c.height) != (cam.width, cam.height):
                 raise RuntimeError("all cameras of a group must have the same size")
         if abs(cam.fx - cam.fy) > 1e-4 * cam.fy or abs(cam.cx - 0.5 * cam.width) > 1e-3 or abs(cam.cy - 0.5 * cam.height) > 1e-3 or cam.skew != 0:
             raise RuntimeError("only centred pinhole cameras with square pixels are supported")
-        mount_body, local = group._camera_mount(cam)
         from maniskill_amd import _native as N
-        cid = L.camera_create(ctx, cam.width, cam.height, float(cam.fovy), float(cam.near), float(cam.far), int(mount_body),
-                              N._fa(list(local._p) + list(local._q), 7))
-        if cid < 0:
-            msg = L.last_error(ctx)
-            raise RuntimeError(f"failed to create camera buffer: {msg.decode() if msg else cid}")
-        self.id = cid
+        self._cams = []          # (engine, camera id, sub-scene indices)
+        for eng, mine, _gi in group._parts:
+            c0 = self.cameras[mine[0]] if len(self.cameras) > mine[0] else cam
+            mount_body, local = group._camera_mount(c0)
+            L, ctx = eng.lib, eng.ctx
+            cid = L.camera_create(ctx, c0.width, c0.height, float(c0.fovy), float(c0.near), float(c0.far), int(mount_body),
+                                  N._fa(list(local._p) + list(local._q), 7))
+            if cid < 0:
+                msg = L.last_error(ctx)
+                raise RuntimeError(f"failed to create camera buffer: {msg.decode() if msg else cid}")
+            self._cams.append((eng, cid, mine))
+        self.id = self._cams[0][1]
         self._tex = {}
+        self._perm = None
+        if len(self._cams) > 1:      # rows of the concatenated group textures -> sub-scene order
+            order = [k for _, _, mine in self._cams for k in mine]
+            inv = np.empty(len(order), dtype=np.int64)
+            inv[np.asarray(order)] = np.arange(len(order))
+            self._perm = inv
 
-    def _buffer(self, name):
+    def _buffer_of(self, eng, cid, name):
         import torch
-        if name in self._tex:
-            return self._tex[name]
-        eng = self._g._engine
+        key = (id(eng), name)
+        if key in self._tex:
+            return self._tex[key]
         L, ctx = eng.lib, eng.ctx
         shape = (C.c_int64 * 4)()
         if name == "PositionSegmentation":
-            ptr, ctype, typestr = L.camera_buffer(ctx, self.id, shape), C.c_int16, "<i2"
+            ptr, ctype, typestr = L.camera_buffer(ctx, cid, shape), C.c_int16, "<i2"
         elif name == "Color":
-            ptr, ctype, typestr = L.camera_obs_buffer(ctx, self.id, 2, shape), C.c_uint8, "|u1"
+            ptr, ctype, typestr = L.camera_obs_buffer(ctx, cid, 2, shape), C.c_uint8, "|u1"
         else:
             raise RuntimeError(f"the minimal shader pack provides Color and PositionSegmentation, not {name}")
         if not ptr:
@@ -621,15 +632,24 @@ class RenderCameraGroup:
         else:
             from maniskill_amd.physx import _DevicePointer
             t = torch.as_tensor(_DevicePointer(ptr, shp, typestr), device=eng.device)
-        self._tex[name] = t
+        self._tex[key] = t
         return t
 
+    def _buffer(self, name):
+        import torch
+        parts = [self._buffer_of(eng, cid, name) for eng, cid, _ in self._cams]
+        if self._perm is None:
+            return parts[0]
+        if not isinstance(self._perm, torch.Tensor):
+            self._perm = torch.as_tensor(self._perm, device=parts[0].device)
+        return torch.cat(parts, dim=0).index_select(0, self._perm)
+
     def take_picture(self):
-        eng = self._g._engine
-        for n in self.texture_names:       # a texture must have been requested before the picture that fills it
-            if n in ("Color",):
-                self._buffer(n)
-        eng.lib.check(eng.ctx, eng.lib.camera_take_picture(eng.ctx, self.id, eng._stream()), "camera_take_picture")
+        for eng, cid, _ in self._cams:
+            for n in self.texture_names:       # a texture must have been requested before the picture that fills it
+                if n in ("Color",):
+                    self._buffer_of(eng, cid, n)
+            eng.lib.check(eng.ctx, eng.lib.camera_take_picture(eng.ctx, cid, eng._stream()), "camera_take_picture")
 
     def get_picture_cuda(self, name):
         return _Picture(self._buffer(name))
@@ -651,7 +671,20 @@ class RenderSystemGroup:
         px = self.systems[0]._scene.physx_system
         self._px = px
         self._engine = px._engine
-        self._compile()
+        # one rasteriser template per structural group of sub-scenes (the groups the physics runs as, _system.py): compiled from the
+        # group's first sub-scene; (engine, sub-scene indices in this RenderSystemGroup's order)
+        self._parts = []
+        if len(self.systems) == 1 or len(px._groups) == 1:
+            self._parts.append((px._engine, list(range(len(self.systems))), 0))
+        else:
+            index = {px._scene_index(rs._scene): k for k, rs in enumerate(self.systems)}
+            for gi, g in enumerate(px._groups):
+                mine = [index[e] for e in g.envs if e in index]
+                if mine:
+                    self._parts.append((g.engine, mine, gi))
+        self.simplification = dict(parts=0, max_surface_error=0.0, tris_before=0, tris_after=0)
+        for eng, mine, gi in self._parts:
+            self._compile(eng, self.systems[mine[0]], gi)
 
     def update_render(self):
         pass     # the rasteriser reads body poses straight from the simulator's state at take_picture
@@ -673,11 +706,9 @@ class RenderSystemGroup:
         body, fold = self._body_of(cam.entity)
         return body, fold * cam.local_pose
 
-    def _compile(self):
+    def _compile(self, eng, rs0, gi):
         from maniskill_amd import _native as N
-        eng = self._engine
         L, ctx = eng.lib, eng.ctx
-        rs0 = self.systems[0]
         # triangle budget of the rasteriser's scene template (include/msk_render.h: 8192 triangles, 4096 vertices): parts above their
         # share are simplified; the largest surface displacement is kept for the record
         counts = [len(f) for rb in rs0.render_bodies for sh in rb.render_shapes for (_, f, _) in sh._triangles()]
@@ -685,8 +716,7 @@ class RenderSystemGroup:
         small = sum(n for n in counts if n <= KEEP)
         dense = sum(1 for n in counts if n > KEEP)
         MAX_TRIS_PER_PART = KEEP if not dense else max(64, min(KEEP, (5200 - small) // dense))   # template: 8192 triangles, 4096 vertices
-        self.simplification = dict(parts=0, max_surface_error=0.0, tris_before=0, tris_after=0)
-        declared = dict(getattr(self._px, "_env_box_shapes", {}))
+        declared = dict(getattr(self._px, "_env_box_shapes_of_group", {}).get(gi, {}))
         for rb in rs0.render_bodies:
             if rb.visibility <= 0:
                 continue

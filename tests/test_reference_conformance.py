@@ -101,3 +101,26 @@ def test_reference_env_zoo_on_hip(built):
     res = _run_zoo("hip", "30", (), "8")
     bad = {k: v for k, v in res.items() if v != "ok"}
     assert not bad and len(res) >= 41, bad
+
+
+def _multi_group_camera(backend):
+    import json
+    r = subprocess.run([sys.executable, os.path.join(HERE, "ref_multi_group_camera.py"), backend], cwd=HERE, capture_output=True, text=True, timeout=3000)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("MGC ")]
+    assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(line[-1][4:])
+    assert res["groups"] > 1 and res["shapes"]["depth"] == [6, 128, 128, 1] and res["shapes"]["rgb"] == [6, 128, 128, 3]
+    assert min(res["covered"]) > 0.5
+    # moving the valve of sub-scene k out of view changed picture k and no other: the groups' textures come back in sub-scene order
+    assert all(res["changed_only_k"]) and res["restored"], res
+
+
+@needs_ref
+def test_cameras_of_a_scene_with_several_groups_on_cpu_checker(built):
+    _multi_group_camera("oracle")
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_cameras_of_a_scene_with_several_groups_on_hip(built):
+    _multi_group_camera("hip")
