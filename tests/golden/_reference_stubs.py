@@ -63,6 +63,7 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
 
 
 def install(reference_root="/root/reference"):
+    sys.dont_write_bytecode = True      # read-only checkout: no __pycache__ left behind
     if not any(isinstance(f, _Finder) for f in sys.meta_path):
         sys.meta_path.insert(0, _Finder())
     if reference_root not in sys.path:

@@ -28,6 +28,8 @@ _done = {}
 
 
 def setup(backend="oracle"):
+    sys.dont_write_bytecode = True      # the reference checkout is read-only: importing it must not leave __pycache__ behind
+    os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
     """-> the imported ``gymnasium`` module with every ManiSkill task registered, or None if no reference checkout exists."""
     ref = find_reference()
     if ref is None:
