@@ -1,0 +1,16 @@
+"""Stand-in for GitPython (``mani_skill.get_commit_info``, mani_skill/__init__.py:40-56, asks it for the checkout's commit when an episode
+recorder writes its metadata): there is no repository information to give, so every path answers like a directory that is not a
+checkout -- the reference then records ``None`` for the commit.  Appended to ``sys.path`` (a real GitPython wins when installed)."""
+
+
+class InvalidGitRepositoryError(Exception):
+    pass
+
+
+class NoSuchPathError(OSError):
+    pass
+
+
+class Repo:
+    def __init__(self, path=None, *a, **k):
+        raise InvalidGitRepositoryError(str(path))

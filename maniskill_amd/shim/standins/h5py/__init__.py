@@ -1,0 +1,228 @@
+"""Stand-in for ``h5py`` in images that do not have it (this one: no network, no wheel): the File / Group / Dataset surface that
+``mani_skill.utils.wrappers.record.RecordEpisode`` and ``mani_skill.trajectory`` use, with the tree kept in memory and written on
+``close()`` as a pickle of numpy arrays.  NOT the HDF5 format: files written here are read back by this module only (which is what the
+reference's tests do: record, then load / replay).  ``maniskill_amd.shim.install()`` appends the stand-ins directory to ``sys.path``, so a
+real h5py always wins when it exists."""
+import os
+import pickle
+
+import numpy as np
+
+__version__ = "0.0.standin"
+_MAGIC = b"MSKH5STANDIN1\n"
+
+
+class AttributeManager(dict):
+    pass
+
+
+class Dataset:
+    def __init__(self, name, data, parent=None):
+        self.name = name
+        self._data = np.asarray(data)
+        self.attrs = AttributeManager()
+        self.parent = parent
+
+    shape = property(lambda self: self._data.shape)
+    dtype = property(lambda self: self._data.dtype)
+    ndim = property(lambda self: self._data.ndim)
+    size = property(lambda self: self._data.size)
+
+    def __len__(self):
+        return len(self._data)
+
+    def __getitem__(self, key):
+        return self._data[key]
+
+    def __setitem__(self, key, value):
+        self._data[key] = value
+
+    def __array__(self, dtype=None, copy=None):
+        return self._data if dtype is None else self._data.astype(dtype)
+
+    def __iter__(self):
+        return iter(self._data)
+
+    def __repr__(self):
+        return f'<stand-in HDF5 dataset "{self.name}": shape {self.shape}, type "{self.dtype}">'
+
+    def asstr(self):
+        return self._data.astype(str)
+
+    def _dump(self):
+        return ("d", self._data, dict(self.attrs))
+
+
+class Group:
+    def __init__(self, name="/", parent=None):
+        self.name = name
+        self.parent = parent
+        self._items = {}          # insertion order == creation order (track_order)
+        self.attrs = AttributeManager()
+
+    # -- creation ---------------------------------------------------------------------------------------------------
+    def _child_name(self, key):
+        return (self.name.rstrip("/") + "/" + key) if self.name != "/" else "/" + key
+
+    def _walk(self, path, create=False):
+        node = self
+        parts = [p for p in str(path).split("/") if p]
+        for p in parts:
+            if not isinstance(node, Group):
+                raise KeyError(path)
+            if p not in node._items:
+                if not create:
+                    raise KeyError(f"Unable to open object (object '{p}' doesn't exist)")
+                node._items[p] = Group(node._child_name(p), node)
+            node = node._items[p]
+        return node
+
+    def create_group(self, name, track_order=None):
+        parts = [p for p in str(name).split("/") if p]
+        parent = self._walk("/".join(parts[:-1]), create=True) if len(parts) > 1 else self
+        if parts[-1] in parent._items:
+            raise ValueError(f"Unable to create group (name already exists): {name}")
+        g = Group(parent._child_name(parts[-1]), parent)
+        parent._items[parts[-1]] = g
+        return g
+
+    def require_group(self, name):
+        return self._walk(name, create=True)
+
+    def create_dataset(self, name, shape=None, dtype=None, data=None, **kwds):   # compression / chunks / maxshape: accepted, no effect
+        parts = [p for p in str(name).split("/") if p]
+        parent = self._walk("/".join(parts[:-1]), create=True) if len(parts) > 1 else self
+        if parts[-1] in parent._items:
+            raise ValueError(f"Unable to create dataset (name already exists): {name}")
+        if data is None:
+            arr = np.zeros(shape if shape is not None else (), dtype=dtype if dtype is not None else np.float32)
+        else:
+            arr = np.array(data, dtype=dtype) if dtype is not None else np.array(data)
+            if shape is not None:
+                arr = arr.reshape(shape)
+        d = Dataset(parent._child_name(parts[-1]), arr, parent)
+        parent._items[parts[-1]] = d
+        return d
+
+    def copy(self, source, dest, name=None, **kwds):
+        src = self[source] if isinstance(source, str) else source
+        target = dest if isinstance(dest, Group) else self.require_group(dest)
+        key = name if name is not None else src.name.rstrip("/").split("/")[-1]
+        target._items[key] = _load(src._dump(), target._child_name(key), target)
+
+    # -- mapping ------------------------------------------------------------------------------------------------------
+    def __getitem__(self, key):
+        return self._walk(key)
+
+    def __setitem__(self, key, value):
+        if isinstance(value, (Group, Dataset)):
+            self._items[key] = value
+        else:
+            self.create_dataset(key, data=value)
+
+    def __delitem__(self, key):
+        parts = [p for p in str(key).split("/") if p]
+        parent = self._walk("/".join(parts[:-1])) if len(parts) > 1 else self
+        del parent._items[parts[-1]]
+
+    def __contains__(self, key):
+        try:
+            self._walk(key)
+            return True
+        except KeyError:
+            return False
+
+    def __iter__(self):
+        return iter(self._items)
+
+    def __len__(self):
+        return len(self._items)
+
+    def keys(self):
+        return self._items.keys()
+
+    def values(self):
+        return self._items.values()
+
+    def items(self):
+        return self._items.items()
+
+    def get(self, key, default=None):
+        try:
+            return self._walk(key)
+        except KeyError:
+            return default
+
+    def visit(self, fn):
+        for k, v in self._items.items():
+            r = fn(v.name.lstrip("/"))
+            if r is not None:
+                return r
+            if isinstance(v, Group):
+                r = v.visit(fn)
+                if r is not None:
+                    return r
+
+    def __repr__(self):
+        return f'<stand-in HDF5 group "{self.name}" ({len(self)} members)>'
+
+    def _dump(self):
+        return ("g", {k: v._dump() for k, v in self._items.items()}, dict(self.attrs))
+
+
+def _load(node, name, parent):
+    kind, payload, attrs = node
+    if kind == "d":
+        d = Dataset(name, payload.copy() if isinstance(payload, np.ndarray) else payload, parent)
+        d.attrs.update(attrs)
+        return d
+    g = Group(name, parent)
+    g.attrs.update(attrs)
+    for k, v in payload.items():
+        g._items[k] = _load(v, g._child_name(k), g)
+    return g
+
+
+class File(Group):
+    def __init__(self, name, mode="r", **kwds):
+        super().__init__("/", None)
+        self.filename = os.fspath(name)
+        self.mode = mode
+        self._open = True
+        if mode in ("r", "r+", "a") and os.path.exists(self.filename):
+            with open(self.filename, "rb") as f:
+                head = f.read(len(_MAGIC))
+                if head != _MAGIC:
+                    raise OSError(f"{self.filename}: not written by the h5py stand-in of this image (a real HDF5 file needs the real h5py)")
+                root = _load(pickle.load(f), "/", None)
+            self._items, self.attrs = root._items, root.attrs
+            for v in self._items.values():
+                v.parent = self
+        elif mode in ("r", "r+"):
+            raise FileNotFoundError(f"Unable to open file (unable to open file: name = '{self.filename}')")
+
+    file = property(lambda self: self)
+
+    def flush(self):
+        if self.mode != "r":
+            os.makedirs(os.path.dirname(os.path.abspath(self.filename)), exist_ok=True)
+            with open(self.filename, "wb") as f:
+                f.write(_MAGIC)
+                pickle.dump(self._dump(), f, protocol=4)
+
+    def close(self):
+        if self._open:
+            self.flush()
+            self._open = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __bool__(self):
+        return self._open
+
+    def __repr__(self):
+        return f'<stand-in HDF5 file "{os.path.basename(self.filename)}" (mode {self.mode})>'

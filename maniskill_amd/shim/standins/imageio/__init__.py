@@ -1,9 +1,66 @@
-"""Stand-in for ``imageio`` (mani_skill/utils/visualization/misc.py:4 imports it at module level; writing videos needs the
-real package)."""
+"""Stand-in for ``imageio`` (mani_skill/utils/visualization/misc.py:4 imports it at module level and ``images_to_video`` drives
+``get_writer(...).append_data(frame)``): this image has no encoder (no ffmpeg, no imageio), so the writer keeps the frames and stores
+them, on ``close()``, as ONE uncompressed numpy archive under the requested path -- with a warning that says so.  The file is not a
+playable video; it holds exactly the frames the recorder produced (``imageio.mimread`` of this module gives them back).  A real imageio
+wins when installed (the stand-ins directory is appended to ``sys.path``)."""
+import io
+import warnings
+
+import numpy as np
+
+_MAGIC = b"MSKFRAMES1\n"
 
 
-def _missing(*a, **k):
-    raise ImportError("imageio is not installed (stand-in module): video / image writing is unavailable")
+class _Writer:
+    def __init__(self, uri, fps=None, **kwds):
+        self.uri, self.fps, self.frames = uri, fps, []
+        self._closed = False
+
+    def append_data(self, im):
+        self.frames.append(np.asarray(im).copy())
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        warnings.warn(f"imageio is not installed: {self.uri} holds {len(self.frames)} raw frames (numpy archive), not an encoded video")
+        buf = io.BytesIO()
+        np.savez(buf, frames=np.stack(self.frames) if self.frames else np.zeros((0,)), fps=np.asarray(self.fps if self.fps is not None else 0.0))
+        with open(self.uri, "wb") as f:
+            f.write(_MAGIC)
+            f.write(buf.getvalue())
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
-get_writer = imwrite = imread = mimsave = mimwrite = _missing
+def get_writer(uri, *a, fps=None, **kwds):
+    return _Writer(uri, fps=fps, **kwds)
+
+
+def mimsave(uri, ims, fps=None, **kwds):
+    w = _Writer(uri, fps=fps)
+    for im in ims:
+        w.append_data(im)
+    w.close()
+
+
+mimwrite = mimsave
+
+
+def mimread(uri, **kwds):
+    with open(uri, "rb") as f:
+        if f.read(len(_MAGIC)) != _MAGIC:
+            raise ImportError("imageio is not installed (stand-in module): only files written by this stand-in can be read")
+        return list(np.load(io.BytesIO(f.read()))["frames"])
+
+
+def imwrite(uri, im, **kwds):
+    mimsave(uri, [im])
+
+
+def imread(uri, **kwds):
+    return mimread(uri)[0]

@@ -29,6 +29,10 @@ STATE_NODES = [
     "tests/structs/test_actor.py",
     "tests/structs/test_link.py",
     "tests/structs/test_obs_mode_struct.py",
+    # the episode recorder (mani_skill/utils/wrappers/record.py): trajectories through the h5py stand-in, frames through the imageio one
+    "tests/test_wrappers.py::test_recordepisode_wrapper_gpu[env_id=PickCube-v1,obs_mode=state]",
+    "tests/test_wrappers.py::test_recordepisode_wrapper[env_id=StackCube-v1,obs_mode=rgb]",
+    "tests/test_wrappers.py::test_recordepisode_wrapper_render_sensor[env_id=PegInsertionSide-v1,obs_mode=state_dict]",
 ]
 
 
@@ -47,7 +51,9 @@ GPU_ONLY_NODES = [
 def run_reference_tests(nodes, backend):
     """tests/ref_run_node.py in a subprocess (fresh interpreter: the shim / backend selection is process-global)."""
     cmd = [sys.executable, os.path.join(HERE, "ref_run_node.py"), backend, *nodes]
-    r = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True, timeout=3000)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:      # the reference's recorder tests write videos/ under the working directory
+        r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True, timeout=3000)
     return r.returncode, (r.stdout[-6000:] + r.stderr[-3000:])
 
 
