@@ -98,8 +98,22 @@ def make(id, max_episode_steps: Optional[int] = None, autoreset: Optional[bool] 
     return env
 
 
-def make_vec(id, num_envs: int = 1, **kwargs):
+def make_vec(id, num_envs: int = 1, vectorization_mode=None, vector_kwargs=None, wrappers=None, **kwargs):
+    """gymnasium 0.29 ``make_vec``: "sync" (or wrappers given) = SyncVectorEnv over ``make(id, **kwargs)`` wrapped by ``wrappers``; otherwise
+    the spec's own vector entry point (ManiSkill's GPU vector env, mani_skill/utils/registration.py:185-189)."""
     env_spec = spec(id)
+    mode = vectorization_mode if isinstance(vectorization_mode, (str, type(None))) else getattr(vectorization_mode, "value", str(vectorization_mode))
+    if mode in ("sync", "async") or (mode is None and wrappers):
+        from ..vector import SyncVectorEnv
+
+        def one():
+            env = make(id, **kwargs)
+            for w in (wrappers or ()):
+                env = w(env)
+            return env
+        return SyncVectorEnv([one for _ in range(num_envs)], **(vector_kwargs or {}))
     if env_spec.vector_entry_point is None:
         raise ValueError(f"{id} has no vector_entry_point")
+    if wrappers:
+        raise ValueError("the `custom` vector environment is not compatible with wrappers")
     return _load(env_spec.vector_entry_point)(num_envs=num_envs, **kwargs)

@@ -42,11 +42,79 @@ class VectorEnv(Env):
         return self
 
 
-class SyncVectorEnv(VectorEnv):
-    """Not provided: the reference only uses it for multi-process CPU PhysX baselines."""
+def _stack(items):
+    """batch a list of per-env observations / values (nested dicts of numpy arrays or scalars)"""
+    import numpy as np
+    first = items[0]
+    if isinstance(first, dict):
+        return {k: _stack([it[k] for it in items]) for k in first}
+    if isinstance(first, (tuple, list)):
+        return type(first)(_stack([it[k] for it in items]) for k in range(len(first)))
+    return np.stack([np.asarray(it) for it in items])
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError("gymnasium stand-in: SyncVectorEnv is not provided")
+
+class SyncVectorEnv(VectorEnv):
+    """gymnasium 0.29's SyncVectorEnv: the envs of ``env_fns`` stepped one after the other in this process, observations stacked; an env
+    that terminates or truncates is reset in the same step and its last observation / info go to ``final_observation`` / ``final_info``."""
+
+    def __init__(self, env_fns, observation_space=None, action_space=None, copy=True):
+        self.env_fns = list(env_fns)
+        self.envs = [fn() for fn in self.env_fns]
+        self.copy = copy
+        e0 = self.envs[0]
+        super().__init__(len(self.envs), observation_space or e0.observation_space, action_space or e0.action_space)
+        self.metadata = getattr(e0, "metadata", {})
+        self.spec = getattr(e0, "spec", None)
+
+    def reset(self, *, seed=None, options=None):
+        import numpy as np
+        seeds = [None] * self.num_envs if seed is None else ([seed + i for i in range(self.num_envs)] if isinstance(seed, int) else list(seed))
+        obs, infos = [], {}
+        for i, (env, sd) in enumerate(zip(self.envs, seeds)):
+            o, info = env.reset(seed=sd, options=options)
+            obs.append(o)
+            infos = self._add_info(infos, info, i)
+        return _stack(obs), infos
+
+    def step(self, actions):
+        import numpy as np
+        obs, rews, terms, truncs, infos = [], [], [], [], {}
+        for i, env in enumerate(self.envs):
+            a = {k: v[i] for k, v in actions.items()} if isinstance(actions, dict) else actions[i]
+            o, r, te, tr, info = env.step(a)
+            if bool(te) or bool(tr):
+                info = dict(info)
+                info["final_observation"], info["final_info"] = o, dict(info)
+                o, _ = env.reset()
+            obs.append(o); rews.append(float(np.asarray(r).reshape(-1)[0]) if np.asarray(r).size else 0.0)
+            terms.append(bool(np.asarray(te).reshape(-1)[0]) if np.asarray(te).size else bool(te))
+            truncs.append(bool(np.asarray(tr).reshape(-1)[0]) if np.asarray(tr).size else bool(tr))
+            infos = self._add_info(infos, info, i)
+        return _stack(obs), np.asarray(rews, dtype=np.float64), np.asarray(terms, dtype=bool), np.asarray(truncs, dtype=bool), infos
+
+    def _add_info(self, infos, info, i):
+        import numpy as np
+        for k, v in info.items():
+            if k not in infos:
+                infos[k] = np.full(self.num_envs, None, dtype=object)
+                infos["_" + k] = np.zeros(self.num_envs, dtype=bool)
+            infos[k][i] = v
+            infos["_" + k][i] = True
+        return infos
+
+    def call(self, name, *args, **kwargs):
+        out = []
+        for env in self.envs:
+            fn = getattr(env, name)
+            out.append(fn(*args, **kwargs) if callable(fn) else fn)
+        return tuple(out)
+
+    def get_attr(self, name):
+        return self.call(name)
+
+    def close_extras(self, **kwargs):
+        for env in self.envs:
+            env.close()
 
 
 class AsyncVectorEnv(VectorEnv):

@@ -33,6 +33,12 @@ STATE_NODES = [
     "tests/test_wrappers.py::test_recordepisode_wrapper_gpu[env_id=PickCube-v1,obs_mode=state]",
     "tests/test_wrappers.py::test_recordepisode_wrapper[env_id=StackCube-v1,obs_mode=rgb]",
     "tests/test_wrappers.py::test_recordepisode_wrapper_render_sensor[env_id=PegInsertionSide-v1,obs_mode=state_dict]",
+    # the CPU simulation backend (sim_backend="cpu", one sub-scene: BASELINE config 1) -- PhysxCpuSystem of the shim, the pinocchio-model IK
+    # of the end-effector control modes, gymnasium's SyncVectorEnv over CPUGymWrapper
+    "tests/test_envs.py::test_env_control_modes[env_id=PickCube-v1,control_mode=pd_ee_delta_pose]",
+    "tests/test_envs.py::test_envs_obs_modes[env_id=StackCube-v1,obs_mode=rgb+depth+segmentation]",
+    "tests/test_envs.py::test_states[env_id=PegInsertionSide-v1]",
+    "tests/test_venv.py::test_gymnasium_cpu_vecenv[env_id=PickCube-v1,obs_mode=state]",
 ]
 
 
