@@ -1240,8 +1240,8 @@ MSK_API int msk_control_step(msk_ctx* c, int substeps, void* stream) {
     const int r = msk_step(c, stream);
     if (r < 0) return r;
   }
-  launch_kinematics(c->model, c->d_model, c->st, (hipStream_t)stream);
-  c->kin_dirty = false;
+  /* the link frames of the post-step state are left to the consumer (every one of them checks kin_dirty): the PickCube observation
+   * computes them in its own launch (k_pickcube_observe_kin) */
   HIP_TRY(hipGetLastError());
   return MSK_OK;
 }
@@ -1250,13 +1250,20 @@ MSK_API int msk_task_pickcube_observe(msk_ctx* c, float* obs, float* reward, uin
                                       void* stream) {
   if (!c->has_pickcube) return fail(c, MSK_ERR_INVALID, "pickcube task not initialised");
   const int N = c->model.N;
-  if (c->kin_dirty) {
-    launch_kinematics(c->model, c->d_model, c->st, (hipStream_t)stream);
-    c->kin_dirty = false;
-  }
   const float cos_max = cosf(c->pickcube.max_angle_deg * 3.14159265358979323846f / 180.0f);
-  hipLaunchKernelGGL(k_pickcube_observe, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, c->d_model, c->st, c->pickcube, c->pick_lsel,
-                     c->pick_rsel, obs, reward, flags, elapsed, advance, cos_max);
+  if (c->kin_dirty) { /* the usual case behind msk_control_step: frames and observation in one launch */
+    const int lpe = lanes_per_env(c->model), epb = 64 / lpe;
+    const size_t lds = (size_t)DynLds(c->model.nb, 0).total * sizeof(float) * epb;
+    if (lpe == 32)
+      hipLaunchKernelGGL(k_pickcube_observe_kin<32>, dim3((N + 1) / 2), dim3(64), lds, (hipStream_t)stream, c->d_model, c->st, c->pickcube, c->pick_lsel,
+                         c->pick_rsel, obs, reward, flags, elapsed, advance, cos_max);
+    else
+      hipLaunchKernelGGL(k_pickcube_observe_kin<64>, dim3(N), dim3(64), lds, (hipStream_t)stream, c->d_model, c->st, c->pickcube, c->pick_lsel,
+                         c->pick_rsel, obs, reward, flags, elapsed, advance, cos_max);
+    c->kin_dirty = false;
+  } else
+    hipLaunchKernelGGL(k_pickcube_observe, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, c->d_model, c->st, c->pickcube, c->pick_lsel,
+                       c->pick_rsel, obs, reward, flags, elapsed, advance, cos_max);
   HIP_TRY(hipGetLastError());
   return MSK_OK;
 }

@@ -167,11 +167,9 @@ MSK_DEV bool finger_grasps(v3 force, v3 dir, float min_force, float cos_max_angl
   return fn >= min_force && c >= cos_max_angle;
 }
 
-__global__ void __launch_bounds__(64) k_pickcube_observe(const DModel* __restrict__ m, DState st, msk_pickcube_desc d, PairSel lsel, PairSel rsel,
-                                                         float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags,
-                                                         int* __restrict__ elapsed, int advance, float cos_max_angle) {
-  const int e = blockIdx.x * 64 + threadIdx.x;
-  if (e >= m->N) return;
+MSK_DEV void pickcube_observe_env(const DModel* __restrict__ m, const DState& st, const msk_pickcube_desc& d, const PairSel& lsel, const PairSel& rsel,
+                                  float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags,
+                                  int* __restrict__ elapsed, int advance, float cos_max_angle, const int e) {
   const float* E = EREC(st, m, e);
   const int nq = d.arm_dofs + 2;
   float* o = obs + (size_t)e * 42;
@@ -219,6 +217,27 @@ __global__ void __launch_bounds__(64) k_pickcube_observe(const DModel* __restric
   f[4] = success;                       /* terminated */
   f[5] = el >= d.max_episode_steps;     /* truncated (TimeLimitWrapper) */
   f[6] = 0; f[7] = 0;
+}
+__global__ void __launch_bounds__(64) k_pickcube_observe(const DModel* __restrict__ m, DState st, msk_pickcube_desc d, PairSel lsel, PairSel rsel,
+                                                         float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags,
+                                                         int* __restrict__ elapsed, int advance, float cos_max_angle) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= m->N) return;
+  pickcube_observe_env(m, st, d, lsel, rsel, obs, reward, flags, elapsed, advance, cos_max_angle, e);
+}
+/* the same behind the link frames of the post-step (q, qd): k_kinematics and the observation in one launch (a control step ends with both;
+ * one dependent launch less).  LPE lanes per env do the frames (msk_dynamics.h), then the env's first lane the observation. */
+template <int LPE>
+__global__ void __launch_bounds__(64) k_pickcube_observe_kin(const DModel* __restrict__ m, DState st, msk_pickcube_desc d, PairSel lsel, PairSel rsel,
+                                                             float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags,
+                                                             int* __restrict__ elapsed, int advance, float cos_max_angle) {
+  extern __shared__ __attribute__((aligned(16))) float lds_ok[];
+  kinematics_block<LPE>(m, st, lds_ok, blockIdx.x);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   /* the frames just stored are read back by the env's first lane */
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const int e = blockIdx.x * (64 / LPE) + threadIdx.x / LPE;
+  if (threadIdx.x % LPE == 0 && e < m->N) pickcube_observe_env(m, st, d, lsel, rsel, obs, reward, flags, elapsed, advance, cos_max_angle, e);
 }
 
 /* ---- PegInsertionSide-v1 ------------------------------------------------------------------------------------------- */

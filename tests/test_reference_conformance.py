@@ -51,6 +51,9 @@ GPU_ONLY_NODES = [
     "tests/test_gpu_envs.py::test_envs_obs_modes[env_id=PickCube-v1,obs_mode=depth+state]",
     "tests/test_gpu_envs.py::test_envs_obs_modes[env_id=StackCube-v1,obs_mode=state]",
     "tests/test_gpu_envs.py::test_envs_obs_modes[env_id=PegInsertionSide-v1,obs_mode=state]",
+    # end-effector control through the batched Jacobian path (agents/controllers/utils/kinematics.py: the GPU branch)
+    "tests/test_gpu_envs.py::test_env_control_modes[env_id=PickCube-v1,control_mode=pd_ee_delta_pose]",
+    "tests/test_gpu_envs.py::test_env_control_modes[env_id=StackCube-v1,control_mode=pd_ee_delta_pos]",
 ]
 
 

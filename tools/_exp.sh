@@ -1,2 +1,3 @@
-timeout 900 python -m pytest tests/test_floating_base.py tests/test_gpu_parity.py tests/test_bound_buffers.py -x -q -m gpu 2>&1 | tail -5
-cd tests && ZOO_ENVS=8 python ref_env_zoo.py hip 30 MS-AntWalk-v1 MS-AntRun-v1 MS-HumanoidStand-v1 MS-HumanoidWalk-v1 MS-HumanoidRun-v1 PickCube-v1 2>&1 | grep "^ZOO"
+timeout 1500 python -m pytest tests -x -q -m gpu --deselect tests/test_reference_conformance.py 2>&1 | tail -4
+python bench.py --steps 1000 --no-cpu-baseline --no-extras 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_us'])"
+python bench.py --steps 1000 --no-cpu-baseline --no-extras 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_us'])"
