@@ -47,7 +47,7 @@ int msk_render_set_lights(msk_ctx* ctx, const float ambient[3], int ndir, const 
 int msk_render_finalize(msk_ctx* ctx);
 /* RenderCameraComponent(width, height) + set_fovy(fovy, compute_x=True) + near / far + local pose
  * (scene.py:198-297; sensors/camera.py:126-186).  mount_body = -1: the camera is fixed in the env frame.
- * width and height must be multiples of 16, at most 256 x 256.  Returns the camera id. */
+ * width and height must be multiples of 16, at most 4096 tiles of 8 x 8 pixels (512 x 512: the human-render cameras).  Returns the camera id. */
 int msk_camera_create(msk_ctx* ctx, int width, int height, float fovy, float near_plane, float far_plane,
                       int mount_body, const float local_pose[7]);
 /* camera_group.get_picture_cuda("PositionSegmentation"): device pointer to int16 [num_envs][height][width][4],

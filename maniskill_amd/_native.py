@@ -94,6 +94,10 @@ class NativeLib:
                 "maniskill_amd has no CPU fallback."
             )
         self.path, self.prefix = path, prefix
+        if prefix == "msk_":
+            # the HIP library shares the process's HIP runtime with torch: torch's own libamdhip64 has to be the one that is loaded
+            # (a library opened first pulls in /opt/rocm's copy, and a second runtime in the process sees no device)
+            import torch  # noqa: F401
         self.dll = C.CDLL(path)
         f = lambda name: getattr(self.dll, prefix + name)  # noqa: E731
         vp, i32, f32, u32 = C.c_void_p, C.c_int, C.c_float, C.c_uint32

@@ -1033,7 +1033,7 @@ MSK_API int msk_camera_create(msk_ctx* c, int width, int height, float fovy, flo
   if (!c->render_finalized) return fail(c, MSK_ERR_INVALID, "camera_create before render_finalize");
   if (c->ncams >= MSK_MAX_CAMERAS) return fail(c, MSK_ERR_CAPACITY, "too many cameras");
   if (width % 16 || height % 16 || width <= 0 || height <= 0 || (width / MSK_TILE) * (height / MSK_TILE) > MSK_MAX_TILES)
-    return fail(c, MSK_ERR_INVALID, "camera size must be a multiple of 16, at most 256 x 256");
+    return fail(c, MSK_ERR_INVALID, "camera size must be a multiple of 16 with at most 4096 tiles of 8 x 8 pixels (512 x 512)");
   if (mount_body >= c->model.nb) return fail(c, MSK_ERR_INVALID, "bad mount body");
   HIP_TRY(hipSetDevice(c->device));
   const size_t N = (size_t)c->model.N;
@@ -1041,6 +1041,7 @@ MSK_API int msk_camera_create(msk_ctx* c, int width, int height, float fovy, flo
   memset(&cam, 0, sizeof(cam));
   cam.W = width; cam.H = height; cam.mount = mount_body;
   cam.tiles_x = width / MSK_TILE; cam.tiles_y = height / MSK_TILE;
+  cam.tile_cap = cam.tiles_x * cam.tiles_y;
   /* set_fovy(fovy, compute_x=True): square pixels, principal point at the image centre */
   cam.fy = (float)(0.5 * height / tan(0.5 * (double)fovy));
   cam.fx = cam.fy;
@@ -1051,11 +1052,11 @@ MSK_API int msk_camera_create(msk_ctx* c, int width, int height, float fovy, flo
   cam.list_cap = 4 * cam.setup_cap + 64 * cam.tiles_x * cam.tiles_y;
   ALLOC(cam.setups, N * cam.setup_cap * MSK_SETUP_WORDS);
   ALLOC(cam.nsetup, N);
-  ALLOC(cam.tile_off, N * (MSK_MAX_TILES + 1));
+  ALLOC(cam.tile_off, N * ((size_t)cam.tile_cap + 1));
   ALLOC(cam.tile_recs, N * (size_t)cam.list_cap * MSK_SETUP_WORDS);
   ALLOC(cam.big_recs, N * (size_t)MSK_MAX_BIG * MSK_SETUP_WORDS);
   ALLOC(cam.nbig, N);
-  ALLOC(cam.tile_bigmask, N * MSK_MAX_TILES);
+  ALLOC(cam.tile_bigmask, N * (size_t)cam.tile_cap);
   ALLOC(cam.out, N * (size_t)width * height * 4);
   ALLOC(cam.depth, N * (size_t)width * height);
   ALLOC(cam.seg, N * (size_t)width * height);
@@ -1092,7 +1093,11 @@ MSK_API int msk_camera_take_picture(msk_ctx* c, int camera, void* stream) {
     c->kin_dirty = false;
   }
   const RCamera& cam = c->cams[camera];
-  const size_t lds = (MSK_MAX_RENDER_SHAPES * MSK_RSHAPE_WORDS + 2 * MSK_MAX_TILES + 8 + MSK_MAX_BIG + MSK_MAX_LIGHTS * 3 + (size_t)c->rmodel->nv * 3) * sizeof(float);
+  const size_t lds = (MSK_MAX_RENDER_SHAPES * MSK_RSHAPE_WORDS + 2 * (size_t)cam.tile_cap + 8 + MSK_MAX_BIG + MSK_MAX_LIGHTS * 3 + (size_t)c->rmodel->nv * 3) * sizeof(float);
+  if (lds > 64 * 1024) { /* above the default dynamic LDS limit (large pictures): the CU has 160 KB */
+    if (lds > 160 * 1024) return fail(c, MSK_ERR_CAPACITY, "camera: picture too large for the setup kernel's LDS");
+    HIP_TRY(hipFuncSetAttribute((const void*)k_render_setup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   hipLaunchKernelGGL(k_render_setup, dim3(N), dim3(256), lds, s, c->d_model, c->st, c->d_rmodel, cam);
   hipLaunchKernelGGL(k_render_tiles, dim3((cam.tiles_x * cam.tiles_y + MSK_TILES_PER_WAVE - 1) / MSK_TILES_PER_WAVE, N), dim3(64), 0, s, cam);
   HIP_TRY(hipGetLastError());

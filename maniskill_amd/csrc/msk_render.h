@@ -23,7 +23,8 @@
 #include "msk_model.h"
 
 #define MSK_TILE 8                 /* one wavefront rasterises an 8 x 8 tile, lane = pixel */
-#define MSK_MAX_TILES 1024         /* up to 256x256 images */
+#define MSK_MAX_TILES 4096         /* 8 x 8 pixel tiles per picture: up to 512 x 512 (the human-render cameras, sapien_env.py _default_human_render_camera_configs);
+                                    * the per-camera arrays and the setup kernel's LDS are sized by the camera's own tile count (RCamera::tile_cap) */
 #define MSK_BIG_TILES 16           /* a triangle over more tiles than this is binned by the whole workgroup */
 #define MSK_MAX_BIG 16
 #define MSK_SEG_BIG 0x40000000      /* flag in TriSetup::seg: the record is in the env's list of large triangles */
@@ -47,6 +48,7 @@ struct RModel {
 };
 struct RCamera {
   int W, H, mount, tiles_x, tiles_y;
+  int tile_cap;                    /* tiles_x * tiles_y: stride of the per-tile arrays below and of the setup kernel's LDS counters */
   float fx, fy, cx, cy, near_, far_;
   pose local;
   int setup_cap, list_cap;         /* per env */
@@ -56,7 +58,7 @@ struct RCamera {
   float* tile_recs;                /* [N][list_cap][16]: per tile, the records of the small triangles that touch it */
   float* big_recs;                 /* [N][MSK_MAX_BIG][16]: triangles over many tiles (table, ground): tested by every tile */
   int* nbig;                       /* [N] */
-  unsigned short* tile_bigmask;    /* [N][MSK_MAX_TILES]: bit b = large triangle b can cover a pixel centre of the tile */
+  unsigned short* tile_bigmask;    /* [N][tile_cap]: bit b = large triangle b can cover a pixel centre of the tile */
   short* out;                      /* [N][H][W][4]        */
   unsigned* color;                 /* [N][H][W]: Color r8g8b8a8unorm (r in the low byte), 0 = background; null until asked for */
   short* depth;                    /* [N][H][W]: -z of out (Camera.get_obs's depth), written by the same store */
@@ -163,8 +165,8 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
   /* LDS: shape transforms and scales [ns][12] | tile counters [ntiles] | tile fill [ntiles] | nsetup | camera-frame vertices [nv][3] */
   float* Lshape = lds;
   int* Lcnt = (int*)(lds + MSK_MAX_RENDER_SHAPES * MSK_RSHAPE_WORDS);
-  int* Lfill = Lcnt + MSK_MAX_TILES + 4;
-  int* Lns = Lfill + MSK_MAX_TILES;
+  int* Lfill = Lcnt + cam.tile_cap + 4;
+  int* Lns = Lfill + cam.tile_cap;
   int* Lnbig = Lns + 1;
   int* Lbig = Lns + 4;
   float* Llight = (float*)(Lbig + MSK_MAX_BIG);          /* light directions in the camera frame [MSK_MAX_LIGHTS][3] */
@@ -255,7 +257,7 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
   const int nbig = min(*Lnbig, MSK_MAX_BIG);
   __syncthreads();
   const int ns = min(*Lns, cam.setup_cap);
-  int* toff = cam.tile_off + (size_t)e * (MSK_MAX_TILES + 1);
+  int* toff = cam.tile_off + (size_t)e * (cam.tile_cap + 1);
   if (tid == 0) {
     int acc = 0;
     for (int i = 0; i < ntiles; ++i) {
@@ -295,7 +297,7 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
   for (int i = tid; i < nbig * 4; i += 256) bigr[i] = ((const float4*)&setups[Lbig[i / 4]])[i % 4];
   if (tid == 0) cam.nbig[e] = nbig;
   /* per tile, the large triangles that can cover one of its pixel centres (bit b = entry b of the list) */
-  unsigned short* bmask = cam.tile_bigmask + (size_t)e * MSK_MAX_TILES;
+  unsigned short* bmask = cam.tile_bigmask + (size_t)e * cam.tile_cap;
   for (int tile = tid; tile < ntiles; tile += 256) {
     const int tx = tile % cam.tiles_x, ty = tile / cam.tiles_x;
     unsigned mk = 0u;
@@ -324,8 +326,8 @@ __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
   }
   const int t0 = blockIdx.x * MSK_TILES_PER_WAVE;
-  const unsigned short* bigmask = cam.tile_bigmask + (size_t)e * MSK_MAX_TILES;
-  const int* toff = cam.tile_off + (size_t)e * (MSK_MAX_TILES + 1);
+  const unsigned short* bigmask = cam.tile_bigmask + (size_t)e * cam.tile_cap;
+  const int* toff = cam.tile_off + (size_t)e * (cam.tile_cap + 1);
   const float4* recs = (const float4*)(cam.tile_recs + (size_t)e * cam.list_cap * MSK_SETUP_WORDS);
   const float wmin = 1.0f / cam.far_;
   /* list bounds of my tiles: lane i holds toff[t0 + i] */
