@@ -104,6 +104,15 @@ def _tree_stack(trees: List[dict]):
 
 
 # ------------------------------------------------------------------------------------------------ recording
+def _env_id_of(env) -> str:
+    """the id the env's class is registered under (what the replay CLI resolves); unknown classes are refused here, not at replay time"""
+    from .envs import registered
+    for eid, cls in registered().items():
+        if type(env) is cls:
+            return eid
+    raise ValueError(f"RecordEpisode: {type(env).__name__} is not a registered env class; pass env_id=...")
+
+
 class RecordEpisode:
     """Wraps an env of this package (or anything with its ``reset / step / get_state_dict`` surface) and keeps, per env,
     the running episode: states, actions, rewards, flags.  ``flush_trajectory`` turns the episodes of the chosen envs into
@@ -124,7 +133,7 @@ class RecordEpisode:
         self._episode_id = -1
         self._groups: dict = {}
         self._json = dict(
-            env_info=dict(env_id=env_id or type(env).__name__,
+            env_info=dict(env_id=env_id or _env_id_of(env),
                           env_kwargs=dict(obs_mode=getattr(env, "obs_mode", "state"), control_mode=getattr(env, "control_mode", None),
                                           num_envs=self.num_envs, sim_backend="gpu"),
                           max_episode_steps=int(getattr(env, "max_episode_steps", 0))),
