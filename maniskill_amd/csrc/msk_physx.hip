@@ -228,10 +228,15 @@ MSK_API int msk_add_link(msk_ctx* c, int art, int parent_body, int joint_type, c
 MSK_API int msk_set_drive(msk_ctx* c, int link_body, float K, float D, float force_limit, int mode_acc) {
   (void)mode_acc;
   DModel& m = c->model;
-  if (c->finalized) return fail(c, MSK_ERR_INVALID, "set_drive after finalize");
   if (link_body < 0 || link_body >= m.nb || m.bodies[link_body].dof < 0) return fail(c, MSK_ERR_INVALID, "set_drive: not an active joint");
   DBody* b = &m.bodies[link_body];
+  if (c->finalized && b->K == K && b->D == D && b->fmax == force_limit) return MSK_OK;
   b->K = K; b->D = D; b->fmax = force_limit;
+  if (c->finalized) { /* a control-mode switch after gpu_init (agent.set_control_mode): the drive lives in the template, every sub-scene takes it */
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&c->d_model->bodies[link_body], b, sizeof(DBody), hipMemcpyHostToDevice));
+  }
   return MSK_OK;
 }
 

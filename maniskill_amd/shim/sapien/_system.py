@@ -311,7 +311,9 @@ class PhysxSystem:
         for key, (gp, s, n, d, off) in planes.items():
             for sc in self._scenes:
                 o = self._offsets.get(id(sc), np.zeros(3))
-                if abs(float(np.dot(n, o - off))) > 1e-4:
+                # the normal comes out of a float32 quaternion (|n . grid direction| ~ 1e-6): over a few hundred metres of grid that is a
+                # fraction of a millimetre, not a tilted plane -- the criterion is the angle, not the absolute distance
+                if abs(float(np.dot(n, o - off))) > 1e-4 + 2e-5 * float(np.linalg.norm(o - off)):
                     raise RuntimeError("a static plane is not parallel to the sub-scene grid: cannot be shared by all sub-scenes")
         self._shape_owner = []       # template shape index -> the PhysxCollisionShape of the group's first sub-scene (or the global plane)
         self._shape_owner_of_group.append(self._shape_owner)
@@ -629,8 +631,14 @@ class PhysxSystem:
         self._add_force_torque(comp, force, np.cross(point - com, force))
 
     def _drive_changed(self, joint):
-        raise RuntimeError("drive properties cannot be changed after the simulation was initialised (choose the control mode at "
-                           "construction)")
+        """joint.set_drive_properties after gpu_init (agent.set_control_mode -> controller.set_drive_property): the drive is part of the
+        group's template, so the first sub-scene's call moves every sub-scene of its group; the others find it done (msk_set_drive
+        returns at once when nothing changes)"""
+        link = joint.child_link
+        g = self._groups[link._group]
+        g.engine.lib.check(g.engine.ctx, g.engine.lib.set_drive(g.engine.ctx, int(link._body_id), float(joint.stiffness), float(joint.damping),
+                                                                float(min(joint.force_limit, 3.0e38)), 1 if joint.drive_mode == "acceleration" else 0),
+                           "set_drive")
 
     # sapien call -> (msk_batch op, mask) for a scene of several groups
     _BATCH = None

@@ -1,0 +1,8 @@
+"""gymnasium.vector.async_vector_env: the stand-in steps the envs in this process (SyncVectorEnv semantics; one process per env is what
+the reference's CPU-PhysX baseline uses it for, not something this backend needs)."""
+from . import SyncVectorEnv
+
+
+class AsyncVectorEnv(SyncVectorEnv):
+    def __init__(self, env_fns, observation_space=None, action_space=None, shared_memory=True, copy=True, context=None, daemon=True, worker=None):
+        super().__init__(env_fns, observation_space, action_space, copy)

@@ -1,0 +1,22 @@
+"""Stand-in for ``pynvml`` (mani_skill/examples/benchmarking/profiling.py:36-43 asks NVML for the process's GPU memory and carries on without
+it when the library is not found): there is no NVML on an AMD box, so ``nvmlInit`` raises exactly that error."""
+
+
+class NVMLError(Exception):
+    pass
+
+
+class NVMLError_LibraryNotFound(NVMLError):
+    pass
+
+
+def nvmlInit():
+    raise NVMLError_LibraryNotFound("NVML is an NVIDIA library; this is an AMD GPU (stand-in module)")
+
+
+def nvmlDeviceGetHandleByIndex(i):
+    raise NVMLError_LibraryNotFound("no NVML")
+
+
+def nvmlDeviceGetComputeRunningProcesses(h):
+    return []

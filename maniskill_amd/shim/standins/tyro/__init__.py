@@ -1,0 +1,72 @@
+"""Stand-in for ``tyro`` (the reference's scripts declare their arguments as ``Annotated[type, tyro.conf.arg(aliases=[...])]`` dataclass fields
+and parse them with ``tyro.cli``): ``conf.arg`` returns an inert marker, ``cli`` builds the dataclass from ``--field value`` / alias pairs --
+enough to run mani_skill/examples/benchmarking/gpu_sim.py with its own argument names.  Appended to ``sys.path``: a real tyro wins."""
+import dataclasses
+import sys
+import typing
+
+
+class _Arg:
+    def __init__(self, **kw):
+        self.kw = kw
+
+
+class conf:
+    @staticmethod
+    def arg(**kw):
+        return _Arg(**kw)
+
+    FlagConversionOff = object()
+
+
+def _convert(tp, text):
+    origin = typing.get_origin(tp)
+    if origin is typing.Annotated:
+        return _convert(typing.get_args(tp)[0], text)
+    if origin is typing.Union:
+        for a in typing.get_args(tp):
+            if a is type(None):
+                if text in ("None", "none"):
+                    return None
+                continue
+            try:
+                return _convert(a, text)
+            except (TypeError, ValueError):
+                pass
+        raise ValueError(text)
+    if tp is bool:
+        return text.lower() in ("1", "true", "yes")
+    return tp(text)
+
+
+def cli(cls, args=None, **kw):
+    argv = list(sys.argv[1:] if args is None else args)
+    hints = typing.get_type_hints(cls, include_extras=True)
+    names = {}
+    for f in dataclasses.fields(cls):
+        names["--" + f.name.replace("_", "-")] = f.name
+        names["--" + f.name] = f.name
+        tp = hints[f.name]
+        if typing.get_origin(tp) is typing.Annotated:
+            for m in typing.get_args(tp)[1:]:
+                if isinstance(m, _Arg):
+                    for al in m.kw.get("aliases", []):
+                        names[al] = f.name
+    values, i = {}, 0
+    while i < len(argv):
+        key = argv[i]
+        if "=" in key and key.startswith("-"):
+            key, val = key.split("=", 1)
+            argv[i:i + 1] = [key, val]
+        if key not in names:
+            raise SystemExit(f"unknown argument {key}")
+        name = names[key]
+        tp = hints[name]
+        base = typing.get_args(tp)[0] if typing.get_origin(tp) is typing.Annotated else tp
+        if base is bool and (i + 1 >= len(argv) or argv[i + 1].startswith("-")):
+            values[name] = True
+            i += 1
+        else:
+            values[name] = _convert(tp, argv[i + 1])
+            i += 2
+    return cls(**values)

@@ -139,3 +139,23 @@ def test_cameras_of_a_scene_with_several_groups_on_cpu_checker(built):
 @pytest.mark.gpu
 def test_cameras_of_a_scene_with_several_groups_on_hip(built):
     _multi_group_camera("hip")
+
+
+def _control_mode_switch(backend):
+    import json
+    r = subprocess.run([sys.executable, os.path.join(HERE, "ref_control_mode_switch.py"), backend], cwd=HERE, capture_output=True, text=True, timeout=3000)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("CMS ")]
+    assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(line[-1][4:])
+    assert res["control_mode"] == "pd_joint_pos" and res["arm_error"] < 0.05, res      # the new drives hold the arm at the absolute targets
+
+
+@needs_ref
+def test_control_mode_switch_after_gpu_init_on_cpu_checker(built):
+    _control_mode_switch("oracle")
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_control_mode_switch_after_gpu_init_on_hip(built):
+    _control_mode_switch("hip")
