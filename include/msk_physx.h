@@ -95,12 +95,14 @@ int msk_add_link(msk_ctx* ctx, int art, int parent_body, int joint_type,
                  float joint_friction);
 /* fix_root_link = False (utils/building/articulation_builder.py:212; agents with a free base: mani_skill/agents/robots/anymal, unitree_*,
  * the MJCF ant / humanoid of envs/tasks/control): the articulation's root link is not held by the world.  It gets six coordinates of
- * its own -- the root's spatial velocity about the sub-scene origin (angular, then linear: Pluecker) -- that enter the joint-space
- * inertia, the solver and the integration like joint coordinates do; qpos / qvel keep SAPIEN's layout (joints only), the root's pose
+ * its own -- those of a free body: velocity of its centre of mass, then angular velocity -- that enter the joint-space inertia, the
+ * solver and the integration like joint coordinates do; qpos / qvel keep SAPIEN's layout (joints only), the root's pose
  * and velocity travel in its row of rigid_body_data (msk_apply with MSK_APPLY_ART_ROOT_POSE / MSK_APPLY_ART_ROOT_VELOCITY).
  * Call before msk_finalize; joint dofs + 6 per floating root <= MSK_MAX_DOF - 1. */
 int msk_set_articulation_floating(msk_ctx* ctx, int articulation);
-/* PhysxArticulationJoint.set_drive_properties (agents/controllers/pd_joint_pos.py:38-52) */
+/* PhysxArticulationJoint.set_drive_properties (agents/controllers/pd_joint_pos.py:38-52).  Also after msk_finalize (BaseAgent.set_control_mode
+ * re-programs the drives of a running simulation: agents/base_agent.py, examples/benchmarking/gpu_sim.py): the drive belongs to the template,
+ * every sub-scene takes the new values; synchronises the device when something changes. */
 int msk_set_drive(msk_ctx* ctx, int link_body, float stiffness, float damping,
                   float force_limit, int mode_acceleration);
 /* PhysxArticulation.create_fixed_tendon for URDF mimic joints
