@@ -1,0 +1,111 @@
+"""The third-party stand-ins of maniskill_amd/shim/standins (used only where the real package is absent) and the shim's PinocchioModel:
+the behaviour the reference's code relies on, checked directly."""
+import dataclasses
+import os
+import sys
+import typing
+
+import numpy as np
+import pytest
+
+import maniskill_amd.shim as shim
+
+STANDINS = shim.STANDIN_DIR
+
+
+def _load(name):
+    """import a stand-in by path, whatever else of that name is installed"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("standin_" + name, os.path.join(STANDINS, name, "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_h5py_standin_round_trip(tmp_path):
+    h5py = _load("h5py")
+    path = tmp_path / "traj.h5"
+    f = h5py.File(path, "w")
+    g = f.create_group("traj_0", track_order=True)
+    g.create_dataset("actions", data=np.arange(12, dtype=np.float32).reshape(4, 3), dtype=np.float32)
+    g.create_dataset("rgb", data=np.zeros((2, 4, 4, 3), np.uint8), dtype=np.uint8, compression="gzip", compression_opts=5)
+    obs = g.create_group("obs", track_order=True)
+    obs.create_dataset("agent/qpos", data=np.ones((5, 9)))
+    g.attrs["note"] = "x"
+    assert f.filename == os.fspath(path) and list(f.keys()) == ["traj_0"] and "traj_0/obs/agent/qpos" in f
+    f.close()
+    with h5py.File(path, "r") as r:
+        assert list(r["traj_0"].keys()) == ["actions", "rgb", "obs"]
+        assert isinstance(r["traj_0"]["actions"], h5py.Dataset) and isinstance(r["traj_0/obs"], h5py.Group)
+        assert r["traj_0"]["actions"].shape == (4, 3) and r["traj_0"]["actions"][2, 1] == 7.0 and r["traj_0"]["actions"][:].dtype == np.float32
+        assert r["traj_0/obs/agent/qpos"][()].sum() == 45 and r["traj_0"].attrs["note"] == "x"
+        w = h5py.File(tmp_path / "merged.h5", "w")
+        r.copy("traj_0", w, "traj_7")
+        w.close()
+    with h5py.File(tmp_path / "merged.h5", "r") as m:
+        assert np.array_equal(m["traj_7/actions"][:], np.arange(12, dtype=np.float32).reshape(4, 3))
+    with pytest.raises(OSError):
+        (tmp_path / "real.h5").write_bytes(b"\\x89HDF\\r\\n\\x1a\\n" + b"0" * 64)
+        h5py.File(tmp_path / "real.h5", "r")
+
+
+def test_imageio_standin_keeps_the_frames(tmp_path):
+    imageio = _load("imageio")
+    frames = [np.full((4, 6, 3), k, np.uint8) for k in range(5)]
+    with pytest.warns(UserWarning, match="raw frames"):
+        w = imageio.get_writer(os.fspath(tmp_path / "v.mp4"), fps=30, quality=5)
+        for fr in frames:
+            w.append_data(fr)
+        w.close()
+    back = imageio.mimread(os.fspath(tmp_path / "v.mp4"))
+    assert len(back) == 5 and all(np.array_equal(a, b) for a, b in zip(back, frames))
+
+
+def test_tyro_standin_parses_the_harness_arguments():
+    tyro = _load("tyro")
+
+    @dataclasses.dataclass
+    class Args:
+        env_id: typing.Annotated[str, tyro.conf.arg(aliases=["-e"])] = "PickCube-v1"
+        num_envs: typing.Annotated[int, tyro.conf.arg(aliases=["-n"])] = 1024
+        cpu_sim: bool = False
+        control_freq: typing.Optional[int] = 60
+        save_results: typing.Optional[str] = None
+
+    a = tyro.cli(Args, args=["-e", "X-v1", "-n=4096", "--control-freq=50", "--cpu-sim", "--save-results", "r.csv"])
+    assert a == Args("X-v1", 4096, True, 50, "r.csv")
+    assert tyro.cli(Args, args=[]) == Args()
+    with pytest.raises(SystemExit):
+        tyro.cli(Args, args=["--nope", "1"])
+
+
+def test_pinocchio_model_ik_reaches_what_its_fk_reports():
+    shim.install()
+    import sapien
+    from sapien.wrapper.pinocchio_model import PinocchioModel
+    urdf = """<robot name="r"><link name="base"/><link name="l1"/><link name="l2"/><link name="l3"/><link name="tip"/>
+      <joint name="j1" type="revolute"><parent link="base"/><child link="l1"/><origin xyz="0 0 0.1"/><axis xyz="0 0 1"/><limit lower="-3" upper="3"/></joint>
+      <joint name="j2" type="revolute"><parent link="l1"/><child link="l2"/><origin xyz="0.2 0 0" rpy="0 0.3 0"/><axis xyz="0 1 0"/><limit lower="-3" upper="3"/></joint>
+      <joint name="j3" type="prismatic"><parent link="l2"/><child link="l3"/><origin xyz="0.2 0 0"/><axis xyz="1 0 0"/><limit lower="-0.1" upper="0.3"/></joint>
+      <joint name="jt" type="fixed"><parent link="l3"/><child link="tip"/><origin xyz="0.05 0 0" rpy="0 0 0.2"/></joint></robot>"""
+    pm = PinocchioModel(urdf, [0, 0, -9.81])
+    pm.set_joint_order(["j1", "j2", "j3"])
+    pm.set_link_order(["base", "l1", "l2", "l3", "tip"])
+    q_true = np.array([0.7, -0.4, 0.12])
+    pm.compute_forward_kinematics(q_true)
+    target = pm.get_link_pose(4)
+    # position-only reachability of a 3-dof chain: ask for the pose its own FK produced, from a different start
+    q, ok, err = pm.compute_inverse_kinematics(4, target, initial_qpos=np.array([0.2, 0.1, 0.0]), active_qmask=np.ones(3, bool), max_iterations=200)
+    assert ok and np.abs(err).max() < 1e-4
+    pm.compute_forward_kinematics(q)
+    got = pm.get_link_pose(4)
+    assert np.abs(np.asarray(got.p) - np.asarray(target.p)).max() < 1e-4
+    # finite-difference check of the Jacobian (base frame, rows [linear; angular])
+    J = pm.get_link_jacobian(4)
+    eps = 1e-6
+    for k in range(3):
+        dq = q.copy(); dq[k] += eps
+        pm.compute_forward_kinematics(dq)
+        p2 = np.asarray(pm.get_link_pose(4).p, dtype=np.float64)
+        assert np.abs((p2 - np.asarray(got.p, dtype=np.float64)) / eps - J[:3, k]).max() < 2e-2
+    assert isinstance(target, sapien.Pose)
