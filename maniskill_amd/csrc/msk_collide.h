@@ -752,49 +752,90 @@ MSK_DEV int epa(const CCtx& m, const CShape* A, const pose* TA, const CShape* B,
     nf = 4;
     grp_sync();
   }
+  /* The serial statement of the oracle (oracle/orc_collide.c epa) scans the face list three times per iteration -- closest face, faces
+   * visible from the new vertex with their horizon edges, free slots for the new faces -- and every lane of the group used to run those
+   * scans redundantly, one dependent LDS read after the other (an item through EPA took 48 k cycles on average, 1.7 M at worst).  Here
+   * the scans run over the group's 16 lanes (face f on lane f mod 16) and come back as ballots; what has to stay in order -- the edge
+   * list (an edge cancels its reverse; removal swaps in the last entry) and the slots the new faces take -- is walked in exactly the
+   * serial order over those ballots, so the polytope, its face numbering and the result are the oracle's bit for bit. */
+  static_assert(ORC_EPA_MAXF <= 96 && NPG == 16, "face masks: 96 faces in a 64 + 32 bit pair, six ballots of 16");
   int bestf = 0;
   for (int it = 0; it < ORC_EPA_ITERS; ++it) {
-    bestf = -1;
-    float bd = 3.0e38f;
-    for (int f = 0; f < nf; ++f)
-      if (fs[f].alive && fs[f].d < bd) { bd = fs[f].d; bestf = f; }
+    { /* closest alive face; equal distances keep the lower index, as the ascending scan with `<` does */
+      float key = -3.0e38f;
+      int bf = NO_INDEX;
+      for (int f = m.gl; f < nf; f += NPG) {
+        const float d = fs[f].d;
+        if (fs[f].alive && -d > key) { key = -d; bf = f; }
+      }
+      grp_argmax(key, bf);
+      bestf = (bf == NO_INDEX) ? -1 : bf;
+    }
     if (bestf < 0) return 0;
     const v3 bn = fs[bestf].n;
     const float bdist = fs[bestf].d;
     mvert w = msupport(m, A, TA, B, TB, bn);
     float dist = v3_dot(w.w, bn);
     if (dist - bdist < 2e-5f || nv >= ORC_EPA_MAXV) break;
-    /* remove faces visible from w, collect the horizon */
+    /* faces visible from w (a face's test does not depend on the faces removed before it) */
+    unsigned long long vlo = 0ull;
+    unsigned vhi = 0u;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int f = k * NPG + m.gl;
+      bool vis = false;
+      if (f < nf && fs[f].alive) vis = v3_dot(fs[f].n, v3_sub(w.w, vs[fs[f].i[0]].w)) > 0.0f;
+      const unsigned bm = grp_ballot(vis);
+      if (k < 4) vlo |= (unsigned long long)bm << (k * NPG);
+      else vhi |= bm << ((k - 4) * NPG);
+    }
+    grp_sync();
+    /* remove them in ascending order, collect the horizon */
     int ne = 0;
-    for (int f = 0; f < nf; ++f) {
-      if (!fs[f].alive) continue;
+    while (vlo != 0ull || vhi != 0u) {
+      int f;
+      if (vlo != 0ull) { f = __ffsll((long long)vlo) - 1; vlo &= vlo - 1ull; }
+      else { f = 64 + __ffs((int)vhi) - 1; vhi &= vhi - 1u; }
       const int fi0 = fs[f].i[0], fi1 = fs[f].i[1], fi2 = fs[f].i[2];
-      if (v3_dot(fs[f].n, v3_sub(w.w, vs[fi0].w)) > 0.0f) {
-        grp_sync();
-        if (m.gl == 0) fs[f].alive = 0;
-        for (int k = 0; k < 3; ++k) {
-          int a = (k == 0) ? fi0 : ((k == 1) ? fi1 : fi2), b = (k == 0) ? fi1 : ((k == 1) ? fi2 : fi0);
-          int found = -1;
-          for (int q = 0; q < ne; ++q) if (edges[q * 2] == b && edges[q * 2 + 1] == a) { found = q; break; }
-          grp_sync();
-          if (found >= 0) {
-            if (m.gl == 0) { edges[found * 2] = edges[(ne - 1) * 2]; edges[found * 2 + 1] = edges[(ne - 1) * 2 + 1]; }
-            ne--;
-          } else if (ne < ORC_EPA_MAXF) {
-            if (m.gl == 0) { edges[ne * 2] = a; edges[ne * 2 + 1] = b; }
-            ne++;
-          }
-          grp_sync();
+      grp_sync();
+      if (m.gl == 0) fs[f].alive = 0;
+      for (int k = 0; k < 3; ++k) {
+        int a = (k == 0) ? fi0 : ((k == 1) ? fi1 : fi2), b = (k == 0) ? fi1 : ((k == 1) ? fi2 : fi0);
+        int found = -1;
+        for (int q0 = 0; q0 < ne && found < 0; q0 += NPG) { /* first reverse edge: the lowest matching lane of the first matching chunk */
+          const int q = q0 + m.gl;
+          const unsigned bm = grp_ballot(q < ne && edges[q * 2] == b && edges[q * 2 + 1] == a);
+          if (bm != 0u) found = q0 + __ffs((int)bm) - 1;
         }
+        grp_sync();
+        if (found >= 0) {
+          if (m.gl == 0) { edges[found * 2] = edges[(ne - 1) * 2]; edges[found * 2 + 1] = edges[(ne - 1) * 2 + 1]; }
+          ne--;
+        } else if (ne < ORC_EPA_MAXF) {
+          if (m.gl == 0) { edges[ne * 2] = a; edges[ne * 2 + 1] = b; }
+          ne++;
+        }
+        grp_sync();
       }
     }
     if (ne == 0) break;
     lds_put_mvert(m, &vs[nv], w);
     grp_sync();
+    /* free slots in ascending order (the serial scan finds the first dead face each time; the faces it fills are alive afterwards) */
+    unsigned long long dlo = 0ull;
+    unsigned dhi = 0u;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int f = k * NPG + m.gl;
+      const unsigned bm = grp_ballot(f < nf && !fs[f].alive);
+      if (k < 4) dlo |= (unsigned long long)bm << (k * NPG);
+      else dhi |= bm << ((k - 4) * NPG);
+    }
     int stop = 0;
     for (int q = 0; q < ne; ++q) {
       int slot = -1;
-      for (int f = 0; f < nf; ++f) if (!fs[f].alive) { slot = f; break; }
+      if (dlo != 0ull) { slot = __ffsll((long long)dlo) - 1; dlo &= dlo - 1ull; }
+      else if (dhi != 0u) { slot = 64 + __ffs((int)dhi) - 1; dhi &= dhi - 1u; }
       if (slot < 0) { if (nf >= ORC_EPA_MAXF) { stop = 1; break; } slot = nf++; }
       grp_sync();
       epa_make_face(m, vs, &fs[slot], edges[q * 2], edges[q * 2 + 1], nv);
