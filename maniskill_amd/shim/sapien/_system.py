@@ -64,6 +64,7 @@ class _Group:
         self.envs, self.engine, self.template = list(envs), engine, template
         self.n, self.nb, self.na, self.max_dof = len(envs), engine.bodies_per_env, engine.arts_per_env, engine.max_dof
         self.base = self.abase = 0        # first row of the group in the unified body / articulation buffers (_MultiBuffers)
+        self.npassive, self.pbase = 0, 0  # pose-only actors per sub-scene and their first row (behind every engine row)
 
 
 class _Tensor:
@@ -92,6 +93,9 @@ class _MultiBuffers:
             g.base, g.abase = rows, arows
             rows += g.n * g.nb
             arows += g.n * max(g.na, 0)
+        for g in gs:                                   # pose-only actors: rows behind the engines' ranges
+            g.pbase = rows
+            rows += g.n * g.npassive
         self.max_dof = max(g.max_dof for g in gs)
         self.max_links = 1
         for g in gs:
@@ -370,6 +374,25 @@ class PhysxSystem:
                     shape_ids.setdefault(id(s), sid)
                     self._shape_owner.append(s)
 
+        # Pose-only actors.  The engine maps a lane to a body (63 per sub-scene).  Tasks that keep hundreds of kinematic actors without any
+        # collision shape around only to move them (the 1010 "dots" of envs/tasks/drawing/draw.py:119-149) do not need the engine for
+        # those: when the sub-scene does not fit otherwise, such actors -- the last ones first -- get a row of cuda_rigid_body_data that
+        # set_pose / pose read and write, and nothing else.  (They are not drawn at their moved poses: the rasteriser takes body poses
+        # from the engine)
+        passive = {}
+        movable = [c for c in env0 if not isinstance(c, P.PhysxRigidStaticComponent)]
+        cap = 63
+        if len(movable) > cap:
+            cand = [c for c in movable if isinstance(c, P.PhysxRigidDynamicComponent) and not isinstance(c, P.PhysxArticulationLinkComponent)
+                    and c.kinematic and not c.collision_shapes]
+            for c in reversed(cand):
+                if len(movable) - len(passive) <= cap:
+                    break
+                passive[id(c)] = 0
+            for k, c in enumerate([c for c in env0 if id(c) in passive]):
+                passive[id(c)] = k
+        self._npassive_of_group = getattr(self, "_npassive_of_group", {})
+        self._npassive_of_group[gi] = len(passive)
         for c in env0:
             if isinstance(c, P.PhysxRigidStaticComponent):
                 add_shapes(c, -1, c.entity._pose)
@@ -396,6 +419,8 @@ class PhysxSystem:
                 if j.dof:
                     tpl.set_drive(bid, j.stiffness, j.damping, j.force_limit, j.drive_mode)
                 add_shapes(c, bid, None)
+            elif id(c) in passive:
+                body_ids[id(c)] = -2 - passive[id(c)]      # pose-only: a row of cuda_rigid_body_data outside the engine's range
             else:
                 m, com, I6 = c._mass_tensor()
                 ep = c.entity._pose
@@ -500,12 +525,14 @@ class PhysxSystem:
                 eng.set_env_boxes(sid, hs, lp)
             for bid, (m, I) in inst["masses"].items():
                 eng.set_env_masses(bid, m, I)
-            self._groups.append(_Group(envs, eng, tpl))
+            g = _Group(envs, eng, tpl)
+            g.npassive = self._npassive_of_group.get(len(self._groups), 0)
+            self._groups.append(g)
         g0 = self._groups[0]
         self._engine, self._template = g0.engine, g0.template      # single-group scenes: the zero-copy fast path
         self._nb, self._na, self._max_dof = g0.nb, g0.na, g0.max_dof
         self._env_box_shapes = self._env_box_shapes_of_group.get(0, {})
-        if len(self._groups) == 1:
+        if len(self._groups) == 1 and g0.npassive == 0:
             eng = g0.engine
             self._multi = None
             self.cuda_rigid_body_data = eng.cuda_rigid_body_data
@@ -523,13 +550,20 @@ class PhysxSystem:
         else:
             self._engines = [g.engine for g in self._groups]
             self._multi = _MultiBuffers(self, torch_device)
+            rows = self.cuda_rigid_body_data.torch()
+            for c in self._components:                    # pose-only actors start where their entities were placed
+                if getattr(c, "_body_id", -1) <= -2 and c.entity is not None:
+                    ep = c.entity._pose
+                    rows[self._pose_index(c), :7] = torch.as_tensor(np.concatenate([ep._p, ep._q]), dtype=torch.float32, device=rows.device)
         self._initialized = True
 
     # indices ------------------------------------------------------------------------------------------------------------
     def _pose_index(self, comp) -> int:
-        if comp._body_id < 0:
+        if comp._body_id == -1:
             raise RuntimeError("static bodies have no row in cuda_rigid_body_data")
         g = self._groups[comp._group]
+        if comp._body_id <= -2:
+            return g.pbase + comp._lenv * g.npassive + (-2 - comp._body_id)
         return g.base + comp._lenv * g.nb + comp._body_id
 
     def _art_index(self, art) -> int:
@@ -548,13 +582,13 @@ class PhysxSystem:
         return self.cuda_rigid_body_data.torch()[self._pose_index(comp)].detach().cpu().numpy().copy()
 
     def _read_body_pose(self, comp) -> Pose:
-        if comp._body_id < 0:
+        if comp._body_id == -1:
             return comp.entity._pose
         r = self._read_body_row(comp)
         return Pose(r[:3], r[3:7])
 
     def _write_body_pose(self, comp, pose: Pose):
-        if comp._body_id < 0:
+        if comp._body_id == -1:
             raise RuntimeError("static bodies cannot be moved after the simulation was initialised")
         self._sync_in()
         row = self.cuda_rigid_body_data.torch()[self._pose_index(comp)]
@@ -838,7 +872,7 @@ class PhysxCpuSystem(PhysxSystem):
         self._start_engine(dev, lib, host)
         # host-side initial state recorded before the first step
         for c in self._components:
-            if c._body_id < 0:
+            if c._body_id == -1:
                 continue
             if isinstance(c, self._P.PhysxArticulationLinkComponent):
                 continue

@@ -717,10 +717,17 @@ class RenderSystemGroup:
         dense = sum(1 for n in counts if n > KEEP)
         MAX_TRIS_PER_PART = KEEP if not dense else max(64, min(KEEP, (5200 - small) // dense))   # template: 8192 triangles, 4096 vertices
         declared = dict(getattr(self._px, "_env_box_shapes_of_group", {}).get(gi, {}))
+        skipped_pose_only = 0
         for rb in rs0.render_bodies:
             if rb.visibility <= 0:
                 continue
             ent = rb.entity
+            pb = ent._physx_body() if ent is not None else None
+            if pb is not None and pb._body_id <= -2:
+                # pose-only actor (_system.py: kinematic, shape-less, beyond the engine's body capacity): the rasteriser takes body poses
+                # from the engine's state, which has no row for it -- left out of the picture rather than drawn frozen where it was built
+                skipped_pose_only += 1
+                continue
             body, fold = self._body_of(ent)
             seg = int(ent.per_scene_id)
             for shape in rb.render_shapes:
@@ -756,6 +763,10 @@ class RenderSystemGroup:
                     L.check(ctx, L.render_set_base_color(ctx, rsid, N._fa(rgba, 4)), "render_set_base_color")
                     if follows is not None:
                         L.check(ctx, L.render_bind_env_box(ctx, rsid, follows), "render_bind_env_box")
+        if skipped_pose_only:
+            import warnings
+            warnings.warn(f"{skipped_pose_only} pose-only actors per sub-scene (kinematic, no collision shape, beyond the engine's 63 bodies) "
+                          "are not drawn by the camera")
         dirs, cols = [], []
         for l in rs0.lights:
             if isinstance(l, RenderDirectionalLightComponent) and len(dirs) < 4:

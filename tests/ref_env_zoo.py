@@ -19,6 +19,9 @@ ENV_IDS = [
     "UnitreeG1PlaceAppleInBowl-v1",
     # free-floating roots (fix_root_link = False: msk_set_articulation_floating)
     "MS-AntWalk-v1", "MS-AntRun-v1", "MS-HumanoidStand-v1", "MS-HumanoidWalk-v1", "MS-HumanoidRun-v1",
+    # hundreds of kinematic, shape-less "dot" actors per env: the ones over the engine's body capacity are pose-only rows of the
+    # unified buffer (shim/_system.py: passive actors)
+    "DrawTriangle-v1", "TableTopFreeDraw-v1",
 ]
 NUM_ENVS = int(__import__("os").environ.get("ZOO_ENVS", "2"))
 NEEDS_RENDER_BODIES = {"PushT-v1"}   # its scene builder reads the render shapes it has just attached (push_t.py:53)

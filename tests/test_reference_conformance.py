@@ -92,13 +92,13 @@ def _run_zoo(backend, steps="3", ids=(), envs="2"):
 
 @needs_ref
 def test_reference_env_zoo_on_cpu_checker(built):
-    """Every task of the reference's registry that needs no downloaded asset (41 of 74: tests/ref_env_zoo.py) is built by the reference's own
+    """Every task of the reference's registry that needs no downloaded asset (43 of 74: tests/ref_env_zoo.py) is built by the reference's own
     code over the shim -- Panda, Fetch-free tabletop tasks, two-robot tasks, SO100, the MJCF control tasks, D'Claw valves with a different
     valve per sub-scene, Allegro hand, TriFinger, Unitree G1 (fixed base) -- reset and stepped; observations, rewards and the raw
     simulation buffers stay finite."""
     res = _run_zoo("oracle")
     bad = {k: v for k, v in res.items() if v != "ok"}
-    assert not bad and len(res) >= 41, bad
+    assert not bad and len(res) >= 43, bad
 
 
 @needs_ref
@@ -115,7 +115,7 @@ def test_overlapping_link_hulls_stay_finite(built):
 def test_reference_env_zoo_on_hip(built):
     res = _run_zoo("hip", "30", (), "8")
     bad = {k: v for k, v in res.items() if v != "ok"}
-    assert not bad and len(res) >= 41, bad
+    assert not bad and len(res) >= 43, bad
 
 
 def _multi_group_camera(backend):
@@ -139,6 +139,29 @@ def test_cameras_of_a_scene_with_several_groups_on_cpu_checker(built):
 @pytest.mark.gpu
 def test_cameras_of_a_scene_with_several_groups_on_hip(built):
     _multi_group_camera("hip")
+
+
+def _pose_only_actors(backend):
+    import json
+    r = subprocess.run([sys.executable, os.path.join(HERE, "ref_pose_only_actors.py"), backend], cwd=HERE, capture_output=True, text=True, timeout=3000)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("POA ")]
+    assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(line[-1][4:])
+    assert res["engine_bodies"] == 63 and res["pose_only"] > 0 and res["rows"] == 3 * (res["engine_bodies"] + res["pose_only"]), res
+    assert res["pose_error"] == 0.0 and res["kept_env0"] == 0.0, res                 # written poses stay put, a reset of env 1 leaves env 0 alone
+    assert abs(res["reset_env1_z"] + 0.003) < 1e-6 and all(abs(z + 0.003) < 1e-6 for z in res["drawn_z"]), res
+
+
+@needs_ref
+def test_pose_only_actors_beyond_the_body_capacity_on_cpu_checker(built):
+    """DrawTriangle-v1: 300 kinematic shape-less dots per env + robot links > 63 engine bodies."""
+    _pose_only_actors("oracle")
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_pose_only_actors_beyond_the_body_capacity_on_hip(built):
+    _pose_only_actors("hip")
 
 
 def _control_mode_switch(backend):
