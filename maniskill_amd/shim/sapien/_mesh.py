@@ -390,6 +390,187 @@ def cook_multiple_convex(path, scale=(1, 1, 1)):
     return out
 
 
+def _clip_triangles(tri, axis, value):
+    """Split triangles (n, 3, 3) by the plane x[axis] = value -> (below, above), each (m, 3, 3); cut triangles are re-triangulated as fans."""
+    d = tri[:, :, axis] - value
+    lo_all, hi_all = (d <= 0).all(axis=1), (d >= 0).all(axis=1)
+    below, above = [tri[lo_all]], [tri[hi_all & ~lo_all]]
+    for t, dd in zip(tri[~lo_all & ~hi_all], d[~lo_all & ~hi_all]):
+        polys = ([], [])
+        for i in range(3):
+            a, b, da, db = t[i], t[(i + 1) % 3], dd[i], dd[(i + 1) % 3]
+            if da <= 0:
+                polys[0].append(a)
+            if da >= 0:
+                polys[1].append(a)
+            if (da < 0 < db) or (db < 0 < da):
+                x = a + (b - a) * (da / (da - db))
+                x[axis] = value
+                polys[0].append(x)
+                polys[1].append(x)
+        for poly, out in zip(polys, (below, above)):
+            if len(poly) >= 3:
+                out.append(np.array([[poly[0], poly[k], poly[k + 1]] for k in range(1, len(poly) - 1)]))
+    return np.concatenate(below), np.concatenate(above)
+
+
+def _surface_samples(tri, spacing):
+    """Points on the triangles no farther apart than ~`spacing` (corners, and a barycentric lattice on the large ones)."""
+    pts = [tri.reshape(-1, 3)]
+    e = np.linalg.norm(tri - np.roll(tri, 1, axis=1), axis=2).max(axis=1)
+    n = np.minimum(np.ceil(e / spacing).astype(int), 64)
+    for k in np.unique(n[n > 1]):
+        t = tri[n == k]
+        i, j = np.meshgrid(np.arange(k + 1), np.arange(k + 1), indexing="ij")
+        m = (i + j) <= k
+        w = np.stack([i[m], j[m], k - i[m] - j[m]], axis=1) / float(k)          # (q, 3) barycentric weights
+        pts.append(np.einsum("qc,ncd->nqd", w, t).reshape(-1, 3))
+    return np.concatenate(pts)
+
+
+def _inside_solid(points, tri):
+    """Ray parity (+z) of `points` against the triangles: True where a point lies inside the closed surface.  Points whose ray grazes
+    an edge are ambiguous; the caller jitters.  Open surfaces give parity of whatever is above the point, which is what a thin
+    sheet should give (nothing is inside)."""
+    out = np.zeros(len(points), dtype=bool)
+    if not len(points):
+        return out
+    lo, hi = points[:, :2].min(0), points[:, :2].max(0)
+    t = tri[(tri[:, :, 0].max(1) >= lo[0]) & (tri[:, :, 0].min(1) <= hi[0]) & (tri[:, :, 1].max(1) >= lo[1]) & (tri[:, :, 1].min(1) <= hi[1])]
+    if not len(t):
+        return out
+    a, b, c = t[:, 0], t[:, 1], t[:, 2]
+    det = (b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])
+    ok = np.abs(det) > 1e-18
+    a, b, c, det = a[ok], b[ok], c[ok], det[ok]
+    for i0 in range(0, len(points), 256):
+        p = points[i0:i0 + 256]
+        px, py = p[:, 0:1] - a[None, :, 0], p[:, 1:2] - a[None, :, 1]
+        u = (px * (c[:, 1] - a[:, 1]) - py * (c[:, 0] - a[:, 0])) / det
+        v = (py * (b[:, 0] - a[:, 0]) - px * (b[:, 1] - a[:, 1])) / det
+        hit = (u >= 0) & (v >= 0) & (u + v <= 1)
+        z = a[None, :, 2] + u * (b[:, 2] - a[:, 2]) + v * (c[:, 2] - a[:, 2])
+        out[i0:i0 + 256] = ((hit & (z > p[:, 2:3])).sum(axis=1) % 2) == 1
+    return out
+
+
+def _concavity(tri, cuts, spacing, whole):
+    """How far the convex hull of a surface piece reaches into free space.  Sample points of the hull's faces -> their distances d to
+    the surface of the WHOLE mesh; samples of faces that lie in one of the piece's cutting planes and fall inside the solid count as
+    0 (the material goes on behind the cut).  `whole` = (KD-tree of surface samples, triangles) of the whole mesh.
+    -> (hull vertices, max d, excess) with excess = sum d x area, a stand-in for the volume the hull adds."""
+    from scipy.spatial import ConvexHull
+    pts = np.unique(np.round(tri.reshape(-1, 3), 7), axis=0)
+    try:
+        h = ConvexHull(pts)
+    except Exception:                                        # flat or degenerate piece: its own hull, nothing to refine
+        return pts, 0.0, 0.0
+    hv = pts[h.vertices]
+    faces = pts[h.simplices]                                 # (m, 3, 3)
+    on_cut = np.zeros(len(faces), dtype=bool)
+    for axis, value in cuts:
+        on_cut |= (np.abs(faces[:, :, axis] - value) < 1e-6).all(axis=1)
+    area = 0.5 * np.linalg.norm(np.cross(faces[:, 1] - faces[:, 0], faces[:, 2] - faces[:, 0]), axis=1)
+    # probes: face centroids + the centroids of the four sub-triangles of every face larger than a probe cell
+    mid = 0.5 * (faces + np.roll(faces, -1, axis=1))
+    big = area > (4.0 * spacing) ** 2
+    sub = [np.stack([faces[big][:, k], mid[big][:, k], mid[big][:, (k + 2) % 3]], axis=1).mean(axis=1) for k in range(3)] + [mid[big].mean(axis=1)]
+    probe = np.concatenate([faces.mean(axis=1)] + sub)
+    w = np.concatenate([np.where(big, 0.2, 1.0) * area, np.tile(0.2 * area[big], 4)])
+    cutp = np.concatenate([on_cut, np.tile(on_cut[big], 4)])
+    tree, wtri = whole
+    cap = 40.0 * spacing                                     # "far" is all the ranking needs to know
+    d, _ = tree.query(probe, distance_upper_bound=cap, workers=-1)
+    d = np.maximum(np.minimum(d, cap) - 0.5 * spacing, 0.0)  # the sampling's own resolution
+    if cutp.any():
+        jit = probe[cutp] + np.array([1.37e-5, 2.11e-5, 0.0])    # off the mesh's own edge / vertex coordinates
+        d[np.flatnonzero(cutp)[_inside_solid(jit, wtri)]] = 0.0
+    return hv, float(d.max()), float((d * w).sum())
+
+
+def convex_decompose(verts, faces, tol=None, max_parts=24, groups=None):
+    """Approximate convex decomposition of a triangle mesh that is NOT convex (static scenery added with
+    add_nonconvex_collision_from_file: PhysX collides its triangles as they are; this engine collides convex shapes).  The mesh is
+    bisected recursively -- always the piece whose hull adds the most volume, across the axis whose halves add the least, triangles
+    clipped at the cut -- until every piece's hull stays within `tol` of the surface (default: 1 % of the bounding-box diagonal, at
+    least 2 mm) or `max_parts` pieces exist.  `groups` (one id per face) names parts of the mesh that start out as pieces of their
+    own.  -> (list of hull vertex arrays, largest remaining hull-to-surface distance).  Deterministic."""
+    import heapq
+    from scipy.spatial import cKDTree
+    v = np.asarray(verts, dtype=np.float64)
+    tri = v[np.asarray(faces, dtype=np.int64)]
+    ok = np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1) > 1e-14
+    tri = tri[ok]
+    gid = np.zeros(len(tri), dtype=np.int64) if groups is None else np.asarray(groups, dtype=np.int64)[ok]
+    diag = float(np.linalg.norm(v.max(0) - v.min(0)))
+    tol = max(0.002, 0.01 * diag) if tol is None else float(tol)
+    spacing = 0.5 * tol
+    surf = _surface_samples(tri, spacing)
+    surf = np.unique(np.round(surf / (0.5 * spacing)).astype(np.int64), axis=0) * (0.5 * spacing)     # one sample per half-spacing cell
+    whole = (cKDTree(surf), tri)
+    heap, done, tick = [], [], 0
+    for g in np.unique(gid):
+        hv, dmax, ex = _concavity(tri[gid == g], (), spacing, whole)
+        heapq.heappush(heap, (-ex, tick, dmax, tri[gid == g], (), hv))
+        tick += 1
+    while heap and len(heap) + len(done) < max_parts:
+        ex, _, dmax, t, cuts, hv = heapq.heappop(heap)
+        if dmax <= tol:
+            done.append((dmax, hv))
+            continue
+        p = t.reshape(-1, 3)
+        lo, hi = p.min(0), p.max(0)
+        best = None
+        for axis in range(3):
+            if hi[axis] - lo[axis] < 2.0 * tol:
+                continue
+            value = float(0.5 * (lo[axis] + hi[axis]))
+            halves = _clip_triangles(t, axis, value)
+            if min(len(halves[0]), len(halves[1])) == 0:
+                continue
+            kids = [(half, cuts + ((axis, value),)) + _concavity(half, cuts + ((axis, value),), spacing, whole) for half in halves]
+            score = sum(k[4] for k in kids)
+            if best is None or score < best[0] - 1e-12:
+                best = (score, kids)
+        if best is None:
+            done.append((dmax, hv))
+            continue
+        for half, hcuts, hhv, hd, hex_ in best[1]:
+            heapq.heappush(heap, (-hex_, tick, hd, half, hcuts, hhv))
+            tick += 1
+    pieces = done + [(dmax, hv) for _, _, dmax, _, _, hv in heap]
+    worst = max(d for d, _ in pieces)
+    return [hv for _, hv in pieces if len(hv) >= 4], worst
+
+
+def cook_nonconvex(path, max_parts=16):
+    """add_nonconvex_collision_from_file: the file as at most max(`max_parts`, number of parts of the file) convex pieces in the file's
+    own frame and units -- every part starts as its hull; the piece whose hull adds the most volume is cut until all hulls stay
+    within 1 % of the mesh's size of the surface or the budget is spent (convex_decompose).
+    -> (list of hull vertex arrays, largest hull-to-surface distance left, as a fraction of the mesh's bounding-box diagonal)"""
+    key = ("nonconvex", os.path.abspath(path), os.path.getmtime(path), max_parts)
+    if key in _cache:
+        return _cache[key]
+    vs, fs, gs, o = [], [], [], 0
+    for k, p in enumerate(load_mesh_parts(path)):
+        if len(p["faces"]) == 0:
+            continue
+        vs.append(np.asarray(p["vertices"], dtype=np.float64))
+        fs.append(np.asarray(p["faces"], dtype=np.int64) + o)
+        gs.append(np.full(len(p["faces"]), k))
+        o += len(vs[-1])
+    if not vs:
+        raise RuntimeError(f"no triangles in {path}")
+    v, f, g = np.concatenate(vs), np.concatenate(fs), np.concatenate(gs)
+    diag = float(np.linalg.norm(v.max(0) - v.min(0)))
+    try:
+        hulls, worst = convex_decompose(v, f, tol=0.01 * diag, max_parts=max(max_parts, len(vs)), groups=g)
+    except Exception:                                        # degenerate input (flat sheets ...): the parts' hulls as they are
+        hulls, worst = vs, 0.0
+    _cache[key] = (hulls, worst / diag if diag > 0 else 0.0)
+    return _cache[key]
+
+
 def prism(radius, half_length, sides=16, axis=0):
     """Cylinder stand-in: `sides`-gon prism along `axis` (SAPIEN / PhysX cylinders and capsules lie along local x)."""
     ang = np.arange(sides) * (2 * np.pi / sides)

@@ -393,9 +393,19 @@ class PhysxSystem:
                 passive[id(c)] = k
         self._npassive_of_group = getattr(self, "_npassive_of_group", {})
         self._npassive_of_group[gi] = len(passive)
+        # non-convex scenery is cut into convex pieces (physx.PhysxCollisionShapeTriangleMesh): as many as the template's 64 shapes allow
+        tms = [s for c in env0 for s in c.collision_shapes if isinstance(s, P.PhysxCollisionShapeTriangleMesh)]
+        others = sum(1 for c in env0 for s in c.collision_shapes if not isinstance(s, (P.PhysxCollisionShapeTriangleMesh, P.PhysxCollisionShapePlane)))
+        parts = 16
+        while tms and parts > 1 and others + len(planes) + sum(len(s._hulls) for s in tms) > 64:
+            parts //= 2
+            for s in tms:
+                if s._max_parts > parts:
+                    s._cook(parts)
+        shapes_of = ([], [], [])
         for c in env0:
             if isinstance(c, P.PhysxRigidStaticComponent):
-                add_shapes(c, -1, c.entity._pose)
+                shapes_of[0].append((c, -1, c.entity._pose))
                 body_ids[id(c)] = -1
             elif isinstance(c, P.PhysxArticulationLinkComponent):
                 art = c.articulation
@@ -418,7 +428,7 @@ class PhysxSystem:
                 body_ids[id(c)] = bid
                 if j.dof:
                     tpl.set_drive(bid, j.stiffness, j.damping, j.force_limit, j.drive_mode)
-                add_shapes(c, bid, None)
+                shapes_of[2].append((c, bid, None))
             elif id(c) in passive:
                 body_ids[id(c)] = -2 - passive[id(c)]      # pose-only: a row of cuda_rigid_body_data outside the engine's range
             else:
@@ -430,7 +440,14 @@ class PhysxSystem:
                 bid = tpl.add_actor(c.entity.name, kind, ep._p, ep._q, 0.0 if c.kinematic else m, com, I6, c.linear_damping,
                                     c.angular_damping, c.disable_gravity)
                 body_ids[id(c)] = bid
-                add_shapes(c, bid, None)
+                shapes_of[1].append((c, bid, None))
+        # Shape order = the order of the candidate-pair table (pairs are enumerated sa < sb) = the order in which an env's contact
+        # capacity is handed out: scenery first, then free actors, then articulation links.  What an env over its capacity loses are
+        # then the link-against-link pairs of its own robot (TriFinger: a dozen speculative contacts between the three fingers), not
+        # the contacts that hold the task's object on the ground.
+        for group in shapes_of:
+            for comp, bid, fold in group:
+                add_shapes(comp, bid, fold)
         for key in planes:
             if key not in placed_planes:
                 add_plane(key)

@@ -306,9 +306,16 @@ class PhysxCollisionShapeConvexMesh(PhysxCollisionShape):
             if vertices is None:
                 v, _ = _mesh.cook_convex(filename, (1, 1, 1))
             else:
-                v = np.asarray(_mesh.reduce_hull(vertices), dtype=np.float32)
+                vin = np.ascontiguousarray(vertices)
+                key = ("reduced", hash(vin.tobytes()), vin.shape)          # every sub-scene cooks the same pieces again
+                if key not in _mesh._cache:
+                    _mesh._cache[key] = np.asarray(_mesh.reduce_hull(vin), dtype=np.float32)
+                v = _mesh._cache[key]
             self.vertices = np.ascontiguousarray(v, dtype=np.float32)
-            self._faces = _mesh.hull_faces(self.vertices * self.scale)
+            key = ("hull_faces", hash(self.vertices.tobytes()), self.vertices.shape, tuple(float(x) for x in self.scale))
+            if key not in _mesh._cache:
+                _mesh._cache[key] = _mesh.hull_faces(self.vertices * self.scale)
+            self._faces = _mesh._cache[key]
         except RuntimeError:
             raise
         except Exception as e:          # degenerate input, unreadable file: SAPIEN raises RuntimeError ("failed to cook")
@@ -344,8 +351,10 @@ class PhysxCollisionShapeConvexMesh(PhysxCollisionShape):
 
 
 class PhysxCollisionShapeTriangleMesh(PhysxCollisionShape):
-    """Non-convex triangle meshes collide (in PhysX) only as static / kinematic geometry; here they are cooked to the hulls of
-    their parts, which is exact for the convex parts ManiSkill's static scenery consists of and conservative otherwise."""
+    """Non-convex triangle meshes collide (in PhysX) only as static / kinematic geometry, triangle by triangle.  This engine collides
+    convex shapes: a part of the file that is convex (to 1 % of its size) becomes its hull, any other part is cut into at most 16
+    convex pieces (_mesh.convex_decompose; `decomposition_error` = how far a piece's hull still reaches off the surface, as a
+    fraction of the mesh size)."""
     _kind = "trimesh"
 
     def __init__(self, filename, scale=(1, 1, 1), material=None):
@@ -361,7 +370,15 @@ class PhysxCollisionShapeTriangleMesh(PhysxCollisionShape):
             faces.append(p["faces"] + o)
             o += len(p["vertices"])
         self._faces = np.concatenate(faces)
-        self._hulls = [PhysxCollisionShapeConvexMesh(filename, self.scale, material, vertices=p["vertices"]) for p in parts]
+        self._cook(16)
+
+    def _cook(self, max_parts):
+        """(re)build the convex pieces with at most `max_parts` pieces per part of the file (the scene compiler asks for fewer when
+        the sub-scene's shapes would not fit the engine's template otherwise)"""
+        hulls, self.decomposition_error = _mesh.cook_nonconvex(self.filename, max_parts)
+        self._max_parts = max_parts
+        self._hulls = [PhysxCollisionShapeConvexMesh(self.filename, self.scale, self.physical_material, vertices=np.asarray(h, dtype=np.float32))
+                       for h in hulls]
 
     def get_vertices(self):
         return self.vertices

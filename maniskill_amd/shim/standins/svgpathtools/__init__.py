@@ -1,0 +1,142 @@
+"""Stand-in for ``svgpathtools`` (mani_skill/envs/tasks/drawing/draw_svg.py:109-173 imports it inside ``_load_scene``): the part that task
+uses -- ``parse_path(d)`` of an SVG path-data string into ``Line`` / ``QuadraticBezier`` / ``CubicBezier`` segments with complex end and
+control points, ``segment.bpoints()`` and ``Path.iscontinuous()`` -- written from the SVG 1.1 path grammar (M L H V C S Q T Z and their
+relative forms).  Elliptical arcs (A) are not provided: a path that has one raises.  A real svgpathtools wins when installed (the
+stand-ins directory is appended to ``sys.path``)."""
+import re
+
+__all__ = ["Line", "QuadraticBezier", "CubicBezier", "Path", "parse_path"]
+
+
+class _Segment:
+    __slots__ = ("start", "end")
+
+    def point(self, t):
+        b = self.bpoints()
+        while len(b) > 1:                       # de Casteljau
+            b = [(1 - t) * p + t * q for p, q in zip(b[:-1], b[1:])]
+        return b[0]
+
+    def __repr__(self):
+        return f"{type(self).__name__}({', '.join(repr(p) for p in self.bpoints())})"
+
+    def __eq__(self, other):
+        return type(self) is type(other) and self.bpoints() == other.bpoints()
+
+
+class Line(_Segment):
+    def __init__(self, start, end):
+        self.start, self.end = complex(start), complex(end)
+
+    def bpoints(self):
+        return (self.start, self.end)
+
+    def length(self):
+        return abs(self.end - self.start)
+
+
+class QuadraticBezier(_Segment):
+    __slots__ = ("control",)
+
+    def __init__(self, start, control, end):
+        self.start, self.control, self.end = complex(start), complex(control), complex(end)
+
+    def bpoints(self):
+        return (self.start, self.control, self.end)
+
+
+class CubicBezier(_Segment):
+    __slots__ = ("control1", "control2")
+
+    def __init__(self, start, control1, control2, end):
+        self.start, self.control1, self.control2, self.end = complex(start), complex(control1), complex(control2), complex(end)
+
+    def bpoints(self):
+        return (self.start, self.control1, self.control2, self.end)
+
+
+class Path(list):
+    def __init__(self, *segments):
+        super().__init__(segments)
+
+    def iscontinuous(self):
+        return all(a.end == b.start for a, b in zip(self[:-1], self[1:]))
+
+    def isclosed(self):
+        return bool(self) and self.iscontinuous() and self[0].start == self[-1].end
+
+    @property
+    def start(self):
+        return self[0].start
+
+    @property
+    def end(self):
+        return self[-1].end
+
+
+_TOKEN = re.compile(r"([MmZzLlHhVvCcSsQqTtAa])|([-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?)")
+_ARGS = dict(M=2, L=2, H=1, V=1, C=6, S=4, Q=4, T=2, Z=0)
+
+
+def parse_path(pathdef, current_pos=0j):
+    """SVG path data -> Path.  As in the SVG grammar: a command letter may be followed by several argument groups (extra groups after
+    M / m are implicit L / l); Z closes the current subpath with a Line when its ends differ."""
+    toks = [(m.group(1), m.group(2)) for m in _TOKEN.finditer(pathdef)]
+    segs, pos, start, i = Path(), complex(current_pos), complex(current_pos), 0
+    cmd, last_cmd, last_ctrl = None, None, None
+    while i < len(toks):
+        if toks[i][0] is not None:
+            cmd = toks[i][0]
+            i += 1
+        elif cmd is None:
+            raise ValueError("path data must start with a command")
+        up, rel = cmd.upper(), cmd.islower()
+        if up == "A":
+            raise NotImplementedError("svgpathtools stand-in: elliptical arcs are not provided")
+        n = _ARGS[up]
+        if any(t[0] is not None for t in toks[i:i + n]) or len(toks[i:i + n]) < n:
+            raise ValueError(f"path command {cmd!r} needs {n} numbers")
+        a = [float(t[1]) for t in toks[i:i + n]]
+        i += n
+        base = pos if rel else 0j
+        if up == "M":
+            pos = start = base + complex(a[0], a[1])
+            cmd = "l" if rel else "L"            # further coordinate pairs are line-tos
+        elif up == "Z":
+            if pos != start:
+                segs.append(Line(pos, start))
+            pos = start
+        elif up == "L":
+            new = base + complex(a[0], a[1])
+            segs.append(Line(pos, new))
+            pos = new
+        elif up == "H":
+            new = complex(a[0] + (pos.real if rel else 0.0), pos.imag)
+            segs.append(Line(pos, new))
+            pos = new
+        elif up == "V":
+            new = complex(pos.real, a[0] + (pos.imag if rel else 0.0))
+            segs.append(Line(pos, new))
+            pos = new
+        elif up == "C":
+            c1, c2, new = base + complex(a[0], a[1]), base + complex(a[2], a[3]), base + complex(a[4], a[5])
+            segs.append(CubicBezier(pos, c1, c2, new))
+            pos, last_ctrl = new, c2
+        elif up == "S":                          # first control point: reflection of the previous cubic's second one
+            c1 = 2 * pos - last_ctrl if last_cmd in ("C", "S") else pos
+            c2, new = base + complex(a[0], a[1]), base + complex(a[2], a[3])
+            segs.append(CubicBezier(pos, c1, c2, new))
+            pos, last_ctrl = new, c2
+        elif up == "Q":
+            c, new = base + complex(a[0], a[1]), base + complex(a[2], a[3])
+            segs.append(QuadraticBezier(pos, c, new))
+            pos, last_ctrl = new, c
+        elif up == "T":
+            c = 2 * pos - last_ctrl if last_cmd in ("Q", "T") else pos
+            new = base + complex(a[0], a[1])
+            segs.append(QuadraticBezier(pos, c, new))
+            pos, last_ctrl = new, c
+        last_cmd = up
+        if up == "Z" and i < len(toks) and toks[i][0] is None:
+            raise ValueError("numbers after a closepath")
+    return segs

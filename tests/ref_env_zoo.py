@@ -21,7 +21,7 @@ ENV_IDS = [
     "MS-AntWalk-v1", "MS-AntRun-v1", "MS-HumanoidStand-v1", "MS-HumanoidWalk-v1", "MS-HumanoidRun-v1",
     # hundreds of kinematic, shape-less "dot" actors per env: the ones over the engine's body capacity are pose-only rows of the
     # unified buffer (shim/_system.py: passive actors)
-    "DrawTriangle-v1", "TableTopFreeDraw-v1",
+    "DrawTriangle-v1", "TableTopFreeDraw-v1", "DrawSVG-v1",
 ]
 NUM_ENVS = int(__import__("os").environ.get("ZOO_ENVS", "2"))
 NEEDS_RENDER_BODIES = {"PushT-v1"}   # its scene builder reads the render shapes it has just attached (push_t.py:53)

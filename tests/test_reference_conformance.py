@@ -92,13 +92,13 @@ def _run_zoo(backend, steps="3", ids=(), envs="2"):
 
 @needs_ref
 def test_reference_env_zoo_on_cpu_checker(built):
-    """Every task of the reference's registry that needs no downloaded asset (43 of 74: tests/ref_env_zoo.py) is built by the reference's own
+    """Every task of the reference's registry that needs no downloaded asset (44 of 74: tests/ref_env_zoo.py) is built by the reference's own
     code over the shim -- Panda, Fetch-free tabletop tasks, two-robot tasks, SO100, the MJCF control tasks, D'Claw valves with a different
     valve per sub-scene, Allegro hand, TriFinger, Unitree G1 (fixed base) -- reset and stepped; observations, rewards and the raw
     simulation buffers stay finite."""
     res = _run_zoo("oracle")
     bad = {k: v for k, v in res.items() if v != "ok"}
-    assert not bad and len(res) >= 43, bad
+    assert not bad and len(res) >= 44, bad
 
 
 @needs_ref
@@ -115,7 +115,7 @@ def test_overlapping_link_hulls_stay_finite(built):
 def test_reference_env_zoo_on_hip(built):
     res = _run_zoo("hip", "30", (), "8")
     bad = {k: v for k, v in res.items() if v != "ok"}
-    assert not bad and len(res) >= 43, bad
+    assert not bad and len(res) >= 44, bad
 
 
 def _multi_group_camera(backend):
@@ -162,6 +162,30 @@ def test_pose_only_actors_beyond_the_body_capacity_on_cpu_checker(built):
 @pytest.mark.gpu
 def test_pose_only_actors_beyond_the_body_capacity_on_hip(built):
     _pose_only_actors("hip")
+
+
+def _trifinger_scene(backend):
+    import json
+    r = subprocess.run([sys.executable, os.path.join(HERE, "ref_trifinger_scene.py"), backend], cwd=HERE, capture_output=True, text=True, timeout=3000)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("TRI ")]
+    assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(line[-1][4:])
+    # the cube rests on the table (centre at its half size) for the whole rollout; before, it fell through the ground from step one
+    assert res["cube_z_min"] > res["half_size"] - 2e-3 and res["cube_z_last"] < 0.2 and res["cube_speed_max"] < 3.0, res
+    assert res["wall_pieces"] == 16 and res["wall_error"] < 0.05, res
+
+
+@needs_ref
+def test_nonconvex_arena_wall_and_contact_priority_on_cpu_checker(built):
+    """TriFingerRotateCubeLevel0-v1: a non-convex static ring (cut into 16 convex pieces) and a robot that fills the env's contact
+    capacity with contacts among its own links."""
+    _trifinger_scene("oracle")
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_nonconvex_arena_wall_and_contact_priority_on_hip(built):
+    _trifinger_scene("hip")
 
 
 def _control_mode_switch(backend):

@@ -109,3 +109,25 @@ def test_pinocchio_model_ik_reaches_what_its_fk_reports():
         p2 = np.asarray(pm.get_link_pose(4).p, dtype=np.float64)
         assert np.abs((p2 - np.asarray(got.p, dtype=np.float64)) / eps - J[:3, k]).max() < 2e-2
     assert isinstance(target, sapien.Pose)
+
+
+def test_svgpathtools_standin_follows_the_svg_path_grammar():
+    """Known answers straight from the SVG 1.1 path grammar: absolute / relative commands, implicit line-tos after a move-to, H / V,
+    smooth curve reflection (S, T), closepath; the default outline of DrawSVG-v1 (draw_svg.py:58) is one closed run of lines."""
+    S = _load("svgpathtools")
+    p = S.parse_path("M 1 2 3 4 l 1 0 H 10 v -4 Z")
+    assert [type(s).__name__ for s in p] == ["Line"] * 5
+    assert [s.end for s in p] == [3 + 4j, 4 + 4j, 10 + 4j, 10 + 0j, 1 + 2j] and p.iscontinuous() and p.isclosed()
+    q = S.parse_path("M0,0 c1,1 2,1 3,0 s2,-1 3,0 q1,1 2,0 t2,0 m1 1 2 2")
+    assert q[1].bpoints() == (3 + 0j, 4 - 1j, 5 - 1j, 6 + 0j)          # S: first control = reflection of (2+1j) about (3+0j)
+    assert q[3].bpoints() == (8 + 0j, 9 - 1j, 10 + 0j)                 # T: control = reflection of (7+1j) about (8+0j)
+    assert isinstance(q[4], S.Line) and q[4].bpoints() == (11 + 1j, 13 + 3j) and not q.iscontinuous()
+    assert abs(q[0].point(0.5) - (1.5 + 0.75j)) < 1e-12                 # cubic at t = 1/2: (p0 + 3 p1 + 3 p2 + p3) / 8
+    assert S.parse_path("M1e1-.5L-2.5.5")[0].bpoints() == (10 - 0.5j, -2.5 + 0.5j)   # numbers need no separator
+    d = ("M7.875 0L0 7.875V55.125L7.875 63H23.763L23.7235 62.9292L11.8418 51.2859L11.8418 35.6268L21.1302 26.915L23.9193 11.6649L40.9773 "
+         "6.3631L46.8835 16.5929L33.2356 19.926L32.6417 29.1349L41.1407 33.618L50.8511 23.465L56.6781 33.5577L43.5576 45.6794L28.9369 "
+         "40.4365L26.1844 42.4266L26.1844 45.6794L43.2157 63H55.125L63 55.125V7.875L55.125 0H7.875Z")
+    o = S.parse_path(d)
+    assert len(o) == 26 and all(isinstance(s, S.Line) for s in o) and o.iscontinuous() and o[-1].end == o[0].start == 7.875 + 0j
+    with pytest.raises(NotImplementedError):
+        S.parse_path("M0 0 A 1 1 0 0 1 2 2")
