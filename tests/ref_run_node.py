@@ -38,6 +38,8 @@ def main():
         print("no ManiSkill checkout found")
         return 3
     failed = ran = 0
+    import tempfile
+    os.chdir(tempfile.mkdtemp(prefix="ref_run_node_"))   # the reference's tests record videos / trajectories relative to the cwd (GBs for a whole module)
     for node in nodes:
         sel = {}
         if node.endswith("]") and "[" in node:          # tests/x.py::test_y[env_id=PickCube-v1,obs_mode=rgb]: only these parameter values
