@@ -1,0 +1,114 @@
+"""Statics of frictional contact as known answers for the CPU oracle: a tall box on a tilted support tips exactly when the line of its
+weight leaves the support polygon (tan(theta) > half width / half height) if friction is high enough not to slide first; one and two
+cubes come to rest, three stay a stack (and come to rest once the solver is given enough sweeps -- the known defect at the default
+count is pinned as a strict xfail).  Gravity is tilted instead of the table (same statics)."""
+import numpy as np
+import pytest
+import torch
+
+from maniskill_amd import _native as N
+from maniskill_amd.envs import scene_builders as sb
+from maniskill_amd.physx import SceneTemplate, SimConfig
+
+G = 9.81
+
+
+def _world(factory, tpl, gravity, poses):
+    cfg = SimConfig()
+    cfg.scene_config.gravity = tuple(gravity)
+    px = factory(tpl, 1, cfg)
+    px.gpu_init()
+    px.set_scene_offsets(np.zeros((1, 3)))
+    rbd = px.cuda_rigid_body_data.torch().view(px.bodies_per_env, 13)
+    rbd[tpl.body_id("table-workspace"), :7] = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)])
+    for b, p in poses.items():
+        rbd[b, :3] = torch.tensor(p)
+        rbd[b, 3:7] = torch.tensor([1.0, 0, 0, 0])
+        rbd[b, 7:13] = 0.0
+    px.gpu_apply_all()
+    return px, rbd
+
+
+@pytest.mark.parametrize("tan_theta", [0.25, 0.30, 0.37, 0.45])
+def test_a_tall_box_tips_when_its_weight_leaves_the_support(oracle_factory, tan_theta):
+    """half sizes 2 x 2 x 6 cm: the critical slope is tan(theta) = 1/3; friction 1.0 keeps it from sliding on either side of it"""
+    hx, hz = 0.02, 0.06
+    tpl = SceneTemplate()
+    sb.add_table_scene(tpl, material=(1.0, 1.0, 0.0))
+    m, I = sb.box_mass_properties((hx, hx, hz))
+    box = tpl.add_actor("tall", N.BODY_DYNAMIC, p=(0, 0, hz), mass=m, inertia6=I, angular_damping=0.0)
+    tpl.add_shape(box, N.SHAPE_BOX, params=(hx, hx, hz), static_friction=1.0, dynamic_friction=1.0)
+    th = np.arctan(tan_theta)
+    px, rbd = _world(oracle_factory, tpl, (G * np.sin(th), 0.0, -G * np.cos(th)), {box: (0.0, 0.0, hz)})
+    for _ in range(60):
+        px.step()
+    px.gpu_fetch_all()
+    w, qy = rbd[box, 3].item(), rbd[box, 5].item()
+    tilt = 2 * np.arctan2(abs(qy), abs(w))                    # rotation about y since the start
+    if tan_theta < 1 / 3:
+        assert tilt < 2e-3 and abs(rbd[box, 0].item()) < 1e-3 and rbd[box, 10:13].abs().max().item() < 1e-2, (tilt, rbd[box])
+    else:
+        assert tilt > 0.2 and rbd[box, 0].item() > 0.02, (tilt, rbd[box])      # over (or on its way), towards +x where gravity pulls
+
+
+def _stack(factory, n, position_iterations=15, steps=300):
+    tpl = SceneTemplate()
+    sb.add_table_scene(tpl)
+    h = 0.02
+    cubes = [sb.add_cube(tpl, f"cube{k}", h, (0, 0, h + 2 * h * k)) for k in range(n)]
+    cfg_iters = position_iterations
+    cfg = SimConfig()
+    cfg.scene_config.solver_position_iterations = cfg_iters
+    px = factory(tpl, 1, cfg)
+    px.gpu_init()
+    px.set_scene_offsets(np.zeros((1, 3)))
+    rbd = px.cuda_rigid_body_data.torch().view(px.bodies_per_env, 13)
+    rbd[tpl.body_id("table-workspace"), :7] = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)])
+    for k, c in enumerate(cubes):
+        rbd[c, :3] = torch.tensor([0.0, 0.0, h + 2 * h * k])
+        rbd[c, 3:7] = torch.tensor([1.0, 0, 0, 0])
+        rbd[c, 7:13] = 0.0
+    px.gpu_apply_all()
+    spin = 0.0
+    for t in range(steps):
+        px.step()
+        if t >= steps - 50:
+            px.gpu_fetch_all()
+            spin = max(spin, rbd[cubes, 10:13].norm(dim=1).max().item())
+    px.gpu_fetch_all()
+    return px, rbd, cubes, h, spin
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_one_and_two_cubes_come_to_rest(oracle_factory, n):
+    px, rbd, cubes, h, spin = _stack(oracle_factory, n)
+    for k, c in enumerate(cubes):
+        assert abs(rbd[c, 2].item() - (h + 2 * h * k)) < 1e-4 and rbd[c, :2].abs().max().item() < 1e-4
+    assert spin < 0.02
+
+
+def test_a_stack_of_three_cubes_stays_a_stack(oracle_factory):
+    """The stack stands (heights to 0.3 mm, 5 mm of creep of the top cube in three seconds) and the table carries all three cubes --
+    but at the scene's 15 position iterations it does not come to rest: see the next two tests."""
+    px, rbd, cubes, h, spin = _stack(oracle_factory, 3)
+    for k, c in enumerate(cubes):
+        assert abs(rbd[c, 2].item() - (h + 2 * h * k)) < 3e-4 and rbd[c, :2].abs().max().item() < 6e-3, (k, rbd[c])
+    ids, vals = px.get_contacts(0, 64)
+    lam = sum(v[7] for (a, b, _), v in zip(ids, vals) if {a, b} == {0, 2})      # table box = shape 0, ground plane = 1, cubes follow
+    m, _ = sb.box_mass_properties((h, h, h))
+    assert abs(lam - 3 * m * G * px.timestep) < 0.12 * 3 * m * G * px.timestep, (lam, 3 * m * G * px.timestep)    # one instant of the wobble
+
+
+def test_a_stack_of_three_cubes_rests_when_the_solver_converges(oracle_factory):
+    px, rbd, cubes, h, spin = _stack(oracle_factory, 3, position_iterations=60, steps=600)
+    for k, c in enumerate(cubes):
+        assert abs(rbd[c, 2].item() - (h + 2 * h * k)) < 1e-4 and rbd[c, :2].abs().max().item() < 1e-4
+    assert spin < 0.02
+
+
+@pytest.mark.xfail(strict=True, reason="known defect (DESIGN.md §8): at 15 position iterations a three-cube stack keeps wobbling at 0.2-1 rad/s -- "
+                                       "the load wanders round the four corners of the bottom contact; the penetration recovery rate of 0.8 / dt "
+                                       "pumps what the unconverged sweep leaves (0.2 / dt: 0.015 rad/s)")
+def test_a_stack_of_three_cubes_comes_to_rest_at_the_default_iteration_count(oracle_factory):
+    px, rbd, cubes, h, spin = _stack(oracle_factory, 3)
+    assert spin < 0.02
