@@ -112,3 +112,36 @@ def test_a_stack_of_three_cubes_rests_when_the_solver_converges(oracle_factory):
 def test_a_stack_of_three_cubes_comes_to_rest_at_the_default_iteration_count(oracle_factory):
     px, rbd, cubes, h, spin = _stack(oracle_factory, 3)
     assert spin < 0.02
+
+
+def _head_on(factory, e, v0, mass_ratio):
+    """cube a slides at v0 on a frictionless table into cube b at rest, face to face, centres aligned"""
+    tpl = SceneTemplate()
+    sb.add_table_scene(tpl, material=(0.0, 0.0, 0.0))
+    h = 0.02
+    a = sb.add_cube(tpl, "a", h, (-0.1, 0, h), material=(0.0, 0.0, e))
+    b = sb.add_cube(tpl, "b", h, (0.0, 0, h), material=(0.0, 0.0, e), density=1000.0 * mass_ratio)
+    px, rbd = _world(factory, tpl, (0, 0, -G), {a: (-0.1, 0.0, h), b: (0.0, 0.0, h)})
+    rbd[a, 7] = v0
+    px.gpu_apply_rigid_dynamic_data()
+    for _ in range(15):
+        px.step()
+    px.gpu_fetch_all()
+    return rbd[a, 7].item(), rbd[b, 7].item(), max(rbd[a, 10:13].abs().max().item(), rbd[b, 10:13].abs().max().item())
+
+
+@pytest.mark.parametrize("mass_ratio", [1.0, 3.0])
+def test_head_on_collision_of_two_cubes_conserves_momentum(oracle_factory, mass_ratio):
+    """restitution 0: both leave with the common velocity m_a v0 / (m_a + m_b) (to 7 %: see the spin below); the momentum is exact"""
+    va, vb, spin = _head_on(oracle_factory, 0.0, 1.0, mass_ratio)
+    common = 1.0 / (1.0 + mass_ratio)
+    assert abs(va + mass_ratio * vb - 1.0) < 1e-4
+    assert abs(va - common) < 0.07 * 1.0 and abs(vb - common) < 0.07 * 1.0 and vb >= va - 1e-6
+    assert spin < 1.5          # known defect, next test
+
+
+@pytest.mark.xfail(strict=True, reason="known defect (DESIGN.md §8): the four normal rows of the face-to-face manifold are swept one after the other and "
+                                       "the impact leaves them unequal (0.0080 / 0.0060 / 0.0105 / 0.0064 N s instead of 4 x 0.0077): the cubes "
+                                       "leave spinning at 0.8 rad/s about the vertical")
+def test_a_central_face_to_face_impact_leaves_no_spin(oracle_factory):
+    assert _head_on(oracle_factory, 0.0, 1.0, 1.0)[2] < 0.05
