@@ -563,6 +563,17 @@ def cook_nonconvex(path, max_parts=16):
         raise RuntimeError(f"no triangles in {path}")
     v, f, g = np.concatenate(vs), np.concatenate(fs), np.concatenate(gs)
     diag = float(np.linalg.norm(v.max(0) - v.min(0)))
+    if len(f) > 40000:        # scanned scenes: the cuts and the inside tests are linear in the triangle count; 0.2 % of the size is below what 16 pieces resolve
+        cell = 0.002 * diag
+        key_ = np.floor((v - v.min(0)) / cell).astype(np.int64)
+        _, inv = np.unique(key_, axis=0, return_inverse=True)
+        inv = inv.reshape(-1)
+        rep = np.zeros((inv.max() + 1, 3))
+        np.add.at(rep, inv, v)
+        rep /= np.bincount(inv)[:, None]
+        f2 = inv[f]
+        ok = (f2[:, 0] != f2[:, 1]) & (f2[:, 1] != f2[:, 2]) & (f2[:, 0] != f2[:, 2])
+        v, f, g = rep, f2[ok], g[ok]
     try:
         hulls, worst = convex_decompose(v, f, tol=0.01 * diag, max_parts=max(max_parts, len(vs)), groups=g)
     except Exception:                                        # degenerate input (flat sheets ...): the parts' hulls as they are
