@@ -145,3 +145,27 @@ def test_head_on_collision_of_two_cubes_conserves_momentum(oracle_factory, mass_
                                        "leave spinning at 0.8 rad/s about the vertical")
 def test_a_central_face_to_face_impact_leaves_no_spin(oracle_factory):
     assert _head_on(oracle_factory, 0.0, 1.0, 1.0)[2] < 0.05
+
+
+def test_a_lever_resting_its_tip_on_a_block_presses_with_m_g_r_over_l(oracle_factory):
+    """Articulation link against scenery: a 2 kg arm on a horizontal hinge, centre of mass 0.3 m out, rests a ball tip 0.5 m out on a
+    static block: the contact carries m g r / L, the hinge the rest."""
+    m, r, L, rho = 2.0, 0.3, 0.5, 0.03
+    tpl = SceneTemplate()
+    art = tpl.add_articulation("lever", root_p=(0, 0, 1.0))
+    base = tpl.add_link(art, "base", -1, N.JOINT_FIXED, mass=1.0, inertia6=(1e-2, 1e-2, 1e-2, 0, 0, 0))
+    arm = tpl.add_link(art, "arm", base, N.JOINT_REVOLUTE, joint_name="hinge", mass=m, com=(0, r, 0), inertia6=(1e-3, 1e-3, 1e-3, 0, 0, 0))
+    tpl.add_shape(arm, N.SHAPE_SPHERE, p=(0, L, 0), params=(rho, 0, 0))
+    tpl.add_shape(-1, N.SHAPE_BOX, p=(0, L, 1.0 - rho - 0.05), params=(0.1, 0.1, 0.05))
+    px = oracle_factory(tpl, 1, SimConfig())
+    px.gpu_init()
+    px.set_scene_offsets(np.zeros((1, 3)))
+    px.cuda_rigid_body_data.torch().view(1, px.bodies_per_env, 13)[:, base, :7] = torch.tensor([0.0, 0.0, 1.0, 1, 0, 0, 0])
+    px.gpu_apply_all()
+    for _ in range(100):
+        px.step()
+    px.gpu_fetch_all()
+    ids, vals = px.get_contacts(0, 16)
+    assert len(ids) == 1
+    assert abs(vals[0][7] / px.timestep - m * G * r / L) < 1e-3 * m * G * r / L
+    assert abs(px.cuda_articulation_qpos.torch()[0, 0].item()) < 1e-5 and abs(px.cuda_articulation_qvel.torch()[0, 0].item()) < 1e-5
