@@ -165,3 +165,24 @@ def test_torque_free_spin_decays_with_the_angular_damping_only(oracle_factory):
     want = torch.cat([torch.tensor([np.cos(angle / 2)], dtype=torch.float32), axis * np.sin(angle / 2)])
     q = rbd[0, cube, 3:7]
     assert min(torch.linalg.norm(q - want).item(), torch.linalg.norm(q + want).item()) < 1e-4
+
+
+def test_a_position_drive_sags_under_gravity_by_the_torque_over_its_stiffness(oracle_factory):
+    """Static equilibrium of the implicit PD drive against gravity: K q = -m g r cos(q) (target 0, arm horizontal at q = 0)."""
+    from scipy.optimize import brentq
+    m, r, K, D = 2.0, 0.3, 200.0, 20.0
+    tpl = SceneTemplate()
+    art = tpl.add_articulation("lever", root_p=(0, 0, 1.0))
+    base = tpl.add_link(art, "base", -1, N.JOINT_FIXED, mass=1.0, inertia6=(1e-2, 1e-2, 1e-2, 0, 0, 0))
+    arm = tpl.add_link(art, "arm", base, N.JOINT_REVOLUTE, joint_name="hinge", mass=m, com=(0, r, 0), inertia6=(1e-3, 1e-3, 1e-3, 0, 0, 0))
+    tpl.set_drive(arm, K, D, 1e6, "force")
+    px = oracle_factory(tpl, 1, SimConfig())
+    px.gpu_init()
+    px.set_scene_offsets(np.zeros((1, 3)))
+    px.cuda_rigid_body_data.torch().view(1, px.bodies_per_env, 13)[:, base, :7] = torch.tensor([0.0, 0.0, 1.0, 1, 0, 0, 0])
+    px.gpu_apply_all()
+    for _ in range(600):
+        px.step()
+    px.gpu_fetch_all()
+    want = brentq(lambda x: K * x + m * 9.81 * r * np.cos(x), -1.5, 0.0)
+    assert abs(px.cuda_articulation_qpos.torch()[0, 0].item() - want) < 1e-5 and abs(px.cuda_articulation_qvel.torch()[0, 0].item()) < 1e-5
