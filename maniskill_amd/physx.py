@@ -397,7 +397,8 @@ class PhysxGpuSystem:
         self.gpu_apply_rigid_dynamic_force()
 
     def gpu_apply_all(self):
-        """The eight calls of ManiSkillScene._gpu_apply_all (scene.py:950-966) in one launch."""
+        """The calls of ManiSkillScene._gpu_apply_all (scene.py:950-966) in one launch -- all but gpu_apply_articulation_root_velocity, which
+        only means something for floating roots: the shim issues it as the reference does, the fused envs of this package have fixed bases."""
         self._apply(N.APPLY_RIGID_DATA | N.APPLY_ART_QPOS | N.APPLY_ART_QVEL | N.APPLY_ART_QF |
                     N.APPLY_ART_TARGET_QPOS | N.APPLY_ART_TARGET_QVEL | N.APPLY_ART_ROOT_POSE)
 

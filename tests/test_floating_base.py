@@ -158,3 +158,45 @@ def test_floating_base_hip_equals_oracle(built, oracle_factory):
     pa.gpu_fetch_all(); pb.gpu_fetch_all()
     assert torch.allclose(ra.cpu(), rb, rtol=1e-4, atol=1e-5)
     assert torch.allclose(pa.cuda_articulation_qpos.torch().cpu(), pb.cuda_articulation_qpos.torch(), rtol=1e-4, atol=1e-5)
+
+
+def test_a_floating_one_link_articulation_collides_like_the_free_actor_it_is(oracle_factory):
+    """An off-centre impact of a sliding cube on a resting one (frictionless table): the striker once as a dynamic actor and once as the
+    root link of a floating articulation -- the same velocities and spins afterwards, although the two take different code paths (free-body
+    block vs. root coordinates of the articulation)."""
+    from maniskill_amd.envs import scene_builders as sb
+
+    def run(floating):
+        tpl = SceneTemplate()
+        sb.add_table_scene(tpl, material=(0.0, 0.0, 0.0))
+        h = 0.02
+        m, I = sb.box_mass_properties((h, h, h))
+        if floating:
+            art = tpl.add_articulation("a", root_p=(-0.1, 0, h), floating=True)
+            a = tpl.add_link(art, "a", -1, N.JOINT_FIXED, mass=m, inertia6=I)
+        else:
+            a = tpl.add_actor("a", N.BODY_DYNAMIC, p=(-0.1, 0, h), mass=m, inertia6=I, angular_damping=0.0)
+        tpl.add_shape(a, N.SHAPE_BOX, params=(h, h, h), static_friction=0.0, dynamic_friction=0.0)
+        b = tpl.add_actor("b", N.BODY_DYNAMIC, p=(0, 0.012, h), mass=m, inertia6=I, angular_damping=0.0)
+        tpl.add_shape(b, N.SHAPE_BOX, params=(h, h, h), static_friction=0.0, dynamic_friction=0.0)
+        px = oracle_factory(tpl, 1, SimConfig())
+        px.gpu_init()
+        px.set_scene_offsets(np.zeros((1, 3)))
+        rbd = px.cuda_rigid_body_data.torch().view(px.bodies_per_env, 13)
+        rbd[tpl.body_id("table-workspace"), :7] = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)])
+        for body, y in ((a, 0.0), (b, 0.012)):
+            rbd[body, :3] = torch.tensor([-0.1 if body == a else 0.0, y, h])
+            rbd[body, 3:7] = torch.tensor([1.0, 0, 0, 0])
+            rbd[body, 7:13] = 0.0
+        rbd[a, 7] = 1.0
+        px.gpu_apply_all()
+        if floating:
+            px.gpu_apply_articulation_root_velocity()
+        for _ in range(25):
+            px.step()
+        px.gpu_fetch_all()
+        return rbd[a].numpy().copy(), rbd[b].numpy().copy()
+
+    (fa, fb), (ra, rb) = run(True), run(False)
+    assert abs(ra[12]) > 1.0 and abs(rb[12]) > 1.0                      # the impact does spin them
+    assert np.allclose(fa, ra, atol=2e-3) and np.allclose(fb, rb, atol=2e-3), (fa - ra, fb - rb)
