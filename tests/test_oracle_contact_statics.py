@@ -169,3 +169,45 @@ def test_a_lever_resting_its_tip_on_a_block_presses_with_m_g_r_over_l(oracle_fac
     assert len(ids) == 1
     assert abs(vals[0][7] / px.timestep - m * G * r / L) < 1e-3 * m * G * r / L
     assert abs(px.cuda_articulation_qpos.torch()[0, 0].item()) < 1e-5 and abs(px.cuda_articulation_qvel.torch()[0, 0].item()) < 1e-5
+
+
+def _prism_world(factory, quat, z, tilt, steps):
+    """a 16-sided prism (circumradius 3 cm, axis along x, 8 cm long) as ONE convex hull: the GJK / EPA path against the table box"""
+    from maniskill_amd.shim.sapien import _mesh
+    R, HL = 0.03, 0.04
+    verts = _mesh.prism(R, HL, sides=16, axis=0)
+    m, _, I33 = _mesh.mesh_mass(verts, _mesh.hull_faces(verts), 1000.0)
+    tpl = SceneTemplate()
+    sb.add_table_scene(tpl, material=(1.0, 1.0, 0.0))
+    a = tpl.add_actor("prism", N.BODY_DYNAMIC, p=(0, 0, 0.1), mass=m, inertia6=(I33[0][0], I33[1][1], I33[2][2], 0, 0, 0), angular_damping=0.0)
+    tpl.add_shape(a, N.SHAPE_CONVEX, verts=verts, static_friction=1.0, dynamic_friction=1.0)
+    px, rbd = _world(factory, tpl, (0.0, G * np.sin(tilt), -G * np.cos(tilt)), {a: (-0.3, 0.0, z)})
+    rbd[a, 3:7] = torch.tensor(quat, dtype=torch.float32)
+    px.gpu_apply_rigid_dynamic_data()
+    for _ in range(steps):
+        px.step()
+    px.gpu_fetch_all()
+    ids, vals = px.get_contacts(0, 16)
+    return rbd[a].numpy().copy(), m, sum(v[7] for v in vals) / px.timestep, len(ids)
+
+
+def test_a_hull_prism_stands_on_its_end_face_and_lies_on_a_facet(oracle_factory):
+    R, HL = 0.03, 0.04
+    s = np.sqrt(0.5)
+    row, m, force, n = _prism_world(oracle_factory, [s, 0, -s, 0], HL, 0.0, 100)           # axis up: on the 16-gon end face
+    assert abs(row[2] - HL) < 1e-5 and abs(force - m * G) < 1e-3 * m * G and np.abs(row[7:13]).max() < 1e-3 and n >= 3
+    half = np.pi / 32
+    row, m, force, n = _prism_world(oracle_factory, [np.cos(half), np.sin(half), 0, 0], R * np.cos(np.pi / 16) + 1e-4, 0.0, 150)
+    assert abs(row[2] - R * np.cos(np.pi / 16)) < 1e-5 and abs(force - m * G) < 1e-3 * m * G and n == 4     # a facet down: at the apothem
+
+
+@pytest.mark.parametrize("tilt", [0.10, 0.17, 0.22, 0.30])
+def test_a_hull_prism_on_a_facet_starts_rolling_beyond_pi_over_16(oracle_factory, tilt):
+    """the weight leaves the facet when tan(tilt) > tan(pi / 16) (friction 1 keeps it from sliding); then it rolls: v = omega * r"""
+    R = 0.03
+    half = np.pi / 32
+    row, _, _, _ = _prism_world(oracle_factory, [np.cos(half), np.sin(half), 0, 0], R * np.cos(np.pi / 16) + 1e-4, tilt, 150)
+    if tilt < np.pi / 16:
+        assert abs(row[8]) < 2e-3 and abs(row[10]) < 0.05 and abs(row[1]) < 1e-3
+    else:
+        assert row[8] > 0.1 and row[10] < -3.0 and abs(row[8] + row[10] * R) < 0.15 * row[8], row
