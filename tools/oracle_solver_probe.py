@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""How well the contact solver converges, on the CPU oracle (same algorithm as the HIP kernels): the residual spin of a stack of cubes at
+rest and the spin a central face-to-face impact leaves (both are zero for a converged solve).
+
+    python tools/oracle_solver_probe.py [--cubes 3] [--position-iterations 15] [--steps 600]
+
+tools/experiments/orc_solver_switches.patch adds three environment switches to oracle/orc_sim.c for trying fixes WITHOUT touching the
+committed oracle (apply, `make -C oracle`, run this, `git checkout oracle/orc_sim.c`): X_BETA (penetration recovery rate x dt),
+X_INNER (Gauss-Seidel sweeps per position iteration).  Numbers measured in round 2 are in DESIGN.md §8."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from maniskill_amd.envs import scene_builders as sb  # noqa: E402
+from maniskill_amd.physx import SceneTemplate, SimConfig  # noqa: E402
+from oracle_backend import OraclePhysxSystem  # noqa: E402
+
+H = 0.02
+
+
+def _start(tpl, cfg, poses, velocities=None):
+    px = OraclePhysxSystem(tpl, 1, cfg)
+    px.gpu_init()
+    px.set_scene_offsets(np.zeros((1, 3)))
+    rbd = px.cuda_rigid_body_data.torch().view(px.bodies_per_env, 13)
+    rbd[tpl.body_id("table-workspace"), :7] = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)])
+    for b, p in poses.items():
+        rbd[b, :3] = torch.tensor(p)
+        rbd[b, 3:7] = torch.tensor([1.0, 0, 0, 0])
+        rbd[b, 7:13] = 0.0
+    for b, v in (velocities or {}).items():
+        rbd[b, 7:10] = torch.tensor(v)
+    px.gpu_apply_all()
+    return px, rbd
+
+
+def stack(n, iterations, steps):
+    tpl = SceneTemplate()
+    sb.add_table_scene(tpl)
+    cubes = [sb.add_cube(tpl, f"cube{k}", H, (0, 0, H + 2 * H * k)) for k in range(n)]
+    cfg = SimConfig()
+    cfg.scene_config.solver_position_iterations = iterations
+    px, rbd = _start(tpl, cfg, {c: (0.0, 0.0, H + 2 * H * k) for k, c in enumerate(cubes)})
+    spin = 0.0
+    for t in range(steps):
+        px.step()
+        if t >= steps - 50:
+            px.gpu_fetch_all()
+            spin = max(spin, rbd[cubes, 10:13].norm(dim=1).max().item())
+    px.gpu_fetch_all()
+    return dict(cubes=n, spin_rad_s=spin, top_cube_creep_mm=1e3 * rbd[cubes[-1], :2].abs().max().item(),
+                height_error_mm=[1e3 * (rbd[c, 2].item() - (H + 2 * H * k)) for k, c in enumerate(cubes)])
+
+
+def impact(iterations, v0=1.0, restitution=0.0):
+    tpl = SceneTemplate()
+    sb.add_table_scene(tpl, material=(0.0, 0.0, 0.0))
+    a = sb.add_cube(tpl, "a", H, (-0.1, 0, H), material=(0.0, 0.0, restitution))
+    b = sb.add_cube(tpl, "b", H, (0.0, 0, H), material=(0.0, 0.0, restitution))
+    cfg = SimConfig()
+    cfg.scene_config.solver_position_iterations = iterations
+    px, rbd = _start(tpl, cfg, {a: (-0.1, 0.0, H), b: (0.0, 0.0, H)}, {a: (v0, 0.0, 0.0)})
+    for _ in range(15):
+        px.step()
+    px.gpu_fetch_all()
+    return dict(va=rbd[a, 7].item(), vb=rbd[b, 7].item(), spin_rad_s=max(rbd[a, 10:13].abs().max().item(), rbd[b, 10:13].abs().max().item()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cubes", type=int, default=3)
+    ap.add_argument("--position-iterations", type=int, default=15)
+    ap.add_argument("--steps", type=int, default=600)
+    a = ap.parse_args()
+    print(json.dumps(dict(stack=stack(a.cubes, a.position_iterations, a.steps), impact=impact(a.position_iterations),
+                          switches={k: os.environ[k] for k in ("X_BETA", "X_INNER") if k in os.environ})))
+
+
+if __name__ == "__main__":
+    main()
