@@ -92,7 +92,16 @@ class URDFLoader:
         if filename.startswith("package://"):
             filename = filename[len("package://"):]
             base = self.package_dir if self.package_dir else urdf_dir
-            return os.path.join(base, filename)
+            path = os.path.join(base, filename)
+            if not os.path.exists(path) and not self.package_dir:
+                # ROS reading: "package://<name>/..." names a directory <name> that holds the files -- usually an ancestor of the URDF
+                # (koch: robots/koch/follower_arm_v1.1.urdf refers to package://koch/meshes/*.stl)
+                up = urdf_dir
+                for _ in range(4):
+                    up = os.path.dirname(up)
+                    if os.path.exists(os.path.join(up, filename)):
+                        return os.path.join(up, filename)
+            return path
         if os.path.isabs(filename):
             return filename
         return os.path.join(urdf_dir, filename)
