@@ -188,6 +188,18 @@ def test_nonconvex_arena_wall_and_contact_priority_on_hip(built):
     _trifinger_scene("hip")
 
 
+@needs_ref
+def test_robots_no_local_task_uses_load_and_step_on_cpu_checker(built):
+    """Fetch, xArm7 + Ability hand, the Koch arm (package:// meshes one directory up), the floating Panda gripper, a fixed Inspire hand, the
+    left Allegro hand, the MJCF humanoid: the reference's own agent classes build them into Empty-v1 over the shim."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(HERE, "ref_robot_sweep.py"), "oracle"], cwd=HERE, capture_output=True, text=True, timeout=3000)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("ROB ")]
+    assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(line[-1][4:])
+    assert len(res) >= 7 and all(v == "ok" for v in res.values()), res
+
+
 def _control_mode_switch(backend):
     import json
     r = subprocess.run([sys.executable, os.path.join(HERE, "ref_control_mode_switch.py"), backend], cwd=HERE, capture_output=True, text=True, timeout=3000)
