@@ -211,3 +211,24 @@ def test_a_hull_prism_on_a_facet_starts_rolling_beyond_pi_over_16(oracle_factory
         assert abs(row[8]) < 2e-3 and abs(row[10]) < 0.05 and abs(row[1]) < 1e-3
     else:
         assert row[8] > 0.1 and row[10] < -3.0 and abs(row[8] + row[10] * R) < 0.15 * row[8], row
+
+
+def test_the_stack_pyramid_end_state_is_static_by_the_references_criterion(oracle_factory):
+    """StackPyramid-v1's goal (cube C on cubes A and B, envs/tasks/tabletop/stack_pyramid.py) is checked with Actor.is_static(lin_thresh=1e-2,
+    ang_thresh=0.5) (utils/structs/actor.py): two layers settle far below both thresholds (the three-layer wobble above would not)."""
+    tpl = SceneTemplate()
+    sb.add_table_scene(tpl)
+    h = 0.02
+    places = {"A": (0.0, -h - 0.001, h), "B": (0.0, h + 0.001, h), "C": (0.0, 0.0, 3 * h)}
+    ids = {k: sb.add_cube(tpl, k, h, p) for k, p in places.items()}
+    px, rbd = _world(oracle_factory, tpl, (0, 0, -G), {ids[k]: p for k, p in places.items()})
+    lin = ang = 0.0
+    rows = list(ids.values())
+    for t in range(300):
+        px.step()
+        if t >= 200:
+            px.gpu_fetch_all()
+            lin = max(lin, rbd[rows, 7:10].norm(dim=1).max().item())
+            ang = max(ang, rbd[rows, 10:13].norm(dim=1).max().item())
+    assert lin < 1e-3 and ang < 0.05, (lin, ang)
+    assert abs(rbd[ids["C"], 2].item() - 3 * h) < 1e-4 and abs(rbd[ids["A"], 1].item() + h + 0.001) < 1e-4
