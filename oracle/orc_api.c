@@ -157,7 +157,6 @@ ORC_EXPORT int orc_add_actor(orc_ctx* c, int kind, const float pose7[7], float m
 ORC_EXPORT int orc_add_shape(orc_ctx* c, int body, int type, const float local_pose[7], const float params[3],
                              const float* verts, int nverts, float sf, float df, float rest, const uint32_t groups[4],
                              float patch_radius, float min_patch_radius) {
-  (void)min_patch_radius;
   if (c->finalized) return fail(c, MSK_ERR_INVALID, "add_shape after finalize");
   if (c->ns >= MSK_MAX_SHAPES) return fail(c, MSK_ERR_CAPACITY, "too many shapes");
   if (body >= c->nb) return fail(c, MSK_ERR_INVALID, "bad body");
@@ -168,7 +167,7 @@ ORC_EXPORT int orc_add_shape(orc_ctx* c, int body, int type, const float local_p
   s->par[0] = params[0]; s->par[1] = params[1]; s->par[2] = params[2];
   s->sf = sf; s->df = df; s->rest = rest;
   memcpy(s->g, groups, sizeof(s->g));
-  s->patch_r = patch_radius;
+  s->patch_r = patch_radius; s->min_patch_r = min_patch_radius;
   /* sphere / capsule / cylinder become rounded hulls (include/msk_physx.h): core vertices + rounding radius in par[0] */
   float gen[32 * 3];
   if (type == MSK_SHAPE_SPHERE) {

@@ -751,13 +751,18 @@ int orc_collide_pair(const orc_ctx* c, const orc_env* e, int pi, orc_contact* ou
     n = build_manifold(A, &TA, B, &TB, nrm, margin, wa, wb, sep, out);
   }
   STAT(12, n);
-  float mu = 0.5f * (A->df + B->df);
+  float mu = 0.5f * (A->df + B->df), mu_s = 0.5f * (A->sf + B->sf);
   float rest = 0.5f * (A->rest + B->rest);
+  /* torsional friction (PhysX: only a friction patch with a single anchor gets a torsional row, i.e. a one-point manifold here) */
+  const int torsional = n == 1 && (A->patch_r > 0.0f || B->patch_r > 0.0f || A->min_patch_r > 0.0f || B->min_patch_r > 0.0f);
   for (int i = 0; i < n; ++i) {
     out[i].sa = c->pairs[pi].sa; out[i].sb = c->pairs[pi].sb;
     out[i].ba = A->body; out[i].bb = B->body;
     out[i].mu = mu;
+    out[i].mu_s = mu_s < mu ? mu : mu_s;   /* static below dynamic makes no sense: PhysX clamps it up */
     out[i].rest = rest;
+    out[i].patch_r = torsional ? fmaxf(A->patch_r, B->patch_r) : 0.0f;
+    out[i].min_patch_r = torsional ? fmaxf(A->min_patch_r, B->min_patch_r) : 0.0f;
     out[i].sep -= c->cfg.rest_offset * 2.0f;
   }
   return n;

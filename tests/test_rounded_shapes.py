@@ -114,7 +114,7 @@ def _stack(factory, n):
 
 def test_ball_on_cube_on_table(oracle_factory):
     px, cube, ball, rbd, r, m = _stack(oracle_factory, 1)
-    _settle(px, 80)
+    _settle(px, 150)
     assert abs(rbd[0, ball, 2].item() - (0.06 + r)) < 1.5e-3 and abs(rbd[0, cube, 2].item() - 0.03) < 1e-3
     assert rbd[0, ball, 7:13].abs().max() < 2e-2
 
