@@ -126,7 +126,7 @@ MSK_DEV void broadphase_env(const DModel* __restrict__ m, const DState& st, cons
       base[t] += __popcll(mask);
     }
     int gone = 0;
-    if (!keep && pi < m->np) { gone = cnts[pi]; if (gone != 0) cnts[pi] = 0; }
+    if (!keep && pi < m->np) { gone = cnts[pi]; if (gone != 0) { cnts[pi] = 0; gone = ct_blocks(m, pi, gone); } }
     dropped += gone;
   }
   if (__ballot(dropped != 0)) { /* keep the env's contact total in step with its row (this wave is the only writer in this launch) */

@@ -327,9 +327,10 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
     }
     float* sc = Senv + di * 8;   /* motion subspace column of coordinate di, for the row assembly */
     sc[0] = S.a.x; sc[1] = S.a.y; sc[2] = S.a.z; sc[3] = S.l.x; sc[4] = S.l.y; sc[5] = S.l.z;
-    /* drive of this joint */
-    vec[DV_KD * MD + di] = b->K;
-    vec[DV_DD * MD + di] = b->D;
+    /* drive of this joint; an acceleration drive's gains are per unit of the joint's own inertia (the diagonal just computed) */
+    const float Mdd = Lm[di * LD + di];
+    vec[DV_KD * MD + di] = b->drive_accel ? b->K * Mdd : b->K;
+    vec[DV_DD * MD + di] = b->drive_accel ? b->D * Mdd : b->D;
     vec[DV_FC * MD + di] = 0.0f;
     vec[DV_ERR * MD + di] = E[m->lay.q + di] - E[m->lay.qt + di];
   }
@@ -358,14 +359,16 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
   dyn_sync();
 
   DPHASE();
-  /* ---- 5. implicit PD: A = M + dt D + dt^2 K (+ tendons), Cholesky, solves; second pass if a drive saturates ---- */
+  /* ---- 5. implicit PD: A = M + dt D + dt^2 K (+ tendons), Cholesky, solves; second pass without the drives whose predicted force
+   * exceeds their limit: those become soft rows of the solver, clamped to +-fmax dt (st.drv_mask, st.drv; oracle: dynamics()) ---- */
   const bool rowlane = i < nd;   /* surplus half-waves compute along (LDS only) and store nothing */
   const float fmax_i = rowlane ? m->bodies[m->dof_body[i]].fmax : 0.0f;
   const float qdt_i = rowlane ? E[m->lay.qdt + i] : 0.0f;
   const float qf_i = rowlane ? E[m->lay.qf + i] : 0.0f;
   const float bias_i = rowlane ? vec[DV_BIAS * MD + i] : 0.0f;
   float Kd = rowlane ? vec[DV_KD * MD + i] : 0.0f, Dd = rowlane ? vec[DV_DD * MD + i] : 0.0f;
-  float fconst = 0.0f, err = rowlane ? vec[DV_ERR * MD + i] : 0.0f;
+  float err = rowlane ? vec[DV_ERR * MD + i] : 0.0f;
+  bool drive_row = false;   /* my joint's drive goes to the solver */
   for (int pass = 0; pass < 2; ++pass) {
     float Arow[MD];
     float rhs = 0.0f;
@@ -381,7 +384,7 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
 #pragma unroll
       for (int k = 0; k < MD; ++k)
         if (k == i) Arow[k] += dadd;
-      const float tau = qf_i - bias_i - Kd * err + Dd * qdt_i + fconst;
+      const float tau = qf_i - bias_i - Kd * err + Dd * qdt_i;
       rhs = fmaf(dt, tau, mv);
       for (int t = 0; t < m->nt; ++t) {
         const DTendon* tn = &m->tendons[t];
@@ -468,19 +471,32 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
     }
     dyn_sync();
     if (pass == 1) break;
-    /* drive force limits: predict the PD force at v*, saturate where it exceeds the limit */
+    /* drive force limits: predict the PD force at v*; where it exceeds the limit the drive becomes a solver row */
     bool sat = false;
     if (rowlane && !(Kd == 0.0f && Dd == 0.0f)) {
       const float vfi = vec[DV_VF * MD + i];
       const float F = -Kd * fmaf(dt, vfi, err) - Dd * (vfi - qdt_i);
       if (fabsf(F) > fmax_i) {
-        fconst = (F > 0.0f) ? fmax_i : -fmax_i;
+        const float cfm = 1.0f / (dt * fmaf(dt, Kd, Dd));
+        if (live) {
+          float4 rec;
+          rec.x = cfm;
+          rec.y = (dt * fmaf(Kd, err, -(Dd * qdt_i))) * cfm;
+          rec.z = fmax_i * dt;
+          rec.w = 0.0f;
+          *(float4*)(st.drv + ((size_t)e * G + i) * 4) = rec;
+        }
         Kd = 0.0f; Dd = 0.0f; err = 0.0f;
         sat = true;
+        drive_row = true;
       }
     }
     /* wave-uniform decision: an env that did not saturate recomputes the identical pass */
     if (__ballot(sat) == 0ull) break;
+  }
+  { /* which drives are solver rows in this substep: one word per env (the classification and the solver read it) */
+    const unsigned long long dm = __ballot(drive_row);
+    if (live && i == 0) st.drv_mask[e] = (unsigned)(dm >> (sub * LPE));
   }
 
   DPHASE();

@@ -21,18 +21,23 @@
 #include "msk_dynamics.h"
 
 #define MSK_WARM_DIST 5.0e-3f
-#define MSK_WARM_FACTOR 0.9f
+#define MSK_SPECULATIVE_SLACK 5.0e-3f   /* oracle: ORC_SPECULATIVE_SLACK */
+#define MSK_WARM_NORMAL 1.0f    /* fraction of last step's normal (and torsional) impulses applied up front (oracle: ORC_WARM_NORMAL) */
+#define MSK_WARM_TANGENT 0.0f   /* ... and of its friction impulses: none (carried over they shake a stack: DESIGN.md §2) */
 
-/* Solver capacity class of env e: constraint blocks = joints within MSK_LIMIT_DISTANCE of a limit + contact points
- * (the same count solve_env makes), against the per-template class capacities. */
+/* Solver capacity class of env e: constraint blocks = joints within MSK_LIMIT_DISTANCE of a limit or with a drive row + joints with
+ * friction + the blocks of the contact slots (the same count solve_env makes), against the per-template class capacities. */
 MSK_DEV int solver_class_of(const DModel* __restrict__ m, const DState& st, const int e, const int contacts) {
   const float* E = EREC(st, m, e);
   int nblk = 0;
+  const unsigned dm = st.drv_mask[e];   /* joints whose force-limited drive is a solver row in this substep (k_dynamics) */
   for (int d = 0; d < m->nd; ++d) {
     const float lo = m->dof_lo[d], hi = m->dof_hi[d], q = E[m->lay.q + d];
-    if (!(lo < -1e30f && hi > 1e30f) && (q - lo < MSK_LIMIT_DISTANCE || hi - q < MSK_LIMIT_DISTANCE)) nblk++;
+    if (((dm >> d) & 1u) || (!(lo < -1e30f && hi > 1e30f) && (q - lo < MSK_LIMIT_DISTANCE || hi - q < MSK_LIMIT_DISTANCE))) nblk++;
   }
-  nblk += contacts < MSK_MAX_CONTACTS ? contacts : MSK_MAX_CONTACTS;
+  nblk += m->njfric;
+  const int room = MSK_MAX_BLOCKS - nblk > 0 ? MSK_MAX_BLOCKS - nblk : 0;
+  nblk += contacts < room ? contacts : room;
   return nblk <= m->cls_cap[0] ? 0 : (nblk <= m->cls_cap[1] ? 1 : (nblk <= m->cls_cap[2] ? 2 : 3));
 }
 
@@ -214,6 +219,38 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
   }
 #endif
   if (!writer) break;
+  /* Speculative points that cannot touch within this step are no contacts (oracle: orc_collide_pair): a point further apart than
+   * MSK_SPECULATIVE_SLACK plus twice what the two bodies' present velocities close along the normal in one step is dropped. */
+  if (n > 0) {
+    const float dt = m->cfg.timestep;
+    const int ba = dA->body, bb = dB->body;
+    v3 cwa = v3_make(0, 0, 0), cwb = v3_make(0, 0, 0), la = cwa, lb = cwa, wa_ = cwa, wb_ = cwa;
+    if (ba >= 0) {
+      const pose Tb = load_pose(E, m->lay.bpose, ba);
+      cwa = v3_add(Tb.p, quat_rotate(Tb.q, m->bodies[ba].com));
+      la = load_v3(E, m->lay.blin, ba); wa_ = load_v3(E, m->lay.bang, ba);
+    }
+    if (bb >= 0) {
+      const pose Tb = load_pose(E, m->lay.bpose, bb);
+      cwb = v3_add(Tb.p, quat_rotate(Tb.q, m->bodies[bb].com));
+      lb = load_v3(E, m->lay.blin, bb); wb_ = load_v3(E, m->lay.bang, bb);
+    }
+    int kept = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k >= n) continue;
+      const v3 va = ba >= 0 ? v3_add(la, v3_cross(wa_, v3_sub(opos[k], cwa))) : v3_make(0, 0, 0);
+      const v3 vb = bb >= 0 ? v3_add(lb, v3_cross(wb_, v3_sub(opos[k], cwb))) : v3_make(0, 0, 0);
+      const float vn = v3_dot(onrm, v3_sub(va, vb));                          /* < 0: approaching */
+      const float reach = fmaf(2.0f * dt, fmaxf(0.0f, -vn), MSK_SPECULATIVE_SLACK);
+      if (osep[k] - m->cfg.rest_offset * 2.0f > reach) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j == kept && j != k) { opos[j] = opos[k]; osep[j] = osep[k]; }
+      kept++;
+    }
+    n = kept;
+  }
   /* warm start from the previous contents of this pair's slot, then overwrite it */
   int* cntp = st.ct_cnt + (size_t)e * m->npp + pi;
   float* rec = st.ct_rec + ((size_t)e * m->npp + pi) * MSK_CT_REC;
@@ -230,8 +267,22 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
   }
   if (n == 0 && nprev == 0) break;
   *cntp = n;
-  if (n != nprev) atomicAdd(&st.ct_total[e], n - nprev);   /* device scope: read by whichever block classifies the env's chunk */
-  if (n > 0) { rec[0] = onrm.x; rec[1] = onrm.y; rec[2] = onrm.z; }
+  {
+    const int blocks = ct_blocks(m, pi, n), blocks_prev = ct_blocks(m, pi, nprev);
+    if (blocks != blocks_prev) atomicAdd(&st.ct_total[e], blocks - blocks_prev);   /* device scope: read by whichever block classifies the env's chunk */
+  }
+  if (m->has_static) { /* static or dynamic friction: the pair slides when its friction impulses of the last step, summed, ended on the cone
+                        * of the coefficient that step used (oracle: collide(), pair_slip) */
+    unsigned char* slip = st.ct_slip + (size_t)e * m->npp + pi;
+    float T1 = 0.0f, T2 = 0.0f, Nn = 0.0f;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      if (jj < nprev) { T1 += plam[jj][1]; T2 += plam[jj][2]; Nn += plam[jj][0]; }
+    const float mu_used = (nprev > 0 && *slip) ? m->pinfo[pi].mu : m->pinfo[pi].mu_s;
+    *slip = (nprev > 0 && Nn > 0.0f && fmaxf(fabsf(T1), fabsf(T2)) >= 0.999f * mu_used * Nn) ? 1 : 0;
+  }
+  const float prev_lam_t = rec[3];
+  if (n > 0) { rec[0] = onrm.x; rec[1] = onrm.y; rec[2] = onrm.z; rec[3] = 0.0f; }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (k >= n) continue;
@@ -246,7 +297,8 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
     }
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
-      if (best == jj) { lam[0] = MSK_WARM_FACTOR * plam[jj][0]; lam[1] = MSK_WARM_FACTOR * plam[jj][1]; lam[2] = MSK_WARM_FACTOR * plam[jj][2]; }
+      if (best == jj) { lam[0] = MSK_WARM_NORMAL * plam[jj][0]; lam[1] = MSK_WARM_TANGENT * plam[jj][1]; lam[2] = MSK_WARM_TANGENT * plam[jj][2]; }
+    if (k == 0 && n == 1 && nprev == 1 && best == 0) rec[3] = MSK_WARM_TANGENT * prev_lam_t;   /* the torsional row of a one-point manifold */
     rec[4 + k * 3 + 0] = opos[k].x;
     rec[4 + k * 3 + 1] = opos[k].y;
     rec[4 + k * 3 + 2] = opos[k].z;
@@ -256,7 +308,9 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
   }
   } while (0);
   if constexpr (GLOBALQ) { /* sign the pass's items off with their chunks (see k_narrowphase); a wave may finish several chunks */
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   /* the writer's atomic on the contact total has been performed */
+    /* the writer's atomic on the contact total must have been performed before the sign-off is: a workgroup-scope release emits no
+     * wait on this target (two global atomics back to back), so the memory counter is drained explicitly -- still no L2 write-back */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int chunk = e / 64;
     const bool signer = act && (lane % LPI) == 0;
     int old = -1;
@@ -313,10 +367,10 @@ MSK_DEV void narrowphase_block(const DModel* __restrict__ m, const DState& st, c
   else narrowphase_body<NP_BOXBOX, 1>(m, st, e0, group, y - cfg.nplane, cfg.nbox, pref, s_ws, s_we, verts, fixed_per_group);
   /* Sign-off.  The only data of this launch the classifying wave reads are the contact totals, and those are device-scope
    * atomics; so all that is needed is that this wave's atomics have been performed before its sign-off is (a wait on the
-   * memory counters: the workgroup-scope release), not __threadfence(): on this part an agent-scope fence writes back and
+   * memory counter), not __threadfence(): on this part an agent-scope fence writes back and
    * invalidates the XCD's L2 (an empty launch of these 1536 blocks took 25 us with it, 4 us without: profiles/r02_np_floor.md).
    * np_done[chunk] starts at minus the chunk's hull items (broadphase); plane / box-box blocks and hull items add one each. */
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* (the workgroup-scope release alone emits no wait: the atomics could overtake each other) */
   const int chunk = e0 / 64;
   int done = 0;
   if (threadIdx.x == 0) done = atomicAdd(&st.np_done[chunk], 1);
@@ -418,7 +472,8 @@ __global__ void __launch_bounds__(256) k_apply(const DModel* __restrict__ m, DSt
  * link within its articulation. */
 struct LinkSlots { signed char slot[MSK_MAX_BODIES]; int max_links; };
 
-__global__ void __launch_bounds__(64) k_link_forces(const DModel* __restrict__ m, DState st, LinkSlots ls, float* __restrict__ out) {
+/* out_body (optional): the same wrenches as [N][nb][6] by body id, for the joint-friction rows of the next substep (DState::jforce) */
+__global__ void __launch_bounds__(64) k_link_forces(const DModel* __restrict__ m, DState st, LinkSlots ls, float* __restrict__ out, float* __restrict__ out_body) {
   const int e = blockIdx.x * 64 + threadIdx.x;
   if (e >= m->N) return;
   const float* E = EREC(st, m, e);
@@ -501,13 +556,14 @@ __global__ void __launch_bounds__(64) k_link_forces(const DModel* __restrict__ m
     const v3 n = v3_make(rec[0], rec[1], rec[2]);
     v3 t1, t2;
     msk_tangents(n, &t1, &t2);
+    const float lam_t = (cnt == 1 && ct_blocks(m, p, 1) == 2) ? rec[3] : 0.0f;   /* the torsional row of a one-point manifold */
     for (int k = 0; k < cnt; ++k) {
       const v3 pos = v3_make(rec[4 + k * 3 + 0], rec[4 + k * 3 + 1], rec[4 + k * 3 + 2]);
       v3 F = v3_scale(n, rec[20 + k * 3 + 0]);
       F = v3_madd(F, t1, rec[20 + k * 3 + 1]);
       F = v3_madd(F, t2, rec[20 + k * 3 + 2]);
       F = v3_scale(F, inv_dt);
-      const v3 Tq = v3_cross(pos, F);
+      const v3 Tq = v3_madd(v3_cross(pos, F), n, lam_t * inv_dt);   /* ... plus the couple of the torsional row */
       if (la) { f[ba].a = v3_sub(f[ba].a, Tq); f[ba].l = v3_sub(f[ba].l, F); }
       if (lb) { f[bb].a = v3_add(f[bb].a, Tq); f[bb].l = v3_add(f[bb].l, F); }
     }
@@ -522,8 +578,14 @@ __global__ void __launch_bounds__(64) k_link_forces(const DModel* __restrict__ m
     const pose C = (b->parent >= 0) ? pose_mul(T[i], pose_inv(b->XcInv)) : T[i];
     const v3 torque = v3_sub(f[i].a, v3_cross(C.p, f[i].l));   /* moved from the env origin to the frame's origin */
     const v3 fl = quat_rotate(quat_conj(C.q), f[i].l), tl = quat_rotate(quat_conj(C.q), torque);
-    float* o = out + (((size_t)e * m->na + b->art) * ls.max_links + ls.slot[i]) * 6;
-    o[0] = fl.x; o[1] = fl.y; o[2] = fl.z; o[3] = tl.x; o[4] = tl.y; o[5] = tl.z;
+    if (out) {
+      float* o = out + (((size_t)e * m->na + b->art) * ls.max_links + ls.slot[i]) * 6;
+      o[0] = fl.x; o[1] = fl.y; o[2] = fl.z; o[3] = tl.x; o[4] = tl.y; o[5] = tl.z;
+    }
+    if (out_body) {
+      float* o = out_body + ((size_t)e * m->nb + i) * 6;
+      o[0] = fl.x; o[1] = fl.y; o[2] = fl.z; o[3] = tl.x; o[4] = tl.y; o[5] = tl.z;
+    }
   }
 }
 

@@ -30,6 +30,8 @@ struct DBody {
   v3 com;
   float I6[6], Iinv6[6];
   float armature, K, D, fmax, lin_damp, ang_damp;
+  float jfriction;   /* PhysxArticulationJoint.friction: coefficient of the joint-friction row (msk_solve.h) */
+  int drive_accel;   /* drive mode "acceleration": gains per unit of the joint's own inertia */
 };
 
 struct DShape {
@@ -42,10 +44,13 @@ struct DShape {
 
 struct DTendon { int dof_a, dof_b; float ca, cb, rest, K, D; };
 struct DPair { int sa, sb; };
-struct DPairInfo { int ba, bb; float mu; float rest; }; /* bodies of the two shapes, friction and restitution of the pair (averages) */
+/* bodies of the two shapes; dynamic and static friction and restitution of the pair (averages: PhysX's default combine mode);
+ * torsional patch of the pair (the larger of the two shapes'), used when the manifold has a single point */
+struct DPairInfo { int ba, bb; float mu, mu_s; float rest; float patch_r, min_patch_r; };
 
 #define MSK_SOLVE_CLASSES 4
 #define MSK_LIMIT_DISTANCE 0.1f   /* a joint closer than this to a limit gets a limit block (solver and classifier) */
+#define MSK_MAX_BLOCKS 64          /* constraint blocks per env: one lane each in the solver (oracle: MSK_MAX_BLOCKS) */
 
 struct DModel {
   msk_config cfg;
@@ -74,14 +79,19 @@ struct DModel {
   float dof_lo[MSK_MAX_DOF], dof_hi[MSK_MAX_DOF];
   DPairInfo pinfo[MSK_MAX_PAIRS];
   int cls_cap[MSK_SOLVE_CLASSES - 1];  /* largest block count of solver classes 0, 1, 2 (the last class takes the rest) */
+  unsigned jfric_mask;                 /* bit d: joint d has a friction coefficient (a joint-friction block in every step) */
+  int njfric;                          /* popcount of it */
+  int has_static;                      /* some pair has static != dynamic friction: the per-pair slide state is kept (DState::ct_slip) */
+  int has_tors;                        /* some pair has a torsional patch radius */
   /* per-env instances: slot of a declared box shape / dynamic actor in the env record, -1 = the template's values */
   signed char xs_slot[MSK_MAX_SHAPES], xb_slot[MSK_MAX_BODIES];
   int nxs, nxb;
 };
 
-#define MSK_MAX_ROWS (2 * MSK_MAX_DOF + 3 * MSK_MAX_CONTACTS)
+#define MSK_MAX_ROWS (3 * MSK_MAX_BLOCKS)
 /* contact slot of one candidate pair of one env: 32 floats
- *   [0..2] normal  [4+3k..] point k  [16+k] separation k  [20+3k+a] impulse k (normal, t1, t2) */
+ *   [0..2] normal  [3] impulse of the torsional row (one-point manifolds)  [4+3k..] point k  [16+k] separation k
+ *   [20+3k+a] impulse k (normal, t1, t2) */
 #define MSK_CT_REC 32
 
 /* All device arrays of one context.  Sizes are in floats / ints per env times N. */
@@ -112,10 +122,21 @@ struct DState {
   float *ext_wrench;                           /* [N][nb][8] external force (0..2) / torque (4..6) of the next step; consumed and cleared by k_dynamics */
   long long *dbg;                              /* [N][8] phase time stamps (MSK_PROFILE_PHASES builds only) */
   int *env_ncontacts;                          /* [N] */
-  int *ct_total;                               /* [N] sum of the env's ct_cnt row, kept in step with every write to it (device-scope atomics in the
-                                                * narrowphase): what the classification reads instead of the row */
+  int *ct_total;                               /* [N] constraint blocks of the env's contact slots: sum of ct_blocks() over its ct_cnt row, kept in step with
+                                                * every write to it (device-scope atomics in the narrowphase): what the classification reads instead of the row */
   int *env_overflow;                           /* [1] */
+  /* force-limited drives that k_dynamics hands to the solver as soft rows (oracle: orc_scratch.drv_*) */
+  unsigned *drv_mask;                          /* [N] bit d: the drive of joint d is a solver row in this substep */
+  float *drv;                                  /* [N][G][4]: compliance 1 / g, velocity bias, impulse limit, pad */
+  unsigned char *ct_slip;                      /* [N][npp] 1: the pair slides, its friction cone is the dynamic one (has_static only, else null) */
+  float *jforce;                               /* [N][nb][6] link incoming joint wrenches of the last step (njfric > 0 only, else null): k_link_forces */
 };
+
+/* constraint blocks a pair with n contact points brings to its env's solve: one per point, and one for the torsional row of a
+ * one-point manifold whose pair has a patch radius (what DState::ct_total adds up) */
+MSK_DEV int ct_blocks(const DModel* m, int pair, int n) {
+  return n + ((n == 1 && m->has_tors && (m->pinfo[pair].patch_r > 0.0f || m->pinfo[pair].min_patch_r > 0.0f)) ? 1 : 0);
+}
 
 /* accessors of the env record E (EnvLayout): scalar fields by offset, poses 8 floats, vectors 4 floats */
 #define EREC(st, m, e) ((st).env + (size_t)(e) * (size_t)(m)->lay.stride)

@@ -76,6 +76,7 @@ struct msk_ctx {
   PairSel pick_lsel, pick_rsel;   /* pickcube task: shape pairs finger <-> object */
   uint32_t groups[MSK_MAX_SHAPES][4]; /* collision groups: only the static pair filter needs them */
   float rest[MSK_MAX_SHAPES];         /* restitution per shape (pair value = average, DPairInfo::rest) */
+  float sfric[MSK_MAX_SHAPES], patch_r[MSK_MAX_SHAPES], min_patch_r[MSK_MAX_SHAPES];   /* static friction, torsional patch radii per shape */
   std::vector<void*> allocs;
   std::vector<HostQuery> queries;
   /* per-kernel event timing (msk_timing_*): MSK_K_SLOTS + 1 events per armed step */
@@ -188,7 +189,6 @@ MSK_API int msk_set_articulation_floating(msk_ctx* c, int art) {
 MSK_API int msk_add_link(msk_ctx* c, int art, int parent_body, int joint_type, const float pose_in_parent[7],
                          const float pose_in_child[7], float limit_lo, float limit_hi, float mass, const float com[3],
                          const float inertia6[6], int disable_gravity, float armature, float joint_friction) {
-  (void)joint_friction;
   if (c->finalized) return fail(c, MSK_ERR_INVALID, "add_link after finalize");
   DModel& m = c->model;
   if (m.nb >= MSK_MAX_BODIES - 1) return fail(c, MSK_ERR_CAPACITY, "too many bodies");
@@ -207,6 +207,7 @@ MSK_API int msk_add_link(msk_ctx* c, int art, int parent_body, int joint_type, c
   memcpy(b->I6, inertia6, sizeof(b->I6));
   b->nograv = disable_gravity;
   b->armature = armature;
+  b->jfriction = joint_friction > 0.0f ? joint_friction : 0.0f;
   b->dof = -1; b->vofs = -1; b->root_dof = -1;
   memset(&c->init_pose[m.nb], 0, sizeof(pose));
   c->init_pose[m.nb].q.w = 1.0f;
@@ -226,12 +227,11 @@ MSK_API int msk_add_link(msk_ctx* c, int art, int parent_body, int joint_type, c
 }
 
 MSK_API int msk_set_drive(msk_ctx* c, int link_body, float K, float D, float force_limit, int mode_acc) {
-  (void)mode_acc;
   DModel& m = c->model;
   if (link_body < 0 || link_body >= m.nb || m.bodies[link_body].dof < 0) return fail(c, MSK_ERR_INVALID, "set_drive: not an active joint");
   DBody* b = &m.bodies[link_body];
-  if (c->finalized && b->K == K && b->D == D && b->fmax == force_limit) return MSK_OK;
-  b->K = K; b->D = D; b->fmax = force_limit;
+  if (c->finalized && b->K == K && b->D == D && b->fmax == force_limit && b->drive_accel == (mode_acc != 0)) return MSK_OK;
+  b->K = K; b->D = D; b->fmax = force_limit; b->drive_accel = mode_acc != 0;
   if (c->finalized) { /* a control-mode switch after gpu_init (agent.set_control_mode): the drive lives in the template, every sub-scene takes it */
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
@@ -289,7 +289,6 @@ MSK_API int msk_add_actor(msk_ctx* c, int kind, const float pose7[7], float mass
 MSK_API int msk_add_shape(msk_ctx* c, int body, int type, const float local_pose[7], const float params[3],
                           const float* verts, int nverts, float sf, float df, float rest, const uint32_t groups[4],
                           float patch_radius, float min_patch_radius) {
-  (void)sf; (void)patch_radius; (void)min_patch_radius;
   DModel& m = c->model;
   if (c->finalized) return fail(c, MSK_ERR_INVALID, "add_shape after finalize");
   if (m.ns >= MSK_MAX_SHAPES) return fail(c, MSK_ERR_CAPACITY, "too many shapes");
@@ -352,6 +351,9 @@ MSK_API int msk_add_shape(msk_ctx* c, int body, int type, const float local_pose
   }
   memcpy(c->groups[m.ns], groups, 4 * sizeof(uint32_t));
   c->rest[m.ns] = rest;
+  c->sfric[m.ns] = sf;
+  c->patch_r[m.ns] = patch_radius > 0.0f ? patch_radius : 0.0f;
+  c->min_patch_r[m.ns] = min_patch_radius > 0.0f ? min_patch_radius : 0.0f;
   return m.ns++;
 }
 
@@ -490,9 +492,19 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
     const DShape* A = &m.shapes[m.pairs[p].sa];
     const DShape* B = &m.shapes[m.pairs[p].sb];
     m.pinfo[p].ba = A->body; m.pinfo[p].bb = B->body;
+    const int ia = m.pairs[p].sa, ib = m.pairs[p].sb;
     m.pinfo[p].mu = 0.5f * (A->df + B->df);
-    m.pinfo[p].rest = 0.5f * (c->rest[m.pairs[p].sa] + c->rest[m.pairs[p].sb]);
+    const float mu_s = 0.5f * (c->sfric[ia] + c->sfric[ib]);
+    m.pinfo[p].mu_s = mu_s < m.pinfo[p].mu ? m.pinfo[p].mu : mu_s;   /* static below dynamic makes no sense: PhysX raises it */
+    m.pinfo[p].rest = 0.5f * (c->rest[ia] + c->rest[ib]);
+    m.pinfo[p].patch_r = fmaxf(c->patch_r[ia], c->patch_r[ib]);
+    m.pinfo[p].min_patch_r = fmaxf(c->min_patch_r[ia], c->min_patch_r[ib]);
+    if (m.pinfo[p].mu_s != m.pinfo[p].mu) m.has_static = 1;
+    if (m.pinfo[p].patch_r > 0.0f || m.pinfo[p].min_patch_r > 0.0f) m.has_tors = 1;
   }
+  m.jfric_mask = 0u; m.njfric = 0;
+  for (int i = 0; i < m.nb; ++i)
+    if (m.bodies[i].kind == MSK_BODY_LINK && m.bodies[i].dof >= 0 && m.bodies[i].jfriction > 0.0f) { m.jfric_mask |= 1u << m.bodies[i].dof; m.njfric++; }
   {
     EnvLayout& L = m.lay;
     int o = 0;
@@ -560,6 +572,9 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
     HIP_TRY(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_solve));
   }
   ALLOC(st.env_ncontacts, N); ALLOC(st.env_overflow, 1); ALLOC(st.ct_total, N);
+  ALLOC(st.drv_mask, N); ALLOC(st.drv, N * G * 4);
+  if (m.has_static) ALLOC(st.ct_slip, N * m.npp);
+  if (m.njfric > 0) ALLOC(st.jforce, N * (size_t)m.nb * 6);
   ALLOC(st.np_count, N * 4); ALLOC(st.np_items, N * NP_TYPES * (size_t)(m.np > 0 ? m.np : 1));
   ALLOC(st.hq_items, N * (size_t)(m.np > 0 ? m.np : 1)); ALLOC(st.hq_count, 1);
   ALLOC(c->d_art_dof0, 8); ALLOC(c->d_art_ndof, 8);
@@ -659,7 +674,7 @@ MSK_API int msk_fetch(msk_ctx* c, uint32_t mask, void* stream) {
   }
   if ((mask & MSK_FETCH_ART_LINK_FORCES) && c->model.na > 0) {
     hipLaunchKernelGGL(k_link_forces, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, c->d_model, c->st, c->link_slots,
-                       c->bufs.buf[MSK_BUF_ART_LINK_JOINT_FORCES]);
+                       c->bufs.buf[MSK_BUF_ART_LINK_JOINT_FORCES], (float*)nullptr);
     if (!(mask & ~(uint32_t)MSK_FETCH_ART_LINK_FORCES)) { HIP_TRY(hipGetLastError()); return MSK_OK; }
   }
   hipLaunchKernelGGL(k_fetch, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->bufs, mask,
@@ -701,6 +716,8 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
   /* k_dynamics: joint-space inertia, drives, unconstrained velocities; consumes and clears pending external wrenches (data-driven,
    * graph-safe); its tail is the broadphase of the same envs.  (Running it as a second branch of the captured graph next to the
    * collision kernels was measured slower than the serial order: 1.64 against 1.58 ms per control step -- removed.) */
+  if (c->model.njfric > 0)   /* joint friction: the wrenches the joints transmitted in the last substep size this one's friction rows */
+    hipLaunchKernelGGL(k_link_forces, dim3((N + 63) / 64), dim3(64), 0, s, c->d_model, c->st, c->link_slots, (float*)nullptr, c->st.jforce);
   launch_dynamics(c->model, c->d_model, c->st, s);
   if (timed) hipEventRecord(ev[1], s);
   if (c->model.np > 0) {
@@ -740,8 +757,13 @@ struct MergedCache {
   int t_dyn = 0, t_np = 0, t_cs = 0, t_af = 0;
   size_t lds_dyn = 0, lds_kin = 0;
   bool any_np = false;
+  unsigned long long used = 0;   /* last use, for eviction */
 };
-static MergedCache g_merged;
+/* one table per list of contexts (a training and an evaluation scene alternate between two lists): a handful of slots, least recently
+ * used evicted.  A slot is valid only while its key is non-empty and its epoch is the current binding epoch. */
+#define MSK_MERGED_SLOTS 4
+static MergedCache g_merged[MSK_MERGED_SLOTS];
+static unsigned long long g_merged_clock = 0;
 
 static int batch_merged(msk_ctx* const* ctxs, int n, int op, uint32_t mask, hipStream_t s) {
   msk_ctx* c = ctxs[0];
@@ -749,19 +771,38 @@ static int batch_merged(msk_ctx* const* ctxs, int n, int op, uint32_t mask, hipS
   static const int e_off = getenv("MSK_BATCH_MERGED") ? atoi(getenv("MSK_BATCH_MERGED")) : 1;
   if (!e_off) return 1;
   const int lpe = lanes_per_env(c->model), md = dyn_md(c->model), G = c->model.G;
+  /* mergeable?  decided before any cached table is touched (a list that is not keeps its streams path and costs no synchronisation) */
   for (int i = 0; i < n; ++i) {
     msk_ctx* x = ctxs[i];
     if (!x->finalized || x->device != c->device || x->t_n < x->t_cap) return 1;
     if (lanes_per_env(x->model) != lpe || dyn_md(x->model) != md || x->model.G != G || x->lds_solve != c->lds_solve) return 1;
+    if (x->model.njfric > 0) return 1;   /* joint friction: an extra launch per context in front of the dynamics */
+    if ((x->model.np > 0) != (c->model.np > 0)) return 1;   /* mixed: the pair-less contexts classify in a kernel of their own */
   }
   if (op == MSK_BATCH_APPLY && (mask & (MSK_APPLY_RIGID_FORCE | MSK_APPLY_RIGID_TORQUE))) return 1;   /* wrench staging: per context */
   if (op == MSK_BATCH_FETCH && (mask & MSK_FETCH_ART_LINK_FORCES)) return 1;
-  MergedCache& mc = g_merged;
-  bool same = mc.epoch == g_bind_epoch && (int)mc.key.size() == n;
-  for (int i = 0; same && i < n; ++i) same = mc.key[i] == ctxs[i];
-  if (!same) {
+  if (op == MSK_BATCH_STEP && c->model.np == 0) return 1;
+  MergedCache* hit = nullptr;
+  for (int k = 0; k < MSK_MERGED_SLOTS && !hit; ++k) {
+    MergedCache& q = g_merged[k];
+    bool same = !q.key.empty() && q.epoch == g_bind_epoch && (int)q.key.size() == n;
+    for (int i = 0; same && i < n; ++i) same = q.key[i] == ctxs[i];
+    if (same) hit = &q;
+  }
+  if (!hit) { /* build the table in the least recently used slot; the slot stays invalid (empty key) until the table is complete */
+    MergedCache* slot = nullptr;
+    for (int k = 0; k < MSK_MERGED_SLOTS && !slot; ++k)
+      if (g_merged[k].key.empty() || g_merged[k].epoch != g_bind_epoch) slot = &g_merged[k];   /* free or stale */
+    if (!slot) {
+      slot = &g_merged[0];
+      for (int k = 1; k < MSK_MERGED_SLOTS; ++k)
+        if (g_merged[k].used < slot->used) slot = &g_merged[k];
+    }
+    MergedCache& mc = *slot;
+    mc.key.clear();
+    mc.epoch = 0;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipDeviceSynchronize());   /* a launch in flight may still read the table that is replaced */
     if (mc.d_refs) { hipFree(mc.d_refs); mc.d_refs = nullptr; }
     std::vector<GroupRef> refs((size_t)n);
     mc.t_dyn = mc.t_np = mc.t_cs = mc.t_af = 0;
@@ -784,13 +825,15 @@ static int batch_merged(msk_ctx* const* ctxs, int n, int op, uint32_t mask, hipS
       if (x->model.np > 0) { mc.t_np += r.np_gx * r.np_gy; mc.any_np = true; } else { r.np_gx = 0; }
       mc.lds_dyn = std::max(mc.lds_dyn, (size_t)DynLds(x->model.nb, md).total * sizeof(float) * epb);
       mc.lds_kin = std::max(mc.lds_kin, (size_t)DynLds(x->model.nb, 0).total * sizeof(float) * epb);
-      if ((x->model.np > 0) != (c->model.np > 0)) return 1;   /* mixed: the pair-less contexts classify in a kernel of their own */
     }
     HIP_TRY(hipMalloc(&mc.d_refs, sizeof(GroupRef) * (size_t)n));
     HIP_TRY(hipMemcpy(mc.d_refs, refs.data(), sizeof(GroupRef) * (size_t)n, hipMemcpyHostToDevice));
     mc.key.assign(ctxs, ctxs + n);
     mc.epoch = g_bind_epoch;
+    hit = &mc;
   }
+  MergedCache& mc = *hit;
+  mc.used = ++g_merged_clock;
   auto kinematics = [&]() {
     if (lpe == 32) hipLaunchKernelGGL(k_multi_kinematics<32>, dim3(mc.t_dyn), dim3(64), mc.lds_kin, s, mc.d_refs, n);
     else hipLaunchKernelGGL(k_multi_kinematics<64>, dim3(mc.t_dyn), dim3(64), mc.lds_kin, s, mc.d_refs, n);
@@ -798,7 +841,6 @@ static int batch_merged(msk_ctx* const* ctxs, int n, int op, uint32_t mask, hipS
   };
   switch (op) {
     case MSK_BATCH_STEP: {
-      if (!mc.any_np) return 1;
       if (lpe == 32) hipLaunchKernelGGL((k_multi_dynamics<32, 16>), dim3(mc.t_dyn), dim3(64), mc.lds_dyn, s, mc.d_refs, n);
       else if (md == 16) hipLaunchKernelGGL((k_multi_dynamics<64, 16>), dim3(mc.t_dyn), dim3(64), mc.lds_dyn, s, mc.d_refs, n);
       else hipLaunchKernelGGL((k_multi_dynamics<64, 32>), dim3(mc.t_dyn), dim3(64), mc.lds_dyn, s, mc.d_refs, n);

@@ -5,8 +5,9 @@
  * of ONE row update.  Carrying a = J v per row (instead of v per coordinate) removes every cross-lane
  * reduction from that chain:
  *
- *   lane b  <->  constraint block b: a joint with an active limit (rows: lower, upper) or a contact
- *                point (rows: normal, tangent 1, tangent 2); <= 16 + 48 = 64 blocks per env.
+ *   lane b  <->  constraint block b, MSK_MAX_BLOCKS = 64 per env, in this order: joints with an active limit or a force-limited
+ *                drive (rows: drive, lower limit, upper limit), joints with friction (one row), contact points (rows: normal,
+ *                tangent 1, tangent 2), torsional rows of one-point manifolds (one row, its cone sized by the point's normal row).
  *                The lane keeps a, b = J dq, lambda, sum(lambda), c0, 1/A_rr of its <= 3 rows in VGPRs.
  *   build        the lane assembles its rows J (S_k . F against the LDS-resident motion subspace
  *                columns), Y = W J^T (W in LDS), parks Y in LDS, then walks all columns r and stores
@@ -35,8 +36,9 @@
 
 #include "msk_model.h"
 
-#define MSK_PEN_BETA 0.8f
+#define MSK_PEN_RATE_COEF 2.0f   /* penetration recovery: bias = depth * 2 sqrt(1 / dt) (oracle: ORC_PEN_RATE_COEF) */
 #define MSK_MAX_DEPEN_VEL 3.0f
+#define MSK_MAX_JOINT_VELOCITY 100.0f   /* PhysX's default maxJointVelocity (oracle: ORC_MAX_JOINT_VELOCITY) */
 /* a row whose own response J W J^T is below this cannot be moved by an impulse (two links with no relative freedom along the normal:
  * fixed-jointed siblings whose hulls overlap; round-off leaves ~1e-8, 1 / that turned one env of UnitreeG1TransportBox-v1 into NaNs):
  * it takes no impulse -- PhysX's minimal-response test (recipResponse = 0).  Lightest response a real body gives: 1 / (1e6 kg). */
@@ -89,14 +91,16 @@ struct CsLds {
   static constexpr int VD = VF + NVP;               /* [2 NVP]   v | dq for the integration         */
   static constexpr int LAMF = VD + 2 * NVP;         /* [COLS]    lambda per row (lambda_0, then final) */
   static constexpr int LAMS = LAMF + COLS;          /* [COLS]    sum of lambda over position sweeps */
-  static constexpr int DESC = LAMS + COLS;          /* int [NDESC] pair*4 + point                   */
-  static constexpr int FIX = ((DESC + NDESC + 3) / 4) * 4;
+  static constexpr int DESC = LAMS + COLS;          /* int [NDESC] contact blocks: pair*4 + point     */
+  static constexpr int TDESC = DESC + NDESC;        /* int [NDESC] torsional blocks: pair             */
+  static constexpr int TREF = TDESC + NDESC;        /* int [NDESC] ... and the contact block (index among the contact blocks) of the pair's point */
+  static constexpr int FIX = ((TREF + NDESC + 3) / 4) * 4;
   /* pool (floats): per env  Y [3 nblk][NVP]  then  A [3 nblk][3][nblk]  (A[(lane, s')][col]) */
   /* one env per wave (GL = 64): room for CAP blocks; packed launch: a shared pool, carved after counting */
   static constexpr int MAXBLK = (GL < 64) ? GL : CAP;
   static constexpr int need(int nb) { return nb * 3 * NVP + 9 * nb * nb; }
   /* the packed class shares its launch with the MSK_CLASS2_BLOCKS image (k_csolve_main): same LDS bytes per workgroup */
-  static constexpr int FIX64 = ((NVP * NVP + NVP * 8 + NVP + 2 * NVP + 6 * 64 + MSK_MAX_CONTACTS + 3) / 4) * 4;
+  static constexpr int FIX64 = ((NVP * NVP + NVP * 8 + NVP + 2 * NVP + 6 * 64 + 3 * MSK_MAX_CONTACTS + 3) / 4) * 4;
   static constexpr int POOL = (GL == 64) ? need(MAXBLK) : (FIX64 + MSK_CLASS2_BLOCKS * 3 * NVP + 9 * MSK_CLASS2_BLOCKS * MSK_CLASS2_BLOCKS - EPW * FIX);
   static constexpr int TOTAL = EPW * FIX + POOL;
   /* packed launch: the block count up to which EPW envs always fit the pool together */
@@ -112,11 +116,11 @@ struct CsLds {
  * recovery or approach speed from c0 + J.dq) or of a friction row (drift J.dq).  b = J.dq only changes
  * between sweeps, so every lane evaluates this once per sweep for its own rows, off the serial chain. */
 template <bool POSIT, bool FRICTION>
-MSK_DEV float bias_over_arr(float b, float c0, float rinv, float inv_h, float inv_dt, float beta_dt, float rest = 0.0f, float vclose = 0.0f) {
+MSK_DEV float bias_over_arr(float b, float c0, float rinv, float inv_h, float inv_dt, float pen_rate, float rest = 0.0f, float vclose = 0.0f) {
   float bias;
   if (!FRICTION) {
     const float cur = c0 + b;
-    if (POSIT) bias = (cur > 0.0f) ? cur * inv_h : fmaxf(cur * beta_dt, -MSK_MAX_DEPEN_VEL);
+    if (POSIT) bias = (cur > 0.0f) ? cur * inv_h : fmaxf(cur * pen_rate, -MSK_MAX_DEPEN_VEL);
     else bias = (cur > 0.0f) ? cur * inv_dt : 0.0f;
     /* restitution: a normal row that came in faster than bounce_threshold aims at the rebound speed (rest = e * J.v* < 0) once the gap
      * is closed (position sweeps) or would be eaten by the approach allowance of the next step (velocity sweep) */
@@ -154,9 +158,14 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   PHASE();
   const int nv = m->nv, nd = m->nd, np = m->np, npp = m->npp;
   const float dt = m->cfg.timestep;
-  const int Np = m->cfg.solver_position_iterations, Nv = m->cfg.solver_velocity_iterations;
-  const float h = dt / (float)Np;
-  const float inv_h = 1.0f / h, inv_dt = 1.0f / dt, beta_dt = MSK_PEN_BETA / dt;
+  /* sweep schedule (oracle: orc_step_env): the T = Np + Nv configured sweeps are spent as nsub sub-steps of (biased sweep, advance of
+   * the rows' positions, relaxing sweep) and nfinal relaxing sweeps: 15 + 1 -> 7 x (1 + 1) + 2 */
+  const int T = (m->cfg.solver_position_iterations > 0 ? m->cfg.solver_position_iterations : 1) +
+                (m->cfg.solver_velocity_iterations > 0 ? m->cfg.solver_velocity_iterations : 0);
+  const int nsub = T >= 4 ? T / 2 - 1 : 1;
+  const int nfinal = T - 2 * nsub > 0 ? T - 2 * nsub : 0;
+  const float h = dt / (float)nsub;
+  const float inv_h = 1.0f / h, inv_dt = 1.0f / dt, pen_rate = MSK_PEN_RATE_COEF * sqrtf(inv_dt);
   float* E = EREC(st, m, e);
   int* cnts = st.ct_cnt + (size_t)e * npp;
   float* recs = st.ct_rec + (size_t)e * npp * MSK_CT_REC;
@@ -167,18 +176,27 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   float* Llamf = lds + LY::LAMF;
   float* Llams = lds + LY::LAMS;
   int* Ldesc = (int*)(lds + LY::DESC);
+  int* Ltdesc = (int*)(lds + LY::TDESC);
+  int* Ltref = (int*)(lds + LY::TREF);
 
-  /* ---- joint limits: lane d owns dof d ---------------------------------------------------------------- */
+  /* ---- joint blocks: lane d owns dof d; a joint has a block when it is near a limit or its drive is a solver row (k_dynamics) ---- */
   float c_lo = 3.0e38f, c_hi = 3.0e38f;
   if (lane < nd) {
     const float lo = m->dof_lo[lane], hi = m->dof_hi[lane], q = E[m->lay.q + lane];
     if (!(lo < -1e30f && hi > 1e30f)) { c_lo = q - lo; c_hi = hi - q; }
   }
+  const unsigned drvm = st.drv_mask[e];
   const unsigned long long blo = GBALLOT(c_lo < MSK_LIMIT_DISTANCE), bhi = GBALLOT(c_hi < MSK_LIMIT_DISTANCE);
-  const int nlim = __popcll(blo | bhi);
+  const unsigned long long bdrv = GBALLOT(lane < nd && ((drvm >> lane) & 1u));
+  const unsigned long long bjoint = blo | bhi | bdrv;
+  const int njoint = __popcll(bjoint);
+  const int nfix = njoint + m->njfric;   /* ... followed by the joint-friction blocks, one per joint with a friction coefficient */
+  const int room = MSK_MAX_BLOCKS - nfix > 0 ? MSK_MAX_BLOCKS - nfix : 0;
+  const int capc = room < MSK_MAX_CONTACTS ? room : MSK_MAX_CONTACTS;   /* contact points this env can take */
 
-  /* ---- contact points in canonical (pair, point) order; capacity MSK_MAX_CONTACTS ----------------------- */
-  int base = 0;
+  /* ---- contact points in canonical (pair, point) order, capacity capc; torsional rows of one-point manifolds ----------- */
+  int base = 0, ntors_pre = 0, ntors_all = 0;
+  const bool any_tors = m->has_tors != 0;
   for (int p0 = 0; p0 < np; p0 += GL) {
     const int p = p0 + lane;
     int cnt = (p < np) ? cnts[p] : 0;
@@ -190,26 +208,33 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
       tot += __popcll(mk);
     }
     const int first = base + pre;
-    if (first + cnt > MSK_MAX_CONTACTS) { /* capacity exhausted: later points are dropped, the slot is trimmed */
-      const int keep = max(0, MSK_MAX_CONTACTS - first);
+    const bool tors_pair = any_tors && p < np && (m->pinfo[p < np ? p : 0].patch_r > 0.0f || m->pinfo[p < np ? p : 0].min_patch_r > 0.0f);
+    if (any_tors) ntors_pre += __popcll(GBALLOT(tors_pair && cnt == 1));
+    if (first + cnt > capc) { /* capacity exhausted: later points are dropped, the slot is trimmed */
+      const int keep = max(0, capc - first);
       if (cnt > 0) cnts[p] = keep;
       cnt = keep;
     }
     if (first + cnt <= LY::NDESC)
       for (int kk = 0; kk < cnt; ++kk) Ldesc[first + kk] = p * 4 + kk;
+    if (any_tors) { /* a pair left with exactly one point and a patch radius: a torsional block behind the contact blocks, in pair order */
+      const bool tors = tors_pair && cnt == 1;
+      const unsigned long long tm = GBALLOT(tors);
+      const int trank = ntors_all + __popcll(tm & ((1ull << lane) - 1ull));
+      if (tors && trank < LY::NDESC) { Ltdesc[trank] = p; Ltref[trank] = first; }
+      ntors_all += __popcll(tm);
+    }
     base += tot;
   }
-  bool overflow = base > MSK_MAX_CONTACTS;
-  if (in_range && lane == 0) { /* the running total the classification read (msk_kernels.h) must be this row's sum; trimmed rows follow */
-    if (st.ct_total[e] != base) atomicOr(st.env_overflow, 4);
-    if (overflow) st.ct_total[e] = MSK_MAX_CONTACTS;
+  bool overflow = base > capc;
+  int ncont = overflow ? capc : base;
+  if (in_range && lane == 0) { /* the running total the classification read (msk_kernels.h) must be this row's block sum; trimmed rows follow */
+    if (st.ct_total[e] != base + ntors_pre) atomicOr(st.env_overflow, 4);
+    if (overflow) st.ct_total[e] = ncont + ntors_all;
   }
-  int ncont = overflow ? MSK_MAX_CONTACTS : base;
-  if (GL == 64 && nlim + ncont > LY::MAXBLK) { /* LDS image of the last class exhausted (NVP = 32 only): trailing points ignored */
-    ncont = LY::MAXBLK - nlim;
-    overflow = true;
-  }
-  int nblk = nlim + ncont;
+  int ntors = ntors_all < room - ncont ? ntors_all : room - ncont;   /* torsional rows get what the points leave */
+  if (ntors > LY::NDESC) ntors = LY::NDESC;
+  int nblk = nfix + ncont + ntors;
   /* carve the pool: groups in order (class 0 admits only block counts that fit together: CsLds::fit) */
   if (!in_range) nblk = 0;
   bool active = in_range;
@@ -252,32 +277,58 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   }
   wave_sync();
 
-  /* ---- my block: rows J, scalars ---------------------------------------------------------------------------- */
+  /* ---- my block: rows J, scalars ----------------------------------------------------------------------------
+   * slot 0: the drive row of a joint block, the row of a joint-friction or torsional block, the normal row of a contact block:
+   *         clamp [lo0, hi0] (torsional blocks: +- mu_r x the normal impulse of their point, fetched when they are swept)
+   * slots 1, 2: the limit rows of a joint block ([0, cap]) or the tangential rows of a contact block (+- flim x lam[0]) */
   float J[3][NVP];
   float c0[3] = {0.0f, 0.0f, 0.0f}, lam[3] = {0.0f, 0.0f, 0.0f};
   bool valid[3] = {false, false, false};
   float mu = 0.0f, erest = 0.0f;
-  int code = -1; /* contact blocks: pair * 4 + point */
+  float lo0 = 0.0f, hi0 = 0.0f, cfm0 = 0.0f, vb0 = 0.0f, mu_r = 0.0f;
+  int code = -1; /* contact blocks: pair * 4 + point; torsional blocks: pair * 4 */
+  int tref = 0;  /* torsional blocks: the lane of their point's contact block */
 #pragma unroll
   for (int s = 0; s < 3; ++s)
 #pragma unroll
     for (int k = 0; k < NVP; ++k) J[s][k] = 0.0f;
-  const bool is_contact = lane >= nlim && lane < nblk;
-  if (lane < nlim) {
-    unsigned long long mk = blo | bhi;
+  const bool is_joint = lane < njoint && lane < nblk;
+  const bool is_jfric = lane >= njoint && lane < nfix && lane < nblk;
+  const bool is_contact = lane >= nfix && lane < nfix + ncont && lane < nblk;
+  const bool is_tors = lane >= nfix + ncont && lane < nblk;
+  if (is_joint) {
+    unsigned long long mk = bjoint;
     for (int t = 0; t < lane; ++t) mk &= mk - 1ull;
     const int d = __ffsll((long long)mk) - 1;
-    valid[0] = (blo >> d) & 1ull;
-    valid[1] = (bhi >> d) & 1ull;
+    valid[0] = (bdrv >> d) & 1ull;
+    valid[1] = (blo >> d) & 1ull;
+    valid[2] = (bhi >> d) & 1ull;
     const float q = E[m->lay.q + d];
-    c0[0] = q - m->dof_lo[d];
-    c0[1] = m->dof_hi[d] - q;
+    c0[1] = q - m->dof_lo[d];
+    c0[2] = m->dof_hi[d] - q;
+    if (valid[0]) { /* force-limited drive as a soft row: compliance, velocity bias, impulse limit (k_dynamics) */
+      const float4 dr = *(const float4*)(st.drv + ((size_t)e * NVP + d) * 4);
+      cfm0 = dr.x; vb0 = dr.y; hi0 = dr.z; lo0 = -dr.z;
+    }
 #pragma unroll
     for (int k = 0; k < NVP; ++k) {
-      if (k == d) { J[0][k] = valid[0] ? 1.0f : 0.0f; J[1][k] = valid[1] ? -1.0f : 0.0f; }
+      if (k == d) { J[0][k] = valid[0] ? 1.0f : 0.0f; J[1][k] = valid[1] ? 1.0f : 0.0f; J[2][k] = valid[2] ? -1.0f : 0.0f; }
     }
+  } else if (is_jfric) { /* joint friction: holds the joint velocity at zero with at most coefficient x |transmitted wrench| x dt */
+    unsigned mk = m->jfric_mask;
+    for (int t = 0; t < lane - njoint; ++t) mk &= mk - 1u;
+    const int d = __ffs((int)mk) - 1;
+    const int body = m->dof_body[d];
+    const float* x = st.jforce + ((size_t)e * m->nb + body) * 6;
+    const float mag = sqrtf(fmaf(x[0], x[0], fmaf(x[1], x[1], fmaf(x[2], x[2], fmaf(x[3], x[3], fmaf(x[4], x[4], x[5] * x[5]))))));
+    valid[0] = true;
+    hi0 = m->bodies[body].jfriction * mag * dt;
+    lo0 = -hi0;
+#pragma unroll
+    for (int k = 0; k < NVP; ++k)
+      if (k == d) J[0][k] = 1.0f;
   } else if (is_contact) {
-    code = Ldesc[lane - nlim];
+    code = Ldesc[lane - nfix];
     const int p = code >> 2, kk = code & 3;
     const DPairInfo pi = m->pinfo[p];
     const float* rec = recs + (size_t)p * MSK_CT_REC;
@@ -286,8 +337,10 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
     msk_tangents(n, &t1, &t2);
     const v3 pt = v3_make(rec[4 + 3 * kk], rec[4 + 3 * kk + 1], rec[4 + 3 * kk + 2]);
     const float sep = rec[16 + kk];
-    mu = pi.mu;
+    /* static friction until the pair slides (narrowphase: ct_slip) */
+    mu = (m->has_static && st.ct_slip[(size_t)e * npp + p]) ? pi.mu : pi.mu_s;
     erest = pi.rest;
+    lo0 = 0.0f; hi0 = MSK_MAX_ROW_IMPULSE;
     /* coordinates that move the two bodies (bit k) */
     const unsigned coordsA = pi.ba >= 0 ? m->body_coords[pi.ba] : 0u, coordsB = pi.bb >= 0 ? m->body_coords[pi.bb] : 0u;
     const v3 dirs[3] = {n, t1, t2};
@@ -313,6 +366,37 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
           if (mvB) Jk = fmaf(-1.0f, x, Jk);
           J[s][k] = Jk;
         }
+      }
+    }
+  } else if (is_tors) { /* relative spin about the normal of a one-point manifold: a pure couple [n; 0] */
+    const int p = Ltdesc[lane - nfix - ncont];
+    code = p * 4;
+    tref = nfix + Ltref[lane - nfix - ncont];
+    const DPairInfo pi = m->pinfo[p];
+    const float* rec = recs + (size_t)p * MSK_CT_REC;
+    const v3 n = v3_make(rec[0], rec[1], rec[2]);
+    const float sep = rec[16];
+    const float rp = fmaxf(pi.min_patch_r, sqrtf(fmaxf(0.0f, -sep) * pi.patch_r));   /* PhysX: the patch grows with the penetration */
+    mu_r = ((m->has_static && st.ct_slip[(size_t)e * npp + p]) ? pi.mu : pi.mu_s) * rp;
+    valid[0] = true;
+    lam[0] = rec[3];
+    const unsigned coordsA = pi.ba >= 0 ? m->body_coords[pi.ba] : 0u, coordsB = pi.bb >= 0 ? m->body_coords[pi.bb] : 0u;
+    sv6 F;
+    F.a = n;
+    F.l = v3_make(0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) {
+      if (k < nv) {
+        const bool mvA = (coordsA >> k) & 1u, mvB = (coordsB >> k) & 1u;
+        const float* sc = Lsc + k * 8;
+        sv6 Sk;
+        Sk.a = v3_make(sc[0], sc[1], sc[2]);
+        Sk.l = v3_make(sc[3], sc[4], sc[5]);
+        const float x = sv6_dot(Sk, F);
+        float Jk = 0.0f;
+        if (mvA) Jk = fmaf(1.0f, x, Jk);
+        if (mvB) Jk = fmaf(-1.0f, x, Jk);
+        J[0][k] = Jk;
       }
     }
   }
@@ -377,8 +461,8 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
         float* a = La + ((size_t)blk * nb + lane) * 9 + s * 3;
         a[0] = d0; a[1] = d1; a[2] = d2;
       }
-      if (lane == blk) { /* my own diagonal */
-        if (s == 0) rinv[0] = d0 > MSK_MIN_RESPONSE ? 1.0f / d0 : 0.0f;
+      if (lane == blk) { /* my own diagonal; a drive row is soft: its compliance adds to the response */
+        if (s == 0) { const float arr = d0 + cfm0; rinv[0] = arr > MSK_MIN_RESPONSE ? 1.0f / arr : 0.0f; }
         if (s == 1) rinv[1] = d1 > MSK_MIN_RESPONSE ? 1.0f / d1 : 0.0f;
         if (s == 2) rinv[2] = d2 > MSK_MIN_RESPONSE ? 1.0f / d2 : 0.0f;
       }
@@ -390,6 +474,7 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
     }
   }
   wave_sync();
+  const float keep0 = fmaf(-cfm0, rinv[0], 1.0f);   /* what a soft row keeps of its impulse in an update; exactly 1 for rigid rows */
 
   PHASE();
   /* ---- Gauss-Seidel sweeps ----------------------------------------------------------------------------------------- */
@@ -404,11 +489,8 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
     for (int i = 0; i < 9; ++i) dst[i] = La[(bc * nb + lrow) * 9 + i];   /* one address, nine immediate offsets */
   };
   /* rows that exist in at least one env of the wave: bit blk*3+s (wave-uniform, tested with scalar ops) */
-  unsigned long long wrows = 0ull;
-  if (GL == 64) {
-    for (int blk = 0; blk < nblk; ++blk)
-      wrows |= (((vm0 >> blk) & 1ull) | (((vm1 >> blk) & 1ull) << 1) | (((vm2 >> blk) & 1ull) << 2)) << ((blk * 3) & 63);
-  } else {
+  unsigned long long wrows = 0ull;   /* the packed class only (16 blocks x 3 bits) */
+  if (GL == 16) {
 #pragma unroll
     for (int blk = 0; blk < 16; ++blk) {
       if (blk >= nbmax) break;
@@ -417,27 +499,44 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
       if (__ballot((vm2 >> blk) & 1ull)) wrows |= 1ull << (blk * 3 + 2);
     }
   }
-  /* clamp bounds without selects: hi = fma(flim, lam_n, hi_c), lo = fma(-flim, lam_n, 0)
-   *   contact block: flim = mu, hi_c = 0 -> +-mu*lam_n ; limit block (slot 1 = upper limit row): flim = 0, hi_c = cap -> [0, cap] */
+  /* blocks that are a torsional block in at least one env of the wave (bit = block index inside the env) */
+  unsigned long long tblocks = 0ull;
+  if (any_tors) {
+    const unsigned long long tb = __ballot(is_tors);
+    tblocks = (GL == 64) ? tb : ((GL == 32) ? ((tb | (tb >> 32)) & 0xFFFFFFFFull) : ((tb | (tb >> 16) | (tb >> 32) | (tb >> 48)) & 0xFFFFull));
+  }
+  /* clamp bounds of slots 1, 2 without selects: hi = fma(flim, lam_n, hi_c), lo = fma(-flim, lam_n, 0)
+   *   contact block: flim = mu, hi_c = 0 -> +-mu*lam_n ; joint block (limit rows): flim = 0, hi_c = cap -> [0, cap] */
   const float flim = is_contact ? mu : 0.0f;
   const float hi_c = is_contact ? 0.0f : MSK_MAX_ROW_IMPULSE;
   auto sweep = [&](auto posit_tag) {
     constexpr bool POSIT = decltype(posit_tag)::value;
-    /* sweep-invariant bias terms of my rows */
-    const float t0 = bias_over_arr<POSIT, false>(bv[0], c0[0], rinv[0], inv_h, inv_dt, beta_dt, rest0, vclose0);
-    const float t1f = bias_over_arr<POSIT, true>(bv[1], c0[1], rinv[1], inv_h, inv_dt, beta_dt);
-    const float t1n = bias_over_arr<POSIT, false>(bv[1], c0[1], rinv[1], inv_h, inv_dt, beta_dt);
+    /* sweep-invariant bias terms of my rows.  slot 0: a contact's normal row (position bias / restitution), or the constant velocity bias
+     * of a drive row (0 for joint-friction and torsional rows); slots 1, 2: limit rows of a joint block, friction rows of a contact block */
+    const float t0n = bias_over_arr<POSIT, false>(bv[0], c0[0], rinv[0], inv_h, inv_dt, pen_rate, rest0, vclose0);
+    const float t0 = is_contact ? t0n : vb0 * rinv[0];
+    const float t1f = bias_over_arr<POSIT, true>(bv[1], c0[1], rinv[1], inv_h, inv_dt, pen_rate);
+    const float t1n = bias_over_arr<POSIT, false>(bv[1], c0[1], rinv[1], inv_h, inv_dt, pen_rate);
     const float t1 = is_contact ? t1f : t1n;
-    const float t2 = bias_over_arr<POSIT, true>(bv[2], c0[2], rinv[2], inv_h, inv_dt, beta_dt);
+    const float t2f = bias_over_arr<POSIT, true>(bv[2], c0[2], rinv[2], inv_h, inv_dt, pen_rate);
+    const float t2n = bias_over_arr<POSIT, false>(bv[2], c0[2], rinv[2], inv_h, inv_dt, pen_rate);
+    const float t2 = is_contact ? t2f : t2n;
     /* one block step; Ac = my rows' nine entries of the three columns of block blk (already in registers) */
     auto block_steps = [&](const int blk, const float* Ac, auto all_rows_tag) {
       const bool owner = lane == blk;
-      const unsigned rowbits = decltype(all_rows_tag)::value ? 7u
-                               : (GL == 64) ? (unsigned)(((vm0 >> blk) & 1ull) | (((vm1 >> blk) & 1ull) << 1) | (((vm2 >> blk) & 1ull) << 2))
-                                            : (unsigned)((wrows >> (blk * 3)) & 7ull);
-      /* new impulse = clamp(lam - (J.v + bias) / A_rr); a row that does not exist has rinv = lam = 0 -> stays 0 */
+      unsigned rowbits;
+      if (decltype(all_rows_tag)::value) rowbits = 7u;
+      else if (GL == 64) rowbits = (unsigned)(((vm0 >> blk) & 1ull) | (((vm1 >> blk) & 1ull) << 1) | (((vm2 >> blk) & 1ull) << 2));
+      else if (GL == 16) rowbits = (unsigned)((wrows >> (blk * 3)) & 7ull);
+      else rowbits = (__ballot((vm0 >> blk) & 1ull) ? 1u : 0u) | (__ballot((vm1 >> blk) & 1ull) ? 2u : 0u) | (__ballot((vm2 >> blk) & 1ull) ? 4u : 0u);
+      /* new impulse = clamp(lam * keep - (J.v + bias) / (A_rr + cfm)); a row that does not exist has rinv = lam = 0 -> stays 0 */
       if (rowbits & 1u) {
-        const float nl = fminf(fmaxf(fmaf(-av[0], rinv[0], lam[0] - t0), 0.0f), MSK_MAX_ROW_IMPULSE);
+        float lo = lo0, hi = hi0;
+        if (!decltype(all_rows_tag)::value && ((tblocks >> blk) & 1ull)) { /* a torsional block: its cone is sized by its point's normal impulse */
+          const float lref = __shfl(lam[0], tref, GL);
+          if (is_tors) { hi = mu_r * lref; lo = -hi; }
+        }
+        const float nl = fminf(fmaxf(fmaf(-av[0], rinv[0], fmaf(lam[0], keep0, -t0)), lo), hi);
         const float dl = group_bcast<GL>(nl - lam[0], blk);
         if (owner) lam[0] = nl;
         av[0] = fmaf(Ac[0], dl, av[0]); av[1] = fmaf(Ac[1], dl, av[1]); av[2] = fmaf(Ac[2], dl, av[2]);
@@ -450,8 +549,8 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
         av[0] = fmaf(Ac[3], dl, av[0]); av[1] = fmaf(Ac[4], dl, av[1]); av[2] = fmaf(Ac[5], dl, av[2]);
       }
       if (rowbits & 4u) {
-        const float hi = flim * lam[0];
-        const float nl = fminf(fmaxf(fmaf(-av[2], rinv[2], lam[2] - t2), -hi), hi);
+        const float hi = fmaf(flim, lam[0], hi_c), lo = fmaf(-flim, lam[0], 0.0f);
+        const float nl = fminf(fmaxf(fmaf(-av[2], rinv[2], lam[2] - t2), lo), hi);
         const float dl = group_bcast<GL>(nl - lam[2], blk);
         if (owner) lam[2] = nl;
         av[0] = fmaf(Ac[6], dl, av[0]); av[1] = fmaf(Ac[7], dl, av[1]); av[2] = fmaf(Ac[8], dl, av[2]);
@@ -468,8 +567,17 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
 #pragma unroll
         for (int i = 0; i < 9; ++i) Ac[i] = An[i];
       }
-    } else { /* one env: limit blocks first (rows 0 / 1 as present), then contact blocks, whose three rows all exist */
-      const int nl0 = __builtin_amdgcn_readfirstlane(nlim < nbmax ? nlim : nbmax);
+    } else { /* one env: joint and joint-friction blocks first (rows as present), then the contact blocks, whose three rows all exist, then the
+              * torsional blocks (slot 0 only) */
+      /* [nl0, nc1): the blocks that are contact blocks in every env of the wave (two envs when GL = 32) */
+      int nl0 = __builtin_amdgcn_readfirstlane(nfix < nbmax ? nfix : nbmax);
+      int nc1 = __builtin_amdgcn_readfirstlane(nfix + ncont);
+      if (GL == 32) {
+        const int nfix1 = __builtin_amdgcn_readlane(nfix, 32), end1 = __builtin_amdgcn_readlane(nfix + ncont, 32);
+        nl0 = max(nl0, nfix1 < nbmax ? nfix1 : nbmax);
+        nc1 = min(nc1, end1);
+      }
+      nc1 = max(nl0, min(nc1, nbmax));
       {
         float Ac[9], An[9];
         load_cols(0, Ac);
@@ -485,17 +593,24 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
       float R[D][9];
 #pragma unroll
       for (int u = 0; u + 1 < D; ++u) load_cols(nl0 + u, R[u]);
-      for (int blk = nl0; blk < nbmax; blk += D) {
+      for (int blk = nl0; blk < nc1; blk += D) {
 #pragma unroll
         for (int u = 0; u < D; ++u) {
-          if (blk + u < nbmax) {
+          if (blk + u < nc1) {
             load_cols(blk + u + D - 1, R[(u + D - 1) % D]);
             block_steps(blk + u, R[u], std::true_type{});
           }
         }
       }
+      if (nc1 < nbmax) {
+        float Ac[9];
+        for (int blk = nc1; blk < nbmax; ++blk) {
+          load_cols(blk, Ac);
+          block_steps(blk, Ac, std::false_type{});
+        }
+      }
     }
-    if (POSIT) {
+    if (POSIT) { /* the sub-step's advance: the rows' positions move on with the biased velocity, the sub-step's impulse is booked */
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         bv[s] = fmaf(h, av[s], bv[s]);
@@ -503,8 +618,11 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
       }
     }
   };
-  for (int it = 0; it < Np; ++it) sweep(std::true_type{});
-  for (int it = 0; it < Nv; ++it) sweep(std::false_type{});
+  for (int sb = 0; sb < nsub; ++sb) {
+    sweep(std::true_type{});
+    sweep(std::false_type{});
+  }
+  for (int it = 0; it < nfinal; ++it) sweep(std::false_type{});
 
   PHASE();
   /* ---- back to generalized coordinates ----------------------------------------------------------------------------------- */
@@ -518,12 +636,13 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
       float* rec = recs + (size_t)(code >> 2) * MSK_CT_REC + 20 + (code & 3) * 3;
       rec[0] = lam[0]; rec[1] = lam[1]; rec[2] = lam[2];
     }
+    if (is_tors) recs[(size_t)(code >> 2) * MSK_CT_REC + 3] = lam[0];
   }
   wave_sync();
   float v = 0.0f, dq = 0.0f;
   if (lane < NVP) {
     const float vf = Lvf[lane];
-    float vk = vf, sk = (float)Np * vf;
+    float vk = vf, sk = (float)nsub * vf;
     for (int blk = 0; blk < nblk; ++blk) {
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
@@ -537,6 +656,10 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
     }
     v = vk;
     dq = h * sk;
+    if (lane < nd && !m->dof_body_is_root[lane]) { /* PhysX's maxJointVelocity: joint coordinates only (a floating root's six are a body's velocity) */
+      v = fminf(fmaxf(v, -MSK_MAX_JOINT_VELOCITY), MSK_MAX_JOINT_VELOCITY);
+      dq = fminf(fmaxf(dq, -MSK_MAX_JOINT_VELOCITY * dt), MSK_MAX_JOINT_VELOCITY * dt);
+    }
     Lvd[lane] = v;
     Lvd[NVP + lane] = dq;
   }

@@ -44,8 +44,8 @@
 #define ORC_MIN_RESPONSE 1.0e-6f /* J W J^T below this: the row takes no impulse (msk_solve.h MSK_MIN_RESPONSE) */
 #define ORC_WARM_DIST 5.0e-3f    /* contact matching radius for warm starting             */
 #ifndef ORC_WARM_NORMAL
-#define ORC_WARM_NORMAL 1.0f     /* fraction of last step's normal (and torsional) impulses applied up front */
-#define ORC_WARM_TANGENT 0.0f    /* ... and of its friction impulses: none -- carried over, the tangential impulses of a manifold's
+#define ORC_WARM_NORMAL 1.0f     /* fraction of last step's normal impulses applied up front */
+#define ORC_WARM_TANGENT 0.0f    /* ... and of its friction (tangential, torsional) impulses: none -- carried over, the tangential impulses of a manifold's
                                   * redundant points build up against each other from step to step and shake a stack (measured:
                                   * 1.0 / 0.9 leaves a five-cube stack swaying at 1.2 rad/s, 1.0 / 0.0 at rest to 1e-4)      */
 #endif
@@ -419,7 +419,7 @@ void orc_link_joint_forces(const orc_ctx* c, orc_env* e, float* out) {
     F = v3_madd(F, ct->t1, ct->lam[1]);
     F = v3_madd(F, ct->t2, ct->lam[2]);
     F = v3_scale(F, inv_dt);
-    const v3 T = v3_cross(ct->pos, F);
+    const v3 T = v3_madd(v3_cross(ct->pos, F), ct->n, ct->lam_t * inv_dt);   /* ... plus the couple of the torsional row */
     if (ct->ba >= 0 && c->bodies[ct->ba].kind == MSK_BODY_LINK) { f[ct->ba].a = v3_sub(f[ct->ba].a, T); f[ct->ba].l = v3_sub(f[ct->ba].l, F); }
     if (ct->bb >= 0 && c->bodies[ct->bb].kind == MSK_BODY_LINK) { f[ct->bb].a = v3_add(f[ct->bb].a, T); f[ct->bb].l = v3_add(f[ct->bb].l, F); }
   }
@@ -665,11 +665,14 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
       r->lam = ct->lam[a]; /* warm start */
     }
   }
-  for (int k = 0; k < e->ncontacts; ++k) { /* torsional rows of one-point manifolds: relative spin about the normal, blocks of their own behind the points' */
+  for (int k = 0; k < e->ncontacts; ++k) { /* torsional rows: relative spin about the normal, blocks of their own behind the points'.  PhysX gives
+                                             * one to a friction patch with a single anchor: here a pair with exactly one point (of those kept) */
     orc_contact* ct = &e->contacts[k];
-    if (!(ct->patch_r > 0.0f || ct->min_patch_r > 0.0f)) continue;
-    const float rp = fmaxf(ct->min_patch_r, sqrtf(fmaxf(0.0f, -ct->sep) * ct->patch_r));   /* PhysX: the patch grows with the penetration */
-    if (!(rp > 0.0f) || nblocks >= MSK_MAX_BLOCKS) { ct->lam_t = 0.0f; continue; }
+    int same = 0;
+    for (int j = 0; j < e->ncontacts; ++j) same += e->contacts[j].sa == ct->sa && e->contacts[j].sb == ct->sb;
+    if (same != 1 || !(ct->patch_r > 0.0f || ct->min_patch_r > 0.0f)) { ct->lam_t = 0.0f; continue; }
+    const float rp = fmaxf(ct->min_patch_r, sqrtf(fmaxf(0.0f, -ct->sep) * ct->patch_r));   /* PhysX: the patch grows with the penetration (0: the row is there and idle) */
+    if (nblocks >= MSK_MAX_BLOCKS) { ct->lam_t = 0.0f; continue; }
     nblocks++;
     orc_row* r = &rows[nr++];
     memset(r, 0, sizeof(*r));

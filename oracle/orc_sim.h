@@ -67,7 +67,7 @@ typedef struct {
   float mu;          /* dynamic friction of the pair: average of the two shapes' (PhysX's default combine mode) */
   float mu_s;        /* static friction, likewise: a friction row sticks up to mu_s * lam_n and slides at mu * lam_n */
   float rest;        /* restitution of the pair, likewise */
-  float patch_r, min_patch_r; /* torsional patch of a single-point manifold (larger of the two shapes'), else 0, 0 */
+  float patch_r, min_patch_r; /* torsional patch of the pair (the larger of the two shapes'): a one-point manifold gets a torsional row */
   float lam[3];      /* accumulated impulses: normal, t1, t2 */
   float lam_t;       /* ... and about the normal (torsional row) */
   int slip;          /* the point's friction rows ended the last step on their cone: it slides, this step's cone is the dynamic one */

@@ -21,9 +21,10 @@ def run(tag, steps, act):
     env.px.timing_enable(0)
     c = env.px.get_env_contact_counts()
     print(tag, {k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in t.items()}, "us/launch; contacts mean %.2f max %d p99 %d"
-          % (c.mean(), c.max(), np.percentile(c, 99)), "hist", np.bincount(c)[:12].tolist())
+          % (c.mean(), c.max(), np.percentile(c, 99)), "hist", np.bincount(c)[:12].tolist(), "classes", env.px.get_solver_class_counts().tolist(),
+          "flags", env.px.get_overflow())
 
 
 run("zero-actions  ", 20, lambda: torch.zeros(N, 8, device="cuda:0"))
-run("random-actions", 60, lambda: 2 * torch.rand(N, 8, device="cuda:0") - 1)
-run("random-actions", 60, lambda: 2 * torch.rand(N, 8, device="cuda:0") - 1)
+for _ in range(int(os.environ.get("PROBE_ROUNDS", "4"))):
+    run("random-actions", 60, lambda: 2 * torch.rand(N, 8, device="cuda:0") - 1)
