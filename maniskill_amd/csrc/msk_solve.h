@@ -76,12 +76,23 @@ MSK_DEV float group_bcast(float x, int blk) {
   }
 }
 
+#define MSK_CLASS0_REG_BLOCKS 12   /* packed class of the 16-coordinate kernels: every lane keeps its A entries (9 per column block) in registers */
 #define MSK_CLASS1_BLOCKS 20   /* capacity classes of the one-env-per-wave images */
 #define MSK_CLASS2_BLOCKS 32
-#define MSK_CLASS3_BLOCKS 64   /* one lane per block: MSK_MAX_DOF limit blocks + MSK_MAX_CONTACTS contact points */
-/* LDS image of one workgroup: 64/GL envs, each with a fixed part, plus one pool for Y and A */
+#define MSK_CLASS3_BLOCKS 64   /* one lane per block: MSK_MAX_BLOCKS */
+/* LDS image of one workgroup: 64/GL envs, each with a fixed part, plus one pool for Y (and A).
+ * NVP = 16 (one Panda + <= 1 free body: the benchmark configurations): the packed class (GL = 16, four envs per wave) keeps A in
+ * REGISTERS and only parks Y in LDS (a fixed region of GL x 3 rows per env); class 1 (<= 20 blocks, one env per wave) has its A image
+ * in LDS; larger envs keep it in global memory.  All three need <= 22 KB per workgroup, so seven workgroups share a CU and the whole
+ * launch is resident at once (it took two rounds at three workgroups per CU with the 46.5 KB image of round 2).
+ * NVP = 32 (Fetch, two arms, cabinets): the round-2 layout, A in LDS up to MSK_CLASS2_BLOCKS blocks. */
+constexpr int cs_fix_words(int nvp, int gl) {
+  return ((nvp * nvp + nvp * 8 + nvp + 2 * nvp + 6 * gl + 3 * (gl < MSK_MAX_CONTACTS ? gl : MSK_MAX_CONTACTS) + 3) / 4) * 4;
+}
+constexpr int cs_max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 template <int NVP, int GL, int CAP>
 struct CsLds {
+  static constexpr bool AREG = (NVP == 16 && GL == 16);
   static constexpr int EPW = 64 / GL;               /* envs per wavefront                              */
   static constexpr int COLS = 3 * GL;
   static constexpr int NDESC = GL < MSK_MAX_CONTACTS ? GL : MSK_MAX_CONTACTS;
@@ -94,17 +105,22 @@ struct CsLds {
   static constexpr int DESC = LAMS + COLS;          /* int [NDESC] contact blocks: pair*4 + point     */
   static constexpr int TDESC = DESC + NDESC;        /* int [NDESC] torsional blocks: pair             */
   static constexpr int TREF = TDESC + NDESC;        /* int [NDESC] ... and the contact block (index among the contact blocks) of the pair's point */
-  static constexpr int FIX = ((TREF + NDESC + 3) / 4) * 4;
+  static constexpr int FIX = cs_fix_words(NVP, GL);
+  static_assert(FIX >= TREF + NDESC, "fixed part");
   /* pool (floats): per env  Y [3 nblk][NVP]  then  A [3 nblk][3][nblk]  (A[(lane, s')][col]) */
-  /* one env per wave (GL = 64): room for CAP blocks; packed launch: a shared pool, carved after counting */
-  static constexpr int MAXBLK = (GL < 64) ? GL : CAP;
+  static constexpr int MAXBLK = AREG ? MSK_CLASS0_REG_BLOCKS : ((GL < 64) ? GL : CAP);
   static constexpr int need(int nb) { return nb * 3 * NVP + 9 * nb * nb; }
-  /* the packed class shares its launch with the MSK_CLASS2_BLOCKS image (k_csolve_main): same LDS bytes per workgroup */
-  static constexpr int FIX64 = ((NVP * NVP + NVP * 8 + NVP + 2 * NVP + 6 * 64 + 3 * MSK_MAX_CONTACTS + 3) / 4) * 4;
-  static constexpr int POOL = (GL == 64) ? need(MAXBLK) : (FIX64 + MSK_CLASS2_BLOCKS * 3 * NVP + 9 * MSK_CLASS2_BLOCKS * MSK_CLASS2_BLOCKS - EPW * FIX);
-  static constexpr int TOTAL = EPW * FIX + POOL;
-  /* packed launch: the block count up to which EPW envs always fit the pool together */
+  static constexpr int YFIX = 3 * GL * NVP;         /* AREG: the env's fixed Y region (rows of idle lanes are zero) */
+  /* one LDS size for every kind of workgroup of a launch */
+  static constexpr int TOTAL16 = cs_max3(4 * cs_fix_words(16, 16) + 4 * 3 * 16 * 16,                      /* packed, A in registers */
+                                         cs_fix_words(16, 64) + MSK_CLASS1_BLOCKS * 3 * 16 + 9 * MSK_CLASS1_BLOCKS * MSK_CLASS1_BLOCKS, /* class 1 */
+                                         cs_fix_words(16, 64) + MSK_CLASS3_BLOCKS * 3 * 16);               /* A in global memory */
+  static constexpr int TOTAL32 = cs_fix_words(32, 64) + MSK_CLASS2_BLOCKS * 3 * 32 + 9 * MSK_CLASS2_BLOCKS * MSK_CLASS2_BLOCKS;
+  static constexpr int TOTAL = (NVP == 16) ? TOTAL16 : TOTAL32;
+  static constexpr int POOL = TOTAL - EPW * FIX;
+  /* packed launch: the block count up to which EPW envs always fit together */
   static constexpr int fit() {
+    if (AREG) return MSK_CLASS0_REG_BLOCKS;
     int nb = 0;
     while (nb + 1 <= GL && EPW * need(nb + 1) <= POOL) ++nb;
     return nb;
@@ -244,7 +260,7 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
 #pragma unroll
     for (int j = 0; j < LY::EPW; ++j) {
       const int nbj = __builtin_amdgcn_readlane(nblk, j * GL);
-      const int need = AGLOB ? nbj * 3 * NVP : LY::need(nbj);
+      const int need = LY::AREG ? LY::YFIX : (AGLOB ? nbj * 3 * NVP : LY::need(nbj));
       const bool fits = nbj <= LY::MAXBLK && off + need <= LY::POOL;
       if (j == g) { pbase = off; if (!fits) active = false; }
       if (fits) off += need;
@@ -260,10 +276,10 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   const int nbmax = (GL == 64) ? nblk : max(max(__builtin_amdgcn_readlane(nblk, 0), __builtin_amdgcn_readlane(nblk, 16 % 64)),
                                            max(__builtin_amdgcn_readlane(nblk, 32 % 64), __builtin_amdgcn_readlane(nblk, 48 % 64)));
   if (nbmax == 0 && __ballot(active) == 0ull) return;
-  float* Ly = pool + pbase;
+  float* Ly = pool + (LY::AREG ? g * LY::YFIX : pbase);
   float* La;
   if constexpr (AGLOB) La = st.a_scratch + (size_t)wg * (9 * CAP * (CAP + 4));
-  else La = Ly + nblk * 3 * NVP;
+  else La = Ly + nblk * 3 * NVP;   /* (unused when the A image lives in registers) */
   const int nb = nblk > 0 ? nblk : 1; /* row stride of my A image */
 
   PHASE();
@@ -401,8 +417,9 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
     }
   }
   PHASE();
-  /* Y = W J^T, parked in LDS; lambda_0 published for the warm start */
-  if (lane < nblk) {
+  /* Y = W J^T, parked in LDS; lambda_0 published for the warm start.  (A image in registers: every lane of the group parks its rows --
+   * zero for the lanes without a block --, the unrolled build below reads all column blocks up to the wave's largest env) */
+  if (LY::AREG || lane < nblk) {
 #pragma unroll
     for (int k = 0; k < NVP; ++k) {
       float y0 = 0.0f, y1 = 0.0f, y2 = 0.0f;
@@ -422,6 +439,17 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   }
   wave_sync();
   const unsigned long long vm0 = GBALLOT(valid[0]), vm1 = GBALLOT(valid[1]), vm2 = GBALLOT(valid[2]);
+  /* rows that exist in at least one env of the wave: bit blk*3+s (wave-uniform, tested with scalar ops) */
+  unsigned long long wrows = 0ull;   /* the packed class only (16 blocks x 3 bits) */
+  if (GL == 16) {
+#pragma unroll
+    for (int blk = 0; blk < 16; ++blk) {
+      if (blk >= nbmax) break;
+      if (__ballot((vm0 >> blk) & 1ull)) wrows |= 1ull << (blk * 3);
+      if (__ballot((vm1 >> blk) & 1ull)) wrows |= 1ull << (blk * 3 + 1);
+      if (__ballot((vm2 >> blk) & 1ull)) wrows |= 1ull << (blk * 3 + 2);
+    }
+  }
 
   PHASE();
   /* ---- constraint-space operator: A[(me, s')][col] = J_(me,s') . Y_col, per (column block, row block) nine contiguous words in LDS -------------------- */
@@ -436,6 +464,43 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   /* restitution bias of my normal row (the oracle's rows[i].rest): e * J.v* if the approach beats bounce_threshold */
   const bool bounces = is_contact && erest > 0.0f && av[0] < -m->cfg.bounce_threshold;
   const float rest0 = bounces ? erest * av[0] : 0.0f, vclose0 = bounces ? -av[0] * dt : 0.0f;
+  constexpr int NREG = LY::AREG ? LY::MAXBLK : 1;
+  float Areg[NREG][9];   /* packed class: my rows' nine entries of every column block, in registers (the loops over blocks are unrolled) */
+  if constexpr (LY::AREG) {
+#pragma unroll
+    for (int blk = 0; blk < NREG; ++blk) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Areg[blk][i] = 0.0f;
+      if (blk < nbmax) { /* wave-uniform */
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const int col = blk * 3 + s;
+          if (!((wrows >> col) & 1ull)) continue;   /* a row no env of the wave has: its column is zero everywhere */
+          /* (in an env that lacks the row, or the whole block, the parked Y row is zero: the dot products are exactly zero) */
+          const float* ycol = Ly + col * NVP;
+          float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
+#pragma unroll
+          for (int k = 0; k < NVP; ++k) {
+            const float y = ycol[k];
+            d0 = fmaf(J[0][k], y, d0);
+            d1 = fmaf(J[1][k], y, d1);
+            d2 = fmaf(J[2][k], y, d2);
+          }
+          Areg[blk][s * 3 + 0] = d0; Areg[blk][s * 3 + 1] = d1; Areg[blk][s * 3 + 2] = d2;
+          if (lane == blk) { /* my own diagonal; a drive row is soft: its compliance adds to the response */
+            if (s == 0) { const float arr = d0 + cfm0; rinv[0] = arr > MSK_MIN_RESPONSE ? 1.0f / arr : 0.0f; }
+            if (s == 1) rinv[1] = d1 > MSK_MIN_RESPONSE ? 1.0f / d1 : 0.0f;
+            if (s == 2) rinv[2] = d2 > MSK_MIN_RESPONSE ? 1.0f / d2 : 0.0f;
+          }
+          /* warm start: a += A[:, col] * lambda_0[col] (rows ascending == columns ascending) */
+          const float l0 = Llamf[col];
+          av[0] = fmaf(d0, l0, av[0]);
+          av[1] = fmaf(d1, l0, av[1]);
+          av[2] = fmaf(d2, l0, av[2]);
+        }
+      }
+    }
+  } else
   for (int blk = 0; blk < nblk; ++blk) { /* per-group trip count: the groups of a wave diverge here, no cross-lane ops inside */
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -488,17 +553,6 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
 #pragma unroll
     for (int i = 0; i < 9; ++i) dst[i] = La[(bc * nb + lrow) * 9 + i];   /* one address, nine immediate offsets */
   };
-  /* rows that exist in at least one env of the wave: bit blk*3+s (wave-uniform, tested with scalar ops) */
-  unsigned long long wrows = 0ull;   /* the packed class only (16 blocks x 3 bits) */
-  if (GL == 16) {
-#pragma unroll
-    for (int blk = 0; blk < 16; ++blk) {
-      if (blk >= nbmax) break;
-      if (__ballot((vm0 >> blk) & 1ull)) wrows |= 1ull << (blk * 3);
-      if (__ballot((vm1 >> blk) & 1ull)) wrows |= 1ull << (blk * 3 + 1);
-      if (__ballot((vm2 >> blk) & 1ull)) wrows |= 1ull << (blk * 3 + 2);
-    }
-  }
   /* blocks that are a torsional block in at least one env of the wave (bit = block index inside the env) */
   unsigned long long tblocks = 0ull;
   if (any_tors) {
@@ -556,7 +610,13 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
         av[0] = fmaf(Ac[6], dl, av[0]); av[1] = fmaf(Ac[7], dl, av[1]); av[2] = fmaf(Ac[8], dl, av[2]);
       }
     };
-    if (GL == 16) { /* unrolled: the block index becomes the immediate of row_newbcast, the copies are renames */
+    if constexpr (LY::AREG) { /* unrolled: the block index becomes the immediate of row_newbcast, A comes from registers */
+#pragma unroll
+      for (int blk = 0; blk < NREG; ++blk) {
+        if (blk >= nbmax) break;
+        block_steps(blk, Areg[blk], std::false_type{});
+      }
+    } else if (GL == 16) { /* unrolled: the block index becomes the immediate of row_newbcast, the copies are renames */
       float Ac[9], An[9];
       load_cols(0, Ac);
 #pragma unroll
@@ -713,16 +773,21 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
  * A image in global memory. */
 template <int NVP, int GL>
 MSK_DEV void csolve_block(const DModel* __restrict__ m, const DState& st, const int gm, const int blk, float* lds) {
-  static_assert(CsLds<NVP, GL, GL>::TOTAL == CsLds<NVP, 64, MSK_CLASS2_BLOCKS>::TOTAL, "one LDS size for both kinds of workgroup");
-  static_assert(MSK_CLASS3_BLOCKS * 3 * NVP <= CsLds<NVP, 64, MSK_CLASS2_BLOCKS>::POOL, "Y of the largest env fits the pool");
+  constexpr int CAPL = (NVP == 16) ? MSK_CLASS1_BLOCKS : MSK_CLASS2_BLOCKS;   /* largest one-env-per-wave image that lives in LDS */
+  static_assert(CsLds<NVP, GL, GL>::TOTAL == CsLds<NVP, 64, CAPL>::TOTAL, "one LDS size for both kinds of workgroup");
+  static_assert(CsLds<NVP, 64, CAPL>::need(CAPL) <= CsLds<NVP, 64, CAPL>::POOL, "the LDS image of the largest in-LDS class fits the pool");
+  static_assert(MSK_CLASS3_BLOCKS * 3 * NVP <= CsLds<NVP, 64, CAPL>::POOL, "Y of the largest env fits the pool");
+  static_assert(!CsLds<NVP, GL, GL>::AREG || CsLds<NVP, GL, GL>::EPW * CsLds<NVP, GL, GL>::YFIX <= CsLds<NVP, GL, GL>::POOL, "the packed class's Y regions fit");
   if (blk == 0 && threadIdx.x == 0) *st.hq_count = 0;   /* the narrowphase has consumed the hull queue; the next broadphase refills it */
   if (blk < gm) {
     const int n3 = st.cls_count[3], n2 = st.cls_count[2], n1 = st.cls_count[1];
     const size_t N = (size_t)m->N;
     for (int i = blk; i < n3 + n2 + n1; i += gm) {
       if (i < n3) solve_env<NVP, 64, MSK_CLASS3_BLOCKS, true>(m, st, st.cls_list + 3 * N, i, n3, lds, blk);
-      else if (i < n3 + n2) solve_env<NVP, 64, MSK_CLASS2_BLOCKS, false>(m, st, st.cls_list + 2 * N, i - n3, n2, lds, blk);
-      else solve_env<NVP, 64, MSK_CLASS2_BLOCKS, false>(m, st, st.cls_list + N, i - n3 - n2, n1, lds, blk);
+      else if (i < n3 + n2) {
+        if constexpr (NVP == 16) solve_env<NVP, 64, MSK_CLASS3_BLOCKS, true>(m, st, st.cls_list + 2 * N, i - n3, n2, lds, blk);   /* 21 .. 32 blocks: A in global memory too */
+        else solve_env<NVP, 64, MSK_CLASS2_BLOCKS, false>(m, st, st.cls_list + 2 * N, i - n3, n2, lds, blk);
+      } else solve_env<NVP, 64, CAPL, false>(m, st, st.cls_list + N, i - n3 - n2, n1, lds, blk);
       wave_sync();
     }
   } else {
