@@ -25,7 +25,7 @@
 #define MSK_WARM_NORMAL 1.0f    /* fraction of last step's normal (and torsional) impulses applied up front (oracle: ORC_WARM_NORMAL) */
 #define MSK_WARM_TANGENT 0.0f   /* ... and of its friction impulses: none (carried over they shake a stack: DESIGN.md §2) */
 
-/* Solver capacity class of env e: constraint blocks = joints within MSK_LIMIT_DISTANCE of a limit or with a drive row + joints with
+/* Solver capacity class of env e: constraint blocks = joints that can reach a limit within the step or have a drive row + joints with
  * friction + the blocks of the contact slots (the same count solve_env makes), against the per-template class capacities. */
 MSK_DEV int solver_class_of(const DModel* __restrict__ m, const DState& st, const int e, const int contacts) {
   const float* E = EREC(st, m, e);
@@ -33,7 +33,12 @@ MSK_DEV int solver_class_of(const DModel* __restrict__ m, const DState& st, cons
   const unsigned dm = st.drv_mask[e];   /* joints whose force-limited drive is a solver row in this substep (k_dynamics) */
   for (int d = 0; d < m->nd; ++d) {
     const float lo = m->dof_lo[d], hi = m->dof_hi[d], q = E[m->lay.q + d];
-    if (((dm >> d) & 1u) || (!(lo < -1e30f && hi > 1e30f) && (q - lo < MSK_LIMIT_DISTANCE || hi - q < MSK_LIMIT_DISTANCE))) nblk++;
+    bool limit = false;
+    if (!(lo < -1e30f && hi > 1e30f)) { /* the solver's rule (msk_solve.h): the joint can reach the limit within this step */
+      const float vf = st.vfree[(size_t)e * m->G + d], dt = m->cfg.timestep;
+      limit = (q - lo < fmaf(2.0f * dt, fmaxf(0.0f, -vf), MSK_LIMIT_SLACK)) || (hi - q < fmaf(2.0f * dt, fmaxf(0.0f, vf), MSK_LIMIT_SLACK));
+    }
+    if (((dm >> d) & 1u) || limit) nblk++;
   }
   nblk += m->njfric;
   const int room = MSK_MAX_BLOCKS - nblk > 0 ? MSK_MAX_BLOCKS - nblk : 0;

@@ -46,10 +46,11 @@ struct DTendon { int dof_a, dof_b; float ca, cb, rest, K, D; };
 struct DPair { int sa, sb; };
 /* bodies of the two shapes; dynamic and static friction and restitution of the pair (averages: PhysX's default combine mode);
  * torsional patch of the pair (the larger of the two shapes'), used when the manifold has a single point */
-struct DPairInfo { int ba, bb; float mu, mu_s; float rest; float patch_r, min_patch_r; };
+struct DPairInfo { int ba, bb; float mu, mu_s; float rest; float patch_r, min_patch_r; unsigned ca, cb; /* DModel::body_coords of ba, bb (0 for the static world): one load for the solver's row assembly */ };
 
 #define MSK_SOLVE_CLASSES 4
-#define MSK_LIMIT_DISTANCE 0.1f   /* a joint closer than this to a limit gets a limit block (solver and classifier) */
+#define MSK_LIMIT_SLACK 5.0e-3f    /* a joint gets a limit row while it can reach the limit in this step: distance < slack + twice what its
+                                   * unconstrained velocity covers towards it in dt (solver and classifier; oracle: ORC_LIMIT_SLACK) */
 #define MSK_MAX_BLOCKS 64          /* constraint blocks per env: one lane each in the solver (oracle: MSK_MAX_BLOCKS) */
 
 struct DModel {

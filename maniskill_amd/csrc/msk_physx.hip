@@ -492,6 +492,8 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
     const DShape* A = &m.shapes[m.pairs[p].sa];
     const DShape* B = &m.shapes[m.pairs[p].sb];
     m.pinfo[p].ba = A->body; m.pinfo[p].bb = B->body;
+    m.pinfo[p].ca = A->body >= 0 ? m.body_coords[A->body] : 0u;
+    m.pinfo[p].cb = B->body >= 0 ? m.body_coords[B->body] : 0u;
     const int ia = m.pairs[p].sa, ib = m.pairs[p].sb;
     m.pinfo[p].mu = 0.5f * (A->df + B->df);
     const float mu_s = 0.5f * (c->sfric[ia] + c->sfric[ib]);

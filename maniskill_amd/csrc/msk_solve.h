@@ -76,7 +76,29 @@ MSK_DEV float group_bcast(float x, int blk) {
   }
 }
 
-#define MSK_CLASS0_REG_BLOCKS 12   /* packed class of the 16-coordinate kernels: every lane keeps its A entries (9 per column block) in registers */
+/* inclusive prefix sum of x over my GL-lane group, and the group's total (in every lane) */
+template <int GL>
+MSK_DEV void group_scan(int x, int* incl, int* total) {
+  if (GL == 16) { /* a DPP row: four shifted adds (lanes shifted in from outside the row read 0), the total is lane 15 of the row */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);   /* row_shr:1 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);   /* row_shr:2 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);   /* row_shr:4 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);   /* row_shr:8 */
+    *incl = x;
+    *total = __builtin_amdgcn_update_dpp(x, x, 0x15F, 0xF, 0xF, false);   /* row_newbcast:15 */
+  } else {
+    const int l = threadIdx.x % GL;
+#pragma unroll
+    for (int d = 1; d < GL; d <<= 1) {
+      const int o = __shfl_up(x, d, GL);
+      if (l >= d) x += o;
+    }
+    *incl = x;
+    *total = __shfl(x, GL - 1, GL);
+  }
+}
+
+#define MSK_CLASS0_REG_BLOCKS 16   /* packed class of the 16-coordinate kernels: every lane keeps its A entries (9 per column block) in registers */
 #define MSK_CLASS1_BLOCKS 20   /* capacity classes of the one-env-per-wave images */
 #define MSK_CLASS2_BLOCKS 32
 #define MSK_CLASS3_BLOCKS 64   /* one lane per block: MSK_MAX_BLOCKS */
@@ -196,13 +218,18 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   int* Ltref = (int*)(lds + LY::TREF);
 
   /* ---- joint blocks: lane d owns dof d; a joint has a block when it is near a limit or its drive is a solver row (k_dynamics) ---- */
-  float c_lo = 3.0e38f, c_hi = 3.0e38f;
+  float c_lo = 3.0e38f, c_hi = 3.0e38f, reach_lo = 0.0f, reach_hi = 0.0f;
   if (lane < nd) {
     const float lo = m->dof_lo[lane], hi = m->dof_hi[lane], q = E[m->lay.q + lane];
-    if (!(lo < -1e30f && hi > 1e30f)) { c_lo = q - lo; c_hi = hi - q; }
+    if (!(lo < -1e30f && hi > 1e30f)) {
+      const float vf = st.vfree[(size_t)e * NVP + lane];   /* a limit row exists while the joint can reach the limit within this step */
+      c_lo = q - lo; c_hi = hi - q;
+      reach_lo = fmaf(2.0f * dt, fmaxf(0.0f, -vf), MSK_LIMIT_SLACK);
+      reach_hi = fmaf(2.0f * dt, fmaxf(0.0f, vf), MSK_LIMIT_SLACK);
+    }
   }
   const unsigned drvm = st.drv_mask[e];
-  const unsigned long long blo = GBALLOT(c_lo < MSK_LIMIT_DISTANCE), bhi = GBALLOT(c_hi < MSK_LIMIT_DISTANCE);
+  const unsigned long long blo = GBALLOT(c_lo < reach_lo), bhi = GBALLOT(c_hi < reach_hi);
   const unsigned long long bdrv = GBALLOT(lane < nd && ((drvm >> lane) & 1u));
   const unsigned long long bjoint = blo | bhi | bdrv;
   const int njoint = __popcll(bjoint);
@@ -213,34 +240,41 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   /* ---- contact points in canonical (pair, point) order, capacity capc; torsional rows of one-point manifolds ----------- */
   int base = 0, ntors_pre = 0, ntors_all = 0;
   const bool any_tors = m->has_tors != 0;
-  for (int p0 = 0; p0 < np; p0 += GL) {
-    const int p = p0 + lane;
-    int cnt = (p < np) ? cnts[p] : 0;
-    int pre = 0, tot = 0;
+  constexpr int PCH = 8;   /* the counts of PCH x GL pairs are fetched side by side: one global round trip instead of one per GL pairs */
+  for (int pc = 0; pc < np; pc += PCH * GL) {
+    int cbuf[PCH];
 #pragma unroll
-    for (int c = 1; c <= 4; ++c) {
-      const unsigned long long mk = GBALLOT(cnt >= c);
-      pre += __popcll(mk & ((1ull << lane) - 1ull));
-      tot += __popcll(mk);
+    for (int u = 0; u < PCH; ++u) {
+      const int p = pc + u * GL + lane;
+      cbuf[u] = (p < np) ? cnts[p] : 0;
     }
-    const int first = base + pre;
-    const bool tors_pair = any_tors && p < np && (m->pinfo[p < np ? p : 0].patch_r > 0.0f || m->pinfo[p < np ? p : 0].min_patch_r > 0.0f);
-    if (any_tors) ntors_pre += __popcll(GBALLOT(tors_pair && cnt == 1));
-    if (first + cnt > capc) { /* capacity exhausted: later points are dropped, the slot is trimmed */
-      const int keep = max(0, capc - first);
-      if (cnt > 0) cnts[p] = keep;
-      cnt = keep;
+#pragma unroll
+    for (int u = 0; u < PCH; ++u) {
+      const int p0 = pc + u * GL;
+      if (p0 >= np) break;
+      const int p = p0 + lane;
+      int cnt = cbuf[u];
+      int incl, tot;
+      group_scan<GL>(cnt, &incl, &tot);
+      const int first = base + incl - cnt;
+      const bool tors_pair = any_tors && p < np && (m->pinfo[p < np ? p : 0].patch_r > 0.0f || m->pinfo[p < np ? p : 0].min_patch_r > 0.0f);
+      if (any_tors) ntors_pre += __popcll(GBALLOT(tors_pair && cnt == 1));
+      if (first + cnt > capc) { /* capacity exhausted: later points are dropped, the slot is trimmed */
+        const int keep = max(0, capc - first);
+        if (cnt > 0) cnts[p] = keep;
+        cnt = keep;
+      }
+      if (first + cnt <= LY::NDESC)
+        for (int kk = 0; kk < cnt; ++kk) Ldesc[first + kk] = p * 4 + kk;
+      if (any_tors) { /* a pair left with exactly one point and a patch radius: a torsional block behind the contact blocks, in pair order */
+        const bool tors = tors_pair && cnt == 1;
+        const unsigned long long tm = GBALLOT(tors);
+        const int trank = ntors_all + __popcll(tm & ((1ull << lane) - 1ull));
+        if (tors && trank < LY::NDESC) { Ltdesc[trank] = p; Ltref[trank] = first; }
+        ntors_all += __popcll(tm);
+      }
+      base += tot;
     }
-    if (first + cnt <= LY::NDESC)
-      for (int kk = 0; kk < cnt; ++kk) Ldesc[first + kk] = p * 4 + kk;
-    if (any_tors) { /* a pair left with exactly one point and a patch radius: a torsional block behind the contact blocks, in pair order */
-      const bool tors = tors_pair && cnt == 1;
-      const unsigned long long tm = GBALLOT(tors);
-      const int trank = ntors_all + __popcll(tm & ((1ull << lane) - 1ull));
-      if (tors && trank < LY::NDESC) { Ltdesc[trank] = p; Ltref[trank] = first; }
-      ntors_all += __popcll(tm);
-    }
-    base += tot;
   }
   bool overflow = base > capc;
   int ncont = overflow ? capc : base;
@@ -283,17 +317,21 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   const int nb = nblk > 0 ? nblk : 1; /* row stride of my A image */
 
   PHASE();
-  /* ---- stage the env's solver tables in LDS -------------------------------------------------------------- */
+  /* ---- loads first: the env's solver tables (for LDS) and everything my block needs from global memory are requested side by side,
+   * then the tables are parked in LDS, then the rows are computed: two global round trips on the critical path instead of six ---- */
+  constexpr int NW4 = (NVP * NVP / 4 + GL - 1) / GL, NS4 = (NVP * 2 + GL - 1) / GL;
+  float4 wreg[NW4], sreg[NS4];
   {
     const float4* wsrc = (const float4*)(st.W + (size_t)e * NVP * NVP);
-    for (int i = lane; i < NVP * NVP / 4; i += GL) ((float4*)Lw)[i] = wsrc[i];
     const float4* ssrc = (const float4*)(st.Scol + (size_t)e * NVP * 8);
-    for (int i = lane; i < NVP * 2; i += GL) ((float4*)Lsc)[i] = ssrc[i];
-    if (lane < NVP) Lvf[lane] = st.vfree[(size_t)e * NVP + lane];
+#pragma unroll
+    for (int u = 0; u < NW4; ++u) { const int i = lane + u * GL; wreg[u] = (i < NVP * NVP / 4) ? wsrc[i] : make_float4(0, 0, 0, 0); }
+#pragma unroll
+    for (int u = 0; u < NS4; ++u) { const int i = lane + u * GL; sreg[u] = (i < NVP * 2) ? ssrc[i] : make_float4(0, 0, 0, 0); }
   }
-  wave_sync();
+  const float vfreg = (lane < NVP) ? st.vfree[(size_t)e * NVP + lane] : 0.0f;
 
-  /* ---- my block: rows J, scalars ----------------------------------------------------------------------------
+  /* ---- my block: what it reads from global memory ---------------------------------------------------------------
    * slot 0: the drive row of a joint block, the row of a joint-friction or torsional block, the normal row of a contact block:
    *         clamp [lo0, hi0] (torsional blocks: +- mu_r x the normal impulse of their point, fetched when they are swept)
    * slots 1, 2: the limit rows of a joint block ([0, cap]) or the tangential rows of a contact block (+- flim x lam[0]) */
@@ -304,6 +342,10 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   float lo0 = 0.0f, hi0 = 0.0f, cfm0 = 0.0f, vb0 = 0.0f, mu_r = 0.0f;
   int code = -1; /* contact blocks: pair * 4 + point; torsional blocks: pair * 4 */
   int tref = 0;  /* torsional blocks: the lane of their point's contact block */
+  int jd = -1;   /* joint and joint-friction blocks: my dof */
+  unsigned coordsA = 0u, coordsB = 0u;   /* contact and torsional blocks: coordinates that move the two bodies (bit k) */
+  v3 cn = v3_make(0, 0, 1), cpt = v3_make(0, 0, 0);   /* ... their normal, my contact point */
+  float csep = 0.0f;
 #pragma unroll
   for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -315,105 +357,109 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   if (is_joint) {
     unsigned long long mk = bjoint;
     for (int t = 0; t < lane; ++t) mk &= mk - 1ull;
-    const int d = __ffsll((long long)mk) - 1;
-    valid[0] = (bdrv >> d) & 1ull;
-    valid[1] = (blo >> d) & 1ull;
-    valid[2] = (bhi >> d) & 1ull;
-    const float q = E[m->lay.q + d];
-    c0[1] = q - m->dof_lo[d];
-    c0[2] = m->dof_hi[d] - q;
+    jd = __ffsll((long long)mk) - 1;
+    valid[0] = (bdrv >> jd) & 1ull;
+    valid[1] = (blo >> jd) & 1ull;
+    valid[2] = (bhi >> jd) & 1ull;
+    const float q = E[m->lay.q + jd];
+    c0[1] = valid[1] ? q - m->dof_lo[jd] : 0.0f;   /* (a row that does not exist is swept along in the packed class: everything about it stays finite) */
+    c0[2] = valid[2] ? m->dof_hi[jd] - q : 0.0f;
     if (valid[0]) { /* force-limited drive as a soft row: compliance, velocity bias, impulse limit (k_dynamics) */
-      const float4 dr = *(const float4*)(st.drv + ((size_t)e * NVP + d) * 4);
+      const float4 dr = *(const float4*)(st.drv + ((size_t)e * NVP + jd) * 4);
       cfm0 = dr.x; vb0 = dr.y; hi0 = dr.z; lo0 = -dr.z;
-    }
-#pragma unroll
-    for (int k = 0; k < NVP; ++k) {
-      if (k == d) { J[0][k] = valid[0] ? 1.0f : 0.0f; J[1][k] = valid[1] ? 1.0f : 0.0f; J[2][k] = valid[2] ? -1.0f : 0.0f; }
     }
   } else if (is_jfric) { /* joint friction: holds the joint velocity at zero with at most coefficient x |transmitted wrench| x dt */
     unsigned mk = m->jfric_mask;
     for (int t = 0; t < lane - njoint; ++t) mk &= mk - 1u;
-    const int d = __ffs((int)mk) - 1;
-    const int body = m->dof_body[d];
+    jd = __ffs((int)mk) - 1;
+    const int body = m->dof_body[jd];
     const float* x = st.jforce + ((size_t)e * m->nb + body) * 6;
     const float mag = sqrtf(fmaf(x[0], x[0], fmaf(x[1], x[1], fmaf(x[2], x[2], fmaf(x[3], x[3], fmaf(x[4], x[4], x[5] * x[5]))))));
     valid[0] = true;
     hi0 = m->bodies[body].jfriction * mag * dt;
     lo0 = -hi0;
+  } else if (is_contact || is_tors) {
+    int p, kk = 0;
+    if (is_contact) { code = Ldesc[lane - nfix]; p = code >> 2; kk = code & 3; }
+    else { p = Ltdesc[lane - nfix - ncont]; code = p * 4; tref = nfix + Ltref[lane - nfix - ncont]; }
+    const DPairInfo pi = m->pinfo[p];
+    const float* rec = recs + (size_t)p * MSK_CT_REC;
+    const float4 r0 = *(const float4*)rec;   /* normal, impulse of the torsional row */
+    cn = v3_make(r0.x, r0.y, r0.z);
+    csep = rec[16 + kk];
+    coordsA = pi.ca; coordsB = pi.cb;
+    /* static friction until the pair slides (narrowphase: ct_slip) */
+    const float mu_eff = (m->has_static && st.ct_slip[(size_t)e * npp + p]) ? pi.mu : pi.mu_s;
+    if (is_contact) {
+      cpt = v3_make(rec[4 + 3 * kk], rec[4 + 3 * kk + 1], rec[4 + 3 * kk + 2]);
+      mu = mu_eff;
+      erest = pi.rest;
+      lo0 = 0.0f; hi0 = MSK_MAX_ROW_IMPULSE;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) { valid[s] = true; c0[s] = csep; lam[s] = rec[20 + 3 * kk + s]; }
+    } else { /* relative spin about the normal of a one-point manifold */
+      const float rp = fmaxf(pi.min_patch_r, sqrtf(fmaxf(0.0f, -csep) * pi.patch_r));   /* PhysX: the patch grows with the penetration */
+      mu_r = mu_eff * rp;
+      valid[0] = true;
+      lam[0] = r0.w;
+    }
+  }
+
+  /* ---- the env's solver tables into LDS -------------------------------------------------------------------------- */
+  {
+#pragma unroll
+    for (int u = 0; u < NW4; ++u) { const int i = lane + u * GL; if (i < NVP * NVP / 4) ((float4*)Lw)[i] = wreg[u]; }
+#pragma unroll
+    for (int u = 0; u < NS4; ++u) { const int i = lane + u * GL; if (i < NVP * 2) ((float4*)Lsc)[i] = sreg[u]; }
+    if (lane < NVP) Lvf[lane] = vfreg;
+  }
+  wave_sync();
+
+  /* ---- my block: rows J -----------------------------------------------------------------------------------------
+   * ucoords: the coordinates some row of the wave touches (wave-uniform): every loop over coordinates below skips the others -- their
+   * entries of J are zero in every lane, so the skipped terms are exact zeros */
+  unsigned ucoords = 0u;
+  {
+    const unsigned mine = (is_joint || is_jfric) ? (1u << jd) : ((is_contact || is_tors) ? (coordsA | coordsB) : 0u);
 #pragma unroll
     for (int k = 0; k < NVP; ++k)
-      if (k == d) J[0][k] = 1.0f;
-  } else if (is_contact) {
-    code = Ldesc[lane - nfix];
-    const int p = code >> 2, kk = code & 3;
-    const DPairInfo pi = m->pinfo[p];
-    const float* rec = recs + (size_t)p * MSK_CT_REC;
-    const v3 n = v3_make(rec[0], rec[1], rec[2]);
-    v3 t1, t2;
-    msk_tangents(n, &t1, &t2);
-    const v3 pt = v3_make(rec[4 + 3 * kk], rec[4 + 3 * kk + 1], rec[4 + 3 * kk + 2]);
-    const float sep = rec[16 + kk];
-    /* static friction until the pair slides (narrowphase: ct_slip) */
-    mu = (m->has_static && st.ct_slip[(size_t)e * npp + p]) ? pi.mu : pi.mu_s;
-    erest = pi.rest;
-    lo0 = 0.0f; hi0 = MSK_MAX_ROW_IMPULSE;
-    /* coordinates that move the two bodies (bit k) */
-    const unsigned coordsA = pi.ba >= 0 ? m->body_coords[pi.ba] : 0u, coordsB = pi.bb >= 0 ? m->body_coords[pi.bb] : 0u;
-    const v3 dirs[3] = {n, t1, t2};
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      valid[s] = true;
-      c0[s] = sep;
-      lam[s] = rec[20 + 3 * kk + s];
-      sv6 F;
-      F.a = v3_cross(pt, dirs[s]);
-      F.l = dirs[s];
-#pragma unroll
-      for (int k = 0; k < NVP; ++k) {
-        if (k < nv) {
-          const bool mvA = (coordsA >> k) & 1u, mvB = (coordsB >> k) & 1u;
-          const float* sc = Lsc + k * 8;
-          sv6 Sk;
-          Sk.a = v3_make(sc[0], sc[1], sc[2]);
-          Sk.l = v3_make(sc[3], sc[4], sc[5]);
-          const float x = sv6_dot(Sk, F);
-          float Jk = 0.0f;
-          if (mvA) Jk = fmaf(1.0f, x, Jk);
-          if (mvB) Jk = fmaf(-1.0f, x, Jk);
-          J[s][k] = Jk;
-        }
-      }
-    }
-  } else if (is_tors) { /* relative spin about the normal of a one-point manifold: a pure couple [n; 0] */
-    const int p = Ltdesc[lane - nfix - ncont];
-    code = p * 4;
-    tref = nfix + Ltref[lane - nfix - ncont];
-    const DPairInfo pi = m->pinfo[p];
-    const float* rec = recs + (size_t)p * MSK_CT_REC;
-    const v3 n = v3_make(rec[0], rec[1], rec[2]);
-    const float sep = rec[16];
-    const float rp = fmaxf(pi.min_patch_r, sqrtf(fmaxf(0.0f, -sep) * pi.patch_r));   /* PhysX: the patch grows with the penetration */
-    mu_r = ((m->has_static && st.ct_slip[(size_t)e * npp + p]) ? pi.mu : pi.mu_s) * rp;
-    valid[0] = true;
-    lam[0] = rec[3];
-    const unsigned coordsA = pi.ba >= 0 ? m->body_coords[pi.ba] : 0u, coordsB = pi.bb >= 0 ? m->body_coords[pi.bb] : 0u;
-    sv6 F;
-    F.a = n;
-    F.l = v3_make(0, 0, 0);
+      if (__ballot((mine >> k) & 1u)) ucoords |= 1u << k;
+  }
+  if (is_joint) {
 #pragma unroll
     for (int k = 0; k < NVP; ++k) {
-      if (k < nv) {
-        const bool mvA = (coordsA >> k) & 1u, mvB = (coordsB >> k) & 1u;
-        const float* sc = Lsc + k * 8;
-        sv6 Sk;
-        Sk.a = v3_make(sc[0], sc[1], sc[2]);
-        Sk.l = v3_make(sc[3], sc[4], sc[5]);
-        const float x = sv6_dot(Sk, F);
-        float Jk = 0.0f;
-        if (mvA) Jk = fmaf(1.0f, x, Jk);
-        if (mvB) Jk = fmaf(-1.0f, x, Jk);
-        J[0][k] = Jk;
-      }
+      if (k == jd) { J[0][k] = valid[0] ? 1.0f : 0.0f; J[1][k] = valid[1] ? 1.0f : 0.0f; J[2][k] = valid[2] ? -1.0f : 0.0f; }
+    }
+  } else if (is_jfric) {
+#pragma unroll
+    for (int k = 0; k < NVP; ++k)
+      if (k == jd) J[0][k] = 1.0f;
+  }
+  {
+    /* contact blocks: F_s = [p x d_s; d_s] for the normal and the two tangents; torsional blocks: the couple [n; 0].
+     * J_k = (+1 if coordinate k moves body A) + (-1 if it moves body B) times S_k . F: the sign factor is exact */
+    v3 t1 = v3_make(0, 0, 0), t2 = t1;
+    if (is_contact) msk_tangents(cn, &t1, &t2);
+    sv6 F0, F1, F2;
+    if (is_contact) {
+      F0.a = v3_cross(cpt, cn); F0.l = cn;
+      F1.a = v3_cross(cpt, t1); F1.l = t1;
+      F2.a = v3_cross(cpt, t2); F2.l = t2;
+    } else {
+      F0.a = cn; F0.l = v3_make(0, 0, 0);
+      F1 = sv6_zero(); F2 = sv6_zero();
+    }
+    const bool rows3 = is_contact, rows1 = is_contact || is_tors;
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) {
+      if (!((ucoords >> k) & 1u)) continue;   /* wave-uniform */
+      const float* sc = Lsc + k * 8;
+      sv6 Sk;
+      Sk.a = v3_make(sc[0], sc[1], sc[2]);
+      Sk.l = v3_make(sc[3], sc[4], sc[5]);
+      const float sgn = (float)((coordsA >> k) & 1u) - (float)((coordsB >> k) & 1u);
+      if (rows1) J[0][k] = sgn * sv6_dot(Sk, F0);
+      if (rows3) { J[1][k] = sgn * sv6_dot(Sk, F1); J[2][k] = sgn * sv6_dot(Sk, F2); }
     }
   }
   PHASE();
@@ -458,7 +504,10 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   for (int s = 0; s < 3; ++s) {
     float acc = 0.0f;
 #pragma unroll
-    for (int k = 0; k < NVP; ++k) acc = fmaf(J[s][k], Lvf[k], acc);
+    for (int k = 0; k < NVP; ++k) {
+      if (!((ucoords >> k) & 1u)) continue;
+      acc = fmaf(J[s][k], Lvf[k], acc);
+    }
     av[s] = acc;
   }
   /* restitution bias of my normal row (the oracle's rows[i].rest): e * J.v* if the approach beats bounce_threshold */
@@ -576,10 +625,15 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
     const float t2n = bias_over_arr<POSIT, false>(bv[2], c0[2], rinv[2], inv_h, inv_dt, pen_rate);
     const float t2 = is_contact ? t2f : t2n;
     /* one block step; Ac = my rows' nine entries of the three columns of block blk (already in registers) */
+    /* clamp(x, lo, hi) as ONE instruction on the serial chain: v_med3_f32 == fminf(fmaxf(x, lo), hi) whenever lo <= hi (always: the bounds
+     * are +-(a coefficient >= 0) x (a normal impulse >= 0), [0, cap] or +-(a limit >= 0)) and x is no NaN */
+    auto clampf = [](float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); };
     auto block_steps = [&](const int blk, const float* Ac, auto all_rows_tag) {
       const bool owner = lane == blk;
+      /* the packed class sweeps all three rows of every block: a row that does not exist has rinv = lam = 0 and a zero column, so its
+       * update is an exact no-op -- cheaper than a scalar branch per row in the unrolled stream */
       unsigned rowbits;
-      if (decltype(all_rows_tag)::value) rowbits = 7u;
+      if (decltype(all_rows_tag)::value || LY::AREG) rowbits = 7u;
       else if (GL == 64) rowbits = (unsigned)(((vm0 >> blk) & 1ull) | (((vm1 >> blk) & 1ull) << 1) | (((vm2 >> blk) & 1ull) << 2));
       else if (GL == 16) rowbits = (unsigned)((wrows >> (blk * 3)) & 7ull);
       else rowbits = (__ballot((vm0 >> blk) & 1ull) ? 1u : 0u) | (__ballot((vm1 >> blk) & 1ull) ? 2u : 0u) | (__ballot((vm2 >> blk) & 1ull) ? 4u : 0u);
@@ -590,21 +644,21 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
           const float lref = __shfl(lam[0], tref, GL);
           if (is_tors) { hi = mu_r * lref; lo = -hi; }
         }
-        const float nl = fminf(fmaxf(fmaf(-av[0], rinv[0], fmaf(lam[0], keep0, -t0)), lo), hi);
+        const float nl = clampf(fmaf(-av[0], rinv[0], fmaf(lam[0], keep0, -t0)), lo, hi);
         const float dl = group_bcast<GL>(nl - lam[0], blk);
         if (owner) lam[0] = nl;
         av[0] = fmaf(Ac[0], dl, av[0]); av[1] = fmaf(Ac[1], dl, av[1]); av[2] = fmaf(Ac[2], dl, av[2]);
       }
       if (rowbits & 2u) {
         const float hi = fmaf(flim, lam[0], hi_c), lo = fmaf(-flim, lam[0], 0.0f);
-        const float nl = fminf(fmaxf(fmaf(-av[1], rinv[1], lam[1] - t1), lo), hi);
+        const float nl = clampf(fmaf(-av[1], rinv[1], lam[1] - t1), lo, hi);
         const float dl = group_bcast<GL>(nl - lam[1], blk);
         if (owner) lam[1] = nl;
         av[0] = fmaf(Ac[3], dl, av[0]); av[1] = fmaf(Ac[4], dl, av[1]); av[2] = fmaf(Ac[5], dl, av[2]);
       }
       if (rowbits & 4u) {
         const float hi = fmaf(flim, lam[0], hi_c), lo = fmaf(-flim, lam[0], 0.0f);
-        const float nl = fminf(fmaxf(fmaf(-av[2], rinv[2], lam[2] - t2), lo), hi);
+        const float nl = clampf(fmaf(-av[2], rinv[2], lam[2] - t2), lo, hi);
         const float dl = group_bcast<GL>(nl - lam[2], blk);
         if (owner) lam[2] = nl;
         av[0] = fmaf(Ac[6], dl, av[0]); av[1] = fmaf(Ac[7], dl, av[1]); av[2] = fmaf(Ac[8], dl, av[2]);

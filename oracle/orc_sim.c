@@ -14,7 +14,7 @@
  *                      becomes a row of the constraint solver (soft row, impulse clamped to
  *                      +-force_limit * dt: PhysX limits a drive's impulse inside the solve)
  *   3. collision       orc_collide.c over the static candidate pair table
- *   4. rows            joint limits (only within ORC_LIMIT_DISTANCE of the limit, the joint
+ *   4. rows            joint limits (only while the joint can reach the limit within the step, the joint
  *                      counterpart of contact_offset), contact normal + 2 friction rows per
  *                      point, in generalized coordinates: J_k = (+-) S_k . F for every coordinate k
  *                      that moves the body (S_k = motion subspace column of coordinate k, free
@@ -50,7 +50,8 @@
                                   * 1.0 / 0.9 leaves a five-cube stack swaying at 1.2 rad/s, 1.0 / 0.0 at rest to 1e-4)      */
 #endif
 #define MSK_MAX_BLOCKS 64        /* constraint blocks per env: one lane each in the device solver (msk_solve.h) */
-#define ORC_LIMIT_DISTANCE 0.1f  /* a joint-limit row exists while q is within this of the limit */
+#define ORC_LIMIT_SLACK 5.0e-3f   /* a joint-limit row exists while the joint can reach the limit in this step: distance < slack + twice what
+                                  * its unconstrained velocity covers towards it in dt (the joint counterpart of the speculative contact rule, orc_collide.c) */
 #ifndef ORC_MAX_JOINT_VELOCITY
 #define ORC_MAX_JOINT_VELOCITY 100.0f /* PhysX's default maxJointVelocity of a reduced-coordinate articulation joint (rad/s, m/s): the second line behind the drive rows */
 #endif
@@ -615,7 +616,8 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
       } else {
         if (!limited) continue;
         c0 = (kind == ROW_LIMLO) ? (e->q[b->dof] - b->lim_lo) : (b->lim_hi - e->q[b->dof]);
-        if (!(c0 < ORC_LIMIT_DISTANCE)) continue;
+        const float toward = (kind == ROW_LIMLO) ? -s.vfree[b->dof] : s.vfree[b->dof];
+        if (!(c0 < fmaf(2.0f * dt, fmaxf(0.0f, toward), ORC_LIMIT_SLACK))) continue;
       }
       orc_row* r = &rows[nr++];
       memset(r, 0, sizeof(*r));

@@ -5,9 +5,9 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 src = os.path.join(ROOT, "maniskill_amd", "csrc")
-lib = "/tmp/libmsk_prof.so"
-subprocess.check_call(f"cd {src} && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden "
-                      f"-Wno-unused-value -DMSK_PROFILE_PHASES -o {lib} msk_physx.hip", shell=True)
+lib = os.path.join(src, "libmsk_prof.so")      # build it where hipcc is (the build container: `make -C maniskill_amd/csrc libmsk_prof.so`); it travels with the snapshot
+if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src) if f.endswith((".h", ".hip"))):
+    subprocess.check_call(f"make -C {src} libmsk_prof.so", shell=True)
 from maniskill_amd import _native as N
 N.DEFAULT_LIB = lib
 from maniskill_amd.envs.pick_cube import PickCubeEnv

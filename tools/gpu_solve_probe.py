@@ -5,6 +5,9 @@ import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from maniskill_amd import _native as _N
+if os.environ.get("MSK_LIB"):      # A/B runs of two builds on the same box: MSK_LIB=maniskill_amd/csrc/libmsk_b.so
+    _N.DEFAULT_LIB = os.path.abspath(os.environ["MSK_LIB"])
 from maniskill_amd.envs.pick_cube import PickCubeEnv
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
