@@ -39,7 +39,7 @@ enum { NP_PLANE = 0, NP_BOXBOX = 1, NP_GJK = 2, NP_TYPES = 3 };
 
 /* the whole wavefront works on env e; aabb / obb: LDS scratch of the calling block, free to be overwritten */
 MSK_DEV void broadphase_env(const DModel* __restrict__ m, const DState& st, const int e, float (*aabb)[6], float (*obb)[13]) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;   /* (the broadphase wave of k_dynamics is the workgroup's second one) */
   const float* E = EREC(st, m, e);
   const float margin = 2.0f * m->cfg.contact_offset;
   if (lane < m->ns) {

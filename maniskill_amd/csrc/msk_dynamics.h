@@ -193,6 +193,22 @@ __global__ void __launch_bounds__(64) k_kinematics(const DModel* __restrict__ m,
 
 /* blk: which block of the env range this workgroup is (its blockIdx.x when the launch serves one context: k_dynamics; its index inside
  * the context's share of a launch over several contexts: k_multi_dynamics, msk_kernels.h) */
+/* broadphase of the block's envs (msk_broadphase.h), the whole wavefront on one env at a time.  It reads the body poses in the env
+ * record and nothing else: in k_dynamics it is the workgroup's SECOND wavefront, released as soon as the first one has published the
+ * link frames (the forward pass), and runs beside the rest of the dynamics on another SIMD of the CU (it used to be the kernel's tail:
+ * ~25 k cycles of the ~105 k of a block). */
+template <int LPE>
+MSK_DEV void broadphase_block(const DModel* __restrict__ m, const DState& st, const int blk) {
+  __shared__ float bp_aabb[MSK_MAX_SHAPES][6];
+  __shared__ float bp_obb[MSK_MAX_SHAPES][13];   /* rotation columns (9), local half extents (3); odd stride: no bank conflicts */
+  if (blk == 0 && (threadIdx.x & 63) < MSK_SOLVE_CLASSES) st.cls_count[threadIdx.x & 63] = 0;   /* this substep's solver lists (filled by the narrowphase) */
+#pragma unroll 1
+  for (int k = 0; k < 64 / LPE; ++k) {
+    const int eb = blk * (64 / LPE) + k;
+    if (eb < m->N) broadphase_env(m, st, eb, bp_aabb, bp_obb);
+  }
+}
+
 template <int LPE, int MD>   /* MD: capacity of the per-lane joint-space rows (16 or 32 dofs) */
 MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, float* lds_all, const int blk) {
   const DynLds ly(m->nb, MD);
@@ -236,6 +252,7 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
     comw = v3_add(T.p, m33_mulv(&R, b->com));
     publish_body(m, E, i, b, T, V, comw);
   }
+  if (blockDim.x == 128) __syncthreads();   /* the link frames are in the env records: the workgroup's broadphase wave may go */
   /* zero M while the forward results settle */
   for (int k = i; k < MD * LD; k += LPE) Lm[k] = 0.0f;
   if (i < nd) vec[DV_QD * MD + i] = E[m->lay.qd + i];
@@ -548,26 +565,25 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
   }
   DPHASE();
 #undef DPHASE
-  /* ---- broadphase of this block's envs (msk_broadphase.h), the whole wavefront on one env at a time.  It reads the body poses
-   * in the env record (this kernel rewrites the link frames with the bits they already hold) and nothing else of the above. */
-  if (m->np > 0) {
-    __shared__ float bp_aabb[MSK_MAX_SHAPES][6];
-    __shared__ float bp_obb[MSK_MAX_SHAPES][13];   /* rotation columns (9), local half extents (3); odd stride: no bank conflicts */
-    if (blk == 0 && threadIdx.x < MSK_SOLVE_CLASSES) st.cls_count[threadIdx.x] = 0;   /* this substep's solver lists (filled by the narrowphase) */
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   /* the other half-wave's stores to its env record */
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll 1
-    for (int k = 0; k < 64 / LPE; ++k) {
-      const int eb = blk * (64 / LPE) + k;
-      if (eb < m->N) broadphase_env(m, st, eb, bp_aabb, bp_obb);
-    }
-  }
 }
+/* 128 threads: wavefront 0 = the dynamics of the block's envs, wavefront 1 = their broadphase (after the frames are published).
+ * 64 threads (the host picks this when the 128-thread form would not be resident at once: more than ~3000 workgroups): the broadphase
+ * is the tail of the one wavefront, as in round 2. */
 template <int LPE, int MD>
-__global__ void __launch_bounds__(64) k_dynamics(const DModel* __restrict__ m, DState st) {
+__global__ void __launch_bounds__(128) k_dynamics(const DModel* __restrict__ m, DState st) {
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-  dynamics_block<LPE, MD>(m, st, lds_dyn, blockIdx.x);
+  if (threadIdx.x < 64) {
+    dynamics_block<LPE, MD>(m, st, lds_dyn, blockIdx.x);
+    if (blockDim.x == 64 && m->np > 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   /* the other half-wave's stores to its env record */
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      broadphase_block<LPE>(m, st, blockIdx.x);
+    }
+  } else {
+    __syncthreads();
+    if (m->np > 0) broadphase_block<LPE>(m, st, blockIdx.x);
+  }
 }
 
 #endif

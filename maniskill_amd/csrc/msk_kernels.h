@@ -657,12 +657,23 @@ MSK_DEV int multi_find(const GroupRef* __restrict__ refs, const int n, const int
   return g;
 }
 template <int LPE, int MD>
-__global__ void __launch_bounds__(64) k_multi_dynamics(const GroupRef* __restrict__ refs, const int n) {
+__global__ void __launch_bounds__(128) k_multi_dynamics(const GroupRef* __restrict__ refs, const int n) {
   extern __shared__ __attribute__((aligned(16))) float lds_md[];
   int blk;
   const GroupRef& r = refs[multi_find<MG_DYN>(refs, n, blockIdx.x, &blk)];
-  if (blk * (64 / LPE) >= r.m->N) return;
-  dynamics_block<LPE, MD>(r.m, r.st, lds_md, blk);
+  if (blk * (64 / LPE) >= r.m->N) return;   /* (the whole workgroup) */
+  if (threadIdx.x < 64) {
+    dynamics_block<LPE, MD>(r.m, r.st, lds_md, blk);
+    if (blockDim.x == 64 && r.m->np > 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      broadphase_block<LPE>(r.m, r.st, blk);
+    }
+  } else {
+    __syncthreads();
+    if (r.m->np > 0) broadphase_block<LPE>(r.m, r.st, blk);
+  }
 }
 template <int LPE>
 __global__ void __launch_bounds__(64) k_multi_kinematics(const GroupRef* __restrict__ refs, const int n) {

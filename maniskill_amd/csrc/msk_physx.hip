@@ -31,13 +31,23 @@ static void launch_kinematics(const DModel& m, const DModel* d_model, const DSta
   if (lpe == 32) hipLaunchKernelGGL(k_kinematics<32>, dim3((m.N + 1) / 2), dim3(64), lds, s, d_model, st);
   else hipLaunchKernelGGL(k_kinematics<64>, dim3(m.N), dim3(64), lds, s, d_model, st);
 }
+/* threads per workgroup of the dynamics launch: 128 (a second wavefront runs the broadphase beside the dynamics) while all workgroups of
+ * that form are resident at once (3 wavefronts per SIMD at the kernel's register count: 3072 on the 256 CUs), else 64 (broadphase as the
+ * tail of the one wavefront).  MI355X: 512 envs 44 -> 38 us per launch with 128; 4096 envs 56 us with 64 against 64 us with 128. */
+static int dyn_threads(int workgroups) {
+  static const int e = getenv("MSK_DYN_THREADS") ? atoi(getenv("MSK_DYN_THREADS")) : 0;   /* tuning aid */
+  if (e == 64 || e == 128) return e;
+  return 2 * workgroups <= 3072 ? 128 : 64;
+}
 static void launch_dynamics(const DModel& m, const DModel* d_model, const DState& st, hipStream_t s) {
   const int lpe = lanes_per_env(m), epb = 64 / lpe;
   const int md = dyn_md(m);
   const size_t lds = (size_t)DynLds(m.nb, md).total * sizeof(float) * epb;
-  if (lpe == 32) hipLaunchKernelGGL((k_dynamics<32, 16>), dim3((m.N + 1) / 2), dim3(64), lds, s, d_model, st);
-  else if (md == 16) hipLaunchKernelGGL((k_dynamics<64, 16>), dim3(m.N), dim3(64), lds, s, d_model, st);
-  else hipLaunchKernelGGL((k_dynamics<64, 32>), dim3(m.N), dim3(64), lds, s, d_model, st);
+  const int wgs = lpe == 32 ? (m.N + 1) / 2 : m.N;
+  const int th = dyn_threads(wgs);
+  if (lpe == 32) hipLaunchKernelGGL((k_dynamics<32, 16>), dim3(wgs), dim3(th), lds, s, d_model, st);
+  else if (md == 16) hipLaunchKernelGGL((k_dynamics<64, 16>), dim3(wgs), dim3(th), lds, s, d_model, st);
+  else hipLaunchKernelGGL((k_dynamics<64, 32>), dim3(wgs), dim3(th), lds, s, d_model, st);
 }
 
 struct msk_ctx {
@@ -843,9 +853,9 @@ static int batch_merged(msk_ctx* const* ctxs, int n, int op, uint32_t mask, hipS
   };
   switch (op) {
     case MSK_BATCH_STEP: {
-      if (lpe == 32) hipLaunchKernelGGL((k_multi_dynamics<32, 16>), dim3(mc.t_dyn), dim3(64), mc.lds_dyn, s, mc.d_refs, n);
-      else if (md == 16) hipLaunchKernelGGL((k_multi_dynamics<64, 16>), dim3(mc.t_dyn), dim3(64), mc.lds_dyn, s, mc.d_refs, n);
-      else hipLaunchKernelGGL((k_multi_dynamics<64, 32>), dim3(mc.t_dyn), dim3(64), mc.lds_dyn, s, mc.d_refs, n);
+      if (lpe == 32) hipLaunchKernelGGL((k_multi_dynamics<32, 16>), dim3(mc.t_dyn), dim3(dyn_threads(mc.t_dyn)), mc.lds_dyn, s, mc.d_refs, n);
+      else if (md == 16) hipLaunchKernelGGL((k_multi_dynamics<64, 16>), dim3(mc.t_dyn), dim3(dyn_threads(mc.t_dyn)), mc.lds_dyn, s, mc.d_refs, n);
+      else hipLaunchKernelGGL((k_multi_dynamics<64, 32>), dim3(mc.t_dyn), dim3(dyn_threads(mc.t_dyn)), mc.lds_dyn, s, mc.d_refs, n);
       hipLaunchKernelGGL(k_multi_narrowphase, dim3(mc.t_np), dim3(64), 0, s, mc.d_refs, n);
       if (G == 16) { auto k0 = k_multi_csolve<16, 16>; hipLaunchKernelGGL(k0, dim3(mc.t_cs), dim3(64), c->lds_solve, s, mc.d_refs, n); }
       else { auto k0 = k_multi_csolve<32, 32>; hipLaunchKernelGGL(k0, dim3(mc.t_cs), dim3(64), c->lds_solve, s, mc.d_refs, n); }
