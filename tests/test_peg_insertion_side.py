@@ -145,3 +145,29 @@ def test_epa_null_normal_reproducer_hip_vs_oracle(oracle_factory):
             sg, sc = gpu.get_state().cpu(), cpu.get_state()
             assert torch.isfinite(sg).all() and torch.isfinite(sc).all()
             assert torch.allclose(sg, sc, rtol=1e-4, atol=1e-5), (k, float((sg - sc).abs().max()))
+
+
+@pytest.mark.gpu
+def test_hip_vs_oracle_at_config4_scale(oracle_factory):
+    """BASELINE config 4's per-GPU share: 2048 PegInsertionSide-v1 envs (per-env peg and hole sizes) x 100 control steps of random actions
+    on HIP; the oracle runs the first 256 of them (same global seeds, sizes and grid cells).  States within 1e-4 relative, contact counts
+    and contact-pair ids equal, no solver scheduling flags (contact overflow -- arms ploughing through peg and box -- is part of the
+    contract and happens on both sides alike)."""
+    n, m, steps = 2048, 256, 100
+    gpu = PegInsertionSideEnv(num_envs=n, device="cuda:0", fused=False)
+    cpu = PegInsertionSideEnv(num_envs=m, px_factory=oracle_factory, env_index_offset=0, total_envs=n)
+    og, _ = gpu.reset(seed=2022); oc, _ = cpu.reset(seed=2022)
+    assert torch.allclose(og[:m].cpu(), oc, atol=2e-6)
+    gen = torch.Generator().manual_seed(4)
+    for t in range(steps):
+        a = 2 * torch.rand(n, 8, generator=gen) - 1
+        og, rg, *_ = gpu.step(a.to("cuda:0"))
+        oc, rc, *_ = cpu.step(a[:m])
+        assert torch.isfinite(og).all() and torch.isfinite(oc).all(), t
+        if t % 10 == 9:
+            sg, sc = gpu.get_state()[:m].cpu(), cpu.get_state()
+            assert torch.allclose(sg, sc, rtol=1e-4, atol=1e-5), (t, float((sg - sc).abs().max()))
+            assert np.array_equal(gpu.px.get_env_contact_counts()[:m], cpu.px.get_env_contact_counts()), t
+            for e in (0, 100, 255):
+                assert np.array_equal(gpu.px.get_contacts(e)[0], cpu.px.get_contacts(e)[0]), (t, e)
+    assert gpu.px.get_overflow() & 6 == 0

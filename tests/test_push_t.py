@@ -181,10 +181,10 @@ def test_reward_modes(oracle_factory):
 
 @pytest.mark.gpu
 def test_pictures_at_4096_envs_match_the_cpu_rasteriser_on_sampled_envs(oracle_factory):
-    """BASELINE config 3 at full size.  4096 PushT envs roll out on HIP; the simulation state of 64 sampled envs is
-    handed to a 64-env oracle instance, both take the picture: depth / segmentation planes and the raw PositionSegmentation texture
+    """BASELINE config 3 at full size.  4096 PushT envs roll out on HIP; the simulation state of 512 sampled envs (every eighth) is
+    handed to a 512-env oracle instance, both take the picture: depth / segmentation planes and the raw PositionSegmentation texture
     of those envs bit-exact."""
-    n, m = 4096, 64
+    n, m = 4096, 512
     gpu = PushTEnv(num_envs=n, device="cuda:0", obs_mode="depth+segmentation")
     gpu.reset(seed=2022)
     for _ in range(12):
@@ -193,7 +193,7 @@ def test_pictures_at_4096_envs_match_the_cpu_rasteriser_on_sampled_envs(oracle_f
     cpu = PushTEnv(num_envs=m, px_factory=oracle_factory, obs_mode="depth+segmentation")
     cpu.reset(seed=1)
     cpu.set_state(gpu.get_state().cpu()[idx])
-    assert torch.allclose(cpu.get_state(), gpu.get_state().cpu()[idx], atol=1e-6)
+    assert torch.allclose(cpu.get_state(), gpu.get_state().cpu()[idx], atol=2e-5)    # (p + offset) - offset through a different grid cell: fp32 spacing at 160 m
     # same bits in both simulators: pull the GPU's own state through set_state too, then compare what the cameras see
     sub = PushTEnv(num_envs=m, device="cuda:0", obs_mode="depth+segmentation")
     sub.reset(seed=1)
