@@ -21,11 +21,15 @@ Defaults follow the reference's protocol: 1000 steps after a seeded reset; the h
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline        dominant kernel of the substep, algorithmic bytes / HIP-event duration; ``traffic`` = PMC bytes of that
-                  kernel from the rocprofv3 passes committed for this round (profiles/r02_pmc_counters_4096.json carries the commit it
-                  was taken at), ``substep_traffic`` the sum over the substep's kernels
+                  kernel from the rocprofv3 passes committed for this round (profiles/r03_pmc_counters_4096.json) -- printed ONLY when the
+                  kernel sources are the ones the passes were taken on (the file carries a digest of maniskill_amd/csrc), else null;
+                  ``substep_traffic`` the sum over the substep's kernels
+  step_late       steps 800..1000 of the rollout (arms on the table: the contact-rich regime), whatever --steps is
   step_reset      the same rollout with a full reset every 200 steps
+  dropin          the reference's own host Python (mani_skill's BaseEnv / controllers / task code, unmodified) over the sapien shim on the
+                  same library, 4096 envs (tools/bench_reference_host.py; where the byte-compiled reference travelled: oracle/_ref), N=1 only
   cpu_baseline    the CPU oracle's physics loop (oracle/liborc.so orc_step, OpenMP over envs, no Python per env) on a bounded sample,
-                  N=1 only: kind "port" -- it is NOT PhysX
+                  N=1 only: kind "port" -- it is NOT PhysX; carries the container's CPU quota
 """
 from __future__ import annotations
 
@@ -49,6 +53,52 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (guides/MI355X_MICROARC
 ALG_BYTES_PER_ENV_SUBSTEP = 3056.0
 
 
+def csrc_digest() -> str:
+    """sha256 over the kernel sources (file names and contents, sorted): what a PMC summary must have been taken on to be quoted"""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "maniskill_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            with open(os.path.join(src, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_quota():
+    """cores this container may use: cgroup v2 cpu.max (or v1 cfs quota), None = unlimited"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+        return None if q == "max" else float(q) / float(p)
+    except OSError:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = float(f.read())
+        return None if q <= 0 else q / p
+    except OSError:
+        return None
+
+
+def dropin_bench(envs: int, steps: int):
+    """tools/bench_reference_host.py in a process of its own (the shim replaces the `sapien` module process-wide)"""
+    import subprocess
+    if not os.path.isdir(os.path.join(ROOT, "oracle", "_ref", "maniskill")) and not os.path.isdir("/root/reference/mani_skill"):
+        return {"error": "no reference build present (oracle/_ref/maniskill is made by __graft_entry__.build() where /root/reference exists)"}
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_reference_host.py"), "--envs", str(envs), "--steps", str(steps)],
+                           capture_output=True, text=True, timeout=900)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        d = json.loads(line[-1])
+        return {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "build_s", "host") if k in d} if "value" in d else d
+    except Exception as exc:   # noqa: BLE001 -- reported, never fatal for the metric
+        return {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
+
+
 def cpu_baseline(sample_envs: int, sample_steps: int):
     """Times the CPU oracle's physics on the host cores: the same PickCube scene, ``sample_steps`` control steps' worth of substeps
     through liborc's orc_step (one ctypes call per substep for ALL envs, OpenMP over envs inside): physics only, no per-env Python.
@@ -61,12 +111,16 @@ def cpu_baseline(sample_envs: int, sample_steps: int):
     from maniskill_amd.envs.pick_cube import PickCubeEnv
 
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cpu_quota()
+    # threads beyond the cgroup's CPU quota only take turns on the same cores (and OpenMP's barriers then spin against each other: the
+    # 256-thread run of round 2 was SLOWER than one thread): the many-thread run uses what the quota allows
+    many = avail if quota is None else max(1, min(avail, int(quota + 0.5)))
     torch.set_num_threads(1)
     env = PickCubeEnv(num_envs=sample_envs, px_factory=lambda tpl, n, cfg: OraclePhysxSystem(tpl, n, cfg))
     gomp = ctypes.CDLL("libgomp.so.1")          # the runtime liborc.so is linked against: one instance per process
     sub = env._sim_steps_per_control
     runs = []
-    for threads in ([1, avail] if avail > 1 else [1]):
+    for threads in ([1, many] if many > 1 else [1]):
         gomp.omp_set_num_threads(threads)
         env.reset(seed=2022)
         gen = torch.Generator().manual_seed(0)
@@ -86,7 +140,7 @@ def cpu_baseline(sample_envs: int, sample_steps: int):
                   + "; ".join(f"{t} thread{'s' if t > 1 else ''}: {v:.0f} env-steps/s in {d:.1f} s" for v, t, d in runs)
                   + f" ({1e6 * runs[0][2] / (sample_envs * sample_steps * sub):.0f} us per env substep on one thread); "
                   "the in-repo CPU restatement, not PhysX",
-        "threads_available": avail,
+        "threads_available": avail, "cpu_quota_cores": quota,
     }
 
 
@@ -185,6 +239,23 @@ def main():
             _gather.flush()
             sync()
             dt_reset = (time.perf_counter() - t1, n2)
+        # the contact-rich regime: steps 800 .. 1000 after a seeded reset, timed on their own whatever --steps is (a 20-step run only sees
+        # arms in the air)
+        dt_late = None
+        if not args.no_extras and not args.reset_every:
+            env.reset(seed=2022)
+            for _ in range(800):
+                out = env.step(2 * torch.rand(n_local, env.action_dim, device=dev) - 1)
+                gather(*out[:4])
+            _gather.flush()
+            sync()
+            t2 = time.perf_counter()
+            for _ in range(200):
+                out = env.step(2 * torch.rand(n_local, env.action_dim, device=dev) - 1)
+                gather(*out[:4])
+            _gather.flush()
+            sync()
+            dt_late = time.perf_counter() - t2
         if args.graph:   # a graph replay records no events: time the kernels on eager steps of the same rollout
             env.disable_step_graph()
             env.px.timing_enable(20 * substeps)
@@ -204,12 +275,14 @@ def main():
             torch.cuda.synchronize(dev)
             cam_us = ev[0].elapsed_time(ev[1]) / 20 * 1e3
 
-    t = torch.tensor([dt, dt_reset[0] if dt_reset else 0.0], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, dt_reset[0] if dt_reset else 0.0, dt_late or 0.0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t[0].item())
     if dt_reset:
         dt_reset = (float(t[1].item()), dt_reset[1])
+    if dt_late:
+        dt_late = float(t[2].item())
 
     if rank == 0:
         dom = max(kernels, key=lambda k: kernels[k][0])
@@ -220,13 +293,18 @@ def main():
         # HBM traffic of the dominant kernel: PMC FETCH_SIZE / WRITE_SIZE cannot be read from inside this process; the
         # value below comes from the committed rocprofv3 --pmc passes of this same command (profiles/, see its "source")
         traffic = substep_traffic = pmc_commit = None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_counters_4096.json")
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc_counters_4096.json")
+        pmc_note = "no PMC summary for this round (profiles/r03_pmc_counters_4096.json)"
         if args.envs == 4096 and world == 1 and args.env == "PickCube-v1" and os.path.exists(pmc):
             with open(pmc) as f:
                 doc = json.load(f)
-            traffic = doc["substep_groups"].get(dom, {}).get("hbm_bytes_per_launch")
-            substep_traffic = sum(g["hbm_bytes_per_launch"] for k, g in doc["substep_groups"].items() if k in kernels)
-            pmc_commit = doc.get("commit")
+            if doc.get("csrc_digest") == csrc_digest():   # taken on exactly these kernels: quotable
+                traffic = doc["substep_groups"].get(dom, {}).get("hbm_bytes_per_launch")
+                substep_traffic = sum(g["hbm_bytes_per_launch"] for k, g in doc["substep_groups"].items() if k in kernels)
+                pmc_commit = doc.get("commit")
+            else:
+                pmc_note = (f"profiles/r03_pmc_counters_4096.json was taken on other kernel sources (digest {doc.get('csrc_digest')}, now "
+                            f"{csrc_digest()}): not quoted")
         result = {
             "metric": f"env steps/sec (whole node), {args.envs} parallel {args.env} envs",
             "value": args.envs * args.steps / dt,
@@ -247,8 +325,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "substep_traffic": substep_traffic,
-                "traffic_source": (f"profiles/r02_pmc_counters_4096.json (rocprofv3 --pmc passes of this command at commit {pmc_commit}, "
-                                   "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch)") if traffic else None,
+                "traffic_source": (f"profiles/r03_pmc_counters_4096.json (rocprofv3 --pmc passes of this command at commit {pmc_commit}, on these "
+                                   "kernel sources; (2*FETCH_SIZE + WRITE_SIZE) KiB per launch)") if traffic else pmc_note,
                 "avg_kernel_us": avg_s * 1e6, "launches": launches,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_us": {k: v[0] / max(v[1], 1) * 1e3 for k, v in kernels.items()},
@@ -265,8 +343,13 @@ def main():
         if dt_reset:
             result["step_reset"] = {"value": args.envs * dt_reset[1] / dt_reset[0], "unit": "env-steps/s", "steps": dt_reset[1],
                                     "ms_per_step": dt_reset[0] / dt_reset[1] * 1e3, "what": "full reset every 200 steps inside the timed region"}
+        if dt_late:
+            result["step_late"] = {"value": args.envs * 200 / dt_late, "unit": "env-steps/s", "steps": 200, "ms_per_step": dt_late / 200 * 1e3,
+                                   "what": "steps 800..1000 of a seeded rollout under random actions (arms lying on the table: the contact-rich regime)"}
+        if world == 1 and not args.no_cpu_baseline and args.env == "PickCube-v1" and not camera_mode:
+            result["dropin"] = dropin_bench(4096, 100)
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(4096, 20)   # the metric's own env count: 16 envs per host thread on a 256-thread box
+            result["cpu_baseline"] = cpu_baseline(4096, 20)   # the metric's own env count
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -370,8 +370,12 @@ def cook_convex(path, scale=(1, 1, 1)):
     if key not in _cache:
         pts = np.concatenate([p["vertices"] for p in load_mesh_parts(path)])
         _cache[key] = np.round(reduce_hull(pts), 6)
-    v = (_cache[key] * sc).astype(np.float32)
-    return v, hull_faces(v)
+    kf = key + (tuple(float(x) for x in sc),)      # every sub-scene asks for the same file and scale again: cooked once
+    if kf not in _cache:
+        v = (_cache[key] * sc).astype(np.float32)
+        v.setflags(write=False)
+        _cache[kf] = (v, hull_faces(v))
+    return _cache[kf]
 
 
 def cook_multiple_convex(path, scale=(1, 1, 1)):

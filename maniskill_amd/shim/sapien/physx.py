@@ -347,7 +347,10 @@ class PhysxCollisionShapeConvexMesh(PhysxCollisionShape):
         return np.ascontiguousarray(self.vertices * self.scale, dtype=np.float32)
 
     def _mass_props(self):
-        return _mesh.mesh_mass(self._scaled_vertices, self._faces, self.density)
+        key = ("mesh_mass", hash(self.vertices.tobytes()), self.vertices.shape, tuple(float(x) for x in self.scale), float(self.density))
+        if key not in _mesh._cache:       # the same hull in every sub-scene
+            _mesh._cache[key] = _mesh.mesh_mass(self._scaled_vertices, self._faces, self.density)
+        return _mesh._cache[key]
 
 
 class PhysxCollisionShapeTriangleMesh(PhysxCollisionShape):

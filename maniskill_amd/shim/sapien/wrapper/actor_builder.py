@@ -262,9 +262,11 @@ class ActorBuilder:
                 shape.set_min_patch_radius(r.min_patch_radius)
                 component.attach(shape)
         if not self._auto_inertial and self.physx_body_type != "kinematic":
-            component.mass = self._mass
-            component.cmass_local_pose = self._cmass_local_pose
-            component.inertia = self._inertia
+            # all three at once: set one by one, `mass` alone would first freeze the shapes' own centre of mass and principal axes
+            # (an eigen-decomposition per link per sub-scene) only for the next two lines to overwrite them
+            component._mass = float(self._mass)
+            component._cmass_local_pose = Pose(self._cmass_local_pose.p, self._cmass_local_pose.q)
+            component._inertia = np.array(self._inertia, dtype=np.float32).reshape(3)
         component.name = self.name
         # loader-side data without a SAPIEN counterpart: the URDF's exact inertia tensor, SRDF-disabled partner links
         if hasattr(self, "_exact_inertial") and not self._auto_inertial:

@@ -36,6 +36,29 @@ def test_stacked_and_released_is_a_success(oracle_factory):
     assert not env.evaluate()["is_cubeA_on_cubeB"].any()
 
 
+def test_a_built_stack_stays_a_success_for_two_hundred_steps(oracle_factory):
+    """Task-level known answer: StackCube-v1's success is `is_cubeA_on_cubeB & is_cubeA_static & ~grasped` with the reference's
+    Actor.is_static(lin_thresh=1e-2, ang_thresh=0.5) (mani_skill/utils/structs/actor.py:220-227, envs/tasks/tabletop/stack_cube.py evaluate).
+    A stack released 0.2 mm above the base settles (one second) and then stays a success in every one of 200 control steps (1000 substeps): the
+    cube never leaves half the linear and a fifth of the angular threshold (bursts of 4 mm/s and 0.09 rad/s, typically 1e-4 and 2e-3) and
+    stays where it was put to 0.2 mm."""
+    env = StackCubeEnv(num_envs=16, px_factory=oracle_factory)
+    env.reset(seed=3)
+    b = env._rbd[:, env._b_cubeB, :7].clone()
+    env._rbd[:, env._b_cube, :3] = b[:, :3] + torch.tensor([0.0, 0.0, 0.0402])
+    env._rbd[:, env._b_cube, 3:7] = b[:, 3:7]
+    env.px.gpu_apply_all(); env.px.gpu_fetch_all()
+    for _ in range(20):
+        env.step(None)
+    p0 = env.cube_pose[:, :3].clone()
+    for t in range(200):
+        obs, r, term, trunc, info = env.step(None)
+        assert info["success"].all() and info["is_cubeA_static"].all(), t
+        v = env._rbd[:, env._b_cube, 7:13]
+        assert v[:, :3].norm(dim=1).max() < 0.5 * 1e-2 and v[:, 3:].norm(dim=1).max() < 0.2 * 0.5, (t, v)
+    assert (env.cube_pose[:, :3] - p0).abs().max() < 2e-4
+
+
 @pytest.mark.gpu
 def test_hip_matches_oracle_rollout(oracle_factory):
     n = 64

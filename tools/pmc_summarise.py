@@ -6,7 +6,7 @@ from collections import defaultdict
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "pmc")
-out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles", "r02_pmc_counters_4096.json")
+out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles", "r03_pmc_counters_4096.json")
 command = sys.argv[3] if len(sys.argv) > 3 else "python bench.py --steps 20 --warmup 40 --no-cpu-baseline --no-extras"
 commit = sys.argv[4] if len(sys.argv) > 4 else os.popen(f"git -C {root} rev-parse --short HEAD 2>/dev/null").read().strip()
 LAST = 100
@@ -30,6 +30,29 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         tail = [x for _, x in v[-LAST:]]
         kernels[k][ctr] = sum(tail) / len(tail)
         kernels[k]["launches_seen"] = len(v)
+# the occupancy pass (tools/pmc_collect.sh): several counters in one collection
+OCC = ("GRBM_GUI_ACTIVE", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")
+vals = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(src, "OCCUPANCY", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] in OCC:
+            vals[short(r["Kernel_Name"])][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+for k, per in vals.items():
+    occ = {}
+    for ctr, v in per.items():
+        v.sort()
+        tail = [x for _, x in v[-LAST:]]
+        occ[ctr] = sum(tail) / len(tail)
+    if occ.get("SQ_WAVES"):
+        occ["wave_quad_cycles_per_wave"] = occ.get("SQ_WAVE_CYCLES", 0.0) / occ["SQ_WAVES"]
+        occ["valu_insts_per_wave"] = occ.get("SQ_INSTS_VALU", 0.0) / occ["SQ_WAVES"]
+    if occ.get("SQ_WAVE_CYCLES"):
+        occ["issuing_fraction_of_wave_cycles"] = occ.get("SQ_ACTIVE_INST_ANY", 0.0) / occ["SQ_WAVE_CYCLES"]
+        occ["waiting_fraction_of_wave_cycles"] = occ.get("SQ_WAIT_ANY", 0.0) / occ["SQ_WAVE_CYCLES"]
+    if occ.get("GRBM_GUI_ACTIVE"):   # mean waves in flight = wave-cycles / kernel cycles (SQ_WAVE_CYCLES counts quad-cycles)
+        occ["mean_waves_in_flight"] = 4.0 * occ.get("SQ_WAVE_CYCLES", 0.0) / occ["GRBM_GUI_ACTIVE"]
+        occ["mean_waves_per_simd"] = occ["mean_waves_in_flight"] / 1024.0
+    kernels[k]["occupancy"] = occ
 for k, d in kernels.items():
     d["hbm_bytes_per_launch"] = (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0
 slots = {"k_dynamics": ["k_dynamics"], "k_collide": ["k_broadphase", "k_narrowphase", "k_classify"], "k_solve": ["k_csolve"],
@@ -39,8 +62,12 @@ for slot, names in slots.items():
     present = [n for n in names if n in kernels]
     if present:
         groups[slot] = {"kernels": present, "hbm_bytes_per_launch": sum(kernels[n]["hbm_bytes_per_launch"] for n in present)}
+sys.path.insert(0, root)
+from bench import csrc_digest  # noqa: E402  (bench.py quotes this file only for the kernel sources it was taken on)
+
 doc = {
     "commit": commit,
+    "csrc_digest": csrc_digest(),
     "source": f"rocprofv3 --pmc <counter> --kernel-trace -- {command} (tools/pmc_collect.sh: one pass per counter, MI355X); "
               f"mean over the last {LAST} launches of each kernel",
     "units": "FETCH_SIZE / WRITE_SIZE in KiB per launch as reported; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE doubled "
