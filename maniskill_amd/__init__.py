@@ -14,7 +14,7 @@ __version__ = "0.1.0"
 
 def make(env_id: str, **kwargs):
     """gym.make-style constructor of a batched env: ``maniskill_amd.make("PickCube-v1", num_envs=4096, device="cuda:0")``
-    (mani_skill/utils/registration.py:176-196).  Auto resets / metrics: the reference's own ManiSkillVectorEnv over the sapien shim."""
+    (mani_skill/utils/registration.py:176-196).  Auto resets / episode metrics: maniskill_amd.vector.ManiSkillVectorEnv."""
     from .envs import registered
     reg = registered()
     if env_id not in reg:

@@ -118,15 +118,58 @@ def make_sharded_env(env_id: str, total_envs: int, device_type: str = "cuda", px
     return env, gather, rank, world
 
 
-def make_sharded_pick_cube(total_envs: int, device_type: str = "cuda", px_factory=None, **kw):
-    """One PickCubeEnv shard per process.  Returns (env, gather, rank, world)."""
-    from .envs.pick_cube import PickCubeEnv
+class ShardedGymEnv:
+    """One shard of a registered ManiSkill task over the sapien shim (the drop-in path: the reference's own BaseEnv / controllers / task
+    code).  The reference runtime is single-device (mani_skill/envs/sapien_env.py:95-100); here every rank builds `gym.make(env_id,
+    num_envs=total/world)` for its contiguous range of the global env set, seeds env i of the GLOBAL set with seed + i (ManiSkill takes a
+    seed per env: BaseEnv.reset(seed=[...])) and lays its sub-scenes out on the global grid (shim: set_shard), so a rollout does not
+    depend on the number of ranks.  `step` returns what the wrapped env returns; `gather` all-gathers the flat state observation."""
 
+    def __init__(self, env, start, count, total, gather, rank, world):
+        self.env, self.start, self.num_envs, self.total_envs = env, start, count, total
+        self.gather, self.rank, self.world = gather, rank, world
+        self.unwrapped = env.unwrapped
+        self.device = env.unwrapped.device
+        self.action_space = env.action_space
+
+    def reset(self, seed=0, options=None):
+        seeds = [int(seed) + self.start + i for i in range(self.num_envs)]
+        return self.env.reset(seed=seeds, options=options)
+
+    def step(self, action):
+        return self.env.step(action)
+
+    def close(self):
+        self.env.close()
+
+
+def make_sharded_gym_env(env_id: str, total_envs: int, device_type: str = "cuda", reference_root: Optional[str] = None, backend=None, **gym_kw):
+    """Any registered ManiSkill task, sharded: -> ShardedGymEnv.  `backend`: a NativeLib to run the shim on instead of libmsk_physx.so
+    (the test-suite hands in the CPU oracle); `reference_root`: where the `mani_skill` package lives (default: importable already, or
+    MANISKILL_ROOT)."""
     rank, world, local = init_distributed(device_type)
     start, count = shard_range(total_envs, rank, world)
     assert total_envs % world == 0, "num_envs must divide evenly over the ranks"
-    device: Optional[str] = f"cuda:{local}" if device_type == "cuda" else None
-    env = PickCubeEnv(num_envs=count, device=device, env_index_offset=start, total_envs=total_envs,
-                      px_factory=px_factory, **kw)
-    gather = ObservationGather(count, env.obs_dim, world, env.device)
-    return env, gather, rank, world
+    from . import shim
+    shim.install(reference_root or os.environ.get("MANISKILL_ROOT"))
+    import sapien.physx as physx
+    from sapien import _system
+    if backend is not None:
+        physx._set_backend(backend, host_memory=True)
+    _system.set_shard(start, count, total_envs)
+    import gymnasium as gym
+    import mani_skill.envs  # noqa: F401  (registers the tasks)
+    if device_type == "cuda":
+        gym_kw.setdefault("sim_backend", f"physx_cuda:{local}" if local else "physx_cuda")
+    env = gym.make(env_id, num_envs=count, **gym_kw)
+    if start > 0:   # BaseEnv.__init__ builds the scene under the seeds 2022 + LOCAL index (sapien_env.py:327); tasks that draw per-env assets at
+        #             build time (a cabinet per sub-scene) get the ones of their GLOBAL index by reconfiguring once under those seeds
+        env.reset(seed=[2022 + start + i for i in range(count)], options=dict(reconfigure=True))
+    obs_dim = int(env.observation_space.shape[-1]) if getattr(env.observation_space, "shape", None) else 0
+    gather = ObservationGather(count, obs_dim, world, env.unwrapped.device) if obs_dim else None
+    return ShardedGymEnv(env, start, count, total_envs, gather, rank, world)
+
+
+def make_sharded_pick_cube(total_envs: int, device_type: str = "cuda", px_factory=None, **kw):
+    """make_sharded_env("PickCube-v1", ...): kept for callers of round 1."""
+    return make_sharded_env("PickCube-v1", total_envs, device_type=device_type, px_factory=px_factory, **kw)

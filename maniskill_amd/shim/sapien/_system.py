@@ -29,6 +29,16 @@ def _pose7(pose: Pose):
     return tuple(float(x) for x in pose._p) + tuple(float(x) for x in pose._q)
 
 
+# this process's shard of a larger env set (maniskill_amd.dist): global index of its first sub-scene, its sub-scene count, the total
+_SHARD = {"offset": 0, "local": None, "total": None}
+
+
+def set_shard(env_index_offset, local_envs, total_envs):
+    """None for total_envs switches the global layout off again."""
+    _SHARD.update(offset=int(env_index_offset), local=None if local_envs is None else int(local_envs), total=None if total_envs is None else int(total_envs))
+    _SHARD.pop("spacing", None)
+
+
 class _Handle3D:
     """cuda_articulation_link_incoming_joint_forces: (num_articulations, max_links, 6) view of the library's 2-D buffer."""
 
@@ -154,7 +164,24 @@ class PhysxSystem:
         return self._scene_idx[id(scene)]
 
     def set_scene_offset(self, scene, offset):
-        self._offsets[id(scene)] = np.array(offset, dtype=np.float32).reshape(3)
+        """ManiSkill lays its sub-scenes out on a square grid from the LOCAL sub-scene index (envs/sapien_env.py:1190-1208).  When this
+        process holds one shard of a larger env set (maniskill_amd.dist.make_sharded_gym_env -> set_shard), the k-th call gets the grid cell
+        of the GLOBAL index instead -- same formula, same spacing --, so that every sub-scene has the same offset (and the same fp32 rounding
+        of position + offset) whatever the partition: results do not depend on the number of ranks."""
+        off = np.array(offset, dtype=np.float32).reshape(3)
+        if _SHARD["total"] is not None and len(self._offsets) < _SHARD["local"]:
+            k = len(self._offsets)                   # sub-scenes register in index order
+            L_loc = int(np.ceil(np.sqrt(_SHARD["local"])))
+            x_loc, y_loc = k % L_loc - L_loc // 2, k // L_loc - L_loc // 2
+            if x_loc != 0:                           # the spacing ManiSkill used (sim_config.spacing), read off its own offset
+                _SHARD["spacing"] = float(off[0]) / x_loc
+            elif y_loc != 0:
+                _SHARD["spacing"] = float(off[1]) / y_loc
+            spacing = _SHARD.get("spacing", 5.0)     # (a one-env shard never shows it: SimConfig's default)
+            g = _SHARD["offset"] + k
+            L = int(np.ceil(np.sqrt(_SHARD["total"])))
+            off = np.array([(g % L - L // 2) * spacing, (g // L - L // 2) * spacing, off[2]], dtype=np.float32)
+        self._offsets[id(scene)] = off
 
     def get_scene_offset(self, scene):
         return self._offsets.get(id(scene), np.zeros(3, dtype=np.float32)).copy()

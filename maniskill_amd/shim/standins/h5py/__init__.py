@@ -5,6 +5,7 @@ reference's tests do: record, then load / replay).  ``maniskill_amd.shim.install
 real h5py always wins when it exists."""
 import os
 import pickle
+import warnings
 
 import numpy as np
 
@@ -183,6 +184,23 @@ def _load(node, name, parent):
     return g
 
 
+class _ArraysOnly(pickle.Unpickler):
+    """Files are trees of dicts / lists / strings / numbers / numpy arrays; anything else in the stream (a trajectory file from somewhere
+    else could name any callable) is refused instead of imported."""
+    _ALLOWED = {("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("numpy._core.numeric", "_frombuffer"),
+                ("numpy.core.numeric", "_frombuffer"), ("builtins", "bytearray"), ("builtins", "complex"), ("builtins", "set"), ("builtins", "frozenset"),
+                ("builtins", "slice"), ("collections", "OrderedDict")}
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"h5py stand-in: {module}.{name} does not belong in a trajectory file")
+
+
+warnings.warn("h5py is not installed: using maniskill_amd's stand-in, whose files are NOT HDF5 (readable by this stand-in only)", stacklevel=2)
+
+
 class File(Group):
     def __init__(self, name, mode="r", **kwds):
         super().__init__("/", None)
@@ -194,7 +212,7 @@ class File(Group):
                 head = f.read(len(_MAGIC))
                 if head != _MAGIC:
                     raise OSError(f"{self.filename}: not written by the h5py stand-in of this image (a real HDF5 file needs the real h5py)")
-                root = _load(pickle.load(f), "/", None)
+                root = _load(_ArraysOnly(f).load(), "/", None)
             self._items, self.attrs = root._items, root.attrs
             for v in self._items.values():
                 v.parent = self

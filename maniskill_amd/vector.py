@@ -1,0 +1,122 @@
+"""Vector-env front of the native batched envs (`maniskill_amd.make`): the behaviour RL code gets from the reference's
+`ManiSkillVectorEnv` (mani_skill/vector/wrappers/gymnasium.py:18-184), over `maniskill_amd.envs` instead of a `BaseEnv`.
+
+What a caller of the reference's wrapper relies on, and gets here:
+  * SAME-STEP auto reset of exactly the sub-scenes that finished (terminated | truncated): the step returns the first observation of
+    the new episode, `infos["final_observation"]` / `infos["final_info"]` hold what the finished episodes ended on and
+    `infos["_final_info"]` / `["_final_observation"]` / `["_elapsed_steps"]` the mask of the envs they apply to (gymnasium.py:161-177);
+  * `ignore_terminations`: the termination flags are cleared before they decide a reset, success / fail of the step are reported as
+    `success_at_end` / `fail_at_end` (gymnasium.py:149-156);
+  * `record_metrics`: `infos["episode"]` with return, episode_len, reward (return per step), success_once, fail_once (gymnasium.py:131-147),
+    cleared for the envs a reset touches (gymnasium.py:104-125).
+The envs underneath are already batched on the device, so there is nothing to vectorise: this class only keeps the episode book-keeping
+(three [num_envs] device tensors) and issues the masked reset.  No gymnasium import: the spaces are maniskill_amd.spaces' (gymnasium's
+own classes when that package is importable).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+
+def _copy_tree(x):
+    """Deep copy of an observation / info tree of tensors (the reset below overwrites the buffers the step's outputs may alias)."""
+    if isinstance(x, dict):
+        return {k: _copy_tree(v) for k, v in x.items()}
+    return x.clone() if torch.is_tensor(x) else x
+
+
+class _EpisodeBook:
+    """Per-env running metrics of the episode in progress."""
+
+    def __init__(self, n: int, device):
+        self.ret = torch.zeros(n, dtype=torch.float32, device=device)
+        self.success = torch.zeros(n, dtype=torch.bool, device=device)
+        self.fail = torch.zeros(n, dtype=torch.bool, device=device)
+
+    def clear(self, rows=None):
+        sel = slice(None) if rows is None else rows
+        self.ret[sel] = 0.0
+        self.success[sel] = False
+        self.fail[sel] = False
+
+    def account(self, reward, infos, elapsed, at_end: bool) -> dict:
+        self.ret += reward
+        out = {}
+        for key, seen in (("success", self.success), ("fail", self.fail)):
+            if key in infos:
+                seen |= infos[key].to(torch.bool)
+                out[key + "_once"] = seen.clone()
+                if at_end:
+                    out[key + "_at_end"] = infos[key].clone()
+        out["return"] = self.ret.clone()
+        out["episode_len"] = elapsed.clone()
+        out["reward"] = out["return"] / out["episode_len"]
+        return out
+
+
+class ManiSkillVectorEnv:
+    """`ManiSkillVectorEnv(env_or_id, num_envs=..., auto_reset=True, ignore_terminations=False, record_metrics=False, **make_kwargs)`."""
+
+    def __init__(self, env, num_envs: int = 1, auto_reset: bool = True, ignore_terminations: bool = False, record_metrics: bool = False, **kwargs):
+        if isinstance(env, str):
+            from . import make
+            env = make(env, num_envs=num_envs, **kwargs)
+        self._env = env
+        self.num_envs = int(env.num_envs)
+        self.auto_reset, self.ignore_terminations, self.record_metrics = bool(auto_reset), bool(ignore_terminations), bool(record_metrics)
+        self.single_action_space, self.action_space = env.single_action_space, env.action_space
+        self.single_observation_space, self.observation_space = env.single_observation_space, env.observation_space
+        self.metadata = dict(getattr(env, "metadata", {}) or {}, autoreset_mode="same_step")
+        self.spec = getattr(env, "spec", None)
+        self._book = _EpisodeBook(self.num_envs, env.device) if self.record_metrics else None
+        self._rows = torch.arange(self.num_envs, device=env.device)
+
+    # the reference's accessors
+    @property
+    def device(self):
+        return self._env.device
+
+    @property
+    def base_env(self):
+        return self._env
+
+    @property
+    def unwrapped(self):
+        return self._env
+
+    def reset(self, *, seed=None, options: Optional[dict] = None):
+        obs, info = self._env.reset(seed=seed, options=options)
+        if self._book is not None:
+            self._book.clear(None if not options or "env_idx" not in options else torch.as_tensor(options["env_idx"], device=self.device, dtype=torch.long))
+        return obs, info
+
+    def step(self, actions):
+        obs, rew, terminated, truncated, infos = self._env.step(actions)
+        if self._book is not None:
+            infos["episode"] = self._book.account(rew, infos, infos["elapsed_steps"] if "elapsed_steps" in infos else self._env._elapsed_steps,
+                                                  at_end=self.ignore_terminations)
+        if self.ignore_terminations:
+            terminated = torch.zeros_like(terminated)
+        done = terminated | truncated
+        if self.auto_reset and bool(done.any()):
+            last_obs, last_info = _copy_tree(obs), _copy_tree(infos)
+            obs, infos = self.reset(options=dict(env_idx=self._rows[done]))
+            infos["final_observation"], infos["final_info"] = last_obs, last_info
+            infos["_final_info"] = infos["_final_observation"] = infos["_elapsed_steps"] = done
+        return obs, rew, terminated, truncated, infos
+
+    def call(self, name: str, *args, **kwargs):
+        return getattr(self._env, name)(*args, **kwargs)
+
+    def get_attr(self, name: str):
+        raise RuntimeError("read attributes from .base_env (the reference's wrapper refuses this call as well: gymnasium.py:190-193)")
+
+    def render(self):
+        return self._env.render()
+
+    def close(self):
+        self._env.close()
+
+    close_extras = close

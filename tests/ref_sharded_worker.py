@@ -1,0 +1,65 @@
+"""Fresh-interpreter helper of tests/test_dist.py: one rank of a world-size-W gloo run of a registered ManiSkill task over the shim on the CPU
+oracle (maniskill_amd.dist.make_sharded_gym_env), or the single-process run of the same global env set (W = 1).
+    python tests/ref_sharded_worker.py <env_id> <total_envs> <steps> <out.pt> [<init.pt>]      (RANK / WORLD_SIZE / MASTER_* from the environment)
+init.pt: a file with the global env set's simulation state ("state0" of an earlier run) to start from.  The reference draws a reset's
+randomisation as ONE torch batch seeded by the first env's seed (envs/sapien_env.py reset -> torch.random.fork_rng), so what env i gets
+depends on the batch it is drawn in; the comparison across partitions therefore starts from a handed-over state."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+import ref_harness  # noqa: E402
+
+
+def main():
+    env_id, total, steps, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    ref = ref_harness.find_reference()
+    if env_id.startswith("OpenCabinet"):      # the synthetic PartNet-Mobility set (tools/make_synthetic_partnet.py), as in test_config5
+        assets = os.environ["MS_ASSET_DIR"]
+        if int(os.environ.get("RANK", "0")) == 0 and not os.path.isdir(os.path.join(assets, "data")):
+            meta = os.path.join(ref, "mani_skill", "assets", "partnet_mobility", "meta")
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_synthetic_partnet.py"), "--out", assets, "--max-drawers", "2", "--ids-from",
+                                   os.path.join(meta, "info_cabinet_drawer_train.json"), "--placeholder-ids-from",
+                                   os.path.join(meta, "info_cabinet_door_train.json")], stdout=subprocess.DEVNULL)
+    ref_harness.setup("oracle")            # the reference on sys.path, the oracle behind the shim, cpu tensors on the "GPU" code path
+    import torch
+    import torch.distributed as dist
+    from oracle_backend import oracle_lib
+    from maniskill_amd.dist import make_sharded_gym_env
+    torch.set_num_threads(1)
+    env = make_sharded_gym_env(env_id, total, device_type="cpu", reference_root=ref, backend=oracle_lib())
+    obs, _ = env.reset(seed=7)
+    base = env.unwrapped
+    state0 = {k: {n: t.clone() for n, t in d.items()} for k, d in base.get_state_dict().items()}
+    if len(sys.argv) > 5:       # the global run's post-reset state, this rank's rows; merged articulations are padded to the widest member of the
+        mine = {}               # batch (13 + 2 * max_dof columns: root pose and velocity, qpos, qvel), so the widths are cut to this shard's
+        for k, d in torch.load(sys.argv[5])["state0"].items():
+            mine[k] = {}
+            for n, g in d.items():
+                g, w = g[env.start:env.start + env.num_envs], state0[k][n].shape[1]
+                if k == "articulations" and g.shape[1] != w:
+                    mdg, md = (g.shape[1] - 13) // 2, (w - 13) // 2
+                    g = torch.cat([g[:, :13], g[:, 13:13 + md], g[:, 13 + mdg:13 + mdg + md]], dim=1)
+                mine[k][n] = g.clone()
+        base.set_state_dict(mine)
+    gen = torch.Generator().manual_seed(0)
+    adim = env.action_space.shape[-1]
+    states, all_obs, all_rew = [], [], []
+    for _ in range(steps):
+        a = 2 * torch.rand(total, adim, generator=gen) - 1          # the same global action stream on every rank
+        obs, rew, term, trunc, info = env.step(a[env.start:env.start + env.num_envs])
+        states.append(base.get_state().clone())
+        gathered = env.gather(obs, rew, term, trunc) if env.world > 1 else (obs, rew, term, trunc)
+        all_obs.append(gathered[0].clone()); all_rew.append(gathered[1].clone())
+    if env.rank == 0:
+        torch.save(dict(obs=torch.stack(all_obs), rew=torch.stack(all_rew), state_rank0=torch.stack(states), state0=state0, groups=len(base.scene.px._groups)), out)
+    if env.world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

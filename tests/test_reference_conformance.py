@@ -57,12 +57,21 @@ GPU_ONLY_NODES = [
 ]
 
 
+# Reference tests that reset WITHOUT a seed and assert something an unlucky draw breaks.  test_timelimits expects all 16 envs truncated at
+# step 50, but a goal drawn within the 2.5 cm success radius of the resting cube terminates that env at once (PickCube evaluate: placed and
+# robot static), the vector wrapper resets it and its clock restarts: about one run in twenty on any backend.  Those nodes get a second draw.
+UNSEEDED_NODES = {"tests/test_gpu_envs.py::test_timelimits"}
+
+
 def run_reference_tests(nodes, backend):
     """tests/ref_run_node.py in a subprocess (fresh interpreter: the shim / backend selection is process-global)."""
     cmd = [sys.executable, os.path.join(HERE, "ref_run_node.py"), backend, *nodes]
     import tempfile
-    with tempfile.TemporaryDirectory() as tmp:      # the reference's recorder tests write videos/ under the working directory
-        r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True, timeout=3000)
+    for attempt in range(2):
+        with tempfile.TemporaryDirectory() as tmp:      # the reference's recorder tests write videos/ under the working directory
+            r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True, timeout=3000)
+        if r.returncode == 0 or not set(nodes) <= UNSEEDED_NODES:
+            break
     return r.returncode, (r.stdout[-6000:] + r.stderr[-3000:])
 
 
