@@ -136,7 +136,7 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
   const CShape* A = &cA;
   const CShape* B = &cB;
 #ifdef MSK_PROFILE_PHASES
-  long long tq[5]; tq[0] = (long long)__builtin_readcyclecounter(); tq[1] = tq[2] = tq[0]; tq[3] = tq[4] = 0;
+  long long tq[6]; tq[0] = (long long)__builtin_readcyclecounter(); tq[1] = tq[2] = tq[5] = tq[0]; tq[3] = tq[4] = 0;
 #endif
   v3 opos[4], onrm = v3_make(0, 0, 1);
   float osep[4];
@@ -190,6 +190,9 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
         world_aabb(dB->aabb_c, hlb, &TB, &cb, &hb);
         /* third cull stage: each shape's vertices against the other's oriented local box (msk_collide.h verts_beyond_obb) */
         hit = !(verts_beyond_obb(cx, A, &TA, &TB, dB->aabb_c, hlb, margin) || verts_beyond_obb(cx, B, &TB, &TA, dA->aabb_c, hla, margin));
+#ifdef MSK_PROFILE_PHASES
+        tq[5] = (long long)__builtin_readcyclecounter();
+#endif
         if (hit) hit = gjk_epa(cx, A, &TA, B, &TB, ca, cb, margin, &nrm, &sep, &wa, &wb);
       }
 #ifdef MSK_PROFILE_PHASES
@@ -217,6 +220,7 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
       unsigned long long* x = (unsigned long long*)st.dbg + (size_t)m->N * 8 + 3 * 8;
       if (tq[3] > 0) { atomicAdd(&x[0], 1ull); atomicAdd(&x[1], (unsigned long long)tq[3]); atomicMax(&x[2], (unsigned long long)tq[3]); }
       atomicAdd(&x[3], (unsigned long long)tq[4]); atomicMax(&x[4], (unsigned long long)tq[4]);
+      atomicAdd(&x[5], (unsigned long long)(tq[5] - tq[0])); if (tq[4] > 0) atomicAdd(&x[6], 1ull);   /* cull stage cycles; items that entered GJK */
       const long long pc = tq[1] - tq[0];
       const int bk = pc < 25000 ? 0 : (pc < 50000 ? 1 : (pc < 100000 ? 2 : (pc < 150000 ? 3 : (pc < 200000 ? 4 : (pc < 300000 ? 5 : (pc < 400000 ? 6 : 7))))));
       atomicAdd(&x[8 + bk], 1ull);

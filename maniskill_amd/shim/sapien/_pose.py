@@ -47,6 +47,12 @@ def _quat2mat(q):
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], dtype=np.float64)
 
 
+_P0 = np.zeros(3, dtype=np.float64)
+_Q0 = np.array([1, 0, 0, 0], dtype=np.float64)
+_P0.setflags(write=False)
+_Q0.setflags(write=False)
+
+
 class Pose:
     __slots__ = ("_p", "_q")
 
@@ -56,9 +62,27 @@ class Pose:
             self._p = M[:3, 3].copy()
             self._q = _mat2quat(M[:3, :3])
             return
-        # kept in float64 (compositions of build-time frames stay exact to the last fp32 bit); .p / .q hand out float32 like SAPIEN
-        self._p = np.zeros(3, dtype=np.float64) if p is None else np.array(p, dtype=np.float64).reshape(3)
-        self._q = np.array([1, 0, 0, 0], dtype=np.float64) if q is None else np.array(q, dtype=np.float64).reshape(4)
+        # kept in float64 (compositions of build-time frames stay exact to the last fp32 bit); .p / .q hand out float32 like SAPIEN.
+        # The arrays are never written in place (setters replace them), so the defaults and copies of another Pose's arrays are shared.
+        if p is None:
+            self._p = _P0
+        elif type(p) is np.ndarray and p.dtype == np.float64 and p.shape == (3,):
+            self._p = p.copy()
+        else:
+            self._p = np.array(p, dtype=np.float64).reshape(3)
+        if q is None:
+            self._q = _Q0
+        elif type(q) is np.ndarray and q.dtype == np.float64 and q.shape == (4,):
+            self._q = q.copy()
+        else:
+            self._q = np.array(q, dtype=np.float64).reshape(4)
+
+    @classmethod
+    def _like(cls, other: "Pose"):
+        """A new Pose object on the same (immutable by convention) arrays."""
+        new = cls.__new__(cls)
+        new._p, new._q = other._p, other._q
+        return new
 
     # -- accessors ----------------------------------------------------------------------------------------------
     @property

@@ -17,6 +17,8 @@ import ctypes as C
 from typing import Optional
 
 import numpy as np
+import os
+
 import torch
 
 from ._pose import Pose
@@ -154,6 +156,18 @@ class PhysxSystem:
         self._cfg = dict(scene=dict(P._config["scene"]), body=dict(P._config["body"]), shape=dict(P._config["shape"]))
         self._engine = None
         self._body_rows = None
+        # Between here and the engine start, the caller builds one entity tree per sub-scene: millions of long-lived objects at 16k
+        # sub-scenes, which the cyclic collector re-traverses on every generation-2 pass (a quarter of the build time).  Collection is
+        # paused while the scene is built and the survivors are frozen out of later passes when the engine starts (_start_engine).
+        import gc
+        self._gc_paused = gc.isenabled() and os.environ.get("MSK_SHIM_KEEP_GC") is None
+        if self._gc_paused:
+            gc.disable()
+
+    def __del__(self):
+        if getattr(self, "_gc_paused", False):
+            import gc
+            gc.enable()
 
     # -- scenes ---------------------------------------------------------------------------------------------------
     def _register_scene(self, scene):
@@ -243,51 +257,32 @@ class PhysxSystem:
     # =============================================================================================================
     # compiler
     # =============================================================================================================
-    def _shape_sig(self, s, fold: Optional[Pose], relaxed: bool):
-        P = self._P
-        lp = s._local_pose if fold is None else fold * s._local_pose
-        mat = s.physical_material
-        base = (s._kind, tuple(s._groups), mat.static_friction, mat.dynamic_friction, mat.restitution, s.patch_radius,
-                s.min_patch_radius, s.contact_offset, s.rest_offset)
-        if isinstance(s, P.PhysxCollisionShapeBox):
-            if relaxed:
-                return base + (tuple(float(x) for x in lp._q),)
-            return base + (_pose7(lp), tuple(float(x) for x in s._half))
-        if isinstance(s, P.PhysxCollisionShapeConvexMesh):
-            h = getattr(s, "_vhash", None)
-            if h is None:
-                h = s._vhash = hash(s._scaled_vertices.tobytes())
-            return base + (_pose7(lp), h)
-        if isinstance(s, P.PhysxCollisionShapeSphere):
-            return base + (_pose7(lp), s.radius)
-        if isinstance(s, (P.PhysxCollisionShapeCapsule, P.PhysxCollisionShapeCylinder)):
-            return base + (_pose7(lp), s.radius, s.half_length)
-        if isinstance(s, P.PhysxCollisionShapePlane):
-            return base + (_pose7(lp),)
-        if isinstance(s, P.PhysxCollisionShapeTriangleMesh):
-            return base + (_pose7(lp), s.filename, tuple(float(x) for x in s.scale))
-        raise TypeError(type(s))
+    # Signatures are compared, never decoded: poses enter as the bytes of their float64 arrays (seven float() calls per pose were the bulk
+    # of a 16k-sub-scene compile).  One pass yields both forms: `relaxed` (what must agree for two sub-scenes to share a compiled
+    # template: box sizes, box positions and masses may differ inside a group) and `strict` (everything).
+    @staticmethod
+    def _pose_key(pose: Pose):
+        return pose._p.tobytes() + pose._q.tobytes()
 
-    def _comp_sig(self, c, relaxed: bool):
+    def _comp_sig(self, c):
+        """-> (relaxed, strict) signature of a component"""
         P = self._P
         if isinstance(c, P.PhysxRigidStaticComponent):
             fold = c.entity._pose
-            shapes = tuple(self._shape_sig(s, fold, relaxed) for s in c.collision_shapes
-                           if not isinstance(s, P.PhysxCollisionShapePlane))     # planes are global, see _compile
-            return ("static", shapes)
-        shapes = tuple(self._shape_sig(s, None, relaxed) for s in c.collision_shapes)
-        if relaxed:
-            massp = ()
-        else:
-            m, com, I6 = c._mass_tensor()
-            massp = (m, tuple(com), tuple(I6))
-        common = (massp, c.linear_damping, c.angular_damping, bool(c.disable_gravity), shapes)
+            sh = [s._sig(fold) for s in c.collision_shapes if not isinstance(s, P.PhysxCollisionShapePlane)]   # planes are global, see _compile
+            return ("static", tuple(x[0] for x in sh)), ("static", tuple(x[1] for x in sh))
+        sh = [s._sig() for s in c.collision_shapes]
+        m, com, I6 = c._mass_tensor()
+        massp = (m, com.tobytes(), tuple(I6))
+        head = (c.linear_damping, c.angular_damping, bool(c.disable_gravity))
         if isinstance(c, P.PhysxArticulationLinkComponent):
             j = c.joint
-            return ("link", c.index, -1 if c.parent is None else c.parent.index, j._type, _pose7(j.pose_in_parent),
-                    _pose7(j.pose_in_child), tuple(j._limits.reshape(-1).tolist()), j.stiffness, j.damping, j.force_limit,
-                    j.drive_mode, j.friction, j._armature) + common
-        return ("kinematic" if c.kinematic else "dynamic", tuple(c.locked_motion_axes)) + common
+            head = ("link", c.index, -1 if c.parent is None else c.parent.index, j._type, self._pose_key(j.pose_in_parent),
+                    self._pose_key(j.pose_in_child), j._limits.tobytes(), j.stiffness, j.damping, j.force_limit,
+                    j.drive_mode, j.friction, j._armature) + head
+        else:
+            head = ("kinematic" if c.kinematic else "dynamic", tuple(c.locked_motion_axes)) + head
+        return head + (tuple(x[0] for x in sh),), head + (massp, tuple(x[1] for x in sh))
 
     def _compile(self):
         """Partition the sub-scenes into structural groups (same bodies, joints, meshes, materials, collision groups; box sizes and
@@ -298,8 +293,11 @@ class PhysxSystem:
             per_env[c._env].append(c)
         self._per_env, self._n_env = per_env, n_env
         groups, order = {}, []
+        self._strict_sig = []
         for e in range(n_env):
-            key = tuple(self._comp_sig(c, True) for c in per_env[e])
+            sigs = [self._comp_sig(c) for c in per_env[e]]
+            key = tuple(x[0] for x in sigs)
+            self._strict_sig.append(tuple(x[1] for x in sigs))
             if key not in groups:
                 groups[key] = []
                 order.append(key)
@@ -320,8 +318,8 @@ class PhysxSystem:
         per_env = [self._per_env[e] for e in envs]
         n_env = len(envs)
         env0 = per_env[0]
-        sig0 = tuple(self._comp_sig(c, False) for c in env0)
-        hetero = [e for e in range(1, n_env) if tuple(self._comp_sig(c, False) for c in per_env[e]) != sig0]
+        sig0 = self._strict_sig[envs[0]]
+        hetero = [e for e in range(1, n_env) if self._strict_sig[envs[e]] != sig0]
 
         # ---- global planes (a plane on a static actor of ANY sub-scene is one infinite plane of the whole PhysX scene;
         #      the reference therefore attaches it in the first sub-scene only, actor_builder.py:76-90) ---------------------
@@ -600,6 +598,12 @@ class PhysxSystem:
                     ep = c.entity._pose
                     rows[self._pose_index(c), :7] = torch.as_tensor(np.concatenate([ep._p, ep._q]), dtype=torch.float32, device=rows.device)
         self._initialized = True
+        if self._gc_paused:
+            import gc
+            gc.collect()
+            gc.freeze()       # the entity trees live as long as the scene: later collections need not walk them
+            gc.enable()
+            self._gc_paused = False
 
     # indices ------------------------------------------------------------------------------------------------------------
     def _pose_index(self, comp) -> int:

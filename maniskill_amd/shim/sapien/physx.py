@@ -134,6 +134,12 @@ class PhysxMaterial:
         self.restitution = float(v)
 
 
+_ZERO3F = np.zeros(3, dtype=np.float32)
+_ZERO3F.setflags(write=False)
+_FREE_LIMITS = np.array([[-np.inf, np.inf]], dtype=np.float32)
+_FREE_LIMITS.setflags(write=False)
+
+
 class PhysxCollisionShape:
     _kind = "shape"
 
@@ -172,6 +178,63 @@ class PhysxCollisionShape:
         b = self._body
         if b is not None and b._system is not None and b._system._initialized:
             raise RuntimeError("collision shapes cannot be changed after the simulation was initialised")
+
+    def __setattr__(self, k, v):
+        # the compiler's signature of the shape (_sig) is cached on it, the mass properties of the body it is attached to on the body:
+        # setting anything drops both
+        object.__setattr__(self, k, v)
+        d = self.__dict__
+        d.pop("_sig_cache", None)
+        b = d.get("_body")
+        if b is not None:
+            b.__dict__.pop("_mt_cache", None)
+
+    def _sig(self, fold=None):
+        """-> (relaxed, strict) signature for the scene compiler (_system._compile): what must agree for two sub-scenes to share a compiled
+        template (box sizes and positions may differ inside a group), and everything.  Compared, never decoded: poses enter as the bytes of
+        their float64 arrays.  `fold`: pose of the static entity the shape sits on (then nothing is cached)."""
+        if fold is None:
+            cached = self.__dict__.get("_sig_cache")
+            if cached is not None:
+                return cached
+        lp = self._local_pose if fold is None else fold * self._local_pose
+        mat = self.physical_material
+        base = (self._kind, tuple(self._groups), mat.static_friction, mat.dynamic_friction, mat.restitution, self.patch_radius,
+                self.min_patch_radius, self.contact_offset, self.rest_offset)
+        pk = lp._p.tobytes() + lp._q.tobytes()
+        kind = self._kind
+        if kind == "box":
+            out = (base + (lp._q.tobytes(),), base + (pk, self._half.tobytes()))
+        elif kind == "convex":
+            h = self.__dict__.get("_vhash")
+            if h is None:
+                h = hash(self._scaled_vertices.tobytes())
+                self.__dict__["_vhash"] = h
+            out = (base + (pk, h),) * 2
+        elif kind == "sphere":
+            out = (base + (pk, self.radius),) * 2
+        elif kind in ("capsule", "cylinder"):
+            out = (base + (pk, self.radius, self.half_length),) * 2
+        elif kind == "plane":
+            out = (base + (pk,),) * 2
+        elif kind == "trimesh":
+            out = (base + (pk, self.filename, np.asarray(self.scale, dtype=np.float64).tobytes()),) * 2
+        else:
+            raise TypeError(type(self))
+        if fold is None:
+            self.__dict__["_sig_cache"] = out
+        return out
+
+    def _clone(self):
+        """A shape equal to this one that shares its immutable parts (cooked vertices, faces, material): what a builder makes for sub-scene
+        k + 1 after it made this one for sub-scene k (building 16k sub-scenes spends its time in constructors otherwise)."""
+        new = object.__new__(type(self))
+        d = new.__dict__
+        d.update(self.__dict__)
+        d["_groups"] = list(self._groups)
+        d["_local_pose"] = Pose._like(self._local_pose)
+        d["_body"] = None
+        return new
 
     def get_collision_groups(self):
         return list(self._groups)
@@ -411,8 +474,9 @@ class PhysxRigidBaseComponent(PhysxBaseComponent):
     def attach(self, shape: PhysxCollisionShape):
         if self._system is not None and self._system._initialized:
             raise RuntimeError("cannot attach collision shapes after the simulation was initialised")
-        shape._body = self
+        shape.__dict__["_body"] = self          # (not through the shape's __setattr__: its cached signature stays valid)
         self.collision_shapes.append(shape)
+        self.__dict__.pop("_mt_cache", None)
         return self
 
     def get_collision_shapes(self):
@@ -470,8 +534,8 @@ class PhysxRigidBodyComponent(PhysxRigidBaseComponent):
         self.disable_gravity = False
         self.max_depenetration_velocity = 5.0   # accepted
         self.max_contact_impulse = 3.0e38       # accepted
-        self._lin_vel = np.zeros(3, dtype=np.float32)
-        self._ang_vel = np.zeros(3, dtype=np.float32)
+        self._lin_vel = _ZERO3F      # replaced, never written in place
+        self._ang_vel = _ZERO3F
 
     # -- mass properties --------------------------------------------------------------------------------------------
     @property
@@ -495,7 +559,16 @@ class PhysxRigidBodyComponent(PhysxRigidBaseComponent):
         return _mesh.combine(parts)
 
     def _mass_tensor(self):
-        """What the engine takes: (mass, com [3], inertia6 [ixx iyy izz ixy ixz iyz] about the com, body axes)."""
+        """What the engine takes: (mass, com [3], inertia6 [ixx iyy izz ixy ixz iyz] about the com, body axes).  Cached (the scene compiler
+        asks twice per body of every sub-scene); the setters of the mass properties, attach() and any attribute set on an attached shape
+        drop the cache (code that writes _mass / _cmass_local_pose / _inertia / _exact_inertial directly pops "_mt_cache" itself)."""
+        mt = self.__dict__.get("_mt_cache")
+        if mt is None:
+            mt = self._mass_tensor_now()
+            self.__dict__["_mt_cache"] = mt
+        return mt
+
+    def _mass_tensor_now(self):
         ex = getattr(self, "_exact_inertial", None)
         if ex is not None and self._mass is not None and float(self._mass) == float(ex[0]):
             m, c, I = ex
@@ -530,6 +603,7 @@ class PhysxRigidBodyComponent(PhysxRigidBaseComponent):
         elif self._inertia is not None and self._mass > 0:
             self._inertia = np.asarray(self._inertia, dtype=np.float32) * (float(m) / float(self._mass))
         self._mass = float(m)
+        self.__dict__.pop("_mt_cache", None)
 
     @property
     def cmass_local_pose(self):
@@ -542,6 +616,7 @@ class PhysxRigidBodyComponent(PhysxRigidBaseComponent):
     def cmass_local_pose(self, pose):
         self._frozen_check()
         self._cmass_local_pose = Pose(pose.p, pose.q)
+        self.__dict__.pop("_mt_cache", None)
 
     def get_cmass_local_pose(self):
         return self.cmass_local_pose
@@ -559,6 +634,7 @@ class PhysxRigidBodyComponent(PhysxRigidBaseComponent):
     def inertia(self, v):
         self._frozen_check()
         self._inertia = np.array(v, dtype=np.float32).reshape(3)
+        self.__dict__.pop("_mt_cache", None)
 
     def get_inertia(self):
         return self.inertia
@@ -709,7 +785,7 @@ class PhysxArticulationJoint:
         self._type = "fixed" if parent_link is not None else "undefined"
         self.pose_in_child = Pose()
         self.pose_in_parent = Pose()
-        self._limits = np.array([[-np.inf, np.inf]], dtype=np.float32)
+        self._limits = _FREE_LIMITS  # replaced, never written in place
         self.stiffness, self.damping, self.force_limit, self.drive_mode = 0.0, 0.0, 3.4028234663852886e38, "force"
         self.friction = 0.0
         self._armature = 0.0

@@ -222,19 +222,16 @@ class ActorBuilder:
             component.attach(shape)
         return component
 
-    def build_physx_component(self, link_parent=None):
-        """Plain-SAPIEN version (ManiSkill overrides it, actor_builder.py:57-164)."""
-        if self.physx_body_type == "dynamic":
-            component = physx.PhysxRigidDynamicComponent()
-        elif self.physx_body_type == "kinematic":
-            component = physx.PhysxRigidDynamicComponent()
-            component.kinematic = True
-        elif self.physx_body_type == "static":
-            component = physx.PhysxRigidStaticComponent()
-        elif self.physx_body_type == "link":
-            component = physx.PhysxArticulationLinkComponent(link_parent)
-        else:
-            raise RuntimeError(f"invalid physx body type [{self.physx_body_type}]")
+    def _collision_prototypes(self):
+        """The shapes the collision records describe, constructed once per (records, collision groups) and cloned per sub-scene: ManiSkill
+        calls build_physx_component once per sub-scene on the same builder (utils/building/articulation_builder.py:65-113)."""
+        fp = (tuple(self.collision_groups), id(physx.get_default_material()),
+              tuple((r.type, r.filename, np.asarray(r.scale, dtype=np.float64).tobytes(), r.radius, r.length, r.density, r.patch_radius,
+                     r.min_patch_radius, id(r.material), r.pose._p.tobytes(), r.pose._q.tobytes()) for r in self.collision_records))
+        cached = self.__dict__.get("_proto_cache")
+        if cached is not None and cached[0] == fp:
+            return cached[1]
+        protos = []
         for r in self.collision_records:
             if r.type == "plane":
                 shapes = [physx.PhysxCollisionShapePlane(material=r.material)]
@@ -260,7 +257,26 @@ class ActorBuilder:
                 shape.set_density(r.density)
                 shape.set_patch_radius(r.patch_radius)
                 shape.set_min_patch_radius(r.min_patch_radius)
-                component.attach(shape)
+                shape._sig()             # cached on the prototype, inherited by its clones
+                protos.append(shape)
+        self.__dict__["_proto_cache"] = (fp, protos)
+        return protos
+
+    def build_physx_component(self, link_parent=None):
+        """Plain-SAPIEN version (ManiSkill overrides it, actor_builder.py:57-164)."""
+        if self.physx_body_type == "dynamic":
+            component = physx.PhysxRigidDynamicComponent()
+        elif self.physx_body_type == "kinematic":
+            component = physx.PhysxRigidDynamicComponent()
+            component.kinematic = True
+        elif self.physx_body_type == "static":
+            component = physx.PhysxRigidStaticComponent()
+        elif self.physx_body_type == "link":
+            component = physx.PhysxArticulationLinkComponent(link_parent)
+        else:
+            raise RuntimeError(f"invalid physx body type [{self.physx_body_type}]")
+        for proto in self._collision_prototypes():
+            component.attach(proto._clone())
         if not self._auto_inertial and self.physx_body_type != "kinematic":
             # all three at once: set one by one, `mass` alone would first freeze the shapes' own centre of mass and principal axes
             # (an eigen-decomposition per link per sub-scene) only for the next two lines to overwrite them
@@ -271,6 +287,22 @@ class ActorBuilder:
         # loader-side data without a SAPIEN counterpart: the URDF's exact inertia tensor, SRDF-disabled partner links
         if hasattr(self, "_exact_inertial") and not self._auto_inertial:
             component._exact_inertial = self._exact_inertial
+        component.__dict__.pop("_mt_cache", None)
+        if not self._auto_inertial and self.physx_body_type != "kinematic":
+            # what the engine takes for these three is the same for every sub-scene this builder is built into: worked out once
+            key = (component._mass, component._cmass_local_pose._p.tobytes(), component._cmass_local_pose._q.tobytes(),
+                   component._inertia.tobytes(), id(getattr(self, "_exact_inertial", None)))
+            mc = self.__dict__.get("_mt_proto")
+            if mc is None or mc[0] != key:
+                mc = self.__dict__["_mt_proto"] = (key, component._mass_tensor())
+            component.__dict__["_mt_cache"] = mc[1]
+        elif self.physx_body_type != "kinematic":
+            # mass properties from the shapes' densities: the shapes are clones of this builder's prototypes, one evaluation serves them all
+            key = self.__dict__["_proto_cache"][0]
+            mc = self.__dict__.get("_mt_proto")
+            if mc is None or mc[0] != key:
+                mc = self.__dict__["_mt_proto"] = (key, component._mass_tensor())
+            component.__dict__["_mt_cache"] = mc[1]
         if hasattr(self, "_srdf_disabled"):
             component._srdf_disabled = set(self._srdf_disabled)
         return component

@@ -37,7 +37,7 @@ def np_report(tag, launches):
     x = out[n * 8 + 24:n * 8 + 24 + 16]
     items = max(d[2, 0], 1)
     print(tag, f"hull items: through EPA {x[0]/launches:.1f}/launch, EPA cycles mean {x[1]/max(x[0],1):.0f} max {x[2]}; GJK iterations mean {x[3]/items:.2f} max {x[4]}; "
-          f"primary histogram (<25k <50k <100k <150k <200k <300k <400k more) per launch {[round(float(v)/launches, 1) for v in x[8:16]]}")
+          f"cull stage mean {x[5]/items:.0f} cycles, items into GJK {x[6]/launches:.1f}/launch; primary histogram (<25k <50k <100k <150k <200k <300k <400k more) per launch {[round(float(v)/launches, 1) for v in x[8:16]]}")
 for _ in range(3): env.step(torch.zeros(n, 8, device="cuda:0"))
 report("zero  ")
 for _ in range(60): env.step(2 * torch.rand(n, 8, device="cuda:0") - 1)
