@@ -66,10 +66,10 @@ typedef struct msk_config {
   int32_t solver_velocity_iterations;
   float contact_offset;       /* per shape; a pair generates contacts below offA+offB  */
   float rest_offset;
-  float bounce_threshold;     /* accepted; restitution is 0 in every scoped task       */
-  float sleep_threshold;      /* accepted; sleeping not modelled                       */
+  float bounce_threshold;     /* a normal row approaching faster than this rebounds with the pair's restitution */
+  float sleep_threshold;      /* accepted, NOT modelled (bodies never sleep): noted in msk_warnings()          */
   int32_t enable_tgs;         /* must be 1                                             */
-  int32_t enable_pcm;         /* accepted                                              */
+  int32_t enable_pcm;         /* accepted, no effect (manifolds are generated one-shot every step): 0 is noted in msk_warnings() */
   int32_t reserved[6];
 } msk_config;
 
@@ -79,6 +79,11 @@ msk_ctx* msk_create(int hip_device, const msk_config* cfg);
 /* scene teardown (sapien_env.py:1232-1243) */
 void msk_destroy(msk_ctx* ctx);
 const char* msk_last_error(msk_ctx* ctx);
+/* Parameters this backend accepted without modelling them, one per line ("" if none): nothing handed over the ABI is dropped
+ * silently.  Today: sleep_threshold > 0 (SAPIEN puts bodies slower than it to sleep; here every body is simulated every step) and
+ * enable_pcm = 0.  Everything else the ABI takes -- static / dynamic friction, restitution, patch radii, joint friction and
+ * armature, drive modes and force limits, dampings -- is part of the simulation. */
+const char* msk_warnings(msk_ctx* ctx);
 
 /* ---- template build phase (host only; before msk_finalize) ------------------------ */
 /* PhysxArticulation creation via ArticulationBuilder.build (building/articulation_builder.py:114).

@@ -30,7 +30,7 @@ EXPORTS = [
     "fetch", "update_kinematics", "step", "query_create_pairs", "query_create_bodies", "query_buffer", "query_run",
     "get_sizes", "get_contacts", "get_env_contact_counts", "timing_enable", "timing_read",
     "set_solver_classes", "get_solver_class_counts", "declare_env_box", "declare_env_mass", "set_env_boxes", "set_env_masses",
-    "bind_buffers", "batch", "set_articulation_floating",
+    "bind_buffers", "batch", "set_articulation_floating", "warnings",
 ]
 # include/msk_render.h — camera pipeline (both libraries)
 RENDER_EXPORTS = ["render_add_mesh", "render_set_base_color", "render_bind_env_box", "render_set_lights", "render_finalize", "camera_create", "camera_buffer",
@@ -106,6 +106,7 @@ class NativeLib:
             "create": (vp, [i32, C.POINTER(MskConfig)]),
             "destroy": (None, [vp]),
             "last_error": (C.c_char_p, [vp]),
+            "warnings": (C.c_char_p, [vp]),
             "add_articulation": (i32, [vp, fp]),
             "add_link": (i32, [vp, i32, i32, i32, fp, fp, f32, f32, f32, fp, fp, i32, f32, f32]),
             "set_drive": (i32, [vp, i32, f32, f32, f32, i32]),

@@ -93,6 +93,7 @@ struct msk_ctx {
   std::vector<hipEvent_t> tev;
   int t_cap, t_n;
   char err[256];
+  char warn[512];
 };
 
 static int fail(msk_ctx* c, int code, const char* msg) {
@@ -161,6 +162,11 @@ MSK_API msk_ctx* msk_create(int hip_device, const msk_config* cfg) {
   c->has_pickcube = false;
   c->rmodel = nullptr; c->d_rmodel = nullptr; c->render_finalized = false; c->ncams = 0;
   c->err[0] = 0;
+  c->warn[0] = 0;
+  if (cfg->sleep_threshold > 0.0f)
+    snprintf(c->warn + strlen(c->warn), sizeof(c->warn) - strlen(c->warn), "sleep_threshold=%g accepted, not modelled: bodies never sleep\n", cfg->sleep_threshold);
+  if (!cfg->enable_pcm)
+    snprintf(c->warn + strlen(c->warn), sizeof(c->warn) - strlen(c->warn), "enable_pcm=0 accepted, no effect: contact manifolds are generated one-shot every step\n");
   return c;
 }
 
@@ -176,6 +182,7 @@ MSK_API void msk_destroy(msk_ctx* c) {
 }
 
 MSK_API const char* msk_last_error(msk_ctx* c) { return c ? c->err : "null context"; }
+MSK_API const char* msk_warnings(msk_ctx* c) { return c ? c->warn : ""; }
 
 MSK_API int msk_add_articulation(msk_ctx* c, const float root_pose[7]) {
   if (c->finalized) return fail(c, MSK_ERR_INVALID, "add_articulation after finalize");

@@ -238,6 +238,9 @@ def batch_call(engines, op: int, mask: int = 0):
     e0.lib.check(e0.ctx, e0.lib.batch(arr[0], arr[1], op, mask, e0._stream()), "batch")
 
 
+_WARNED = set()
+
+
 class PhysxGpuSystem:
     """All sub-scenes of one process / one GPU (reference: one ``physx.PhysxGpuSystem``)."""
 
@@ -339,6 +342,13 @@ class PhysxGpuSystem:
         # (N * arts, max_links, 6) once viewed; Articulation.get_link_incoming_joint_forces (structs/articulation.py:596-620)
         self.cuda_articulation_link_incoming_joint_forces = handle(N.BUF_ART_LINK_JOINT_FORCES)
         self._initialized = True
+        # what the library accepted without modelling it (include/msk_physx.h msk_warnings): said once per process, kept on the system
+        self.backend_warnings = [w for w in (L.warnings(ctx) or b"").decode().splitlines() if w]
+        for w in self.backend_warnings:
+            if w not in _WARNED:
+                _WARNED.add(w)
+                import warnings
+                warnings.warn(f"maniskill_amd backend: {w}", stacklevel=2)
         # publish the initial state so that the torch-visible buffers are valid
         self.gpu_update_articulation_kinematics()
         self._fetch(N.FETCH_RIGID_DATA | N.FETCH_ART_QPOS | N.FETCH_ART_QVEL | N.FETCH_ART_QACC | N.FETCH_ART_TARGETS)

@@ -550,6 +550,13 @@ class PhysxSystem:
     def _start_engine(self, torch_device, lib, host_memory):
         from maniskill_amd import physx as E
         compiled = self._compile()
+        # body parameters SAPIEN takes and this backend has no counterpart for: said, not dropped silently
+        odd = [c for c in self._components if hasattr(c, "max_depenetration_velocity")
+               and (c.max_depenetration_velocity != 5.0 or c.max_contact_impulse < 3.0e38)]
+        if odd:
+            import warnings
+            warnings.warn(f"maniskill_amd backend: max_depenetration_velocity / max_contact_impulse of {len(odd)} bodies (e.g. {odd[0].name!r}) "
+                          "accepted, not modelled: penetration recovery is capped by the engine's own constant", stacklevel=3)
         sc, bc, shc = self._cfg["scene"], self._cfg["body"], self._cfg["shape"]
         cfg = E.SimConfig(sim_freq=1.0 / self._timestep, control_freq=1.0 / self._timestep, scene_config=E.SceneConfig(
             gravity=[float(g) for g in sc["gravity"]], bounce_threshold=sc["bounce_threshold"], sleep_threshold=bc["sleep_threshold"],

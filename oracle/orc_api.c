@@ -28,6 +28,10 @@ ORC_EXPORT orc_ctx* orc_create(int device, const msk_config* cfg) {
   c->cfg = *cfg;
   for (int i = 0; i < MSK_MAX_SHAPES; ++i) c->xs_slot[i] = -1;
   for (int i = 0; i < MSK_MAX_BODIES; ++i) c->xb_slot[i] = -1;
+  if (cfg->sleep_threshold > 0.0f)
+    snprintf(c->warn + strlen(c->warn), sizeof(c->warn) - strlen(c->warn), "sleep_threshold=%g accepted, not modelled: bodies never sleep\n", cfg->sleep_threshold);
+  if (!cfg->enable_pcm)
+    snprintf(c->warn + strlen(c->warn), sizeof(c->warn) - strlen(c->warn), "enable_pcm=0 accepted, no effect: contact manifolds are generated one-shot every step\n");
   return c;
 }
 
@@ -44,6 +48,7 @@ ORC_EXPORT void orc_destroy(orc_ctx* c) {
 }
 
 ORC_EXPORT const char* orc_last_error(orc_ctx* c) { return c->err; }
+ORC_EXPORT const char* orc_warnings(orc_ctx* c) { return c ? c->warn : ""; }
 
 ORC_EXPORT int orc_add_articulation(orc_ctx* c, const float root_pose[7]) {
   if (c->finalized) return fail(c, MSK_ERR_INVALID, "add_articulation after finalize");

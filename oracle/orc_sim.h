@@ -125,6 +125,7 @@ typedef struct orc_ctx {
   int any_overflow;  /* some env dropped contacts past MSK_MAX_CONTACTS since finalize */
   void* render;      /* orc_render.c: render geometry and cameras */
   char err[256];
+  char warn[512];
 } orc_ctx;
 
 /* orc_collide.c */

@@ -83,3 +83,15 @@ def test_cpu_device_is_rejected():
 
     with pytest.raises(RuntimeError, match="no CPU backend"):
         PickCubeEnv(num_envs=1, device="cpu")
+
+
+def test_accepted_but_unmodelled_parameters_are_reported(oracle_factory):
+    """msk_warnings (include/msk_physx.h): nothing handed over the ABI is dropped silently.  ManiSkill's default scene config has
+    sleep_threshold = 0.005 (utils/structs/types.py:35-67): accepted, and said to be without effect."""
+    import warnings
+    from maniskill_amd.envs.pick_cube import PickCubeEnv
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env = PickCubeEnv(num_envs=1, px_factory=oracle_factory)
+    assert any("sleep_threshold" in w and "not modelled" in w for w in env.px.backend_warnings)
+    assert not any("enable_pcm" in w for w in env.px.backend_warnings)
