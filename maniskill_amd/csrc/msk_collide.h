@@ -502,7 +502,7 @@ MSK_DEV int sat_box_box(const CShape* A, const pose* TA, const CShape* B, const 
 }
 
 /* ---- GJK / EPA ------------------------------------------------------------------------ */
-typedef struct { v3 w, a, b; } mvert;
+typedef struct { v3 w, a, b; int id; } mvert;   /* id: the two vertex numbers it is made of, ia | ib << 8 (GJK's simplex cache) */
 
 /* Support point of the Minkowski difference A - B in direction d.  The two support scans are independent chains: written out side
  * by side and branch-free (a box enters its scan with zero vertices and takes the sign formula), so the scheduler interleaves them --
@@ -533,6 +533,18 @@ MSK_DEV mvert msupport(const CCtx& m, const CShape* A, const pose* TA, const CSh
   mvert r;
   r.a = pose_apply(*TA, pa);
   r.b = pose_apply(*TB, pb);
+  r.w = v3_sub(r.a, r.b);
+  const int ka = boxa ? ((dla.x >= 0.0f ? 1 : 0) | (dla.y >= 0.0f ? 2 : 0) | (dla.z >= 0.0f ? 4 : 0)) : ia;
+  const int kb = boxb ? ((dlb.x >= 0.0f ? 1 : 0) | (dlb.y >= 0.0f ? 2 : 0) | (dlb.z >= 0.0f ? 4 : 0)) : ib;
+  r.id = ka | (kb << 8);
+  return r;
+}
+/* the same point from its two vertex numbers (a cached simplex, rebuilt under this step's poses: oracle mvert_of) */
+MSK_DEV mvert mvert_of(const CCtx& m, const CShape* A, const pose* TA, const CShape* B, const pose* TB, const int id) {
+  mvert r;
+  r.id = id;
+  r.a = pose_apply(*TA, shape_vert(m, A, id & 63));
+  r.b = pose_apply(*TB, shape_vert(m, B, (id >> 8) & 63));
   r.w = v3_sub(r.a, r.b);
   return r;
 }
@@ -580,6 +592,7 @@ MSK_DEV v3 v3_sel(bool c, v3 a, v3 b) { return v3_make(c ? a.x : b.x, c ? a.y : 
 MSK_DEV mvert mv_sel(bool c, const mvert& a, const mvert& b) {
   mvert r;
   r.w = v3_sel(c, a.w, b.w); r.a = v3_sel(c, a.a, b.a); r.b = v3_sel(c, a.b, b.b);
+  r.id = c ? a.id : b.id;
   return r;
 }
 MSK_DEV mvert simplex_get(const Simplex& S, int i) { return mv_sel(i == 0, S.s0, mv_sel(i == 1, S.s1, mv_sel(i == 2, S.s2, S.s3))); }
@@ -863,8 +876,18 @@ MSK_DEV int epa(const CCtx& m, const CShape* A, const pose* TA, const CShape* B,
 }
 
 /* GJK distance + EPA. Returns 0 if farther apart than margin. n from B to A. */
+/* the simplex cache word of an (env, pair): count (3 bits) and four (ia, ib) pairs of 6 bits each -- the oracle's simplex_pack */
+MSK_DEV unsigned long long simplex_pack(const Simplex& S, const int n) {
+  unsigned long long w = (unsigned long long)n;
+  const int id[4] = {S.s0.id, S.s1.id, S.s2.id, S.s3.id};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < n) w |= ((unsigned long long)(id[i] & 63) << (4 + 12 * i)) | ((unsigned long long)((id[i] >> 8) & 63) << (10 + 12 * i));
+  return w;
+}
+
 MSK_DEV int gjk_epa(const CCtx& m, const CShape* A, const pose* TA, const CShape* B, const pose* TB, v3 ca, v3 cb, float margin,
-                   v3* n_out, float* sep_out, v3* wa, v3* wb) {
+                   v3* n_out, float* sep_out, v3* wa, v3* wb, unsigned long long* cache) {
   Simplex S;
   float bary[4] = {1, 0, 0, 0};
   int n = 0;
@@ -872,20 +895,37 @@ MSK_DEV int gjk_epa(const CCtx& m, const CShape* A, const pose* TA, const CShape
   margin += rsum;   /* distances below are between the cores */
   v3 d0 = v3_sub(ca, cb);
   if (v3_len2(d0) < 1e-12f) d0 = v3_make(1, 0, 0);
-  S.s0 = msupport(m, A, TA, B, TB, v3_neg(d0));
-  S.s1 = S.s0; S.s2 = S.s0; S.s3 = S.s0;
-  n = 1;
-  v3 v = S.s0.w;
-  float vv = v3_len2(v);
+  v3 v = v3_make(0, 0, 0);
+  float vv = -1.0f;
   int hit = 0;
-  for (int it = 0; it < ORC_GJK_ITERS; ++it) {
+  const unsigned long long cw = *cache;   /* (every lane of the group reads the same word) */
+  if (cw & 7ull) { /* warm start: last step's simplex under this step's poses, reduced to its part closest to the origin */
+    n = (int)(cw & 7ull);
+    S.s0 = mvert_of(m, A, TA, B, TB, (int)((cw >> 4) & 63ull) | ((int)((cw >> 10) & 63ull) << 8));
+    S.s1 = S.s0; S.s2 = S.s0; S.s3 = S.s0;
+    if (n > 1) S.s1 = mvert_of(m, A, TA, B, TB, (int)((cw >> 16) & 63ull) | ((int)((cw >> 22) & 63ull) << 8));
+    if (n > 2) S.s2 = mvert_of(m, A, TA, B, TB, (int)((cw >> 28) & 63ull) | ((int)((cw >> 34) & 63ull) << 8));
+    if (n > 3) S.s3 = mvert_of(m, A, TA, B, TB, (int)((cw >> 40) & 63ull) | ((int)((cw >> 46) & 63ull) << 8));
+    if (simplex_closest(S, &n, &v, bary, m.gl)) hit = 1;
+    vv = hit ? 0.0f : v3_len2(v);
+    if (!(vv >= 0.0f && vv < 3.0e38f)) { vv = -1.0f; hit = 0; }   /* a degenerate rebuild (NaN): cold start */
+  }
+  if (vv < 0.0f) {
+    S.s0 = msupport(m, A, TA, B, TB, v3_neg(d0));
+    S.s1 = S.s0; S.s2 = S.s0; S.s3 = S.s0;
+    n = 1;
+    v = S.s0.w;
+    vv = v3_len2(v);
+    bary[0] = 1; bary[1] = 0; bary[2] = 0; bary[3] = 0;
+  }
+  for (int it = 0; it < ORC_GJK_ITERS && !hit; ++it) {
     if (vv < 1e-10f) { hit = 1; break; }
 #ifdef MSK_PROFILE_PHASES
     m.gjk_iters++;
 #endif
     mvert w = msupport(m, A, TA, B, TB, v3_neg(v));
     float vw = v3_dot(v, w.w);
-    if (vw > 0.0f && vw * vw > margin * margin * vv) return 0; /* separated by more than margin */
+    if (vw > 0.0f && vw * vw > margin * margin * vv) { if (m.gl == 0) *cache = simplex_pack(S, n); return 0; } /* separated by more than margin */
     if (vv - vw <= 1e-6f * vv) break;                          /* converged */
     int dupl = 0;
 #pragma unroll
@@ -900,6 +940,7 @@ MSK_DEV int gjk_epa(const CCtx& m, const CShape* A, const pose* TA, const CShape
     v = nvv;
     vv = nvl;
   }
+  if (m.gl == 0) *cache = simplex_pack(S, n);
   if (!hit) {
     float dist = sqrtf(vv);
     if (dist > margin) return 0;

@@ -193,7 +193,7 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
 #ifdef MSK_PROFILE_PHASES
         tq[5] = (long long)__builtin_readcyclecounter();
 #endif
-        if (hit) hit = gjk_epa(cx, A, &TA, B, &TB, ca, cb, margin, &nrm, &sep, &wa, &wb);
+        if (hit) hit = gjk_epa(cx, A, &TA, B, &TB, ca, cb, margin, &nrm, &sep, &wa, &wb, st.gjk_cache + (size_t)e * m->npp + pi);
       }
 #ifdef MSK_PROFILE_PHASES
       tq[1] = (long long)__builtin_readcyclecounter();
@@ -465,7 +465,8 @@ MSK_DEV void apply_block(const DModel* __restrict__ m, const DState& st, const D
     }
   if (teleported) { /* no warm start across a teleport: replays from a state are reproducible */
     int* cnts = st.ct_cnt + (size_t)e * m->npp;
-    for (int p = 0; p < m->np; ++p) cnts[p] = 0;
+    unsigned long long* gc = st.gjk_cache + (size_t)e * m->npp;
+    for (int p = 0; p < m->np; ++p) { cnts[p] = 0; gc[p] = 0ull; }
     st.ct_total[e] = 0;
   }
 }

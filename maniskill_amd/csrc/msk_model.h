@@ -130,6 +130,7 @@ struct DState {
   unsigned *drv_mask;                          /* [N] bit d: the drive of joint d is a solver row in this substep */
   float *drv;                                  /* [N][G][4]: compliance 1 / g, velocity bias, impulse limit, pad */
   unsigned char *ct_slip;                      /* [N][npp] 1: the pair slides, its friction cone is the dynamic one (has_static only, else null) */
+  unsigned long long *gjk_cache;               /* [N][npp] the simplex GJK ended on last step for this (env, pair): count + four vertex-number pairs, 0 = none (msk_collide.h) */
   float *jforce;                               /* [N][nb][6] link incoming joint wrenches of the last step (njfric > 0 only, else null): k_link_forces */
 };
 

@@ -593,6 +593,7 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   ALLOC(st.env_ncontacts, N); ALLOC(st.env_overflow, 1); ALLOC(st.ct_total, N);
   ALLOC(st.drv_mask, N); ALLOC(st.drv, N * G * 4);
   if (m.has_static) ALLOC(st.ct_slip, N * m.npp);
+  ALLOC(st.gjk_cache, N * (size_t)(m.npp > 0 ? m.npp : 1));
   if (m.njfric > 0) ALLOC(st.jforce, N * (size_t)m.nb * 6);
   ALLOC(st.np_count, N * 4); ALLOC(st.np_items, N * NP_TYPES * (size_t)(m.np > 0 ? m.np : 1));
   ALLOC(st.hq_items, N * (size_t)(m.np > 0 ? m.np : 1)); ALLOC(st.hq_count, 1);

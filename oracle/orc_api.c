@@ -43,6 +43,7 @@ ORC_EXPORT void orc_destroy(orc_ctx* c) {
   free(c->xbody);
   for (int i = 0; i < MSK_BUF_COUNT; ++i) free((c->buf_bound && i <= MSK_BUF_RIGID_BODY_TORQUE) ? c->buf_own[i] : c->buf[i]);
   free(c->wrench);
+  free(c->gjk_cache);
   for (int i = 0; i < c->nqueries; ++i) { free(c->queries[i].pairs); free(c->queries[i].out); }
   free(c);
 }
@@ -307,6 +308,7 @@ ORC_EXPORT int orc_finalize(orc_ctx* c, int num_envs) {
   c->num_envs = num_envs;
   c->envs = (orc_env*)calloc((size_t)num_envs, sizeof(orc_env));
   c->offsets = (float*)calloc((size_t)num_envs * 3, sizeof(float));
+  if (c->npairs > 0) c->gjk_cache = (uint64_t*)calloc((size_t)num_envs * c->npairs, sizeof(uint64_t));
   /* per-env instance parameters start at the template's values */
   if (c->nxs > 0) c->xshape = (float*)calloc((size_t)num_envs * c->nxs * 8, sizeof(float));
   if (c->nxb > 0) c->xbody = (float*)calloc((size_t)num_envs * c->nxb * 8, sizeof(float));
@@ -427,7 +429,10 @@ ORC_EXPORT int orc_apply(orc_ctx* c, uint32_t mask, void* stream) {
         if (mask & MSK_APPLY_ART_TARGET_QPOS) env->qt[d] = art_row(c, MSK_BUF_ART_TARGET_QPOS, e, a)[j];
         if (mask & MSK_APPLY_ART_TARGET_QVEL) env->qdt[d] = art_row(c, MSK_BUF_ART_TARGET_QVEL, e, a)[j];
       }
-    if (teleported) env->ncontacts = 0; /* no warm start across a teleport: replays from a state are reproducible */
+    if (teleported) { /* no warm start across a teleport: replays from a state are reproducible */
+      env->ncontacts = 0;
+      if (c->gjk_cache) memset(c->gjk_cache + (size_t)e * c->npairs, 0, (size_t)c->npairs * sizeof(uint64_t));
+    }
   }
   return MSK_OK;
 }

@@ -58,13 +58,14 @@ static v3 shape_vert(const orc_shape* sh, int i) {
   return sh->verts[i];
 }
 
-/* support point (world) of a box / hull in world direction d */
-static v3 support(const orc_shape* sh, const pose* T, v3 d) {
+/* support point (world) of a box / hull in world direction d; *idx: which vertex it is (shape_vert's numbering) */
+static v3 support_idx(const orc_shape* sh, const pose* T, v3 d, int* idx) {
   v3 dl = quat_rotate_inv(T->q, d);
   v3 pl;
   if (sh->type == MSK_SHAPE_BOX) {
     pl = v3_make(dl.x >= 0.0f ? sh->par[0] : -sh->par[0], dl.y >= 0.0f ? sh->par[1] : -sh->par[1],
                  dl.z >= 0.0f ? sh->par[2] : -sh->par[2]);
+    *idx = (dl.x >= 0.0f ? 1 : 0) | (dl.y >= 0.0f ? 2 : 0) | (dl.z >= 0.0f ? 4 : 0);
   } else {
     int best = 0;
     float bd = v3_dot(sh->verts[0], dl);
@@ -73,9 +74,11 @@ static v3 support(const orc_shape* sh, const pose* T, v3 d) {
       if (di > bd) { bd = di; best = i; }
     }
     pl = sh->verts[best];
+    *idx = best;
   }
   return pose_apply(*T, pl);
 }
+static v3 support(const orc_shape* sh, const pose* T, v3 d) { int i; return support_idx(sh, T, d, &i); }
 
 static void world_aabb(const orc_shape* sh, const pose* T, v3* c, v3* h) {
   m33 R = quat_to_m33(T->q);
@@ -100,6 +103,28 @@ static int obb_separated(const orc_shape* A, const pose* TA, const orc_shape* B,
     if (fabsf(v3_dot(d, L)) > ra + rb + margin) return 1;
   }
   return 0;
+}
+
+/* Third-stage cull: are the vertices of V (a box or a rounded hull) farther than `margin` from the oriented box (centre c, half extents
+ * h, in the frame TO) along one of that box's face normals?  The box contains the other shape, so a gap along any of its three axes is
+ * a gap between the shapes.  Conservative by 1e-4 m, so what it drops GJK would have reported as separated beyond the margin; it is
+ * part of the contract all the same, because GJK keeps a per-pair simplex from step to step and must be run on the same pairs by
+ * oracle and HIP library alike (msk_collide.h verts_beyond_obb: the same arithmetic, min / max over the lanes). */
+static int verts_beyond_obb(const orc_shape* V, const pose* TV, const pose* TO, v3 c, v3 h, float margin) {
+  const quat qrel = quat_mul(quat_conj(TO->q), TV->q);
+  const v3 prel = v3_sub(quat_rotate_inv(TO->q, v3_sub(TV->p, TO->p)), c);
+  v3 lo = v3_make(3.0e38f, 3.0e38f, 3.0e38f), hi = v3_make(-3.0e38f, -3.0e38f, -3.0e38f);
+  const int nv = shape_nverts(V);
+  for (int i = 0; i < nv; ++i) {
+    const v3 w = v3_add(quat_rotate(qrel, shape_vert(V, i)), prel);
+    lo = v3_make(fminf(lo.x, w.x), fminf(lo.y, w.y), fminf(lo.z, w.z));
+    hi = v3_make(fmaxf(hi.x, w.x), fmaxf(hi.y, w.y), fmaxf(hi.z, w.z));
+  }
+  const float r = shape_rad(V) + margin + 1.0e-4f;
+  const float gx = fmaxf(lo.x - h.x, -h.x - hi.x);
+  const float gy = fmaxf(lo.y - h.y, -h.y - hi.y);
+  const float gz = fmaxf(lo.z - h.z, -h.z - hi.z);
+  return fmaxf(gx, fmaxf(gy, gz)) > r;
 }
 
 /* ---- manifold ------------------------------------------------------------------------ */
@@ -375,14 +400,33 @@ static int sat_box_box(const orc_shape* A, const pose* TA, const orc_shape* B, c
 }
 
 /* ---- GJK / EPA ------------------------------------------------------------------------ */
-typedef struct { v3 w, a, b; } mvert;
+#ifndef ORC_GJK_WARM
+#define ORC_GJK_WARM 1   /* start GJK from the simplex it ended on last step (4.5 -> 1.1 iterations per call on PickCube's hull pairs) */
+#endif
+typedef struct { v3 w, a, b; int ia, ib; } mvert;   /* a point of the Minkowski difference A - B and the two vertices it is made of */
 
 static mvert msupport(const orc_shape* A, const pose* TA, const orc_shape* B, const pose* TB, v3 d) {
   mvert r;
-  r.a = support(A, TA, d);
-  r.b = support(B, TB, v3_neg(d));
+  r.a = support_idx(A, TA, d, &r.ia);
+  r.b = support_idx(B, TB, v3_neg(d), &r.ib);
   r.w = v3_sub(r.a, r.b);
   return r;
+}
+/* the same point from its two vertex numbers (a cached simplex, rebuilt under this step's poses) */
+static mvert mvert_of(const orc_shape* A, const pose* TA, const orc_shape* B, const pose* TB, int ia, int ib) {
+  mvert r;
+  r.ia = ia; r.ib = ib;
+  r.a = pose_apply(*TA, shape_vert(A, ia));
+  r.b = pose_apply(*TB, shape_vert(B, ib));
+  r.w = v3_sub(r.a, r.b);
+  return r;
+}
+/* The simplex GJK ended on last step, per (env, candidate pair): count (3 bits, 0 = none) and up to four vertex-number pairs (6 bits
+ * each).  Any set of Minkowski-difference vertices is a valid start, so a stale entry costs iterations, never correctness. */
+static uint64_t simplex_pack(const mvert* s, int n) {
+  uint64_t w = (uint64_t)n;
+  for (int i = 0; i < n; ++i) w |= ((uint64_t)(s[i].ia & 63) << (4 + 12 * i)) | ((uint64_t)(s[i].ib & 63) << (10 + 12 * i));
+  return w;
 }
 
 /* closest point to the origin on triangle (p0,p1,p2); returns barycentrics and a mask of used vertices */
@@ -594,7 +638,7 @@ static int epa(const orc_shape* A, const pose* TA, const orc_shape* B, const pos
 
 /* GJK distance + EPA. Returns 0 if farther apart than margin. n from B to A. */
 static int gjk_epa(const orc_shape* A, const pose* TA, const orc_shape* B, const pose* TB, v3 ca, v3 cb, float margin,
-                   v3* n_out, float* sep_out, v3* wa, v3* wb) {
+                   v3* n_out, float* sep_out, v3* wa, v3* wb, uint64_t* cache) {
   mvert s[4];
   float bary[4] = {1, 0, 0, 0};
   int n = 0;
@@ -602,18 +646,30 @@ static int gjk_epa(const orc_shape* A, const pose* TA, const orc_shape* B, const
   margin += rsum;   /* distances below are between the cores */
   v3 d0 = v3_sub(ca, cb);
   if (v3_len2(d0) < 1e-12f) d0 = v3_make(1, 0, 0);
-  s[0] = msupport(A, TA, B, TB, v3_neg(d0));
-  n = 1;
-  v3 v = s[0].w;
-  float vv = v3_len2(v);
+  v3 v;
+  float vv = -1.0f;
   int hit = 0;
+  if (cache && (*cache & 7u)) { /* warm start: last step's simplex under this step's poses, reduced to its part closest to the origin */
+    n = (int)(*cache & 7u);
+    for (int i = 0; i < n; ++i) s[i] = mvert_of(A, TA, B, TB, (int)((*cache >> (4 + 12 * i)) & 63u), (int)((*cache >> (10 + 12 * i)) & 63u));
+    if (simplex_closest(s, &n, &v, bary)) hit = 1;
+    vv = hit ? 0.0f : v3_len2(v);
+    if (!(vv >= 0.0f && vv < 3.0e38f)) { vv = -1.0f; hit = 0; }   /* a degenerate rebuild (NaN): cold start */
+  }
+  if (vv < 0.0f) {
+    s[0] = msupport(A, TA, B, TB, v3_neg(d0));
+    n = 1;
+    v = s[0].w;
+    vv = v3_len2(v);
+    bary[0] = 1; bary[1] = bary[2] = bary[3] = 0;
+  }
   STAT(0, 1);
-  for (int it = 0; it < ORC_GJK_ITERS; ++it) {
+  for (int it = 0; it < ORC_GJK_ITERS && !hit; ++it) {
     if (vv < 1e-10f) { hit = 1; break; }
     STAT(1, 1);
     mvert w = msupport(A, TA, B, TB, v3_neg(v));
     float vw = v3_dot(v, w.w);
-    if (vw > 0.0f && vw * vw > margin * margin * vv) { STAT(2, 1); return 0; } /* separated by more than margin */
+    if (vw > 0.0f && vw * vw > margin * margin * vv) { STAT(2, 1); if (cache) *cache = simplex_pack(s, n); return 0; } /* separated by more than margin */
     if (vv - vw <= 1e-6f * vv) break;                          /* converged */
     int dupl = 0;
     for (int i = 0; i < n; ++i) if (v3_len2(v3_sub(s[i].w, w.w)) < 1e-14f) dupl = 1;
@@ -626,6 +682,7 @@ static int gjk_epa(const orc_shape* A, const pose* TA, const orc_shape* B, const
     v = nvv;
     vv = nvl;
   }
+  if (cache) *cache = simplex_pack(s, n);
   if (!hit) {
     float dist = sqrtf(vv);
     if (dist > margin) return 0;
@@ -754,7 +811,9 @@ int orc_collide_pair(const orc_ctx* c, const orc_env* e, int pi, orc_contact* ou
     } else {
       STAT(7, 1);
       if (obb_separated(A, &TA, B, &TB, ca, cb, margin)) { STAT(6, 1); return 0; }
-      if (!gjk_epa(A, &TA, B, &TB, ca, cb, margin, &nrm, &sep, &wa, &wb)) return 0;
+      if (verts_beyond_obb(A, &TA, &TB, B->aabb_c, B->aabb_h, margin) || verts_beyond_obb(B, &TB, &TA, A->aabb_c, A->aabb_h, margin)) { STAT(6, 1); return 0; }
+      uint64_t* cache = (c->gjk_cache && ORC_GJK_WARM) ? &c->gjk_cache[(size_t)(e - c->envs) * c->npairs + pi] : NULL;
+      if (!gjk_epa(A, &TA, B, &TB, ca, cb, margin, &nrm, &sep, &wa, &wb, cache)) return 0;
     }
     STAT(11, 1);
     n = build_manifold(A, &TA, B, &TB, nrm, margin, wa, wb, sep, out);

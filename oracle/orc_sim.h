@@ -122,6 +122,7 @@ typedef struct orc_ctx {
   int wrench_pending;
   float* xshape;     /* [num_envs][nxs][8]: half sizes (3), pad, local position (3), pad */
   float* xbody;      /* [num_envs][nxb][8]: mass, inverse principal inertia (3), pad */
+  uint64_t* gjk_cache;    /* [num_envs][npairs]: the simplex GJK ended on last step (orc_collide.c), 0 = none */
   int any_overflow;  /* some env dropped contacts past MSK_MAX_CONTACTS since finalize */
   void* render;      /* orc_render.c: render geometry and cameras */
   char err[256];
