@@ -68,8 +68,8 @@ struct RCamera {
 
 /* One screen triangle: A,B,C of the three edge functions (inside = all >= 0), the 1/depth plane,
  * segmentation id, primitive id (tie break), pixel bounding box. */
-struct TriSetup {
-  float A0, B0, C0, A1, B1, C1, A2, B2, C2, Aw, Bw, Cw;
+struct TriSetup {   /* (word order = what the tile kernel loads: the first two edges' coefficients side by side for packed FMAs) */
+  float A0, A1, B0, B1, C0, C1, A2, B2, C2, Aw, Bw, Cw;
   int seg, prim, bb;               /* bb = x0 | x1 << 8 | y0 << 16 | y1 << 24 (images are at most 256 x 256) */
   unsigned color;                  /* shaded r8g8b8a8 of the (flat) triangle */
 };
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
     if (__float_as_int(r3.x) & MSK_SEG_BIG) continue;   /* lives in the list of large triangles */
     for (int ty = ty0; ty <= ty1; ++ty)
       for (int tx = tx0; tx <= tx1; ++tx) {
-        if (!tile_touches(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, tx, ty)) continue;   /* same test as the count pass */
+        if (!tile_touches(r0.x, r0.z, r1.x, r0.y, r0.w, r1.y, r1.z, r1.w, r2.x, tx, ty)) continue;   /* same test as the count pass (record words: A0 A1 B0 B1 | C0 C1 A2 B2 | C2 ...) */
         const int tile = ty * cam.tiles_x + tx;
         const int pos = Lcnt[tile] + atomicAdd(&Lfill[tile], 1);
         if (pos < Lcnt[tile + 1]) {
@@ -311,9 +311,32 @@ __global__ void __launch_bounds__(256) k_render_setup(const DModel* __restrict__
   }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+/* Inside test + depth test of one record against my pixel: the three edge functions fma(A, x, fma(B, y, C)) as two packed FMAs (edges
+ * 0 and 1) and two scalar ones, one min3 and one compare (7 VALU instructions per record instead of 11).  Measured: no faster, because
+ * the loop is not bound by VALU issue but by the LDS return path -- every lane needs the same record, and a broadcast ds_read_b128
+ * still hands 64 x 16 B to the VGPRs: 36 B of coefficients per record = 18 clocks of the CU's one LDS against 7 clocks of VALU per
+ * record on each of its four SIMDs.  Reading the records through the scalar cache instead (constant address space, s_load into SGPRs,
+ * four records in flight) was tried and is slower still (1.5 ms per picture instead of 0.85): DESIGN.md section 8. */
+#define MSK_RASTER_RECORD(t4)                                                                                                   \
+  do {                                                                                                                          \
+    const float4 ta = (t4)[0], tb = (t4)[1], tc = (t4)[2];                                                                      \
+    const f32x2 e01 = __builtin_elementwise_fma((f32x2){ta.x, ta.y}, X2, __builtin_elementwise_fma((f32x2){ta.z, ta.w}, Y2, (f32x2){tb.x, tb.y})); \
+    const float e2 = fmaf(tb.z, x, fmaf(tb.w, y, tc.x));                                                                       \
+    if (fminf(fminf(e01.x, e01.y), e2) >= 0.0f) {                                                                              \
+      const float w = fmaf(tc.y, x, fmaf(tc.z, y, tc.w));                                                                      \
+      const float4 td = (t4)[3];                                                                                               \
+      const int prim = __float_as_int(td.y);                                                                                   \
+      if (w >= wmin && (w > best_w || (w == best_w && prim < best_prim))) {                                                    \
+        best_w = w; best_prim = prim; best_seg = __float_as_int(td.x); best_col = (unsigned)__float_as_int(td.w);              \
+      }                                                                                                                         \
+    }                                                                                                                           \
+  } while (0)
+
 /* One wavefront per (group of MSK_TILES_PER_WAVE consecutive 8 x 8 tiles, env), lane = pixel.  The launch is bound by
- * the dependent loads of a tile (offsets -> records), not by arithmetic or by the 8 bytes per pixel it writes, so a wave
- * keeps the NEXT tile's records in flight (registers) while it rasterises the current one out of LDS. */
+ * the dependent loads of a tile (offsets -> records) and by the LDS return path of the record broadcasts (see MSK_RASTER_RECORD), not
+ * by arithmetic or by the 8 bytes per pixel it writes; a wave keeps the NEXT tile's records in flight (registers) while it rasterises
+ * the current one out of LDS. */
 __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
   __shared__ __attribute__((aligned(16))) float Ls[64 * MSK_SETUP_WORDS];
   __shared__ __attribute__((aligned(16))) float Lb[MSK_MAX_BIG * MSK_SETUP_WORDS];
@@ -349,6 +372,7 @@ __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
     const int tx = tile % cam.tiles_x, ty = tile / cam.tiles_x;
     const int px = tx * MSK_TILE + (lane % MSK_TILE), py = ty * MSK_TILE + (lane / MSK_TILE);
     const float x = (float)px + 0.5f, y = (float)py + 0.5f;
+    const f32x2 X2 = {x, x}, Y2 = {y, y};
     float best_w = 0.0f;
     int best_seg = 0, best_prim = 0x7FFFFFFF;
     unsigned best_col = 0u;
@@ -356,18 +380,7 @@ __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
     for (unsigned mk = __builtin_amdgcn_readfirstlane((int)bigmask[tile]); mk != 0u; mk &= mk - 1u) {
       const int k = __builtin_ctz(mk);
       const float4* t4 = (const float4*)(Lb + k * MSK_SETUP_WORDS);
-      const float4 ta = t4[0], tb = t4[1], tc = t4[2];
-      const float e0 = fmaf(ta.x, x, fmaf(ta.y, y, ta.z));
-      const float e1 = fmaf(ta.w, x, fmaf(tb.x, y, tb.y));
-      const float e2 = fmaf(tb.z, x, fmaf(tb.w, y, tc.x));
-      if (e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f) {
-        const float w = fmaf(tc.y, x, fmaf(tc.z, y, tc.w));
-        const float4 td = t4[3];
-        const int prim = __float_as_int(td.y);
-        if (w >= wmin && (w > best_w || (w == best_w && prim < best_prim))) {
-          best_w = w; best_prim = prim; best_seg = __float_as_int(td.x); best_col = (unsigned)__float_as_int(td.w);
-        }
-      }
+      MSK_RASTER_RECORD(t4);
     }
     for (int c0 = l0; c0 < l1; c0 += 64) {
       const int n = min(64, l1 - c0);
@@ -390,20 +403,9 @@ __global__ void __launch_bounds__(64) k_render_tiles(RCamera cam) {
         pf0 = src[0]; pf1 = src[1]; pf2 = src[2]; pf3 = src[3];
       }
       for (int k = 0; k < n; ++k) {
-        /* record: A0 B0 C0 A1 | B1 C1 A2 B2 | C2 Aw Bw Cw | seg prim bb color (same address in every lane: LDS broadcast) */
+        /* record: A0 A1 B0 B1 | C0 C1 A2 B2 | C2 Aw Bw Cw | seg prim bb color (same address in every lane: LDS broadcast) */
         const float4* t4 = (const float4*)(Ls + k * MSK_SETUP_WORDS);
-        const float4 ta = t4[0], tb = t4[1], tc = t4[2];
-        const float e0 = fmaf(ta.x, x, fmaf(ta.y, y, ta.z));
-        const float e1 = fmaf(ta.w, x, fmaf(tb.x, y, tb.y));
-        const float e2 = fmaf(tb.z, x, fmaf(tb.w, y, tc.x));
-        if (e0 >= 0.0f && e1 >= 0.0f && e2 >= 0.0f) {
-          const float w = fmaf(tc.y, x, fmaf(tc.z, y, tc.w));
-          const float4 td = t4[3];
-          const int prim = __float_as_int(td.y);
-          if (w >= wmin && (w > best_w || (w == best_w && prim < best_prim))) {
-            best_w = w; best_prim = prim; best_seg = __float_as_int(td.x); best_col = (unsigned)__float_as_int(td.w);
-          }
-        }
+        MSK_RASTER_RECORD(t4);
       }
     }
     if (l0 == l1 && i + 1 < MSK_TILES_PER_WAVE && tile + 1 < ntiles) { /* empty tile: still start the next prefetch */

@@ -4,6 +4,7 @@ reference's own code over the sapien shim, reset and stepped with sampled action
     python tests/ref_env_zoo.py <oracle|hip> [steps] [env ids ...]      (ZOO_ENVS=<n> sub-scenes per task, default 2)
 """
 import json
+import os
 import sys
 
 import ref_harness
@@ -58,6 +59,12 @@ def main():
             raw = [px.cuda_rigid_body_data.torch()] + ([px.cuda_articulation_qpos.torch(), px.cuda_articulation_qvel.torch()] if len(env.unwrapped.scene.articulations) else [])
             ok = not bad and all(bool(torch.isfinite(t).all()) for t in raw)
             res[eid] = "ok" if ok else "non-finite observation / reward / simulation state"
+            if ok and os.environ.get("ZOO_REPORT_OVERFLOW"):      # which tasks run into the per-env row capacity (sticky flag of each group's engine)
+                flags = 0
+                for g in getattr(px, "_groups", []):
+                    flags |= int(g.engine.get_overflow())
+                if flags:
+                    res[eid] = f"ok overflow={flags}"
             env.close()
         except BaseException as ex:  # noqa: BLE001 -- the report is the point
             res[eid] = f"{type(ex).__name__}: {str(ex)[:200]}"
