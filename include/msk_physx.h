@@ -120,6 +120,10 @@ int msk_add_tendon(msk_ctx* ctx, int link_a, int link_b, float coef_a, float coe
 int msk_add_actor(msk_ctx* ctx, int kind, const float pose[7], float mass,
                   const float com[3], const float inertia6[6], float linear_damping,
                   float angular_damping, int disable_gravity);
+/* PhysxRigidDynamicComponent.set_locked_motion_axes([lin x, y, z, ang x, y, z]) (utils/structs/base.py:340-354, 455-468): bit k of `mask`
+ * locks world axis k of the dynamic actor `body` -- the body keeps no velocity along / about it, constraints find infinite mass there
+ * (the corresponding rows and columns of its inverse mass matrix are zero).  Before msk_finalize. */
+int msk_set_locked_axes(msk_ctx* ctx, int body, uint32_t mask);
 /* PhysxCollisionShape* + body.attach(shape) (actor_builder.py:57-164).  body = -1
  * attaches to the static world (PhysxRigidStaticComponent).  params: box half sizes /
  * sphere {radius} / capsule and cylinder {radius, half length} (axis = +x of the shape frame, as in

@@ -30,7 +30,7 @@ EXPORTS = [
     "fetch", "update_kinematics", "step", "query_create_pairs", "query_create_bodies", "query_buffer", "query_run",
     "get_sizes", "get_contacts", "get_env_contact_counts", "timing_enable", "timing_read",
     "set_solver_classes", "get_solver_class_counts", "declare_env_box", "declare_env_mass", "set_env_boxes", "set_env_masses",
-    "bind_buffers", "batch", "set_articulation_floating", "warnings",
+    "bind_buffers", "batch", "set_articulation_floating", "warnings", "set_locked_axes",
 ]
 # include/msk_render.h — camera pipeline (both libraries)
 RENDER_EXPORTS = ["render_add_mesh", "render_set_base_color", "render_bind_env_box", "render_set_lights", "render_finalize", "camera_create", "camera_buffer",
@@ -135,6 +135,7 @@ class NativeLib:
             "set_solver_classes": (i32, [vp, C.POINTER(C.c_int32)]),
             "get_solver_class_counts": (i32, [vp, C.POINTER(C.c_int32)]),
             "set_articulation_floating": (i32, [vp, i32]),
+            "set_locked_axes": (i32, [vp, i32, u32]),
             "bind_buffers": (i32, [vp, C.POINTER(C.c_void_p), C.c_int64]),
             "batch": (i32, [C.POINTER(C.c_void_p), i32, i32, u32, vp]),
             "timing_enable": (i32, [vp, i32]),

@@ -546,6 +546,15 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
     const float ka = fmaxf(0.0f, 1.0f - dt * b->ang_damp);
     v = v3_scale(v, kl);
     w = v3_scale(w, ka);
+    const unsigned lk = b->lock;   /* locked world axes: no velocity, no response (oracle: dynamics(), assemble) */
+    if (lk) {
+      if (lk & 1u) v.x = 0.0f;
+      if (lk & 2u) v.y = 0.0f;
+      if (lk & 4u) v.z = 0.0f;
+      if (lk & 8u) w.x = 0.0f;
+      if (lk & 16u) w.y = 0.0f;
+      if (lk & 32u) w.z = 0.0f;
+    }
     const int o = b->vofs;
     vfenv[o + 0] = v.x; vfenv[o + 1] = v.y; vfenv[o + 2] = v.z;
     vfenv[o + 3] = w.x; vfenv[o + 4] = w.y; vfenv[o + 5] = w.z;
@@ -553,8 +562,8 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
     const float Im[3][3] = {{Iinv[0], Iinv[3], Iinv[4]}, {Iinv[3], Iinv[1], Iinv[5]}, {Iinv[4], Iinv[5], Iinv[2]}};
     const v3 ex[3] = {v3_make(1, 0, 0), v3_make(0, 1, 0), v3_make(0, 0, 1)};
     for (int a = 0; a < 3; ++a) {
-      Wenv[(o + a) * G + o + a] = im;
-      for (int j = 0; j < 3; ++j) Wenv[(o + 3 + a) * G + o + 3 + j] = Im[a][j];
+      Wenv[(o + a) * G + o + a] = ((lk >> a) & 1u) ? 0.0f : im;
+      for (int j = 0; j < 3; ++j) Wenv[(o + 3 + a) * G + o + 3 + j] = (((lk >> (3 + a)) | (lk >> (3 + j))) & 1u) ? 0.0f : Im[a][j];
       float* sl = Senv + (o + a) * 8;       /* v_com */
       sl[0] = 0.0f; sl[1] = 0.0f; sl[2] = 0.0f; sl[3] = ex[a].x; sl[4] = ex[a].y; sl[5] = ex[a].z;
       float* sa = Senv + (o + 3 + a) * 8;   /* omega: point velocity = w x (p - c) */

@@ -32,6 +32,7 @@ struct DBody {
   float armature, K, D, fmax, lin_damp, ang_damp;
   float jfriction;   /* PhysxArticulationJoint.friction: coefficient of the joint-friction row (msk_solve.h) */
   int drive_accel;   /* drive mode "acceleration": gains per unit of the joint's own inertia */
+  unsigned lock;     /* dynamic actors: bit k = world axis k (linear x y z, angular x y z) is locked (msk_set_locked_axes) */
 };
 
 struct DShape {

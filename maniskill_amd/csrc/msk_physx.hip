@@ -203,6 +203,13 @@ MSK_API int msk_set_articulation_floating(msk_ctx* c, int art) {
   return MSK_OK;
 }
 
+MSK_API int msk_set_locked_axes(msk_ctx* c, int body, uint32_t mask) {
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "set_locked_axes after finalize");
+  if (body < 0 || body >= c->model.nb || c->model.bodies[body].kind != MSK_BODY_DYNAMIC) return fail(c, MSK_ERR_INVALID, "set_locked_axes: not a dynamic actor");
+  c->model.bodies[body].lock = mask & 63u;
+  return MSK_OK;
+}
+
 MSK_API int msk_add_link(msk_ctx* c, int art, int parent_body, int joint_type, const float pose_in_parent[7],
                          const float pose_in_child[7], float limit_lo, float limit_hi, float mass, const float com[3],
                          const float inertia6[6], int disable_gravity, float armature, float joint_friction) {

@@ -138,6 +138,11 @@ class SceneTemplate:
         self.body_kind.append(kind)
         return bid
 
+    def set_locked_axes(self, body: int, axes) -> None:
+        """PhysxRigidDynamicComponent.set_locked_motion_axes: six flags (linear x y z, angular x y z, world axes) of a dynamic actor."""
+        mask = sum(1 << k for k, f in enumerate(axes) if f)
+        self.ops.append(("set_locked_axes", (int(body), int(mask))))
+
     # -- shapes -----------------------------------------------------------------------
     def add_shape(self, body, shape_type, p=(0, 0, 0), q=(1, 0, 0, 0), params=(0, 0, 0), verts=None,
                   static_friction=0.3, dynamic_friction=0.3, restitution=0.0, groups=(1, 1, 0, 0),
@@ -297,6 +302,8 @@ class PhysxGpuSystem:
                                          groups, a[9], a[10]), op)
             elif op == "disable_collision":
                 L.check(ctx, L.disable_collision(ctx, *a), op)
+            elif op == "set_locked_axes":
+                L.check(ctx, L.set_locked_axes(ctx, *a), op)
             elif op == "add_visual":
                 pass  # render.attach_template_visuals
             elif op == "declare_env_box":

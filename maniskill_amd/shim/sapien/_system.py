@@ -460,10 +460,10 @@ class PhysxSystem:
                 m, com, I6 = c._mass_tensor()
                 ep = c.entity._pose
                 kind = N.BODY_KINEMATIC if c.kinematic else N.BODY_DYNAMIC
-                if any(c.locked_motion_axes):
-                    raise RuntimeError("locked motion axes are not supported")
                 bid = tpl.add_actor(c.entity.name, kind, ep._p, ep._q, 0.0 if c.kinematic else m, com, I6, c.linear_damping,
                                     c.angular_damping, c.disable_gravity)
+                if any(c.locked_motion_axes) and not c.kinematic:
+                    tpl.set_locked_axes(bid, c.locked_motion_axes)
                 body_ids[id(c)] = bid
                 shapes_of[1].append((c, bid, None))
         # Shape order = the order of the candidate-pair table (pairs are enumerated sa < sb) = the order in which an env's contact

@@ -109,6 +109,13 @@ ORC_EXPORT int orc_set_articulation_floating(orc_ctx* c, int art) {
   return MSK_OK;
 }
 
+ORC_EXPORT int orc_set_locked_axes(orc_ctx* c, int body, uint32_t mask) {
+  if (c->finalized) return fail(c, MSK_ERR_INVALID, "set_locked_axes after finalize");
+  if (body < 0 || body >= c->nb || c->bodies[body].kind != MSK_BODY_DYNAMIC) return fail(c, MSK_ERR_INVALID, "set_locked_axes: not a dynamic actor");
+  c->bodies[body].lock = mask & 63u;
+  return MSK_OK;
+}
+
 ORC_EXPORT int orc_set_drive(orc_ctx* c, int link_body, float K, float D, float force_limit, int mode_acc) {
   if (link_body < 0 || link_body >= c->nb || c->bodies[link_body].dof < 0) return fail(c, MSK_ERR_INVALID, "set_drive: not an active joint");
   orc_body* b = &c->bodies[link_body];

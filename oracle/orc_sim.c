@@ -362,6 +362,14 @@ static void dynamics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
     float ka = fmaxf(0.0f, 1.0f - dt * b->ang_damp);
     v = v3_scale(v, kl);
     w = v3_scale(w, ka);
+    if (b->lock) { /* locked world axes carry no velocity (PhysxRigidDynamicComponent.set_locked_motion_axes) */
+      if (b->lock & 1u) v.x = 0.0f;
+      if (b->lock & 2u) v.y = 0.0f;
+      if (b->lock & 4u) v.z = 0.0f;
+      if (b->lock & 8u) w.x = 0.0f;
+      if (b->lock & 16u) w.y = 0.0f;
+      if (b->lock & 32u) w.z = 0.0f;
+    }
     s->vfree[b->vofs + 0] = v.x; s->vfree[b->vofs + 1] = v.y; s->vfree[b->vofs + 2] = v.z;
     s->vfree[b->vofs + 3] = w.x; s->vfree[b->vofs + 4] = w.y; s->vfree[b->vofs + 5] = w.z;
   }
@@ -529,8 +537,9 @@ static void coordinate_tables(const orc_ctx* c, const orc_env* e, orc_scratch* s
         s->Scol[b->vofs + 3 + a].a = ex[a];                      /* omega: point velocity = w x (p - c) */
         s->Scol[b->vofs + 3 + a].l = v3_cross(s->comw[i], ex[a]);
         s->moves[b->vofs + a] = s->moves[b->vofs + 3 + a] = (uint64_t)1 << i;
-        s->W[b->vofs + a][b->vofs + a] = im;
-        for (int j = 0; j < 3; ++j) s->W[b->vofs + 3 + a][b->vofs + 3 + j] = Im[a][j];
+        /* ... and no response: the rows and columns of a locked axis are zero */
+        s->W[b->vofs + a][b->vofs + a] = ((b->lock >> a) & 1u) ? 0.0f : im;
+        for (int j = 0; j < 3; ++j) s->W[b->vofs + 3 + a][b->vofs + 3 + j] = (((b->lock >> (3 + a)) | (b->lock >> (3 + j))) & 1u) ? 0.0f : Im[a][j];
       }
     }
   }

@@ -39,6 +39,7 @@ typedef struct {
   int drive_accel;
   float lin_damp, ang_damp;
   pose init_pose;    /* actors: initial pose; root links: articulation root pose */
+  unsigned lock;     /* dynamic actors: bit k = world axis k (linear x y z, angular x y z) is locked (msk_set_locked_axes) */
   int movable;       /* 1 if the body can move (dynamic actor, or link below a moving joint) */
 } orc_body;
 
