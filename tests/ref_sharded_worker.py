@@ -24,13 +24,17 @@ def main():
             subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_synthetic_partnet.py"), "--out", assets, "--max-drawers", "2", "--ids-from",
                                    os.path.join(meta, "info_cabinet_drawer_train.json"), "--placeholder-ids-from",
                                    os.path.join(meta, "info_cabinet_door_train.json")], stdout=subprocess.DEVNULL)
-    ref_harness.setup("oracle")            # the reference on sys.path, the oracle behind the shim, cpu tensors on the "GPU" code path
+    on_gpu = os.environ.get("SHARD_BACKEND", "oracle") == "hip"      # -m gpu: the HIP library, one rank (a box has one GPU)
+    ref_harness.setup("hip" if on_gpu else "oracle")   # the reference on sys.path; oracle: the CPU checker behind the shim, cpu tensors on the "GPU" code path
     import torch
     import torch.distributed as dist
-    from oracle_backend import oracle_lib
     from maniskill_amd.dist import make_sharded_gym_env
     torch.set_num_threads(1)
-    env = make_sharded_gym_env(env_id, total, device_type="cpu", reference_root=ref, backend=oracle_lib())
+    if on_gpu:
+        env = make_sharded_gym_env(env_id, total, device_type="cuda", reference_root=ref)
+    else:
+        from oracle_backend import oracle_lib
+        env = make_sharded_gym_env(env_id, total, device_type="cpu", reference_root=ref, backend=oracle_lib())
     obs, _ = env.reset(seed=7)
     base = env.unwrapped
     state0 = {k: {n: t.clone() for n, t in d.items()} for k, d in base.get_state_dict().items()}
@@ -39,7 +43,7 @@ def main():
         for k, d in torch.load(sys.argv[5])["state0"].items():
             mine[k] = {}
             for n, g in d.items():
-                g, w = g[env.start:env.start + env.num_envs], state0[k][n].shape[1]
+                g, w = g[env.start:env.start + env.num_envs].to(env.device), state0[k][n].shape[1]
                 if k == "articulations" and g.shape[1] != w:
                     mdg, md = (g.shape[1] - 13) // 2, (w - 13) // 2
                     g = torch.cat([g[:, :13], g[:, 13:13 + md], g[:, 13 + mdg:13 + mdg + md]], dim=1)
@@ -50,12 +54,13 @@ def main():
     states, all_obs, all_rew = [], [], []
     for _ in range(steps):
         a = 2 * torch.rand(total, adim, generator=gen) - 1          # the same global action stream on every rank
-        obs, rew, term, trunc, info = env.step(a[env.start:env.start + env.num_envs])
+        obs, rew, term, trunc, info = env.step(a[env.start:env.start + env.num_envs].to(env.device))
         states.append(base.get_state().clone())
         gathered = env.gather(obs, rew, term, trunc) if env.world > 1 else (obs, rew, term, trunc)
         all_obs.append(gathered[0].clone()); all_rew.append(gathered[1].clone())
     if env.rank == 0:
-        torch.save(dict(obs=torch.stack(all_obs), rew=torch.stack(all_rew), state_rank0=torch.stack(states), state0=state0, groups=len(base.scene.px._groups)), out)
+        cpu = lambda t: t.cpu() if torch.is_tensor(t) else {k: cpu(v) for k, v in t.items()}   # noqa: E731
+        torch.save(dict(obs=torch.stack(all_obs).cpu(), rew=torch.stack(all_rew).cpu(), state_rank0=torch.stack(states).cpu(), state0=cpu(state0), groups=len(base.scene.px._groups)), out)
     if env.world > 1:
         dist.barrier()
         dist.destroy_process_group()
