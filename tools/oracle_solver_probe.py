@@ -4,9 +4,9 @@ rest and the spin a central face-to-face impact leaves (both are 
 
     python tools/oracle_solver_probe.py [--cubes 3] [--position-iterations 15] [--steps 600]
 
-tools/experiments/orc_solver_switches.patch adds three environment switches to oracle/orc_sim.c for trying fixes WITHOUT touching the
-committed oracle (apply, `make -C oracle`, run this, `git checkout oracle/orc_sim.c`): X_BETA (penetration recovery rate x dt),
-X_INNER (Gauss-Seidel sweeps per position iteration).  Numbers measured in round 2 are in DESIGN.md §8."""
+The oracle's solver constants (ORC_PEN_RATE_COEF, ORC_WARM_NORMAL, ORC_WARM_TANGENT, ... in oracle/orc_sim.c) are #ifndef-overridable:
+build a variant with `cc ... -DORC_PEN_RATE_COEF=...` and point oracle_backend at it to sweep them.  The round-3 schedule rests the
+stacks this probe was written for (tests/test_oracle_solver_rows.py)."""
 import argparse
 import json
 import os
