@@ -69,3 +69,47 @@ def test_a_ball_pushed_off_sliding_ends_up_rolling_at_five_sevenths(oracle_facto
         px.step()
     px.gpu_fetch_all()
     assert abs(rbd[a, 7].item() - 5.0 / 7.0) < 1e-4 and abs(rbd[a, 11].item() * H - rbd[a, 7].item()) < 1e-4
+
+
+def test_a_pushed_train_of_two_cubes_accelerates_as_one_and_the_coupling_force_is_the_second_cubes_share(oracle_factory):
+    """Newton's second law across a contact.  A force F pushes cube 1 (m1) which pushes cube 2 (m2), both sliding on the table with friction
+    mu (of the pair): the train accelerates with a = F / (m1 + m2) - mu g, and the contact between the cubes transmits m2 (a + mu g) = F m2 / (m1 + m2)
+    -- whatever mu is.  The force goes in through cuda_rigid_body_force (Actor.apply_force), the coupling force comes out of the pair
+    impulse query: a known answer through the wrench path, two friction contacts, a normal contact between moving bodies and the query."""
+    import numpy as np
+    from maniskill_amd import _native as N
+    from maniskill_amd.envs import scene_builders as sb
+    from maniskill_amd.physx import SceneTemplate, SimConfig
+    h, m1, m2, mu, F, g = 0.02, 0.3, 0.1, 0.2, 2.0, 9.81
+    tpl = SceneTemplate()
+    sb.add_table_scene(tpl)
+    ids = []
+    for k, (x, m) in enumerate(((-2 * h - 1e-4, m1), (0.0, m2))):
+        b = tpl.add_actor(f"c{k}", N.BODY_DYNAMIC, p=(x, 0, h), mass=m, inertia6=(m / 6 * (2 * h) ** 2,) * 3 + (0, 0, 0))
+        tpl.add_shape(b, N.SHAPE_BOX, params=(h, h, h), static_friction=mu, dynamic_friction=mu)
+        ids.append(b)
+    px = oracle_factory(tpl, 1, SimConfig())
+    px.gpu_init()
+    px.set_scene_offsets(np.zeros((1, 3)))
+    rbd = px.cuda_rigid_body_data.torch().view(1, px.bodies_per_env, 13)
+    rbd[:, tpl.body_id("table-workspace"), :7] = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)])
+    px.gpu_apply_all()
+    q = px.gpu_create_contact_pair_impulse_query([(ids[1], ids[0])])
+    Fbuf = px.cuda_rigid_body_force.torch().view(1, px.bodies_per_env, 4)
+    dt = px.timestep
+    vs, imp = [], []
+    for k in range(40):
+        Fbuf[0, ids[0], :3] = torch.tensor([F, 0.0, 0.0])
+        px.gpu_apply_rigid_dynamic_force()
+        px.step()
+        px.gpu_fetch_all()
+        px.gpu_query_contact_pair_impulses(q)
+        vs.append(rbd[0, ids[1], 7].item())
+        imp.append(q.cuda_impulses.torch().view(1, 1, 3)[0, 0, 0].item())
+    a = (vs[-1] - vs[9]) / (30 * dt)
+    mu_pair = 0.5 * (mu + 0.3)           # PhysX's default combine: the average of the cube's and the table's (0.3, scene_builders) coefficient
+    a_want = F / (m1 + m2) - mu_pair * g
+    assert abs(a - a_want) < 0.03 * a_want, (a, a_want)
+    assert abs(rbd[0, ids[0], 7].item() - rbd[0, ids[1], 7].item()) < 2e-3          # one train
+    f_couple = np.mean(imp[10:]) / dt
+    assert abs(f_couple - F * m2 / (m1 + m2)) < 0.04 * F * m2 / (m1 + m2), (f_couple, F * m2 / (m1 + m2))

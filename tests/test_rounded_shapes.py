@@ -207,3 +207,21 @@ def test_bounce_hip_equals_oracle(built, oracle_factory):
     a[0].gpu_fetch_all(); b[0].gpu_fetch_all()
     assert torch.allclose(a[2].cpu(), b[2], rtol=1e-4, atol=1e-5)
     assert b[2][0, b[1], 9].abs() > 0.1      # still bouncing
+
+
+@pytest.mark.parametrize("inertia_factor, coef", [(0.4, 5.0 / 7.0), (2.0 / 3.0, 3.0 / 5.0)])
+def test_ball_rolling_down_a_slope_accelerates_with_the_textbook_fraction_of_g(oracle_factory, inertia_factor, coef):
+    """Gravity tilted by theta about y is a slope of angle theta.  A ball released at rest on a rough slope rolls without slipping with
+    a = g sin(theta) / (1 + I / (m r^2)): 5/7 g sin(theta) for a solid ball (I = 2/5 m r^2), 3/5 for a thin shell (I = 2/3 m r^2) -- a known
+    answer that involves the friction row, the normal row and the rotational inertia together and none of this solver's own constants."""
+    r, m, th = 0.03, 0.5, np.deg2rad(10.0)
+    g = 9.81
+    px, b, rbd = _world(oracle_factory, 1, N.SHAPE_SPHERE, (r, 0, 0), z=r, mass=m, inertia=(inertia_factor * m * r * r,) * 3, friction=1.0,
+                        gravity=(g * np.sin(th), 0.0, -g * np.cos(th)))
+    _settle(px, 10)                      # let the contact form
+    v0, t0 = rbd[0, b, 7].item(), 10 * px.timestep
+    _settle(px, 40)
+    v1, t1 = rbd[0, b, 7].item(), 50 * px.timestep
+    a = (v1 - v0) / (t1 - t0)
+    assert abs(a - coef * g * np.sin(th)) < 0.02 * coef * g * np.sin(th), (a, coef * g * np.sin(th))
+    assert abs(rbd[0, b, 7].item() - rbd[0, b, 11].item() * r) < 0.02 * abs(v1)       # still rolling: v = omega r
