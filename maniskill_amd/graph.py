@@ -36,16 +36,26 @@ def const(values, device, dtype=torch.float32):
     return t
 
 
-def _clone_tree(x):
+def _clone_tree(x, _bases=None):
     """Snapshots of every tensor a replay hands out.  Everything produced inside the capture — the camera planes under
     ``sensor_data`` included: their ``.clone()`` in render.get_obs runs inside the graph and lands in a fixed pool allocation —
-    lives in memory the next replay overwrites, so callers get copies made after the replay."""
+    lives in memory the next replay overwrites, so callers get copies made after the replay.  Views of one small tensor (the task
+    kernels write all per-env flags into one [N, 8] byte tensor and hand out its columns as terminated / truncated / success / ...) are
+    copied ONCE, as their base, and re-sliced: each copy is a launch of its own behind the graph, and six of them were 4 % of a step."""
+    if _bases is None:
+        _bases = {}
     if isinstance(x, torch.Tensor):
+        base = x._base
+        if base is not None and base.numel() <= 16 * x.numel():
+            c = _bases.get(id(base))
+            if c is None:
+                c = _bases[id(base)] = base.clone()
+            return c.as_strided(x.size(), x.stride(), x.storage_offset() - base.storage_offset())
         return x.clone()
     if isinstance(x, dict):
-        return {k: _clone_tree(v) for k, v in x.items()}
+        return {k: _clone_tree(v, _bases) for k, v in x.items()}
     if isinstance(x, (list, tuple)):
-        return type(x)(_clone_tree(v) for v in x)
+        return type(x)(_clone_tree(v, _bases) for v in x)
     return x
 
 
@@ -84,5 +94,4 @@ class StepGraph:
             self.action.copy_(action)
         self.graph.replay()
         self.replays += 1
-        obs, rew, term, trunc, info = self.out
-        return _clone_tree(obs), rew.clone(), term.clone(), trunc.clone(), _clone_tree(info)
+        return _clone_tree(tuple(self.out))
