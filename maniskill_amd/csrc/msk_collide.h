@@ -886,12 +886,27 @@ MSK_DEV unsigned long long simplex_pack(const Simplex& S, const int n) {
   return w;
 }
 
-MSK_DEV int gjk_epa(const CCtx& m, const CShape* A, const pose* TA, const CShape* B, const pose* TB, v3 ca, v3 cb, float margin,
+/* A box enters GJK / EPA as a core, its half extents reduced by a small radius, swept by a ball of that radius: resting shapes overlap by
+ * the solver's slop, and without a margin every such pair needs EPA -- the longest item of a launch (oracle: box_core, same constant). */
+#define MSK_BOX_CORE_RADIUS 2.0e-3f   /* oracle: ORC_BOX_CORE_RADIUS */
+MSK_DEV float box_core(const CShape* sh, CShape* core) {
+  *core = *sh;
+  if (sh->type != MSK_SHAPE_BOX) return 0.0f;
+  const float r = fminf(MSK_BOX_CORE_RADIUS, 0.25f * fminf(sh->par[0], fminf(sh->par[1], sh->par[2])));
+  core->par[0] -= r; core->par[1] -= r; core->par[2] -= r;
+  return r;
+}
+
+MSK_DEV int gjk_epa(const CCtx& m, const CShape* A0, const pose* TA, const CShape* B0, const pose* TB, v3 ca, v3 cb, float margin,
                    v3* n_out, float* sep_out, v3* wa, v3* wb, unsigned long long* cache) {
   Simplex S;
   float bary[4] = {1, 0, 0, 0};
   int n = 0;
-  const float ra = shape_rad(A), rb = shape_rad(B), rsum = ra + rb;
+  CShape coreA, coreB;
+  const float ka = box_core(A0, &coreA), kb = box_core(B0, &coreB);
+  const CShape* A = &coreA;
+  const CShape* B = &coreB;
+  const float ra = shape_rad(A0) + ka, rb = shape_rad(B0) + kb, rsum = ra + rb;
   margin += rsum;   /* distances below are between the cores */
   v3 d0 = v3_sub(ca, cb);
   if (v3_len2(d0) < 1e-12f) d0 = v3_make(1, 0, 0);

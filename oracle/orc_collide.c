@@ -637,12 +637,33 @@ static int epa(const orc_shape* A, const pose* TA, const orc_shape* B, const pos
 }
 
 /* GJK distance + EPA. Returns 0 if farther apart than margin. n from B to A. */
-static int gjk_epa(const orc_shape* A, const pose* TA, const orc_shape* B, const pose* TB, v3 ca, v3 cb, float margin,
+/* A box enters GJK / EPA as a CORE, its half extents reduced by a small radius, swept by a ball of that radius (like the rounded hulls):
+ * two shapes at rest on each other overlap by the solver's slop (0.1 - 0.5 mm), and without a margin every such pair is an "origin inside
+ * the simplex" case that needs EPA for its depth and normal -- the longest item of a narrowphase launch.  With the margin the cores stay
+ * apart, GJK's distance minus the radius is the (negative) separation, and EPA is left to penetrations deeper than the radius.  The price:
+ * against a hull, a box's edges and corners are rounded by ORC_BOX_CORE_RADIUS (PhysX's convex collision shrinks its shapes the same
+ * way).  Box against box does not come here (SAT). */
+#ifndef ORC_BOX_CORE_RADIUS
+#define ORC_BOX_CORE_RADIUS 2.0e-3f
+#endif
+static float box_core(const orc_shape* sh, orc_shape* core) {
+  if (sh->type != MSK_SHAPE_BOX || !(ORC_BOX_CORE_RADIUS > 0.0f)) return 0.0f;
+  const float r = fminf(ORC_BOX_CORE_RADIUS, 0.25f * fminf(sh->par[0], fminf(sh->par[1], sh->par[2])));
+  *core = *sh;
+  core->par[0] -= r; core->par[1] -= r; core->par[2] -= r;
+  return r;
+}
+
+static int gjk_epa(const orc_shape* A0, const pose* TA, const orc_shape* B0, const pose* TB, v3 ca, v3 cb, float margin,
                    v3* n_out, float* sep_out, v3* wa, v3* wb, uint64_t* cache) {
   mvert s[4];
   float bary[4] = {1, 0, 0, 0};
   int n = 0;
-  const float ra = shape_rad(A), rb = shape_rad(B), rsum = ra + rb;
+  orc_shape coreA, coreB;
+  const float ka = box_core(A0, &coreA), kb = box_core(B0, &coreB);
+  const orc_shape* A = ka > 0.0f ? &coreA : A0;
+  const orc_shape* B = kb > 0.0f ? &coreB : B0;
+  const float ra = shape_rad(A0) + ka, rb = shape_rad(B0) + kb, rsum = ra + rb;
   margin += rsum;   /* distances below are between the cores */
   v3 d0 = v3_sub(ca, cb);
   if (v3_len2(d0) < 1e-12f) d0 = v3_make(1, 0, 0);

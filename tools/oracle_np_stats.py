@@ -45,7 +45,7 @@ def main():
     raw.orc_stats_read(buf, 1)
     sub = env._sim_steps_per_control
     print(f"{args.env}, {args.envs} envs; per env and substep:")
-    print(f"{'control steps':>14} {'pairs':>6} {'plane':>6} {'boxbox':>6} {'sat hit':>7} {'hull':>6} {'obb out':>7} {'gjk':>5} {'gjk it':>6} {'epa':>5} {'epa it':>6} {'epa deg':>7} {'manif':>6} {'points':>6}")
+    print(f"{'control steps':>14} {'pairs':>6} {'plane':>6} {'boxbox':>6} {'sat hit':>7} {'hull':>6} {'obb out':>7} {'gjk':>5} {'gjk it':>6} {'epa/k':>5} {'epa it':>6} {'epa deg':>7} {'manif':>6} {'points':>6}")
     chunk = max(args.steps // 5, 1)
     counts = []
     for k in range(args.steps):
@@ -56,7 +56,7 @@ def main():
             g, gi, mo, e, ei, ed, oc, ot, pl, bb, sat, mf, pts, vis = list(buf)[:14]
             per = args.envs * sub * chunk
             print(f"{k + 1 - chunk:>6}..{k + 1:<6} {vis / per:>6.1f} {pl / per:>6.2f} {bb / per:>6.2f} {sat / per:>7.2f} {ot / per:>6.2f} {oc / per:>7.2f} {g / per:>5.2f} "
-                  f"{gi / max(g, 1):>6.2f} {e / per:>5.2f} {ei / max(e, 1):>6.2f} {ed / per:>7.2f} {mf / per:>6.2f} {pts / per:>6.2f}")
+                  f"{gi / max(g, 1):>6.2f} {1000 * e / per:>5.2f} {ei / max(e, 1):>6.2f} {ed / per:>7.2f} {mf / per:>6.2f} {pts / per:>6.2f}")
 
 
     return counts
