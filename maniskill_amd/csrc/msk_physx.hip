@@ -61,6 +61,7 @@ struct msk_ctx {
   int *d_art_dof0, *d_art_ndof;
   int max_dof;
   int ndisabled;
+  int plane_pairs;   /* candidate pairs with a plane: 0 = the narrowphase launch needs no plane blocks */
   int disabled[256][2];
   pose init_pose[MSK_MAX_BODIES];
   pose pending_root;
@@ -458,11 +459,13 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
     if (c->art_ndof[a] > c->max_dof) c->max_dof = c->art_ndof[a];
   }
   m.np = 0;
+  c->plane_pairs = 0;
   for (int i = 0; i < m.ns; ++i)
     for (int j = i + 1; j < m.ns; ++j)
       if (pair_enabled(c, i, j)) {
         if (m.np >= MSK_MAX_PAIRS) return fail(c, MSK_ERR_CAPACITY, "too many candidate pairs");
         m.pairs[m.np].sa = i; m.pairs[m.np].sb = j;
+        if (m.shapes[i].type == MSK_SHAPE_PLANE || m.shapes[j].type == MSK_SHAPE_PLANE) c->plane_pairs++;
         m.np++;
       }
   m.N = num_envs;
@@ -720,13 +723,17 @@ MSK_API int msk_update_kinematics(msk_ctx* c, void* stream) {
 }
 
 /* env-group size and block kinds of the narrowphase launch for N envs */
-static void np_launch_shape(int N, int* group_out, NpCfg* cfg) {
-  int group = N / 256;   /* ~256 x 6 waves whatever the env count */
+static void np_launch_shape(int N, int plane_pairs, int* group_out, NpCfg* cfg) {
+  static const int e_group = getenv("MSK_NP_GROUP") ? atoi(getenv("MSK_NP_GROUP")) : 0;
+  int group = e_group > 0 ? e_group : N / 256;   /* ~256 x 6 waves whatever the env count */
   group = group < 1 ? 1 : (group > NP_GROUP_MAX ? NP_GROUP_MAX : group);
   while (group & (group - 1)) group &= group - 1;   /* a power of two: groups never straddle the 64-env classification chunks */
-  static const int e_nbox = getenv("MSK_NP_NBOX") ? atoi(getenv("MSK_NP_NBOX")) : 1;       /* tuning aids */
+  static const int e_nbox = getenv("MSK_NP_NBOX") ? atoi(getenv("MSK_NP_NBOX")) : 2;       /* tuning aids */
   static const int e_nhull = getenv("MSK_NP_NHULL") ? atoi(getenv("MSK_NP_NHULL")) : 4;
-  cfg->nplane = 1;
+  /* Block kinds per env group.  Two box-box blocks: a group whose list needs a second pass of 32 pairs (arms lying on the table) ran them
+   * one after the other and ended the launch (one block: k_narrowphase 56 / 59 us, two: 48 / 52).  More is worse: the kernel holds 256
+   * VGPRs, so 2048 waves are resident and a launch beyond that waits for a second round (three: 63 us, four: 72). */
+  cfg->nplane = plane_pairs > 0 ? 1 : 0;
   cfg->nbox = e_nbox;
   cfg->nhull = e_nhull;
   *group_out = group;
@@ -750,7 +757,7 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
   if (c->model.np > 0) {
     int group;
     NpCfg cfg;
-    np_launch_shape(N, &group, &cfg);
+    np_launch_shape(N, c->plane_pairs, &group, &cfg);
     hipLaunchKernelGGL(k_narrowphase, dim3((N + group - 1) / group, cfg.nplane + cfg.nbox + cfg.nhull), dim3(64), 0, s, c->d_model,
                        c->st, group, cfg);
   } else {
@@ -845,7 +852,7 @@ static int batch_merged(msk_ctx* const* ctxs, int n, int op, uint32_t mask, hipS
       r.b_af = mc.t_af; mc.t_af += (N + 255) / 256;
       r.gm = x->solve_workers;
       r.b_cs = mc.t_cs; mc.t_cs += r.gm + (N + epw - 1) / epw;
-      np_launch_shape(N, &r.np_group, &r.np_cfg);
+      np_launch_shape(N, x->plane_pairs, &r.np_group, &r.np_cfg);
       r.np_gx = (N + r.np_group - 1) / r.np_group;
       r.np_gy = r.np_cfg.nplane + r.np_cfg.nbox + r.np_cfg.nhull;
       r.b_np = mc.t_np;
