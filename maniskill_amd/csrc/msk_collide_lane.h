@@ -16,7 +16,7 @@
 
 namespace perlane {
 
-#define PL_LANES 32          /* pairs per wavefront pass */
+#define PL_LANES 32          /* pairs per wavefront pass (x PL_WORDS words of LDS each) */
 /* per-lane LDS arrays (words) */
 #define PL_FA 0              /* p3[8]       */
 #define PL_FB 24             /* p3[8]       */

@@ -340,15 +340,25 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
  * blocks of one kind share the group's list of that kind.
  * Per 64 consecutive envs, the block that finishes last sorts them into the solver lists (one wave, one env per lane:
  * a handful of same-address atomics per 64 envs). */
-struct NpCfg { int nplane, nbox, nhull; };
+struct NpCfg { int nplane, nbox, nhull; int lds_words; /* dynamic LDS of the launch, in floats (np_lds_words) */ };
+#define NP_LDS_BASE ((64 / NPG) * WS_TOTAL + WE_TOTAL)   /* four group workspaces + the wave's EPA workspace; the staged hull vertices follow */
+/* LDS a narrowphase block needs for a template with `nverts` hull vertices: the box-box image (PL_LANES x PL_WORDS) or the lane-group
+ * workspaces plus the staged vertex pool, whichever is larger; a pool beyond MSK_NP_MAX_STAGED vertices is read from global memory
+ * instead.  (Measured, round 3: the size is NOT what limits this kernel -- 19.5 KB per block with 24 box lanes was 4 us slower than
+ * 26.6 KB with 32, because groups of 25-32 pairs then need a second pass.) */
+#define MSK_NP_MAX_STAGED 1280
+static inline int np_lds_words(int nverts) {
+  const int box = PL_WORDS * PL_LANES;
+  const int grp = NP_LDS_BASE + (nverts <= MSK_NP_MAX_STAGED ? nverts * 3 : 0);
+  return box > grp ? box : grp;
+}
 MSK_DEV void narrowphase_block(const DModel* __restrict__ m, const DState& st, const int group, const NpCfg cfg, const int bx, const int by, const int gx,
                                const int gy) {
   __shared__ int pref[NP_GROUP_MAX + 1];
-  /* one LDS image for both kinds of block: 32 lanes x 208 words of per-pair arrays (box-box), or four group workspaces
-   * and the wave's EPA workspace (plane, hull) */
-  constexpr int GROUP_WORDS = (64 / NPG) * WS_TOTAL + WE_TOTAL + 3 * MSK_MAX_SHAPES * 20;   /* workspaces + room for 1280 staged hull vertices */
-  constexpr int LDS_WORDS = PL_WORDS * PL_LANES > GROUP_WORDS ? PL_WORDS * PL_LANES : GROUP_WORDS;
-  __shared__ float s_lds[LDS_WORDS];
+  /* one LDS image for both kinds of block: PL_LANES lanes x 208 words of per-pair arrays (box-box), or four group workspaces
+   * and the wave's EPA workspace (plane, hull) followed by the staged vertex pool; sized by the launch (np_lds_words) */
+  extern __shared__ __attribute__((aligned(16))) float s_lds[];
+  const int LDS_WORDS = cfg.lds_words;
   float* s_ws = s_lds;
   float* s_we = s_lds + (64 / NPG) * WS_TOTAL;
   const int e0 = bx * group;

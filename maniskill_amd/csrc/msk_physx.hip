@@ -723,7 +723,7 @@ MSK_API int msk_update_kinematics(msk_ctx* c, void* stream) {
 }
 
 /* env-group size and block kinds of the narrowphase launch for N envs */
-static void np_launch_shape(int N, int plane_pairs, int* group_out, NpCfg* cfg) {
+static void np_launch_shape(int N, int plane_pairs, int nverts, int* group_out, NpCfg* cfg) {
   static const int e_group = getenv("MSK_NP_GROUP") ? atoi(getenv("MSK_NP_GROUP")) : 0;
   int group = e_group > 0 ? e_group : N / 256;   /* ~256 x 6 waves whatever the env count */
   group = group < 1 ? 1 : (group > NP_GROUP_MAX ? NP_GROUP_MAX : group);
@@ -731,11 +731,13 @@ static void np_launch_shape(int N, int plane_pairs, int* group_out, NpCfg* cfg) 
   static const int e_nbox = getenv("MSK_NP_NBOX") ? atoi(getenv("MSK_NP_NBOX")) : 2;       /* tuning aids */
   static const int e_nhull = getenv("MSK_NP_NHULL") ? atoi(getenv("MSK_NP_NHULL")) : 4;
   /* Block kinds per env group.  Two box-box blocks: a group whose list needs a second pass of 32 pairs (arms lying on the table) ran them
-   * one after the other and ended the launch (one block: k_narrowphase 56 / 59 us, two: 48 / 52).  More is worse: the kernel holds 256
-   * VGPRs, so 2048 waves are resident and a launch beyond that waits for a second round (three: 63 us, four: 72). */
+   * one after the other and ended the launch (one block: k_narrowphase 56 / 59 us, two: 48 / 52; three: 49 / 54).  Dealing the pairs
+   * out item by item instead of pass by pass (fewer divergent manifold cases per wave) was measured too and is no better with two
+   * blocks and much worse with three or four (63 / 72 us). */
   cfg->nplane = plane_pairs > 0 ? 1 : 0;
   cfg->nbox = e_nbox;
   cfg->nhull = e_nhull;
+  cfg->lds_words = np_lds_words(nverts);
   *group_out = group;
 }
 
@@ -757,9 +759,9 @@ MSK_API int msk_step(msk_ctx* c, void* stream) {
   if (c->model.np > 0) {
     int group;
     NpCfg cfg;
-    np_launch_shape(N, c->plane_pairs, &group, &cfg);
-    hipLaunchKernelGGL(k_narrowphase, dim3((N + group - 1) / group, cfg.nplane + cfg.nbox + cfg.nhull), dim3(64), 0, s, c->d_model,
-                       c->st, group, cfg);
+    np_launch_shape(N, c->plane_pairs, c->nverts_total, &group, &cfg);
+    hipLaunchKernelGGL(k_narrowphase, dim3((N + group - 1) / group, cfg.nplane + cfg.nbox + cfg.nhull), dim3(64),
+                       (size_t)cfg.lds_words * sizeof(float), s, c->d_model, c->st, group, cfg);
   } else {
     hipMemsetAsync(c->st.cls_count, 0, sizeof(int) * MSK_SOLVE_CLASSES, s);
     hipLaunchKernelGGL(k_classify, dim3(nblk), dim3(64), 0, s, c->d_model, c->st);
@@ -789,7 +791,7 @@ struct MergedCache {
   unsigned long long epoch = 0;
   GroupRef* d_refs = nullptr;
   int t_dyn = 0, t_np = 0, t_cs = 0, t_af = 0;
-  size_t lds_dyn = 0, lds_kin = 0;
+  size_t lds_dyn = 0, lds_kin = 0, lds_np = 0;
   bool any_np = false;
   unsigned long long used = 0;   /* last use, for eviction */
 };
@@ -840,7 +842,7 @@ static int batch_merged(msk_ctx* const* ctxs, int n, int op, uint32_t mask, hipS
     if (mc.d_refs) { hipFree(mc.d_refs); mc.d_refs = nullptr; }
     std::vector<GroupRef> refs((size_t)n);
     mc.t_dyn = mc.t_np = mc.t_cs = mc.t_af = 0;
-    mc.lds_dyn = mc.lds_kin = 0;
+    mc.lds_dyn = mc.lds_kin = mc.lds_np = 0;
     mc.any_np = false;
     const int epb = 64 / lpe, epw = (G == 16) ? 4 : 2;
     for (int i = 0; i < n; ++i) {
@@ -852,10 +854,11 @@ static int batch_merged(msk_ctx* const* ctxs, int n, int op, uint32_t mask, hipS
       r.b_af = mc.t_af; mc.t_af += (N + 255) / 256;
       r.gm = x->solve_workers;
       r.b_cs = mc.t_cs; mc.t_cs += r.gm + (N + epw - 1) / epw;
-      np_launch_shape(N, x->plane_pairs, &r.np_group, &r.np_cfg);
+      np_launch_shape(N, x->plane_pairs, x->nverts_total, &r.np_group, &r.np_cfg);
       r.np_gx = (N + r.np_group - 1) / r.np_group;
       r.np_gy = r.np_cfg.nplane + r.np_cfg.nbox + r.np_cfg.nhull;
       r.b_np = mc.t_np;
+      mc.lds_np = std::max(mc.lds_np, (size_t)r.np_cfg.lds_words * sizeof(float));
       if (x->model.np > 0) { mc.t_np += r.np_gx * r.np_gy; mc.any_np = true; } else { r.np_gx = 0; }
       mc.lds_dyn = std::max(mc.lds_dyn, (size_t)DynLds(x->model.nb, md).total * sizeof(float) * epb);
       mc.lds_kin = std::max(mc.lds_kin, (size_t)DynLds(x->model.nb, 0).total * sizeof(float) * epb);
@@ -878,7 +881,7 @@ static int batch_merged(msk_ctx* const* ctxs, int n, int op, uint32_t mask, hipS
       if (lpe == 32) hipLaunchKernelGGL((k_multi_dynamics<32, 16>), dim3(mc.t_dyn), dim3(dyn_threads(mc.t_dyn)), mc.lds_dyn, s, mc.d_refs, n);
       else if (md == 16) hipLaunchKernelGGL((k_multi_dynamics<64, 16>), dim3(mc.t_dyn), dim3(dyn_threads(mc.t_dyn)), mc.lds_dyn, s, mc.d_refs, n);
       else hipLaunchKernelGGL((k_multi_dynamics<64, 32>), dim3(mc.t_dyn), dim3(dyn_threads(mc.t_dyn)), mc.lds_dyn, s, mc.d_refs, n);
-      hipLaunchKernelGGL(k_multi_narrowphase, dim3(mc.t_np), dim3(64), 0, s, mc.d_refs, n);
+      hipLaunchKernelGGL(k_multi_narrowphase, dim3(mc.t_np), dim3(64), mc.lds_np, s, mc.d_refs, n);
       if (G == 16) { auto k0 = k_multi_csolve<16, 16>; hipLaunchKernelGGL(k0, dim3(mc.t_cs), dim3(64), c->lds_solve, s, mc.d_refs, n); }
       else { auto k0 = k_multi_csolve<32, 32>; hipLaunchKernelGGL(k0, dim3(mc.t_cs), dim3(64), c->lds_solve, s, mc.d_refs, n); }
       for (int i = 0; i < n; ++i) ctxs[i]->kin_dirty = true;
