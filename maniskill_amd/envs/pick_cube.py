@@ -223,7 +223,9 @@ class PickCubeEnv:
         if self.camera is None:
             return state_obs
         self.camera.take_picture()
-        return dict(state=state_obs, sensor_data=dict(base_camera=self.camera.get_obs(**self._textures)),
+        from .. import graph as _graph
+        # inside a step-graph capture the replay snapshots every output once (graph._clone_tree): no first copy of the planes here
+        return dict(state=state_obs, sensor_data=dict(base_camera=self.camera.get_obs(copy=not _graph.CAPTURING, **self._textures)),
                     sensor_param=dict(base_camera=self.camera.get_params()))
 
     # ---------------------------------------------------------------- struct-style views

@@ -21,6 +21,8 @@ import torch
 
 
 _CONSTANTS = {}
+CAPTURING = False   # True while a StepGraph warms up / captures: the step's outputs are snapshotted by the replay anyway (_clone_tree), so code
+                    # inside the step hands out its static buffers (the camera planes) instead of cloning them a first time
 
 
 def const(values, device, dtype=torch.float32):
@@ -70,18 +72,23 @@ class StepGraph:
         self.action = torch.zeros(num_envs, action_dim, dtype=torch.float32, device=device)
         # eager warm-up on a side stream: lazy initialisation (module loads, allocator pools, lazily created camera
         # planes) must not happen inside the capture
+        global CAPTURING
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                step_fn(self.action)
-        torch.cuda.current_stream(device).wait_stream(side)
-        torch.cuda.synchronize(device)
-        self.graph = torch.cuda.CUDAGraph()
-        # thread_local: API calls of other host threads (RCCL's watchdog polling its events, a data loader) must not
-        # invalidate this thread's capture
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.out = step_fn(self.action)
+        CAPTURING = True
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    step_fn(self.action)
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize(device)
+            self.graph = torch.cuda.CUDAGraph()
+            # thread_local: API calls of other host threads (RCCL's watchdog polling its events, a data loader) must not
+            # invalidate this thread's capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.out = step_fn(self.action)
+        finally:
+            CAPTURING = False
         self.replays = 0
 
     def __call__(self, action):
