@@ -1,0 +1,20 @@
+"""On the GPU box: how long does the reference's gym.make take over the shim (build-time instancing)?
+    python tools/gpu_build_time.py [PickCube-v1] [16384]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ref_harness
+env_id = sys.argv[1] if len(sys.argv) > 1 else "PickCube-v1"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+gym = ref_harness.setup("hip")
+import torch
+t0 = time.perf_counter()
+env = gym.make(env_id, num_envs=n, render_backend="none")
+t1 = time.perf_counter()
+obs, _ = env.reset(seed=0)
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+for _ in range(3):
+    obs, *_ = env.step(torch.zeros(n, env.action_space.shape[-1], device=obs.device))
+torch.cuda.synchronize()
+print(f"{env_id} num_envs={n}: gym.make {t1 - t0:.1f} s, first reset {t2 - t1:.1f} s, obs {tuple(obs.shape)} finite {bool(torch.isfinite(obs).all())}")
