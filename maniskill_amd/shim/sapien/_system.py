@@ -607,6 +607,7 @@ class PhysxSystem:
         self._initialized = True
         if self._gc_paused:
             import gc
+            gc.unfreeze()     # (what an earlier scene froze is garbage by now if the caller reconfigured: let this collection see it)
             gc.collect()
             gc.freeze()       # the entity trees live as long as the scene: later collections need not walk them
             gc.enable()

@@ -111,9 +111,16 @@ def get_scene_config():
 
 
 # ----------------------------------------------------------------------------------------------------------- materials, shapes
+_MATERIAL_EPOCH = [0]   # bumped by every write to a material: cached shape signatures (PhysxCollisionShape._sig) carry the epoch they were made in
+
+
 class PhysxMaterial:
     def __init__(self, static_friction, dynamic_friction, restitution):
         self.static_friction, self.dynamic_friction, self.restitution = float(static_friction), float(dynamic_friction), float(restitution)
+
+    def __setattr__(self, k, v):
+        object.__setattr__(self, k, v)
+        _MATERIAL_EPOCH[0] += 1
 
     def get_static_friction(self):
         return self.static_friction
@@ -195,8 +202,8 @@ class PhysxCollisionShape:
         their float64 arrays.  `fold`: pose of the static entity the shape sits on (then nothing is cached)."""
         if fold is None:
             cached = self.__dict__.get("_sig_cache")
-            if cached is not None:
-                return cached
+            if cached is not None and cached[0] == _MATERIAL_EPOCH[0]:     # (materials are shared objects: a write to any of them re-reads them)
+                return cached[1]
         lp = self._local_pose if fold is None else fold * self._local_pose
         mat = self.physical_material
         base = (self._kind, tuple(self._groups), mat.static_friction, mat.dynamic_friction, mat.restitution, self.patch_radius,
@@ -222,7 +229,7 @@ class PhysxCollisionShape:
         else:
             raise TypeError(type(self))
         if fold is None:
-            self.__dict__["_sig_cache"] = out
+            self.__dict__["_sig_cache"] = (_MATERIAL_EPOCH[0], out)
         return out
 
     def _clone(self):
