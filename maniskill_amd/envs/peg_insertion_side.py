@@ -62,14 +62,13 @@ class PegInsertionSideEnv(PickCubeEnv):
         import ctypes as C
         L, px = self.px.lib, self.px
         N, dev = self.num_envs, self.device
-        obs = torch.empty(N, self.obs_dim, dtype=torch.float32, device=dev)
-        rew = torch.empty(N, dtype=torch.float32, device=dev)
-        fl = torch.empty(N, 8, dtype=torch.bool, device=dev)
-        head = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        from ..graph import alloc_step_outputs
+        obs, rew, fl, elapsed, head = alloc_step_outputs(N, self.obs_dim, dev, extra_floats=3)
         L.check(px.ctx, L.task_peg_observe(px.ctx, C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()), C.c_void_p(fl.data_ptr()),
                                            C.c_void_p(self._elapsed_steps.data_ptr()), C.c_void_p(head.data_ptr()),
                                            1 if advance else 0, px._stream()), "task_peg_observe")
-        info = dict(elapsed_steps=self._elapsed_steps.clone(), success=fl[:, 0], peg_head_pos_at_hole=head)
+        elapsed.copy_(self._elapsed_steps)
+        info = dict(elapsed_steps=elapsed, success=fl[:, 0], peg_head_pos_at_hole=head)
         return self._with_sensor_data(obs), self._fused_reward(rew, info), fl[:, 4], fl[:, 5], info
 
     # ---- scene -----------------------------------------------------------------------------------------------------------

@@ -533,13 +533,13 @@ class PickCubeEnv:
         # the kernel writes straight into this step's fresh output tensors (no staging buffers, no copies); the flag bytes
         # are 0 / 1, i.e. valid torch.bool storage
         N, dev = self.num_envs, self.device
-        obs = torch.empty(N, self.obs_dim, dtype=torch.float32, device=dev)
-        rew = torch.empty(N, dtype=torch.float32, device=dev)
-        fl = torch.empty(N, 8, dtype=torch.bool, device=dev)
+        from ..graph import alloc_step_outputs
+        obs, rew, fl, elapsed, _ = alloc_step_outputs(N, self.obs_dim, dev)     # one allocation: a graph replay snapshots it with one copy
         L.check(px.ctx, L.task_pickcube_observe(px.ctx, C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()),
                                                 C.c_void_p(fl.data_ptr()), C.c_void_p(self._elapsed_steps.data_ptr()),
                                                 1 if advance else 0, px._stream()), "task_pickcube_observe")
-        info = dict(elapsed_steps=self._elapsed_steps.clone(), success=fl[:, 0], is_obj_placed=fl[:, 1], is_robot_static=fl[:, 2],
+        elapsed.copy_(self._elapsed_steps)
+        info = dict(elapsed_steps=elapsed, success=fl[:, 0], is_obj_placed=fl[:, 1], is_robot_static=fl[:, 2],
                     is_grasped=fl[:, 3])
         return self._with_sensor_data(obs), self._fused_reward(rew, info), fl[:, 4], fl[:, 5], info
 

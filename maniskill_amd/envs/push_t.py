@@ -266,12 +266,12 @@ class PushTEnv:
         import ctypes as C
         L, px, N, dev = self.px.lib, self.px, self.num_envs, self.device
         od = self.obs_dim if self.camera is None else 21
-        obs = torch.empty(N, od, dtype=torch.float32, device=dev)
-        rew = torch.empty(N, dtype=torch.float32, device=dev)
-        fl = torch.empty(N, 8, dtype=torch.bool, device=dev)
+        from ..graph import alloc_step_outputs
+        obs, rew, fl, elapsed, _ = alloc_step_outputs(N, od, dev)
         L.check(px.ctx, L.task_pusht_observe(px.ctx, C.c_void_p(obs.data_ptr()), od, C.c_void_p(rew.data_ptr()), C.c_void_p(fl.data_ptr()),
                                              C.c_void_p(self._elapsed_steps.data_ptr()), 1 if advance else 0, px._stream()), "task_pusht_observe")
-        info = dict(elapsed_steps=self._elapsed_steps.clone(), success=fl[:, 0])
+        elapsed.copy_(self._elapsed_steps)
+        info = dict(elapsed_steps=elapsed, success=fl[:, 0])
         if self.camera is not None:
             self.camera.take_picture()
             obs = dict(state=obs, sensor_data=dict(base_camera=self.camera.get_obs(**self._textures)),

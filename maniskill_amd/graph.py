@@ -38,21 +38,53 @@ def const(values, device, dtype=torch.float32):
     return t
 
 
+def alloc_step_outputs(n: int, obs_dim: int, device, extra_floats: int = 0):
+    """Fresh output tensors of one fused step -- observations [n, obs_dim] f32, reward [n] f32, flag bytes [n, 8] bool, elapsed steps [n]
+    i32, optional extra [n, extra_floats] f32 -- carved out of ONE allocation: every tensor is contiguous on its own, and a step-graph
+    replay snapshots all of them with a single copy (_clone_tree) instead of one launch each."""
+    words = n * (obs_dim + 1 + 2 + 1 + extra_floats)
+    pack = torch.empty(words, dtype=torch.float32, device=device)
+    o = n * obs_dim
+    obs = pack[:o].view(n, obs_dim)
+    rew = pack[o:o + n]
+    fl = pack[o + n:o + 3 * n].view(torch.uint8).view(n, 8).view(torch.bool)
+    elapsed = pack[o + 3 * n:o + 4 * n].view(torch.int32)
+    extra = pack[o + 4 * n:].view(n, extra_floats) if extra_floats else None
+    return obs, rew, fl, elapsed, extra
+
+
+def _tensors_of(x, out):
+    if isinstance(x, torch.Tensor):
+        out.append(x)
+    elif isinstance(x, dict):
+        for v in x.values():
+            _tensors_of(v, out)
+    elif isinstance(x, (list, tuple)):
+        for v in x:
+            _tensors_of(v, out)
+
+
 def _clone_tree(x, _bases=None):
-    """Snapshots of every tensor a replay hands out.  Everything produced inside the capture — the camera planes under
-    ``sensor_data`` included: their ``.clone()`` in render.get_obs runs inside the graph and lands in a fixed pool allocation —
-    lives in memory the next replay overwrites, so callers get copies made after the replay.  Views of one small tensor (the task
-    kernels write all per-env flags into one [N, 8] byte tensor and hand out its columns as terminated / truncated / success / ...) are
-    copied ONCE, as their base, and re-sliced: each copy is a launch of its own behind the graph, and six of them were 4 % of a step."""
-    if _bases is None:
-        _bases = {}
+    """Snapshots of every tensor a replay hands out.  Everything produced inside the capture lives in memory the next replay
+    overwrites, so callers get copies made after the replay.  Views of one allocation (alloc_step_outputs; the columns of the task
+    kernels' flag bytes) are copied ONCE, as their base, and re-sliced: each copy is a launch of its own behind the graph."""
+    if _bases is None:      # first call: which bases are worth copying whole (their views cover at least half of them)
+        ts = []
+        _tensors_of(x, ts)
+        cover = {}
+        for t in ts:
+            if t._base is not None:
+                cover[id(t._base)] = cover.get(id(t._base), 0) + t.numel() * t.element_size()
+        _bases = {"whole": {k for k, v in cover.items()}, "cover": cover, "clones": {}}
     if isinstance(x, torch.Tensor):
         base = x._base
-        if base is not None and base.numel() <= 16 * x.numel():
-            c = _bases.get(id(base))
+        if base is not None and 2 * _bases["cover"].get(id(base), 0) >= base.numel() * base.element_size():
+            c = _bases["clones"].get(id(base))
             if c is None:
-                c = _bases[id(base)] = base.clone()
-            return c.as_strided(x.size(), x.stride(), x.storage_offset() - base.storage_offset())
+                c = _bases["clones"][id(base)] = base.clone()
+            off = x.storage_offset() * x.element_size() - base.storage_offset() * base.element_size()
+            cv = c if x.dtype == c.dtype else c.reshape(-1).view(x.dtype)
+            return cv.as_strided(x.size(), x.stride(), off // x.element_size())
         return x.clone()
     if isinstance(x, dict):
         return {k: _clone_tree(v, _bases) for k, v in x.items()}
