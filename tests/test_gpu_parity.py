@@ -471,3 +471,29 @@ def test_hip_vs_oracle_late_in_the_rollout(oracle_factory):
                 assert np.array_equal(ig, ic), (t, e)
     assert torch.allclose(gpu.get_state()[e0:e0 + m].cpu(), cpu.get_state(), rtol=1e-4, atol=1e-5)
     assert gpu.px.get_overflow() & 6 == 0
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 17, 63, 65, 130])
+def test_ragged_env_counts_match_the_oracle(oracle_factory, n):
+    """Env counts that fill no wavefront, no 4-env solver workgroup, no 16-env narrowphase group and no 64-env classification chunk evenly
+    (n = 1 is BASELINE config 1's size): every kernel runs with idle lanes / partial groups, and the result is still the oracle's, in the
+    eager and in the fused form (contact-pair ids included)."""
+    gpu = PickCubeEnv(num_envs=n, device=DEV, fused=False)
+    fus = PickCubeEnv(num_envs=n, device=DEV, fused=True)
+    cpu = PickCubeEnv(num_envs=n, px_factory=oracle_factory)
+    og, _ = gpu.reset(seed=11); of, _ = fus.reset(seed=11); oc, _ = cpu.reset(seed=11)
+    assert torch.equal(og.cpu(), oc)
+    gen = torch.Generator().manual_seed(n)
+    for t in range(30):
+        a = 2 * torch.rand(n, 8, generator=gen) - 1
+        og, rg, tg, ug, _ = gpu.step(a.to(DEV))
+        of, rf, *_ = fus.step(a.to(DEV))
+        oc, rc, tc, uc, _ = cpu.step(a)
+        assert _close(og.cpu().numpy(), oc.numpy()) and _close(rg.cpu().numpy(), rc.numpy()), (n, t)
+        assert _close(of.cpu().numpy(), oc.numpy()) and _close(rf.cpu().numpy(), rc.numpy()), (n, t, "fused")
+        assert torch.equal(tg.cpu(), tc) and torch.equal(ug.cpu(), uc)
+    for e in sorted({0, n // 2, n - 1}):
+        gi, gv = gpu.px.get_contacts(e)
+        ci, cv = cpu.px.get_contacts(e)
+        assert gi.shape == ci.shape and (gi == ci).all() and _close(gv, cv), (n, e)
+    assert gpu.px.get_overflow() & 6 == 0 and fus.px.get_overflow() & 6 == 0

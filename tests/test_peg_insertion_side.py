@@ -171,3 +171,22 @@ def test_hip_vs_oracle_at_config4_scale(oracle_factory):
             for e in (0, 100, 255):
                 assert np.array_equal(gpu.px.get_contacts(e)[0], cpu.px.get_contacts(e)[0]), (t, e)
     assert gpu.px.get_overflow() & 6 == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 5, 67])
+def test_ragged_env_counts_with_per_env_sizes_match_the_oracle(oracle_factory, n):
+    """Partial wavefronts / groups with per-env peg and hole sizes (the env records carry them): HIP == oracle for env counts that fill
+    nothing evenly."""
+    gpu = PegInsertionSideEnv(num_envs=n, device="cuda:0", fused=False)
+    cpu = PegInsertionSideEnv(num_envs=n, px_factory=oracle_factory)
+    og, _ = gpu.reset(seed=3); oc, _ = cpu.reset(seed=3)
+    assert torch.allclose(og.cpu(), oc, atol=2e-6)
+    gen = torch.Generator().manual_seed(10 + n)
+    for t in range(25):
+        a = 2 * torch.rand(n, 8, generator=gen) - 1
+        og, rg, *_ = gpu.step(a.to("cuda:0")); oc, rc, *_ = cpu.step(a)
+        assert torch.isfinite(og).all() and torch.isfinite(oc).all(), t
+        assert torch.allclose(og.cpu(), oc, rtol=1e-4, atol=1e-5), (n, t, float((og.cpu() - oc).abs().max()))
+    assert torch.allclose(gpu.get_state().cpu(), cpu.get_state(), rtol=1e-4, atol=1e-5)
+    assert gpu.px.get_overflow() & 6 == 0
