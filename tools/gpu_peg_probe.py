@@ -4,6 +4,9 @@ import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from maniskill_amd import _native as _N
+if os.environ.get("MSK_LIB"):
+    _N.DEFAULT_LIB = os.path.abspath(os.environ["MSK_LIB"])
 from maniskill_amd.envs.peg_insertion_side import PegInsertionSideEnv
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 env = PegInsertionSideEnv(num_envs=N, device="cuda:0")

@@ -11,8 +11,9 @@ if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(os.pa
 from maniskill_amd import _native as N
 N.DEFAULT_LIB = lib
 from maniskill_amd.envs.pick_cube import PickCubeEnv
+from maniskill_amd.envs.peg_insertion_side import PegInsertionSideEnv
 n = int(os.environ.get("PROBE_ENVS", "4096"))
-env = PickCubeEnv(num_envs=n, device="cuda:0")
+env = (PegInsertionSideEnv if os.environ.get("PROBE_ENV", "PickCube") == "Peg" else PickCubeEnv)(num_envs=n, device="cuda:0")
 env.reset(seed=2022); torch.manual_seed(0)
 dll = env.px.lib.dll
 dll.msk_debug_phases.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
