@@ -1,5 +1,5 @@
 """On the GPU box: HIP vs oracle over long rollouts from several seeds (a wider net than the -m gpu tests: every step of the early, middle
-and late regime of the same envs).   python tools/gpu_fuzz_parity.py [envs=128] [steps=400] [seeds=1,2,3]"""
+and late regime of the same envs).   python tools/gpu_fuzz_parity.py [envs=128] [steps=400] [seeds=1,2,3] [tasks=PickCube,Peg]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,10 +8,13 @@ import torch
 from oracle_backend import OraclePhysxSystem
 from maniskill_amd.envs.pick_cube import PickCubeEnv
 from maniskill_amd.envs.peg_insertion_side import PegInsertionSideEnv
+from maniskill_amd.envs.push_t import PushTEnv
+from maniskill_amd.envs.stack_cube import StackCubeEnv
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 seeds = [int(s) for s in (sys.argv[3] if len(sys.argv) > 3 else "1,2,3").split(",")]
-for cls in (PickCubeEnv, PegInsertionSideEnv):
+tasks = dict(PickCube=PickCubeEnv, Peg=PegInsertionSideEnv, PushT=PushTEnv, StackCube=StackCubeEnv)
+for cls in [tasks[k] for k in (sys.argv[4] if len(sys.argv) > 4 else "PickCube,Peg").split(",")]:
     for seed in seeds:
         gpu = cls(num_envs=n, device="cuda:0", fused=False)
         cpu = cls(num_envs=n, px_factory=lambda t, k, c: OraclePhysxSystem(t, k, c))
@@ -19,7 +22,7 @@ for cls in (PickCubeEnv, PegInsertionSideEnv):
         gen = torch.Generator().manual_seed(100 + seed)
         bit, worst = 0, 0.0
         for t in range(steps):
-            a = 2 * torch.rand(n, 8, generator=gen) - 1
+            a = 2 * torch.rand(n, gpu.action_dim, generator=gen) - 1
             og, *_ = gpu.step(a.to("cuda:0")); oc, *_ = cpu.step(a)
             d = float((og.cpu() - oc).abs().max())
             worst = max(worst, d); bit += int(d == 0.0)
