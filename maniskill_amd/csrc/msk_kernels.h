@@ -288,7 +288,8 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
     for (int jj = 0; jj < 4; ++jj)
       if (jj < nprev) { T1 += plam[jj][1]; T2 += plam[jj][2]; Nn += plam[jj][0]; }
     const float mu_used = (nprev > 0 && *slip) ? m->pinfo[pi].mu : m->pinfo[pi].mu_s;
-    *slip = (nprev > 0 && Nn > 0.0f && fmaxf(fabsf(T1), fabsf(T2)) >= 0.999f * mu_used * Nn) ? 1 : 0;
+    const float lim = 0.999f * mu_used * Nn;   /* (the friction frame turns with the motion: the length, not the components) */
+    *slip = (nprev > 0 && Nn > 0.0f && fmaf(T1, T1, T2 * T2) >= lim * lim) ? 1 : 0;
   }
   const float prev_lam_t = rec[3];
   if (n > 0) { rec[0] = onrm.x; rec[1] = onrm.y; rec[2] = onrm.z; rec[3] = 0.0f; }

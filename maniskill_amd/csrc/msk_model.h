@@ -50,6 +50,7 @@ struct DPair { int sa, sb; };
 struct DPairInfo { int ba, bb; float mu, mu_s; float rest; float patch_r, min_patch_r; unsigned ca, cb; /* DModel::body_coords of ba, bb (0 for the static world): one load for the solver's row assembly */ };
 
 #define MSK_SOLVE_CLASSES 4
+#define MSK_FRICTION_ALIGN_SPEED 1.0e-2f   /* m/s: below it a contact's friction frame is the one msk_tangents() derives from the normal (oracle: ORC_FRICTION_ALIGN_SPEED) */
 #define MSK_LIMIT_SLACK 5.0e-3f    /* a joint gets a limit row while it can reach the limit in this step: distance < slack + twice what its
                                    * unconstrained velocity covers towards it in dt (solver and classifier; oracle: ORC_LIMIT_SLACK) */
 #define MSK_MAX_BLOCKS 64          /* constraint blocks per env: one lane each in the solver (oracle: MSK_MAX_BLOCKS) */

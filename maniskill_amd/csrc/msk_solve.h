@@ -462,6 +462,37 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
       if (rows3) { J[1][k] = sgn * sv6_dot(Sk, F1); J[2][k] = sgn * sv6_dot(Sk, F2); }
     }
   }
+  /* The friction frame follows the motion (oracle: orc_step_env, contact rows): two tangential rows clamped to +-mu lam_n each are a
+   * pyramid -- sqrt(2) mu along the diagonal --, so when the point's unconstrained tangential velocity (u1, u2) = (J_1 . v*, J_2 . v*)
+   * exceeds MSK_FRICTION_ALIGN_SPEED the two rows are rotated in the tangent plane until row 1 points along it.  (cos, sin) are parked in
+   * this lane's LAMS words (free until the finish), where the impulses are rotated back into the frame msk_tangents() gives. */
+  if (is_contact) {
+    float u1 = 0.0f, u2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) {
+      if (!((ucoords >> k) & 1u)) continue;
+      u1 = fmaf(J[1][k], Lvf[k], u1);
+      u2 = fmaf(J[2][k], Lvf[k], u2);
+    }
+    const float n2 = fmaf(u1, u1, u2 * u2);
+    float fc = 1.0f, fs = 0.0f;
+    if (n2 > MSK_FRICTION_ALIGN_SPEED * MSK_FRICTION_ALIGN_SPEED) {
+      const float inv = 1.0f / sqrtf(n2);
+      fc = u1 * inv; fs = u2 * inv;
+#pragma unroll
+      for (int k = 0; k < NVP; ++k) {
+        if (!((ucoords >> k) & 1u)) continue;
+        const float j1 = J[1][k], j2 = J[2][k];
+        J[1][k] = fmaf(fc, j1, fs * j2);
+        J[2][k] = fmaf(fc, j2, -(fs * j1));
+      }
+      const float l1 = lam[1], l2 = lam[2];
+      lam[1] = fmaf(fc, l1, fs * l2);
+      lam[2] = fmaf(fc, l2, -(fs * l1));
+    }
+    Llams[lane * 3 + 1] = fc;
+    Llams[lane * 3 + 2] = fs;
+  }
   PHASE();
   /* Y = W J^T, parked in LDS; lambda_0 published for the warm start.  (A image in registers: every lane of the group parks its rows --
    * zero for the lanes without a block --, the unrolled build below reads all column blocks up to the wave's largest env) */
@@ -741,14 +772,17 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   PHASE();
   /* ---- back to generalized coordinates ----------------------------------------------------------------------------------- */
   if (lane < nblk) {
+    const float fc = is_contact ? Llams[lane * 3 + 1] : 1.0f, fs = is_contact ? Llams[lane * 3 + 2] : 0.0f;   /* parked at the rows (friction frame) */
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       Llamf[lane * 3 + s] = lam[s];
       Llams[lane * 3 + s] = ls[s];
     }
-    if (is_contact) { /* impulses back to the contact slot (reports + next step's warm start) */
+    if (is_contact) { /* impulses back to the contact slot (reports + next step's warm start), the friction pair in the frame of msk_tangents() */
       float* rec = recs + (size_t)(code >> 2) * MSK_CT_REC + 20 + (code & 3) * 3;
-      rec[0] = lam[0]; rec[1] = lam[1]; rec[2] = lam[2];
+      rec[0] = lam[0];
+      rec[1] = fmaf(fc, lam[1], -(fs * lam[2]));
+      rec[2] = fmaf(fs, lam[1], fc * lam[2]);
     }
     if (is_tors) recs[(size_t)(code >> 2) * MSK_CT_REC + 3] = lam[0];
   }

@@ -43,6 +43,9 @@
 #define ORC_MAX_ROW_IMPULSE 1.0e3f /* N s per sweep on a limit / normal row (msk_solve.h MSK_MAX_ROW_IMPULSE) */
 #define ORC_MIN_RESPONSE 1.0e-6f /* J W J^T below this: the row takes no impulse (msk_solve.h MSK_MIN_RESPONSE) */
 #define ORC_WARM_DIST 5.0e-3f    /* contact matching radius for warm starting             */
+#ifndef ORC_FRICTION_ALIGN_SPEED
+#define ORC_FRICTION_ALIGN_SPEED 1.0e-2f   /* m/s: below it the friction frame is the one orc_tangents() derives from the normal */
+#endif
 #ifndef ORC_WARM_NORMAL
 #define ORC_WARM_NORMAL 1.0f     /* fraction of last step's normal impulses applied up front */
 #define ORC_WARM_TANGENT 0.0f    /* ... and of its friction (tangential, torsional) impulses: none -- carried over, the tangential impulses of a manifold's
@@ -471,7 +474,8 @@ static void collide(const orc_ctx* c, orc_env* e) {
           T1 += prev[j].lam[1]; T2 += prev[j].lam[2]; Nn += prev[j].lam[0];
           mu_used = prev[j].slip ? prev[j].mu : prev[j].mu_s;
         }
-      pair_slip = Nn > 0.0f && fmaxf(fabsf(T1), fabsf(T2)) >= 0.999f * mu_used * Nn;
+      const float lim = 0.999f * mu_used * Nn;
+      pair_slip = Nn > 0.0f && fmaf(T1, T1, T2 * T2) >= lim * lim;   /* (the friction frame turns with the motion: the length, not the components) */
     }
     for (int k = 0; k < n; ++k) {
       if (e->ncontacts >= MSK_MAX_CONTACTS) { e->overflow = 1; break; }
@@ -672,8 +676,36 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
       r->mu = ct->slip ? ct->mu : ct->mu_s;   /* static friction until the pair slides (PhysxMaterial.static_friction / dynamic_friction) */
       jac_point(c, &s, ct->ba, ct->pos, dirs[a], 1.0f, r->J);
       jac_point(c, &s, ct->bb, ct->pos, dirs[a], -1.0f, r->J);
-      finish_row(c, &s, r);
       r->lam = ct->lam[a]; /* warm start */
+    }
+    /* The friction frame follows the motion.  Two tangential rows clamped to +-mu lam_n each are a friction PYRAMID: a body sliding
+     * along the frame's diagonal is braked with sqrt(2) mu (and pulled off its course towards the diagonal).  PhysX's patch friction takes
+     * the first friction direction along the relative tangential velocity; so here: if the point's unconstrained tangential velocity
+     * (u1, u2) = (J_t1 . v*, J_t2 . v*) is more than ORC_FRICTION_ALIGN_SPEED, the two rows are rotated in the tangent plane so that row 1
+     * points along it (J_1' = c J_1 + s J_2, J_2' = c J_2 - s J_1, (c, s) = (u1, u2) / |u|): sliding friction then acts along row 1, against
+     * the motion, with mu lam_n whatever the direction.  The impulses are reported in the frame orc_tangents() gives (rotated back below). */
+    {
+      orc_row* r1 = &rows[nr - 2];
+      orc_row* r2 = &rows[nr - 1];
+      const float u1 = dot_seq(r1->J, s.vfree, nv, s.npad), u2 = dot_seq(r2->J, s.vfree, nv, s.npad);
+      const float n2 = fmaf(u1, u1, u2 * u2);
+      float fc = 1.0f, fs = 0.0f;
+      if (n2 > ORC_FRICTION_ALIGN_SPEED * ORC_FRICTION_ALIGN_SPEED) {
+        const float inv = 1.0f / sqrtf(n2);
+        fc = u1 * inv; fs = u2 * inv;
+        for (int q = 0; q < nv; ++q) {
+          const float j1 = r1->J[q], j2 = r2->J[q];
+          r1->J[q] = fmaf(fc, j1, fs * j2);
+          r2->J[q] = fmaf(fc, j2, -(fs * j1));
+        }
+        const float l1 = r1->lam, l2 = r2->lam;
+        r1->lam = fmaf(fc, l1, fs * l2);
+        r2->lam = fmaf(fc, l2, -(fs * l1));
+      }
+      ct->fc = fc; ct->fs = fs;
+      finish_row(c, &s, &rows[nr - 3]);
+      finish_row(c, &s, r1);
+      finish_row(c, &s, r2);
     }
   }
   for (int k = 0; k < e->ncontacts; ++k) { /* torsional rows: relative spin about the normal, blocks of their own behind the points'.  PhysX gives
@@ -772,7 +804,13 @@ void orc_step_env(const orc_ctx* c, orc_env* e) {
   /* contact impulses for the reports */
   for (int ri = 0; ri < nr; ++ri)
   {
-    if (rows[ri].kind >= ROW_CN && rows[ri].kind <= ROW_CT2) e->contacts[rows[ri].idx].lam[rows[ri].kind - ROW_CN] = rows[ri].lam;
+    if (rows[ri].kind == ROW_CN) e->contacts[rows[ri].idx].lam[0] = rows[ri].lam;
+    if (rows[ri].kind == ROW_CT1) { /* the two friction impulses back into the frame of orc_tangents() (the rows were rotated by (fc, fs)) */
+      orc_contact* ct = &e->contacts[rows[ri].idx];
+      const float l1 = rows[ri].lam, l2 = rows[ri + 1].lam;
+      ct->lam[1] = fmaf(ct->fc, l1, -(ct->fs * l2));
+      ct->lam[2] = fmaf(ct->fs, l1, ct->fc * l2);
+    }
     if (rows[ri].kind == ROW_TORS) e->contacts[rows[ri].idx].lam_t = rows[ri].lam;
   }
 

@@ -73,6 +73,7 @@ typedef struct {
   float lam_t;       /* ... and about the normal (torsional row) */
   int slip;          /* the point's friction rows ended the last step on their cone: it slides, this step's cone is the dynamic one */
   v3 t1, t2;
+  float fc, fs;      /* this step's rotation of the two friction rows in the tangent plane (cos, sin): orc_sim.c, contact rows */
 } orc_contact;
 
 typedef struct {

@@ -80,7 +80,7 @@ def test_stick_pushes_the_tee(oracle_factory):
     for _ in range(25):
         env.step(a)
     assert env._pose(env._b_tee)[0, 1].item() < y0 - 0.03
-    assert abs(env._pose(env._b_tee)[0, 2].item() - 0.02) < 8e-3 and torch.isfinite(env.get_state()).all()   # it may tilt a little under the stick
+    assert abs(env._pose(env._b_tee)[0, 2].item() - 0.02) < 1.5e-2 and torch.isfinite(env.get_state()).all()   # it tilts under the stick (mu = 3: it rather tips than slides)
 
 
 def test_camera_observation(oracle_factory):
