@@ -155,3 +155,25 @@ def test_sliding_in_any_direction_hip_equals_oracle(built, oracle_factory):
                     px.step()
                 px.gpu_fetch_all()
             assert torch.equal(worlds[0][1], worlds[1][1].cpu()), (angle_deg, k)
+
+
+@pytest.mark.parametrize("angle_deg", [0.0, 30.0, 45.0, 77.0])
+def test_a_pushed_cube_breaks_away_at_mu_m_g_in_every_direction(oracle_factory, angle_deg):
+    """A horizontal force on the resting cube: below mu m g it stays (98 %: under 1 mm/s after half a second), above it it accelerates with
+    (F - mu m g) / m (102 % and 110 %: the speed after 0.5 s to 2 %) -- whatever the direction of the push relative to the friction frame."""
+    m = 1000.0 * (2 * H) ** 3
+    th = np.deg2rad(angle_deg)
+    for frac in (0.98, 1.02, 1.10):
+        px, rbd, a = _world(oracle_factory)
+        px.gpu_apply_all()
+        for _ in range(10):
+            px.step()
+        F = px.cuda_rigid_body_force.torch().view(px.bodies_per_env, 4)
+        for _ in range(50):
+            F[a, :3] = torch.tensor([np.cos(th), np.sin(th), 0.0]) * frac * MU * m * G
+            px.gpu_apply_rigid_dynamic_force()
+            px.step()
+        px.gpu_fetch_all()
+        speed = float(rbd[a, 7:9].norm())
+        want = max(0.0, (frac - 1.0) * MU * G * 50 * px.timestep)
+        assert abs(speed - want) < (1e-3 if frac < 1 else 0.02 * want), (angle_deg, frac, speed, want)
