@@ -95,6 +95,12 @@ class PegInsertionSideEnv(PickCubeEnv):
     def _hidden_bodies(self):
         return ()
 
+    def _camera_configs(self, tpl):
+        """base_camera (:93-96) and the agent's hand_camera on camera_link (agents/robots/panda/panda_wristcam.py:19-32)."""
+        from ..render import CameraConfig
+        hand = CameraConfig("hand_camera", (0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0), 128, 128, np.pi / 2, 0.01, 100.0, mount=tpl.body_id("camera_link"))
+        return super()._camera_configs(tpl) + [hand]
+
     def _after_gpu_init(self):
         """Sizes drawn once per env from its own seed (the reference draws them at reconfiguration, :114-131)."""
         n = self.num_envs

@@ -208,25 +208,33 @@ class PickCubeEnv:
         # obs mode -> textures (sapien_env.py:120-160 parse_obs_mode_to_struct)
         self._textures = dict(rgb="rgb" in obs_mode, depth=("depth" in obs_mode or obs_mode == "rgbd"), segmentation="segmentation" in obs_mode)
         self._want_color = self._textures["rgb"]
-        self.camera = None
+        self.camera, self.cameras = None, {}
         if obs_mode != "state":
-            from ..render import CameraConfig, RenderCameraGroup, attach_template_visuals, look_at
+            from ..render import RenderCameraGroup, attach_template_visuals
             attach_template_visuals(self.px, tpl, hidden_bodies=self._hidden_bodies())
-            p, q = look_at(eye=self.camera_eye, target=self.camera_target)
-            self.camera = RenderCameraGroup(self.px, CameraConfig("base_camera", p, q, 128, 128, np.pi / 2, 0.01, 100.0))
-            if self._want_color:
-                self.camera.enable_color()
+            for cfg in self._camera_configs(tpl):      # the env's sensors, then the agent's (sapien_env.py _setup_sensors)
+                self.cameras[cfg.uid] = RenderCameraGroup(self.px, cfg)
+                if self._want_color:
+                    self.cameras[cfg.uid].enable_color()
+            self.camera = self.cameras["base_camera"]
         self.reset(seed=None)
+
+    def _camera_configs(self, tpl):
+        from ..render import CameraConfig, look_at
+        p, q = look_at(eye=self.camera_eye, target=self.camera_target)
+        return [CameraConfig("base_camera", p, q, 128, 128, np.pi / 2, 0.01, 100.0)]
 
     def _with_sensor_data(self, state_obs):
         """_get_obs_with_sensor_data (sapien_env.py:627-634): update_render, take_picture, texture transforms."""
         if self.camera is None:
             return state_obs
-        self.camera.take_picture()
         from .. import graph as _graph
+        for cam in self.cameras.values():
+            cam.take_picture()
         # inside a step-graph capture the replay snapshots every output once (graph._clone_tree): no first copy of the planes here
-        return dict(state=state_obs, sensor_data=dict(base_camera=self.camera.get_obs(copy=not _graph.CAPTURING, **self._textures)),
-                    sensor_param=dict(base_camera=self.camera.get_params()))
+        return dict(state=state_obs,
+                    sensor_data={uid: cam.get_obs(copy=not _graph.CAPTURING, **self._textures) for uid, cam in self.cameras.items()},
+                    sensor_param={uid: cam.get_params() for uid, cam in self.cameras.items()})
 
     # ---------------------------------------------------------------- struct-style views
     def _fresh(self):

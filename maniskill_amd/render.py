@@ -158,6 +158,7 @@ class RenderCameraGroup:
         # intrinsics of set_fovy(fovy, compute_x=True) (scene.py:250-257)
         fy = 0.5 * cfg.height / np.tan(0.5 * cfg.fov)
         self.intrinsic_cv = torch.tensor([[fy, 0, 0.5 * cfg.width], [0, fy, 0.5 * cfg.height], [0, 0, 1]], dtype=torch.float32)
+        self._local = None
         self._cached_extrinsic = None
         self._cached_intrinsic = None
         self._cached_model = None
@@ -179,7 +180,9 @@ class RenderCameraGroup:
     def get_global_pose(self) -> torch.Tensor:
         """(N, 7) camera pose in its sub-scene's frame: the local pose, or mount.pose * local_pose (render_camera.py:313-317)."""
         cfg, px = self.cfg, self.px
-        local = torch.tensor(list(cfg.p) + list(cfg.q), dtype=torch.float32, device=px.device)
+        if self._local is None:      # uploaded once: a host-to-device copy per call could not be captured into a step graph
+            self._local = torch.tensor(list(cfg.p) + list(cfg.q), dtype=torch.float32, device=px.device)
+        local = self._local
         N = px.num_envs
         if cfg.mount < 0:
             return local[None].repeat(N, 1)
@@ -203,7 +206,13 @@ class RenderCameraGroup:
             return self._cached_extrinsic
         g = self.get_global_pose()
         T = self._pose_to_matrix(g[:, :3], g[:, 3:7])
-        Tinv = torch.linalg.inv(T)
+        # inverse of a rigid transform, written out (Pose.inv() in the reference; torch.linalg.inv checks its `info` on the host, which a
+        # graph capture refuses): [R p]^-1 = [R^T  -R^T p]
+        Tinv = torch.zeros_like(T)
+        Rt = T[:, :3, :3].transpose(1, 2)
+        Tinv[:, :3, :3] = Rt
+        Tinv[:, :3, 3] = -(Rt @ T[:, :3, 3:4])[:, :, 0]
+        Tinv[:, 3, 3] = 1
         ros2opencv = const(((0, 0, 1, 0), (-1, 0, 0, 0), (0, -1, 0, 0), (0, 0, 0, 1)), g.device).T
         res = (ros2opencv @ Tinv)[:, :3, :4]
         if self.cfg.mount < 0:

@@ -46,6 +46,45 @@ def test_a_peg_put_into_its_hole_is_a_success_and_stays_there(oracle_factory):
     assert not env.has_peg_inserted()[0].any()
 
 
+def test_the_hand_camera_rides_on_camera_link_and_sees_the_table_where_its_ray_meets_it(oracle_factory):
+    """panda_wristcam's hand_camera (agents/robots/panda/panda_wristcam.py:19-32: 128 x 128, fov pi / 2, identity pose on camera_link).
+    Known answers: its model matrix is camera_link's pose (OpenGL axes: x = -left, y = up, z = -forward of the link's x-forward frame);
+    where the centre pixel shows the table, its depth is the forward distance at which that pixel's ray meets the plane z = 0; after a
+    few steps of arm motion the camera has moved with the link."""
+    env = PegInsertionSideEnv(num_envs=3, px_factory=oracle_factory, obs_mode="depth+segmentation")
+    obs, _ = env.reset(seed=0)
+    assert list(obs["sensor_data"]) == ["base_camera", "hand_camera"] and list(obs["sensor_param"]) == ["base_camera", "hand_camera"]
+    link = env.px.template.body_id("camera_link")
+    table_id = env.px.template.body_id("table-workspace") + 1
+
+    def check(obs):
+        pose = env._pose(link)
+        M = obs["sensor_param"]["hand_camera"]["cam2world_gl"]
+        R = torch.stack([env._qrot(pose[:, 3:7], torch.tensor(v).expand(3, 3)) for v in ([1.0, 0, 0], [0.0, 1, 0], [0.0, 0, 1])], dim=-1)  # columns: forward, left, up
+        assert torch.allclose(M[:, :3, 3], pose[:, :3], atol=1e-6)
+        assert torch.allclose(M[:, :3, 0], -R[:, :, 1], atol=1e-5) and torch.allclose(M[:, :3, 1], R[:, :, 2], atol=1e-5) and torch.allclose(M[:, :3, 2], -R[:, :, 0], atol=1e-5)
+        depth, seg = obs["sensor_data"]["hand_camera"]["depth"], obs["sensor_data"]["hand_camera"]["segmentation"]
+        seen = 0
+        for e in range(3):
+            for (i, j) in ((64, 64), (20, 30), (100, 90)):
+                if seg[e, i, j, 0].item() != table_id:
+                    continue
+                # pixel (row i, column j), centre at (j + 0.5, i + 0.5); focal length 64 pixels at fov pi / 2: ray = forward - left (u - 64) / 64 - up (v - 64) / 64
+                d = R[e, :, 0] - R[e, :, 1] * ((j + 0.5 - 64) / 64) - R[e, :, 2] * ((i + 0.5 - 64) / 64)
+                t = -pose[e, 2] / d[2]                      # the table top is the plane z = 0 of the sub-scene
+                assert abs(depth[e, i, j, 0].item() - 1000.0 * t.item()) <= 1.0, (e, i, j, depth[e, i, j, 0].item(), 1000.0 * t.item())
+                seen += 1
+        assert seen >= 3
+        return pose.clone()
+
+    p0 = check(obs)
+    a = torch.zeros(3, 8); a[:, 1] = -1.0; a[:, 3] = 1.0
+    for _ in range(5):
+        obs = env.step(a)[0]
+    p1 = check(obs)
+    assert (p1[:, :3] - p0[:, :3]).norm(dim=1).min().item() > 0.01
+
+
 @pytest.mark.gpu
 def test_hip_matches_oracle_rollout(oracle_factory):
     n = 64
@@ -62,9 +101,13 @@ def test_hip_matches_oracle_rollout(oracle_factory):
         oc, rc, tc, uc, _ = cpu.step(a)
         assert np.allclose(og["state"].cpu().numpy(), oc["state"].numpy(), rtol=1e-4, atol=1e-5), t
         assert np.allclose(rg.cpu().numpy(), rc.numpy(), atol=2e-5) and torch.equal(tg.cpu(), tc)
-    cg, cc = og["sensor_data"]["base_camera"], oc["sensor_data"]["base_camera"]
-    assert torch.equal(cg["rgb"].cpu(), cc["rgb"]) and torch.equal(cg["depth"].cpu(), cc["depth"])
-    assert torch.equal(cg["segmentation"].cpu(), cc["segmentation"])
+    assert list(og["sensor_data"]) == ["base_camera", "hand_camera"]
+    for uid in ("base_camera", "hand_camera"):          # the fixed camera and the one riding on camera_link, after 30 random steps
+        cg, cc = og["sensor_data"][uid], oc["sensor_data"][uid]
+        assert torch.equal(cg["rgb"].cpu(), cc["rgb"]) and torch.equal(cg["depth"].cpu(), cc["depth"]), uid
+        assert torch.equal(cg["segmentation"].cpu(), cc["segmentation"]), uid
+        for k in ("extrinsic_cv", "cam2world_gl", "intrinsic_cv"):
+            assert torch.allclose(og["sensor_param"][uid][k].cpu(), oc["sensor_param"][uid][k], rtol=1e-4, atol=1e-5), (uid, k)
     # inserted pegs stay inserted on the GPU too
     for env in (gpu, cpu):
         goal = env.goal_pose

@@ -62,6 +62,22 @@ def test_graph_replay_equals_eager_fused_path_with_camera():
 
 
 @pytest.mark.gpu
+def test_graph_replay_with_a_mounted_camera_equals_eager():
+    """PegInsertionSide's hand_camera rides on camera_link: its picture and its per-step camera matrices (pose product and rigid inverse,
+    written without host-checked linear algebra) are part of the captured step."""
+    from maniskill_amd.envs.peg_insertion_side import PegInsertionSideEnv
+    make = lambda: PegInsertionSideEnv(num_envs=48, device="cuda:0", obs_mode="depth+segmentation")   # noqa: E731
+    eager, graphed, e, r = _rollout_pair(make, steps=6, scale=1.0)
+    for uid in ("base_camera", "hand_camera"):
+        de, dr = e[0]["sensor_data"][uid], r[0]["sensor_data"][uid]
+        assert torch.equal(de["depth"], dr["depth"]) and torch.equal(de["segmentation"], dr["segmentation"]), uid
+        for k in ("extrinsic_cv", "cam2world_gl", "intrinsic_cv"):
+            assert torch.equal(e[0]["sensor_param"][uid][k], r[0]["sensor_param"][uid][k]), (uid, k)
+    moved = (r[0]["sensor_param"]["hand_camera"]["cam2world_gl"][:, :3, 3] - graphed.reset(seed=3)[0]["sensor_param"]["hand_camera"]["cam2world_gl"][:, :3, 3]).norm(dim=1)
+    assert moved.min().item() > 1e-3
+
+
+@pytest.mark.gpu
 def test_outputs_of_a_replay_survive_the_next_replay():
     from maniskill_amd.envs.push_cube import PushCubeEnv
     env = PushCubeEnv(num_envs=32, device="cuda:0")
