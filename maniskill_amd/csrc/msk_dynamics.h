@@ -493,7 +493,9 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
     if (rowlane && !(Kd == 0.0f && Dd == 0.0f)) {
       const float vfi = vec[DV_VF * MD + i];
       const float F = -Kd * fmaf(dt, vfi, err) - Dd * (vfi - qdt_i);
-      if (fabsf(F) > fmax_i) {
+      /* ... and the force of the stalled joint (v = 0: a link that a contact holds back loses the damping term the free prediction counts on) */
+      const float Fstall = fmaf(Dd, qdt_i, -(Kd * err));
+      if (fabsf(F) > fmax_i || fabsf(Fstall) > fmax_i) {
         const float cfm = 1.0f / (dt * fmaf(dt, Kd, Dd));
         if (live) {
           float4 rec;

@@ -324,7 +324,10 @@ static void dynamics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
     for (int i = 0; i < nd; ++i) {
       if (Kd[i] == 0.0f && Dd[i] == 0.0f) continue;
       float F = -Kd[i] * fmaf(dt, s->vfree[i], err[i]) - Dd[i] * (s->vfree[i] - e->qdt[i]);
-      if (fabsf(F) > fmaxd[i]) {
+      /* ... and the force of the stalled joint (v = 0: a link that a contact holds back loses the damping term the free prediction counts on:
+       * K err alone may be several times the limit while the prediction at v* stays under it) */
+      const float Fstall = fmaf(Dd[i], e->qdt[i], -(Kd[i] * err[i]));
+      if (fabsf(F) > fmaxd[i] || fabsf(Fstall) > fmaxd[i]) {
         const float cfm = 1.0f / (dt * fmaf(dt, Kd[i], Dd[i]));
         s->drv_on[i] = 1;
         s->drv_cfm[i] = cfm;
