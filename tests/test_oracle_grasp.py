@@ -84,3 +84,17 @@ def test_above_it_the_cube_is_held(oracle_factory, F):
     assert worst < 2e-2, worst
     if F >= 3.0:      # (caught at 1.6 times its weight the cube slides a centimetre first and may turn about the pads' axis while it does)
         assert abs(rbd[cube, 3].item()) > 0.9999
+
+
+@pytest.mark.gpu
+def test_grasp_hip_equals_oracle(built, oracle_factory):
+    """Sliding between the pads (0.5 N) and caught (3 N): the HIP solver follows the oracle bit for bit."""
+    from maniskill_amd.physx import PhysxGpuSystem
+    for F in (0.5, 3.0):
+        worlds = [_gripper(oracle_factory, F), _gripper(lambda t, n, c: PhysxGpuSystem("cuda:0", t, n, c), F)]
+        for k in range(10):
+            for px, *_ in worlds:
+                for _ in range(3):
+                    px.step()
+                px.gpu_fetch_all()
+            assert torch.equal(worlds[0][1], worlds[1][1].cpu()), (F, k)
