@@ -104,3 +104,40 @@ def test_a_hard_squeeze_does_not_push_the_cube_into_the_table(oracle_factory):
         px.gpu_fetch_all()
         worst = min(worst, rbd[cube, 2].item())
     assert worst > H - 2e-3, worst
+
+
+@pytest.mark.parametrize("ratio,dip", [(1, 0.2e-3), (10, 1.0e-3), (30, 3.0e-3)])
+def test_a_heavy_cube_on_a_light_one_settles_with_exact_forces(oracle_factory, ratio, dip):
+    """The same chain with weight instead of a drive: table - 64 g cube - cube of `ratio` times its mass, put down touching.  The forces
+    end exact (table -> light = (m1 + m2) g, light -> heavy = m2 g) and the stack ends where it was built; on the way the light cube dips
+    0.1 / 0.8 / 2.6 mm.  (At a ratio of 100 -- 6.4 kg on 64 g -- it is pressed through the table top: DESIGN 8, the squeeze leak.)"""
+    m1 = M_CUBE
+    m2 = ratio * m1
+    tpl = SceneTemplate()
+    sb.add_table_scene(tpl)
+    a = tpl.add_actor("light", N.BODY_DYNAMIC, p=(0, 0, H), mass=m1, inertia6=(m1 / 6 * (2 * H) ** 2,) * 3 + (0, 0, 0))
+    tpl.add_shape(a, N.SHAPE_BOX, params=(H, H, H))
+    b = tpl.add_actor("heavy", N.BODY_DYNAMIC, p=(0, 0, 3 * H), mass=m2, inertia6=(m2 / 6 * (2 * H) ** 2,) * 3 + (0, 0, 0))
+    tpl.add_shape(b, N.SHAPE_BOX, params=(H, H, H))
+    px = oracle_factory(tpl, 1, SimConfig())
+    px.gpu_init()
+    px.set_scene_offsets(np.zeros((1, 3)))
+    rbd = px.cuda_rigid_body_data.torch().view(px.bodies_per_env, 13)
+    table = tpl.body_id("table-workspace")
+    rbd[table, :7] = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)])
+    rbd[a, :7] = torch.tensor([0, 0, H, 1, 0, 0, 0])
+    rbd[b, :7] = torch.tensor([0, 0, 3 * H, 1, 0, 0, 0])
+    rbd[a, 7:13] = 0
+    rbd[b, 7:13] = 0
+    px.gpu_apply_all()
+    query = px.gpu_create_contact_pair_impulse_query([(a, table), (b, a)])
+    lowest = H
+    for _ in range(300):
+        px.step()
+        px.gpu_fetch_all()
+        lowest = min(lowest, rbd[a, 2].item())
+    px.gpu_query_contact_pair_impulses(query)
+    f = query.cuda_impulses.torch().view(2, 3)[:, 2] / px.timestep
+    assert abs(f[0].item() - (m1 + m2) * G) < 1e-3 * (m1 + m2) * G and abs(f[1].item() - m2 * G) < 1e-3 * m2 * G, f
+    assert H - lowest < dip, H - lowest
+    assert abs(rbd[a, 2].item() - H) < 1e-5 and abs(rbd[b, 2].item() - 3 * H) < 2e-5 and rbd[[a, b], 7:13].abs().max().item() < 1e-4
