@@ -1,0 +1,67 @@
+"""Random piles of mixed shapes (box, sphere, capsule, cylinder, random hull) dropped into a walled pen on the table, on the CPU oracle.
+A seed is SEVERE when after five seconds some body still reports more than 5 cm/s and 3 rad/s (the signature of a body stuck inside
+static geometry: velocity for ever, position static) or the state is not finite; the looser flag also fires on bodies that merely roll.
+    python tools/oracle_pen_fuzz.py [seeds=40] [kinds=box,sphere,capsule,cylinder,hull]
+Round 3, main: 7 severe of 40 hull,box pens; branch r04-deep-feature: 0."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import warnings; warnings.simplefilter("ignore")
+import numpy as np, torch
+from oracle_backend import OraclePhysxSystem
+from maniskill_amd import _native as N
+from maniskill_amd.envs import scene_builders as sb
+from maniskill_amd.physx import SceneTemplate, SimConfig
+def quat_rand(rng):
+    q = rng.normal(size=4); return q/np.linalg.norm(q)
+bad = severe = 0
+nseeds = int(sys.argv[1]) if len(sys.argv)>1 else 40
+kinds_allowed = sys.argv[2].split(",") if len(sys.argv)>2 else ["box","sphere","capsule","cylinder","hull"]
+for seed in range(nseeds):
+    rng = np.random.default_rng(1000+seed)
+    tpl = SceneTemplate(); sb.add_table_scene(tpl)
+    W = 0.09
+    for (px_, py_, hx, hy) in ((W+0.01,0,0.01,W+0.02),(-W-0.01,0,0.01,W+0.02),(0,W+0.01,W+0.02,0.01),(0,-W-0.01,W+0.02,0.01)):
+        tpl.add_shape(-1, N.SHAPE_BOX, p=(px_,py_,0.04), params=(hx,hy,0.04))
+    nb = rng.integers(2, 6); bodies=[]; kinds=[]; rmin=[]
+    for k in range(nb):
+        kind = rng.choice(kinds_allowed); dens = rng.uniform(300, 3000)
+        if kind=="box":
+            hs = rng.uniform(0.01, 0.03, size=3); m = dens*8*hs.prod(); I = m/3*np.array([hs[1]**2+hs[2]**2, hs[0]**2+hs[2]**2, hs[0]**2+hs[1]**2])
+            b = tpl.add_actor(f"b{k}", N.BODY_DYNAMIC, p=(0,0,1), mass=m, inertia6=tuple(I)+(0,0,0)); tpl.add_shape(b, N.SHAPE_BOX, params=tuple(hs)); rmin.append(hs.min())
+        elif kind=="sphere":
+            r = rng.uniform(0.01,0.03); m = dens*4/3*np.pi*r**3
+            b = tpl.add_actor(f"b{k}", N.BODY_DYNAMIC, p=(0,0,1), mass=m, inertia6=(0.4*m*r*r,)*3+(0,0,0)); tpl.add_shape(b, N.SHAPE_SPHERE, params=(r,0,0)); rmin.append(r)
+        elif kind=="capsule":
+            r = rng.uniform(0.008,0.02); hl = rng.uniform(0.01,0.03); m = dens*(np.pi*r*r*2*hl+4/3*np.pi*r**3)
+            I = (0.5*m*r*r, m*(r*r/4+hl*hl/3), m*(r*r/4+hl*hl/3))
+            b = tpl.add_actor(f"b{k}", N.BODY_DYNAMIC, p=(0,0,1), mass=m, inertia6=I+(0,0,0)); tpl.add_shape(b, N.SHAPE_CAPSULE, params=(r,hl,0)); rmin.append(r)
+        elif kind=="cylinder":
+            r = rng.uniform(0.01,0.025); hl = rng.uniform(0.01,0.03); m = dens*np.pi*r*r*2*hl
+            I = (0.5*m*r*r, m*(r*r/4+hl*hl/3), m*(r*r/4+hl*hl/3))
+            b = tpl.add_actor(f"b{k}", N.BODY_DYNAMIC, p=(0,0,1), mass=m, inertia6=I+(0,0,0)); tpl.add_shape(b, N.SHAPE_CYLINDER, params=(r,hl,0)); rmin.append(min(r,hl))
+        else:
+            nvx = rng.integers(5, 12); V = rng.normal(size=(nvx,3)); V = V/np.linalg.norm(V,axis=1,keepdims=True)*rng.uniform(0.015,0.03)
+            m = dens*4/3*np.pi*0.02**3; 
+            b = tpl.add_actor(f"b{k}", N.BODY_DYNAMIC, p=(0,0,1), mass=m, inertia6=(0.4*m*0.02**2,)*3+(0,0,0)); tpl.add_shape(b, N.SHAPE_CONVEX, verts=V); rmin.append(0.004)
+        bodies.append(b); kinds.append(str(kind))
+    px = OraclePhysxSystem(tpl, 1, SimConfig()); px.gpu_init(); px.set_scene_offsets(np.zeros((1,3)))
+    rbd = px.cuda_rigid_body_data.torch().view(px.bodies_per_env, 13)
+    rbd[tpl.body_id("table-workspace"), :7] = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)])
+    for k,b in enumerate(bodies):
+        rbd[b,:3] = torch.tensor([rng.uniform(-0.03,0.03), rng.uniform(-0.03,0.03), 0.06+0.07*k], dtype=torch.float32)
+        rbd[b,3:7] = torch.tensor(quat_rand(rng), dtype=torch.float32); rbd[b,7:13] = torch.tensor(rng.normal(size=6)*np.array([0.2,0.2,0.2,2,2,2]), dtype=torch.float32)
+    px.gpu_apply_all()
+    vmax=0; pen=0
+    rm = torch.tensor(rmin, dtype=torch.float32)
+    for t in range(500):
+        px.step(); px.gpu_fetch_all()
+        vmax=max(vmax, rbd[bodies,7:10].norm(dim=1).max().item()); pen = max(pen, (rm - rbd[bodies,2]).max().item())
+    fin = bool(torch.isfinite(rbd).all()); vend = rbd[bodies,7:10].norm(dim=1).max().item(); wend = rbd[bodies,10:13].norm(dim=1).max().item()
+    inside = ((rbd[bodies,0].abs() < W+0.005) & (rbd[bodies,1].abs() < W+0.005)).all().item() or (rbd[bodies,2] > 0.07).any().item()
+    flag = (not fin) or vmax>6 or pen > 0.004 or vend>0.03 or wend > 1.5 or not inside
+    bad += flag
+    sev = (not fin) or (vend > 0.05 and wend > 3.0)
+    severe += sev
+    if flag or seed<2: print(1000+seed, nb, kinds, "finite",fin,"vmax %.2f pen %.4f vend %.4f wend %.3f inside %s ovf %d"%(vmax,pen,vend,wend,inside,px.get_overflow()), ("SEVERE" if sev else "<<<") if flag else "")
+print("flagged", bad, "severe", severe, "of", nseeds)
