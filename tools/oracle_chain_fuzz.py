@@ -1,0 +1,73 @@
+"""Random serial chains on the CPU oracle: 2-5 light capsule links (50-500 g, 10 cm) on revolute joints with limits, PD drives of random stiffness
+(30-1000) and force limit (1-100), targets redrawn every 25 steps (some beyond the limits), hanging over the table next to a loose box.
+Reports the worst joint-limit overshoot, the largest joint speed and whether anything went through the table.
+    python tools/oracle_chain_fuzz.py [seeds=20]
+Round 3: 8 of 16 chains overshoot a limit by more than 0.05 rad (up to 0.58) while a stiff drive jams the chain against the table -- the
+limit row is there and unsaturated, Gauss-Seidel does not converge on the closed, ill-conditioned loop.  The Panda of the
+benchmarked tasks stays within 0.0002 rad (arm) / 4 mm (fingers) of its limits over 256 envs x 600 random actions."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import warnings; warnings.simplefilter("ignore")
+import numpy as np, torch
+from oracle_backend import OraclePhysxSystem
+from maniskill_amd import _native as N
+from maniskill_amd.envs import scene_builders as sb
+from maniskill_amd.physx import SceneTemplate, SimConfig
+def qaxis(axis, ang):
+    axis = np.asarray(axis, float); axis /= np.linalg.norm(axis); return (np.cos(ang/2),) + tuple(np.sin(ang/2)*axis)
+nseeds = int(sys.argv[1]) if len(sys.argv)>1 else 20
+bad = 0
+for seed in range(nseeds):
+    rng = np.random.default_rng(7000+seed)
+    tpl = SceneTemplate(); sb.add_table_scene(tpl)
+    h0 = rng.uniform(0.15, 0.35)
+    art = tpl.add_articulation("chain", root_p=(0, 0, h0))
+    base = tpl.add_link(art, "base", -1, N.JOINT_FIXED, mass=1.0, inertia6=(1e-2,)*3+(0,0,0))
+    nl = rng.integers(2, 6); links=[]; lims=[]
+    parent = base; L = 0.1
+    for k in range(nl):
+        # joint frame: x = joint axis; choose the axis among parent's y or z so that the chain (along parent's x) bends
+        ax = rng.choice(["y","z"])
+        qj = qaxis((0,0,1), np.pi/2) if ax=="y" else qaxis((0,1,0), -np.pi/2)     # rotate frame so its x is along parent's y / z
+        m = rng.uniform(0.05, 0.5); r = rng.uniform(0.012, 0.025)
+        lo, hi = -rng.uniform(0.5, 2.0), rng.uniform(0.5, 2.0)
+        # child link frame origin at the joint; its body extends along its local x by L: pose_in_child = joint frame in child = same rotation at origin
+        lk = tpl.add_link(art, f"l{k}", parent, N.JOINT_REVOLUTE, joint_name=f"j{k}", pose_in_parent=((L if k>0 else 0.0),0,0)+qj, pose_in_child=(0,0,0)+qj,
+                          mass=m, com=(L/2,0,0), inertia6=(0.5*m*r*r, m*L*L/12, m*L*L/12, 0,0,0), limits=(lo,hi))
+        tpl.add_shape(lk, N.SHAPE_CAPSULE, p=(L/2,0,0), params=(r, L/2 - r*0.5, 0))
+        K = 10**rng.uniform(1.5,3); D = K/10; fmax = 10**rng.uniform(0,2)
+        tpl.set_drive(lk, K, D, fmax, "force")
+        links.append(lk); lims.append((lo,hi)); parent = lk
+    # a loose box to hit
+    hs = rng.uniform(0.015,0.03,size=3); mb = 1000*8*hs.prod()
+    box = tpl.add_actor("box", N.BODY_DYNAMIC, p=(0.1,0,0.05), mass=mb, inertia6=tuple(mb/3*np.array([hs[1]**2+hs[2]**2, hs[0]**2+hs[2]**2, hs[0]**2+hs[1]**2]))+(0,0,0)); tpl.add_shape(box, N.SHAPE_BOX, params=tuple(hs))
+    n = 8
+    try:
+        px = OraclePhysxSystem(tpl, n, SimConfig()); px.gpu_init()
+    except Exception as ex:
+        print(7000+seed, "build failed", ex); continue
+    px.set_scene_offsets(np.zeros((n,3)))
+    rbd = px.cuda_rigid_body_data.torch().view(n, px.bodies_per_env, 13)
+    rbd[:, tpl.body_id("table-workspace"), :7] = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)])
+    rbd[:, box, :7] = torch.tensor([0.12, 0.0, hs[2], 1,0,0,0], dtype=torch.float32); rbd[:, box, 7:13] = 0
+    px.gpu_apply_all()
+    tq = px.cuda_articulation_target_qpos.torch()
+    lo = torch.tensor([l[0] for l in lims]); hi = torch.tensor([l[1] for l in lims])
+    gen = torch.Generator().manual_seed(seed)
+    worst_lim = 0.0; vmax = 0.0; fin=True
+    for t in range(400):
+        if t % 25 == 0:
+            tq[:, :nl] = lo + (hi-lo)*torch.rand(n, nl, generator=gen)*1.3 - 0.15*(hi-lo)    # targets also slightly beyond the limits
+            px.gpu_apply_articulation_target_position()
+        px.step()
+        if t % 4 == 3:
+            px.gpu_fetch_all()
+            q = px.cuda_articulation_qpos.torch()[:, :nl]; qd = px.cuda_articulation_qvel.torch()[:, :nl]
+            worst_lim = max(worst_lim, (q - hi).clamp(min=0).max().item(), (lo - q).clamp(min=0).max().item()); vmax = max(vmax, qd.abs().max().item())
+            fin = fin and bool(torch.isfinite(rbd).all()) and bool(torch.isfinite(q).all())
+    zmin = rbd[:, links, 2].min().item(); bz = rbd[:, box, 2].min().item()
+    flag = (not fin) or worst_lim > 0.05 or vmax > 60 or zmin < -0.01 or bz < hs.min() - 0.004 and bz > -0.1
+    bad += flag
+    print(7000+seed, "links", nl, "finite", fin, "limit overshoot %.4f rad, max |qd| %.1f, lowest link frame z %.4f, box z min %.4f (half %.3f) ovf %d" % (worst_lim, vmax, zmin, bz, hs.min(), px.get_overflow()), "<<<" if flag else "")
+print("flagged", bad, "of", nseeds)
