@@ -145,14 +145,22 @@ def dropin_bench(envs: int, steps: int, extra=(), timeout=900):
     import subprocess
     if not os.path.isdir(os.path.join(ROOT, "oracle", "_ref", "maniskill")) and not os.path.isdir("/root/reference/mani_skill"):
         return {"error": "no reference build present (oracle/_ref/maniskill is made by __graft_entry__.build() where /root/reference exists)"}
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_reference_host.py"), "--envs", str(envs), "--steps", str(steps), *extra]
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_reference_host.py"), "--envs", str(envs), "--steps", str(steps), *extra],
-                           capture_output=True, text=True, timeout=timeout)
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired as exc:
+        tail = exc.stderr.decode(errors="replace") if isinstance(exc.stderr, bytes) else (exc.stderr or "")
+        return {"error": f"no result within {timeout} s", "rc": None, "stderr_tail": tail[-1500:]}
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if not line:        # the child died before its JSON line: say how (round 4's record only said "IndexError")
+        return {"error": "the child printed no result line", "rc": r.returncode, "stderr_tail": r.stderr[-1500:], "stdout_tail": r.stdout[-300:]}
+    try:
         d = json.loads(line[-1])
-        return {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "build_s", "accelerate", "host") if k in d} if "value" in d else d
-    except Exception as exc:   # noqa: BLE001 -- reported, never fatal for the metric
-        return {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
+    except ValueError as exc:
+        return {"error": f"unreadable result line: {exc}", "rc": r.returncode, "stderr_tail": r.stderr[-1500:], "stdout_tail": line[-1][-300:]}
+    if "value" not in d:
+        return dict(d, rc=r.returncode, stderr_tail=r.stderr[-1500:])
+    return {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "build_s", "accelerate", "host") if k in d}
 
 
 def cpu_baseline(sample_envs: int, sample_steps: int):

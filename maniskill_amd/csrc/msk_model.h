@@ -83,7 +83,7 @@ struct DModel {
   DPairInfo pinfo[MSK_MAX_PAIRS];
   int cls_cap[MSK_SOLVE_CLASSES - 1];  /* largest block count of solver classes 0 .. 3 (the wide class takes the rest: msk_config.contact_capacity) */
   int cap_contacts, cap_blocks;        /* contact points / solver blocks an env can have (msk_config.contact_capacity) */
-  unsigned jfric_mask;                 /* bit d: joint d has a friction coefficient (a joint-friction block in every step) */
+  unsigned long long jfric_mask;               /* bit d: joint d has a friction coefficient (a joint-friction block in every step) */
   int njfric;                          /* popcount of it */
   int has_static;                      /* some pair has static != dynamic friction: the per-pair slide state is kept (DState::ct_slip) */
   int has_tors;                        /* some pair has a torsional patch radius */

@@ -621,9 +621,9 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
     if (m.pinfo[p].mu_s != m.pinfo[p].mu) m.has_static = 1;
     if (m.pinfo[p].patch_r > 0.0f || m.pinfo[p].min_patch_r > 0.0f) m.has_tors = 1;
   }
-  m.jfric_mask = 0u; m.njfric = 0;
+  m.jfric_mask = 0ull; m.njfric = 0;
   for (int i = 0; i < m.nb; ++i)
-    if (m.bodies[i].kind == MSK_BODY_LINK && m.bodies[i].dof >= 0 && m.bodies[i].jfriction > 0.0f) { m.jfric_mask |= 1u << m.bodies[i].dof; m.njfric++; }
+    if (m.bodies[i].kind == MSK_BODY_LINK && m.bodies[i].dof >= 0 && m.bodies[i].jfriction > 0.0f) { m.jfric_mask |= 1ull << m.bodies[i].dof; m.njfric++; }
   {
     EnvLayout& L = m.lay;
     int o = 0;

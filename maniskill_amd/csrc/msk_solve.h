@@ -451,9 +451,9 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
       cfm0 = dr.x; vb0 = dr.y; hi0 = dr.z; lo0 = -dr.z;
     }
   } else if (is_jfric) { /* joint friction: holds the joint velocity at zero with at most coefficient x |transmitted wrench| x dt */
-    unsigned mk = m->jfric_mask;
-    for (int t = 0; t < lane - njoint; ++t) mk &= mk - 1u;
-    jd = __ffs((int)mk) - 1;
+    unsigned long long mk = m->jfric_mask;   /* 64 coordinates: bit d = dof d */
+    for (int t = 0; t < lane - njoint; ++t) mk &= mk - 1ull;
+    jd = __ffsll((long long)mk) - 1;
     const int body = m->dof_body[jd];
     const float* x = st.jforce + ((size_t)e * m->nb + body) * 6;
     const float mag = sqrtf(fmaf(x[0], x[0], fmaf(x[1], x[1], fmaf(x[2], x[2], fmaf(x[3], x[3], fmaf(x[4], x[4], x[5] * x[5]))))));

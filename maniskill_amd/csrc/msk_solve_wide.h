@@ -239,9 +239,9 @@ MSK_DEV void solve_env_wide(const DModel* __restrict__ m, const DState& st, cons
         X.cfm0 = dr.x; X.vb0 = dr.y; X.hi0 = dr.z; X.lo0 = -dr.z;
       }
     } else if (X.is_jfric) {
-      unsigned mk = m->jfric_mask;
-      for (int t = 0; t < b - njoint; ++t) mk &= mk - 1u;
-      X.jd = __ffs((int)mk) - 1;
+      unsigned long long mk = m->jfric_mask;   /* 64 coordinates: bit d = dof d */
+      for (int t = 0; t < b - njoint; ++t) mk &= mk - 1ull;
+      X.jd = __ffsll((long long)mk) - 1;
       const int body = m->dof_body[X.jd];
       const float* x = st.jforce + ((size_t)e * m->nb + body) * 6;
       const float mag = sqrtf(fmaf(x[0], x[0], fmaf(x[1], x[1], fmaf(x[2], x[2], fmaf(x[3], x[3], fmaf(x[4], x[4], x[5] * x[5]))))));

@@ -76,3 +76,59 @@ def test_hip_many_free_boxes_match_oracle(oracle_factory):
         b, pb = _roll(oracle_factory, tpl, ids, 70, 80)
         assert torch.equal(a, b), (nbox, (a - b).abs().max().item())
         assert pa.get_overflow() == 0
+
+
+def _tree_with_friction_beyond_the_32nd_coordinate(nbranch=12, nlink=3):
+    """A fixed hub carrying `nbranch` short chains of `nlink` hinges (36 coordinates): joint friction on the LAST link of every branch, so
+    friction blocks sit on coordinates below and above 32 (DModel::jfric_mask is one bit per coordinate: a 32-bit mask put the friction of
+    coordinate 32 + k on coordinate k)."""
+    tpl = SceneTemplate()
+    art = tpl.add_articulation("tree", root_p=(0, 0, 1.0))
+    hub = tpl.add_link(art, "hub", -1, N.JOINT_FIXED, mass=1.0, inertia6=(1e-2, 1e-2, 1e-2, 0, 0, 0))
+    tips = []
+    for b in range(nbranch):
+        c, s = np.cos(2 * np.pi * b / nbranch), np.sin(2 * np.pi * b / nbranch)
+        parent = hub
+        for k in range(nlink):
+            pin = [0.05 * c, 0.05 * s, 0.0, 1, 0, 0, 0] if k == 0 else [0.0, 0.0, -0.1, 1, 0, 0, 0]
+            parent = tpl.add_link(art, f"l{b}_{k}", parent, N.JOINT_REVOLUTE, joint_name=f"j{b}_{k}", pose_in_parent=pin, mass=0.2, com=(0.02, 0, -0.05),
+                                  inertia6=(2e-4, 2e-4, 1e-4, 0, 0, 0), friction=(0.05 + 0.01 * b) if k == nlink - 1 else 0.0)
+        tips.append(parent)
+    return tpl, hub, tips
+
+
+def _roll_tree(factory, n, steps):
+    tpl, hub, tips = _tree_with_friction_beyond_the_32nd_coordinate()
+    px = factory(tpl, n, SimConfig()); px.gpu_init()
+    rbd = px.cuda_rigid_body_data.torch().view(n, px.bodies_per_env, 13)
+    rbd[:, hub, :7] = torch.tensor([0.0, 0.0, 1.0, 1, 0, 0, 0], device=rbd.device)
+    q = px.cuda_articulation_qpos.torch(); qd = px.cuda_articulation_qvel.torch()
+    nq = 36
+    for e in range(n):
+        q[e, :nq] = torch.linspace(-0.6, 0.7, nq, device=q.device) * (1.0 + 0.1 * e)
+        qd[e, :nq] = torch.linspace(1.0, -1.5, nq, device=q.device)
+    px.gpu_apply_all()
+    out = []
+    for t in range(steps):
+        px.step()
+        px.gpu_fetch_all()
+        out.append(torch.cat([q[:, :nq], qd[:, :nq]], 1).cpu().clone())
+    return torch.stack(out), px
+
+
+def test_joint_friction_beyond_the_32nd_coordinate_matches_oracle_under_emulation(oracle_factory):
+    from emu_backend import EmuPhysxSystem
+    a, _ = _roll_tree(lambda t, n, c: EmuPhysxSystem(t, n, c), 2, 25)
+    b, _ = _roll_tree(oracle_factory, 2, 25)
+    assert torch.isfinite(b).all()
+    assert torch.equal(a, b), (a - b).abs().max().item()
+    # the friction is felt where it was put: the tip joints (coordinates 2, 5, ..., 35) lose speed against a frictionless twin's
+    assert b[-1, 0, 36 + 35].abs() < 5.0
+
+
+@pytest.mark.gpu
+def test_hip_joint_friction_beyond_the_32nd_coordinate_matches_oracle(oracle_factory):
+    from maniskill_amd.physx import PhysxGpuSystem
+    a, _ = _roll_tree(lambda t, n, c: PhysxGpuSystem("cuda:0", t, n, c), 70, 40)
+    b, _ = _roll_tree(oracle_factory, 70, 40)
+    assert torch.equal(a, b), (a - b).abs().max().item()
