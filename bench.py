@@ -163,6 +163,111 @@ def dropin_bench(envs: int, steps: int, extra=(), timeout=900):
     return {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "build_s", "accelerate", "host") if k in d}
 
 
+FUSED_HOSTS = ("PickCube-v1", "PushT-v1", "PegInsertionSide-v1")
+
+
+def timed_rollout(step, make_action, gather, flush, sync, steps: int, warmup: int):
+    """The contract's timed region for any env shard: `warmup` untimed steps, then exactly `steps` steps (random actions made on the device inside the
+    region, the per-step observation gather issued) bracketed by barrier + device sync; returns the seconds of this rank (the caller takes the MAX)."""
+    for _ in range(warmup):
+        out = step(make_action())
+        gather(*out[:4])
+    flush()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step(make_action())
+        gather(*out[:4])
+    flush()
+    sync()
+    return time.perf_counter() - t0
+
+
+def dropin_sharded_main(args) -> int:
+    """`bench.py --gpus N --env <any registered task>`: the reference's own env (BaseEnv, controllers, task code) per rank over the sapien shim,
+    sharded like the fused hosts (contiguous ranges, seeds 2022 + global index, one pipelined all-gather of the state observation per step), its
+    control step run by maniskill_amd.fused_step (--accelerate).  BASELINE config 5 is `--env OpenCabinetDrawer-v1 --envs 8192 --gpus 8`."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ref_harness      # locates the reference build (a checkout, or oracle/_ref/maniskill); third-party stand-ins this image lacks
+    ref = ref_harness.find_reference()
+    if ref is None:
+        print(json.dumps({"error": "no reference build present (oracle/_ref/maniskill is made by __graft_entry__.build() where /root/reference exists)"}))
+        return 1
+    ref_harness.setup("hip")      # the reference on sys.path over the sapien shim on libmsk_physx.so (stand-ins for gymnasium etc. appended)
+    from maniskill_amd.dist import make_sharded_gym_env
+    kw = {}
+    if args.env.startswith("OpenCabinet") and args.synthetic_partnet:
+        import subprocess
+        assets = f"/tmp/ms_assets_synth_bench_{os.environ.get('LOCAL_RANK', '0')}"
+        meta = os.path.join(ref, "mani_skill", "assets", "partnet_mobility", "meta")
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_synthetic_partnet.py"), "--out", assets, "--max-drawers", str(args.synthetic_partnet),
+                               "--ids-from", os.path.join(meta, "info_cabinet_drawer_train.json"), "--placeholder-ids-from",
+                               os.path.join(meta, "info_cabinet_door_train.json")], stdout=subprocess.DEVNULL)
+        os.environ["MS_ASSET_DIR"] = assets
+    elif args.obs_mode == "state":
+        kw["render_backend"] = "none"
+    t_build = time.perf_counter()
+    shard = make_sharded_gym_env(args.env, args.envs, device_type="cuda", reference_root=ref, obs_mode=args.obs_mode,
+                                 accelerate=None if args.accelerate == "none" else args.accelerate, **kw)
+    rank, world, dev, n_local = shard.rank, shard.world, shard.device, shard.num_envs
+    shard.reset(seed=2022)
+    build_s = time.perf_counter() - t_build
+    adim = shard.action_space.shape[-1]
+    acc = getattr(shard.unwrapped, "_msk_accelerated", None)
+    g = shard.gather
+    state_obs = args.obs_mode in ("state",) and g is not None
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    gather = (lambda o, r, t, u: g.pipelined(o, r, t, u)) if state_obs else (lambda *a: None)
+    flush = g.flush if state_obs else (lambda: None)
+    torch.manual_seed(0 + rank)
+    with torch.inference_mode(acc is None or acc.graph is None):
+        dt = timed_rollout(shard.step, lambda: 2 * torch.rand(n_local, adim, device=dev) - 1, gather, flush, sync, args.steps, args.warmup)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t[0].item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"env steps/sec (whole node), {args.envs} parallel {args.env} envs",
+            "path": "drop-in: mani_skill (unmodified) builds, resets and owns each rank's env over the sapien shim; maniskill_amd.fused_step runs its control "
+                    f"step ({acc.level + ('+graph' if acc.graph is not None else '') if acc is not None else 'not accelerated'})",
+            "value": args.envs * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (uniform random actions in [-1,1], seed-2022 resets" + ("; synthetic cabinets in place of PartNet-Mobility" if args.env.startswith("OpenCabinet") else "") + ")",
+            "config": {"workload": f"{args.env}, num_envs={args.envs}, {args.obs_mode} obs, the task's default control mode", "envs_per_gpu": n_local,
+                       "parallelism": f"env-shard x{world}", "build_s": build_s},
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def self_leg(extra, timeout):
+    """another workload of this same script in a process of its own (one context per process keeps the legs independent): its JSON line, trimmed"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-extras", *extra]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": f"no result within {timeout:.0f} s"}
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if not line:
+        return {"error": "the child printed no result line", "rc": r.returncode, "stderr_tail": r.stderr[-1500:]}
+    d = json.loads(line[-1])
+    keep = {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "error") if k in d}
+    if "camera" in d:
+        keep["camera"] = {k: d["camera"][k] for k in ("kernel", "us_per_frame", "frac")}
+    if "roofline" in d:
+        keep["kernel_us"] = d["roofline"]["kernel_us"]
+    keep["config"] = d.get("config", {}).get("workload")
+    return keep
+
+
 def cpu_baseline(sample_envs: int, sample_steps: int):
     """Times the CPU oracle's physics on the host cores: the same PickCube scene, ``sample_steps`` control steps' worth of substeps
     through liborc's orc_step (one ctypes call per substep for ALL envs, OpenMP over envs inside): physics only, no per-env Python.
@@ -216,9 +321,16 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="total env count over all ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the step+reset pass (profiling runs)")
-    ap.add_argument("--env", default="PickCube-v1", choices=["PickCube-v1", "PushT-v1", "PegInsertionSide-v1"],
-                    help="PickCube-v1 (BASELINE.json's metric, default), PushT-v1 (its camera config) or "
-                         "PegInsertionSide-v1 (its contact-rich config)")
+    ap.add_argument("--env", default="PickCube-v1",
+                    help="PickCube-v1 (BASELINE.json's metric, default), PushT-v1 (its camera config), PegInsertionSide-v1 (its contact-rich config): "
+                         "the fused hosts of maniskill_amd.envs.  Any other registered task id (OpenCabinetDrawer-v1: BASELINE config 5) runs over the "
+                         "drop-in path: the reference's own env per rank over the sapien shim (dist.make_sharded_gym_env), its control step "
+                         "accelerated as --accelerate says")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong (default, BASELINE.json's metric: --envs is the TOTAL over all ranks) or weak (--envs per GPU)")
+    ap.add_argument("--accelerate", default="graph", choices=["none", "control", "task", "graph"], help="drop-in path only: maniskill_amd.fused_step.accelerate level")
+    ap.add_argument("--synthetic-partnet", type=int, default=1, metavar="MAX_DRAWERS",
+                    help="drop-in OpenCabinet tasks: write tools/make_synthetic_partnet.py's cabinets (no PartNet-Mobility download here) with up to this many drawers")
     ap.add_argument("--obs-mode", default="state", choices=["state", "depth+segmentation", "rgb", "rgbd", "rgb+depth+segmentation"],
                     help="state (BASELINE.json's metric, default) or the camera path: 128x128 textures per env")
     ap.add_argument("--control-freq", type=int, default=20,
@@ -234,6 +346,8 @@ def main():
     ap.add_argument("--bootstrap-selftest", action="store_true", help=argparse.SUPPRESS)   # the rank bootstrap alone, over gloo (CPU test)
     args = ap.parse_args()
     args.graph = not args.no_graph
+    if args.scaling == "weak":
+        args.envs *= args.gpus          # per-GPU work fixed: the total grows with the rank count
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # the driver's plain form `python bench.py --gpus N`: this process becomes the launcher of the N ranks
@@ -246,6 +360,8 @@ def main():
         raise SystemExit(bootstrap_selftest(args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (the product path has no CPU fallback)")
+    if args.env not in FUSED_HOSTS:
+        raise SystemExit(dropin_sharded_main(args))
 
     from maniskill_amd.physx import SimConfig
     env, gather, rank, world = make_sharded_env(args.env, args.envs, device_type="cuda", obs_mode=args.obs_mode,
@@ -329,14 +445,30 @@ def main():
             _gather.flush()
             sync()
             dt_late = time.perf_counter() - t2
-        if args.graph:   # a graph replay records no events: time the kernels on eager steps of the same rollout
-            env.disable_step_graph()
-            env.px.timing_enable(20 * substeps)
-            for _ in range(20):
+        def eager_kernel_times(k):
+            """each substep kernel's own begin -> end over k eager control steps from where the rollout stands (a graph replay records no events: the
+            captured graph is set aside for these steps, same kernels, same order, same stream)"""
+            g, env._step_graph = getattr(env, "_step_graph", None), None
+            env.px.timing_enable(k * substeps)
+            for _ in range(k):
                 env.step(2 * torch.rand(n_local, env.action_dim, device=dev) - 1)
             torch.cuda.synchronize(dev)
-        kernels = env.px.timing_read()
-        env.px.timing_enable(0)
+            out = env.px.timing_read()
+            env.px.timing_enable(0)
+            env._step_graph = g
+            return out
+        kernels_late = None
+        if args.graph:
+            if dt_late:      # the rollout stands at step 1000: the contact-rich regime
+                kernels_late = eager_kernel_times(20)
+            # the regime of the timed region itself: the same seeded reset and warm-up, then 20 eager steps
+            env.reset(seed=2022)
+            for _ in range(args.warmup):
+                env.step(2 * torch.rand(n_local, env.action_dim, device=dev) - 1)
+            kernels = eager_kernel_times(20)
+        else:
+            kernels = env.px.timing_read()
+            env.px.timing_enable(0)
         mean_contacts = float(env.px.get_env_contact_counts().mean())
         cam_us = None
         if camera_mode:   # the rasteriser alone, HIP events on the launch stream
@@ -398,7 +530,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (uniform random actions in [-1,1], seed-2022 resets)",
@@ -406,8 +538,8 @@ def main():
                                    f"sim 100 Hz / control {args.control_freq} Hz ({substeps} substeps, 15+1 TGS iterations)"
                                    + (f", full reset every {args.reset_every} steps" if args.reset_every else ""),
                        "envs_per_gpu": n_local, "parallelism": f"env-shard x{world}",
-                       "launch": ("one HIP graph replay per control step; kernel_us from HIP events on 20 eager steps after the "
-                                  "timed region") if args.graph else "eager launches; kernel_us from HIP events over the timed region"},
+                       "launch": ("one HIP graph replay per control step; kernel_us from HIP events on 20 eager steps of the same regime "
+                                  "(roofline.regime)") if args.graph else "eager launches; kernel_us from HIP events over the timed region"},
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "substep_traffic": substep_traffic,
@@ -422,8 +554,12 @@ def main():
                 "tgs_solver": dict(kernel="k_csolve", **per_kernel.get("k_csolve", {})),
                 "substep_us": span_us, "launch_gap_us_per_substep": span_us - sum(avg_us.values()),
                 "timing": "each kernel's own begin/end time stamps (hipExtLaunchKernelGGL start/stop events on the launch stream: the duration "
-                          "rocprofv3 --kernel-trace reports), " + ("20 eager control steps of the same rollout right after the timed region "
-                          "(a graph replay records no events)" if args.graph else "over the timed region"),
+                          "rocprofv3 --kernel-trace reports), " + (f"20 eager control steps in the timed region's own regime -- the same seed-2022 reset and "
+                          f"{args.warmup} warm-up steps again, then steps {args.warmup}..{args.warmup + 20} eagerly (a graph replay records no events)"
+                          if args.graph else "over the timed region"),
+                "regime": f"early: steps {args.warmup}..{args.warmup + (20 if args.graph else args.steps)} after a seed-2022 reset (arms in the air, few contacts)",
+                "kernel_us_late": ({k: v[0] / max(v[1], 1) * 1e3 for k, v in kernels_late.items() if k != "substep"} if kernels_late else None),
+                "kernel_us_late_regime": "steps 1000..1020 of the same rollout (arms lying on the table: what step_late times)" if kernels_late else None,
                 "mean_contacts_per_env": mean_contacts,
             },
         }
@@ -467,6 +603,13 @@ def main():
             # BASELINE config 4's task over the drop-in path (4096 envs on this GPU): the reference's own task code behind the fused controller as one graph
             result["config4_peg_insertion_side_4096_dropin"] = {"fused_graph": leg(4096, 50, ("--env", "PegInsertionSide-v1", "--accelerate", "graph"))}
             result["config5_open_cabinet_drawer_1024"]["reference_step"] = leg(1024, 50, cab)
+
+            def fused_leg(extra):
+                left = budget - (time.perf_counter() - t_extra)
+                return self_leg(extra, timeout=left) if left > 30 else {"skipped": "the extra legs' time budget (MSK_BENCH_EXTRA_S) is spent"}
+            # BASELINE configs 3 and 4 on this GPU over the fused hosts (the headline's path): PushT-v1 with its 128 x 128 depth + segmentation camera, PegInsertionSide-v1
+            result["config3_pusht_camera_4096"] = fused_leg(("--env", "PushT-v1", "--obs-mode", "depth+segmentation", "--steps", "50"))
+            result["config4_peg_insertion_side_4096"] = fused_leg(("--env", "PegInsertionSide-v1", "--steps", "100"))
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(4096, 20)   # the metric's own env count
         print(json.dumps(result), flush=True)

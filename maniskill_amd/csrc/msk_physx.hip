@@ -25,6 +25,7 @@
     else hipLaunchKernelGGL(kern, grid, block, lds, s, __VA_ARGS__);                                           \
   } while (0)
 
+static void merged_forget(struct msk_ctx* c);   /* the merged-batch tables that hold a context's pointers go with it (below, at msk_batch) */
 static unsigned long long g_bind_epoch = 1;   /* msk_bind_buffers calls so far: invalidates the merged-batch table */
 
 struct HostQuery { int npairs; int* d_pairs; float* d_out; };
@@ -200,6 +201,7 @@ MSK_API void msk_destroy(msk_ctx* c) {
   g_bind_epoch++;   /* a merged-batch table may hold this context's pointers */
   hipSetDevice(c->device);
   hipDeviceSynchronize();
+  merged_forget(c);
   for (void* p : c->allocs) hipFree(p);
   for (hipEvent_t e : c->tev) hipEventDestroy(e);
   delete c->rmodel;
@@ -971,11 +973,21 @@ struct MergedCache {
   bool any_np = false;
   unsigned long long used = 0;   /* last use, for eviction */
 };
-/* one table per list of contexts (a training and an evaluation scene alternate between two lists): a handful of slots, least recently
- * used evicted.  A slot is valid only while its key is non-empty and its epoch is the current binding epoch. */
-#define MSK_MERGED_SLOTS 4
-static MergedCache g_merged[MSK_MERGED_SLOTS];
+/* one table per list of contexts, kept for as long as its contexts live: a captured step graph holds the table's device address, so a table is
+ * never freed or moved behind a graph's back -- when a buffer binding changes it is rewritten IN PLACE, and only msk_destroy of one of its
+ * contexts releases it.  (Round 4 kept four slots, least recently used evicted and freed: two envs of 17 contexts each in one process evicted each
+ * other's tables, and a replayed graph then read whatever the allocator had put at the old address -- first seen on hardware in round 5,
+ * tests/test_fused_step.py::test_open_cabinet_drawer_step_as_one_hip_graph.) */
+static std::vector<MergedCache*> g_merged;
 static unsigned long long g_merged_clock = 0;
+static void merged_forget(msk_ctx* c) { /* msk_destroy: the device is idle (synchronised by the caller) */
+  for (size_t k = 0; k < g_merged.size();) {
+    MergedCache* q = g_merged[k];
+    bool has = false;
+    for (msk_ctx* x : q->key) has = has || x == c;
+    if (has) { if (q->d_refs) hipFree(q->d_refs); delete q; g_merged.erase(g_merged.begin() + (long)k); } else ++k;
+  }
+}
 
 static int batch_merged(msk_ctx* const* ctxs, int n, int op, uint32_t mask, hipStream_t s) {
   msk_ctx* c = ctxs[0];
@@ -995,27 +1007,18 @@ static int batch_merged(msk_ctx* const* ctxs, int n, int op, uint32_t mask, hipS
   if (op == MSK_BATCH_FETCH && (mask & MSK_FETCH_ART_LINK_FORCES)) return 1;
   if (op == MSK_BATCH_STEP && c->model.np == 0) return 1;
   MergedCache* hit = nullptr;
-  for (int k = 0; k < MSK_MERGED_SLOTS && !hit; ++k) {
-    MergedCache& q = g_merged[k];
-    bool same = !q.key.empty() && q.epoch == g_bind_epoch && (int)q.key.size() == n;
-    for (int i = 0; same && i < n; ++i) same = q.key[i] == ctxs[i];
-    if (same) hit = &q;
+  for (size_t k = 0; k < g_merged.size() && !hit; ++k) {
+    MergedCache* q = g_merged[k];
+    bool same = (int)q->key.size() == n;
+    for (int i = 0; same && i < n; ++i) same = q->key[i] == ctxs[i];
+    if (same) hit = q;
   }
-  if (!hit) { /* build the table in the least recently used slot; the slot stays invalid (empty key) until the table is complete */
-    MergedCache* slot = nullptr;
-    for (int k = 0; k < MSK_MERGED_SLOTS && !slot; ++k)
-      if (g_merged[k].key.empty() || g_merged[k].epoch != g_bind_epoch) slot = &g_merged[k];   /* free or stale */
-    if (!slot) {
-      slot = &g_merged[0];
-      for (int k = 1; k < MSK_MERGED_SLOTS; ++k)
-        if (g_merged[k].used < slot->used) slot = &g_merged[k];
-    }
-    MergedCache& mc = *slot;
-    mc.key.clear();
+  if (!hit || hit->epoch != g_bind_epoch) { /* a new list of contexts, or a binding changed since the table was written: (re)write it, at the same address */
+    if (!hit) { hit = new MergedCache(); hit->key.assign(ctxs, ctxs + n); g_merged.push_back(hit); }
+    MergedCache& mc = *hit;
     mc.epoch = 0;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipDeviceSynchronize());   /* a launch in flight may still read the table that is replaced */
-    if (mc.d_refs) { hipFree(mc.d_refs); mc.d_refs = nullptr; }
+    HIP_TRY(hipDeviceSynchronize());   /* a launch in flight may still read the table that is rewritten */
     std::vector<GroupRef> refs((size_t)n);
     mc.t_dyn = mc.t_np = mc.t_cs = mc.t_af = 0;
     mc.lds_dyn = mc.lds_kin = mc.lds_np = 0;
@@ -1041,11 +1044,9 @@ static int batch_merged(msk_ctx* const* ctxs, int n, int op, uint32_t mask, hipS
       mc.lds_dyn = std::max(mc.lds_dyn, (size_t)DynLds(x->model.nb, md).total * sizeof(float) * epb);
       mc.lds_kin = std::max(mc.lds_kin, (size_t)DynLds(x->model.nb, 0).total * sizeof(float) * epb);
     }
-    HIP_TRY(hipMalloc(&mc.d_refs, sizeof(GroupRef) * (size_t)n));
+    if (!mc.d_refs) HIP_TRY(hipMalloc(&mc.d_refs, sizeof(GroupRef) * (size_t)n));
     HIP_TRY(hipMemcpy(mc.d_refs, refs.data(), sizeof(GroupRef) * (size_t)n, hipMemcpyHostToDevice));
-    mc.key.assign(ctxs, ctxs + n);
     mc.epoch = g_bind_epoch;
-    hit = &mc;
   }
   MergedCache& mc = *hit;
   mc.used = ++g_merged_clock;

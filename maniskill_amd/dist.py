@@ -147,7 +147,9 @@ class ShardedGymEnv:
         return self._reset(seeds, options)
 
     def _reset(self, seed, options):
-        if options and options.get("reconfigure"):      # the scene is rebuilt: a new PhysxSystem, under this shard again
+        # the scene is rebuilt -- a new PhysxSystem, under this shard again -- when the caller asks for it or when BaseEnv.reset reconfigures on its own
+        # (reconfiguration_freq != 0, sapien_env.py:898: the default of some tasks when a rank holds one env)
+        if (options and options.get("reconfigure")) or getattr(self.unwrapped, "reconfiguration_freq", 0):
             from sapien import _system
             _system.set_shard(self.start, self.num_envs, self.total_envs)
             try:

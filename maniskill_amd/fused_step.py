@@ -270,6 +270,8 @@ class OpenCabinetDrawerStep:
             raise Unsupported(f"reward mode {base.reward_mode}")
         if len(base.agent.controller.get_state()) > 0:
             raise Unsupported("controllers with state in the observation")
+        if base.scene.parallel_in_single_scene:      # Link.pose / Actor.pose subtract scene_offsets there (structs/link.py:240, actor.py:357): raw rows would differ
+            raise Unsupported("sub-scenes laid out in one scene")
         self.base, self.control, self.px, self.scene = base, control, base.scene.px, base.scene
         self.boundary = control.boundary
         dev = base.device
@@ -492,76 +494,87 @@ def _pusht_pseudo_render_intersection(base):
     return pseudo_render_intersection
 
 
-def _stackcube_compute_dense_reward(base):
-    """StackCube-v1's ``compute_dense_reward`` (envs/tasks/tabletop/stack_cube.py:145-181) with selects where the reference assigns through masks
-    (``reward[mask] = values[mask]``: a nonzero() each); the values are computed by the same expressions, so the selected ones have the same bits."""
-    def compute_dense_reward(obs, action, info):
-        self = base
-        tcp_pose = self.agent.tcp.pose.p
-        cubeA_pos = self.cubeA.pose.p
-        cubeA_to_tcp_dist = torch.linalg.norm(tcp_pose - cubeA_pos, axis=1)
-        reward = 2 * (1 - torch.tanh(5 * cubeA_to_tcp_dist))
-        cubeA_pos = self.cubeA.pose.p
-        cubeB_pos = self.cubeB.pose.p
-        goal_xyz = torch.hstack([cubeB_pos[:, 0:2], (cubeB_pos[:, 2] + self.cube_half_size[2] * 2)[:, None]])
-        cubeA_to_goal_dist = torch.linalg.norm(goal_xyz - cubeA_pos, axis=1)
-        place_reward = 1 - torch.tanh(5.0 * cubeA_to_goal_dist)
-        is_cubeA_grasped = info["is_cubeA_grasped"]
-        reward = torch.where(is_cubeA_grasped, 4 + place_reward, reward)
-        gripper_width = (self.agent.robot.get_qlimits()[0, -1, 1] * 2).to(self.device)
-        ungrasp_reward = torch.sum(self.agent.robot.get_qpos()[:, -2:], axis=1) / gripper_width
-        ungrasp_reward[~is_cubeA_grasped] = 1.0
-        v = torch.linalg.norm(self.cubeA.linear_velocity, axis=1)
-        av = torch.linalg.norm(self.cubeA.angular_velocity, axis=1)
-        static_reward = 1 - torch.tanh(v * 10 + av)
-        reward = torch.where(info["is_cubeA_on_cubeB"], 6 + (ungrasp_reward + static_reward) / 2.0, reward)
-        reward[info["success"]] = 8
-        return reward
-    return compute_dense_reward
-
-
-def _placesphere_compute_dense_reward(base):
-    """PlaceSphere-v1's ``compute_dense_reward`` (envs/tasks/tabletop/place_sphere.py:216-252), selects for the two masked assignments of tensors"""
-    def compute_dense_reward(obs, action, info):
-        self = base
-        tcp_pose = self.agent.tcp.pose.p
-        obj_pos = self.obj.pose.p
-        obj_to_tcp_dist = torch.linalg.norm(tcp_pose - obj_pos, axis=1)
-        reward = 2 * (1 - torch.tanh(5 * obj_to_tcp_dist))
-        obj_pos = self.obj.pose.p
-        bin_top_pos = self.bin.pose.p.clone()
-        bin_top_pos[:, 2] = bin_top_pos[:, 2] + self.block_half_size[0] + self.radius
-        obj_to_bin_top_dist = torch.linalg.norm(bin_top_pos - obj_pos, axis=1)
-        place_reward = 1 - torch.tanh(5.0 * obj_to_bin_top_dist)
-        is_obj_grasped = info["is_obj_grasped"]
-        reward = torch.where(is_obj_grasped, 4 + place_reward, reward)
-        gripper_width = (self.agent.robot.get_qlimits()[0, -1, 1] * 2).to(self.device)
-        ungrasp_reward = torch.sum(self.agent.robot.get_qpos()[:, -2:], axis=1) / gripper_width
-        ungrasp_reward[~is_obj_grasped] = 16.0
-        v = torch.linalg.norm(self.obj.linear_velocity, axis=1)
-        av = torch.linalg.norm(self.obj.angular_velocity, axis=1)
-        static_reward = 1 - torch.tanh(v * 10 + av)
-        robot_static_reward = self.agent.is_static(0.2)
-        reward = torch.where(info["is_obj_on_bin"], 6 + (ungrasp_reward + static_reward + robot_static_reward) / 3.0, reward)
-        reward[info["success"]] = 13
-        return reward
-    return compute_dense_reward
-
-
-# Tasks whose OWN step (behind the fused controller, with the method patches below) passed the watch of tests/ref_fused_step.py graph_safe on the CPU checker: no
-# synchronising op, no boolean-mask indexing, no state carried between steps through a tensor the earlier step allocated.  The last one is why this is a list and
-# not an attempt: such a step captures without an error and replays with stale state (RotateSingleObjectInHand keeps its previous unit vector that way).
-GRAPH_VERIFIED = frozenset([
-    "PushCube-v1", "PullCube-v1", "StackCube-v1", "StackPyramid-v1", "LiftPegUpright-v1", "PegInsertionSide-v1", "PlaceSphere-v1", "RollBall-v1", "PushT-v1",
-    "Empty-v1", "FMBAssembly1Easy-v1", "PickCube-v1", "PickCubeSO100-v1", "MS-CartpoleBalance-v1", "MS-CartpoleSwingUp-v1", "MS-HopperStand-v1",
-    "RotateValveLevel0-v1", "RotateValveLevel1-v1", "RotateValveLevel2-v1", "RotateValveLevel3-v1", "RotateValveLevel4-v1",
-    "TriFingerRotateCubeLevel0-v1", "TriFingerRotateCubeLevel1-v1", "TriFingerRotateCubeLevel2-v1", "TriFingerRotateCubeLevel3-v1", "TriFingerRotateCubeLevel4-v1"])
-
 # env id -> {method name: factory(base) -> replacement}: single methods of a task whose results are restated bit for bit so that the rest of the task's OWN
 # step can be captured (used by the generic graph level; installed as instance attributes, removed by restore())
-_METHOD_PATCHES = {"PushT-v1": {"pseudo_render_intersection": _pusht_pseudo_render_intersection},
-                   "StackCube-v1": {"compute_dense_reward": _stackcube_compute_dense_reward},
-                   "PlaceSphere-v1": {"compute_dense_reward": _placesphere_compute_dense_reward}}
+_METHOD_PATCHES = {"PushT-v1": {"pseudo_render_intersection": _pusht_pseudo_render_intersection}}
+
+
+# --------------------------------------------------------------------------------------------------------------------- masked assignments
+class _MaskedSelection(torch.Tensor):
+    """``y[mask]`` for a boolean ``mask`` over the leading dimensions, not evaluated yet (DeviceConstants hands it out while a step is warmed up, watched and
+    captured).  Its one cheap use is the reference's idiom ``x[mask] = y[mask]`` (stack_cube.py:161, place_sphere.py:230, poke_cube.py:208, ...), which
+    DeviceConstants turns into ``x <- where(mask, y, x)``: the same values in the same places, no ``nonzero()`` -- no host synchronisation, capturable.  ANY
+    other use makes it the real selection first (the data-dependent shape a capture forbids: such a task fails the capture as before)."""
+
+    @staticmethod
+    def make(src, mask):
+        sel = src.as_subclass(_MaskedSelection)
+        sel._msk_src, sel._msk_mask = src, mask
+        return sel
+
+    def _real(self):
+        with torch._C.DisableTorchFunctionSubclass():
+            return torch.Tensor.__getitem__(self._msk_src, self._msk_mask)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        def real(a):
+            if isinstance(a, _MaskedSelection):
+                return a._real()
+            if isinstance(a, (list, tuple)):
+                return type(a)(real(v) for v in a)
+            if isinstance(a, dict):
+                return {k: real(v) for k, v in a.items()}
+            return a
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*real(args), **real(kwargs or {}))
+
+
+# elementwise arithmetic on unevaluated selections of ONE mask stays unevaluated: a[m] op b[m] == (a op b)[m], element for element (`reward[m] += bonus[m]`,
+# poke_cube.py:221, is __getitem__, __iadd__, __setitem__); (function, operation on the sources, operands swapped)
+_T = torch.Tensor
+_SELECTION_ARITHMETIC = {f: (op, swap) for op, fs, swap in (
+    (torch.add, (_T.__add__, _T.__iadd__, _T.add, _T.add_, torch.add), False), (torch.add, (_T.__radd__,), True),
+    (torch.sub, (_T.__sub__, _T.__isub__, _T.sub, _T.sub_, torch.sub), False), (torch.sub, (_T.__rsub__,), True),
+    (torch.mul, (_T.__mul__, _T.__imul__, _T.mul, _T.mul_, torch.mul), False), (torch.mul, (_T.__rmul__,), True),
+    (torch.true_divide, (_T.__truediv__, _T.__itruediv__, _T.div, _T.div_, torch.div, torch.true_divide), False), (torch.true_divide, (_T.__rtruediv__,), True)) for f in fs}
+
+
+_SELECTION_UNARY = {f: getattr(torch, n) for n in ("sin", "cos", "tan", "tanh", "exp", "log", "sqrt", "abs", "neg", "square", "sigmoid", "asin", "acos", "atan")
+                    for f in (getattr(torch, n), getattr(_T, n))}
+_SELECTION_UNARY.update({_T.__neg__: torch.neg, _T.__abs__: torch.abs})
+_MASK_NOT = (_T.__invert__, torch.logical_not, _T.logical_not, torch.bitwise_not, _T.bitwise_not)
+
+
+def _selection_arithmetic(func, args, kwargs):
+    """the unevaluated result, or None when the operands are not selections of one mask (and plain numbers)"""
+    if len(args) != 2 or kwargs:
+        return None
+    op, swap = _SELECTION_ARITHMETIC[func]
+    sels = [a for a in args if isinstance(a, _MaskedSelection)]
+    mask = sels[0]._msk_mask
+    srcs = []
+    for a in args:
+        if isinstance(a, _MaskedSelection):
+            if a._msk_mask is not mask or a._msk_src.shape != sels[0]._msk_src.shape:
+                return None
+            srcs.append(a._msk_src)
+        elif isinstance(a, (int, float)) and not isinstance(a, bool):
+            srcs.append(a)
+        else:
+            return None
+    if swap:
+        srcs.reverse()
+    with torch._C.DisableTorchFunctionSubclass():
+        return _MaskedSelection.make(op(*srcs), mask)
+
+
+def _leading_mask(x, idx):
+    return isinstance(idx, torch.Tensor) and idx.dtype == torch.bool and 1 <= idx.ndim <= x.ndim and tuple(idx.shape) == tuple(x.shape[:idx.ndim]) and idx.device == x.device
+
+
+def _broadcast_mask(mask, x):
+    return mask if mask.ndim == x.ndim else mask[(...,) + (None,) * (x.ndim - mask.ndim)]
 
 
 # --------------------------------------------------------------------------------------------------------------------- host constants inside a step
@@ -578,22 +591,45 @@ class DeviceConstants(torch.overrides.TorchFunctionMode):
         self.device = torch.device(device)
         self.cache = {}
         self.served = 0
+        self.masked = self.rewritten = 0      # y[mask] handed out unevaluated / masked assignments turned into selects
+        self._seen, self._nots = {}, {}
+
+    def __enter__(self):
+        self._seen = {}                 # one step = one `with`: the k-th evaluation of a call path inside a step is its own constant (loops)
+        self._nots = {}
+        return super().__enter__()
 
     @staticmethod
     def _site():
+        """The call path of the expression: (file, line) of the frames outside torch and this module, innermost first.  The innermost frame alone is not
+        enough: ``Pose.create`` -> ``common.to_tensor`` (utils/common.py:167) is one line that every caller's host data goes through -- keyed by it, two
+        callers looked like one site whose data changes (PegInsertionSide-v1's reward, first seen on hardware in round 5)."""
         import sys
         f = sys._getframe(2)
         here = __file__
-        while f is not None and (f.f_code.co_filename == here or "/torch/" in f.f_code.co_filename):
+        path = []
+        while f is not None and len(path) < 24:
+            fn = f.f_code.co_filename
+            if fn == here:          # the step's entry (captured_step / a plugin's step): what lies outside differs between warm-up, capture and replay
+                if f.f_code.co_name not in ("__torch_function__", "_serve", "_site", "conv"):
+                    if not path:
+                        path.append((fn, f.f_lineno))
+                    break
+            elif "/torch/" not in fn:
+                path.append((fn, f.f_lineno))
             f = f.f_back
-        return (f.f_code.co_filename, f.f_lineno) if f is not None else ("?", 0)
+        return tuple(path) if path else (("?", 0),)
 
     def _serve(self, site_key, content, make):
+        k = self._seen.get(site_key, 0)
+        self._seen[site_key] = k + 1
+        site_key = site_key + (k,)
         hit = self.cache.get(site_key)
         if hit is None:
             hit = self.cache[site_key] = (content, make())
         elif hit[0] != content:
-            raise Unsupported(f"host data that changes from step to step is uploaded inside the step at {site_key[0]}:{site_key[1]}: a replayed graph would keep the first value")
+            where = site_key[0]
+            raise Unsupported(f"host data that changes from step to step is uploaded inside the step at {where[0]}:{where[1]}: a replayed graph would keep the first value")
         self.served += 1
         return hit[1].clone()
 
@@ -613,6 +649,35 @@ class DeviceConstants(torch.overrides.TorchFunctionMode):
                 tc = t.detach().contiguous()
                 content = (str(tc.dtype), tuple(tc.shape), tc.numpy().tobytes() if tc.dtype != torch.bfloat16 else tc.float().numpy().tobytes())
                 return self._serve(self._site() + ("to", str(kwargs.get("dtype"))), content, lambda: func(*args, **kwargs))
+        elif func in _SELECTION_UNARY and len(args) == 1 and not kwargs and isinstance(args[0], _MaskedSelection):
+            with torch._C.DisableTorchFunctionSubclass():      # f(a[m]) == f(a)[m], element for element (what f makes of the unselected elements is never looked at)
+                return _MaskedSelection.make(_SELECTION_UNARY[func](args[0]._msk_src), args[0]._msk_mask)
+        elif func in _MASK_NOT and len(args) == 1 and not kwargs and type(args[0]) is torch.Tensor and args[0].dtype == torch.bool:
+            # `x[~m] = f(y[~m])` evaluates ~m once per use (rotation_conversions.py:549-552): the uses have to be ONE mask to be recognised as one selection
+            hit = self._nots.get(id(args[0]))
+            if hit is None or hit[0] is not args[0] or hit[2] != args[0]._version:
+                hit = self._nots[id(args[0])] = (args[0], func(args[0]), args[0]._version)
+            return hit[1]
+        elif func in _SELECTION_ARITHMETIC and any(isinstance(a, _MaskedSelection) for a in args):
+            out = _selection_arithmetic(func, args, kwargs)
+            if out is not None:
+                return out
+        elif func is torch.Tensor.__getitem__ and len(args) == 2 and type(args[0]) is torch.Tensor and _leading_mask(args[0], args[1]) and args[0].device.type == self.device.type:
+            self.masked += 1
+            return _MaskedSelection.make(args[0], args[1])          # y[mask]: evaluated only if something other than `x[mask] = ...` wants it
+        elif func is torch.Tensor.__setitem__ and len(args) == 3 and type(args[0]) is torch.Tensor and _leading_mask(args[0], args[1]):
+            x, mask, v = args
+            if isinstance(v, _MaskedSelection):
+                if v._msk_mask is mask and v._msk_src.shape == x.shape and v._msk_src.dtype == x.dtype:       # x[mask] = y[mask]
+                    with torch._C.DisableTorchFunctionSubclass():
+                        x.copy_(torch.where(_broadcast_mask(mask, x), v._msk_src, x))
+                    self.rewritten += 1
+                    return None
+                return func(x, mask, v._real())
+            if isinstance(v, torch.Tensor) and v.numel() == 1 and v.device == x.device and v.dtype == x.dtype:      # x[mask] = a one-element device tensor
+                x.copy_(torch.where(_broadcast_mask(mask, x), v.reshape(()), x))
+                self.rewritten += 1
+                return None
         elif func is torch.Tensor.__getitem__ and len(args) == 2 and isinstance(args[1], (list, tuple)):
             # data[..., [2]] (render/shaders.py:80): a Python list as an index becomes an index tensor, made on the host and uploaded, at every evaluation
             idx, dev, site = args[1], args[0].device, None
@@ -629,6 +694,81 @@ class DeviceConstants(torch.overrides.TorchFunctionMode):
         return func(*args, **kwargs)
 
 
+# --------------------------------------------------------------------------------------------------------------------- is a step safe to replay?
+def graph_safety(step_fn, action, settle: int = 2) -> dict:
+    """What a HIP-graph replay of ``step_fn(action)`` would get wrong, found on the operator stream of two consecutive eager steps (after ``settle`` unwatched
+    ones; works on any device, the CPU checker included):
+
+    * ``sync``: operators that wait for the device or size their result by its data (``nonzero``, boolean-mask indexing, ``.item()``): a capture refuses them;
+    * ``flow``: an operator of the second step reads a tensor the FIRST step allocated -- state handed from one step to the next through fresh memory.  This one
+      is silent: the capture succeeds and every replay re-reads the memory that was current at capture time (RotateSingleObjectInHand keeps its previous unit
+      vector that way).  State has to live in tensors that persist and are updated in place.
+
+    An empty ``sync`` and ``flow`` is what ``accelerate(env, graph=True)`` requires before it captures the reference's own step (round 4 consulted a hand-kept list
+    of task ids instead)."""
+    import os
+    import traceback
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    def tensors(x, out):
+        if isinstance(x, torch.Tensor):
+            out.append(x)
+        elif isinstance(x, (list, tuple)):
+            for v in x:
+                tensors(v, out)
+        elif isinstance(x, dict):
+            for v in x.values():
+                tensors(v, out)
+        return out
+
+    def site():
+        for f in reversed(traceback.extract_stack(limit=60)[:-2]):
+            if "/torch/" not in f.filename and f.filename != __file__ and f.name != "__torch_function__":
+                return f"{os.path.basename(f.filename)}:{f.lineno}"
+        return "?"
+
+    class Watch(TorchDispatchMode):
+        def __init__(self, earlier):
+            super().__init__()
+            self.earlier, self.made, self.keep, self.sync, self.flow, self.host = earlier, set(), [], [], [], []
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = str(func)
+            ins = tensors([args, kwargs or {}], [])
+            if any(t in name for t in ("_local_scalar_dense", "nonzero", "masked_select", "aten.equal", "is_nonzero", "unique")):
+                self.sync.append(f"{name} @ {site()}")
+            if "aten.index" in name:
+                for ix in (args[1] or []):
+                    if ix is not None and ix.dtype in (torch.bool, torch.uint8):
+                        v = args[2] if len(args) > 2 else None
+                        if "index_put" in name and v is not None and v.numel() == 1 and v.device.type == "cpu" and len(args[1]) == 1:
+                            continue        # x[mask] = scalar: dispatched to masked_fill, no nonzero()
+                        self.sync.append(f"{name} with a mask @ {site()}")
+            if "lift_fresh" in name and ins and ins[0].ndim > 0:
+                # host data turned into a tensor inside the step: with `device=` in the same call DeviceConstants serves it (then this op does not appear);
+                # `torch.tensor(array).to(device)` makes the host tensor here and uploads in `.to`, which DeviceConstants serves on a GPU: listed, not counted
+                self.host.append(f"host data of shape {tuple(ins[0].shape)} @ {site()}")
+            for t in ins:
+                if t.untyped_storage().nbytes() > 0 and t.untyped_storage().data_ptr() in self.earlier:      # (empty tensors share the null address)
+                    self.flow.append(f"{name} reads a tensor the previous step allocated @ {site()}")
+            out = func(*args, **(kwargs or {}))
+            inp = {t.untyped_storage().data_ptr() for t in ins}
+            for t in tensors(out, []):
+                if t.untyped_storage().nbytes() > 0 and t.untyped_storage().data_ptr() not in inp:
+                    self.made.add(t.untyped_storage().data_ptr())
+                    self.keep.append(t)            # alive until the next step was watched: its address is not handed out again
+            return out
+    for _ in range(settle):
+        step_fn(action)
+    w1 = Watch(set())
+    with w1:
+        step_fn(action)
+    w2 = Watch(w1.made)
+    with w2:
+        step_fn(action)
+    return dict(sync=sorted(set(w1.sync + w2.sync)), flow=sorted(set(w2.flow)), host_data=sorted(set(w1.host + w2.host)))
+
+
 # --------------------------------------------------------------------------------------------------------------------- entry point
 class Accelerated:
     """What accelerate() installed on an env: ``.level`` ("control" | "task" | "graph": the reference's own task code, captured | "graph-dry"), ``.graph`` (the
@@ -641,7 +781,7 @@ class Accelerated:
         self.env, self.base = env, env.unwrapped
         self._want_graph, self._want_task = graph, task
         self._saved = [(n, n in self.base.__dict__, self.base.__dict__.get(n)) for n in ("_step_action", "step")]
-        self.graph = self.plugin = self.constants = self.plugin_refused = None
+        self.graph = self.plugin = self.constants = self.plugin_refused = self.safety = None
         self.rebuilds = 0
         try:
             self._build(graph)
@@ -662,12 +802,28 @@ class Accelerated:
         """a reconfigured env (new scene, new px) or another control mode (agent.set_control_mode: another controller object)"""
         return self.base.scene is not self.scene or self.base.agent.controller is not self.control.ctrl
 
+    def _reference(self, name, action):
+        """the reference's own method, with the instance-level replacements out of the way for the call ({'control_mode': ..., 'action': ...} actions:
+        sapien_env.py:1086-1093 switches the controller, then ``_stale()`` rebuilds for the new one)"""
+        base, mine = self.base, {}
+        for n in ("_step_action", "step"):
+            if n in base.__dict__:
+                mine[n] = base.__dict__.pop(n)
+        try:
+            return getattr(base, name)(action)
+        finally:
+            base.__dict__.update(mine)
+
     def _step_action(self, action):
+        if isinstance(action, dict):
+            return self._reference("_step_action", action)
         if self._stale():
             self._rebuild()
         return self._control_fn(action)
 
     def _step(self, action):
+        if isinstance(action, dict):
+            return self._reference("step", action)
         if self._stale():
             self._rebuild()
             return self.base.step(action)
@@ -714,13 +870,17 @@ class Accelerated:
             self._step_fn = plugin.step
             if graph and graph != "dry":
                 from .graph import StepGraph
-                g = self.graph = StepGraph(plugin.step, base.num_envs, control.adim, base.device)
+                try:
+                    g = self.graph = StepGraph(plugin.step, base.num_envs, control.adim, base.device)
+                except Exception as e:      # noqa: BLE001  (not a GPU env, host-memory backend, a capture error): the caller falls back to the task level
+                    if base.device.type == "cuda":
+                        torch.cuda.synchronize()
+                    if isinstance(e, Unsupported):
+                        raise
+                    raise Unsupported(f"the task plugin's step cannot be captured as a HIP graph: {str(e).splitlines()[0][:300]}") from e
                 self._step_fn = lambda action: g(action) if action is not None else plugin.step(None)
             base.step = self._step
         elif graph:
-            if graph is True and self._eid() not in GRAPH_VERIFIED:
-                raise Unsupported(f"{self._eid()} is not among the tasks whose own step was checked for what a replayed graph gets wrong silently -- state handed from "
-                                  "one step to the next through a freshly allocated tensor (tests/ref_fused_step.py graph_safe:<env id>; graph='force' captures anyway)")
             for name, factory in _METHOD_PATCHES.get(self._eid(), {}).items():
                 if name not in [n for n, _, _ in self._saved]:
                     self._saved.append((name, name in base.__dict__, base.__dict__.get(name)))
@@ -737,7 +897,17 @@ class Accelerated:
             if graph == "dry":          # everything the capture would run, eagerly at every step (no GPU needed: the CPU suite checks the results and the op stream)
                 self.level = "graph-dry"
                 self._step_fn = captured_step
+            elif graph == "watch":      # the verdict alone (any device): what graph=True decides on
+                self.level = "graph-dry"
+                self._step_fn = captured_step
+                self.safety = graph_safety(captured_step, torch.zeros(base.num_envs, control.adim, device=base.device))
             else:
+                if graph is True:       # (graph="force" captures without asking)
+                    verdict = self.safety = graph_safety(captured_step, torch.zeros(base.num_envs, control.adim, device=base.device))
+                    if verdict["sync"] or verdict["flow"]:
+                        what = "; ".join((verdict["sync"] + verdict["flow"])[:3])
+                        raise Unsupported(f"the task's own step is not safe to replay as a graph: {what}" + (" (a capture refuses the first kind; the second kind -- state "
+                                          "handed to the next step through a freshly allocated tensor -- would capture and replay stale)" if verdict["flow"] else ""))
                 from .graph import StepGraph
                 try:
                     g = self.graph = StepGraph(captured_step, base.num_envs, control.adim, base.device)
@@ -746,7 +916,14 @@ class Accelerated:
                         torch.cuda.synchronize()
                     if isinstance(e, Unsupported):
                         raise
-                    raise Unsupported(f"the task's step cannot be captured as a HIP graph: {str(e).splitlines()[0][:300]}") from e
+                    culprit = ""
+                    if base.device.type == "cuda":
+                        from .graph import probe_capture
+                        try:
+                            culprit = probe_capture(captured_step, torch.zeros(base.num_envs, control.adim, device=base.device), base.device)
+                        except Exception as pe:   # noqa: BLE001 -- a diagnostic must not mask the error it explains
+                            culprit = f"(probe failed: {str(pe).splitlines()[0][:120]})"
+                    raise Unsupported(f"the task's step cannot be captured as a HIP graph: {str(e).splitlines()[0][:300]}" + (f" -- first offender: {culprit}" if culprit else "")) from e
                 self.level = "graph"
                 self._step_fn = lambda action: g(action) if action is not None else cls_step(base, None)
             base.step = self._step
@@ -759,5 +936,6 @@ def accelerate(env, graph=False, task: bool = True) -> Accelerated:
     it was when the env uses a controller / hook / observation mode that is not restated here.  ``graph=True`` (task level, GPU) additionally captures the
     control step as one HIP graph (with a task plugin: the plugin's step; without: the reference's own ``BaseEnv.step`` behind the fused controller, for tasks
     whose code is capturable); call ``env.reset`` afterwards (the capture runs throw-away steps).  ``graph="dry"``: what the capture would run, run eagerly at
-    every step -- for the CPU suite and for debugging; ``graph="force"``: capture a task that is not in ``GRAPH_VERIFIED``."""
+    every step -- for the CPU suite and for debugging; ``graph="watch"``: the same plus ``.safety``, the verdict of ``graph_safety`` that ``graph=True`` asks
+    for before it captures a task's own step; ``graph="force"``: capture without asking."""
     return Accelerated(env, graph, task)

@@ -98,6 +98,63 @@ def _clone_tree(x, _st=None):
     return x
 
 
+def probe_capture(step_fn, action, device) -> str:
+    """Why a step cannot be captured: runs ``step_fn`` once more inside a (throw-away) stream capture and asks the HIP runtime after every torch operator
+    and every C-ABI call whether the capture is still valid (``hipStreamIsCapturing``); returns the first one after which it is not, with the line of host
+    code that issued it -- or "" when the capture survives.  A diagnostic for error messages: a failed capture otherwise only says
+    "operation failed due to a previous error during capture"."""
+    import ctypes
+    import os
+    import traceback
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from . import _native
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+    except OSError:
+        return ""
+    hip.hipStreamIsCapturing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    found = []
+
+    def site():
+        for f in reversed(traceback.extract_stack(limit=80)[:-2]):
+            if "/torch/" not in f.filename and not f.filename.endswith(("maniskill_amd/graph.py", "maniskill_amd/fused_step.py")):
+                return f"{os.path.basename(os.path.dirname(f.filename))}/{os.path.basename(f.filename)}:{f.lineno}"
+        return "?"
+
+    def alive(what):
+        if found:
+            return
+        st = ctypes.c_int(0)
+        rc = hip.hipStreamIsCapturing(ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream), ctypes.byref(st))
+        if rc != 0 or st.value != 1:       # hipStreamCaptureStatusActive = 1; 2 = invalidated
+            found.append(f"{what} @ {site()} (hipStreamIsCapturing: rc {rc}, status {st.value})")
+
+    class Probe(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            out = func(*args, **(kwargs or {}))
+            alive(str(func))
+            return out
+    orig_check = _native.NativeLib.check
+
+    def check(self, ctx, code, what):
+        alive(f"{self.prefix}{what}")
+        return orig_check(self, ctx, code, what)
+    _native.NativeLib.check = check
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            alive("capture begin")
+            with Probe():
+                step_fn(action)
+    except Exception as e:   # noqa: BLE001 -- the failure this probe is asked to explain
+        if not found:
+            found.append(f"no operator or C-ABI call was caught invalidating the capture; it ended with: {str(e).splitlines()[0][:200]}")
+    finally:
+        _native.NativeLib.check = orig_check
+        torch.cuda.synchronize(device)
+    return found[0] if found else ""
+
+
 class StepGraph:
     """Captures ``step_fn(action) -> (obs, reward, terminated, truncated, info)`` of one env shard."""
 

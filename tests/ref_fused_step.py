@@ -133,14 +133,20 @@ def main():
 
         def task_code(k):
             return torch.tensor([float(k), 0.0], device="cpu")
-        with mode:
-            a = task_code(1.0)
-            b = task_code(1.0)
+        def step(k):                # one `with` = one step (the k-th evaluation of a call path INSIDE a step is a constant of its own: loops)
+            with mode:
+                return task_code(k)
+        outs, raised = [], False
+        for k in (1.0, 1.0, 2.0):   # (one call line: the call path is part of the key -- in the product it ends at the step's entry in fused_step.py)
             try:
-                task_code(2.0)
-                raised = False
+                outs.append(step(k))
             except Unsupported:
                 raised = True
+        a, b = outs[0], outs[1]
+        raised = raised and len(outs) == 2
+        with mode:                  # two callers of one helper line inside one step: two constants, not one that changes (Pose.create -> common.to_tensor)
+            c1, c2 = task_code(5.0), task_code(6.0)
+        raised = raised and float(c1[0]) == 5.0 and float(c2[0]) == 6.0
         res = dict(raised=raised, served=mode.served, clones=a.data_ptr() != b.data_ptr(), equal=bool(torch.equal(a, b)))
     elif case == "auto":
         import warnings
@@ -194,9 +200,7 @@ def main():
             accelerate(env, graph=True)
             res = dict(raised=False)
         except Unsupported as e:
-            res = dict(raised=True, message=str(e)[:120], untouched="_step_action" not in env.unwrapped.__dict__ and "step" not in env.unwrapped.__dict__)
-        from maniskill_amd.fused_step import GRAPH_VERIFIED
-        res["listed"] = sorted(GRAPH_VERIFIED)
+            res = dict(raised=True, message=str(e)[:400], untouched="_step_action" not in env.unwrapped.__dict__ and "step" not in env.unwrapped.__dict__)
     elif case == "unsupported":
         env = gym.make("PickCube-v1", num_envs=2, render_backend="none", control_mode="pd_ee_delta_pose")
         try:
@@ -208,75 +212,15 @@ def main():
         # What a HIP-graph replay of the step needs, checked on the op stream (no GPU needed): (1) nothing that synchronises, (2) no state that travels
         # from one step to the next through a tensor the earlier step ALLOCATED (a replay re-reads the memory that was current at capture time; state has to
         # live in tensors that persist and are updated in place)
-        from torch.utils._python_dispatch import TorchDispatchMode
-        import traceback
         eid = case.split(":", 1)[1]
         kw = {} if eid.startswith("OpenCabinet") or eid == "PushT-v1" else dict(render_backend="none")      # (PushT reads the render shapes it has just attached)
         env = gym.make(eid, num_envs=n, **kw)
-        acc = accelerate(env, graph="dry")            # (a task plugin where there is one, else the reference's own step under DeviceConstants)
         env.reset(seed=0)
-        base = env.unwrapped
-
-        def tensors(x, out):
-            if isinstance(x, torch.Tensor):
-                out.append(x)
-            elif isinstance(x, (list, tuple)):
-                for v in x:
-                    tensors(v, out)
-            elif isinstance(x, dict):
-                for v in x.values():
-                    tensors(v, out)
-            return out
-
-        def site():
-            for f in reversed(traceback.extract_stack(limit=60)[:-2]):
-                if "/torch/" not in f.filename and not f.filename.endswith("ref_fused_step.py") and f.name != "__torch_function__":
-                    return f"{os.path.basename(f.filename)}:{f.lineno}"
-            return "?"
-
-        class Watch(TorchDispatchMode):
-            def __init__(self, earlier):
-                super().__init__()
-                self.earlier, self.made, self.keep, self.sync, self.flow, self.host = earlier, set(), [], [], [], []
-
-            def __torch_dispatch__(self, func, types, args=(), kwargs=None):
-                name = str(func)
-                ins = tensors([args, kwargs or {}], [])
-                if any(t in name for t in ("_local_scalar_dense", "nonzero", "masked_select", "aten.equal", "is_nonzero", "unique")):
-                    self.sync.append(f"{name} @ {site()}")
-                if "aten.index" in name:
-                    for ix in (args[1] or []):
-                        if ix is not None and ix.dtype in (torch.bool, torch.uint8):
-                            v = args[2] if len(args) > 2 else None
-                            if "index_put" in name and v is not None and v.numel() == 1 and v.device.type == "cpu" and len(args[1]) == 1:
-                                continue        # x[mask] = scalar: dispatched to masked_fill, no nonzero()
-                            self.sync.append(f"{name} with a mask @ {site()}")
-                if "lift_fresh" in name and ins and ins[0].ndim > 0:
-                    # host data turned into a tensor inside the step.  With `device=` in the same call it is an upload, which fused_step.DeviceConstants serves
-                    # from the device (then this op does not appear); `torch.tensor(array).to(device)` (utils/common.py:167) makes the host tensor here and
-                    # uploads in `.to`, which DeviceConstants serves on a GPU and which is no copy at all on the CPU checker: listed, not counted
-                    self.host.append(f"host data of shape {tuple(ins[0].shape)} @ {site()}")
-                for t in ins:
-                    if t.untyped_storage().nbytes() > 0 and t.untyped_storage().data_ptr() in self.earlier:      # (empty tensors share the null address)
-                        self.flow.append(f"{name} reads a tensor the previous step allocated @ {site()}")
-                out = func(*args, **(kwargs or {}))
-                inp = {t.untyped_storage().data_ptr() for t in ins}
-                for t in tensors(out, []):
-                    if t.untyped_storage().nbytes() > 0 and t.untyped_storage().data_ptr() not in inp:
-                        self.made.add(t.untyped_storage().data_ptr())
-                        self.keep.append(t)            # alive until the next step was watched: its address is not handed out again
-                return out
-        act = 2 * torch.rand(env.action_space.shape) - 1
-        for _ in range(2):
-            base.step(act)
-        w1 = Watch(set())
-        with w1:
-            base.step(act)
-        w2 = Watch(w1.made)
-        with w2:
-            base.step(act)
-        res = dict(level=acc.level, sync=sorted(set(w1.sync + w2.sync)), flow=sorted(set(w2.flow)), host_data=sorted(set(w1.host + w2.host)),
-                   constants_served=getattr(getattr(acc, "constants", None), "served", 0))
+        acc = accelerate(env, graph="watch")          # (a task plugin where there is one -- then no verdict is needed --, else the reference's own step under DeviceConstants, watched)
+        v = acc.safety or dict(sync=[], flow=[], host_data=[])
+        c = getattr(acc, "constants", None)
+        res = dict(level=acc.level, sync=v["sync"], flow=v["flow"], host_data=v["host_data"], constants_served=getattr(c, "served", 0), rewritten=getattr(c, "rewritten", 0),
+                   masked=getattr(c, "masked", 0))
     elif case == "speed":
         out = {}
         for form, kw in (("reference", None), ("control", dict(task=False)), ("task", {}), ("graph", dict(graph=True))):

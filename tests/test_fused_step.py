@@ -117,25 +117,37 @@ def test_push_t_with_its_intersection_renderer_patched_has_the_references_bits(b
 
 
 @needs_ref
-def test_a_task_that_is_not_verified_for_replay_is_not_captured(built):
+def test_a_task_that_carries_state_through_fresh_tensors_is_not_captured(built):
+    """accelerate(graph=True) watches the task's own step first (fused_step.graph_safety): RotateSingleObjectInHand keeps its previous unit vector in a tensor
+    it allocates anew every step -- that captures without an error and replays stale, so it is refused (round 4 kept a list of task ids instead)"""
     res = _run("oracle", "not_verified")
-    assert res["raised"] and res["untouched"] and "not among the tasks" in res["message"], res
-    assert "PushT-v1" in res["listed"] and "RotateSingleObjectInHandLevel0-v1" not in res["listed"]
+    assert res["raised"] and res["untouched"] and "not safe to replay" in res["message"] and "previous step allocated" in res["message"], res
 
 
 @needs_ref
 def test_host_data_that_changes_between_steps_cannot_be_baked_into_a_graph(built):
     res = _run("oracle", "changing_constant")
-    assert res["raised"] and res["served"] == 2 and res["clones"] and res["equal"], res
+    assert res["raised"] and res["served"] == 4 and res["clones"] and res["equal"], res
+
+
+@needs_ref
+@pytest.mark.parametrize("env_id,idioms", [("StackCube-v1", 8), ("PokeCube-v1", 12), ("PlugCharger-v1", 8), ("PullCubeTool-v1", 16)])
+def test_masked_assignments_of_the_reference_become_selects(built, env_id, idioms):
+    """``x[mask] = y[mask]`` (stack_cube.py:161), ``x[mask] += y[mask]`` (poke_cube.py:221), ``x[~m] = sin(h[~m]) / a[~m]`` (rotation_conversions.py:549-552): each
+    a ``nonzero()`` -- a host synchronisation no capture allows.  DeviceConstants rewrites them into ``where`` while the step is warmed up, watched and captured:
+    the watch then finds nothing, and the eager run of the same path has the reference's bits.  No per-task code (round 4 restated two reward functions)."""
+    res = _run("oracle", "graph_safe:" + env_id, 3)
+    assert res["sync"] == [] and res["flow"] == [] and res["rewritten"] >= idioms, res
+    res = _run("oracle", "dry:" + env_id, 4, 12)
+    assert res["worst_state"] == 0.0 and res["worst_obs"] == 0.0 and res["worst_rew"] == 0.0 and res["flags"], res
 
 
 @needs_ref
 def test_the_watch_does_flag_a_step_that_cannot_be_captured(built):
-    res = _run("oracle", "graph_safe:PokeCube-v1", 3)           # poke_cube.py:208: reward[mask] = tensor
-    assert any("with a mask" in s for s in res["sync"]), res
+    res = _run("oracle", "graph_safe:MS-HopperHop-v1", 3)           # a scalar read back from the device
+    assert res["sync"], res
 
 
-@needs_ref
 @pytest.mark.gpu
 @pytest.mark.first_hardware_run
 def test_open_cabinet_drawer_task_plugin_on_hip(built):

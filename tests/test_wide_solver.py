@@ -40,7 +40,7 @@ def _roll(factory, tpl, n, steps, capacity, push=None):
     rbd[:, tpl.body_id("table-workspace"), :7] = torch.tensor([-0.12, 0.0, -sb.TABLE_HEIGHT, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)], device=rbd.device)
     if push is not None:
         for e in range(n):
-            rbd[e, push, 7:10] = torch.tensor([0.05 * e, 0.02 * e, 0.0], device=rbd.device)
+            rbd[e, push, 7:10] = torch.tensor([0.05 * (e % 7), 0.02 * (e % 7), 0.0], device=rbd.device)      # (a comb sent off at 15 m/s ends in a heap of more than 128 points)
     px.gpu_apply_all()
     px.set_scene_offsets(np.zeros((n, 3)))
     out = []
@@ -99,7 +99,8 @@ def test_hip_wide_class_matches_the_oracle(oracle_factory, scene):
     hip, pa = _roll(lambda t, k, c: PhysxGpuSystem("cuda:0", t, k, c), tpl, n, steps, 1, push=ids[0])
     orc, pb = _roll(oracle_factory, tpl, n, steps, 1, push=ids[0])
     assert torch.equal(hip, orc), (scene, (hip - orc).abs().max().item())
-    assert pa.get_overflow() == 0 and pa.get_solver_class_counts()[4] > 0
+    assert pa.get_overflow() == pb.get_overflow() == 0
+    assert pa.get_solver_class_counts()[4] > 0
 
 
 def test_the_reference_tasks_that_overflowed_run_without_overflow_with_the_wide_capacity(built):
