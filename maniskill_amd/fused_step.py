@@ -591,13 +591,25 @@ class DeviceConstants(torch.overrides.TorchFunctionMode):
         self.device = torch.device(device)
         self.cache = {}
         self.served = 0
-        self.masked = self.rewritten = 0      # y[mask] handed out unevaluated / masked assignments turned into selects
+        self.masked = self.rewritten = self.syncs_skipped = 0      # y[mask] handed out unevaluated / masked assignments turned into selects / device waits skipped
         self._seen, self._nots = {}, {}
 
     def __enter__(self):
         self._seen = {}                 # one step = one `with`: the k-th evaluation of a call path inside a step is its own constant (loops)
         self._nots = {}
+        # `torch.cuda.synchronize()` inside the step (sapien_env.py:624, behind take_picture: "prevents the GPU from making poor scheduling decisions") is
+        # a scheduling hint there, not a data dependency -- everything of a step is ordered on one stream -- and a stream capture forbids it (first seen on
+        # hardware in round 5: the CPU checker has no device to wait for): a no-op while the step is warmed up, watched, captured
+        self._sync = torch.cuda.synchronize
+        torch.cuda.synchronize = self._no_sync
         return super().__enter__()
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize = self._sync
+        return super().__exit__(*exc)
+
+    def _no_sync(self, *a, **k):
+        self.syncs_skipped += 1
 
     @staticmethod
     def _site():
@@ -783,6 +795,7 @@ class Accelerated:
         self._saved = [(n, n in self.base.__dict__, self.base.__dict__.get(n)) for n in ("_step_action", "step")]
         self.graph = self.plugin = self.constants = self.plugin_refused = self.safety = None
         self.rebuilds = 0
+        self.throwaway_steps = 0         # control steps (zero action) the build ran on the env: the watch's 4, a capture's warm-up + 1
         try:
             self._build(graph)
         except BaseException:
@@ -868,10 +881,11 @@ class Accelerated:
         if plugin is not None:
             self.level, self.plugin = "task", plugin
             self._step_fn = plugin.step
-            if graph and graph != "dry":
+            if graph and graph not in ("dry", "watch"):      # (a plugin's step is written for replay: no verdict needed)
                 from .graph import StepGraph
                 try:
                     g = self.graph = StepGraph(plugin.step, base.num_envs, control.adim, base.device)
+                    self.throwaway_steps += 3
                 except Exception as e:      # noqa: BLE001  (not a GPU env, host-memory backend, a capture error): the caller falls back to the task level
                     if base.device.type == "cuda":
                         torch.cuda.synchronize()
@@ -901,9 +915,11 @@ class Accelerated:
                 self.level = "graph-dry"
                 self._step_fn = captured_step
                 self.safety = graph_safety(captured_step, torch.zeros(base.num_envs, control.adim, device=base.device))
+                self.throwaway_steps += 4
             else:
                 if graph is True:       # (graph="force" captures without asking)
                     verdict = self.safety = graph_safety(captured_step, torch.zeros(base.num_envs, control.adim, device=base.device))
+                    self.throwaway_steps += 4
                     if verdict["sync"] or verdict["flow"]:
                         what = "; ".join((verdict["sync"] + verdict["flow"])[:3])
                         raise Unsupported(f"the task's own step is not safe to replay as a graph: {what}" + (" (a capture refuses the first kind; the second kind -- state "
@@ -911,6 +927,7 @@ class Accelerated:
                 from .graph import StepGraph
                 try:
                     g = self.graph = StepGraph(captured_step, base.num_envs, control.adim, base.device)
+                    self.throwaway_steps += 3
                 except Exception as e:      # noqa: BLE001  (a capture error: HIP reports the forbidden call)
                     if base.device.type == "cuda":
                         torch.cuda.synchronize()
@@ -935,7 +952,10 @@ def accelerate(env, graph=False, task: bool = True) -> Accelerated:
     replacements of ``_step_action`` and -- where a task plugin exists and ``task`` is true -- of ``step``).  Raises ``Unsupported`` and leaves the env as
     it was when the env uses a controller / hook / observation mode that is not restated here.  ``graph=True`` (task level, GPU) additionally captures the
     control step as one HIP graph (with a task plugin: the plugin's step; without: the reference's own ``BaseEnv.step`` behind the fused controller, for tasks
-    whose code is capturable); call ``env.reset`` afterwards (the capture runs throw-away steps).  ``graph="dry"``: what the capture would run, run eagerly at
+    whose code is capturable); call ``env.reset`` afterwards (the capture and the watch before it run ``.throwaway_steps`` throw-away steps with a zero action --
+    a reset of the REFERENCE does not undo everything a step did: drive targets stay in the simulation until the next action, and OpenCabinetDrawer-v1's
+    ``_initialize_episode`` steps the physics once (open_cabinet_drawer.py:276-283), so an env that has stepped resets to a slightly different state than a
+    fresh one -- on PhysX as here).  ``graph="dry"``: what the capture would run, run eagerly at
     every step -- for the CPU suite and for debugging; ``graph="watch"``: the same plus ``.safety``, the verdict of ``graph_safety`` that ``graph=True`` asks
     for before it captures a task's own step; ``graph="force"``: capture without asking."""
     return Accelerated(env, graph, task)

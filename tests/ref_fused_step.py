@@ -36,18 +36,25 @@ def _flat(x):
     return x.reshape(x.shape[0], -1).float()
 
 
-def _compare(gym, eid, n, steps, kw, acc_kw, atol=0.0):
+def _compare(gym, eid, n, steps, kw, acc_kw, atol=0.0, history=0):
     import torch
     from maniskill_amd.fused_step import accelerate
     a, b = gym.make(eid, num_envs=n, **kw), gym.make(eid, num_envs=n, **kw)
     dev = a.unwrapped.device
     acc = accelerate(b, **acc_kw)
+    for _ in range(history):      # what a capture does to an env before its first reset: throw-away steps with a zero action
+        b.unwrapped.step(torch.zeros(b.action_space.shape, device=dev))
+    # ... and the reference's reset does not undo all of it (drive targets stay in the simulation until the next action; OpenCabinetDrawer's _initialize_episode
+    # steps the physics once under them): the env that is compared against gets the same history
+    for _ in range(getattr(acc, "throwaway_steps", 0) + history):
+        a.unwrapped.step(torch.zeros(a.action_space.shape, device=dev))
     oa, _ = a.reset(seed=3)
     ob, _ = b.reset(seed=3)
     res = dict(level=acc.level, graph=acc.graph is not None, reset_equal=bool(torch.equal(_flat(oa), _flat(ob))), groups=len(getattr(a.unwrapped.scene.px, "_groups", [0])))
     g = torch.Generator().manual_seed(1)
     worst_obs = worst_rew = worst_state = 0.0
     flags = True
+    trace = []
     for k in range(steps):
         act = 2 * torch.rand(a.action_space.shape, generator=g) - 1
         if k % 7 == 3:
@@ -56,6 +63,9 @@ def _compare(gym, eid, n, steps, kw, acc_kw, atol=0.0):
         ra, rb = a.step(act), b.step(act)
         sa, sb = a.unwrapped.get_state(), b.unwrapped.get_state()
         worst_state = max(worst_state, float((sa - sb).abs().max()))
+        if len(trace) < 6 and float((sa - sb).abs().max()) > 0:      # where a mismatch starts: step, env, state column
+            d = (sa - sb).abs()
+            trace.append((k, int(d.max(dim=1).values.argmax()), int(d.max(dim=0).values.argmax()), float(d.max()), int((d.max(dim=1).values > 0).sum())))
         worst_obs = max(worst_obs, float((_flat(ra[0]) - _flat(rb[0])).abs().max()))
         assert ra[1].dtype == rb[1].dtype and type(ra[0]) is type(rb[0])
         worst_rew = max(worst_rew, float((ra[1].float() - rb[1].float()).abs().max()))
@@ -70,7 +80,7 @@ def _compare(gym, eid, n, steps, kw, acc_kw, atol=0.0):
         ra, rb = a.step(act), b.step(act)
         worst_obs = max(worst_obs, float((_flat(ra[0]) - _flat(rb[0])).abs().max()))
         worst_state = max(worst_state, float((a.unwrapped.get_state() - b.unwrapped.get_state()).abs().max()))
-    res.update(worst_obs=worst_obs, worst_rew=worst_rew, worst_state=worst_state, flags=flags, finite=bool(torch.isfinite(_flat(ra[0])).all()))
+    res.update(worst_obs=worst_obs, worst_rew=worst_rew, worst_state=worst_state, flags=flags, finite=bool(torch.isfinite(_flat(ra[0])).all()), mismatch_trace=trace)
     acc.restore()
     res["restored"] = "step" not in b.unwrapped.__dict__ and "_step_action" not in b.unwrapped.__dict__
     return res
@@ -87,6 +97,8 @@ def main():
     from maniskill_amd.fused_step import Unsupported, accelerate
     if case == "cabinet":
         res = _compare(gym, "OpenCabinetDrawer-v1", n, steps, {}, {})
+    elif case == "cabinet_history":        # the eager plugin on envs that have stepped before their first reset, like a captured one (both: see _compare)
+        res = _compare(gym, "OpenCabinetDrawer-v1", n, steps, {}, {}, history=3)
     elif case == "cabinet_graph":
         res = _compare(gym, "OpenCabinetDrawer-v1", n, steps, {}, dict(graph=True))
     elif case.startswith("graph:"):           # the reference's OWN task code behind the fused controller, captured (tasks whose step is graph-safe)

@@ -35,6 +35,15 @@ def test_open_cabinet_drawer_task_plugin_has_the_references_bits_on_cpu_checker(
 
 
 @needs_ref
+def test_envs_that_stepped_before_their_first_reset_still_agree(built):
+    """A capture runs throw-away steps before the env's first reset, and the reference's reset does not undo all of a step (drive targets stay in the simulation;
+    OpenCabinetDrawer's _initialize_episode steps the physics once under them): with the SAME history the plugin and the reference agree bit for bit -- the
+    comparison the -m gpu graph tests make (round 5's first hardware run compared a captured env with a fresh one: 0.29 apart at the first step)."""
+    res = _run("oracle", "cabinet_history", 6, 8)
+    assert res["reset_equal"] and res["worst_state"] == 0.0 and res["worst_obs"] == 0.0 and res["worst_rew"] == 0.0 and res["flags"], res
+
+
+@needs_ref
 @pytest.mark.parametrize("case", ["pickcube", "pickcube:dense", "pickcube:sparse"])
 def test_pick_cube_task_plugin_has_the_references_bits_on_cpu_checker(built, case):
     _same_bits(_run("oracle", case, 5, 25), "task")
