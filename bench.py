@@ -92,7 +92,7 @@ def spawn_ranks(n: int, argv) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def bootstrap_selftest(gpus: int) -> int:
+def bootstrap_selftest(gpus: int, args=None) -> int:
     """The rank bootstrap alone, without a GPU (tests/test_bench_bootstrap.py): rendezvous over gloo, one all-reduce, rank 0 prints one
     JSON line.  No physics runs here -- the product path has no CPU fallback."""
     from maniskill_amd.dist import init_distributed
@@ -102,6 +102,13 @@ def bootstrap_selftest(gpus: int) -> int:
         dist.all_reduce(t)
         dist.barrier()
     ok = world == gpus and float(t.item()) == world * (world + 1) / 2
+    hook = os.environ.get("MSK_BENCH_SELFTEST_HOOK")
+    if hook and ok:      # test infrastructure (tests/ref_bench_hook.py): runs bench's own rollout code on shards it builds on the CPU checker, on these ranks
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("msk_bench_hook", hook)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return int(mod.run(sys.modules[__name__], args, rank, world) or 0)
     if rank == 0:
         print(json.dumps({"bootstrap": "ok" if ok else "mismatch", "world": world, "sum": float(t.item())}), flush=True)
     if world > 1:
@@ -209,9 +216,14 @@ def dropin_sharded_main(args) -> int:
     t_build = time.perf_counter()
     shard = make_sharded_gym_env(args.env, args.envs, device_type="cuda", reference_root=ref, obs_mode=args.obs_mode,
                                  accelerate=None if args.accelerate == "none" else args.accelerate, **kw)
-    rank, world, dev, n_local = shard.rank, shard.world, shard.device, shard.num_envs
     shard.reset(seed=2022)
-    build_s = time.perf_counter() - t_build
+    return dropin_sharded_run(args, shard, time.perf_counter() - t_build)
+
+
+def dropin_sharded_run(args, shard, build_s: float = 0.0) -> int:
+    """the timed rollout of one rank's shard of a drop-in env and rank 0's JSON line (the env is built by the caller: dropin_sharded_main on the GPU; the CPU
+    suite hands in shards on its checker through the bootstrap self-test's hook, tests/ref_bench_hook.py)"""
+    rank, world, dev, n_local = shard.rank, shard.world, shard.device, shard.num_envs
     adim = shard.action_space.shape[-1]
     acc = getattr(shard.unwrapped, "_msk_accelerated", None)
     g = shard.gather
@@ -220,7 +232,8 @@ def dropin_sharded_main(args) -> int:
     def sync():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
     gather = (lambda o, r, t, u: g.pipelined(o, r, t, u)) if state_obs else (lambda *a: None)
     flush = g.flush if state_obs else (lambda: None)
     torch.manual_seed(0 + rank)
@@ -241,7 +254,7 @@ def dropin_sharded_main(args) -> int:
             "config": {"workload": f"{args.env}, num_envs={args.envs}, {args.obs_mode} obs, the task's default control mode", "envs_per_gpu": n_local,
                        "parallelism": f"env-shard x{world}", "build_s": build_s},
         }), flush=True)
-    if world > 1:
+    if world > 1 and build_s:       # (the self-test's hook keeps the process group: bootstrap_selftest ends it)
         dist.barrier()
         dist.destroy_process_group()
     return 0
@@ -357,7 +370,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
                          "or without a launcher (bench.py then starts its ranks itself)")
     if args.bootstrap_selftest:
-        raise SystemExit(bootstrap_selftest(args.gpus))
+        raise SystemExit(bootstrap_selftest(args.gpus, args))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (the product path has no CPU fallback)")
     if args.env not in FUSED_HOSTS:
