@@ -200,10 +200,9 @@ def dropin_sharded_main(args) -> int:
     if ref is None:
         print(json.dumps({"error": "no reference build present (oracle/_ref/maniskill is made by __graft_entry__.build() where /root/reference exists)"}))
         return 1
-    ref_harness.setup("hip")      # the reference on sys.path over the sapien shim on libmsk_physx.so (stand-ins for gymnasium etc. appended)
     from maniskill_amd.dist import make_sharded_gym_env
     kw = {}
-    if args.env.startswith("OpenCabinet") and args.synthetic_partnet:
+    if args.env.startswith("OpenCabinet") and args.synthetic_partnet:      # (before mani_skill is imported: it reads MS_ASSET_DIR then)
         import subprocess
         assets = f"/tmp/ms_assets_synth_bench_{os.environ.get('LOCAL_RANK', '0')}"
         meta = os.path.join(ref, "mani_skill", "assets", "partnet_mobility", "meta")
@@ -213,6 +212,7 @@ def dropin_sharded_main(args) -> int:
         os.environ["MS_ASSET_DIR"] = assets
     elif args.obs_mode == "state":
         kw["render_backend"] = "none"
+    ref_harness.setup("hip")      # the reference on sys.path over the sapien shim on libmsk_physx.so (stand-ins for gymnasium etc. appended)
     t_build = time.perf_counter()
     shard = make_sharded_gym_env(args.env, args.envs, device_type="cuda", reference_root=ref, obs_mode=args.obs_mode,
                                  accelerate=None if args.accelerate == "none" else args.accelerate, **kw)
@@ -577,11 +577,14 @@ def main():
             },
         }
         if camera_mode:
-            img_bytes = n_local * 128 * 128 * (8 + 2 + 2 + (4 if "rgb" in args.obs_mode else 0))   # PositionSegmentation int16 x 4, the depth and segmentation planes int16 (+ Color u8 x 4) per pixel
+            # what one picture writes: the depth and segmentation planes, int16 each (+ Color u8 x 4) -- the fused envs ask the rasteriser for the planes only
+            # (msk_camera_set_outputs: no obs mode of theirs hands out `position`); with the int16 x 4 PositionSegmentation texture it was 12 bytes per pixel
+            tex = 8 if env.camera._position_texture else 0
+            img_bytes = n_local * 128 * 128 * (tex + 2 + 2 + (4 if "rgb" in args.obs_mode else 0))
             result["metric"] = f"env steps/sec (whole node), {args.envs} parallel {args.env} envs, 128x128 {args.obs_mode} camera obs"
-            result["config"]["workload"] += ", base_camera 128x128 PositionSegmentation" + (" + Color" if "rgb" in args.obs_mode else "")
+            result["config"]["workload"] += ", base_camera 128x128 " + ("PositionSegmentation + " if tex else "") + "depth + segmentation planes" + (" + Color" if "rgb" in args.obs_mode else "")
             result["camera"] = {"kernel": "k_render_env" if os.environ.get("MSK_RENDER_MODE") == "0" else "k_render_splat", "us_per_frame": cam_us,
-                                "bound": "hbm", "algorithmic_bytes_per_frame": img_bytes,
+                                "bound": "hbm", "algorithmic_bytes_per_frame": img_bytes, "position_texture": bool(tex),
                                 "achieved": img_bytes / (cam_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": img_bytes / (cam_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
         if dt_reset:

@@ -84,6 +84,11 @@ void* msk_camera_buffer(msk_ctx* ctx, int camera, int64_t shape[4]);
  * at the triangle's centroid, inverse-square, see msk_render_set_local_lights). */
 enum msk_camera_plane { MSK_CAM_DEPTH = 0, MSK_CAM_SEGMENTATION = 1, MSK_CAM_COLOR = 2 };
 void* msk_camera_obs_buffer(msk_ctx* ctx, int camera, int which, int64_t shape[4]);
+/* Which outputs msk_camera_take_picture fills from now on.  position_texture = 0: the caller only reads the depth / segmentation planes (Camera.get_obs with
+ * position=False -- every ManiSkill obs mode but the ones with `position`, sensors/camera.py:190-242) and the int16 x 4 PositionSegmentation texture is neither
+ * computed (camera-space x, y) nor stored: 8 of the 12 bytes a pixel costs; the texture's contents are then undefined until a picture is taken with
+ * position_texture = 1 (the default).  The planes are the same bits either way. */
+int msk_camera_set_outputs(msk_ctx* ctx, int camera, int position_texture);
 /* render_system_group.update_render() + camera_group.take_picture(): rasterises every env. */
 int msk_camera_take_picture(msk_ctx* ctx, int camera, void* stream);
 

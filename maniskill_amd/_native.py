@@ -35,7 +35,7 @@ EXPORTS = [
 ]
 # include/msk_render.h — camera pipeline (both libraries)
 RENDER_EXPORTS = ["render_add_mesh", "render_set_base_color", "render_set_texture", "render_bind_env_box", "render_set_lights", "render_set_local_lights", "render_finalize", "camera_create", "camera_buffer",
-                  "camera_obs_buffer", "camera_take_picture"]
+                  "camera_obs_buffer", "camera_set_outputs", "camera_take_picture"]
 # include/msk_task.h — fused task kernels (HIP library only; the test-suite's CPU checker has no counterpart)
 TASK_EXPORTS = ["task_pickcube_init", "task_pickcube_set_action", "task_pickcube_set_action_ee", "compute_ik_delta", "control_step", "task_pickcube_observe",
                 "task_pusht_init", "task_pusht_set_action", "task_pusht_observe", "task_peg_init", "task_peg_observe"]
@@ -171,6 +171,7 @@ class NativeLib:
             "render_set_texture": (i32, [vp, i32, C.POINTER(C.c_uint8), i32, i32, C.POINTER(C.c_float)]),
             "camera_buffer": (vp, [vp, i32, C.POINTER(C.c_int64)]),
             "camera_obs_buffer": (vp, [vp, i32, i32, C.POINTER(C.c_int64)]),
+            "camera_set_outputs": (i32, [vp, i32, i32]),
             "camera_take_picture": (i32, [vp, i32, vp]),
         }
         for name, (res, args) in render_sig.items():

@@ -1422,7 +1422,14 @@ MSK_API int msk_camera_create(msk_ctx* c, int width, int height, float fovy, flo
   ALLOC(cam.depth, N * (size_t)width * height);
   ALLOC(cam.seg, N * (size_t)width * height);
   ALLOC(cam.overflow, 1);
+  cam.want_tex = 1;
   return c->ncams++;
+}
+
+MSK_API int msk_camera_set_outputs(msk_ctx* c, int camera, int position_texture) {
+  if (camera < 0 || camera >= c->ncams) return fail(c, MSK_ERR_INVALID, "bad camera");
+  c->cams[camera].want_tex = position_texture ? 1 : 0;   /* a kernel argument of the next msk_camera_take_picture (a captured step graph keeps the value it was captured with) */
+  return MSK_OK;
 }
 
 MSK_API void* msk_camera_buffer(msk_ctx* c, int camera, int64_t shape[4]) {

@@ -83,6 +83,7 @@ struct RCamera {
   int uvcap;                       /* k_render_splat: screen triangles of textured shapes whose u/depth, v/depth planes the workgroup keeps (LDS); 0: no textures */
   unsigned* uvt;                   /* [N][H][W]: 1 + index of the texel under the pixel (0: none), written next to Color, resolved by k_render_texture */
   int bcap;                        /* k_render_splat: entries of the tile rows' lists of small records (LDS) */
+  int want_tex;                    /* 1: `out` is written; 0: only the planes (msk_camera_set_outputs): camera-space x, y are not computed, 8 of 12 bytes per pixel not stored */
 };
 #define MSK_SEG_SMALL 0x20000000    /* flag in TriSetup::seg (k_render_splat): pixel box <= 16 x 16, bb = x0 | y0 << 10 | (x1 - x0) << 20 | (y1 - y0) << 24 */
 #define MSK_SPLAT_MAX 16
@@ -554,7 +555,7 @@ __global__ void __launch_bounds__(MSK_RENDER_THREADS) k_render_env(const DModel*
       if (cam.dbg_cut == 5 && best_prim != -7) continue;      /* 5: the walk without its stores */
       if (cam.dbg_cut == 7) { ((short4*)cam.out)[pix] = o; continue; }   /* 7: only the 8-byte texture store */
 #endif
-      ((short4*)cam.out)[pix] = o;
+      if (cam.want_tex) ((short4*)cam.out)[pix] = o;
       if (cam.color) cam.color[pix] = best_col;
       cam.depth[pix] = (short)(-(int)o.z);   /* int16 negation wraps like the host-side `-position[..., 2]` */
       cam.seg[pix] = o.w;
@@ -946,9 +947,12 @@ __global__ void __launch_bounds__(MSK_RENDER_THREADS) k_render_splat(const DMode
         if (best_w > 0.0f) {
           const float4 rd = rec4(best_slot)[3];
           const float d = 1.0f / best_w;
-          const float gx = (x - cam.cx) / cam.fx * d, gy = gyc * d, gz = -d;
-          o.x = (short)fminf(fmaxf(rintf(gx * 1000.0f), -32768.0f), 32767.0f);
-          o.y = (short)fminf(fmaxf(rintf(gy * 1000.0f), -32768.0f), 32767.0f);
+          const float gz = -d;
+          if (cam.want_tex) { /* (wave-uniform: a kernel argument) */
+            const float gx = (x - cam.cx) / cam.fx * d, gy = gyc * d;
+            o.x = (short)fminf(fmaxf(rintf(gx * 1000.0f), -32768.0f), 32767.0f);
+            o.y = (short)fminf(fmaxf(rintf(gy * 1000.0f), -32768.0f), 32767.0f);
+          }
           o.z = (short)fminf(fmaxf(rintf(gz * 1000.0f), -32768.0f), 32767.0f);
           o.w = (short)(__float_as_int(rd.x) & 0xFFFF);
           best_col = __float_as_uint(rd.w);
@@ -966,7 +970,7 @@ __global__ void __launch_bounds__(MSK_RENDER_THREADS) k_render_splat(const DMode
         }
         const size_t pix = rowpix + (size_t)tx * MSK_TW;
         if (MSK_CUT_IS(9) && best_prim != -7) continue;
-        ((short4*)cam.out)[pix] = o;
+        if (cam.want_tex) ((short4*)cam.out)[pix] = o;
         if (cam.color) cam.color[pix] = best_col;
         if (cam.uvt) cam.uvt[pix] = texel;
         cam.depth[pix] = (short)(-(int)o.z);

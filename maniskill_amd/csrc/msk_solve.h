@@ -748,13 +748,10 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
       /* the packed class sweeps all three rows of every block: a row that does not exist has rinv = lam = 0 and a zero column, so its
        * update is an exact no-op -- cheaper than a scalar branch per row in the unrolled stream */
       unsigned rowbits;
-#ifdef MSK_AREG_ROWBITS      /* candidate (round 5 A/B): the packed class skips a row that no env of the wave has -- its update is an exact no-op on the serial chain
-                              * (rinv = lam = 0, a zero column: dl = +0, a += A * 0 leaves every a as it is, a is never -0) -- for one scalar bit test */
-      if (decltype(all_rows_tag)::value) rowbits = 7u;
-      else if (LY::AREG) rowbits = (unsigned)((wrows >> (blk * 3)) & 7ull);
-#else
+      /* (measured, round 5 A/B on one box: skipping the rows no env of the wave has with a scalar bit test each -- fewer steps on the serial chain -- makes
+       * the packed class SLOWER, k_csolve 58.0 -> 69.3 us: three scalar branches per block cost more than the no-op row updates they save;
+       * profiles/r05_ab_head_vs_e1_vs_c73dab6.log) */
       if (decltype(all_rows_tag)::value || LY::AREG) rowbits = 7u;
-#endif
       else if (GL == 64) rowbits = (unsigned)(((vm0 >> blk) & 1ull) | (((vm1 >> blk) & 1ull) << 1) | (((vm2 >> blk) & 1ull) << 2));
       else if (GL == 16) rowbits = (unsigned)((wrows >> (blk * 3)) & 7ull);
       else rowbits = (__ballot((vm0 >> blk) & 1ull) ? 1u : 0u) | (__ballot((vm1 >> blk) & 1ull) ? 2u : 0u) | (__ballot((vm2 >> blk) & 1ull) ? 4u : 0u);

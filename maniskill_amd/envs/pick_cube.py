@@ -216,6 +216,7 @@ class PickCubeEnv:
                 self.cameras[cfg.uid] = RenderCameraGroup(self.px, cfg)
                 if self._want_color:
                     self.cameras[cfg.uid].enable_color()
+                self.cameras[cfg.uid].set_outputs(position_texture=False)      # no obs mode of these envs hands out `position`
             self.camera = self.cameras["base_camera"]
         self.reset(seed=None)
 

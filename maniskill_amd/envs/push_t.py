@@ -104,6 +104,7 @@ class PushTEnv:
             self.camera = RenderCameraGroup(self.px, CameraConfig("base_camera", p, q, 128, 128, np.pi / 2, 0.01, 100.0))
             if self._want_color:
                 self.camera.enable_color()
+            self.camera.set_outputs(position_texture=False)      # no obs mode of this env hands out `position`: the planes (and Color) are all a step needs
         self.obs_dim = 7 + 7 + 7 + 3 + 7
         # fused task kernels (include/msk_task.h): controller, evaluate / obs / reward as two launches instead of ~100 torch ops
         can_fuse = getattr(self.px.lib, "has_task_kernels", False)      # (the CPU oracle has none; the emulated HIP library of tests/hipemu does)

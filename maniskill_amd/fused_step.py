@@ -795,7 +795,7 @@ class Accelerated:
         self._saved = [(n, n in self.base.__dict__, self.base.__dict__.get(n)) for n in ("_step_action", "step")]
         self.graph = self.plugin = self.constants = self.plugin_refused = self.safety = None
         self.rebuilds = 0
-        self.throwaway_steps = 0         # control steps (zero action) the build ran on the env: the watch's 4, a capture's warm-up + 1
+        self.throwaway_steps = 0         # control steps (zero action) the build ran on the env: the watch's 4, a capture's warm-up steps
         try:
             self._build(graph)
         except BaseException:
@@ -885,7 +885,7 @@ class Accelerated:
                 from .graph import StepGraph
                 try:
                     g = self.graph = StepGraph(plugin.step, base.num_envs, control.adim, base.device)
-                    self.throwaway_steps += 3
+                    self.throwaway_steps += g.executed_steps      # the warm-up steps run; the captured one is recorded, not executed
                 except Exception as e:      # noqa: BLE001  (not a GPU env, host-memory backend, a capture error): the caller falls back to the task level
                     if base.device.type == "cuda":
                         torch.cuda.synchronize()
@@ -927,7 +927,7 @@ class Accelerated:
                 from .graph import StepGraph
                 try:
                     g = self.graph = StepGraph(captured_step, base.num_envs, control.adim, base.device)
-                    self.throwaway_steps += 3
+                    self.throwaway_steps += g.executed_steps      # the warm-up steps run; the captured one is recorded, not executed
                 except Exception as e:      # noqa: BLE001  (a capture error: HIP reports the forbidden call)
                     if base.device.type == "cuda":
                         torch.cuda.synchronize()

@@ -184,6 +184,7 @@ class StepGraph:
         finally:
             CAPTURING = False
         self.replays = 0
+        self.executed_steps = warmup      # what the env went through while this object was built: the warm-up steps ran, the captured step was only recorded
 
     def __call__(self, action):
         if action is not None:

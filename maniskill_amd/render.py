@@ -154,6 +154,7 @@ class RenderCameraGroup:
         self._depth = wrap(L.camera_obs_buffer(px.ctx, cam, 0, shape), shape, "msk_camera_obs_buffer")
         self._seg = wrap(L.camera_obs_buffer(px.ctx, cam, 1, shape), shape, "msk_camera_obs_buffer")
         self._color_t = None   # Color r8g8b8a8unorm (N, H, W, 4) uint8: requested lazily (the backend only renders it once asked)
+        self._position_texture = True      # msk_camera_set_outputs: False = only the depth / segmentation planes are rendered (set_outputs)
         self._wrap = wrap
         # intrinsics of set_fovy(fovy, compute_x=True) (scene.py:250-257)
         fy = 0.5 * cfg.height / np.tan(0.5 * cfg.fov)
@@ -259,22 +260,41 @@ class RenderCameraGroup:
         """Ask for the Color texture before the first take_picture that should fill it."""
         return self._color
 
+    def set_outputs(self, position_texture: bool):
+        """``position_texture=False``: the caller only reads ``get_obs(depth=..., segmentation=..., rgb=...)`` -- the int16 x 4 PositionSegmentation texture is
+        neither computed nor stored from the next ``take_picture`` on (8 of the 12 bytes a pixel costs; the planes keep their bits).  Asking for the texture
+        all the same (``get_picture_cuda``, ``get_obs(position=True)``) renders it for that request."""
+        position_texture = bool(position_texture)
+        if position_texture != self._position_texture:
+            L = self.px.lib
+            L.check(self.px.ctx, L.camera_set_outputs(self.px.ctx, self.id, int(position_texture)), "camera_set_outputs")
+            self._position_texture = position_texture
+
+    def _texture(self):
+        """the PositionSegmentation texture of the CURRENT state.  With ``set_outputs(False)`` in force the pictures do not fill it (a captured step graph
+        keeps the mode it was captured with, whatever is set later), so it is rendered here, for this request, and the configured mode is restored."""
+        if not self._position_texture:
+            L = self.px.lib
+            L.check(self.px.ctx, L.camera_set_outputs(self.px.ctx, self.id, 1), "camera_set_outputs")
+            self.take_picture()
+            L.check(self.px.ctx, L.camera_set_outputs(self.px.ctx, self.id, 0), "camera_set_outputs")
+        return self._tex
+
     def get_picture_cuda(self, name: str = "PositionSegmentation") -> PictureHandle:
         if name == "Color":
             return PictureHandle(self._color)
         if name != "PositionSegmentation":
             raise KeyError(f"the minimal shader pack provides Color and PositionSegmentation, not {name}")
-        return PictureHandle(self._tex)
+        return PictureHandle(self._texture())
 
     def get_obs(self, depth=True, segmentation=True, position=False, copy=True, rgb=False):
         """Camera.get_obs (sensors/camera.py:190-242) with the minimal pack's texture transform.  ``copy=False`` hands
         out the rasteriser's own planes (overwritten by the next take_picture) instead of a snapshot."""
-        data = self._tex
         out = {}
         if rgb:          # Color[..., :3] (render/shaders.py:74)
             out["rgb"] = self._color[..., :3].clone() if copy else self._color[..., :3]
         if position:
-            out["position"] = data[..., :3]
+            out["position"] = self._texture()[..., :3]
         if depth:        # == -data[..., [2]]
             out["depth"] = self._depth.clone() if copy else self._depth
         if segmentation:  # == data[..., [3]]

@@ -288,6 +288,15 @@ ORC_EXPORT void* orc_camera_obs_buffer(orc_ctx* c, int camera, int which, int64_
   return which == MSK_CAM_DEPTH ? (void*)r->cams[camera].depth : (void*)r->cams[camera].seg;
 }
 
+/* msk_camera_set_outputs (include/msk_render.h): with position_texture = 0 the texture's contents are undefined -- this restatement keeps using it as its
+ * working picture, so it simply stays defined here; the planes are the same either way */
+ORC_EXPORT int orc_camera_set_outputs(orc_ctx* c, int camera, int position_texture) {
+  r_model* r = (r_model*)c->render;
+  (void)position_texture;
+  if (!r || camera < 0 || camera >= r->ncams) return rfail(c, MSK_ERR_INVALID, "bad camera");
+  return MSK_OK;
+}
+
 static void project_point(const r_camera* cam, v3 p, float* u, float* v, float* w) {
   const float iw = 1.0f / p.x;
   *u = fmaf(cam->fx, -p.y * iw, cam->cx);

@@ -169,8 +169,8 @@ def test_open_cabinet_drawer_task_plugin_on_hip(built):
 def test_open_cabinet_drawer_step_as_one_hip_graph(built):
     """the replayed graph against the reference's eager step: same launches, same arithmetic"""
     res = _run("hip", "cabinet_graph", 32, 20)
-    assert res["graph"] and res["level"] == "task" and res["flags"] and res["finite"], res
-    assert res["worst_state"] <= 1e-6 and res["worst_obs"] <= 1e-6 and res["worst_rew"] <= 1e-6, res
+    assert res["graph"] and res["level"] == "task" and res["flags"] and res["finite"], json.dumps(res)
+    assert res["worst_state"] <= 1e-6 and res["worst_obs"] <= 1e-6 and res["worst_rew"] <= 1e-6, json.dumps(res)
 
 
 @needs_ref

@@ -99,6 +99,28 @@ def test_pictures_match_oracle_bit_for_bit(emu_factory, oracle_factory, monkeypa
         assert emu.px.get_overflow() == 0
 
 
+def test_planes_only_pictures_leave_the_texture_alone_and_keep_the_planes_bits(emu_factory, oracle_factory):
+    """msk_camera_set_outputs(position_texture = 0), what the fused envs ask for (no obs mode of theirs hands out `position`): the rasteriser neither computes
+    camera-space x, y nor stores the int16 x 4 texture -- a sentinel in it survives the picture -- and depth / segmentation are the oracle's bits; asking for
+    the texture all the same renders it for that request"""
+    n = 2
+    emu = PushTEnv(num_envs=n, px_factory=emu_factory, fused=False, obs_mode="depth+segmentation")
+    cpu = PushTEnv(num_envs=n, px_factory=oracle_factory, obs_mode="depth+segmentation")
+    emu.reset(seed=4); cpu.reset(seed=4)
+    a = torch.zeros(n, 7)
+    emu.step(a); cpu.step(a)
+    assert emu.camera._position_texture is False
+    emu.camera._tex.fill_(-12345)
+    emu.camera.take_picture(); cpu.camera.take_picture()
+    assert bool((emu.camera._tex == -12345).all())
+    oe, oc = emu.camera.get_obs(), cpu.camera.get_obs()
+    assert torch.equal(oe["depth"], oc["depth"]) and torch.equal(oe["segmentation"], oc["segmentation"]) and int((oc["segmentation"] != 0).sum()) > 1000
+    assert torch.equal(emu.camera.get_picture_cuda().torch(), cpu.camera.get_picture_cuda().torch())      # rendered on request
+    emu.camera._tex.fill_(-12345)
+    emu.camera.take_picture()
+    assert bool((emu.camera._tex == -12345).all())      # ... and the configured mode is back in force
+
+
 def test_lights_textures_and_picture_sizes_match_oracle(emu_factory, oracle_factory):
     """the scenes of tests/test_render.py's -m gpu tests: point / spot lights, a textured wall (perspective, mip levels), pictures that are not
     128 x 128 with splatted, medium and large triangles"""

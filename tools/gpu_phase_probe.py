@@ -27,7 +27,9 @@ def report(tag):
     for lo, hi in ((0, 4), (5, 12), (13, 20), (21, 48)):
         sel = (c >= lo) & (c <= hi)
         if sel.sum():
-            print(tag, f"contacts {lo}-{hi} n={sel.sum()}", {k: int(v) for k, v in zip(names[1:], d[sel].mean(0))}, "total", int((t[sel, 6] - t[sel, 0]).mean()))
+            tot = t[sel, 6] - t[sel, 0]
+            print(tag, f"contacts {lo}-{hi} n={sel.sum()}", {k: int(v) for k, v in zip(names[1:], d[sel].mean(0))}, "total mean", int(tot.mean()), "max", int(tot.max()),
+                  "of the slowest env:", {k: int(v) for k, v in zip(names[1:], d[sel][tot.argmax()])}, "its contacts", int(c[sel][tot.argmax()]))
 def np_report(tag, launches):
     out = np.zeros(n * 16 + 64, dtype=np.int64)
     dll.msk_debug_phases(env.px.ctx, out.ctypes.data_as(C.POINTER(C.c_longlong)))
