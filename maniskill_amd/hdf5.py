@@ -86,6 +86,10 @@ def _load():
                 fn.restype, fn.argtypes = res, args
             if lib.H5open() < 0:
                 raise OSError("H5open failed")
+            va, vb, vc = C.c_uint(), C.c_uint(), C.c_uint()
+            lib.H5get_libversion(C.byref(va), C.byref(vb), C.byref(vc))
+            if (va.value, vb.value) < (1, 10):      # hid_t is 64-bit from 1.10 on (int in 1.8): the ids read from the H5T_* / H5P_* globals would be garbage
+                raise OSError(f"libhdf5 {va.value}.{vb.value}.{vc.value} is older than 1.10 (32-bit hid_t): not supported")
         except (AttributeError, OSError) as e:
             _err = f"{path}: {e}"
             continue
@@ -149,9 +153,11 @@ def _h5_type(dt: np.dtype):
     dt = np.dtype(dt)
     if dt == np.bool_:
         return _bool_type(), True
-    if dt.kind in "SU":     # fixed-length strings (attributes): stored as ASCII / UTF-8 bytes, null padded
+    if dt.kind == "U":      # numpy's UCS-4 would be written as raw bytes and end at the first NUL: callers encode first (_as_bytes)
+        raise TypeError("maniskill_amd.hdf5: unicode arrays are written as UTF-8 bytes: np.char.encode(a, 'utf-8') first")
+    if dt.kind == "S":      # fixed-length strings (attributes): ASCII / UTF-8 bytes, null padded
         t = lib.H5Tcopy(_g("H5T_C_S1_g"))
-        lib.H5Tset_size(t, max(int(dt.itemsize if dt.kind == "S" else dt.itemsize // 4 * 4), 1))
+        lib.H5Tset_size(t, max(int(dt.itemsize), 1))
         return t, True
     key = dt.kind + str(dt.itemsize)
     if key not in _NATIVE or dt.byteorder == ">":
@@ -180,6 +186,8 @@ def _np_type(tid) -> np.dtype:
 def _c(x) -> np.ndarray:
     """C-contiguous array that keeps 0-d (np.ascontiguousarray would make scalars 1-d)"""
     a = np.asarray(x)
+    if a.dtype.kind == "U":      # unicode arrays go to the file as UTF-8 bytes (numpy's UCS-4 buffer would end at the first NUL when read as a C string)
+        a = np.char.encode(a, "utf-8")
     return a if a.flags.c_contiguous else np.array(a, order="C")
 
 

@@ -101,3 +101,18 @@ def test_recorder_and_replay_through_hdf5(tmp_path, oracle_factory):
     assert arrays["traj_1"]["env_states"]["actors"]["cube"].shape == (7, 13) and arrays["traj_2"]["success"].dtype == np.bool_
     res = replay_trajectory(PickCubeEnv(num_envs=n, px_factory=oracle_factory), path)
     assert res.num_replays == n and res.max_state_error == 0.0
+
+
+def test_unicode_arrays_are_written_as_utf8_and_old_libraries_are_refused(tmp_path):
+    """numpy 'U' arrays (UCS-4) used to be written as raw bytes and ended at the first NUL; libhdf5 < 1.10 has a 32-bit hid_t this binding cannot talk to"""
+    from maniskill_amd import hdf5
+    if not hdf5.available():
+        pytest.skip("no libhdf5")
+    p = str(tmp_path / "u.h5")
+    with hdf5.File(p, "w") as f:
+        f.create_dataset("names", data=np.array(["PickCube-v1", "größe"]))
+        f.attrs["who"] = np.array(["a", "bc"])
+    with hdf5.File(p, "r") as f:
+        got = [x.decode("utf-8") if isinstance(x, bytes) else str(x) for x in np.asarray(f["names"][()]).tolist()]
+        assert got == ["PickCube-v1", "größe"], got
+    assert tuple(int(x) for x in hdf5.version.hdf5_version.split(".")[:2]) >= (1, 10)
