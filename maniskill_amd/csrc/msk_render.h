@@ -160,6 +160,25 @@ MSK_DEV void project_point(const RCamera& cam, v3 p, float* u, float* v, float* 
   *w = iw;
 }
 
+/* The decisions of setup_triangle's cull, and nothing else: 1 if the screen triangle (p0, p1, p2), all in front of the near plane, would get a record.  The
+ * same expressions in the same order as there (projection, signed area, pixel box), so it never disagrees with it; k_render_splat's first pass asks it for every
+ * triangle of the template and runs the full set-up -- which repeats these tests -- only for the ~30 % that pass. */
+MSK_DEV int triangle_survives_cull(const RCamera& cam, v3 p0, v3 p1, v3 p2) {
+  float u0, v0, w0, u1, v1, w1, u2, v2, w2;
+  project_point(cam, p0, &u0, &v0, &w0);
+  project_point(cam, p1, &u1, &v1, &w1);
+  project_point(cam, p2, &u2, &v2, &w2);
+  const float area = fmaf(u1 - u0, v2 - v0, -((v1 - v0) * (u2 - u0)));
+  if (!(area < -1e-12f)) return 0;
+  const float umin = fminf(u0, fminf(u2, u1)), umax = fmaxf(u0, fmaxf(u2, u1));
+  const float vmin = fminf(v0, fminf(v2, v1)), vmax = fmaxf(v0, fmaxf(v2, v1));
+  int x0 = (int)ceilf(umin - 0.5f), x1 = (int)floorf(umax - 0.5f);
+  int y0 = (int)ceilf(vmin - 0.5f), y1 = (int)floorf(vmax - 0.5f);
+  if (!(umin < 1e9f && umax > -1e9f && vmin < 1e9f && vmax > -1e9f)) return 0;
+  x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, cam.W - 1); y1 = min(y1, cam.H - 1);
+  return !(x0 > x1 || y0 > y1);
+}
+
 /* sets up the screen triangle (p0, p1, p2), all in front of the near plane; returns 0 if it is culled */
 /* uv (optional): texture coordinates of the corners (u0 v0 u1 v1 u2 v2); uvp gets the planes of u / depth and v / depth (Au Bu Cu Av Bv Cv) */
 MSK_DEV int setup_triangle(const RCamera& cam, v3 p0, v3 p1, v3 p2, int seg, int prim, TriSetup* t, int* box = nullptr, const float* uv = nullptr,
@@ -646,10 +665,8 @@ __global__ void __launch_bounds__(MSK_RENDER_THREADS) k_render_splat(const DMode
     if (slot < rcap) *(TriSetup*)(Lrec + (size_t)slot * MSK_SETUP_WORDS) = t;
     else spill[slot - rcap] = t;
   };
-  for (int ti = tid; ti < rm->nt; ti += MSK_RENDER_THREADS) {
-    const RTri tr = rm->tris[ti];
+  auto corners = [&](const RTri& tr, v3* p) {
     const int vid[3] = {tr.v0, tr.v1, tr.v2};
-    v3 p[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const float* o = Lshape + rm->vshape[vid[k]] * MSK_RSHAPE_WORDS;
@@ -659,6 +676,43 @@ __global__ void __launch_bounds__(MSK_RENDER_THREADS) k_render_splat(const DMode
       const v3 vl = rm->verts[vid[k]];
       p[k] = pose_apply(T, v3_make(vl.x * o[8], vl.y * o[9], vl.z * o[10]));
     }
+  };
+  /* First pass: which triangles can get a record at all.  Two of three are culled (back faces, off the picture), and a wavefront that sets up 64 triangles
+   * of which 20 survive pays the whole set-up -- shading, clipping, the planes -- for all 64.  Here every triangle gets its corners and the cull's own tests
+   * (~ a quarter of the set-up), the survivors' numbers are packed into a work list (it lives where the tile lists will be: those are filled later), and the
+   * set-up below runs on full wavefronts.  Which slot a record gets was never defined (an atomic counter): the pictures do not depend on it. */
+  unsigned short* Lwork = Lidx;
+  const int nt = rm->nt;
+  const bool packed = nt <= icap;      /* (icap >= 2 x triangles up to 32767 triangles: always, for templates within the rasteriser's capacity) */
+  if (packed) {
+    for (int t0 = 0; t0 < nt; t0 += MSK_RENDER_THREADS) { /* uniform trip count: the ballot below needs the whole wavefront */
+      const int ti = t0 + tid;
+      bool keep = false;
+      if (ti < nt) {
+        const RTri tr = rm->tris[ti];
+        v3 p[3];
+        corners(tr, p);
+        const int nin = (int)(p[0].x >= cam.near_) + (int)(p[1].x >= cam.near_) + (int)(p[2].x >= cam.near_);
+        keep = nin == 3 ? triangle_survives_cull(cam, p[0], p[1], p[2]) != 0 : nin > 0;      /* (a clipped triangle is decided by the set-up itself) */
+      }
+      const unsigned long long mk = __ballot(keep);
+      if (mk != 0ull) {
+        int base = 0;
+        if (lane == __ffsll((long long)mk) - 1) base = atomicAdd(&Lmisc[7], __popcll(mk));
+        base = __builtin_amdgcn_readlane(base, __ffsll((long long)mk) - 1);
+        if (keep) Lwork[base + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)ti;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  const int nwork = packed ? Lmisc[7] : nt;
+  for (int wi = tid; wi < nwork; wi += MSK_RENDER_THREADS) {
+    const int ti = packed ? (int)Lwork[wi] : wi;
+    const RTri tr = rm->tris[ti];
+    const int vid[3] = {tr.v0, tr.v1, tr.v2};
+    v3 p[3];
+    corners(tr, p);
     const int seg = rm->shapes[tr.shape].seg;
     const unsigned col = cam.color ? shade_triangle(p[0], p[1], p[2], rm->shapes[tr.shape].color, rm->ambient, rm->nlights, Llight, &rm->lcol[0][0],
                                                     rm->nlocal, Lppos, Lpdir, &rm->pcol[0][0], &rm->pcone[0][0]) : 0u;

@@ -78,7 +78,6 @@ def test_hip_trimming_matches_the_oracle_under_emulation(oracle_factory, capacit
 
 
 @pytest.mark.gpu
-@pytest.mark.first_hardware_run
 @pytest.mark.parametrize("capacity", [0, 1])
 def test_hip_trimming_matches_the_oracle(oracle_factory, capacity):
     from maniskill_amd.physx import PhysxGpuSystem

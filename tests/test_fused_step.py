@@ -158,14 +158,12 @@ def test_the_watch_does_flag_a_step_that_cannot_be_captured(built):
 
 
 @pytest.mark.gpu
-@pytest.mark.first_hardware_run
 def test_open_cabinet_drawer_task_plugin_on_hip(built):
     _same_bits(_run("hip", "cabinet", 32, 20), "task")
 
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.first_hardware_run
 def test_open_cabinet_drawer_step_as_one_hip_graph(built):
     """the replayed graph against the reference's eager step: same launches, same arithmetic"""
     res = _run("hip", "cabinet_graph", 32, 20)
@@ -175,7 +173,6 @@ def test_open_cabinet_drawer_step_as_one_hip_graph(built):
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.first_hardware_run
 def test_pick_cube_task_plugin_as_one_hip_graph(built):
     res = _run("hip", "pickcube_graph", 64, 20)
     assert res["graph"] and res["level"] == "task" and res["flags"] and res["finite"], res
@@ -184,7 +181,6 @@ def test_pick_cube_task_plugin_as_one_hip_graph(built):
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.first_hardware_run
 def test_push_cube_reference_task_code_behind_the_fused_controller_as_one_hip_graph(built):
     res = _run("hip", "graph:PushCube-v1", 64, 20)
     assert res["graph"] and res["level"] == "graph" and res["flags"] and res["finite"], res
@@ -193,7 +189,6 @@ def test_push_cube_reference_task_code_behind_the_fused_controller_as_one_hip_gr
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.first_hardware_run
 def test_peg_insertion_side_reference_task_code_as_one_hip_graph(built):
     """BASELINE config 4's task over the drop-in path: host constants made inside the step come from the device (DeviceConstants)"""
     res = _run("hip", "graph:PegInsertionSide-v1", 64, 20)
@@ -203,7 +198,6 @@ def test_peg_insertion_side_reference_task_code_as_one_hip_graph(built):
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.first_hardware_run
 def test_pick_cube_with_camera_observations_as_one_hip_graph(built):
     """the reference's own step incl. take_picture / get_picture_cuda over the shim, captured: pictures and state against the eager twin"""
     res = _run("hip", "graph_rgbd", 16, 10)
@@ -213,7 +207,6 @@ def test_pick_cube_with_camera_observations_as_one_hip_graph(built):
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.first_hardware_run
 def test_push_t_with_cameras_as_one_hip_graph(built):
     """BASELINE config 3 over the drop-in path: the reference's own step (patched intersection, take_picture, texture transforms) captured"""
     res = _run("hip", "graph_pusht", 16, 10)

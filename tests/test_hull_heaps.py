@@ -66,7 +66,6 @@ def test_hip_heaps_of_hulls_match_the_oracle_under_emulation(oracle_factory):
 
 
 @pytest.mark.gpu
-@pytest.mark.first_hardware_run
 def test_hip_heaps_of_hulls_identical_envs_identical_bits_and_the_oracles(oracle_factory):
     from maniskill_amd.physx import PhysxGpuSystem
     for nbody, spread in ((5, 0.03), (8, 0.04)):

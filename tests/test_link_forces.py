@@ -63,7 +63,6 @@ def test_hip_link_forces_match_the_oracle_under_emulation(oracle_factory):
 
 
 @pytest.mark.gpu
-@pytest.mark.first_hardware_run
 def test_hip_link_forces_match_the_oracle(oracle_factory):
     from maniskill_amd.physx import PhysxGpuSystem
     a, _ = _step_with(lambda t, k, c: PhysxGpuSystem("cuda:0", t, k, c), 70, (2.0, 7.0, 0.0), (0.3, -0.2, 1.5), (0.4, 9.0, -1.0), steps=4)

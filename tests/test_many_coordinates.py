@@ -67,7 +67,6 @@ def test_hip_many_free_boxes_match_oracle_under_emulation(oracle_factory):
 
 
 @pytest.mark.gpu
-@pytest.mark.first_hardware_run
 def test_hip_many_free_boxes_match_oracle(oracle_factory):
     from maniskill_amd.physx import PhysxGpuSystem
     for nbox in (6, 9):

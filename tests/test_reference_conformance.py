@@ -131,7 +131,6 @@ def test_reference_env_zoo_on_hip(built):
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.first_hardware_run
 def test_reference_tasks_of_more_than_32_coordinates_on_hip(built):
     """FMBAssembly1Easy-v1 (39 coordinates: the 64-coordinate kernels), with the default and with the wide contact capacity"""
     assert _run_zoo("hip", "30", ("FMBAssembly1Easy-v1",), "8") == {"FMBAssembly1Easy-v1": "ok"}
@@ -186,7 +185,6 @@ def test_floor_texture_and_local_lights_through_the_reference_api_on_cpu_checker
 
 @needs_ref
 @pytest.mark.gpu
-@pytest.mark.first_hardware_run
 def test_floor_texture_and_local_lights_through_the_reference_api_on_hip(built):
     _lights_textures("hip")
 

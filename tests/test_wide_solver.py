@@ -90,7 +90,6 @@ def test_hip_wide_class_matches_the_oracle_under_emulation(oracle_factory, scene
 
 
 @pytest.mark.gpu
-@pytest.mark.first_hardware_run
 @pytest.mark.parametrize("scene", ["comb16", "comb32", "comb64"])
 def test_hip_wide_class_matches_the_oracle(oracle_factory, scene):
     from maniskill_amd.physx import PhysxGpuSystem
