@@ -356,6 +356,8 @@ def main():
                          "HIP graph (maniskill_amd/graph.py) -- same kernels, same order, same stream; a replay records no "
                          "events, so the per-kernel durations of the roofline block are then measured with HIP events on 20 "
                          "eager steps of the same rollout right after the timed region")
+    ap.add_argument("--contact-capacity", type=int, default=0, choices=[0, 1],
+                    help="msk_config.contact_capacity of the fused hosts: 0 = 48 points / 64 solver blocks per env (default), 1 = 128 / 128 (the wide solver class: one more launch per substep)")
     ap.add_argument("--bootstrap-selftest", action="store_true", help=argparse.SUPPRESS)   # the rank bootstrap alone, over gloo (CPU test)
     args = ap.parse_args()
     args.graph = not args.no_graph
@@ -376,9 +378,9 @@ def main():
     if args.env not in FUSED_HOSTS:
         raise SystemExit(dropin_sharded_main(args))
 
-    from maniskill_amd.physx import SimConfig
+    from maniskill_amd.physx import SceneConfig, SimConfig
     env, gather, rank, world = make_sharded_env(args.env, args.envs, device_type="cuda", obs_mode=args.obs_mode,
-                                                sim_config=SimConfig(control_freq=args.control_freq))
+                                                sim_config=SimConfig(control_freq=args.control_freq, scene_config=SceneConfig(contact_capacity=args.contact_capacity)))
     camera_mode = args.obs_mode != "state"
     # one all-gather per control step, issued on RCCL's stream and waited for one step later (dist.py pipelined()): the
     # next step's physics never waits for xGMI; flush() inside the timed region completes the last one
@@ -549,7 +551,8 @@ def main():
             "data": "synthetic (uniform random actions in [-1,1], seed-2022 resets)",
             "config": {"workload": f"{args.env}, num_envs={args.envs}, {'state' if not camera_mode else args.obs_mode + ' camera'} obs, pd_joint_delta_pos, "
                                    f"sim 100 Hz / control {args.control_freq} Hz ({substeps} substeps, 15+1 TGS iterations)"
-                                   + (f", full reset every {args.reset_every} steps" if args.reset_every else ""),
+                                   + (f", full reset every {args.reset_every} steps" if args.reset_every else "")
+                                   + (", contact capacity 128 points / 128 blocks" if args.contact_capacity else ""),
                        "envs_per_gpu": n_local, "parallelism": f"env-shard x{world}",
                        "launch": ("one HIP graph replay per control step; kernel_us from HIP events on 20 eager steps of the same regime "
                                   "(roofline.regime)") if args.graph else "eager launches; kernel_us from HIP events over the timed region"},
