@@ -356,8 +356,9 @@ def main():
                          "HIP graph (maniskill_amd/graph.py) -- same kernels, same order, same stream; a replay records no "
                          "events, so the per-kernel durations of the roofline block are then measured with HIP events on 20 "
                          "eager steps of the same rollout right after the timed region")
-    ap.add_argument("--contact-capacity", type=int, default=0, choices=[0, 1],
-                    help="msk_config.contact_capacity of the fused hosts: 0 = 48 points / 64 solver blocks per env (default), 1 = 128 / 128 (the wide solver class: one more launch per substep)")
+    ap.add_argument("--contact-capacity", type=int, default=1, choices=[0, 1],
+                    help="msk_config.contact_capacity of the fused hosts: 1 = 128 points / 128 solver blocks per env (the package's default: the wide solver class, one more "
+                         "launch per substep), 0 = 48 / 64")
     ap.add_argument("--bootstrap-selftest", action="store_true", help=argparse.SUPPRESS)   # the rank bootstrap alone, over gloo (CPU test)
     args = ap.parse_args()
     args.graph = not args.no_graph
@@ -552,7 +553,7 @@ def main():
             "config": {"workload": f"{args.env}, num_envs={args.envs}, {'state' if not camera_mode else args.obs_mode + ' camera'} obs, pd_joint_delta_pos, "
                                    f"sim 100 Hz / control {args.control_freq} Hz ({substeps} substeps, 15+1 TGS iterations)"
                                    + (f", full reset every {args.reset_every} steps" if args.reset_every else "")
-                                   + (", contact capacity 128 points / 128 blocks" if args.contact_capacity else ""),
+                                   + ("" if args.contact_capacity else ", contact capacity 48 points / 64 blocks"),
                        "envs_per_gpu": n_local, "parallelism": f"env-shard x{world}",
                        "launch": ("one HIP graph replay per control step; kernel_us from HIP events on 20 eager steps of the same regime "
                                   "(roofline.regime)") if args.graph else "eager launches; kernel_us from HIP events over the timed region"},

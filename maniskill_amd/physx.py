@@ -43,7 +43,8 @@ class SceneConfig:
     enable_enhanced_determinism: bool = False
     enable_friction_every_iteration: bool = True
     cpu_workers: int = 0
-    contact_capacity: int = 0      # msk_config.contact_capacity: 0 = 48 points / 64 solver blocks per sub-scene, 1 = 128 / 128 (the wide solver class)
+    contact_capacity: int = 1      # msk_config.contact_capacity: 1 = 128 points / 128 solver blocks per sub-scene (the wide solver class behind the others: the
+                                   # default since round 5 -- 1.1 % of the headline, profiles/r05_contact_capacity_cost.log --, PegInsertionSide-v1 overran 48); 0 = 48 / 64
 
 
 @dataclass

@@ -588,8 +588,8 @@ class PhysxSystem:
             solver_position_iterations=int(bc["solver_position_iterations"]), solver_velocity_iterations=int(bc["solver_velocity_iterations"]),
             enable_pcm=bool(sc["enable_pcm"]), enable_tgs=bool(sc["enable_tgs"]),
             # PhysX sizes its contact buffers per scene (GPUMemoryConfig.max_rigid_contact_count, structs/types.py:18-23); this backend per
-            # sub-scene: MSK_CONTACT_CAPACITY=1 selects the 128-point / 128-block capacity (include/msk_physx.h: msk_config.contact_capacity)
-            contact_capacity=int(os.environ.get("MSK_CONTACT_CAPACITY", "0"))))
+            # sub-scene: 128 points / 128 solver blocks (include/msk_physx.h: msk_config.contact_capacity = 1; MSK_CONTACT_CAPACITY=0 selects 48 / 64)
+            contact_capacity=int(os.environ.get("MSK_CONTACT_CAPACITY", "1"))))
         cls = E.PhysxGpuSystem
         if host_memory:
             cls = type("HostMemorySystem", (E.PhysxGpuSystem,), dict(host_memory=True))
