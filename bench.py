@@ -55,7 +55,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (guides/MI355X_MICROARC
 # algorithmic bytes of one physics substep of one PickCube env
 # (18 body rows r+w 1872 B + generalized state 288 B + ~8 contacts x 112 B = 896 B)
 ALG_BYTES_PER_ENV_SUBSTEP = 3056.0
-PMC_FILE = "r04_pmc_counters_4096.json"        # profiles/: rocprofv3 --pmc passes of this command (tools/pmc_collect.sh)
+PMC_FILE = "r05_pmc_counters_4096.json"        # profiles/: rocprofv3 --pmc passes of this command (tools/pmc_collect.sh)
 
 
 def algorithmic_bytes_per_env_substep(env_id: str, px, mean_contacts: float):
