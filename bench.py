@@ -271,7 +271,10 @@ def self_leg(extra, timeout):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if not line:
         return {"error": "the child printed no result line", "rc": r.returncode, "stderr_tail": r.stderr[-1500:]}
-    d = json.loads(line[-1])
+    try:
+        d = json.loads(line[-1])
+    except ValueError as exc:
+        return {"error": f"unreadable result line: {exc}", "rc": r.returncode, "stderr_tail": r.stderr[-1500:]}
     keep = {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "error") if k in d}
     if "camera" in d:
         keep["camera"] = {k: d["camera"][k] for k in ("kernel", "us_per_frame", "frac")}
