@@ -288,7 +288,11 @@ class PickCubeEnv:
         self._episode_count[idx_np] += np.uint64(1)
         self._elapsed_steps[env_idx] = 0
         b = len(idx_np)
-        f32 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+        f32 = getattr(self, "_stage", None)      # every host-made row of this reset goes through a pinned buffer of its own (envs/_stage.py)
+        if f32 is None:
+            from ._stage import HostStage
+            f32 = self._stage = HostStage(dev, self.num_envs)
+        f32.begin()
         off = self._offsets[env_idx]
         # _clear_sim_state (sapien_env.py:1023-1036)
         self._rbd[env_idx, self._b_cube, 7:13] = 0.0
