@@ -108,7 +108,11 @@ def bootstrap_selftest(gpus: int, args=None) -> int:
         spec = importlib.util.spec_from_file_location("msk_bench_hook", hook)
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
-        return int(mod.run(sys.modules[__name__], args, rank, world) or 0)
+        rc = int(mod.run(sys.modules[__name__], args, rank, world) or 0)
+        if world > 1:       # every rank leaves through the same door: a process that exits with its gloo group alive aborts now and then
+            dist.barrier()
+            dist.destroy_process_group()
+        return rc
     if rank == 0:
         print(json.dumps({"bootstrap": "ok" if ok else "mismatch", "world": world, "sum": float(t.item())}), flush=True)
     if world > 1:
