@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5, GPU call 1: the whole -m gpu suite on HEAD (round 4 ended red after 14 of 140), then the driver's bench line with every leg, kernel statistics.
-#   gpurun --timeout 1500 -- 'bash tools/gpu_r05_1.sh'
+#   gpurun --timeout 1500 -- 'bash tools/gpu_calls/gpu_r05_1.sh'
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r05_1; mkdir -p $O
 cd $R

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, GPU call 2: the five tests call 1 failed (fixed on the host side), the new paths of bench.py, and the A/B of kernel builds on ONE box:
 # HEAD, HEAD with MSK_AREG_ROWBITS (libmsk_e1.so), and round 4's mid-round commit c73dab6 (the 13-20 % question of the round-4 review)
-#   gpurun --timeout 1500 -- 'bash tools/gpu_r05_2.sh'
+#   gpurun --timeout 1500 -- 'bash tools/gpu_calls/gpu_r05_2.sh'
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r05_2; mkdir -p $O
 cd $R

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, GPU call 3: the cabinet graph test with matched histories, the planes-only camera (parity + what it buys + phase cuts), the sharded drop-in bench
 # leg, and where PegInsertionSide's solver time goes (class histogram, per-class phase cycles on the -DMSK_PROFILE_PHASES build)
-#   gpurun --timeout 1500 -- 'bash tools/gpu_r05_3.sh'
+#   gpurun --timeout 1500 -- 'bash tools/gpu_calls/gpu_r05_3.sh'
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r05_3; mkdir -p $O
 cd $R

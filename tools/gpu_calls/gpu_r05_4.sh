@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, GPU call 4: the two-pass triangle set-up of k_render_splat against the build before it (one box), its phase cuts, the render parity tests; what the
 # wide contact capacity costs on the headline and buys on the Allegro task; the 512-env point
-#   gpurun --timeout 1200 -- 'bash tools/gpu_r05_4.sh'
+#   gpurun --timeout 1200 -- 'bash tools/gpu_calls/gpu_r05_4.sh'
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r05_4; mkdir -p $O
 cd $R
