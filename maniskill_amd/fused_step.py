@@ -510,9 +510,19 @@ class _MaskedSelection(torch.Tensor):
     def make(src, mask):
         sel = src.as_subclass(_MaskedSelection)
         sel._msk_src, sel._msk_mask = src, mask
+        sel._msk_versions = (src._version, mask._version)      # the selection ALIASES its source: it is only y[mask] while neither was written since
         return sel
 
+    def _unchanged(self):
+        """eager ``y[mask]`` is a copy; this one is not -- a source or mask written between the selection and its use (``old = x[m]; x[m] = 0; y[m] = old``)
+        would hand out the new values.  Such a step is refused, loudly, instead of replayed wrong."""
+        if (self._msk_src._version, self._msk_mask._version) != self._msk_versions:
+            raise Unsupported("a masked selection `y[mask]` was used after its source or mask had been written in place (a save / restore idiom): the lazy "
+                              "selection of fused_step aliases its source, eager torch copies it -- this step cannot run under DeviceConstants")
+        return self
+
     def _real(self):
+        self._unchanged()
         with torch._C.DisableTorchFunctionSubclass():
             return torch.Tensor.__getitem__(self._msk_src, self._msk_mask)
 
@@ -558,7 +568,7 @@ def _selection_arithmetic(func, args, kwargs):
         if isinstance(a, _MaskedSelection):
             if a._msk_mask is not mask or a._msk_src.shape != sels[0]._msk_src.shape:
                 return None
-            srcs.append(a._msk_src)
+            srcs.append(a._unchanged()._msk_src)
         elif isinstance(a, (int, float)) and not isinstance(a, bool):
             srcs.append(a)
         else:
@@ -593,8 +603,12 @@ class DeviceConstants(torch.overrides.TorchFunctionMode):
         self.served = 0
         self.masked = self.rewritten = self.syncs_skipped = 0      # y[mask] handed out unevaluated / masked assignments turned into selects / device waits skipped
         self._seen, self._nots = {}, {}
+        self._depth, self._sync = 0, None
 
     def __enter__(self):
+        self._depth += 1
+        if self._depth > 1:             # re-entered (a step that calls a step): one set of per-step tables, one patch of synchronize, undone by the outermost exit
+            return super().__enter__()
         self._seen = {}                 # one step = one `with`: the k-th evaluation of a call path inside a step is its own constant (loops)
         self._nots = {}
         # `torch.cuda.synchronize()` inside the step (sapien_env.py:624, behind take_picture: "prevents the GPU from making poor scheduling decisions") is
@@ -605,7 +619,9 @@ class DeviceConstants(torch.overrides.TorchFunctionMode):
         return super().__enter__()
 
     def __exit__(self, *exc):
-        torch.cuda.synchronize = self._sync
+        self._depth -= 1
+        if self._depth == 0:
+            torch.cuda.synchronize = self._sync
         return super().__exit__(*exc)
 
     def _no_sync(self, *a, **k):
@@ -663,12 +679,13 @@ class DeviceConstants(torch.overrides.TorchFunctionMode):
                 return self._serve(self._site() + ("to", str(kwargs.get("dtype"))), content, lambda: func(*args, **kwargs))
         elif func in _SELECTION_UNARY and len(args) == 1 and not kwargs and isinstance(args[0], _MaskedSelection):
             with torch._C.DisableTorchFunctionSubclass():      # f(a[m]) == f(a)[m], element for element (what f makes of the unselected elements is never looked at)
-                return _MaskedSelection.make(_SELECTION_UNARY[func](args[0]._msk_src), args[0]._msk_mask)
+                return _MaskedSelection.make(_SELECTION_UNARY[func](args[0]._unchanged()._msk_src), args[0]._msk_mask)
         elif func in _MASK_NOT and len(args) == 1 and not kwargs and type(args[0]) is torch.Tensor and args[0].dtype == torch.bool:
             # `x[~m] = f(y[~m])` evaluates ~m once per use (rotation_conversions.py:549-552): the uses have to be ONE mask to be recognised as one selection
             hit = self._nots.get(id(args[0]))
-            if hit is None or hit[0] is not args[0] or hit[2] != args[0]._version:
-                hit = self._nots[id(args[0])] = (args[0], func(args[0]), args[0]._version)
+            if hit is None or hit[0] is not args[0] or hit[2] != args[0]._version or hit[3] != hit[1]._version:      # (the cached result itself written in place: `nm = ~m; nm[1] = False`)
+                out = func(args[0])
+                hit = self._nots[id(args[0])] = (args[0], out, args[0]._version, out._version)
             return hit[1]
         elif func in _SELECTION_ARITHMETIC and any(isinstance(a, _MaskedSelection) for a in args):
             out = _selection_arithmetic(func, args, kwargs)
@@ -681,6 +698,7 @@ class DeviceConstants(torch.overrides.TorchFunctionMode):
             x, mask, v = args
             if isinstance(v, _MaskedSelection):
                 if v._msk_mask is mask and v._msk_src.shape == x.shape and v._msk_src.dtype == x.dtype:       # x[mask] = y[mask]
+                    v._unchanged()
                     with torch._C.DisableTorchFunctionSubclass():
                         x.copy_(torch.where(_broadcast_mask(mask, x), v._msk_src, x))
                     self.rewritten += 1
@@ -749,9 +767,9 @@ def graph_safety(step_fn, action, settle: int = 2) -> dict:
             ins = tensors([args, kwargs or {}], [])
             if any(t in name for t in ("_local_scalar_dense", "nonzero", "masked_select", "aten.equal", "is_nonzero", "unique")):
                 self.sync.append(f"{name} @ {site()}")
-            if "aten.index" in name:
-                for ix in (args[1] or []):
-                    if ix is not None and ix.dtype in (torch.bool, torch.uint8):
+            if any(t in name for t in ("aten.index.Tensor", "aten.index_put")) and len(args) > 1 and isinstance(args[1], (list, tuple)):      # (index_select / index_add / ...: args[1] is a dim)
+                for ix in args[1]:
+                    if isinstance(ix, torch.Tensor) and ix.dtype in (torch.bool, torch.uint8):
                         v = args[2] if len(args) > 2 else None
                         if "index_put" in name and v is not None and v.numel() == 1 and v.device.type == "cpu" and len(args[1]) == 1:
                             continue        # x[mask] = scalar: dispatched to masked_fill, no nonzero()
@@ -779,6 +797,17 @@ def graph_safety(step_fn, action, settle: int = 2) -> dict:
     with w2:
         step_fn(action)
     return dict(sync=sorted(set(w1.sync + w2.sync)), flow=sorted(set(w2.flow)), host_data=sorted(set(w1.host + w2.host)))
+
+
+def _verdict(step_fn, action) -> dict:
+    """graph_safety for accelerate(): whatever the watch itself trips over (an operator signature it does not know, an error of the task's step under
+    DeviceConstants) becomes ``Unsupported`` -- the caller gets a verdict or a refusal, never a TypeError out of the watch."""
+    try:
+        return graph_safety(step_fn, action)
+    except Unsupported:
+        raise
+    except Exception as e:      # noqa: BLE001
+        raise Unsupported(f"the step could not be watched for graph safety: {type(e).__name__}: {str(e).splitlines()[0][:300] if str(e) else ''}") from e
 
 
 # --------------------------------------------------------------------------------------------------------------------- entry point
@@ -914,11 +943,11 @@ class Accelerated:
             elif graph == "watch":      # the verdict alone (any device): what graph=True decides on
                 self.level = "graph-dry"
                 self._step_fn = captured_step
-                self.safety = graph_safety(captured_step, torch.zeros(base.num_envs, control.adim, device=base.device))
+                self.safety = _verdict(captured_step, torch.zeros(base.num_envs, control.adim, device=base.device))
                 self.throwaway_steps += 4
             else:
                 if graph is True:       # (graph="force" captures without asking)
-                    verdict = self.safety = graph_safety(captured_step, torch.zeros(base.num_envs, control.adim, device=base.device))
+                    verdict = self.safety = _verdict(captured_step, torch.zeros(base.num_envs, control.adim, device=base.device))
                     self.throwaway_steps += 4
                     if verdict["sync"] or verdict["flow"]:
                         what = "; ".join((verdict["sync"] + verdict["flow"])[:3])

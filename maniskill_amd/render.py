@@ -272,12 +272,16 @@ class RenderCameraGroup:
 
     def _texture(self):
         """the PositionSegmentation texture of the CURRENT state.  With ``set_outputs(False)`` in force the pictures do not fill it (a captured step graph
-        keeps the mode it was captured with, whatever is set later), so it is rendered here, for this request, and the configured mode is restored."""
+        keeps the mode it was captured with, whatever is set later), so it is rendered here, for this request, and the configured mode is restored.
+        SIDE EFFECT: that request is a full ``take_picture`` of the current physics state -- it also rewrites the depth, segmentation and colour planes, so
+        planes handed out earlier with ``copy=False`` show the current state afterwards (ask for copies when the state has advanced in between)."""
         if not self._position_texture:
             L = self.px.lib
             L.check(self.px.ctx, L.camera_set_outputs(self.px.ctx, self.id, 1), "camera_set_outputs")
-            self.take_picture()
-            L.check(self.px.ctx, L.camera_set_outputs(self.px.ctx, self.id, 0), "camera_set_outputs")
+            try:
+                self.take_picture()
+            finally:
+                L.check(self.px.ctx, L.camera_set_outputs(self.px.ctx, self.id, int(self._position_texture)), "camera_set_outputs")
         return self._tex
 
     def get_picture_cuda(self, name: str = "PositionSegmentation") -> PictureHandle:

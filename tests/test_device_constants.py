@@ -1,0 +1,110 @@
+"""maniskill_amd.fused_step.DeviceConstants / _MaskedSelection / graph_safety on plain torch tensors (no env, no reference checkout): the lazy ``y[mask]`` has
+to be either exactly what eager torch computes or a loud refusal -- never a silently different value (round 5's advisor findings, each reproduced here)."""
+import pytest
+import torch
+
+from maniskill_amd.fused_step import DeviceConstants, Unsupported, _verdict, graph_safety
+
+
+def _mode():
+    return DeviceConstants("cpu")
+
+
+def test_masked_copy_idiom_is_a_select_with_eager_values():
+    x, y = torch.arange(6.0), torch.arange(6.0) * 10
+    m = torch.tensor([True, False, True, False, False, True])
+    ex = x.clone()
+    ex[m] = y[m]
+    with _mode() as c:
+        x[m] = y[m]
+    assert torch.equal(x, ex) and c.rewritten == 1
+
+
+def test_save_restore_idiom_is_refused_not_aliased():
+    """old = x[m]; x[m] = 0; y[m] = old: eager torch restores the OLD values; the lazy selection would read the zeros."""
+    x, y = torch.arange(3.0) + 1, torch.zeros(3)
+    m = torch.tensor([True, False, True])
+    zero = torch.zeros(())
+    with pytest.raises(Unsupported):
+        with _mode():
+            old = x[m]
+            x[m] = zero
+            y[m] = old
+
+
+def test_selection_used_after_its_source_was_written_is_refused():
+    """keep = x[m]; x += 10; x[m] = keep"""
+    x = torch.arange(3.0)
+    m = torch.tensor([True, False, True])
+    with pytest.raises(Unsupported):
+        with _mode():
+            keep = x[m]
+            x += 10
+            x[m] = keep
+
+
+def test_selection_made_real_after_a_write_is_refused_as_well():
+    x = torch.arange(4.0)
+    m = torch.tensor([True, False, True, False])
+    with pytest.raises(Unsupported):
+        with _mode():
+            sel = x[m]
+            x.mul_(2)
+            sel.sum()          # any other use makes the selection real: it must be the values at selection time
+
+
+def test_selection_arithmetic_keeps_eager_values():
+    r, b = torch.arange(5.0), torch.arange(5.0) + 0.5
+    m = torch.tensor([False, True, True, False, True])
+    er = r.clone()
+    er[m] += b[m]
+    with _mode():
+        r[m] += b[m]
+    assert torch.equal(r, er)
+
+
+def test_inverted_mask_cache_sees_in_place_edits_of_its_result():
+    """nm = ~m; nm[1] = False; x[~m] = ...: the second ~m is a fresh inversion in eager torch"""
+    x = torch.zeros(3)
+    m = torch.tensor([True, False, False])
+    one = torch.ones(())
+    with _mode():
+        nm = ~m
+        nm[1] = False
+        x[~m] = one
+    assert x.tolist() == [0.0, 1.0, 1.0]
+
+
+def test_device_constants_are_reentrant_and_put_synchronize_back():
+    orig = torch.cuda.synchronize
+    c = _mode()
+    with c:
+        with c:
+            assert torch.cuda.synchronize is not orig
+        assert torch.cuda.synchronize is not orig      # the inner exit must not restore (or lose) the original
+    assert torch.cuda.synchronize is orig
+
+
+def test_the_watch_takes_index_select_with_a_dim():
+    x, idx = torch.arange(12.0).view(3, 4), torch.tensor([0, 2])
+
+    def step(a):
+        return torch.index_select(x, 1, idx) + a
+    v = graph_safety(step, torch.zeros(()))
+    assert v["sync"] == []
+
+
+def test_the_watch_still_flags_mask_indexing():
+    x = torch.arange(4.0)
+
+    def step(a):
+        return x[x > 1.0] + a
+    v = graph_safety(step, torch.zeros(()))
+    assert any("mask" in s or "nonzero" in s for s in v["sync"])
+
+
+def test_an_error_inside_the_watch_becomes_unsupported():
+    def step(a):
+        raise TypeError("'int' object is not iterable")
+    with pytest.raises(Unsupported):
+        _verdict(step, torch.zeros(()))
