@@ -29,7 +29,7 @@ Rank 0 prints ONE JSON line.  Extra objects:
   step_reset      the same rollout with a full reset every 200 steps
   dropin          the reference's own host Python (mani_skill's BaseEnv / controllers / task code, unmodified) over the sapien shim on the
                   same library, 4096 envs (tools/bench_reference_host.py; where the byte-compiled reference travelled: oracle/_ref), N=1 only
-  dropin_fused_graph, config5_open_cabinet_drawer_1024, config3_pusht_camera_1024_dropin, config4_peg_insertion_side_4096_dropin
+  dropin_fused_graph, config5_open_cabinet_drawer_1024, config3_pusht_camera_4096_dropin, config4_peg_insertion_side_4096_dropin
                   envs built, reset and owned by the reference's code, their control step run by maniskill_amd/fused_step.py (task plugin or the
                   reference's own task code behind the fused controller) as one HIP graph replay; N=1 only; a leg that fails reports its error
   cpu_baseline    the CPU oracle's physics loop (oracle/liborc.so orc_step, OpenMP over envs, no Python per env) on a bounded sample,
@@ -645,11 +645,11 @@ def main():
             # BASELINE config 5 at its per-GPU share (1024 envs of 8192 on 8 GPUs): the task plugin as one graph, then the reference's step
             cab = ("--env", "OpenCabinetDrawer-v1", "--synthetic-partnet", "1")
             result["config5_open_cabinet_drawer_1024"] = {"fused_graph": leg(1024, 50, cab + ("--accelerate", "graph"))}
-            # BASELINE config 3's task and observations over the drop-in path (1024 envs, as profiles/r02_bench_reference_host_pusht_camera_1024.json: 26.9 k for
-            # the reference's eager step): its own step, the intersection 'renderer' patched mask-free (fused_step._METHOD_PATCHES), cameras included, as one graph
-            result["config3_pusht_camera_1024_dropin"] = {
-                "fused_graph": leg(1024, 50, ("--env", "PushT-v1", "--obs-mode", "depth+segmentation", "--accelerate", "graph"))}
-            # BASELINE config 4's task over the drop-in path (4096 envs on this GPU): the reference's own task code behind the fused controller as one graph
+            # BASELINE config 3's task and observations over the drop-in path at its 4096 envs (round 5: 1024): the reference's env, its control step on the fused
+            # task kernels (fused_step.PushTKernelStep: set-action, substeps, intersection / observation / reward kernel, the shim's take_picture), as one graph
+            result["config3_pusht_camera_4096_dropin"] = {
+                "fused_graph": leg(4096, 50, ("--env", "PushT-v1", "--obs-mode", "depth+segmentation", "--accelerate", "graph"))}
+            # BASELINE config 4's task over the drop-in path (4096 envs on this GPU): fused_step.PegInsertionSideKernelStep as one graph
             result["config4_peg_insertion_side_4096_dropin"] = {"fused_graph": leg(4096, 50, ("--env", "PegInsertionSide-v1", "--accelerate", "graph"))}
             result["config5_open_cabinet_drawer_1024"]["reference_step"] = leg(1024, 50, cab)
 

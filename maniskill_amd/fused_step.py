@@ -447,7 +447,308 @@ class PickCubeStep:
         return obs, reward, success.clone(), torch.zeros(n, dtype=torch.bool, device=base.device), info
 
 
-_PLUGINS = [OpenCabinetDrawerStep, PickCubeStep]
+# --------------------------------------------------------------------------------------------------------------------- task plugins on the fused task kernels
+def _single_engine(base):
+    """the one library context behind the env's ``px`` (sub-scenes of one structural group), if that library has the fused task kernels (include/msk_task.h)"""
+    px = base.scene.px
+    eng = getattr(px, "_engine", None)
+    if eng is None or getattr(px, "_multi", 0) is not None:
+        raise Unsupported("the fused task kernels need every sub-scene in one structural group (one library context)")
+    if not getattr(eng.lib, "has_task_kernels", False):
+        raise Unsupported("this backend has no fused task kernels")
+    return eng
+
+
+def _template_body(struct, what):
+    """the template body id of an Actor / Link (the same body of every sub-scene of the group)"""
+    ids = {int(b._body_id) for b in struct._bodies}
+    if len(ids) != 1 or min(ids) < 0:
+        raise Unsupported(f"{what} is not one body of the scene template")
+    return ids.pop()
+
+
+def _delta_arm_controller(control, n_arm, gripper):
+    """-> (arm_delta, gripper_mid, gripper_half) when the env's controller is what k_pickcube_set_action / k_pusht_set_action compute: a normalised
+    PDJointPos(use_delta) on coordinates 0..n_arm-1 (pd_joint_pos.py:76-93) [+ a normalised absolute PDJointPosMimic on the two finger joints,
+    :207-228]; the constants are read off FusedControl's own clip-and-scale tensors (0.5 (high + low), 0.5 (high - low) in the reference's fp32 order of
+    operations), so the targets have the reference's bits."""
+    plan = control.plan
+    if len(plan) != (2 if gripper else 1):
+        raise Unsupported("the fused task kernels restate pd_joint_delta_pos only")
+    kind, c, s, e, cols, _ = plan[0]
+    if not (kind == "pos" and c.config.use_delta and not c.config.use_target and getattr(c, "_normalize_action", False) and (s, e) == (0, n_arm)
+            and cols.tolist() == list(range(n_arm))):
+        raise Unsupported("the fused task kernels restate pd_joint_delta_pos only")
+    c0, c1 = control.c0[:n_arm], control.c1[:n_arm]
+    if bool((c0 != 0).any()) or bool((c1 != c1[0]).any()):
+        raise Unsupported("an arm delta range that is not symmetric and uniform")
+    mid = half = 0.0
+    if gripper:
+        kind, g, s, e, cols, _ = plan[1]
+        if not (kind == "mimic" and not g.config.use_delta and getattr(g, "_normalize_action", False) and (s, e) == (n_arm, n_arm + 1)
+                and cols.tolist() == [n_arm, n_arm + 1] and g.control_joint_indices.tolist() == [0] and g.mimic_joint_indices.tolist() == [1]
+                and g.mimic_control_joint_indices.tolist() == [0] and g._multiplier.tolist() == [1.0] and g._offset.tolist() == [0.0]):
+            raise Unsupported("the fused task kernels restate the Panda's mimic gripper controller only")
+        mid, half = float(control.c0[n_arm]), float(control.c1[n_arm])
+    if control.adim != n_arm + (1 if gripper else 0) or control.sets_qvel:
+        raise Unsupported("the fused task kernels restate pd_joint_delta_pos only")
+    return float(c1[0]), mid, half
+
+
+class _KernelStep:
+    """Shared by the plugins that run ``BaseEnv.step`` on the library's fused task kernels (include/msk_task.h) -- the launches the fused hosts of
+    maniskill_amd.envs issue, here for an env the REFERENCE built and owns: set-action kernel (controller + commit of the drive targets), the substeps, ONE fetch
+    (the sapien buffers stay what the reference's structs read), the task's observe kernel (evaluate + observation + normalised dense reward + flags + step
+    counter).  The simulation state has the reference's bits (same targets, same substeps); observation and reward are the kernels' fp32 restatement of the
+    task's arithmetic -- equal to the reference's own torch code within 2e-6 (libm tanhf / sqrtf against torch's; tests/test_fused_step.py states the bound),
+    flags equal except on exact threshold ties."""
+
+    level = "task-kernel"
+    hidden_actors = ()
+
+    def _setup(self, base, control):
+        import ctypes
+        from mani_skill.envs.sapien_env import BaseEnv
+        if base.scene.parallel_in_single_scene:
+            raise Unsupported("sub-scenes laid out in one scene")
+        if len(base.agent.controller.get_state()) > 0:
+            raise Unsupported("controllers with state in the observation")
+        if _overridden(base, "_after_control_step", BaseEnv):
+            raise Unsupported("the task overrides _after_control_step")
+        if base.reward_mode not in ("normalized_dense", "dense", "sparse", "none"):
+            raise Unsupported(f"reward mode {base.reward_mode}")
+        if base._elapsed_steps.dtype != torch.int32 or not base._elapsed_steps.is_contiguous():
+            raise Unsupported("the step counter is not a contiguous int32 tensor")
+        self.base, self.control, self.scene, self.boundary = base, control, base.scene, control.boundary
+        self.eng = _single_engine(base)
+        self.L, self.ctx, self.C = self.eng.lib, self.eng.ctx, ctypes
+        self.n = base.num_envs
+
+    def _ptr(self, t):
+        return self.C.c_void_p(t.data_ptr())
+
+    def _action(self, action):
+        base = self.base
+        if not isinstance(action, torch.Tensor):
+            action = torch.as_tensor(action)
+        action = action.to(base.device)
+        if action.ndim == 1 and self.n == 1:
+            action = action[None]
+        if tuple(action.shape) != (self.n, self.control.adim):
+            raise AssertionError(f"Received action of shape {tuple(action.shape)} but expected shape ({self.n}, {self.control.adim})")
+        return action.float().contiguous()
+
+    def _physics(self, action, set_action):
+        """_step_action: targets (kernel), substeps.  The observe kernel comes next (PickCube's computes the link frames of the new state in the same
+        launch), then ``_publish``: ONE fetch of everything scene._gpu_fetch_all() fetches."""
+        L, eng = self.L, self.eng
+        if action is not None:
+            action = self._action(action)
+            L.check(self.ctx, set_action(self.ctx, self._ptr(action), eng._stream()), "task set_action")
+        L.check(self.ctx, L.control_step(self.ctx, self.control.sim_steps, eng._stream()), "control_step")
+
+    def _publish(self):
+        self.boundary.fetch_all()
+
+    def step(self, action):
+        """the env's ``step``: the kernels, or -- while the kernels cannot see what the reference's structs report (``_usable``) -- the reference's own step"""
+        if not self._usable():
+            return type(self.base).step(self.base, action)
+        return self.kernel_step(action)
+
+    def _usable(self):
+        """what the kernels cannot see from inside the simulation: an actor the reference 'hid' by moving it 99999 m away (Actor.hide_visual in GPU
+        simulation, structs/actor.py:176-201) reports its remembered pose -- then the reference's own step runs"""
+        return not any(a.hidden for a in self.hidden_actors)
+
+    def _reward(self, rew, success, scale):
+        mode = self.base.reward_mode
+        if mode == "normalized_dense":
+            return rew
+        if mode == "dense":
+            return rew * scale
+        if mode == "sparse":
+            return success                 # compute_sparse_reward (sapien_env.py:683-690): info["success"] itself
+        return torch.zeros(self.n, device=self.base.device)
+
+
+class PickCubeKernelStep(_KernelStep):
+    """``BaseEnv.step`` of PickCube-v1 (Panda, pd_joint_delta_pos, state observations) on msk_task_pickcube_set_action / msk_control_step /
+    msk_task_pickcube_observe (envs/tasks/tabletop/pick_cube.py:132-190; panda.py:237-269)."""
+
+    env_ids = ("PickCube-v1",)
+
+    def __init__(self, base, control: FusedControl):
+        if base.obs_mode not in ("state", "state_dict"):
+            raise Unsupported("state observations only")
+        if base.robot_uids != "panda" or type(base).__name__ != "PickCubeEnv":
+            raise Unsupported("the Panda PickCube task only")
+        self._setup(base, control)
+        from . import _native as NN
+        delta, mid, half = _delta_arm_controller(control, 7, gripper=True)
+        agent = base.agent
+        d = NN.PickCubeDesc(cube=_template_body(base.cube, "the cube"), goal=_template_body(base.goal_site, "the goal site"), tcp=_template_body(agent.tcp, "the tcp link"),
+                            left_finger=_template_body(agent.finger1_link, "finger 1"), right_finger=_template_body(agent.finger2_link, "finger 2"),
+                            arm_dofs=7, arm_delta=delta, gripper_mid=mid, gripper_half=half, goal_thresh=float(base.goal_thresh), min_force=0.5,
+                            max_angle_deg=85.0, static_thresh=0.2, max_episode_steps=2 ** 31 - 1)      # (truncation is the TimeLimitWrapper's: BaseEnv.step returns False)
+        self.L.check(self.ctx, self.L.task_pickcube_init(self.ctx, self.C.byref(d)), "task_pickcube_init")
+        self.hidden_actors = (base.goal_site,)
+        self.flat = base.obs_mode == "state"
+
+    def kernel_step(self, action):
+        from .graph import alloc_step_outputs
+        base, L = self.base, self.L
+        self._physics(action, L.task_pickcube_set_action)
+        obs, rew, fl, elapsed, _ = alloc_step_outputs(self.n, 42, base.device)
+        L.check(self.ctx, L.task_pickcube_observe(self.ctx, self._ptr(obs), self._ptr(rew), self._ptr(fl), self._ptr(base._elapsed_steps), 1, self.eng._stream()),
+                "task_pickcube_observe")
+        self._publish()
+        elapsed.copy_(base._elapsed_steps)
+        info = dict(elapsed_steps=elapsed, success=fl[:, 0], is_obj_placed=fl[:, 1], is_robot_static=fl[:, 2], is_grasped=fl[:, 3])
+        if not self.flat:
+            obs = dict(agent=dict(qpos=obs[:, 0:9], qvel=obs[:, 9:18]),
+                       extra=dict(is_grasped=fl[:, 3], tcp_pose=obs[:, 19:26], goal_pos=obs[:, 26:29], obj_pose=obs[:, 29:36], tcp_to_obj_pos=obs[:, 36:39],
+                                  obj_to_goal_pos=obs[:, 39:42]))
+        base._last_obs = obs
+        return obs, self._reward(rew, fl[:, 0], 5.0), fl[:, 4], fl[:, 5], info
+
+
+class PegInsertionSideKernelStep(_KernelStep):
+    """``BaseEnv.step`` of PegInsertionSide-v1 (BASELINE config 4's task; panda_wristcam, pd_joint_delta_pos, state observations) on the pickcube controller
+    kernel and msk_task_peg_observe (envs/tasks/tabletop/peg_insertion_side.py:248-337): the peg is the 'cube' of the binding, box_with_hole its 'goal'; per-env
+    peg sizes, hole offsets and hole radii are the env's own tensors (:114-131)."""
+
+    env_ids = ("PegInsertionSide-v1",)
+
+    def __init__(self, base, control: FusedControl):
+        import numpy as np
+        if base.obs_mode not in ("state", "state_dict"):
+            raise Unsupported("state observations only")
+        if type(base).__name__ != "PegInsertionSideEnv" or base.robot_uids not in ("panda_wristcam", "panda"):
+            raise Unsupported("the Panda PegInsertionSide task only")
+        self._setup(base, control)
+        from . import _native as NN
+        delta, mid, half = _delta_arm_controller(control, 7, gripper=True)
+        agent = base.agent
+        d = NN.PickCubeDesc(cube=_template_body(base.peg, "the peg"), goal=_template_body(base.box, "the box"), tcp=_template_body(agent.tcp, "the tcp link"),
+                            left_finger=_template_body(agent.finger1_link, "finger 1"), right_finger=_template_body(agent.finger2_link, "finger 2"),
+                            arm_dofs=7, arm_delta=delta, gripper_mid=mid, gripper_half=half, goal_thresh=0.0, min_force=0.5, max_angle_deg=20.0,
+                            static_thresh=0.2, max_episode_steps=2 ** 31 - 1)
+        self.L.check(self.ctx, self.L.task_pickcube_init(self.ctx, self.C.byref(d)), "task_pickcube_init")
+        f32 = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)      # noqa: E731
+        halfs, holes, radii = f32(base.peg_half_sizes), f32(base.box_hole_offsets.p), f32(base.box_hole_radii)
+        if halfs.shape != (self.n, 3) or holes.shape != (self.n, 3) or radii.shape != (self.n,):
+            raise Unsupported("unexpected per-env peg tables")
+        FP = self.C.POINTER(self.C.c_float)
+        self.L.check(self.ctx, self.L.task_peg_init(self.ctx, halfs.ctypes.data_as(FP), holes.ctypes.data_as(FP), radii.ctypes.data_as(FP)), "task_peg_init")
+        self.flat = base.obs_mode == "state"
+
+    def kernel_step(self, action):
+        from .graph import alloc_step_outputs
+        base, L = self.base, self.L
+        self._physics(action, L.task_pickcube_set_action)
+        obs, rew, fl, elapsed, head = alloc_step_outputs(self.n, 43, base.device, extra_floats=3)
+        L.check(self.ctx, L.task_peg_observe(self.ctx, self._ptr(obs), self._ptr(rew), self._ptr(fl), self._ptr(base._elapsed_steps), self._ptr(head), 1,
+                                             self.eng._stream()), "task_peg_observe")
+        self._publish()
+        elapsed.copy_(base._elapsed_steps)
+        info = dict(elapsed_steps=elapsed, success=fl[:, 0], peg_head_pos_at_hole=head)
+        if not self.flat:
+            obs = dict(agent=dict(qpos=obs[:, 0:9], qvel=obs[:, 9:18]),
+                       extra=dict(tcp_pose=obs[:, 18:25], peg_pose=obs[:, 25:32], peg_half_size=obs[:, 32:35], box_hole_pose=obs[:, 35:42], box_hole_radius=obs[:, 42]))
+        base._last_obs = obs
+        return obs, self._reward(rew, fl[:, 0], 10.0), fl[:, 4], fl[:, 5], info
+
+
+class PushTKernelStep(_KernelStep):
+    """``BaseEnv.step`` of PushT-v1 (BASELINE config 3's task; panda_stick, pd_joint_delta_pos) on msk_task_pusht_set_action / msk_control_step /
+    msk_task_pusht_observe (envs/tasks/tabletop/push_t.py:343-431 the 64 x 64 intersection 'renderer', :484-540 evaluate / observation / reward), state
+    observations or the minimal pack's camera observations (rgb / depth / segmentation): the pictures are the shim's own take_picture, depth and segmentation
+    handed out from the rasteriser's planes (what render/shaders.py:75-83 computes from PositionSegmentation, without the int16 x 4 texture in between)."""
+
+    env_ids = ("PushT-v1",)
+
+    def __init__(self, base, control: FusedControl):
+        import numpy as np
+        if type(base).__name__ != "PushTEnv" or base.robot_uids != "panda_stick":
+            raise Unsupported("the panda_stick PushT task only")
+        self._setup(base, control)
+        from . import _native as NN
+        C = self.C
+        st = base.obs_mode_struct
+        self.cameras = []
+        if base.obs_mode in ("state", "state_dict"):
+            self.obs_dim = 31
+        else:
+            vis = st.visual
+            if st.state or st.state_dict or vis.position or vis.normal or vis.albedo or base.obs_mode in ("pointcloud", "sensor_data"):
+                raise Unsupported(f"observation mode {base.obs_mode}")
+            from mani_skill.sensors.camera import Camera
+            self.scene.update_render(update_sensors=True, update_human_render_cameras=False)      # (the camera groups exist from here on)
+            for name, sensor in self.scene.sensors.items():
+                group = self.scene.camera_groups.get(name) if isinstance(sensor, Camera) else None
+                if group is None or not hasattr(group, "planes") or sensor.config.shader_config.shader_pack != "minimal":
+                    raise Unsupported("a sensor that is not a minimal-pack camera of this backend")
+                depth, seg = group.planes()
+                color = group.get_picture_cuda("Color").torch() if vis.rgb else None
+                self.cameras.append((name, group, depth, seg, color))
+            self.want = (bool(vis.rgb), bool(vis.depth), bool(vis.segmentation))
+            self.obs_dim = 21
+        delta, _, _ = _delta_arm_controller(control, 7, gripper=False)
+        w2g = base.world_to_goal_trans.detach().cpu().numpy().astype(np.float32)
+        mask = np.ascontiguousarray(base.tee_render.detach().cpu().numpy() == 1, dtype=np.uint8)
+        if mask.shape != (64, 64) or int(base.res) != 64:
+            raise Unsupported("the intersection kernel is written for the task's 64 x 64 grid")
+        goal_xy = [float(v) for v in base.goal_offset]
+        d = NN.PushTDesc(tee=_template_body(base.tee, "the T"), goal=_template_body(base.goal_tee, "the goal T"), tcp=_template_body(base.agent.tcp, "the tcp link"),
+                         arm_dofs=7, arm_delta=delta, goal_xy=(C.c_float * 2)(*goal_xy), goal_z_rot=float(base.goal_z_rot),
+                         world_to_goal=(C.c_float * 6)(*[float(x) for x in w2g[:2].reshape(-1)]),
+                         uv_scale=float(np.float32((base.res / 2) / base.uv_half_width)), intersection_thresh=float(base.intersection_thresh),
+                         max_episode_steps=2 ** 31 - 1)
+        self.L.check(self.ctx, self.L.task_pusht_init(self.ctx, C.byref(d), mask.ctypes.data_as(C.POINTER(C.c_uint8))), "task_pusht_init")
+        for _, group, *_ in self.cameras:
+            group.set_outputs(False)
+        self.flat = base.obs_mode == "state"
+        self.consts = DeviceConstants(base.device)
+
+    def restore(self):
+        for _, group, *_ in self.cameras:
+            group.set_outputs(True)
+
+    def kernel_step(self, action):
+        from . import graph as _graph
+        base, L = self.base, self.L
+        self._physics(action, L.task_pusht_set_action)
+        obs, rew, fl, elapsed, _ = _graph.alloc_step_outputs(self.n, self.obs_dim, base.device)
+        L.check(self.ctx, L.task_pusht_observe(self.ctx, self._ptr(obs), self.obs_dim, self._ptr(rew), self._ptr(fl), self._ptr(base._elapsed_steps), 1,
+                                               self.eng._stream()), "task_pusht_observe")
+        self._publish()
+        elapsed.copy_(base._elapsed_steps)
+        info = dict(elapsed_steps=elapsed, success=fl[:, 0])
+        if self.cameras:          # _get_obs_with_sensor_data (sapien_env.py:627-634): agent, extra, sensor_param, sensor_data
+            rgb, depth, seg = self.want
+            keep = (lambda t: t) if _graph.CAPTURING else (lambda t: t.clone())      # (a replay snapshots every output once)
+            data = {}
+            for name, group, dplane, splane, color in self.cameras:
+                group.take_picture()
+                pics = {}
+                if rgb:
+                    pics["rgb"] = keep(color[..., :3])
+                if depth:
+                    pics["depth"] = keep(dplane)
+                if seg:
+                    pics["segmentation"] = keep(splane)
+                data[name] = pics
+            with self.consts:      # (a mounted camera's matrices are made from host constants at every call: render_camera.py:77-155)
+                params = base.get_sensor_params()
+            obs = dict(agent=dict(qpos=obs[:, 0:7], qvel=obs[:, 7:14]), extra=dict(tcp_pose=obs[:, 14:21]), sensor_param=params, sensor_data=data)
+        elif not self.flat:
+            obs = dict(agent=dict(qpos=obs[:, 0:7], qvel=obs[:, 7:14]), extra=dict(tcp_pose=obs[:, 14:21], goal_pos=obs[:, 21:24], obj_pose=obs[:, 24:31]))
+        base._last_obs = obs
+        return obs, self._reward(rew, fl[:, 0], 3.0), fl[:, 4], fl[:, 5], info
+
+
+_PLUGINS = [OpenCabinetDrawerStep, PickCubeKernelStep, PickCubeStep, PegInsertionSideKernelStep, PushTKernelStep]
 
 
 # --------------------------------------------------------------------------------------------------------------------- method patches
@@ -837,6 +1138,8 @@ class Accelerated:
                 setattr(self.base, name, val)
             elif name in self.base.__dict__:
                 delattr(self.base, name)
+        if self.plugin is not None and hasattr(self.plugin, "restore"):
+            self.plugin.restore()
         self.graph = None
 
     # the two entry points the env sees
@@ -898,22 +1201,24 @@ class Accelerated:
         plugin = None
         if self._want_task:
             eid = self._eid()
-            for P in _PLUGINS:
-                if eid in P.env_ids:
+            for P in _PLUGINS:       # the first that takes the env: a plugin on the fused task kernels before its torch restatement (task="torch": the latter only)
+                if eid in P.env_ids and not (self._want_task == "torch" and issubclass(P, _KernelStep)):
                     try:
                         plugin = P(base, control)
+                        self.plugin_refused = None
+                        break
                     except Unsupported as e:       # (camera observations, another robot, ...): the task's own code stays, behind the fused controller
                         self.plugin_refused = str(e)
         base._step_action = self._step_action
         self.level = "control"
         cls_step = type(base).step
         if plugin is not None:
-            self.level, self.plugin = "task", plugin
+            self.level, self.plugin = getattr(plugin, "level", "task"), plugin
             self._step_fn = plugin.step
             if graph and graph not in ("dry", "watch"):      # (a plugin's step is written for replay: no verdict needed)
                 from .graph import StepGraph
                 try:
-                    g = self.graph = StepGraph(plugin.step, base.num_envs, control.adim, base.device)
+                    g = self.graph = StepGraph(getattr(plugin, "kernel_step", plugin.step), base.num_envs, control.adim, base.device)
                     self.throwaway_steps += g.executed_steps      # the warm-up steps run; the captured one is recorded, not executed
                 except Exception as e:      # noqa: BLE001  (not a GPU env, host-memory backend, a capture error): the caller falls back to the task level
                     if base.device.type == "cuda":
@@ -921,7 +1226,8 @@ class Accelerated:
                     if isinstance(e, Unsupported):
                         raise
                     raise Unsupported(f"the task plugin's step cannot be captured as a HIP graph: {str(e).splitlines()[0][:300]}") from e
-                self._step_fn = lambda action: g(action) if action is not None else plugin.step(None)
+                usable = getattr(plugin, "_usable", lambda: True)      # (decided per step on the host: a replay cannot)
+                self._step_fn = lambda action: g(action) if (action is not None and usable()) else plugin.step(action)
             base.step = self._step
         elif graph:
             for name, factory in _METHOD_PATCHES.get(self._eid(), {}).items():

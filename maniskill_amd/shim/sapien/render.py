@@ -694,10 +694,51 @@ class RenderCameraGroup:
             eng.lib.check(eng.ctx, eng.lib.camera_take_picture(eng.ctx, cid, eng._stream()), "camera_take_picture")
 
     def get_picture_cuda(self, name):
+        if name == "PositionSegmentation" and not getattr(self, "_position_texture", True):
+            # pictures are taken without the texture (set_outputs(False)): rendered for this request, from the current state, the mode put back
+            self.set_outputs(True)
+            try:
+                self.take_picture()
+            finally:
+                self.set_outputs(False)
         return _Picture(self._buffer(name))
 
     def get_picture_names(self):
         return ["Color", "PositionSegmentation"]
+
+    # extension of this backend (not in SAPIEN; maniskill_amd/fused_step.py uses it when present): the rasteriser's own depth / segmentation planes --
+    # what the minimal pack's texture transform (render/shaders.py:75-83: -data[..., [2]], data[..., [3]]) computes from PositionSegmentation, written by
+    # the rasteriser's own store -- and pictures without the int16 x 4 texture (msk_camera_set_outputs)
+    def planes(self):
+        """-> (depth, segmentation) int16 [N, H, W, 1] of the last take_picture; one structural group only"""
+        if len(self._cams) != 1:
+            raise RuntimeError("planes(): sub-scenes of several structural groups render into several buffers")
+        eng, cid, _ = self._cams[0]
+        out = []
+        for which in (0, 1):
+            key = (id(eng), f"plane{which}")
+            t = self._tex.get(key)
+            if t is None:
+                import torch
+                shape = (C.c_int64 * 4)()
+                ptr = eng.lib.camera_obs_buffer(eng.ctx, cid, which, shape)
+                if not ptr:
+                    raise RuntimeError("no plane buffer")
+                shp = tuple(int(v) for v in shape)
+                if eng.host_memory:
+                    t = torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int16)), shape=(int(np.prod(shp)),)).reshape(shp))
+                else:
+                    from maniskill_amd.physx import _DevicePointer
+                    t = torch.as_tensor(_DevicePointer(ptr, shp, "<i2"), device=eng.device)
+                self._tex[key] = t
+            out.append(t)
+        return tuple(out)
+
+    def set_outputs(self, position_texture: bool):
+        """False: take_picture fills the planes (and Color) only, not the PositionSegmentation texture"""
+        for eng, cid, _ in self._cams:
+            eng.lib.check(eng.ctx, eng.lib.camera_set_outputs(eng.ctx, cid, int(bool(position_texture))), "camera_set_outputs")
+        self._position_texture = bool(position_texture)
 
 
 class RenderSystemGroup:

@@ -1,7 +1,7 @@
 """Runs inside a fresh interpreter (tests/test_fused_step.py): envs built by the REFERENCE's own code over the sapien shim, one stepped by the reference's
 unmodified BaseEnv.step, its twin by maniskill_amd.fused_step.accelerate -- same seeds, same actions.  Prints one line ``FUSED {json}``.
 
-    python tests/ref_fused_step.py <oracle|hip> <case> [num_envs] [steps]
+    python tests/ref_fused_step.py <oracle|emu|hip> <case> [num_envs] [steps]
 cases: cabinet (task plugin, several structural groups), cabinet_graph (hip only: the control step as one HIP graph), panda:<control_mode> (control level),
        graph:<env id> (hip: the reference's own task code behind the fused controller, captured), unsupported,
        graph_safe:<env id> (the op stream of two consecutive steps holds nothing a graph capture / replay gets wrong), speed (hip: env-steps/s of the forms)
@@ -31,8 +31,8 @@ def _cabinet_assets(max_drawers="2"):
 def _flat(x):
     """observations as one float tensor (camera modes hand out nested dicts)"""
     import torch
-    if isinstance(x, dict):
-        return torch.cat([_flat(v) for v in x.values()], dim=-1) if x else torch.zeros(0)
+    if isinstance(x, dict):      # (by key: the reference's texture order follows a set's iteration order, sensors/camera.py:206)
+        return torch.cat([_flat(x[k]) for k in sorted(x)], dim=-1) if x else torch.zeros(0)
     return x.reshape(x.shape[0], -1).float()
 
 
@@ -101,15 +101,36 @@ def main():
         res = _compare(gym, "OpenCabinetDrawer-v1", n, steps, {}, {}, history=3)
     elif case == "cabinet_graph":
         res = _compare(gym, "OpenCabinetDrawer-v1", n, steps, {}, dict(graph=True))
+    elif case.startswith(("kernel:", "kernel_graph:")):      # kernel[_graph]:<env id>[:obs mode]: the plugins on the fused task kernels (emu | hip) against the reference's own step
+        parts = case.split(":")
+        kw = dict(obs_mode=parts[2]) if len(parts) > 2 else {}
+        if kw.get("obs_mode", "state") in ("state", "state_dict") and parts[1] != "PushT-v1":      # (PushT reads the render shapes it has just attached)
+            kw["render_backend"] = "none"
+        res = _compare(gym, parts[1], n, steps, kw, dict(graph=True) if parts[0] == "kernel_graph" else {})
+    elif case == "kernel_hidden":             # an actor the reference 'hid' (moved 99999 m away, its pose remembered: structs/actor.py:176-201): the kernels step aside for the reference's own step
+        a, b = gym.make("PickCube-v1", num_envs=n, render_backend="none"), gym.make("PickCube-v1", num_envs=n, render_backend="none")
+        acc = accelerate(b)
+        a.reset(seed=3); b.reset(seed=3)
+        g = torch.Generator().manual_seed(4)
+        worst, phases = 0.0, []
+        for phase in ("shown", "hidden", "shown"):
+            for e in (a, b):
+                (e.unwrapped.goal_site.hide_visual if phase == "hidden" else e.unwrapped.goal_site.show_visual)()
+            phases.append(bool(acc.plugin._usable()))
+            for _ in range(steps):
+                act = 2 * torch.rand(a.action_space.shape, generator=g) - 1
+                ra, rb = a.step(act), b.step(act)
+                worst = max(worst, float((ra[0] - rb[0]).abs().max()), float((ra[1] - rb[1]).abs().max()), float((a.unwrapped.get_state() - b.unwrapped.get_state()).abs().max()))
+        res = dict(level=acc.level, worst=worst, usable=phases)
     elif case.startswith("graph:"):           # the reference's OWN task code behind the fused controller, captured (tasks whose step is graph-safe)
-        res = _compare(gym, case.split(":", 1)[1], n, steps, dict(render_backend="none"), dict(graph=True))
+        res = _compare(gym, case.split(":", 1)[1], n, steps, dict(render_backend="none"), dict(graph=True, task=False))
     elif case in ("dry_rgbd", "graph_rgbd"):  # camera observations: the plugin steps aside, the reference's own step (take_picture, texture transforms) is what is captured
         res = _compare(gym, "PickCube-v1", n, steps, dict(obs_mode="rgbd"), dict(graph="dry" if case == "dry_rgbd" else True))
     elif case in ("dry_pusht", "dry_pusht_cam", "graph_pusht"):    # PushT-v1 (BASELINE config 3's task): its intersection 'renderer' patched mask-free, the rest of its own step captured
         kw = dict(obs_mode="state") if case == "dry_pusht" else dict(obs_mode="rgb+depth+segmentation")
-        res = _compare(gym, "PushT-v1", n, steps, kw, dict(graph=True if case == "graph_pusht" else "dry"))
+        res = _compare(gym, "PushT-v1", n, steps, kw, dict(graph=True if case == "graph_pusht" else "dry", task=False))
     elif case.startswith("dry:"):             # ... the same path without the capture (CPU checker): the results have to be the reference's
-        res = _compare(gym, case.split(":", 1)[1], n, steps, dict(render_backend="none"), dict(graph="dry"))
+        res = _compare(gym, case.split(":", 1)[1], n, steps, dict(render_backend="none"), dict(graph="dry", task=False))
     elif case.startswith("panda:"):
         res = _compare(gym, "PickCube-v1", n, steps, dict(render_backend="none", control_mode=case.split(":")[1]), dict(task=False))
     elif case == "pickcube_grasp":                # the grasp branch of is_grasping: the cube put between the open fingers, the gripper closed on it, the arm lifted
@@ -138,7 +159,8 @@ def main():
         kw = dict(render_backend="none")
         if ":" in case:
             kw["reward_mode"] = case.split(":")[1]
-        res = _compare(gym, "PickCube-v1", n, steps, kw, dict(graph=True) if case.startswith("pickcube_graph") else {})
+        # (the torch restatement: on a library with the fused task kernels it is the second choice, asked for by task="torch")
+        res = _compare(gym, "PickCube-v1", n, steps, kw, dict(graph=True, task="torch") if case.startswith("pickcube_graph") else dict(task="torch"))
     elif case == "changing_constant":
         from maniskill_amd.fused_step import DeviceConstants
         mode = DeviceConstants("cpu")

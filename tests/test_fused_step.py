@@ -43,6 +43,28 @@ def test_envs_that_stepped_before_their_first_reset_still_agree(built):
     assert res["reset_equal"] and res["worst_state"] == 0.0 and res["worst_obs"] == 0.0 and res["worst_rew"] == 0.0 and res["flags"], res
 
 
+def _kernel_bar(res, graph=False):
+    """the plugins on the fused task kernels: the simulation state has the reference's bits (eager; a replayed graph orders its launches differently: 1e-6);
+    observation and reward are the kernels' fp32 restatement of the task code -- libm's tanhf / sqrtf / acosf against torch's: within 2e-6 --, flags equal"""
+    assert res["level"] == "task-kernel" and res["graph"] == graph and res["reset_equal"] and res["flags"] and res["finite"] and res["restored"], res
+    assert res["worst_state"] <= (1e-6 if graph else 0.0) and res["worst_obs"] <= 2e-6 and res["worst_rew"] <= 2e-6, res
+
+
+@needs_ref
+@pytest.mark.parametrize("case", ["kernel:PickCube-v1", "kernel:PickCube-v1:state_dict", "kernel:PegInsertionSide-v1", "kernel:PushT-v1", "kernel:PushT-v1:depth+segmentation",
+                                  "kernel:PushT-v1:rgb+depth+segmentation"])
+def test_task_plugins_on_the_fused_task_kernels_against_the_references_step_on_the_emulated_library(built, case):
+    """BASELINE configs 2, 3 and 4 over the drop-in path: the env is the reference's, its control step the library's fused kernels (controller, substeps, one
+    fetch, observe) -- here with the HIP sources compiled against tests/hipemu, against the reference's unmodified BaseEnv.step on the same library"""
+    _kernel_bar(_run("emu", case, 4, 10))
+
+
+@needs_ref
+def test_the_kernel_plugin_steps_aside_while_the_reference_hides_an_actor(built):
+    res = _run("emu", "kernel_hidden", 3, 3)
+    assert res["level"] == "task-kernel" and res["usable"] == [True, False, True] and res["worst"] <= 2e-6, res
+
+
 @needs_ref
 @pytest.mark.parametrize("case", ["pickcube", "pickcube:dense", "pickcube:sparse"])
 def test_pick_cube_task_plugin_has_the_references_bits_on_cpu_checker(built, case):
@@ -173,8 +195,16 @@ def test_open_cabinet_drawer_step_as_one_hip_graph(built):
 
 @needs_ref
 @pytest.mark.gpu
-def test_pick_cube_task_plugin_as_one_hip_graph(built):
-    res = _run("hip", "pickcube_graph", 64, 20)
+@pytest.mark.parametrize("case", ["kernel_graph:PickCube-v1", "kernel_graph:PegInsertionSide-v1", "kernel_graph:PushT-v1:depth+segmentation"])
+def test_task_plugins_on_the_fused_task_kernels_as_one_hip_graph(built, case):
+    """BASELINE configs 2, 3, 4 over the drop-in path, replayed: the reference's env, the library's kernels, against the reference's eager step"""
+    _kernel_bar(_run("hip", case, 64, 20), graph=True)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_pick_cube_torch_plugin_as_one_hip_graph(built):
+    res = _run("hip", "pickcube_graph_torch", 64, 20)
     assert res["graph"] and res["level"] == "task" and res["flags"] and res["finite"], res
     assert res["worst_state"] <= 1e-6 and res["worst_obs"] <= 1e-6 and res["worst_rew"] <= 1e-6, res
 
