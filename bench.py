@@ -214,7 +214,7 @@ def dropin_sharded_main(args) -> int:
                                "--ids-from", os.path.join(meta, "info_cabinet_drawer_train.json"), "--placeholder-ids-from",
                                os.path.join(meta, "info_cabinet_door_train.json")], stdout=subprocess.DEVNULL)
         os.environ["MS_ASSET_DIR"] = assets
-    elif args.obs_mode == "state":
+    elif args.obs_mode == "state" and not args.env.startswith("PushT"):      # (PushT reads the render shapes it has just attached)
         kw["render_backend"] = "none"
     ref_harness.setup("hip")      # the reference on sys.path over the sapien shim on libmsk_physx.so (stand-ins for gymnasium etc. appended)
     t_build = time.perf_counter()

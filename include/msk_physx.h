@@ -205,6 +205,26 @@ enum msk_fetch_mask {
 };
 int msk_apply(msk_ctx* ctx, uint32_t mask, void* stream);
 int msk_fetch(msk_ctx* ctx, uint32_t mask, void* stream);
+
+/* ---- partial reset without the host ---------------------------------------------------------------------------------------
+ * ManiSkillVectorEnv.step resets the sub-scenes that finished inside the same step (vector/wrappers/gymnasium.py:164-176), and once episodes drift out of
+ * phase that is almost every step.  The reference's reset is host work: BaseEnv.reset -> _clear_sim_state, _initialize_episode (numpy / torch
+ * RNG), controller.reset, masked writes through the torch views, _gpu_apply_all, kinematics, _gpu_fetch_all (envs/sapien_env.py:857-978,1023-1036;
+ * utils/scene_builder/table/scene_builder.py:67-103).  msk_reset_masked is that apply for the envs a DEVICE-side mask names, from episode images prepared
+ * ahead of time: nothing on the step path waits for the host.
+ *   mask      device [num_envs] u8: the envs to reset (the step's `terminated | truncated`)
+ *   image     device [num_envs][slots][nent] f32: per env a ring of prepared episodes; episode k of an env lives in slot k % slots
+ *   ent       device [nent] i32: where entry t of an image goes -- (buffer << 24) | word, buffer 0 = rigid_body_data (word = body * 13 + column),
+ *             1 = qpos, 2 = qvel, 3 = target_qpos, 4 = target_qvel (word = articulation * pitch + coordinate): the sapien buffers' own layout per env
+ *   episode   device [num_envs] i32, read-modify-write: the env's next episode number; a reset consumes image slot episode % slots and adds one
+ *   elapsed   device [num_envs] i32 or NULL: the env's step counter, zeroed by a reset
+ * Per named env: msk_fetch's rows of that env (so that entries the image does not name keep their values), the image's entries over them, then
+ * msk_apply's work for that env with MSK_APPLY_RIGID_DATA | ART_ROOT_POSE | ART_QPOS | ART_QVEL | ART_QF | ART_TARGET_QPOS | ART_TARGET_QVEL -- the same
+ * comparisons, the same normalisation, the contact cache of a teleported env dropped: bit for bit what the host-side path leaves.  Envs the mask does not
+ * name are not touched at all.  Link frames are stale afterwards as after msk_step (the next fetch / observe refreshes them).  Asynchronous on `stream`. */
+enum { MSK_RESET_RIGID_BODY_DATA = 0, MSK_RESET_ART_QPOS = 1, MSK_RESET_ART_QVEL = 2, MSK_RESET_ART_TARGET_QPOS = 3, MSK_RESET_ART_TARGET_QVEL = 4 };
+int msk_reset_masked(msk_ctx* ctx, const uint8_t* mask, const float* image, int slots, const int32_t* ent, int nent, int32_t* episode, int32_t* elapsed,
+                     void* stream);
 /* PhysxGpuSystem.gpu_update_articulation_kinematics (sapien_env.py:959,1304) */
 int msk_update_kinematics(msk_ctx* ctx, void* stream);
 /* PhysxGpuSystem.step() (envs/scene.py:379-380): one substep of `timestep` for all envs. */

@@ -31,7 +31,7 @@ EXPORTS = [
     "fetch", "update_kinematics", "step", "step_n", "get_step_parts", "set_step_parts", "query_create_pairs", "query_create_bodies", "query_buffer", "query_run",
     "get_sizes", "get_contacts", "get_env_contact_counts", "timing_enable", "timing_read",
     "set_solver_classes", "get_solver_class_counts", "declare_env_box", "declare_env_mass", "set_env_boxes", "set_env_masses",
-    "bind_buffers", "batch", "set_articulation_floating", "warnings", "set_locked_axes",
+    "bind_buffers", "batch", "set_articulation_floating", "warnings", "set_locked_axes", "reset_masked",
 ]
 # include/msk_render.h — camera pipeline (both libraries)
 RENDER_EXPORTS = ["render_add_mesh", "render_set_base_color", "render_set_texture", "render_bind_env_box", "render_set_lights", "render_set_local_lights", "render_finalize", "camera_create", "camera_buffer",
@@ -132,6 +132,7 @@ class NativeLib:
             "apply": (i32, [vp, u32, vp]),
             "fetch": (i32, [vp, u32, vp]),
             "update_kinematics": (i32, [vp, vp]),
+            "reset_masked": (i32, [vp, vp, vp, i32, vp, i32, vp, vp, vp]),
             "step": (i32, [vp, vp]),
             "step_n": (i32, [vp, i32, vp]),
             "get_step_parts": (i32, [vp]),

@@ -425,11 +425,8 @@ __global__ void k_apply_wrench(float* __restrict__ wrench, const float* __restri
   }
 }
 
-MSK_DEV void apply_block(const DModel* __restrict__ m, const DState& st, const DBuffers& bf, unsigned mask, const int* __restrict__ art_dof0,
-                         const int* __restrict__ art_ndof, const int blk) {
-  const int N = m->N;
-  const int e = blk * 256 + threadIdx.x;
-  if (e >= N) return;
+MSK_DEV void apply_env(const DModel* __restrict__ m, const DState& st, const DBuffers& bf, unsigned mask, const int* __restrict__ art_dof0,
+                       const int* __restrict__ art_ndof, const int e) {
   float* E = EREC(st, m, e);
   const float ox = E[m->lay.off + 0], oy = E[m->lay.off + 1], oz = E[m->lay.off + 2];
   bool teleported = false; /* a pose or joint position was overwritten: the env's contact cache is stale */
@@ -481,6 +478,12 @@ MSK_DEV void apply_block(const DModel* __restrict__ m, const DState& st, const D
     for (int p = 0; p < m->np; ++p) { cnts[p] = 0; gc[p] = 0ull; }
     st.ct_total[e] = 0;
   }
+}
+MSK_DEV void apply_block(const DModel* __restrict__ m, const DState& st, const DBuffers& bf, unsigned mask, const int* __restrict__ art_dof0,
+                         const int* __restrict__ art_ndof, const int blk) {
+  const int e = blk * 256 + threadIdx.x;
+  if (e >= m->N) return;
+  apply_env(m, st, bf, mask, art_dof0, art_ndof, e);
 }
 
 __global__ void __launch_bounds__(256) k_apply(const DModel* __restrict__ m, DState st, DBuffers bf, unsigned mask, const int* __restrict__ art_dof0,
@@ -611,11 +614,8 @@ __global__ void __launch_bounds__(64) k_link_forces(const DModel* __restrict__ m
   }
 }
 
-MSK_DEV void fetch_block(const DModel* __restrict__ m, const DState& st, const DBuffers& bf, unsigned mask, const int* __restrict__ art_dof0,
-                         const int* __restrict__ art_ndof, const int blk) {
-  const int N = m->N;
-  const int e = blk * 256 + threadIdx.x;
-  if (e >= N) return;
+MSK_DEV void fetch_env(const DModel* __restrict__ m, const DState& st, const DBuffers& bf, unsigned mask, const int* __restrict__ art_dof0,
+                       const int* __restrict__ art_ndof, const int e) {
   float* E = EREC(st, m, e);
   const float ox = E[m->lay.off + 0], oy = E[m->lay.off + 1], oz = E[m->lay.off + 2];
   if (mask & MSK_FETCH_RIGID_DATA)
@@ -639,6 +639,41 @@ MSK_DEV void fetch_block(const DModel* __restrict__ m, const DState& st, const D
         bf.buf[MSK_BUF_ART_TARGET_QVEL][row] = E[m->lay.qdt + (d)];
       }
     }
+}
+MSK_DEV void fetch_block(const DModel* __restrict__ m, const DState& st, const DBuffers& bf, unsigned mask, const int* __restrict__ art_dof0,
+                         const int* __restrict__ art_ndof, const int blk) {
+  const int e = blk * 256 + threadIdx.x;
+  if (e >= m->N) return;
+  fetch_env(m, st, bf, mask, art_dof0, art_ndof, e);
+}
+
+/* msk_reset_masked (include/msk_physx.h): the partial reset of the envs a device-side mask names, without the host.  For such an env: the sapien buffers are
+ * brought up to date (fetch of this env: entries the episode image does not name keep their current values), the image's entries are written over them -- the
+ * rows a host-side reset would have written through the torch views (BaseEnv.reset -> _clear_sim_state, _initialize_episode, controller.reset:
+ * envs/sapien_env.py:857-978,1023-1036) --, and the env is applied exactly as scene._gpu_apply_all() applies it (rows that did not change are left alone, a teleport
+ * drops the env's contact cache).  image: [N][slots][nent] floats, slot = episode[e] % slots; entry t of an image goes to word ent[t] of the env's buffer image
+ * (MSK_RESET_*: a buffer id in the high bits, the word inside the env's rows of that buffer in the low ones). */
+struct ResetPlan { const float* image; const int* ent; int nent, slots; const unsigned char* mask; int* episode; int* elapsed; };
+__global__ void __launch_bounds__(256) k_reset_masked(const DModel* __restrict__ m, DState st, DBuffers bf, ResetPlan rp, unsigned fetch_mask, unsigned apply_mask,
+                                                      const int* __restrict__ art_dof0, const int* __restrict__ art_ndof) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= m->N || !rp.mask[e]) return;
+  fetch_env(m, st, bf, fetch_mask, art_dof0, art_ndof, e);
+  const int ep = rp.episode[e];
+  const float* img = rp.image + ((size_t)e * rp.slots + (size_t)(ep % rp.slots)) * rp.nent;
+  for (int t = 0; t < rp.nent; ++t) {
+    const int code = rp.ent[t], which = code >> 24, word = code & 0xFFFFFF;
+    float* base;
+    if (which == 0) base = bf.buf[MSK_BUF_RIGID_BODY_DATA] + (size_t)e * m->nb * 13;
+    else {
+      const int id = which == 1 ? MSK_BUF_ART_QPOS : (which == 2 ? MSK_BUF_ART_QVEL : (which == 3 ? MSK_BUF_ART_TARGET_QPOS : MSK_BUF_ART_TARGET_QVEL));
+      base = bf.buf[id] + (size_t)e * m->na * bf.pitch;
+    }
+    base[word] = img[t];
+  }
+  apply_env(m, st, bf, apply_mask, art_dof0, art_ndof, e);
+  rp.episode[e] = ep + 1;
+  if (rp.elapsed) rp.elapsed[e] = 0;
 }
 
 __global__ void __launch_bounds__(256) k_fetch(const DModel* __restrict__ m, DState st, DBuffers bf, unsigned mask, const int* __restrict__ art_dof0,

@@ -825,6 +825,26 @@ MSK_API int msk_fetch(msk_ctx* c, uint32_t mask, void* stream) {
   return MSK_OK;
 }
 
+MSK_API int msk_reset_masked(msk_ctx* c, const uint8_t* mask, const float* image, int slots, const int32_t* ent, int nent, int32_t* episode, int32_t* elapsed,
+                             void* stream) {
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "reset_masked before finalize");
+  if (!mask || !image || !ent || !episode || slots < 1 || nent < 0) return fail(c, MSK_ERR_INVALID, "reset_masked: null argument or empty ring");
+  const int N = c->model.N;
+  if (c->kin_dirty) { /* the fetch of a named env publishes its link frames: those of the state the last step left */
+    launch_kinematics(c->model, c->d_model, c->st, (hipStream_t)stream);
+    c->kin_dirty = false;
+  }
+  ResetPlan rp;
+  rp.image = image; rp.ent = ent; rp.nent = nent; rp.slots = slots; rp.mask = mask; rp.episode = episode; rp.elapsed = elapsed;
+  const unsigned fetch_mask = MSK_FETCH_RIGID_DATA | MSK_FETCH_ART_QPOS | MSK_FETCH_ART_QVEL | MSK_FETCH_ART_QACC | MSK_FETCH_ART_TARGETS;
+  const unsigned apply_mask = MSK_APPLY_RIGID_DATA | MSK_APPLY_ART_ROOT_POSE | MSK_APPLY_ART_QPOS | MSK_APPLY_ART_QVEL | MSK_APPLY_ART_QF | MSK_APPLY_ART_TARGET_QPOS | MSK_APPLY_ART_TARGET_QVEL;
+  hipLaunchKernelGGL(k_reset_masked, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->bufs, rp, fetch_mask, apply_mask,
+                     c->d_art_dof0, c->d_art_ndof);
+  HIP_TRY(hipGetLastError());
+  c->kin_dirty = true;   /* joint positions of the named envs changed: their link frames follow at the next fetch / observe */
+  return MSK_OK;
+}
+
 MSK_API int msk_update_kinematics(msk_ctx* c, void* stream) {
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "update_kinematics before finalize");
   const int N = c->model.N;

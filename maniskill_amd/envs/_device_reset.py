@@ -1,0 +1,298 @@
+"""Partial resets of the fused envs without the host on the step path (include/msk_physx.h: msk_reset_masked).
+
+``ManiSkillVectorEnv.step`` resets the sub-scenes that finished inside the same step (mani_skill/vector/wrappers/gymnasium.py:164-176); once episodes drift out of phase
+that happens at almost every step.  The host-side reset of these envs -- the reference's structure: ``BaseEnv.reset`` -> ``_clear_sim_state``,
+``_initialize_episode`` with a numpy RNG per sub-scene, ``controller.reset``, masked writes through the torch views, ``_gpu_apply_all``, kinematics, ``_gpu_fetch_all``
+(envs/sapien_env.py:857-978,1023-1036; utils/scene_builder/table/scene_builder.py:67-103) -- is ~30 torch launches, ~10 uploads and two waits for the device per call,
+0.3-0.7 ms whatever the number of envs it names (profiles/r05_soak_where_after_pinned_uploads.log).
+
+Here the SAME reset code produces, ahead of time and off the step path, the rows it would write -- an *episode image* per (sub-scene, episode number): the env's
+own ``reset`` is run on a host-memory shadow of the env (same class, same seeds: ``2022 + global index`` main seeds, episode seed = f(main seed, episode counter),
+envs/utils/randomization/batched_rng.py:13-70 in spirit), the entries it writes are found by probing with NaNs once, and a ring of ``slots`` images per sub-scene is
+kept on the device.  A reset is then one kernel over a device-side mask: the named envs take their next image (fetch of the env, the image's entries, the apply of the
+env: bit for bit what the host path leaves -- ``tests/test_device_reset.py``), their episode counters advance on the device.  The host looks at the counters every
+``slots // 2`` resets (one small read-back), refills what was consumed, and otherwise only launches."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+RIGID, QPOS, QVEL, TQPOS, TQVEL = 0, 1, 2, 3, 4      # include/msk_physx.h: MSK_RESET_*
+
+
+class _NullPx:
+    """what a shadow env's reset calls on its physics system: nothing happens there (the rows it wrote ARE the product)"""
+
+    host_memory = True
+
+    def __init__(self, px):
+        self.lib, self.device = px.lib, torch.device("cpu")
+        self.num_envs, self.bodies_per_env, self.timestep = px.num_envs, px.bodies_per_env, px.timestep
+
+    def gpu_apply_all(self): pass
+    def gpu_update_articulation_kinematics(self): pass
+    def gpu_fetch_all(self): pass
+    def _apply(self, mask): pass
+    def _fetch(self, mask): pass
+
+
+class DeviceReset:
+    """``env.reset_mask(done)`` for a fused env of maniskill_amd.envs (PickCubeEnv and its subclasses, PushTEnv)."""
+
+    def __init__(self, env, slots: int = 64):
+        if getattr(env, "control_mode", "pd_joint_delta_pos").startswith("pd_ee") and "target" in env.control_mode:
+            raise RuntimeError("controllers that keep an end-effector target re-read the link frames inside reset(): host-side resets only")
+        if not hasattr(env.px.lib, "reset_masked"):
+            raise RuntimeError("this library has no msk_reset_masked")
+        self.env, self.px, self.slots = env, env.px, int(slots)
+        self.n = env.num_envs
+        dev = env.device
+        self.dev = dev
+        self._shadow = self._make_shadow()
+        self._probe_entries()
+        self.nent = len(self.codes)
+        self.ent = torch.as_tensor(self.codes, dtype=torch.int32, device=dev)
+        self.image = torch.zeros(self.n, self.slots, self.nent, dtype=torch.float32, device=dev)
+        self.episode = torch.zeros(self.n, dtype=torch.int32, device=dev)        # next episode number per env (the device's copy is the one that counts)
+        self.mask = torch.zeros(self.n, dtype=torch.uint8, device=dev)
+        self.filled = np.zeros(self.n, dtype=np.int64)                            # episodes [.., filled) are in the ring
+        self.since_refresh = 0
+        self.resets = self.refreshes = self.images_made = 0
+        self._stage = None
+        self.rebuild(np.arange(self.n))
+
+    # ---------------------------------------------------------------------------------------------------------------- the shadow env
+    def _make_shadow(self):
+        env = self.env
+        sh = object.__new__(type(env))
+        d = dict(env.__dict__)
+        cpu = torch.device("cpu")
+        for k, v in list(d.items()):          # the env's small device constants (poses, rest positions): host copies
+            if isinstance(v, torch.Tensor) and v.device.type != "cpu" and v.numel() <= 64 * max(self.n, 1):
+                d[k] = v.detach().cpu().clone()
+        sh.__dict__ = d
+        n, nb = self.n, env.px.bodies_per_env
+        sh.device = cpu
+        sh.px = _NullPx(env.px)
+        sh._rbd = torch.zeros(n, nb, 13)
+        for name in ("_qpos", "_qvel", "_target_qpos_buf", "_target_qvel_buf"):
+            t = getattr(env, name, None)
+            if t is not None:
+                setattr(sh, name, torch.zeros(tuple(t.shape)))
+        if isinstance(getattr(env, "_target_qpos", None), torch.Tensor):
+            sh._target_qpos = torch.zeros(tuple(env._target_qpos.shape))
+        sh._elapsed_steps = torch.zeros(n, dtype=torch.int32)
+        sh._offsets = env._offsets.detach().cpu().clone()
+        from .pick_cube import BatchedRNG
+        sh._rng = BatchedRNG(np.zeros(n, dtype=np.uint64))
+        sh._episode_count = np.zeros(n, dtype=np.uint64)
+        sh._main_seeds = env._main_seeds                   # (shared: a reseeded env is reseeded here too)
+        sh._stage = None
+        sh._buffers_stale = False
+        sh._step_graph = None
+        sh._dev_reset = None
+        sh.device_reset = False                            # (the shadow's own resets are the host's, by definition)
+        sh.camera, sh.cameras = None, {}
+        sh.fused = True                                    # (whatever the env's mode: the shadow's reset ends in the stub below, not in task code)
+        sh._fused_observe = lambda advance: (None, None, None, None, {})
+        return sh
+
+    def _buffers(self, sh):
+        """(code base, tensor viewed [n, words per env]) of the shadow's sapien-style buffers"""
+        n = self.n
+        out = [(RIGID, sh._rbd.view(n, -1))]
+        pitch = sh._qpos.shape[1]
+        for which, name in ((QPOS, "_qpos"), (QVEL, "_qvel"), (TQPOS, "_target_qpos_buf"), (TQVEL, "_target_qvel_buf")):
+            t = getattr(sh, name, None)
+            if t is not None:
+                assert t.shape[1] == pitch
+                out.append((which, t.view(n, -1)))
+        return out
+
+    def _run(self, idx: np.ndarray, episodes: np.ndarray):
+        """the env's own reset for sub-scenes ``idx`` at episode numbers ``episodes``, on the shadow"""
+        sh = self._shadow
+        sh._episode_count[idx] = episodes.astype(np.uint64)
+        sh.reset(seed=None, options=dict(env_idx=torch.as_tensor(idx, dtype=torch.long)))
+
+    def _probe_entries(self):
+        """which words of the buffers does a reset write?  Two runs over NaN-filled buffers (the same episode twice would hide nothing; two different episodes make sure
+        a word is listed even when one of them happens to write a NaN-free value... every written word is non-NaN in both)"""
+        sh = self._shadow
+        idx = np.arange(self.n)
+        written = None
+        for ep in (0, 1):
+            for _, t in self._buffers(sh):
+                t.fill_(float("nan"))
+            self._run(idx, np.full(self.n, ep))
+            w = [(~torch.isnan(t)).all(dim=0) for _, t in self._buffers(sh)]       # written in EVERY env
+            anyw = [(~torch.isnan(t)).any(dim=0) for _, t in self._buffers(sh)]
+            for a, b in zip(w, anyw):
+                if not torch.equal(a, b):
+                    raise RuntimeError("a reset writes different words in different sub-scenes: host-side resets only")
+            written = w if written is None else [a | b for a, b in zip(written, w)]
+        self.codes, self._gather = [], []
+        for (which, t), w in zip(self._buffers(sh), written):
+            words = torch.nonzero(w).reshape(-1)
+            self._gather.append(words)
+            self.codes += [(which << 24) | int(v) for v in words]
+        for _, t in self._buffers(sh):
+            t.zero_()
+
+    def _rows(self, idx: np.ndarray) -> torch.Tensor:
+        sh = self._shadow
+        ii = torch.as_tensor(idx, dtype=torch.long)
+        return torch.cat([t[ii][:, words] for (_, t), words in zip(self._buffers(sh), self._gather)], dim=1)
+
+    # ---------------------------------------------------------------------------------------------------------------- the ring
+    def _upload(self, idx: np.ndarray, slot: np.ndarray, rows: torch.Tensor):
+        if self.dev.type != "cuda":
+            self.image[torch.as_tensor(idx, dtype=torch.long), torch.as_tensor(slot, dtype=torch.long)] = rows
+            return
+        if self._stage is None:
+            self._stage = [torch.empty(self.n, self.nent).pin_memory(), torch.empty(self.n, 2, dtype=torch.int64).pin_memory(), torch.cuda.Event()]
+        host, hidx, ev = self._stage
+        ev.synchronize()
+        k = len(idx)
+        host[:k] = rows
+        hidx[:k, 0] = torch.as_tensor(idx)
+        hidx[:k, 1] = torch.as_tensor(slot)
+        d = host[:k].to(self.dev, non_blocking=True)
+        di = hidx[:k].to(self.dev, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.dev))
+        self.image[di[:, 0], di[:, 1]] = d
+
+    def _fill(self, idx: np.ndarray, first: np.ndarray, upto: np.ndarray):
+        """images of episodes first[i] .. upto[i] - 1 of sub-scene idx[i]"""
+        j = 0
+        while True:
+            sel = first + j < upto
+            if not sel.any():
+                break
+            ii, ep = idx[sel], (first + j)[sel]
+            self._run(ii, ep)
+            self._upload(ii, ep % self.slots, self._rows(ii))
+            self.images_made += len(ii)
+            j += 1
+
+    def rebuild(self, idx: np.ndarray):
+        """sub-scenes whose seeds or episode counters the host set (a seeded reset, set_state ...): their ring starts over at the host's counter"""
+        idx = np.asarray(idx, dtype=np.int64)
+        if len(idx) == 0:
+            return
+        ep0 = self.env._episode_count[idx].astype(np.int64)
+        self.episode[torch.as_tensor(idx, dtype=torch.long, device=self.dev)] = torch.as_tensor(ep0, dtype=torch.int32, device=self.dev)
+        self._fill(idx, ep0, ep0 + self.slots)
+        self.filled[idx] = ep0 + self.slots
+
+    def pull_counts(self) -> np.ndarray:
+        """the device's episode counters (one read-back); the host's copy follows"""
+        ep = self.episode.cpu().numpy().astype(np.int64)
+        self.env._episode_count[:] = ep.astype(np.uint64)
+        return ep
+
+    def refresh(self):
+        ep = self.pull_counts()
+        idx = np.nonzero(ep + self.slots > self.filled)[0]
+        if len(idx):
+            self._fill(idx, self.filled[idx], ep[idx] + self.slots)
+            self.filled[idx] = ep[idx] + self.slots
+        self.since_refresh = 0
+        self.refreshes += 1
+
+    # ---------------------------------------------------------------------------------------------------------------- the reset
+    def reset_mask(self, done: torch.Tensor):
+        """the partial reset of the envs ``done`` names (bool / uint8 [num_envs], on the device); -> (obs, info) of ``env.reset``"""
+        env, px, L = self.env, self.px, self.px.lib
+        if self.since_refresh >= self.slots // 2:      # an env advances at most one episode per reset: the ring cannot run dry in between
+            self.refresh()
+        self.since_refresh += 1
+        self.resets += 1
+        if done.dtype in (torch.bool, torch.uint8) and done.is_contiguous() and done.device == self.mask.device:
+            mask = done                    # (a bool tensor is one byte per element, 0 / 1: the kernel reads it as it is)
+        else:
+            self.mask.copy_(done)
+            mask = self.mask
+        p = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
+        L.check(px.ctx, L.reset_masked(px.ctx, p(mask), p(self.image), self.slots, p(self.ent), self.nent, p(self.episode), p(env._elapsed_steps), px._stream()),
+                "reset_masked")
+        tq = getattr(env, "_target_qpos", None)
+        if isinstance(tq, torch.Tensor) and getattr(env, "control_mode", "") != "pd_joint_delta_pos":
+            # controller.reset(): the torch-side controllers' own copy of the targets (pd_joint_pos.py:54-69); pd_joint_delta_pos rewrites all of it at every action
+            self._controller_targets(mask)
+        if getattr(env, "fused", False):      # the first observation of the new episodes: the task kernel (it computes the link frames of the new state itself)
+            env._buffers_stale = True
+            obs, _, _, _, info = env._fused_observe(False)
+            return obs, info
+        px.gpu_update_articulation_kinematics()      # the torch task code reads the sapien buffers: the tail of the host-side reset
+        px.gpu_fetch_all()
+        env._buffers_stale = False
+        info = env.get_info()
+        obs = env.get_obs(info)
+        return (env._with_sensor_data(obs) if hasattr(env, "_with_sensor_data") else obs), info
+
+    def _controller_targets(self, done):
+        """env._target_qpos rows of the reset envs = their new qpos: read from the image (no fetch): only the torch-side controllers of the less common control modes
+        read it, the fused controller kernels read the simulator's own targets"""
+        env = self.env
+        if not hasattr(self, "_q_cols"):
+            nq = env._target_qpos.shape[1]
+            pos = {c: t for t, c in enumerate(self.codes)}
+            try:
+                self._q_cols = torch.as_tensor([pos[(QPOS << 24) | j] for j in range(nq)], dtype=torch.long, device=self.dev)
+            except KeyError:
+                self._q_cols = None
+        if self._q_cols is None:
+            return
+        slot = ((self.episode - 1) % self.slots).long()      # (the kernel has advanced the counters of the reset envs)
+        rows = self.image[torch.arange(self.n, device=self.dev), slot][:, self._q_cols]
+        env._target_qpos.copy_(torch.where(done.bool()[:, None], rows, env._target_qpos))
+
+
+class DeviceResetMixin:
+    """``reset`` of the fused envs: without a seed and without a state to restore it is the device-side reset (all envs, or the ``env_idx`` named); ``reset_mask``
+    is the form ManiSkillVectorEnv's same-step auto reset uses (a device-side mask, no index list, no wait).  ``device_reset``: None = on for the fused envs on a
+    GPU, True / False = as said (the CPU suite asks for it on its host-memory backends)."""
+
+    _dev_reset = None
+    device_reset = None
+
+    def _device_reset_wanted(self) -> bool:
+        want = self.device_reset
+        if want is None:
+            want = bool(getattr(self, "fused", False)) and not getattr(self.px, "host_memory", False)
+        if want and self._dev_reset is None:
+            try:
+                self._dev_reset = DeviceReset(self, slots=int(getattr(self, "device_reset_slots", 64)))
+            except RuntimeError:
+                self.device_reset = want = False
+        return bool(want)
+
+    def _reset_on_device(self, seed, options):
+        """-> (obs, info), or None when this reset is the host's (a seed, a state to restore, device resets switched off)"""
+        if seed is not None or (options and any(k != "env_idx" for k in options)) or not getattr(self, "_constructed", False) or not self._device_reset_wanted():
+            return None
+        if options and "env_idx" in options:
+            idx = torch.as_tensor(options["env_idx"], device=self.device, dtype=torch.long)
+            mask = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
+            mask[idx] = 1
+        else:
+            mask = torch.ones(self.num_envs, dtype=torch.uint8, device=self.device)
+        return self._dev_reset.reset_mask(mask)
+
+    def reset_mask(self, done: torch.Tensor):
+        """partial reset of the envs a device-side mask names (``terminated | truncated`` of a step) -> (obs, info)"""
+        if self._device_reset_wanted():
+            return self._dev_reset.reset_mask(done)
+        rows = torch.nonzero(done.reshape(-1)).reshape(-1)
+        return self.reset(options=dict(env_idx=rows))
+
+    def _host_reset_begins(self):
+        if self._dev_reset is not None:
+            self._dev_reset.pull_counts()
+
+    def _host_reset_ends(self, idx_np):
+        if self._dev_reset is not None:
+            self._dev_reset.rebuild(idx_np)

@@ -80,7 +80,10 @@ def compute_angle_between(x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     return torch.arccos(torch.clip((n1 * n2).sum(1), -1, 1))
 
 
-class PickCubeEnv:
+from ._device_reset import DeviceResetMixin      # noqa: E402
+
+
+class PickCubeEnv(DeviceResetMixin):
     """PickCube-v1, state observations, ``pd_joint_delta_pos`` control, Panda.
 
     ``num_envs`` sub-scenes live on one device in one ``PhysxGpuSystem``.  The constructor
@@ -107,8 +110,9 @@ class PickCubeEnv:
     def __init__(self, num_envs: int = 1, device: Optional[str] = None, sim_config: Optional[SimConfig] = None,
                  robot_init_qpos_noise: float = 0.02, reward_mode: str = "normalized_dense",
                  env_index_offset: int = 0, total_envs: Optional[int] = None, px_factory=None,
-                 fused: Optional[bool] = None, obs_mode: str = "state", control_mode: str = "pd_joint_delta_pos"):
+                 fused: Optional[bool] = None, obs_mode: str = "state", control_mode: str = "pd_joint_delta_pos", device_reset: Optional[bool] = None):
         self.num_envs = int(num_envs)
+        self.device_reset = device_reset      # partial resets from a device-side mask (envs/_device_reset.py); None: on for the fused envs on a GPU
         self.sim_config = sim_config or SimConfig()
         self.robot_init_qpos_noise = robot_init_qpos_noise
         if reward_mode not in ("normalized_dense", "dense", "sparse", "none"):
@@ -219,6 +223,7 @@ class PickCubeEnv:
                 self.cameras[cfg.uid].set_outputs(position_texture=False)      # no obs mode of these envs hands out `position`
             self.camera = self.cameras["base_camera"]
         self.reset(seed=None)
+        self._constructed = True
 
     def _camera_configs(self, tpl):
         from ..render import CameraConfig, look_at
@@ -269,12 +274,16 @@ class PickCubeEnv:
     # ---------------------------------------------------------------- reset
     def reset(self, seed=None, options: Optional[dict] = None):
         options = options or {}
+        on_device = self._reset_on_device(seed, options)
+        if on_device is not None:
+            return on_device
         dev = self.device
         if "env_idx" in options:
             env_idx = torch.as_tensor(options["env_idx"], device=dev, dtype=torch.long)
         else:
             env_idx = torch.arange(self.num_envs, device=dev)
         idx_np = env_idx.cpu().numpy()
+        self._host_reset_begins()
         if getattr(self, "fused", False) and getattr(self, "_buffers_stale", False):
             self.sync_buffers()   # the masked setters below write into the torch-visible buffers
         if seed is not None:
@@ -319,6 +328,7 @@ class PickCubeEnv:
         self.px.gpu_apply_all()
         self.px.gpu_update_articulation_kinematics()
         self.px.gpu_fetch_all()
+        self._host_reset_ends(idx_np)
         if "target_delta" in self.control_mode and self.control_mode.startswith("pd_ee"):   # controller.reset(): target = current ee pose
             cur = self.ee_pose_at_base()
             if getattr(self, "_target_pose", None) is None:

@@ -26,7 +26,10 @@ from . import scene_builders as sb
 from .pick_cube import BatchedRNG
 
 
-class PushTEnv:
+from ._device_reset import DeviceResetMixin      # noqa: E402
+
+
+class PushTEnv(DeviceResetMixin):
     """PushT-v1, ``pd_joint_delta_pos`` control, PandaStick; obs_mode 'state' or 'depth+segmentation'."""
 
     max_episode_steps = 100
@@ -42,7 +45,9 @@ class PushTEnv:
 
     def __init__(self, num_envs: int = 1, device: Optional[str] = None, sim_config: Optional[SimConfig] = None,
                  robot_init_qpos_noise: float = 0.02, obs_mode: str = "state", env_index_offset: int = 0,
-                 total_envs: Optional[int] = None, px_factory=None, fused: Optional[bool] = None, reward_mode: str = "normalized_dense"):
+                 total_envs: Optional[int] = None, px_factory=None, fused: Optional[bool] = None, reward_mode: str = "normalized_dense",
+                 device_reset: Optional[bool] = None):
+        self.device_reset = device_reset      # partial resets from a device-side mask (envs/_device_reset.py); None: on for the fused env on a GPU
         if reward_mode not in ("normalized_dense", "dense", "sparse", "none"):
             raise NotImplementedError(f"reward_mode {reward_mode!r}: one of 'normalized_dense', 'dense', 'sparse', 'none' (sapien_env.py:648-670)")
         self.reward_mode = reward_mode
@@ -125,6 +130,7 @@ class PushTEnv:
             self.px.lib.check(self.px.ctx, self.px.lib.task_pusht_init(self.px.ctx, C.byref(d), mask.ctypes.data_as(C.POINTER(C.c_uint8))),
                               "task_pusht_init")
         self.reset(seed=None)
+        self._constructed = True
 
     # ---------------------------------------------------------------- the 64 x 64 "pseudo render" tables (push_t.py:264-320)
     def _setup_pseudo_render(self):
@@ -209,9 +215,13 @@ class PushTEnv:
     # ---------------------------------------------------------------- reset
     def reset(self, seed=None, options: Optional[dict] = None):
         options = options or {}
+        on_device = self._reset_on_device(seed, options)
+        if on_device is not None:
+            return on_device
         dev = self.device
         env_idx = torch.as_tensor(options["env_idx"], device=dev, dtype=torch.long) if "env_idx" in options else torch.arange(self.num_envs, device=dev)
         idx_np = env_idx.cpu().numpy()
+        self._host_reset_begins()
         self._fresh()
         if seed is not None:
             seeds = (np.asarray(seed).reshape(-1) if not np.isscalar(seed) else np.array([seed])).astype(np.int64)
@@ -260,6 +270,7 @@ class PushTEnv:
         self.px.gpu_update_articulation_kinematics()
         self.px.gpu_fetch_all()
         self._buffers_stale = False
+        self._host_reset_ends(idx_np)
         if self.fused:
             obs, _, _, _, info = self._fused_observe(False)
             return obs, info

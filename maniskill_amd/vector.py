@@ -41,6 +41,12 @@ class _EpisodeBook:
         self.success[sel] = False
         self.fail[sel] = False
 
+    def clear_mask(self, done):
+        """the same for the envs a device-side mask names, without an index list"""
+        self.ret.masked_fill_(done, 0.0)
+        self.success &= ~done
+        self.fail &= ~done
+
     def account(self, reward, infos, elapsed, at_end: bool) -> dict:
         self.ret += reward
         out = {}
@@ -100,9 +106,15 @@ class ManiSkillVectorEnv:
         if self.ignore_terminations:
             terminated = torch.zeros_like(terminated)
         done = terminated | truncated
-        if self.auto_reset and bool(done.any()):
+        if self.auto_reset and bool(done.any()):      # (the reference's own wait: `if dones.any()`, gymnasium.py:164)
             last_obs, last_info = _copy_tree(obs), _copy_tree(infos)
-            obs, infos = self.reset(options=dict(env_idx=self._rows[done]))
+            reset_mask = getattr(self._env, "reset_mask", None)
+            if reset_mask is not None:      # the fused envs reset from the device-side mask itself: no index list, no second wait (envs/_device_reset.py)
+                obs, infos = reset_mask(done)
+                if self._book is not None:
+                    self._book.clear_mask(done)
+            else:
+                obs, infos = self.reset(options=dict(env_idx=self._rows[done]))
             infos["final_observation"], infos["final_info"] = last_obs, last_info
             infos["_final_info"] = infos["_final_observation"] = infos["_elapsed_steps"] = done
         return obs, rew, terminated, truncated, infos

@@ -384,6 +384,9 @@ ORC_EXPORT int orc_bind_buffers(orc_ctx* c, void* const ptrs[9], int64_t art_pit
   return MSK_OK;
 }
 
+static void apply_env(orc_ctx* c, int e, uint32_t mask);
+static void fetch_env(orc_ctx* c, int e, uint32_t mask);
+
 ORC_EXPORT int orc_apply(orc_ctx* c, uint32_t mask, void* stream) {
   (void)stream;
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "apply before finalize");
@@ -396,7 +399,13 @@ ORC_EXPORT int orc_apply(orc_ctx* c, uint32_t mask, void* stream) {
       }
     c->wrench_pending = 1;
   }
-  for (int e = 0; e < c->num_envs; ++e) {
+  for (int e = 0; e < c->num_envs; ++e) apply_env(c, e, mask);
+  return MSK_OK;
+}
+
+/* the env-record half of orc_apply for one env (orc_reset_masked applies the envs its mask names, nothing else) */
+static void apply_env(orc_ctx* c, int e, uint32_t mask) {
+  {
     orc_env* env = &c->envs[e];
     const float* off = c->offsets + 3 * e;
     int teleported = 0; /* a pose or joint position was overwritten: the env's contact cache is stale */
@@ -443,7 +452,6 @@ ORC_EXPORT int orc_apply(orc_ctx* c, uint32_t mask, void* stream) {
       if (c->gjk_cache) memset(c->gjk_cache + (size_t)e * c->npairs, 0, (size_t)c->npairs * sizeof(uint64_t));
     }
   }
-  return MSK_OK;
 }
 
 ORC_EXPORT int orc_update_kinematics(orc_ctx* c, void* stream) {
@@ -456,7 +464,12 @@ ORC_EXPORT int orc_update_kinematics(orc_ctx* c, void* stream) {
 ORC_EXPORT int orc_fetch(orc_ctx* c, uint32_t mask, void* stream) {
   (void)stream;
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "fetch before finalize");
-  for (int e = 0; e < c->num_envs; ++e) {
+  for (int e = 0; e < c->num_envs; ++e) fetch_env(c, e, mask);
+  return MSK_OK;
+}
+
+static void fetch_env(orc_ctx* c, int e, uint32_t mask) {
+  {
     const orc_env* env = &c->envs[e];
     const float* off = c->offsets + 3 * e;
     if (mask & MSK_FETCH_RIGID_DATA)
@@ -486,6 +499,36 @@ ORC_EXPORT int orc_fetch(orc_ctx* c, uint32_t mask, void* stream) {
           memcpy(c->buf[MSK_BUF_ART_LINK_JOINT_FORCES] + (((size_t)e * c->na + c->bodies[i].art) * c->max_links + c->link_slot[i]) * 6,
                  w + 6 * i, sizeof(float) * 6);
     }
+  }
+}
+
+/* msk_reset_masked (include/msk_physx.h): the envs a mask names are fetched, overwritten from their prepared episode image and applied -- the host-side
+ * partial reset of the reference (BaseEnv.reset with env_idx: masked writes through the torch views, then _gpu_apply_all: envs/sapien_env.py:857-978),
+ * restricted to the named envs; the others are not touched (orc_apply leaves rows alone that did not change). */
+ORC_EXPORT int orc_reset_masked(orc_ctx* c, const uint8_t* mask, const float* image, int slots, const int32_t* ent, int nent, int32_t* episode,
+                                int32_t* elapsed, void* stream) {
+  (void)stream;
+  if (!c->finalized) return fail(c, MSK_ERR_INVALID, "reset_masked before finalize");
+  if (!mask || !image || !ent || !episode || slots < 1 || nent < 0) return fail(c, MSK_ERR_INVALID, "reset_masked: null argument or empty ring");
+  const uint32_t fetch_mask = MSK_FETCH_RIGID_DATA | MSK_FETCH_ART_QPOS | MSK_FETCH_ART_QVEL | MSK_FETCH_ART_QACC | MSK_FETCH_ART_TARGETS;
+  const uint32_t apply_mask = MSK_APPLY_RIGID_DATA | MSK_APPLY_ART_ROOT_POSE | MSK_APPLY_ART_QPOS | MSK_APPLY_ART_QVEL | MSK_APPLY_ART_QF | MSK_APPLY_ART_TARGET_QPOS |
+                              MSK_APPLY_ART_TARGET_QVEL;
+  static const int ids[5] = {MSK_BUF_RIGID_BODY_DATA, MSK_BUF_ART_QPOS, MSK_BUF_ART_QVEL, MSK_BUF_ART_TARGET_QPOS, MSK_BUF_ART_TARGET_QVEL};
+  for (int e = 0; e < c->num_envs; ++e) {
+    if (!mask[e]) continue;
+    fetch_env(c, e, fetch_mask);
+    const int ep = episode[e];
+    const float* img = image + ((size_t)e * slots + (size_t)(ep % slots)) * nent;
+    for (int t = 0; t < nent; ++t) {
+      const int which = ent[t] >> 24, word = ent[t] & 0xFFFFFF;
+      if (which < 0 || which > 4) return fail(c, MSK_ERR_INVALID, "reset_masked: unknown buffer in an image entry");
+      float* base = which == 0 ? c->buf[ids[0]] + (size_t)e * c->nb * 13 : art_row(c, ids[which], e, 0);
+      base[word] = img[t];
+    }
+    apply_env(c, e, apply_mask);
+    orc_forward_kinematics(c, &c->envs[e]);   /* (the HIP library leaves the frames to the next fetch / observe: same values) */
+    episode[e] = ep + 1;
+    if (elapsed) elapsed[e] = 0;
   }
   return MSK_OK;
 }

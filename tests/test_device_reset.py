@@ -1,0 +1,117 @@
+"""Partial resets from a device-side mask (include/msk_physx.h msk_reset_masked, maniskill_amd/envs/_device_reset.py) against the host-side reset of the same
+env: the same episodes (seeds 2022 + index, episode seed from the episode counter), the same rows, the same apply -- state, observation, reward and flags
+bit-equal through many resets, whichever path resets which env; the ring of prepared episodes is kept small here so that it is refilled several times.
+CPU suite: the oracle library (orc_reset_masked, torch task code) and the HIP sources under tests/hipemu (k_reset_masked, fused task kernels)."""
+import numpy as np
+import pytest
+import torch
+
+from maniskill_amd.envs.peg_insertion_side import PegInsertionSideEnv
+from maniskill_amd.envs.pick_cube import PickCubeEnv
+from maniskill_amd.envs.push_t import PushTEnv
+from maniskill_amd.vector import ManiSkillVectorEnv
+
+
+@pytest.fixture()
+def emu_factory(built):
+    from emu_backend import EmuPhysxSystem
+    return lambda tpl, n, cfg: EmuPhysxSystem(tpl, n, cfg)
+
+
+def _pair(cls, n, factory, fused, slots=4, **kw):
+    host = cls(num_envs=n, px_factory=factory, fused=fused, device_reset=False, **kw)
+    dev = cls(num_envs=n, px_factory=factory, fused=fused, device_reset=True, **kw)
+    dev.device_reset_slots = slots
+    return host, dev
+
+
+def _same(a, b, what):
+    if isinstance(a, dict):
+        for k in a:
+            _same(a[k], b[k], f"{what}.{k}")
+    elif torch.is_tensor(a):
+        assert torch.equal(a, b), f"{what} differs"
+
+
+def _rollout(host, dev, adim, steps, seed=0, every=3):
+    """both envs through the same actions; every few steps a random subset is reset -- host-side on one env, from the mask on the other"""
+    n = host.num_envs
+    g = torch.Generator().manual_seed(seed)
+    oh, _ = host.reset(seed=2022)
+    od, _ = dev.reset(seed=2022)
+    _same(oh, od, "first obs")
+    for t in range(steps):
+        a = 2 * torch.rand(n, adim, generator=g) - 1
+        rh, rd = host.step(a), dev.step(a)
+        for k in range(4):
+            _same(rh[k], rd[k], f"step {t} output {k}")
+        assert torch.equal(host.get_state(), dev.get_state()), f"state differs at step {t}"
+        if t % every == every - 1:
+            done = torch.rand(n, generator=g) < 0.4
+            if t % (2 * every) == every - 1:
+                done[:] = done | (torch.arange(n) == (t % n))          # (never empty)
+            rows = torch.nonzero(done).reshape(-1)
+            oh, ih = host.reset(options=dict(env_idx=rows)) if len(rows) else (None, None)
+            od, idv = dev.reset_mask(done)
+            if oh is not None:
+                _same(oh, od, f"obs after the reset at step {t}")
+                _same(ih, idv, f"info after the reset at step {t}")
+            assert torch.equal(host.get_state(), dev.get_state()), f"state differs after the reset at step {t}"
+            assert torch.equal(host._elapsed_steps, dev._elapsed_steps)
+    return dev._dev_reset
+
+
+@pytest.mark.parametrize("cls,adim", [(PickCubeEnv, 8), (PegInsertionSideEnv, 8), (PushTEnv, 7)])
+def test_reset_from_a_mask_equals_the_host_side_reset_on_the_oracle(oracle_factory, cls, adim):
+    host, dev = _pair(cls, 6, oracle_factory, fused=False)
+    dr = _rollout(host, dev, adim, 40)
+    assert dr is not None and dr.resets >= 12 and dr.refreshes >= 3           # the ring of 4 episodes went round
+    counts = dr.pull_counts()
+    assert np.array_equal(counts, host._episode_count.astype(np.int64))      # same episode numbering on both paths
+
+
+@pytest.mark.parametrize("cls,adim", [(PickCubeEnv, 8), (PushTEnv, 7)])
+def test_reset_from_a_mask_on_the_emulated_hip_library_with_the_fused_task_kernels(emu_factory, cls, adim):
+    host, dev = _pair(cls, 5, emu_factory, fused=True)
+    dr = _rollout(host, dev, adim, 14, every=2)
+    assert dr.resets >= 7 and dr.refreshes >= 2
+
+
+def test_full_resets_without_a_seed_take_the_device_path_and_seeded_ones_restart_the_ring(oracle_factory):
+    host, dev = _pair(PickCubeEnv, 4, oracle_factory, fused=False)
+    g = torch.Generator().manual_seed(3)
+    for rnd in range(3):
+        kw = dict(seed=7 + rnd) if rnd != 1 else {}
+        oh, _ = host.reset(**kw)
+        od, _ = dev.reset(**kw)
+        assert torch.equal(oh, od)
+        for _ in range(3):
+            a = 2 * torch.rand(4, 8, generator=g) - 1
+            rh, rd = host.step(a), dev.step(a)
+            assert torch.equal(rh[0], rd[0]) and torch.equal(host.get_state(), dev.get_state())
+        idx = torch.tensor([1, 3])
+        oh, _ = host.reset(options=dict(env_idx=idx))
+        od, _ = dev.reset(options=dict(env_idx=idx))
+        assert torch.equal(oh, od) and torch.equal(host.get_state(), dev.get_state())
+    assert dev._dev_reset.resets >= 4
+
+
+def test_vector_env_auto_resets_from_the_mask(oracle_factory):
+    """ManiSkillVectorEnv's same-step auto reset (vector/wrappers/gymnasium.py:164-176) over both kinds of env: identical outputs, final_* entries included"""
+    host, dev = _pair(PickCubeEnv, 5, oracle_factory, fused=False)
+    host.max_episode_steps = dev.max_episode_steps = 4
+    vh, vd = ManiSkillVectorEnv(host, record_metrics=True), ManiSkillVectorEnv(dev, record_metrics=True)
+    vh.reset(seed=11); vd.reset(seed=11)
+    host._elapsed_steps[:] = torch.tensor([0, 1, 2, 3, 1], dtype=torch.int32)      # episodes out of phase: some env finishes at almost every step
+    dev._elapsed_steps[:] = host._elapsed_steps
+    g = torch.Generator().manual_seed(5)
+    finals = 0
+    for t in range(12):
+        a = 2 * torch.rand(5, 8, generator=g) - 1
+        rh, rd = vh.step(a), vd.step(a)
+        for k in range(4):
+            _same(rh[k], rd[k], f"step {t} output {k}")
+        assert set(rh[4]) == set(rd[4])
+        _same(rh[4], rd[4], f"step {t} infos")
+        finals += int("final_info" in rd[4])
+    assert finals >= 8 and dev._dev_reset is not None and dev._dev_reset.resets == finals

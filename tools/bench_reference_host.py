@@ -45,7 +45,7 @@ def main():
         os.environ["MS_ASSET_DIR"] = assets
     gym = ref_harness.setup(os.environ.get("MSK_REF_BACKEND", "hip"))      # ("oracle": a smoke run of this script without a GPU)
     t0 = time.perf_counter()
-    kw = dict(render_backend="none") if (a.obs_mode == "state" and not a.env.startswith("OpenCabinet")) else {}      # (the cabinet task reads render shapes)
+    kw = dict(render_backend="none") if (a.obs_mode == "state" and not a.env.startswith(("OpenCabinet", "PushT"))) else {}      # (the cabinet and PushT tasks read render shapes)
     env = gym.make(a.env, num_envs=a.envs, obs_mode=a.obs_mode, **kw)
     level = "none"
     if a.accelerate != "none":

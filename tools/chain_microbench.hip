@@ -43,10 +43,9 @@ __global__ void __launch_bounds__(64) k_chain(float* out, long long* cyc, int n,
       } else if (KIND == 6) {     // the row update with the clamp and the subtraction off the chain is not possible (they ARE the chain); this is the bare broadcast: fma, dpp, fma
         const float dl = dpp_mov<0x153>(fmaf(-x, r, lam));
         x = fmaf(a, dl, x);
-      } else if (KIND == 7) {     // empty body: the loop's own cost
-        asm volatile("" : "+v"(x));
       }
     }
+    if (KIND == 7) asm volatile("" : "+v"(x));     // empty body: the loop's own cost (ONE opaque use per loop iteration: an asm per unrolled body is padded with an s_nop each)
   }
 done:
   const long long t1 = (long long)__builtin_readcyclecounter();
