@@ -475,6 +475,26 @@ def main():
             sync()
             dt_late = time.perf_counter() - t2
             dt_1000 = time.perf_counter() - t1k
+        # what an RL trainer sees: the same env behind ManiSkillVectorEnv (vector/wrappers/gymnasium.py:127-184: same-step auto reset of the envs that finished,
+        # episode metrics), the episode phases randomised at the start so that some env finishes at almost every step -- the steady state a 20-step or a
+        # synchronised 1000-step pass never reaches.  Resets come from the device-side mask (envs/_device_reset.py)
+        dt_vec = None
+        if not args.no_extras and not args.reset_every and world == 1:
+            from maniskill_amd.vector import ManiSkillVectorEnv
+            venv = ManiSkillVectorEnv(env, record_metrics=True)
+            venv.reset(seed=2022)
+            env._elapsed_steps.copy_(torch.randint(0, int(env.max_episode_steps), (n_local,), device=dev, dtype=torch.int32))
+            for _ in range(max(args.warmup, 60)):       # (the first pass through every phase: the ring of prepared episodes has been refilled once)
+                venv.step(2 * torch.rand(n_local, env.action_dim, device=dev) - 1)
+            sync()
+            t3 = time.perf_counter()
+            n_vec, n_final = 400, 0
+            for _ in range(n_vec):
+                out = venv.step(2 * torch.rand(n_local, env.action_dim, device=dev) - 1)
+                n_final += int("final_info" in out[4])
+            sync()
+            dr = getattr(env, "_dev_reset", None)
+            dt_vec = (time.perf_counter() - t3, n_vec, n_final, None if dr is None else (dr.resets, dr.refreshes, dr.images_made))
         def eager_kernel_times(k):
             """each substep kernel's own begin -> end over k eager control steps from where the rollout stands (a graph replay records no events: the
             captured graph is set aside for these steps, same kernels, same order, same stream)"""
@@ -625,6 +645,11 @@ def main():
             # the reference harness's pass (gpu_sim.py:96-108: 1000 steps after the seeded reset) beside the driver's --steps
             result["value_1000"] = args.envs * 1000 / dt_1000 if dt_1000 else result["value"]
             result["value_1000_what"] = "env-steps/s over 1000 steps after the seed-2022 reset and the warm-up steps (the reference harness's length), same path as `value`"
+        if dt_vec:
+            result["vector_env_steady"] = {"value": args.envs * dt_vec[1] / dt_vec[0], "unit": "env-steps/s", "steps": dt_vec[1], "ms_per_step": dt_vec[0] / dt_vec[1] * 1e3,
+                                           "steps_with_a_reset": dt_vec[2], "device_reset": None if dt_vec[3] is None else dict(zip(("resets_issued", "ring_refreshes", "episodes_prepared"), dt_vec[3])),
+                                           "what": "the same env (graph replay) behind maniskill_amd.vector.ManiSkillVectorEnv: same-step auto resets from the device-side mask "
+                                                   "(msk_reset_masked), record_metrics on, episode phases randomised at the start (some env finishes at almost every step)"}
         if dt_late:
             result["step_late"] = {"value": args.envs * 200 / dt_late, "unit": "env-steps/s", "steps": 200, "ms_per_step": dt_late / 200 * 1e3,
                                    "what": "steps 800..1000 of a seeded rollout under random actions (arms lying on the table: the contact-rich regime)"}

@@ -106,15 +106,25 @@ class ManiSkillVectorEnv:
         if self.ignore_terminations:
             terminated = torch.zeros_like(terminated)
         done = terminated | truncated
-        if self.auto_reset and bool(done.any()):      # (the reference's own wait: `if dones.any()`, gymnasium.py:164)
+        if not self.auto_reset:
+            return obs, rew, terminated, truncated, infos
+        env = self._env
+        if getattr(env, "reset_mask", None) is not None and getattr(env, "_device_reset_wanted", lambda: False)():
+            # the envs of this package reset from the device-side mask itself (envs/_device_reset.py: one kernel, then the task's observe kernel): everything is
+            # ISSUED before the one wait the reference's wrapper has (`if dones.any()`, gymnasium.py:164) -- a reset over an empty mask changes nothing, so it needs
+            # no verdict first, and the device never idles behind the wait.  The step's own outputs are fresh tensors (nothing below overwrites them).
+            new_obs, new_infos = env.reset_mask(done)
+            if self._book is not None:
+                self._book.clear_mask(done)
+            if bool(done.any()):
+                last_obs, last_info = (obs, infos) if getattr(env, "fused", False) else (_copy_tree(obs), _copy_tree(infos))
+                obs, infos = new_obs, new_infos
+                infos["final_observation"], infos["final_info"] = last_obs, last_info
+                infos["_final_info"] = infos["_final_observation"] = infos["_elapsed_steps"] = done
+            return obs, rew, terminated, truncated, infos
+        if bool(done.any()):      # (the reference's own wait: `if dones.any()`, gymnasium.py:164)
             last_obs, last_info = _copy_tree(obs), _copy_tree(infos)
-            reset_mask = getattr(self._env, "reset_mask", None)
-            if reset_mask is not None:      # the fused envs reset from the device-side mask itself: no index list, no second wait (envs/_device_reset.py)
-                obs, infos = reset_mask(done)
-                if self._book is not None:
-                    self._book.clear_mask(done)
-            else:
-                obs, infos = self.reset(options=dict(env_idx=self._rows[done]))
+            obs, infos = self.reset(options=dict(env_idx=self._rows[done]))
             infos["final_observation"], infos["final_info"] = last_obs, last_info
             infos["_final_info"] = infos["_final_observation"] = infos["_elapsed_steps"] = done
         return obs, rew, terminated, truncated, infos

@@ -114,4 +114,57 @@ def test_vector_env_auto_resets_from_the_mask(oracle_factory):
         assert set(rh[4]) == set(rd[4])
         _same(rh[4], rd[4], f"step {t} infos")
         finals += int("final_info" in rd[4])
-    assert finals >= 8 and dev._dev_reset is not None and dev._dev_reset.resets == finals
+    assert finals >= 8 and dev._dev_reset is not None and dev._dev_reset.resets >= finals      # (the masked reset is issued at every step, before the wait: an empty mask changes nothing)
+
+
+# ---------------------------------------------------------------------------------------------------------------- on the GPU
+DEV = "cuda:0"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls,adim", [(PickCubeEnv, 8), (PegInsertionSideEnv, 8), (PushTEnv, 7)])
+def test_hip_reset_from_a_mask_equals_the_oracles_host_side_reset(oracle_factory, cls, adim):
+    """k_reset_masked on hardware against the CPU oracle stepping the same envs with HOST-side resets: states bit-equal through 20 partial resets"""
+    n = 64
+    cpu = cls(num_envs=n, px_factory=oracle_factory, fused=False, device_reset=False)
+    gpu = cls(num_envs=n, device=DEV, fused=False, device_reset=True)
+    gpu.device_reset_slots = 4
+    g = torch.Generator().manual_seed(0)
+    cpu.reset(seed=2022); gpu.reset(seed=2022)
+    for t in range(60):
+        a = 2 * torch.rand(n, adim, generator=g) - 1
+        cpu.step(a); gpu.step(a.to(DEV))
+        assert torch.equal(cpu.get_state(), gpu.get_state().cpu()), f"state differs at step {t}"
+        if t % 3 == 2:
+            done = torch.rand(n, generator=g) < 0.3
+            done[t % n] = True
+            cpu.reset(options=dict(env_idx=torch.nonzero(done).reshape(-1)))
+            gpu.reset_mask(done.to(DEV))
+            assert torch.equal(cpu.get_state(), gpu.get_state().cpu()), f"state differs after the reset at step {t}"
+    assert gpu._dev_reset.resets == 20 and gpu._dev_reset.refreshes >= 5
+
+
+@pytest.mark.gpu
+def test_hip_vector_env_with_step_graph_and_mask_resets_equals_the_host_side_path():
+    """what an RL trainer runs: the fused env, its control step replayed as a graph, same-step auto resets from the mask -- against the same env with eager steps and
+    host-side resets: observation, reward, flags and final_* bit-equal over 300 steps with episodes out of phase"""
+    n = 256
+    a_env = PickCubeEnv(num_envs=n, device=DEV, device_reset=False)
+    b_env = PickCubeEnv(num_envs=n, device=DEV, device_reset=True)
+    b_env.device_reset_slots = 8
+    b_env.enable_step_graph()
+    va, vb = ManiSkillVectorEnv(a_env, record_metrics=True), ManiSkillVectorEnv(b_env, record_metrics=True)
+    va.reset(seed=5); vb.reset(seed=5)
+    phase = torch.randint(0, 50, (n,), generator=torch.Generator().manual_seed(1), dtype=torch.int32).to(DEV)
+    a_env._elapsed_steps.copy_(phase); b_env._elapsed_steps.copy_(phase)
+    torch.manual_seed(0)
+    finals = 0
+    for t in range(300):
+        act = 2 * torch.rand(n, 8, device=DEV) - 1
+        ra, rb = va.step(act), vb.step(act)
+        for k in range(4):
+            _same(ra[k], rb[k], f"step {t} output {k}")
+        assert set(ra[4]) == set(rb[4])
+        _same(ra[4], rb[4], f"step {t} infos")
+        finals += int("final_info" in rb[4])
+    assert finals >= 250

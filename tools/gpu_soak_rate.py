@@ -32,11 +32,18 @@ for w in range(W):
         env.step(2 * torch.rand(n, 8, device="cuda:0") - 1)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"bare env  window {w}: {dt:.3f} ms/step, {n * 1000 / dt / 1e6:.2f} M env-steps/s | {smi()}", flush=True)
+# round 6: the env behind the wrapper replays its control step as a graph like the bare one, its auto resets come from the device-side mask (envs/_device_reset.py),
+# and the episode phases are randomised at the start: the steady state (some env finishes at almost every step) from the first window on
 venv = ManiSkillVectorEnv("PickCube-v1", num_envs=n, device="cuda:0", record_metrics=True)
+if os.environ.get("SOAK_HOST_RESETS"):
+    venv.base_env.device_reset = False
+venv.base_env.enable_step_graph()
 venv.reset(seed=7)
+venv.base_env._elapsed_steps.copy_(torch.randint(0, 50, (n,), device="cuda:0", dtype=torch.int32))
 for w in range(W):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for k in range(1000):
         venv.step(2 * torch.rand(n, 8, device="cuda:0") - 1)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"vector env window {w}: {dt:.3f} ms/step, {n * 1000 / dt / 1e6:.2f} M env-steps/s | {smi()}", flush=True)
+    dr = venv.base_env._dev_reset
+    print(f"vector env window {w}: {dt:.3f} ms/step, {n * 1000 / dt / 1e6:.2f} M env-steps/s | {smi()}" + (f" | ring refreshes {dr.refreshes}, episodes prepared {dr.images_made}" if dr else " | host-side resets"), flush=True)
