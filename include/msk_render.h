@@ -87,7 +87,10 @@ void* msk_camera_obs_buffer(msk_ctx* ctx, int camera, int which, int64_t shape[4
 /* Which outputs msk_camera_take_picture fills from now on.  position_texture = 0: the caller only reads the depth / segmentation planes (Camera.get_obs with
  * position=False -- every ManiSkill obs mode but the ones with `position`, sensors/camera.py:190-242) and the int16 x 4 PositionSegmentation texture is neither
  * computed (camera-space x, y) nor stored: 8 of the 12 bytes a pixel costs; the texture's contents are then undefined until a picture is taken with
- * position_texture = 1 (the default).  The planes are the same bits either way. */
+ * position_texture = 1 (the default).  The planes are the same bits either way.  The argument is a bit mask: MSK_CAM_OUT_POSITION_TEXTURE (1) as above,
+ * MSK_CAM_OUT_NO_COLOR (2): Color is neither shaded nor stored although its buffer was asked for (SAPIEN renders every texture of the shader pack whatever the
+ * observation mode reads; a caller that knows the mode -- depth + segmentation: BASELINE config 3 -- switches the rest off); the buffer keeps its old contents. */
+enum { MSK_CAM_OUT_POSITION_TEXTURE = 1, MSK_CAM_OUT_NO_COLOR = 2 };
 int msk_camera_set_outputs(msk_ctx* ctx, int camera, int position_texture);
 /* render_system_group.update_render() + camera_group.take_picture(): rasterises every env. */
 int msk_camera_take_picture(msk_ctx* ctx, int camera, void* stream);

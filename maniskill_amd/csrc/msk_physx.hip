@@ -93,6 +93,7 @@ struct msk_ctx {
   RModel* d_rmodel;
   bool render_finalized;
   int ncams;
+  bool cam_no_color[MSK_MAX_CAMERAS] = {false, false, false, false};   /* msk_camera_set_outputs: MSK_CAM_OUT_NO_COLOR */
   RCamera cams[MSK_MAX_CAMERAS];
   msk_pickcube_desc pickcube; /* fused task kernels (include/msk_task.h) */
   bool has_pickcube;
@@ -1448,7 +1449,8 @@ MSK_API int msk_camera_create(msk_ctx* c, int width, int height, float fovy, flo
 
 MSK_API int msk_camera_set_outputs(msk_ctx* c, int camera, int position_texture) {
   if (camera < 0 || camera >= c->ncams) return fail(c, MSK_ERR_INVALID, "bad camera");
-  c->cams[camera].want_tex = position_texture ? 1 : 0;   /* a kernel argument of the next msk_camera_take_picture (a captured step graph keeps the value it was captured with) */
+  c->cams[camera].want_tex = (position_texture & 1) ? 1 : 0;   /* a kernel argument of the next msk_camera_take_picture (a captured step graph keeps the value it was captured with) */
+  c->cam_no_color[camera] = (position_texture & MSK_CAM_OUT_NO_COLOR) != 0;
   return MSK_OK;
 }
 
@@ -1481,7 +1483,8 @@ MSK_API int msk_camera_take_picture(msk_ctx* c, int camera, void* stream) {
     launch_kinematics(c->model, c->d_model, c->st, s);
     c->kin_dirty = false;
   }
-  const RCamera& cam = c->cams[camera];
+  RCamera cam = c->cams[camera];
+  if (c->cam_no_color[camera]) { cam.color = nullptr; cam.uvt = nullptr; }   /* msk_camera_set_outputs: neither shaded nor stored */
   if (cam.mode == 1) {
     const size_t lds = render_splat_lds_words(cam.ns, cam.rcap, cam.icap, cam.tile_cap, render_segments(cam.tiles_x, cam.tiles_y), cam.bcap, cam.uvcap) * sizeof(float);
     if (lds > 64 * 1024)   /* above the default dynamic LDS limit (large pictures, large models): the CU has 160 KB */

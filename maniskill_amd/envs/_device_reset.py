@@ -10,11 +10,14 @@ Here the SAME reset code produces, ahead of time and off the step path, the rows
 own ``reset`` is run on a host-memory shadow of the env (same class, same seeds: ``2022 + global index`` main seeds, episode seed = f(main seed, episode counter),
 envs/utils/randomization/batched_rng.py:13-70 in spirit), the entries it writes are found by probing with NaNs once, and a ring of ``slots`` images per sub-scene is
 kept on the device.  A reset is then one kernel over a device-side mask: the named envs take their next image (fetch of the env, the image's entries, the apply of the
-env: bit for bit what the host path leaves -- ``tests/test_device_reset.py``), their episode counters advance on the device.  The host looks at the counters every
-``slots // 2`` resets (one small read-back), refills what was consumed, and otherwise only launches."""
+env: bit for bit what the host path leaves -- ``tests/test_device_reset.py``), their episode counters advance on the device.  Every ``slots // 2`` resets the counters
+are copied to pinned memory behind the stream (no wait) and a worker thread refills what was consumed -- the shadow's reset on ONE intra-op thread (its ~40 torch
+ops over a few thousand rows cost 4 ms that way and 200 ms through an OpenMP team per op: profiles/r06_device_reset_refresh.log), uploaded on a side stream into
+slots nothing reads (the slots of episodes already consumed) -- so the step path only launches; the next refill first joins the one before it."""
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -41,7 +44,7 @@ class _NullPx:
 class DeviceReset:
     """``env.reset_mask(done)`` for a fused env of maniskill_amd.envs (PickCubeEnv and its subclasses, PushTEnv)."""
 
-    def __init__(self, env, slots: int = 64):
+    def __init__(self, env, slots: int = 64, threaded=None):
         if getattr(env, "control_mode", "pd_joint_delta_pos").startswith("pd_ee") and "target" in env.control_mode:
             raise RuntimeError("controllers that keep an end-effector target re-read the link frames inside reset(): host-side resets only")
         if not hasattr(env.px.lib, "reset_masked"):
@@ -61,6 +64,12 @@ class DeviceReset:
         self.since_refresh = 0
         self.resets = self.refreshes = self.images_made = 0
         self._stage = None
+        # refills off the step path: a worker thread + a side stream (None: where there is a device to overlap with)
+        self.threaded = (dev.type == "cuda") if threaded is None else bool(threaded)
+        self._job = None                  # the refill in flight: (thread, [exception])
+        self._side = torch.cuda.Stream(dev) if dev.type == "cuda" else None
+        self._uploaded = None             # event on the side stream: the last refill's uploads
+        self._snap = None                 # pinned host copy of the counters + its event
         self.rebuild(np.arange(self.n))
 
     # ---------------------------------------------------------------------------------------------------------------- the shadow env
@@ -115,7 +124,14 @@ class DeviceReset:
         """the env's own reset for sub-scenes ``idx`` at episode numbers ``episodes``, on the shadow"""
         sh = self._shadow
         sh._episode_count[idx] = episodes.astype(np.uint64)
-        sh.reset(seed=None, options=dict(env_idx=torch.as_tensor(idx, dtype=torch.long)))
+        k = torch.get_num_threads()       # (OpenMP's thread count is the calling thread's own setting: the worker's 1 does not reach the caller's ops)
+        if k != 1:
+            torch.set_num_threads(1)
+        try:
+            sh.reset(seed=None, options=dict(env_idx=torch.as_tensor(idx, dtype=torch.long)))
+        finally:
+            if k != 1:
+                torch.set_num_threads(k)
 
     def _probe_entries(self):
         """which words of the buffers does a reset write?  Two runs over NaN-filled buffers (the same episode twice would hide nothing; two different episodes make sure
@@ -159,10 +175,11 @@ class DeviceReset:
         host[:k] = rows
         hidx[:k, 0] = torch.as_tensor(idx)
         hidx[:k, 1] = torch.as_tensor(slot)
-        d = host[:k].to(self.dev, non_blocking=True)
-        di = hidx[:k].to(self.dev, non_blocking=True)
-        ev.record(torch.cuda.current_stream(self.dev))
-        self.image[di[:, 0], di[:, 1]] = d
+        with torch.cuda.stream(self._side if self._job_thread() else torch.cuda.current_stream(self.dev)):
+            d = host[:k].to(self.dev, non_blocking=True)
+            di = hidx[:k].to(self.dev, non_blocking=True)
+            ev.record(torch.cuda.current_stream(self.dev))
+            self.image[di[:, 0], di[:, 1]] = d
 
     def _fill(self, idx: np.ndarray, first: np.ndarray, upto: np.ndarray):
         """images of episodes first[i] .. upto[i] - 1 of sub-scene idx[i]"""
@@ -179,6 +196,7 @@ class DeviceReset:
 
     def rebuild(self, idx: np.ndarray):
         """sub-scenes whose seeds or episode counters the host set (a seeded reset, set_state ...): their ring starts over at the host's counter"""
+        self.join()
         idx = np.asarray(idx, dtype=np.int64)
         if len(idx) == 0:
             return
@@ -189,18 +207,69 @@ class DeviceReset:
 
     def pull_counts(self) -> np.ndarray:
         """the device's episode counters (one read-back); the host's copy follows"""
+        self.join()
         ep = self.episode.cpu().numpy().astype(np.int64)
         self.env._episode_count[:] = ep.astype(np.uint64)
         return ep
 
-    def refresh(self):
-        ep = self.pull_counts()
+    def _refill(self, ep: np.ndarray):
         idx = np.nonzero(ep + self.slots > self.filled)[0]
         if len(idx):
             self._fill(idx, self.filled[idx], ep[idx] + self.slots)
             self.filled[idx] = ep[idx] + self.slots
+
+    def refresh(self):
+        """refill the ring up to ``slots`` episodes past the device's counters.  Threaded: the counters are snapshot behind the stream and a worker does the rest;
+        what it writes are the slots of episodes [filled, snapshot + slots) = the slots of episodes consumed before the snapshot, which no later reset reads (an
+        env is at most ``slots // 2`` episodes past the previous snapshot, so its reads stay inside [snapshot, filled)); the refill after this one joins it first."""
+        self.join()
         self.since_refresh = 0
         self.refreshes += 1
+        if not self.threaded:
+            self._refill(self.pull_counts())
+            return
+        if self.dev.type == "cuda":
+            if self._snap is None:
+                self._snap = (torch.empty(self.n, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+            host, ev = self._snap
+            host.copy_(self.episode, non_blocking=True)
+            ev.record(torch.cuda.current_stream(self.dev))
+        else:
+            host, ev = self.episode.clone(), None
+        err = []
+
+        def work():
+            try:
+                torch.set_num_threads(1)
+                if ev is not None:
+                    ev.synchronize()
+                ep = host.numpy().astype(np.int64)
+                self.env._episode_count[:] = ep.astype(np.uint64)
+                self._refill(ep)
+                if self._side is not None:
+                    self._uploaded = self._side.record_event()
+            except BaseException as e:          # noqa: BLE001 -- re-raised on the caller's thread at the join
+                err.append(e)
+
+        t = threading.Thread(target=work, name="msk-device-reset-refill", daemon=True)
+        self._job = (t, err)
+        t.start()
+
+    def _job_thread(self) -> bool:
+        return self._job is not None and threading.current_thread() is self._job[0]
+
+    def join(self):
+        """the refill in flight has finished, and the caller's stream is behind its uploads"""
+        job = self._job
+        if job is None or threading.current_thread() is job[0]:
+            return
+        job[0].join()
+        self._job = None
+        if self._uploaded is not None:
+            torch.cuda.current_stream(self.dev).wait_event(self._uploaded)
+            self._uploaded = None
+        if job[1]:
+            raise job[1][0]
 
     # ---------------------------------------------------------------------------------------------------------------- the reset
     def reset_mask(self, done: torch.Tensor):
@@ -265,7 +334,7 @@ class DeviceResetMixin:
             want = bool(getattr(self, "fused", False)) and not getattr(self.px, "host_memory", False)
         if want and self._dev_reset is None:
             try:
-                self._dev_reset = DeviceReset(self, slots=int(getattr(self, "device_reset_slots", 64)))
+                self._dev_reset = DeviceReset(self, slots=int(getattr(self, "device_reset_slots", 64)), threaded=getattr(self, "device_reset_threaded", None))
             except RuntimeError:
                 self.device_reset = want = False
         return bool(want)

@@ -81,9 +81,9 @@ class FusedControl:
             raise Unsupported("one agent per env")
         if not base.gpu_sim_enabled:
             raise Unsupported("the batched (GPU) simulation path only")
-        for hook in ("_before_control_step", "_before_simulation_step", "_after_simulation_step"):
-            if _overridden(base, hook, BaseEnv):
-                raise Unsupported(f"the task overrides {hook}")
+        # the task's hooks run where the reference runs them (sapien_env.py:1122-1128); whether a step with them may be replayed as a graph is the watch's call
+        self.hook_before_control = _overridden(base, "_before_control_step", BaseEnv)
+        self.hooks_per_substep = _overridden(base, "_before_simulation_step", BaseEnv) or _overridden(base, "_after_simulation_step", BaseEnv)
         ctrl = agent.controller
         if isinstance(ctrl, CombinedController):
             subs = [(c, ctrl.action_mapping[uid]) for uid, c in ctrl.controllers.items()]
@@ -222,8 +222,16 @@ class FusedControl:
                 raise AssertionError(f"Received action of shape {tuple(action.shape)} but expected shape ({base.num_envs}, {self.adim})")
             self.set_action(action)
             self.apply_targets()
-        for _ in range(self.sim_steps):
-            self.scene.step()
+        if self.hook_before_control:
+            base._before_control_step()
+        if self.hooks_per_substep:
+            for _ in range(self.sim_steps):
+                base._before_simulation_step()
+                self.scene.step()
+                base._after_simulation_step()
+        else:
+            for _ in range(self.sim_steps):
+                self.scene.step()
         base._after_control_step()
         self.boundary.fetch_all()
         return action
@@ -513,8 +521,9 @@ class _KernelStep:
             raise Unsupported("sub-scenes laid out in one scene")
         if len(base.agent.controller.get_state()) > 0:
             raise Unsupported("controllers with state in the observation")
-        if _overridden(base, "_after_control_step", BaseEnv):
-            raise Unsupported("the task overrides _after_control_step")
+        for hook in ("_after_control_step", "_before_control_step", "_before_simulation_step", "_after_simulation_step"):
+            if _overridden(base, hook, BaseEnv):
+                raise Unsupported(f"the task overrides {hook}")
         if base.reward_mode not in ("normalized_dense", "dense", "sparse", "none"):
             raise Unsupported(f"reward mode {base.reward_mode}")
         if base._elapsed_steps.dtype != torch.int32 or not base._elapsed_steps.is_contiguous():
@@ -707,13 +716,13 @@ class PushTKernelStep(_KernelStep):
                          max_episode_steps=2 ** 31 - 1)
         self.L.check(self.ctx, self.L.task_pusht_init(self.ctx, C.byref(d), mask.ctypes.data_as(C.POINTER(C.c_uint8))), "task_pusht_init")
         for _, group, *_ in self.cameras:
-            group.set_outputs(False)
+            group.set_outputs(False, color=self.want[0])      # what the observation mode reads, nothing else (SAPIEN fills every texture of the pack)
         self.flat = base.obs_mode == "state"
         self.consts = DeviceConstants(base.device)
 
     def restore(self):
         for _, group, *_ in self.cameras:
-            group.set_outputs(True)
+            group.set_outputs(True, True)
 
     def kernel_step(self, action):
         from . import graph as _graph
@@ -905,6 +914,12 @@ class DeviceConstants(torch.overrides.TorchFunctionMode):
         self.masked = self.rewritten = self.syncs_skipped = 0      # y[mask] handed out unevaluated / masked assignments turned into selects / device waits skipped
         self._seen, self._nots = {}, {}
         self._depth, self._sync = 0, None
+        # masks that are all True for the whole step, by construction: `scene._reset_mask` outside a reset (the reference indexes through it in every pose setter,
+        # utils/structs/actor.py:389-391 `idx[reset_mask[scene_idxs]]`: a boolean index, i.e. nonzero() and a wait, for a selection that selects everything).
+        # all_true(): the current mask object; a selection through it -- or through a gather of it -- is the whole source.  Checked once per mask object (a wait,
+        # outside any capture: the warm-up steps see every such object first).
+        self.all_true = None
+        self._true_ok, self._true_derived = {}, {}
 
     def __enter__(self):
         self._depth += 1
@@ -927,6 +942,24 @@ class DeviceConstants(torch.overrides.TorchFunctionMode):
 
     def _no_sync(self, *a, **k):
         self.syncs_skipped += 1
+
+    def _is_all_true(self, mask) -> bool:
+        if self.all_true is None or not isinstance(mask, torch.Tensor) or mask.dtype != torch.bool:
+            return False
+        hit = self._true_derived.get(id(mask))
+        if hit is not None and hit[0] is mask and hit[1] == mask._version:
+            return True
+        cur = self.all_true()
+        if mask is not cur:
+            return False
+        ok = self._true_ok.get(id(cur))
+        if ok is None or ok[0] is not cur or ok[1] != cur._version:
+            from . import graph as _graph
+            if _graph.CAPTURING and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                return False          # (an object the warm-up never showed: no wait inside a capture -- the ordinary path decides)
+            with torch._C.DisableTorchFunctionSubclass():
+                ok = self._true_ok[id(cur)] = (cur, cur._version, bool(cur.all()))
+        return ok[2]
 
     @staticmethod
     def _site():
@@ -992,6 +1025,22 @@ class DeviceConstants(torch.overrides.TorchFunctionMode):
             out = _selection_arithmetic(func, args, kwargs)
             if out is not None:
                 return out
+        elif func is torch.Tensor.__getitem__ and len(args) == 2 and type(args[0]) is torch.Tensor and args[0].dtype == torch.bool and self._is_all_true(args[0]) \
+                and isinstance(args[1], torch.Tensor) and args[1].dtype in (torch.int64, torch.int32):
+            out = func(*args)                                       # reset_mask[scene_idxs]: a gather of an all-true mask is all true
+            self._true_derived[id(out)] = (out, out._version)
+            if len(self._true_derived) > 256:
+                self._true_derived = {id(out): (out, out._version)}
+            return out
+        elif func is torch.Tensor.__getitem__ and len(args) == 2 and type(args[0]) is torch.Tensor and _leading_mask(args[0], args[1]) and self._is_all_true(args[1]):
+            self.masked += 1
+            return args[0].clone()                                  # y[all-true mask] is y, row for row (eager indexing copies: so does this)
+        elif func is torch.Tensor.__setitem__ and len(args) == 3 and type(args[0]) is torch.Tensor and _leading_mask(args[0], args[1]) and self._is_all_true(args[1]) \
+                and isinstance(args[2], torch.Tensor) and not isinstance(args[2], _MaskedSelection):
+            x, mask, v = args
+            x.copy_(torch.broadcast_to(v.to(x.dtype), x.shape))      # x[all-true mask] = v
+            self.rewritten += 1
+            return None
         elif func is torch.Tensor.__getitem__ and len(args) == 2 and type(args[0]) is torch.Tensor and _leading_mask(args[0], args[1]) and args[0].device.type == self.device.type:
             self.masked += 1
             return _MaskedSelection.make(args[0], args[1])          # y[mask]: evaluated only if something other than `x[mask] = ...` wants it
@@ -1239,6 +1288,7 @@ class Accelerated:
             # does); host constants made inside the step are served from the device (DeviceConstants); a task that synchronises (StackCube-v1: `reward[mask] =
             # tensor`) fails the capture and is left as the reference built it
             consts = self.constants = DeviceConstants(base.device)
+            consts.all_true = lambda: base.scene._reset_mask      # all True outside a reset (sapien_env.py:880-882, 975: a fresh all-true tensor ends every reset)
 
             def captured_step(a):
                 with consts:

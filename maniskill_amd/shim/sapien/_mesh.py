@@ -598,7 +598,7 @@ def prism(radius, half_length, sides=16, axis=0):
 
 def cluster_simplify(verts, faces, max_tris):
     """Vertex-clustering simplification of a triangle mesh to at most `max_tris` triangles: vertices are merged per cell of a
-    uniform grid (representative = the cell's mean), collapsed triangles dropped; the cell size is bisected to the finest grid that
+    uniform grid (representative = the cell's quadric-error minimiser), collapsed triangles dropped; the cell size is bisected to the finest grid that
     meets the budget.  -> (vertices, faces, moved) where `moved` is the largest distance between an input vertex and the vertex
     that replaces it: the measured error quoted for visual meshes that are too dense for the rasteriser's scene template
     (SURVEY.md §7.2)."""
@@ -631,7 +631,32 @@ def cluster_simplify(verts, faces, max_tris):
             a = mid
     uniq, inv, nf = at(b)
     cnt = np.bincount(inv, minlength=len(uniq)).astype(np.float64)
-    nv = np.stack([np.bincount(inv, weights=v[:, k], minlength=len(uniq)) / np.maximum(cnt, 1) for k in range(3)], axis=1)
+    mean = np.stack([np.bincount(inv, weights=v[:, k], minlength=len(uniq)) / np.maximum(cnt, 1) for k in range(3)], axis=1)
+    # the representative of a cell: the point that minimises the summed squared distances to the planes of the triangles that touch the cell's vertices (quadric
+    # error, area weighted; Lindstrom's clustering) instead of the cell's mean -- a mean pulls convex surfaces inwards (silhouettes shrink: tools/camera_fidelity.py
+    # measured segmentation IoU 0.82-0.94 per Panda link at 128 x 128 with means).  Solved about the mean, along the well-determined directions only, and kept inside
+    # the cell: a flat or degenerate neighbourhood stays at its mean.
+    tri = v[f]
+    nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    area = np.linalg.norm(nrm, axis=1)
+    okt = area > 1e-18
+    nrm = np.where(okt[:, None], nrm / np.maximum(area, 1e-300)[:, None], 0.0)
+    dpl = -(nrm * tri[:, 0]).sum(1)
+    A = np.zeros((len(uniq), 3, 3))
+    rhs = np.zeros((len(uniq), 3))
+    wA = area[:, None, None] * nrm[:, :, None] * nrm[:, None, :]
+    wb = -(area * dpl)[:, None] * nrm
+    for k in range(3):
+        cells = inv[f[:, k]]
+        np.add.at(A, cells, wA)
+        np.add.at(rhs, cells, wb)
+    r = rhs - np.einsum("nij,nj->ni", A, mean)
+    U, S, Vt = np.linalg.svd(A)
+    Sinv = np.where(S > 1e-3 * np.maximum(S[:, :1], 1e-300), 1.0 / np.maximum(S, 1e-300), 0.0)
+    dx = np.einsum("nji,nj->ni", Vt, Sinv * np.einsum("nji,nj->ni", U, r))
+    clo = lo + uniq * b
+    nv = np.clip(mean + dx, clo - 0.25 * b, clo + 1.25 * b)
+    nv = np.where(np.isfinite(nv).all(axis=1, keepdims=True), nv, mean)
     used = np.unique(nf)
     remap = -np.ones(len(uniq), dtype=np.int64)
     remap[used] = np.arange(len(used))

@@ -694,13 +694,15 @@ class RenderCameraGroup:
             eng.lib.check(eng.ctx, eng.lib.camera_take_picture(eng.ctx, cid, eng._stream()), "camera_take_picture")
 
     def get_picture_cuda(self, name):
-        if name == "PositionSegmentation" and not getattr(self, "_position_texture", True):
-            # pictures are taken without the texture (set_outputs(False)): rendered for this request, from the current state, the mode put back
-            self.set_outputs(True)
+        off = (name == "PositionSegmentation" and not getattr(self, "_position_texture", True)) or (name == "Color" and not getattr(self, "_color_on", True))
+        if off:
+            # pictures are taken without this texture (set_outputs): rendered for this request, from the current state, the mode put back
+            was = (getattr(self, "_position_texture", True), getattr(self, "_color_on", True))
+            self.set_outputs(True, True)
             try:
                 self.take_picture()
             finally:
-                self.set_outputs(False)
+                self.set_outputs(*was)
         return _Picture(self._buffer(name))
 
     def get_picture_names(self):
@@ -734,11 +736,13 @@ class RenderCameraGroup:
             out.append(t)
         return tuple(out)
 
-    def set_outputs(self, position_texture: bool):
-        """False: take_picture fills the planes (and Color) only, not the PositionSegmentation texture"""
+    def set_outputs(self, position_texture: bool, color: bool = True):
+        """position_texture False: take_picture fills the planes (and Color) only, not the PositionSegmentation texture; color False: Color is neither shaded
+        nor stored although the pack lists it (include/msk_render.h: MSK_CAM_OUT_NO_COLOR)"""
         for eng, cid, _ in self._cams:
-            eng.lib.check(eng.ctx, eng.lib.camera_set_outputs(eng.ctx, cid, int(bool(position_texture))), "camera_set_outputs")
+            eng.lib.check(eng.ctx, eng.lib.camera_set_outputs(eng.ctx, cid, int(bool(position_texture)) | (0 if color else 2)), "camera_set_outputs")
         self._position_texture = bool(position_texture)
+        self._color_on = bool(color)
 
 
 class RenderSystemGroup:
@@ -795,10 +799,13 @@ class RenderSystemGroup:
         # triangle budget of the rasteriser's scene template (include/msk_render.h: 8192 triangles, 4096 vertices): parts above their
         # share are simplified; the largest surface displacement is kept for the record
         counts = [len(f) for rb in rs0.render_bodies for sh in rb.render_shapes for (_, f, _) in sh._triangles()]
-        KEEP = 400                                              # parts up to this size are drawn as they are (table.glb's four meshes)
+        # MSK_RENDER_TRI_BUDGET / MSK_RENDER_PART_KEEP: the template's triangle budget for simplified parts and the size up to which a part is drawn as it is
+        # (tools/camera_fidelity.py measures what a budget costs in segmentation IoU against the un-simplified geometry; a picture's cost grows with the triangles)
+        KEEP = int(os.environ.get("MSK_RENDER_PART_KEEP", "400"))   # parts up to this size are drawn as they are (table.glb's four meshes)
+        BUDGET = int(os.environ.get("MSK_RENDER_TRI_BUDGET", "2600"))   # (round 6: 5200 with cell means gave 99.36 % pixel agreement, 2600 with quadric minimisers 99.67 %: profiles/r06_camera_fidelity.log)
         small = sum(n for n in counts if n <= KEEP)
         dense = sum(1 for n in counts if n > KEEP)
-        MAX_TRIS_PER_PART = KEEP if not dense else max(64, min(KEEP, (5200 - small) // dense))   # template: 8192 triangles, 4096 vertices
+        MAX_TRIS_PER_PART = KEEP if not dense else max(64, min(max(KEEP, BUDGET // 8), (BUDGET - small) // dense))   # template: 8192 triangles, 4096 vertices
         declared = dict(getattr(self._px, "_env_box_shapes_of_group", {}).get(gi, {}))
         skipped_pose_only = 0
         textures_used = {}

@@ -31,6 +31,7 @@ typedef struct {
   int16_t* out;
   int16_t *depth, *seg;
   uint32_t* color;   /* Color r8g8b8a8unorm, r in the low byte */
+  int no_color;      /* msk_camera_set_outputs: MSK_CAM_OUT_NO_COLOR -- the Color buffer keeps its contents */
 } r_camera;
 typedef struct {
   int nv, nt, ns, finalized, ncams;
@@ -292,8 +293,8 @@ ORC_EXPORT void* orc_camera_obs_buffer(orc_ctx* c, int camera, int which, int64_
  * working picture, so it simply stays defined here; the planes are the same either way */
 ORC_EXPORT int orc_camera_set_outputs(orc_ctx* c, int camera, int position_texture) {
   r_model* r = (r_model*)c->render;
-  (void)position_texture;
   if (!r || camera < 0 || camera >= r->ncams) return rfail(c, MSK_ERR_INVALID, "bad camera");
+  r->cams[camera].no_color = (position_texture & MSK_CAM_OUT_NO_COLOR) != 0;   /* (the texture itself is always filled here: its contents are undefined there) */
   return MSK_OK;
 }
 
@@ -471,7 +472,7 @@ ORC_EXPORT int orc_camera_take_picture(orc_ctx* c, int camera, void* stream) {
     int16_t* img = cam->out + (size_t)e * cam->W * cam->H * 4;
     uint32_t* cimg = cam->color + (size_t)e * cam->W * cam->H;
     memset(img, 0, sizeof(int16_t) * (size_t)cam->W * cam->H * 4);
-    memset(cimg, 0, sizeof(uint32_t) * (size_t)cam->W * cam->H);
+    if (!cam->no_color) memset(cimg, 0, sizeof(uint32_t) * (size_t)cam->W * cam->H);
     for (int i = 0; i < cam->W * cam->H; ++i) bw[i] = 0.0f;
     /* triangles in primitive order; strictly nearer wins, so equal depths keep the lower primitive id */
     for (int k = 0; k < ns; ++k) {
@@ -502,7 +503,7 @@ ORC_EXPORT int orc_camera_take_picture(orc_ctx* c, int camera, void* stream) {
             const float rho = fmaxf(fmaxf(fabsf(ux), fabsf(uy)) * (float)tx->w, fmaxf(fabsf(vx), fabsf(vy)) * (float)tx->h);
             col = modulate(tx->texels[texel_index(tx->w, tx->h, uu, vv, rho)], col);
           }
-          cimg[py * cam->W + px] = col;
+          if (!cam->no_color) cimg[py * cam->W + px] = col;
         }
     }
     for (int i = 0; i < cam->W * cam->H; ++i) {

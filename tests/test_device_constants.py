@@ -108,3 +108,30 @@ def test_an_error_inside_the_watch_becomes_unsupported():
         raise TypeError("'int' object is not iterable")
     with pytest.raises(Unsupported):
         _verdict(step, torch.zeros(()))
+
+
+def test_selections_through_a_mask_known_to_be_all_true_are_the_whole_source():
+    """actor.py:389: ``buf[idx[reset_mask[scene_idxs]], :7] = pose`` outside a reset: the mask is all True, so nothing needs nonzero()"""
+    reset_mask = torch.ones(4, dtype=torch.bool)
+    scene_idxs = torch.tensor([0, 1, 2, 3])
+    idx = torch.tensor([2, 5, 8, 11])
+    buf, pose = torch.zeros(12, 3), torch.arange(12.0).view(4, 3)
+    ebuf = buf.clone()
+    ebuf[idx[reset_mask[scene_idxs]], :3] = pose
+    c = _mode()
+    c.all_true = lambda: reset_mask
+    with c:
+        sel = idx[reset_mask[scene_idxs]]
+        assert type(sel) is torch.Tensor and sel.data_ptr() != idx.data_ptr()      # a plain copy, as eager indexing makes one
+        buf[sel, :3] = pose
+    assert torch.equal(buf, ebuf)
+
+
+def test_a_mask_that_is_not_all_true_takes_the_ordinary_path():
+    reset_mask = torch.tensor([True, False, True])
+    x = torch.arange(3.0)
+    c = _mode()
+    c.all_true = lambda: reset_mask
+    with c:
+        out = x[reset_mask] * 1.0
+    assert out.tolist() == [0.0, 2.0]

@@ -70,6 +70,20 @@ def test_reset_from_a_mask_equals_the_host_side_reset_on_the_oracle(oracle_facto
     assert np.array_equal(counts, host._episode_count.astype(np.int64))      # same episode numbering on both paths
 
 
+def test_refills_by_the_worker_thread_leave_the_same_rows(oracle_factory):
+    """the refill of the ring handed to a worker thread (what a GPU run does: envs/_device_reset.py refresh): same episodes, same bits, and an error in the worker
+    surfaces on the caller's thread at the next join"""
+    host, dev = _pair(PickCubeEnv, 6, oracle_factory, fused=False)
+    dev.device_reset_threaded = True
+    dr = _rollout(host, dev, 8, 40)
+    assert dr.threaded and dr.refreshes >= 3
+    assert np.array_equal(dr.pull_counts(), host._episode_count.astype(np.int64))
+    dr._refill = lambda ep: (_ for _ in ()).throw(RuntimeError("boom"))
+    dr.refresh()
+    with pytest.raises(RuntimeError, match="boom"):
+        dr.join()
+
+
 @pytest.mark.parametrize("cls,adim", [(PickCubeEnv, 8), (PushTEnv, 7)])
 def test_reset_from_a_mask_on_the_emulated_hip_library_with_the_fused_task_kernels(emu_factory, cls, adim):
     host, dev = _pair(cls, 5, emu_factory, fused=True)

@@ -97,7 +97,8 @@ def test_unsupported_controllers_leave_the_env_untouched(built):
 
 
 @needs_ref
-@pytest.mark.parametrize("env_id", ["OpenCabinetDrawer-v1", "PickCube-v1", "RollBall-v1", "PushCube-v1", "PegInsertionSide-v1", "PushT-v1", "StackCube-v1"])
+@pytest.mark.parametrize("env_id", ["OpenCabinetDrawer-v1", "PickCube-v1", "RollBall-v1", "PushCube-v1", "PegInsertionSide-v1", "PushT-v1", "StackCube-v1",
+                                    "MS-AntWalk-v1", "MS-HumanoidStand-v1"])      # (round 6: pose setters through the all-true reset mask; a task's _before_control_step hook)
 def test_steps_that_are_replayed_as_hip_graphs_are_graph_safe(built, env_id):
     """What a stream capture forbids (.item(), nonzero, boolean-mask indexing, host constants uploaded inside the step) and what a replay gets wrong (state
     handed from one step to the next through a tensor the earlier step allocated), watched in the op stream of two consecutive steps: OpenCabinetDrawer-v1
@@ -108,7 +109,8 @@ def test_steps_that_are_replayed_as_hip_graphs_are_graph_safe(built, env_id):
 
 
 @needs_ref
-@pytest.mark.parametrize("env_id", ["PushCube-v1", "PegInsertionSide-v1", "StackCube-v1", "PlaceSphere-v1"])
+@pytest.mark.parametrize("env_id", ["PushCube-v1", "PegInsertionSide-v1", "StackCube-v1", "PlaceSphere-v1", "MS-HumanoidWalk-v1"])      # (the Ant tasks: the reference's own partial reset
+                                                                                                                              # raises -- ant.py:178 sets ALL envs' torso poses through the reset mask)
 def test_the_capture_path_run_eagerly_has_the_references_bits(built, env_id):
     """accelerate(graph="dry"): the reference's own step under DeviceConstants behind the fused controller -- what a capture would run -- against the twin"""
     res = _run("oracle", "dry:" + env_id, 4, 10)
