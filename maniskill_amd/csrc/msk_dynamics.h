@@ -75,17 +75,32 @@ MSK_DEV void root_project(sv6 F, v3 c, float out[6]) {
   out[0] = F.l.x; out[1] = F.l.y; out[2] = F.l.z; out[3] = mc.x; out[4] = mc.y; out[5] = mc.z;
 }
 
-/* Forward pass shared by k_dynamics and k_kinematics: link frames, joint subspaces, spatial
- * velocities (and accelerations with zero joint acceleration), level by level.
- * Returns this lane's body frame; S/V/acc of every body are in LDS afterwards. */
-template <bool WITH_ACC>
-MSK_DEV pose forward_pass(const DModel* m, const float* E, float* lds, const DynLds& ly, int i, bool has, sv6* Sout, sv6* Vout,
-                          sv6* Aout) {
+/* Forward pass shared by k_dynamics and k_kinematics: link frames, joint subspaces, spatial velocities (and accelerations with zero joint
+ * acceleration).  Returns this lane's body frame; S / V of every body are in LDS afterwards.
+ *
+ * Only ONE pose product per tree level depends on the parent (oracle: kinematics()): U = U_parent * L, the rotation as composed.  The level loop -- the
+ * serial part: one lane per env works, the wavefront issues every instruction of a level anyway -- is that product and its LDS hand-off (~60
+ * instructions a level; the loop that also normalised, built S, V and acc inside was ~300).  Everything else is lane-parallel work around it: L
+ * before, the published frame (normalised), the joint axis and S after; V and acc are sums along each body's own path from its root (DModel::path),
+ * which every lane walks by itself in the oracle's order of additions, no hand-offs.
+ * EARLY (k_dynamics): the frames go to the env record as soon as they exist and the workgroup's barrier lets the broadphase wave start on them. */
+template <bool WITH_ACC, bool EARLY>
+MSK_DEV pose forward_pass(const DModel* m, float* E, float* lds, const DynLds& ly, int i, bool has, sv6* Sout, sv6* Vout, sv6* Aout) {
   const DBody* b = &m->bodies[has ? i : 0];
   pose T;
   T.p = v3_make(0, 0, 0);
   T.q = quat_make(1, 0, 0, 0);
   sv6 S = sv6_zero(), V = sv6_zero(), A = sv6_zero();
+  const bool child_link = has && b->kind == MSK_BODY_LINK && b->parent >= 0;
+  const int mydepth = has ? m->depth[i] : -1;
+  const int maxdepth = m->maxdepth;
+  /* everything a lane needs from the template and the env record is fetched here, side by side: inside the level loop only the parent's LDS image is read */
+  int parent = 0, dof = -1, jtype = MSK_JOINT_FIXED;
+  pose L, Xp;
+  L.p = Xp.p = v3_make(0, 0, 0);
+  L.q = Xp.q = quat_make(1, 0, 0, 0);
+  float qdi = 0.0f;
+  uint4 pk = make_uint4(0, 0, 0, 0);
   if (has) {
     T = load_pose(E, m->lay.bpose, i);
     if (b->kind == MSK_BODY_LINK && b->parent < 0 && b->root_dof >= 0) { /* floating root: (v of its centre of mass, omega) is state, as for a free body */
@@ -97,67 +112,117 @@ MSK_DEV pose forward_pass(const DModel* m, const float* E, float* lds, const Dyn
       V.l = v3_add(vc, v3_cross(cr, w));   /* Pluecker: velocity of the point at the env origin */
       if (WITH_ACC) A.l = v3_cross(vc, w);  /* the angular unit motions turn about the moving centre of mass: d/dt (c x e) = v_c x e */
     }
+    if (child_link) {
+      parent = b->parent; dof = b->dof; jtype = b->jtype;
+      Xp = b->Xp;
+      float qi = 0.0f;
+      if (dof >= 0) { qi = E[m->lay.q + dof]; qdi = E[m->lay.qd + dof]; }
+      pose Jq;
+      Jq.p = v3_make(0, 0, 0);
+      Jq.q = quat_make(1, 0, 0, 0);
+      if (jtype == MSK_JOINT_REVOLUTE) {
+        float sn, cs;
+        msk_sincos(0.5f * qi, &sn, &cs);
+        Jq.q = quat_make(cs, sn, 0, 0);
+      } else if (jtype == MSK_JOINT_PRISMATIC) {
+        Jq.p = v3_make(qi, 0, 0);
+      }
+      L = pose_mul(pose_mul(Xp, Jq), b->XcInv);
+      L.q = quat_normalize(L.q);
+      pk = *(const uint4*)(m->path[i]);   /* root, ancestors at depth 1 .. 15 */
+    }
     float* pp = lds + ly.pose + i * 8;
-    pp[0] = T.p.x; pp[1] = T.p.y; pp[2] = T.p.z; pp[3] = T.q.w; pp[4] = T.q.x; pp[5] = T.q.y; pp[6] = T.q.z;
+    pp[0] = T.p.x; pp[1] = T.p.y; pp[2] = T.p.z; pp[3] = T.q.w; pp[4] = T.q.x; pp[5] = T.q.y; pp[6] = T.q.z; pp[7] = qdi;
     lds_put_sv6(lds + ly.S + i * 6, S);
     lds_put_sv6(lds + ly.V + i * 6, V);
     if (WITH_ACC) lds_put_sv6(lds + ly.acc + i * 6, A);
   }
   dyn_sync();
-  const bool child_link = has && b->kind == MSK_BODY_LINK && b->parent >= 0;
-  const int mydepth = has ? m->depth[i] : -1;
-  /* everything a lane needs from the template and the env record is fetched here, side by side for all levels: inside
-   * the level loop (one dependent hop per tree level) only the parent's LDS image is read */
-  const int maxdepth = m->maxdepth;
-  int parent = 0, dof = -1, jtype = MSK_JOINT_FIXED;
-  pose Xp, XcInv;
-  Xp.p = XcInv.p = v3_make(0, 0, 0);
-  Xp.q = XcInv.q = quat_make(1, 0, 0, 0);
-  float qi = 0.0f, qdi = 0.0f, sn = 0.0f, cs = 1.0f;
-  if (child_link) {
-    parent = b->parent; dof = b->dof; jtype = b->jtype;
-    Xp = b->Xp; XcInv = b->XcInv;
-    if (dof >= 0) { qi = E[m->lay.q + dof]; qdi = E[m->lay.qd + dof]; }
-    if (jtype == MSK_JOINT_REVOLUTE) msk_sincos(0.5f * qi, &sn, &cs);
-  }
+  /* ---- the chain: one pose product per level ---- */
+  pose U = T;
   for (int d = 1; d <= maxdepth; ++d) {
     if (child_link && mydepth == d) {
       const float* pp = lds + ly.pose + parent * 8;
-      pose Tp;
-      Tp.p = v3_make(pp[0], pp[1], pp[2]);
-      Tp.q = quat_make(pp[3], pp[4], pp[5], pp[6]);
-      const sv6 Vp = lds_sv6(lds + ly.V + parent * 6);
-      pose Tj = pose_mul(Tp, Xp);
-      v3 axis = quat_rotate(Tj.q, v3_make(1, 0, 0));
-      pose Jq;
-      Jq.p = v3_make(0, 0, 0);
-      Jq.q = quat_make(1, 0, 0, 0);
-      if (jtype == MSK_JOINT_REVOLUTE) {
-        Jq.q = quat_make(cs, sn, 0, 0);
-        S.a = axis;
-        S.l = v3_cross(Tj.p, axis);
-      } else if (jtype == MSK_JOINT_PRISMATIC) {
-        Jq.p = v3_make(qi, 0, 0);
-        S.l = axis;
-      }
-      T = pose_mul(pose_mul(Tj, Jq), XcInv);
-      T.q = quat_normalize(T.q);
-      V = Vp;
-      if (dof >= 0) V = sv6_madd(V, S, qdi);
-      if (WITH_ACC) {
-        A = lds_sv6(lds + ly.acc + parent * 6);
-        if (dof >= 0) {
-          sv6 sq = {v3_scale(S.a, qdi), v3_scale(S.l, qdi)};
-          A = sv6_add(A, sv6_crossm(Vp, sq));
-        }
-        lds_put_sv6(lds + ly.acc + i * 6, A);
-      }
+      pose Up;
+      Up.p = v3_make(pp[0], pp[1], pp[2]);
+      Up.q = quat_make(pp[3], pp[4], pp[5], pp[6]);
+      U = pose_mul(Up, L);
       float* po = lds + ly.pose + i * 8;
-      po[0] = T.p.x; po[1] = T.p.y; po[2] = T.p.z; po[3] = T.q.w; po[4] = T.q.x; po[5] = T.q.y; po[6] = T.q.z;
-      lds_put_sv6(lds + ly.S + i * 6, S);
-      lds_put_sv6(lds + ly.V + i * 6, V);
+      po[0] = U.p.x; po[1] = U.p.y; po[2] = U.p.z; po[3] = U.q.w; po[4] = U.q.x; po[5] = U.q.y; po[6] = U.q.z;
     }
     dyn_sync();
+  }
+  /* ---- published frames: the composed rotation normalised (every lane for itself; the parents' images in LDS are replaced) ---- */
+  if (child_link) {
+    T.p = U.p;
+    T.q = quat_normalize(U.q);
+    float* po = lds + ly.pose + i * 8;
+    po[3] = T.q.w; po[4] = T.q.x; po[5] = T.q.y; po[6] = T.q.z;
+    if (EARLY) store_pose(E, m->lay.bpose, i, T);
+  }
+  if (EARLY) { if (blockDim.x > 64) __syncthreads(); }   /* the link frames are in the env records: the workgroup's broadphase wave may go */
+  dyn_sync();
+  /* ---- joint axes from the parents' published frames ---- */
+  if (child_link) {
+    const float* pp = lds + ly.pose + parent * 8;
+    pose Tp;
+    Tp.p = v3_make(pp[0], pp[1], pp[2]);
+    Tp.q = quat_make(pp[3], pp[4], pp[5], pp[6]);
+    const pose Tj = pose_mul(Tp, Xp);
+    const v3 axis = quat_rotate(Tj.q, v3_make(1, 0, 0));
+    if (jtype == MSK_JOINT_REVOLUTE) {
+      S.a = axis;
+      S.l = v3_cross(Tj.p, axis);
+    } else if (jtype == MSK_JOINT_PRISMATIC) {
+      S.l = axis;
+    }
+    lds_put_sv6(lds + ly.S + i * 6, S);
+  }
+  dyn_sync();
+  /* ---- V = V_root + sum over the path of S qd, in path order ---- */
+  if (child_link) {
+    V = lds_sv6(lds + ly.V + (pk.x & 0xffu) * 6);
+    for (int d0 = 0; d0 < mydepth; d0 += 16) {   /* (trees deeper than 15: the next sixteen path entries) */
+      if (d0 > 0) pk = *(const uint4*)(m->path[i] + d0);
+      const unsigned w4[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int d = d0 + k;
+        if (d >= 1 && d <= mydepth) {
+          const int a = (int)((w4[k >> 2] >> ((k & 3) * 8)) & 0xffu);
+          V = sv6_madd(V, lds_sv6(lds + ly.S + a * 6), lds[ly.pose + a * 8 + 7]);
+        }
+      }
+    }
+    lds_put_sv6(lds + ly.V + i * 6, V);
+  }
+  if (WITH_ACC) {
+    dyn_sync();
+    /* ---- acc = acc_root + sum over the path of V_parent x (S qd) ---- */
+    float* cx = lds + ly.Ic;   /* (free until the RNEA phase) */
+    if (child_link) {
+      const sv6 Vp = lds_sv6(lds + ly.V + parent * 6);
+      const sv6 sq = {v3_scale(S.a, qdi), v3_scale(S.l, qdi)};
+      lds_put_sv6(cx + i * 6, sv6_crossm(Vp, sq));
+    }
+    dyn_sync();
+    if (child_link) {
+      pk = *(const uint4*)(m->path[i]);
+      A = lds_sv6(lds + ly.acc + (pk.x & 0xffu) * 6);
+      for (int d0 = 0; d0 < mydepth; d0 += 16) {
+        if (d0 > 0) pk = *(const uint4*)(m->path[i] + d0);
+        const unsigned w4[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int d = d0 + k;
+          if (d >= 1 && d <= mydepth) {
+            const int a = (int)((w4[k >> 2] >> ((k & 3) * 8)) & 0xffu);
+            A = sv6_add(A, lds_sv6(cx + a * 6));
+          }
+        }
+      }
+    }
+    dyn_sync();   /* (everybody has read the cross terms: the RNEA phase may write its inertias there) */
   }
   *Sout = S; *Vout = V; *Aout = A;
   return T;
@@ -187,7 +252,7 @@ MSK_DEV void kinematics_block(const DModel* __restrict__ m, const DState& st, fl
   const bool has = live && i < m->nb;
   float* E = EREC(st, m, e);
   sv6 S, V, A;
-  pose T = forward_pass<false>(m, E, lds, ly, i, has, &S, &V, &A);
+  pose T = forward_pass<false, false>(m, E, lds, ly, i, has, &S, &V, &A);
   if (!has) return;
   const DBody* b = &m->bodies[i];
   m33 R = quat_to_m33(T.q);
@@ -249,7 +314,7 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
   DPHASE();
   /* ---- 1. frames, velocities, bias accelerations (down the tree) ------------------------------------ */
   sv6 S, V, acc;
-  const pose T = forward_pass<true>(m, E, lds, ly, i, has, &S, &V, &acc);
+  const pose T = forward_pass<true, true>(m, E, lds, ly, i, has, &S, &V, &acc);
   const DBody* b = &m->bodies[has ? i : 0];
   const bool link = has && b->kind == MSK_BODY_LINK;
   v3 comw = v3_make(0, 0, 0);
@@ -262,9 +327,8 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
   if (has) {
     R = quat_to_m33(T.q);
     comw = v3_add(T.p, m33_mulv(&R, b->com));
-    publish_body(m, E, i, b, T, V, comw);
+    publish_body(m, E, i, b, T, V, comw);   /* (the frames went out inside the forward pass, and the workgroup's broadphase wave with them) */
   }
-  if (blockDim.x > 64) __syncthreads();   /* the link frames are in the env records: the workgroup's broadphase wave may go */
   /* zero M while the forward results settle */
   for (int k = i; k < MD * LD; k += LPE) Lm[k] = 0.0f;
   if (i < nd) vec[DV_QD * MD + i] = E[m->lay.qd + i];

@@ -425,12 +425,14 @@ __global__ void k_apply_wrench(float* __restrict__ wrench, const float* __restri
   }
 }
 
+/* NL = 1: the calling lane does the whole env (k_apply: lane = env); NL = 64: the wavefront shares one env, lane = body / joint / candidate pair (k_reset_masked) */
+template <int NL = 1>
 MSK_DEV void apply_env(const DModel* __restrict__ m, const DState& st, const DBuffers& bf, unsigned mask, const int* __restrict__ art_dof0,
-                       const int* __restrict__ art_ndof, const int e) {
+                       const int* __restrict__ art_ndof, const int e, const int lane = 0) {
   float* E = EREC(st, m, e);
   const float ox = E[m->lay.off + 0], oy = E[m->lay.off + 1], oz = E[m->lay.off + 2];
   bool teleported = false; /* a pose or joint position was overwritten: the env's contact cache is stale */
-  for (int i = 0; i < m->nb; ++i) {
+  for (int i = lane; i < m->nb; i += NL) {
     const DBody* b = &m->bodies[i];
     const float* r = bf.buf[MSK_BUF_RIGID_BODY_DATA] + ((size_t)e * m->nb + i) * 13;
     const bool is_root = b->kind == MSK_BODY_LINK && b->parent < 0;
@@ -459,7 +461,7 @@ MSK_DEV void apply_env(const DModel* __restrict__ m, const DState& st, const DBu
     }
   }
   for (int a = 0; a < m->na; ++a)
-    for (int j = 0; j < art_ndof[a]; ++j) {
+    for (int j = lane; j < art_ndof[a]; j += NL) {
       const int d = art_dof0[a] + j;
       const size_t row = ((size_t)e * m->na + a) * bf.pitch + j;
       if (mask & MSK_APPLY_ART_QPOS) {
@@ -472,11 +474,12 @@ MSK_DEV void apply_env(const DModel* __restrict__ m, const DState& st, const DBu
       if (mask & MSK_APPLY_ART_TARGET_QPOS) E[m->lay.qt + (d)] = bf.buf[MSK_BUF_ART_TARGET_QPOS][row];
       if (mask & MSK_APPLY_ART_TARGET_QVEL) E[m->lay.qdt + (d)] = bf.buf[MSK_BUF_ART_TARGET_QVEL][row];
     }
+  if (NL > 1) teleported = __any(teleported);
   if (teleported) { /* no warm start across a teleport: replays from a state are reproducible */
     int* cnts = st.ct_cnt + (size_t)e * m->npp;
     unsigned long long* gc = st.gjk_cache + (size_t)e * m->npp;
-    for (int p = 0; p < m->np; ++p) { cnts[p] = 0; gc[p] = 0ull; }
-    st.ct_total[e] = 0;
+    for (int p = lane; p < m->np; p += NL) { cnts[p] = 0; gc[p] = 0ull; }
+    if (lane == 0) st.ct_total[e] = 0;
   }
 }
 MSK_DEV void apply_block(const DModel* __restrict__ m, const DState& st, const DBuffers& bf, unsigned mask, const int* __restrict__ art_dof0,
@@ -504,20 +507,18 @@ __global__ void __launch_bounds__(64) k_link_forces(const DModel* __restrict__ m
   const float* E = EREC(st, m, e);
   const float inv_dt = 1.0f / m->cfg.timestep;
   const v3 g = v3_make(m->cfg.gravity[0], m->cfg.gravity[1], m->cfg.gravity[2]);
-  pose T[MSK_MAX_BODIES];
+  pose T[MSK_MAX_BODIES], U[MSK_MAX_BODIES];
   sv6 V[MSK_MAX_BODIES], f[MSK_MAX_BODIES], acc[MSK_MAX_BODIES];
   const int nb = m->nb;
   for (int i = 0; i < nb; ++i) {
     const DBody* b = &m->bodies[i];
-    T[i] = load_pose(E, m->lay.bpose, i);
+    T[i] = U[i] = load_pose(E, m->lay.bpose, i);
     V[i] = sv6_zero();
     f[i] = sv6_zero();
     acc[i] = sv6_zero();
     if (b->kind != MSK_BODY_LINK) continue;
     sv6 S = sv6_zero();
-    if (b->parent >= 0) {   /* the oracle's kinematics(): frame, joint subspace and spatial velocity from the parent's */
-      const pose Tj = pose_mul(T[b->parent], b->Xp);
-      const v3 axis = quat_rotate(Tj.q, v3_make(1, 0, 0));
+    if (b->parent >= 0) {   /* the oracle's kinematics(): frame (composed rotation down the tree, normalised where published), joint subspace and spatial velocity */
       pose Jq;
       Jq.p = v3_make(0, 0, 0);
       Jq.q = quat_make(1, 0, 0, 0);
@@ -525,17 +526,25 @@ __global__ void __launch_bounds__(64) k_link_forces(const DModel* __restrict__ m
         float sn, cs;
         msk_sincos(0.5f * E[m->lay.q + b->dof], &sn, &cs);
         Jq.q = quat_make(cs, sn, 0, 0);
+      } else if (b->jtype == MSK_JOINT_PRISMATIC) {
+        Jq.p = v3_make(E[m->lay.q + b->dof], 0, 0);
+      }
+      pose Lq = pose_mul(pose_mul(b->Xp, Jq), b->XcInv);
+      Lq.q = quat_normalize(Lq.q);
+      U[i] = pose_mul(U[b->parent], Lq);
+      pose Ti;
+      Ti.p = U[i].p;
+      Ti.q = quat_normalize(U[i].q);
+      T[i] = Ti;
+      const pose Tj = pose_mul(T[b->parent], b->Xp);
+      const v3 axis = quat_rotate(Tj.q, v3_make(1, 0, 0));
+      if (b->jtype == MSK_JOINT_REVOLUTE) {
         S.a = axis;
         S.l = v3_cross(Tj.p, axis);
       } else if (b->jtype == MSK_JOINT_PRISMATIC) {
-        Jq.p = v3_make(E[m->lay.q + b->dof], 0, 0);
         S.l = axis;
       }
-      pose Ti = pose_mul(pose_mul(Tj, Jq), b->XcInv);
-      Ti.q = quat_normalize(Ti.q);
-      T[i] = Ti;
-      V[i] = V[b->parent];
-      if (b->dof >= 0) V[i] = sv6_madd(V[i], S, E[m->lay.qd + b->dof]);
+      V[i] = sv6_madd(V[b->parent], S, b->dof >= 0 ? E[m->lay.qd + b->dof] : 0.0f);
     }
     const m33 R = quat_to_m33(T[i].q);
     const v3 cw = v3_add(T[i].p, m33_mulv(&R, b->com));
@@ -614,12 +623,13 @@ __global__ void __launch_bounds__(64) k_link_forces(const DModel* __restrict__ m
   }
 }
 
+template <int NL = 1>
 MSK_DEV void fetch_env(const DModel* __restrict__ m, const DState& st, const DBuffers& bf, unsigned mask, const int* __restrict__ art_dof0,
-                       const int* __restrict__ art_ndof, const int e) {
+                       const int* __restrict__ art_ndof, const int e, const int lane = 0) {
   float* E = EREC(st, m, e);
   const float ox = E[m->lay.off + 0], oy = E[m->lay.off + 1], oz = E[m->lay.off + 2];
   if (mask & MSK_FETCH_RIGID_DATA)
-    for (int i = 0; i < m->nb; ++i) {
+    for (int i = lane; i < m->nb; i += NL) {
       float* r = bf.buf[MSK_BUF_RIGID_BODY_DATA] + ((size_t)e * m->nb + i) * 13;
       pose T = load_pose(E, m->lay.bpose, i);
       v3 lv = load_v3(E, m->lay.blin, i), av = load_v3(E, m->lay.bang, i);
@@ -628,7 +638,7 @@ MSK_DEV void fetch_env(const DModel* __restrict__ m, const DState& st, const DBu
       r[7] = lv.x; r[8] = lv.y; r[9] = lv.z; r[10] = av.x; r[11] = av.y; r[12] = av.z;
     }
   for (int a = 0; a < m->na; ++a)
-    for (int j = 0; j < art_ndof[a]; ++j) {
+    for (int j = lane; j < art_ndof[a]; j += NL) {
       const int d = art_dof0[a] + j;
       const size_t row = ((size_t)e * m->na + a) * bf.pitch + j;
       if (mask & MSK_FETCH_ART_QPOS) bf.buf[MSK_BUF_ART_QPOS][row] = E[m->lay.q + (d)];
@@ -654,14 +664,18 @@ MSK_DEV void fetch_block(const DModel* __restrict__ m, const DState& st, const D
  * drops the env's contact cache).  image: [N][slots][nent] floats, slot = episode[e] % slots; entry t of an image goes to word ent[t] of the env's buffer image
  * (MSK_RESET_*: a buffer id in the high bits, the word inside the env's rows of that buffer in the low ones). */
 struct ResetPlan { const float* image; const int* ent; int nent, slots; const unsigned char* mask; int* episode; int* elapsed; };
-__global__ void __launch_bounds__(256) k_reset_masked(const DModel* __restrict__ m, DState st, DBuffers bf, ResetPlan rp, unsigned fetch_mask, unsigned apply_mask,
-                                                      const int* __restrict__ art_dof0, const int* __restrict__ art_ndof) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+/* one wavefront per env (grid = N): a wavefront whose env is not named leaves at once; the others share their env's bodies, joints, image entries and candidate
+ * pairs among the 64 lanes (lane = env, one thread walking its env's ~500 words alone, made a reset of 82 of 4096 envs a 60 us chain of dependent memory
+ * operations).  The phases hand over through global memory inside the wavefront: a barrier (one wavefront: the wait for its own stores) between them. */
+__global__ void __launch_bounds__(64) k_reset_masked(const DModel* __restrict__ m, DState st, DBuffers bf, ResetPlan rp, unsigned fetch_mask, unsigned apply_mask,
+                                                     const int* __restrict__ art_dof0, const int* __restrict__ art_ndof) {
+  const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= m->N || !rp.mask[e]) return;
-  fetch_env(m, st, bf, fetch_mask, art_dof0, art_ndof, e);
+  fetch_env<64>(m, st, bf, fetch_mask, art_dof0, art_ndof, e, lane);
+  __syncthreads();
   const int ep = rp.episode[e];
   const float* img = rp.image + ((size_t)e * rp.slots + (size_t)(ep % rp.slots)) * rp.nent;
-  for (int t = 0; t < rp.nent; ++t) {
+  for (int t = lane; t < rp.nent; t += 64) {
     const int code = rp.ent[t], which = code >> 24, word = code & 0xFFFFFF;
     float* base;
     if (which == 0) base = bf.buf[MSK_BUF_RIGID_BODY_DATA] + (size_t)e * m->nb * 13;
@@ -671,9 +685,13 @@ __global__ void __launch_bounds__(256) k_reset_masked(const DModel* __restrict__
     }
     base[word] = img[t];
   }
-  apply_env(m, st, bf, apply_mask, art_dof0, art_ndof, e);
-  rp.episode[e] = ep + 1;
-  if (rp.elapsed) rp.elapsed[e] = 0;
+  __syncthreads();
+  apply_env<64>(m, st, bf, apply_mask, art_dof0, art_ndof, e, lane);
+  __syncthreads();   /* (every lane has read the counter) */
+  if (lane == 0) {
+    rp.episode[e] = ep + 1;
+    if (rp.elapsed) rp.elapsed[e] = 0;
+  }
 }
 
 __global__ void __launch_bounds__(256) k_fetch(const DModel* __restrict__ m, DState st, DBuffers bf, unsigned mask, const int* __restrict__ art_dof0,

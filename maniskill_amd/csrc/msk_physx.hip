@@ -592,6 +592,12 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
     m.depth[i] = (b->kind == MSK_BODY_LINK && b->parent >= 0) ? m.depth[b->parent] + 1 : 0;
     if (m.depth[i] > m.maxdepth) m.maxdepth = m.depth[i];
     if (b->kind == MSK_BODY_LINK && b->dof >= 0) m.dof_body[b->dof] = i;
+    /* the body's path from its root (entry 0) down to itself (entry depth[i]): what the velocity sums of the forward pass walk */
+    for (int k = 0; k < MSK_MAX_BODIES; ++k) m.path[i][k] = (unsigned char)i;
+    if (m.depth[i] > 0) {
+      for (int k = 0; k < m.depth[i]; ++k) m.path[i][k] = m.path[b->parent][k];
+      m.path[i][m.depth[i]] = (unsigned char)i;
+    }
   }
   {
     int o = 0;
@@ -839,7 +845,7 @@ MSK_API int msk_reset_masked(msk_ctx* c, const uint8_t* mask, const float* image
   rp.image = image; rp.ent = ent; rp.nent = nent; rp.slots = slots; rp.mask = mask; rp.episode = episode; rp.elapsed = elapsed;
   const unsigned fetch_mask = MSK_FETCH_RIGID_DATA | MSK_FETCH_ART_QPOS | MSK_FETCH_ART_QVEL | MSK_FETCH_ART_QACC | MSK_FETCH_ART_TARGETS;
   const unsigned apply_mask = MSK_APPLY_RIGID_DATA | MSK_APPLY_ART_ROOT_POSE | MSK_APPLY_ART_QPOS | MSK_APPLY_ART_QVEL | MSK_APPLY_ART_QF | MSK_APPLY_ART_TARGET_QPOS | MSK_APPLY_ART_TARGET_QVEL;
-  hipLaunchKernelGGL(k_reset_masked, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->bufs, rp, fetch_mask, apply_mask,
+  hipLaunchKernelGGL(k_reset_masked, dim3(N), dim3(64), 0, (hipStream_t)stream, c->d_model, c->st, c->bufs, rp, fetch_mask, apply_mask,
                      c->d_art_dof0, c->d_art_ndof);
   HIP_TRY(hipGetLastError());
   c->kin_dirty = true;   /* joint positions of the named envs changed: their link frames follow at the next fetch / observe */

@@ -106,14 +106,19 @@ typedef struct {
 } orc_scratch;
 
 /* ---- 1. kinematics ---------------------------------------------------------------- */
+/* Link frames down the tree.  What a link hands to its children is the composed frame U = U_parent * L with the rotation AS COMPOSED (not normalised), L = Xp * J(q) *
+ * XcInv being the joint-local transform with a normalised rotation: one pose product per tree level is all that depends on the parent (the HIP kernels run the levels
+ * one after the other; L, the normalisation of the published frame, the joint axis and the velocity sums are per-body work beside that chain).  The published frame
+ * is (U.p, normalised U.q); |U.q| stays within a few ulp of 1 (a product of unit quaternions), so the un-normalised rotation costs nothing measurable.
+ * Velocities: V = V_parent + S qd, acc = acc_parent + V_parent x (S qd), added for every link (S = 0, qd = 0 where the joint is fixed). */
 static void kinematics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
+  pose U[MSK_MAX_BODIES];
   for (int i = 0; i < c->nb; ++i) {
     const orc_body* b = &c->bodies[i];
     s->S[i] = sv6_zero();
     s->V[i] = sv6_zero();
+    U[i] = e->bpose[i];
     if (b->kind == MSK_BODY_LINK && b->parent >= 0) {
-      pose Tj = pose_mul(e->bpose[b->parent], b->Xp);
-      v3 axis = quat_rotate(Tj.q, v3_make(1, 0, 0));
       pose Jq;
       Jq.p = v3_make(0, 0, 0);
       Jq.q = quat_make(1, 0, 0, 0);
@@ -121,17 +126,26 @@ static void kinematics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
         float sn, cs;
         orc_sincos(0.5f * e->q[b->dof], &sn, &cs);
         Jq.q = quat_make(cs, sn, 0, 0);
+      } else if (b->jtype == MSK_JOINT_PRISMATIC) {
+        Jq.p = v3_make(e->q[b->dof], 0, 0);
+      }
+      pose L = pose_mul(pose_mul(b->Xp, Jq), b->XcInv);
+      L.q = quat_normalize(L.q);
+      U[i] = pose_mul(U[b->parent], L);
+      pose T;
+      T.p = U[i].p;
+      T.q = quat_normalize(U[i].q);
+      e->bpose[i] = T;
+      /* joint frame and axis from the parent's PUBLISHED frame */
+      const pose Tj = pose_mul(e->bpose[b->parent], b->Xp);
+      const v3 axis = quat_rotate(Tj.q, v3_make(1, 0, 0));
+      if (b->jtype == MSK_JOINT_REVOLUTE) {
         s->S[i].a = axis;
         s->S[i].l = v3_cross(Tj.p, axis);
       } else if (b->jtype == MSK_JOINT_PRISMATIC) {
-        Jq.p = v3_make(e->q[b->dof], 0, 0);
         s->S[i].l = axis;
       }
-      pose T = pose_mul(pose_mul(Tj, Jq), b->XcInv);
-      T.q = quat_normalize(T.q);
-      e->bpose[i] = T;
-      s->V[i] = s->V[b->parent];
-      if (b->dof >= 0) s->V[i] = sv6_madd(s->V[i], s->S[i], e->qd[b->dof]);
+      s->V[i] = sv6_madd(s->V[b->parent], s->S[i], b->dof >= 0 ? e->qd[b->dof] : 0.0f);
     }
     m33 R = quat_to_m33(e->bpose[i].q);
     s->comw[i] = v3_add(e->bpose[i].p, m33_mulv(&R, b->com));
@@ -215,11 +229,9 @@ static void dynamics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
         acc[i].l = v3_cross(v3_make(qr[0], qr[1], qr[2]), v3_make(qr[3], qr[4], qr[5]));
       }
     } else {
-      acc[i] = acc[b->parent];
-      if (b->dof >= 0) {
-        sv6 sq = {v3_scale(s->S[i].a, e->qd[b->dof]), v3_scale(s->S[i].l, e->qd[b->dof])};
-        acc[i] = sv6_add(acc[i], sv6_crossm(s->V[b->parent], sq));
-      }
+      const float qdi = b->dof >= 0 ? e->qd[b->dof] : 0.0f;      /* (every link adds its term: kinematics()) */
+      const sv6 sq = {v3_scale(s->S[i].a, qdi), v3_scale(s->S[i].l, qdi)};
+      acc[i] = sv6_add(acc[b->parent], sv6_crossm(s->V[b->parent], sq));
     }
     sv6 Iv = sinertia_mul(&Isp[i], s->V[i]);
     f[i] = sv6_add(sinertia_mul(&Isp[i], acc[i]), sv6_crossf(s->V[i], Iv));

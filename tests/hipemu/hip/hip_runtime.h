@@ -54,6 +54,8 @@ extern thread_local dim3 blockDim, gridDim;
 struct float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r = {x, y, z, w}; return r; }
 struct alignas(8) short4 { short x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r = {x, y, z, w}; return r; }
 static inline short4 make_short4(short x, short y, short z, short w) { short4 r = {x, y, z, w}; return r; }
