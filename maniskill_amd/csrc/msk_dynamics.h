@@ -33,13 +33,14 @@ MSK_DEV void dyn_sync() {
 
 /* dynamic LDS carve (floats) for a template with nb bodies */
 struct DynLds {
-  int pose, S, V, acc, Ic, M, L, vec, total;
+  int pose, S, V, acc, meta, Ic, M, L, vec, total;
   __host__ __device__ DynLds(int nb, int md) {
     int o = 0;
     pose = o; o += nb * 8;
     S = o; o += nb * 6;
     V = o; o += nb * 6;
     acc = o; o += nb * 6;            /* acc on the way down, f on the way back */
+    meta = o; o += nb * 2;           /* per body: its joint's dof, its root_dof (int bits): what the CRBA rows ask of their ancestors */
     Ic = o; o += nb * 10;
     M = o; o += md * (md + 1);
     L = o; o += md * (md + 1);
@@ -179,21 +180,31 @@ MSK_DEV pose forward_pass(const DModel* m, float* E, float* lds, const DynLds& l
     lds_put_sv6(lds + ly.S + i * 6, S);
   }
   dyn_sync();
-  /* ---- V = V_root + sum over the path of S qd, in path order ---- */
-  if (child_link) {
-    V = lds_sv6(lds + ly.V + (pk.x & 0xffu) * 6);
-    for (int d0 = 0; d0 < mydepth; d0 += 16) {   /* (trees deeper than 15: the next sixteen path entries) */
-      if (d0 > 0) pk = *(const uint4*)(m->path[i] + d0);
-      const unsigned w4[4] = {pk.x, pk.y, pk.z, pk.w};
+  /* ---- V = V_root + sum over the path of S qd, in path order ----
+   * The first 15 steps in chunks of four without branches inside a chunk (a step past the body's own depth reads the body's own entry -- the table's filler --
+   * and is dropped by a select), so that a chunk's 28 LDS reads are in flight together; deeper trees go on one step at a time. */
+  const uint4 pk0 = pk;
+  auto path_walk = [&](auto step) {
+    const unsigned w4[4] = {pk0.x, pk0.y, pk0.z, pk0.w};
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int d = d0 + k;
-        if (d >= 1 && d <= mydepth) {
-          const int a = (int)((w4[k >> 2] >> ((k & 3) * 8)) & 0xffu);
-          V = sv6_madd(V, lds_sv6(lds + ly.S + a * 6), lds[ly.pose + a * 8 + 7]);
+    for (int c = 0; c < 4; ++c) {
+      if (4 * c + 1 <= maxdepth) {
+#pragma unroll
+        for (int u = 1; u <= 4; ++u) {
+          const int d = 4 * c + u;
+          if (d <= 15) step((int)((w4[d >> 2] >> ((d & 3) * 8)) & 0xffu), d <= mydepth);
         }
       }
     }
+    for (int d = 16; d <= mydepth; ++d) step((int)m->path[i][d], true);
+  };
+  if (child_link) {
+    V = lds_sv6(lds + ly.V + (pk0.x & 0xffu) * 6);
+    path_walk([&](const int a, const bool on) {
+      const sv6 Vn = sv6_madd(V, lds_sv6(lds + ly.S + a * 6), lds[ly.pose + a * 8 + 7]);
+      V.a.x = on ? Vn.a.x : V.a.x; V.a.y = on ? Vn.a.y : V.a.y; V.a.z = on ? Vn.a.z : V.a.z;
+      V.l.x = on ? Vn.l.x : V.l.x; V.l.y = on ? Vn.l.y : V.l.y; V.l.z = on ? Vn.l.z : V.l.z;
+    });
     lds_put_sv6(lds + ly.V + i * 6, V);
   }
   if (WITH_ACC) {
@@ -207,20 +218,12 @@ MSK_DEV pose forward_pass(const DModel* m, float* E, float* lds, const DynLds& l
     }
     dyn_sync();
     if (child_link) {
-      pk = *(const uint4*)(m->path[i]);
-      A = lds_sv6(lds + ly.acc + (pk.x & 0xffu) * 6);
-      for (int d0 = 0; d0 < mydepth; d0 += 16) {
-        if (d0 > 0) pk = *(const uint4*)(m->path[i] + d0);
-        const unsigned w4[4] = {pk.x, pk.y, pk.z, pk.w};
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const int d = d0 + k;
-          if (d >= 1 && d <= mydepth) {
-            const int a = (int)((w4[k >> 2] >> ((k & 3) * 8)) & 0xffu);
-            A = sv6_add(A, lds_sv6(cx + a * 6));
-          }
-        }
-      }
+      A = lds_sv6(lds + ly.acc + (pk0.x & 0xffu) * 6);
+      path_walk([&](const int a, const bool on) {
+        const sv6 An = sv6_add(A, lds_sv6(cx + a * 6));
+        A.a.x = on ? An.a.x : A.a.x; A.a.y = on ? An.a.y : A.a.y; A.a.z = on ? An.a.z : A.a.z;
+        A.l.x = on ? An.l.x : A.l.x; A.l.y = on ? An.l.y : A.l.y; A.l.z = on ? An.l.z : A.l.z;
+      });
     }
     dyn_sync();   /* (everybody has read the cross terms: the RNEA phase may write its inertias there) */
   }
@@ -317,6 +320,12 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
   const pose T = forward_pass<true, true>(m, E, lds, ly, i, has, &S, &V, &acc);
   const DBody* b = &m->bodies[has ? i : 0];
   const bool link = has && b->kind == MSK_BODY_LINK;
+  const uint4 pk = (link && b->parent >= 0) ? *(const uint4*)(m->path[i]) : make_uint4(0, 0, 0, 0);   /* root, ancestors at depth 1 .. 15: the CRBA rows (phase 4) */
+  if (has) {
+    int* meta = (int*)(lds + ly.meta);
+    meta[i * 2] = b->kind == MSK_BODY_LINK ? b->dof : -1;
+    meta[i * 2 + 1] = b->kind == MSK_BODY_LINK ? b->root_dof : -1;
+  }
   v3 comw = v3_make(0, 0, 0);
   m33 R;
   sinertia Ic;
@@ -427,23 +436,41 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
 #endif
     const sv6 F = sinertia_mul(&Ic, S);
     Lm[di * LD + di] = sv6_dot(S, F) + b->armature;
-    int j = b->parent;
-    while (j >= 0) {
-      const DBody* bj = &m->bodies[j];
-      if (bj->dof >= 0) {
+    /* the row's entries with its ancestors' joints (the entries are disjoint: any order).  Trees of depth <= 15: the ancestors are the bytes of the body's path
+     * (DModel::path, already in registers) and what is asked of an ancestor -- its dof, its root_dof -- is in LDS: no walk up the parent pointers, whose every
+     * hop was a dependent load from the template (~10 k cycles of this phase on a 12-deep arm) */
+    auto with_ancestor = [&](const int j, const int dofj, const int rootj) {
+      if (dofj >= 0) {
         const float v = sv6_dot(lds_sv6(lds + ly.S + j * 6), F);
-        Lm[di * LD + bj->dof] = v;
-        Lm[bj->dof * LD + di] = v;
+        Lm[di * LD + dofj] = v;
+        Lm[dofj * LD + di] = v;
       }
-      if (bj->root_dof >= 0) { /* coupling with the floating root's six unit motions */
+      if (rootj >= 0) { /* coupling with the floating root's six unit motions */
         float Fc[6];
         const float* pj = lds + ly.pose + j * 8;
         const m33 Rj = quat_to_m33(quat_make(pj[3], pj[4], pj[5], pj[6]));
-        root_project(F, v3_add(v3_make(pj[0], pj[1], pj[2]), m33_mulv(&Rj, bj->com)), Fc);
+        root_project(F, v3_add(v3_make(pj[0], pj[1], pj[2]), m33_mulv(&Rj, m->bodies[j].com)), Fc);
 #pragma unroll
-        for (int a = 0; a < 6; ++a) { Lm[di * LD + bj->root_dof + a] = Fc[a]; Lm[(bj->root_dof + a) * LD + di] = Fc[a]; }
+        for (int a = 0; a < 6; ++a) { Lm[di * LD + rootj + a] = Fc[a]; Lm[(rootj + a) * LD + di] = Fc[a]; }
       }
-      j = bj->parent;
+    };
+    if (maxdepth <= 15) {
+      const unsigned w4[4] = {pk.x, pk.y, pk.z, pk.w};
+      const int* meta = (const int*)(lds + ly.meta);
+#pragma unroll
+      for (int d = 0; d < 15; ++d) {
+        if (d < mydepth) {
+          const int j = (int)((w4[d >> 2] >> ((d & 3) * 8)) & 0xffu);
+          with_ancestor(j, meta[j * 2], meta[j * 2 + 1]);
+        }
+      }
+    } else {
+      int j = b->parent;
+      while (j >= 0) {
+        const DBody* bj = &m->bodies[j];
+        with_ancestor(j, bj->dof, bj->root_dof);
+        j = bj->parent;
+      }
     }
     float* sc = Senv + di * 8;   /* motion subspace column of coordinate di, for the row assembly */
     sc[0] = S.a.x; sc[1] = S.a.y; sc[2] = S.a.z; sc[3] = S.l.x; sc[4] = S.l.y; sc[5] = S.l.z;
@@ -538,57 +565,45 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
       }
       vec[DV_RHS * MD + i] = rhs;
     }
-    /* Cholesky A = L L^T, lane i owns row i; column j is finished at step j */
-    float Lrow[MD];
-#pragma unroll
-    for (int k = 0; k < MD; ++k) Lrow[k] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < MD; ++j) {
-      if (j < nd) {
-        float sum = 0.0f;
-        if (rowlane && i >= j) {
-          sum = Arow[j];
-#pragma unroll
-          for (int k = 0; k < j; ++k) sum = fmaf(-Lrow[k], Ll[j * LD + k], sum);
-          if (i == j) {
-            Lrow[j] = sqrtf(sum);
-            Ll[j * LD + j] = Lrow[j];
-          }
-        }
-        dyn_sync();
-        if (rowlane && i > j) {
-          Lrow[j] = sum / Ll[j * LD + j];
-          Ll[i * LD + j] = Lrow[j];
-        }
-        dyn_sync();
-      }
-    }
-    /* triangular solves: lane c < nd -> column c of A^-1, lane VFL -> vfree = A^-1 rhs (VFL = MD, or the wavefront's last lane in the
-     * 64-row form: nd <= 63 leaves it free) */
-    constexpr int VFL = (MD < LPE) ? MD : LPE - 1;
-    const bool col = i < nd, vf = i == VFL;
+    /* The 16-row form (two envs per wavefront, an env's rows in ONE DPP row of 16 lanes): L stays in the row lanes' registers and an entry of another row is
+     * a row_newbcast of that lane's register -- no LDS image of L, no hand-off barriers, no loads inside the factorisation and the substitutions (they were
+     * one ds_read per multiply-add and two barriers per column).  Same operations in the same order as the LDS form below: the same bits.  The unconstrained
+     * velocity is solved by lane 15 of the row (nd <= 15 in this form), whose right-hand side is the row lanes' own `rhs`.  Every lane runs along (a DPP
+     * source lane must be active); only the lanes with a result store. */
 #ifdef MSK_VP_GUARD
-    /* the guard's two right-hand sides (M qd and -dt bias_vp) ride along as two more columns where the half-wave has lanes to spare (every form but the
-     * 64-row one, which solves them in a phase of its own below) */
-    constexpr bool GUARD_RIDES = (MD < LPE) && (MD + 2 < LPE);
-    const bool g0 = GUARD_RIDES && i == VFL + 1, g1 = GUARD_RIDES && i == VFL + 2;
+    constexpr bool DPP_ROWS = false;   /* (the guard's two extra right-hand sides ride on lanes of the LDS form) */
 #else
-    constexpr bool g0 = false, g1 = false;
+    constexpr bool DPP_ROWS = (LPE == 32 && MD == 16);
 #endif
-    float y[MD], x[MD];
-    if (col || vf || g0 || g1) {
+    if constexpr (DPP_ROWS) {
+      float Lrow[MD];
+#pragma unroll
+      for (int k = 0; k < MD; ++k) { Lrow[k] = 0.0f; if (!rowlane) Arow[k] = 0.0f; }
+      if (!rowlane) rhs = 0.0f;
+#pragma unroll
+      for (int j = 0; j < MD; ++j) {
+        if (j < nd) {
+          float sum = Arow[j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) sum = fmaf(-Lrow[k], group_bcast<16>(Lrow[k], j), sum);
+          const float dj = sqrtf(sum);                      /* (meant for lane j) */
+          const float djj = group_bcast<16>(dj, j);
+          const float below = sum / djj;
+          Lrow[j] = (i == j) ? dj : ((i > j) ? below : 0.0f);
+        }
+      }
+      constexpr int VFL = 15;
+      const bool col = i < nd, vf = i == VFL;
+      float y[MD], x[MD];
 #pragma unroll
       for (int r = 0; r < MD; ++r) {
         y[r] = 0.0f;
         if (r < nd) {
-          float sum = vf ? vec[DV_RHS * MD + r] : ((r == i) ? 1.0f : 0.0f);
-#ifdef MSK_VP_GUARD
-          if (g0) sum = vec[DV_R0 * MD + r];
-          if (g1) sum = -(dt * vec[DV_BVP * MD + r]);
-#endif
+          const float rr = group_bcast<16>(rhs, r);
+          float sum = vf ? rr : ((r == i) ? 1.0f : 0.0f);
 #pragma unroll
-          for (int k = 0; k < r; ++k) sum = fmaf(-Ll[r * LD + k], y[k], sum);
-          y[r] = sum / Ll[r * LD + r];
+          for (int k = 0; k < r; ++k) sum = fmaf(-group_bcast<16>(Lrow[k], r), y[k], sum);
+          y[r] = sum / group_bcast<16>(Lrow[r], r);
         }
       }
 #pragma unroll
@@ -598,24 +613,99 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
           float sum = y[r];
 #pragma unroll
           for (int k = r + 1; k < MD; ++k)
-            if (k < nd) sum = fmaf(-Ll[k * LD + r], x[k], sum);
-          x[r] = sum / Ll[r * LD + r];
+            if (k < nd) sum = fmaf(-group_bcast<16>(Lrow[r], k), x[k], sum);
+          x[r] = sum / group_bcast<16>(Lrow[r], r);
         }
       }
       if (vf) {
 #pragma unroll
         for (int r = 0; r < MD; ++r)
           if (r < nd) { vec[DV_VF * MD + r] = x[r]; if (live) vfenv[r] = x[r]; }
-#ifdef MSK_VP_GUARD
-      } else if (g0 || g1) {
-#pragma unroll
-        for (int r = 0; r < MD; ++r)
-          if (r < nd) vec[(g0 ? DV_V0 : DV_VB) * MD + r] = x[r];      /* (the vb row holds dv until the guard adds v0) */
-#endif
-      } else if (live) {
+      } else if (col && live) {
 #pragma unroll
         for (int r = 0; r < MD; ++r)
           if (r < nd) Wenv[r * G + i] = x[r];
+      }
+    } else {
+      /* Cholesky A = L L^T, lane i owns row i; column j is finished at step j */
+      float Lrow[MD];
+  #pragma unroll
+      for (int k = 0; k < MD; ++k) Lrow[k] = 0.0f;
+  #pragma unroll
+      for (int j = 0; j < MD; ++j) {
+        if (j < nd) {
+          float sum = 0.0f;
+          if (rowlane && i >= j) {
+            sum = Arow[j];
+  #pragma unroll
+            for (int k = 0; k < j; ++k) sum = fmaf(-Lrow[k], Ll[j * LD + k], sum);
+            if (i == j) {
+              Lrow[j] = sqrtf(sum);
+              Ll[j * LD + j] = Lrow[j];
+            }
+          }
+          dyn_sync();
+          if (rowlane && i > j) {
+            Lrow[j] = sum / Ll[j * LD + j];
+            Ll[i * LD + j] = Lrow[j];
+          }
+          dyn_sync();
+        }
+      }
+      /* triangular solves: lane c < nd -> column c of A^-1, lane VFL -> vfree = A^-1 rhs (VFL = MD, or the wavefront's last lane in the
+       * 64-row form: nd <= 63 leaves it free) */
+      constexpr int VFL = (MD < LPE) ? MD : LPE - 1;
+      const bool col = i < nd, vf = i == VFL;
+  #ifdef MSK_VP_GUARD
+      /* the guard's two right-hand sides (M qd and -dt bias_vp) ride along as two more columns where the half-wave has lanes to spare (every form but the
+       * 64-row one, which solves them in a phase of its own below) */
+      constexpr bool GUARD_RIDES = (MD < LPE) && (MD + 2 < LPE);
+      const bool g0 = GUARD_RIDES && i == VFL + 1, g1 = GUARD_RIDES && i == VFL + 2;
+  #else
+      constexpr bool g0 = false, g1 = false;
+  #endif
+      float y[MD], x[MD];
+      if (col || vf || g0 || g1) {
+  #pragma unroll
+        for (int r = 0; r < MD; ++r) {
+          y[r] = 0.0f;
+          if (r < nd) {
+            float sum = vf ? vec[DV_RHS * MD + r] : ((r == i) ? 1.0f : 0.0f);
+  #ifdef MSK_VP_GUARD
+            if (g0) sum = vec[DV_R0 * MD + r];
+            if (g1) sum = -(dt * vec[DV_BVP * MD + r]);
+  #endif
+  #pragma unroll
+            for (int k = 0; k < r; ++k) sum = fmaf(-Ll[r * LD + k], y[k], sum);
+            y[r] = sum / Ll[r * LD + r];
+          }
+        }
+  #pragma unroll
+        for (int r = MD - 1; r >= 0; --r) {
+          x[r] = 0.0f;
+          if (r < nd) {
+            float sum = y[r];
+  #pragma unroll
+            for (int k = r + 1; k < MD; ++k)
+              if (k < nd) sum = fmaf(-Ll[k * LD + r], x[k], sum);
+            x[r] = sum / Ll[r * LD + r];
+          }
+        }
+        if (vf) {
+  #pragma unroll
+          for (int r = 0; r < MD; ++r)
+            if (r < nd) { vec[DV_VF * MD + r] = x[r]; if (live) vfenv[r] = x[r]; }
+  #ifdef MSK_VP_GUARD
+        } else if (g0 || g1) {
+  #pragma unroll
+          for (int r = 0; r < MD; ++r)
+            if (r < nd) vec[(g0 ? DV_V0 : DV_VB) * MD + r] = x[r];      /* (the vb row holds dv until the guard adds v0) */
+  #endif
+        } else if (live) {
+  #pragma unroll
+          for (int r = 0; r < MD; ++r)
+            if (r < nd) Wenv[r * G + i] = x[r];
+        }
       }
     }
     dyn_sync();

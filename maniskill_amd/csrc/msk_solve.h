@@ -756,6 +756,9 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
       else if (GL == 16) rowbits = (unsigned)((wrows >> (blk * 3)) & 7ull);
       else rowbits = (__ballot((vm0 >> blk) & 1ull) ? 1u : 0u) | (__ballot((vm1 >> blk) & 1ull) ? 2u : 0u) | (__ballot((vm2 >> blk) & 1ull) ? 4u : 0u);
       /* new impulse = clamp(lam * keep - (J.v + bias) / (A_rr + cfm)); a row that does not exist has rinv = lam = 0 -> stays 0 */
+      /* the normal impulse that sizes the friction cone of rows 1, 2: the owner's is the value row 0 just took; the other lanes' candidates for this block are
+       * never broadcast, so their bounds may come from anything finite -- their own candidate: no select on the way to the clamp */
+      float l0 = lam[0];
       if (rowbits & 1u) {
         float lo = lo0, hi = hi0;
         if (!decltype(all_rows_tag)::value && ((tblocks >> blk) & 1ull)) { /* a torsional block: its cone is sized by its point's normal impulse */
@@ -765,17 +768,18 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
         const float nl = clampf(fmaf(-av[0], rinv[0], fmaf(lam[0], keep0, -t0)), lo, hi);
         const float dl = group_bcast<GL>(nl - lam[0], blk);
         if (owner) lam[0] = nl;
+        l0 = nl;
         av[0] = fmaf(Ac[0], dl, av[0]); av[1] = fmaf(Ac[1], dl, av[1]); av[2] = fmaf(Ac[2], dl, av[2]);
       }
       if (rowbits & 2u) {
-        const float hi = fmaf(flim, lam[0], hi_c), lo = fmaf(-flim, lam[0], 0.0f);
+        const float hi = fmaf(flim, l0, hi_c), lo = fmaf(-flim, l0, 0.0f);
         const float nl = clampf(fmaf(-av[1], rinv[1], lam[1] - t1), lo, hi);
         const float dl = group_bcast<GL>(nl - lam[1], blk);
         if (owner) lam[1] = nl;
         av[0] = fmaf(Ac[3], dl, av[0]); av[1] = fmaf(Ac[4], dl, av[1]); av[2] = fmaf(Ac[5], dl, av[2]);
       }
       if (rowbits & 4u) {
-        const float hi = fmaf(flim, lam[0], hi_c), lo = fmaf(-flim, lam[0], 0.0f);
+        const float hi = fmaf(flim, l0, hi_c), lo = fmaf(-flim, l0, 0.0f);
         const float nl = clampf(fmaf(-av[2], rinv[2], lam[2] - t2), lo, hi);
         const float dl = group_bcast<GL>(nl - lam[2], blk);
         if (owner) lam[2] = nl;
