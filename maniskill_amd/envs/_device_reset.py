@@ -45,6 +45,12 @@ class DeviceReset:
     """``env.reset_mask(done)`` for a fused env of maniskill_amd.envs (PickCubeEnv and its subclasses, PushTEnv)."""
 
     def __init__(self, env, slots: int = 64, threaded=None):
+        # every tensor of this object and of the shadow env is an ordinary tensor, whatever mode the caller is in: the refill thread is not in the caller's
+        # torch.inference_mode() (thread-local), and an inference tensor refuses in-place writes from outside it
+        with torch.inference_mode(False):
+            self._init(env, slots, threaded)
+
+    def _init(self, env, slots, threaded):
         if getattr(env, "control_mode", "pd_joint_delta_pos").startswith("pd_ee") and "target" in env.control_mode:
             raise RuntimeError("controllers that keep an end-effector target re-read the link frames inside reset(): host-side resets only")
         if not hasattr(env.px.lib, "reset_masked"):

@@ -1025,6 +1025,20 @@ class DeviceConstants(torch.overrides.TorchFunctionMode):
             out = _selection_arithmetic(func, args, kwargs)
             if out is not None:
                 return out
+        elif func in (torch.Tensor.__getitem__, torch.Tensor.__setitem__) and len(args) >= 2 and type(args[0]) is torch.Tensor and isinstance(args[1], tuple) and len(args[1]) >= 2 \
+                and isinstance(args[1][0], torch.Tensor) and _leading_mask(args[0], args[1][0]) and all(isinstance(r, (slice, int)) and not isinstance(r, bool) for r in args[1][1:]) \
+                and args[1][0].ndim + len(args[1]) - 1 <= args[0].ndim:
+            # x[mask, :2] / x[mask, 2] (drawing/draw.py:178-183): the mask over the leading dimensions of the VIEW x[:, :2] -- the forms below, on that view
+            mask, rest = args[1][0], args[1][1:]
+            view = torch.Tensor.__getitem__(args[0], (slice(None),) * mask.ndim + rest)
+            if func is torch.Tensor.__getitem__:
+                return self.__torch_function__(func, types, (view, mask))
+            v = args[2]
+            if isinstance(v, (int, float)) and not isinstance(v, bool):
+                view.masked_fill_(_broadcast_mask(mask, view), v)      # x[mask, 2] = number
+                self.rewritten += 1
+                return None
+            return self.__torch_function__(func, types, (view, mask, v))
         elif func is torch.Tensor.__getitem__ and len(args) == 2 and type(args[0]) is torch.Tensor and args[0].dtype == torch.bool and self._is_all_true(args[0]) \
                 and isinstance(args[1], torch.Tensor) and args[1].dtype in (torch.int64, torch.int32):
             out = func(*args)                                       # reset_mask[scene_idxs]: a gather of an all-true mask is all true
@@ -1111,12 +1125,15 @@ def graph_safety(step_fn, action, settle: int = 2) -> dict:
         def __init__(self, earlier):
             super().__init__()
             self.earlier, self.made, self.keep, self.sync, self.flow, self.host = earlier, set(), [], [], [], []
+            self.hostmade = set()      # storages made from host data WITHOUT a device (torch.tensor([body.mass ...]), structs/base.py:274): they live on the host on any backend
 
         def __torch_dispatch__(self, func, types, args=(), kwargs=None):
             name = str(func)
             ins = tensors([args, kwargs or {}], [])
             if any(t in name for t in ("_local_scalar_dense", "nonzero", "masked_select", "aten.equal", "is_nonzero", "unique")):
-                self.sync.append(f"{name} @ {site()}")
+                # (.item() of host data the step has just made -- `link.mass[0].item()`, control/hopper.py:196 -- reads host memory: no wait for the device)
+                if not ("_local_scalar_dense" in name and ins and ins[0].untyped_storage().data_ptr() in self.hostmade):
+                    self.sync.append(f"{name} @ {site()}")
             if any(t in name for t in ("aten.index.Tensor", "aten.index_put")) and len(args) > 1 and isinstance(args[1], (list, tuple)):      # (index_select / index_add / ...: args[1] is a dim)
                 for ix in args[1]:
                     if isinstance(ix, torch.Tensor) and ix.dtype in (torch.bool, torch.uint8):
@@ -1128,6 +1145,8 @@ def graph_safety(step_fn, action, settle: int = 2) -> dict:
                 # host data turned into a tensor inside the step: with `device=` in the same call DeviceConstants serves it (then this op does not appear);
                 # `torch.tensor(array).to(device)` makes the host tensor here and uploads in `.to`, which DeviceConstants serves on a GPU: listed, not counted
                 self.host.append(f"host data of shape {tuple(ins[0].shape)} @ {site()}")
+                if ins[0].device.type == "cpu":
+                    self.hostmade.add(ins[0].untyped_storage().data_ptr())
             for t in ins:
                 if t.untyped_storage().nbytes() > 0 and t.untyped_storage().data_ptr() in self.earlier:      # (empty tensors share the null address)
                     self.flow.append(f"{name} reads a tensor the previous step allocated @ {site()}")
@@ -1290,21 +1309,69 @@ class Accelerated:
             consts = self.constants = DeviceConstants(base.device)
             consts.all_true = lambda: base.scene._reset_mask      # all True outside a reset (sapien_env.py:880-882, 975: a fresh all-true tensor ends every reset)
 
+            # State a task hands from one step to the next by REBINDING an attribute to a tensor the step has just made (`self.prev_unit_vector = new_unit_vector`,
+            # dexterity/rotate_single_object_in_hand.py:261; the Draw tasks' dot bookkeeping): a replayed graph would re-read the memory that was current when it was
+            # captured.  For the attributes found to do that (below), the value moves into ONE persistent tensor at the end of every step -- a copy the capture records
+            # -- and the attribute is bound to it: same values at every step, the state now lives where a replay finds it.  A reset may rebind the attribute too
+            # (ibid. :209): the buffer adopts the value before the next step runs.
+            persist = self.persist = {}
+
+            def adopt():
+                for name, buf in persist.items():
+                    cur = base.__dict__.get(name)
+                    if cur is not buf and isinstance(cur, torch.Tensor) and cur.shape == buf.shape and cur.dtype == buf.dtype and cur.device == buf.device:
+                        buf.copy_(cur)
+                        base.__dict__[name] = buf
+
             def captured_step(a):
                 with consts:
-                    return cls_step(base, a)
+                    out = cls_step(base, a)
+                    if persist:
+                        adopt()
+                    return out
+
+            def host_state():
+                return {k: x for k, x in base.__dict__.items() if type(x) in (int, float, bool, str)}
+
+            def verdict_with_persistent_state():
+                zero = torch.zeros(base.num_envs, control.adim, device=base.device)
+                h0 = host_state()
+                v = _verdict(captured_step, zero)
+                self.throwaway_steps += 4
+                # the third hazard, as silent as the second: state the step keeps in PYTHON (the Draw tasks count their dots in `self.draw_step` and pick this step's
+                # actor with it, drawing/draw.py:185-188) -- a replay runs no Python, it would move the dot the capture saw for ever
+                moved = sorted(k for k, x in host_state().items() if k in h0 and h0[k] != x)
+                if moved:
+                    v = dict(v, flow=v["flow"] + [f"the step changes the Python attribute `{k}` ({h0[k]!r} -> {base.__dict__[k]!r}): a replay would not" for k in moved])
+                    return v
+                if v["flow"] and not v["sync"]:
+                    before = {k: t for k, t in base.__dict__.items() if isinstance(t, torch.Tensor)}
+                    captured_step(zero)
+                    self.throwaway_steps += 1
+                    for k, t in list(base.__dict__.items()):
+                        o = before.get(k)
+                        if isinstance(t, torch.Tensor) and o is not None and t is not o and t.shape == o.shape and t.dtype == o.dtype and t.device == o.device \
+                                and not t.requires_grad:
+                            persist[k] = base.__dict__[k] = t.clone()
+                    if persist:
+                        v2 = _verdict(captured_step, zero)
+                        self.throwaway_steps += 4
+                        if not v2["flow"] and not v2["sync"]:
+                            return v2
+                        for k in list(persist):      # (it did not help: the env stays as the task wrote it)
+                            base.__dict__[k] = persist.pop(k).clone()
+                return v
             if graph == "dry":          # everything the capture would run, eagerly at every step (no GPU needed: the CPU suite checks the results and the op stream)
                 self.level = "graph-dry"
                 self._step_fn = captured_step
+                verdict_with_persistent_state()      # (state attributes move into persistent tensors here too: the eager run checks what a capture would run)
             elif graph == "watch":      # the verdict alone (any device): what graph=True decides on
                 self.level = "graph-dry"
                 self._step_fn = captured_step
-                self.safety = _verdict(captured_step, torch.zeros(base.num_envs, control.adim, device=base.device))
-                self.throwaway_steps += 4
+                self.safety = verdict_with_persistent_state()
             else:
                 if graph is True:       # (graph="force" captures without asking)
-                    verdict = self.safety = _verdict(captured_step, torch.zeros(base.num_envs, control.adim, device=base.device))
-                    self.throwaway_steps += 4
+                    verdict = self.safety = verdict_with_persistent_state()
                     if verdict["sync"] or verdict["flow"]:
                         what = "; ".join((verdict["sync"] + verdict["flow"])[:3])
                         raise Unsupported(f"the task's own step is not safe to replay as a graph: {what}" + (" (a capture refuses the first kind; the second kind -- state "
@@ -1327,7 +1394,11 @@ class Accelerated:
                             culprit = f"(probe failed: {str(pe).splitlines()[0][:120]})"
                     raise Unsupported(f"the task's step cannot be captured as a HIP graph: {str(e).splitlines()[0][:300]}" + (f" -- first offender: {culprit}" if culprit else "")) from e
                 self.level = "graph"
-                self._step_fn = lambda action: g(action) if action is not None else cls_step(base, None)
+                def replayed(action):
+                    if persist:
+                        adopt()      # (a reset in between may have rebound a state attribute)
+                    return g(action) if action is not None else cls_step(base, None)
+                self._step_fn = replayed
             base.step = self._step
         base._msk_accelerated = self
 

@@ -135,3 +135,27 @@ def test_a_mask_that_is_not_all_true_takes_the_ordinary_path():
     with c:
         out = x[reset_mask] * 1.0
     assert out.tolist() == [0.0, 2.0]
+
+
+def test_a_mask_with_a_slice_behind_it_is_the_mask_over_the_view():
+    """drawing/draw.py:178-183: ``pos[touching, :2] = tcp[touching, :2]; pos[touching, 2] = height`` -- no nonzero(), the same values"""
+    m = torch.tensor([True, False, True, False])
+    tcp = torch.arange(12.0).view(4, 3)
+    pos, epos = torch.zeros(4, 3), torch.zeros(4, 3)
+    epos[m, :2] = tcp[m, :2]
+    epos[m, 2] = 0.5
+    c = _mode()
+    with c:
+        pos[m, :2] = tcp[m, :2]
+        pos[m, 2] = 0.5
+    assert torch.equal(pos, epos) and c.rewritten == 2
+
+    def step(a):
+        with c:
+            out = torch.zeros(4, 3)
+            out[m, :2] = tcp[m, :2] * 2.0
+            out[:, 0] += a
+            out[m, 2] = 0.5
+            return out
+    v = graph_safety(step, torch.zeros(()))
+    assert v["sync"] == [] and v["flow"] == [], v

@@ -84,6 +84,20 @@ def test_refills_by_the_worker_thread_leave_the_same_rows(oracle_factory):
         dr.join()
 
 
+def test_an_env_built_under_inference_mode_refills_from_the_worker_thread(oracle_factory):
+    """bench.py steps under torch.inference_mode(); the refill thread is outside it (the mode is thread-local) and must still be allowed to write the shadow's
+    buffers and the ring: round 6's first default bench run died on `Inplace update to inference tensor outside InferenceMode`"""
+    with torch.inference_mode():
+        env = PickCubeEnv(num_envs=6, px_factory=oracle_factory, fused=False, device_reset=True)
+        env.device_reset_slots, env.device_reset_threaded = 4, True
+        env.reset(seed=3)
+        for _ in range(10):
+            env.step(torch.zeros(6, 8))
+            env.reset_mask(torch.tensor([True, False, True, False, True, True]))
+        env._dev_reset.join()
+        assert env._dev_reset.threaded and env._dev_reset.refreshes >= 3
+
+
 @pytest.mark.parametrize("cls,adim", [(PickCubeEnv, 8), (PushTEnv, 7)])
 def test_reset_from_a_mask_on_the_emulated_hip_library_with_the_fused_task_kernels(emu_factory, cls, adim):
     host, dev = _pair(cls, 5, emu_factory, fused=True)

@@ -150,11 +150,23 @@ def test_push_t_with_its_intersection_renderer_patched_has_the_references_bits(b
 
 
 @needs_ref
-def test_a_task_that_carries_state_through_fresh_tensors_is_not_captured(built):
-    """accelerate(graph=True) watches the task's own step first (fused_step.graph_safety): RotateSingleObjectInHand keeps its previous unit vector in a tensor
-    it allocates anew every step -- that captures without an error and replays stale, so it is refused (round 4 kept a list of task ids instead)"""
+def test_a_task_that_keeps_state_in_python_is_not_captured(built):
+    """accelerate(graph=True) watches the task's own step first (fused_step.graph_safety + the env's Python scalars before and after): the Draw tasks count their
+    dots in ``self.draw_step`` and move THIS step's dot actor (drawing/draw.py:185-188) -- a replay runs no Python and would move the captured dot for ever.  That
+    captures without an error, so it is refused by the watch (round 4 kept a list of task ids instead)"""
     res = _run("oracle", "not_verified")
-    assert res["raised"] and res["untouched"] and "not safe to replay" in res["message"] and "previous step allocated" in res["message"], res
+    assert res["raised"] and res["untouched"] and "not safe to replay" in res["message"] and "Python attribute `draw_step`" in res["message"], res
+
+
+@needs_ref
+def test_state_handed_over_through_fresh_tensors_moves_into_persistent_ones(built):
+    """RotateSingleObjectInHand rebinds ``self.prev_unit_vector`` to a tensor each step makes (rotate_single_object_in_hand.py:261): replayed as it is, a graph
+    would re-read the capture's memory (round 5 refused the task for it).  The capture path copies such an attribute's value into ONE persistent tensor at the end
+    of the step and binds the attribute to it: the watch then finds nothing, and the same path run eagerly has the reference's bits, through a partial reset"""
+    res = _run("oracle", "graph_safe:RotateSingleObjectInHandLevel0-v1", 3)
+    assert res["sync"] == [] and res["flow"] == [], res
+    res = _run("oracle", "dry:RotateSingleObjectInHandLevel0-v1", 2, 12)
+    assert res["worst_state"] == 0.0 and res["worst_obs"] == 0.0 and res["worst_rew"] == 0.0 and res["flags"], res
 
 
 @needs_ref
@@ -177,8 +189,10 @@ def test_masked_assignments_of_the_reference_become_selects(built, env_id, idiom
 
 @needs_ref
 def test_the_watch_does_flag_a_step_that_cannot_be_captured(built):
-    res = _run("oracle", "graph_safe:MS-HopperHop-v1", 3)           # a scalar read back from the device
+    res = _run("oracle", "graph_safe:SO100GraspCube-v1", 3)         # a row picked per env through a 2-D one-hot mask (rotation_conversions.py:161-163): nonzero()
     assert res["sync"], res
+    res = _run("oracle", "graph_safe:MS-HopperHop-v1", 3)           # `link.mass[0].item()` (control/hopper.py:196): host data the step has just made, read on the host
+    assert res["sync"] == [] and res["flow"] == [], res
 
 
 @pytest.mark.gpu

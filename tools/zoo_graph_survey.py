@@ -25,9 +25,9 @@ def main():
     ok = 0
     with ThreadPoolExecutor(workers) as ex:
         for eid, res in ex.map(one, ids):
-            clean = res.get("level") not in ("error", None) and not res.get("sync") and not res.get("flow") and not res.get("host_data")
+            clean = res.get("level") not in ("error", None) and not res.get("sync") and not res.get("flow")      # (host_data: served from the device, listed only)
             ok += clean
-            why = "" if clean else "  <- " + (res.get("error") or "; ".join(f"{k}: {str(res.get(k))[:160]}" for k in ("sync", "flow", "host_data") if res.get(k)))
+            why = "" if clean else "  <- " + (res.get("error") or "; ".join(f"{k}: {str(res.get(k))[:160]}" for k in ("sync", "flow") if res.get(k)))
             print(f"{eid:36s} {'graph' if clean else 'eager':5s} level {res.get('level')}{why}", flush=True)
     print(f"{ok} of {len(ids)} tasks pass the watch")
 
