@@ -225,6 +225,39 @@ int msk_fetch(msk_ctx* ctx, uint32_t mask, void* stream);
 enum { MSK_RESET_RIGID_BODY_DATA = 0, MSK_RESET_ART_QPOS = 1, MSK_RESET_ART_QVEL = 2, MSK_RESET_ART_TARGET_QPOS = 3, MSK_RESET_ART_TARGET_QVEL = 4 };
 int msk_reset_masked(msk_ctx* ctx, const uint8_t* mask, const float* image, int slots, const int32_t* ent, int nent, int32_t* episode, int32_t* elapsed,
                      void* stream);
+/* ---- the vector wrapper's episode book-keeping in one launch --------------------------------------------------------------
+ * ManiSkillVectorEnv.step (vector/wrappers/gymnasium.py:127-176) keeps, per sub-scene, the running return and the success_once / fail_once flags of the
+ * episode in progress, reports them (`infos["episode"]`: return, episode_len, reward = return / episode_len, success_once, fail_once, with
+ * ignore_terminations also success_at_end / fail_at_end), clears the termination flags when it ignores terminations, forms `dones = terminated | truncated`,
+ * asks `dones.any()` and clears the book of the envs it then resets (:104-125) -- a dozen elementwise torch launches per step.  msk_episode_book_step is that
+ * sequence for all sub-scenes: same values, same order (accumulate, report, clear).  Plain device pointers, [n] each; the u8 inputs come with the number of bytes
+ * between consecutive envs (the fused task kernels hand their flags out as columns of one [n][6] block).  Asynchronous on `stream`. */
+typedef struct msk_episode_book {
+  const float* reward;             /* the step's reward */
+  const int32_t* elapsed;          /* BaseEnv.elapsed_steps after the step (episode_len) */
+  const uint8_t* success;          /* infos["success"], NULL when the task reports none */
+  const uint8_t* fail;             /* infos["fail"], NULL when the task reports none */
+  const uint8_t* terminated;
+  const uint8_t* truncated;
+  int32_t success_stride, fail_stride, terminated_stride, truncated_stride;   /* bytes between consecutive envs (1 = a plain [n] array) */
+  int32_t record_metrics;          /* 0: only out_terminated / out_done / any_done are produced */
+  int32_t ignore_terminations;     /* out_terminated = 0 everywhere; success / fail of the step are reported as *_at_end */
+  int32_t clear_done;              /* auto_reset: the book of the envs that are done is cleared after it was reported (the reset that follows does that) */
+  float* returns;                  /* state, read-modify-write (record_metrics) */
+  uint8_t* success_once;
+  uint8_t* fail_once;
+  float* out_return;               /* outputs (record_metrics; the *_once / *_at_end ones only where the input exists) */
+  int32_t* out_episode_len;
+  float* out_reward;
+  uint8_t* out_success_once;
+  uint8_t* out_fail_once;
+  uint8_t* out_success_at_end;
+  uint8_t* out_fail_at_end;
+  uint8_t* out_terminated;         /* always */
+  uint8_t* out_done;               /* always: out_terminated | truncated */
+  int32_t* any_done;               /* always, [1]: 1 when some env is done, else 0 (`dones.any()`: the one value the host reads back) */
+} msk_episode_book;
+int msk_episode_book_step(msk_ctx* ctx, int n, const msk_episode_book* book, void* stream);
 /* PhysxGpuSystem.gpu_update_articulation_kinematics (sapien_env.py:959,1304) */
 int msk_update_kinematics(msk_ctx* ctx, void* stream);
 /* PhysxGpuSystem.step() (envs/scene.py:379-380): one substep of `timestep` for all envs. */

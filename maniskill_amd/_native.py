@@ -31,7 +31,7 @@ EXPORTS = [
     "fetch", "update_kinematics", "step", "step_n", "get_step_parts", "set_step_parts", "query_create_pairs", "query_create_bodies", "query_buffer", "query_run",
     "get_sizes", "get_contacts", "get_env_contact_counts", "timing_enable", "timing_read",
     "set_solver_classes", "get_solver_class_counts", "declare_env_box", "declare_env_mass", "set_env_boxes", "set_env_masses",
-    "bind_buffers", "batch", "set_articulation_floating", "warnings", "set_locked_axes", "reset_masked",
+    "bind_buffers", "batch", "set_articulation_floating", "warnings", "set_locked_axes", "reset_masked", "episode_book_step",
 ]
 # include/msk_render.h — camera pipeline (both libraries)
 RENDER_EXPORTS = ["render_add_mesh", "render_set_base_color", "render_set_texture", "render_bind_env_box", "render_set_lights", "render_set_local_lights", "render_finalize", "camera_create", "camera_buffer",
@@ -43,6 +43,16 @@ BATCH_STEP, BATCH_APPLY, BATCH_FETCH, BATCH_UPDATE_KINEMATICS = 0, 1, 2, 3
 K_DYNAMICS, K_COLLIDE, K_SOLVE, K_SUBSTEP = 0, 1, 2, 3
 # the kernels' names as rocprofv3 prints them (template arguments dropped); "substep" = begin of the first to end of the last
 KERNEL_SLOTS = {"k_dynamics": K_DYNAMICS, "k_narrowphase": K_COLLIDE, "k_csolve": K_SOLVE, "substep": K_SUBSTEP}
+
+
+class MskEpisodeBook(C.Structure):
+    """include/msk_physx.h: msk_episode_book"""
+    _fields_ = [("reward", C.c_void_p), ("elapsed", C.c_void_p), ("success", C.c_void_p), ("fail", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p),
+                ("success_stride", C.c_int32), ("fail_stride", C.c_int32), ("terminated_stride", C.c_int32), ("truncated_stride", C.c_int32),
+                ("record_metrics", C.c_int32), ("ignore_terminations", C.c_int32), ("clear_done", C.c_int32),
+                ("returns", C.c_void_p), ("success_once", C.c_void_p), ("fail_once", C.c_void_p),
+                ("out_return", C.c_void_p), ("out_episode_len", C.c_void_p), ("out_reward", C.c_void_p), ("out_success_once", C.c_void_p), ("out_fail_once", C.c_void_p),
+                ("out_success_at_end", C.c_void_p), ("out_fail_at_end", C.c_void_p), ("out_terminated", C.c_void_p), ("out_done", C.c_void_p), ("any_done", C.c_void_p)]
 
 
 class MskConfig(C.Structure):
@@ -133,6 +143,7 @@ class NativeLib:
             "fetch": (i32, [vp, u32, vp]),
             "update_kinematics": (i32, [vp, vp]),
             "reset_masked": (i32, [vp, vp, vp, i32, vp, i32, vp, vp, vp]),
+            "episode_book_step": (i32, [vp, i32, C.POINTER(MskEpisodeBook), vp]),
             "step": (i32, [vp, vp]),
             "step_n": (i32, [vp, i32, vp]),
             "get_step_parts": (i32, [vp]),

@@ -694,6 +694,45 @@ __global__ void __launch_bounds__(64) k_reset_masked(const DModel* __restrict__ 
   }
 }
 
+/* msk_episode_book_step (include/msk_physx.h): one workgroup walks all sub-scenes (a dozen bytes per env: 4096 envs are four rounds of its 1024 lanes), so that
+ * `dones.any()` needs no second launch and no atomics: the lanes' verdicts meet in LDS and lane 0 stores the flag */
+__global__ void __launch_bounds__(1024) k_episode_book(const int n, const msk_episode_book b) {
+  __shared__ int s_any;
+  if (threadIdx.x == 0) s_any = 0;
+  __syncthreads();
+  bool mine = false;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    const bool term = !b.ignore_terminations && b.terminated[(size_t)e * b.terminated_stride] != 0;
+    const bool done = term || b.truncated[(size_t)e * b.truncated_stride] != 0;
+    if (b.record_metrics) {
+      const float ret = b.returns[e] + b.reward[e];
+      const int len = b.elapsed[e];
+      b.out_return[e] = ret;
+      b.out_episode_len[e] = len;
+      b.out_reward[e] = ret / (float)len;
+      b.returns[e] = (done && b.clear_done) ? 0.0f : ret;
+      if (b.success) {
+        const bool now = b.success[(size_t)e * b.success_stride] != 0, once = b.success_once[e] != 0 || now;
+        b.out_success_once[e] = once ? 1 : 0;
+        if (b.ignore_terminations) b.out_success_at_end[e] = now ? 1 : 0;
+        b.success_once[e] = (once && !(done && b.clear_done)) ? 1 : 0;
+      }
+      if (b.fail) {
+        const bool now = b.fail[(size_t)e * b.fail_stride] != 0, once = b.fail_once[e] != 0 || now;
+        b.out_fail_once[e] = once ? 1 : 0;
+        if (b.ignore_terminations) b.out_fail_at_end[e] = now ? 1 : 0;
+        b.fail_once[e] = (once && !(done && b.clear_done)) ? 1 : 0;
+      }
+    }
+    b.out_terminated[e] = term ? 1 : 0;
+    b.out_done[e] = done ? 1 : 0;
+    mine = mine || done;
+  }
+  if (mine) s_any = 1;      /* (every writer stores the same value) */
+  __syncthreads();
+  if (threadIdx.x == 0) b.any_done[0] = s_any;
+}
+
 __global__ void __launch_bounds__(256) k_fetch(const DModel* __restrict__ m, DState st, DBuffers bf, unsigned mask, const int* __restrict__ art_dof0,
                                                const int* __restrict__ art_ndof) {
   fetch_block(m, st, bf, mask, art_dof0, art_ndof, blockIdx.x);

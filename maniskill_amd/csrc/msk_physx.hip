@@ -852,6 +852,23 @@ MSK_API int msk_reset_masked(msk_ctx* c, const uint8_t* mask, const float* image
   return MSK_OK;
 }
 
+static const char* episode_book_problem(int n, const msk_episode_book* b) {
+  if (n < 1 || !b) return "episode_book_step: no sub-scenes or no book";
+  if (!b->terminated || !b->truncated || !b->out_terminated || !b->out_done || !b->any_done) return "episode_book_step: terminated / truncated / out_terminated / out_done / any_done are required";
+  if (b->record_metrics) {
+    if (!b->reward || !b->elapsed || !b->returns || !b->out_return || !b->out_episode_len || !b->out_reward) return "episode_book_step: record_metrics needs reward, elapsed, returns and their outputs";
+    if (b->success && (!b->success_once || !b->out_success_once || (b->ignore_terminations && !b->out_success_at_end))) return "episode_book_step: success without its state / outputs";
+    if (b->fail && (!b->fail_once || !b->out_fail_once || (b->ignore_terminations && !b->out_fail_at_end))) return "episode_book_step: fail without its state / outputs";
+  }
+  return nullptr;
+}
+MSK_API int msk_episode_book_step(msk_ctx* c, int n, const msk_episode_book* book, void* stream) {
+  if (const char* why = episode_book_problem(n, book)) return fail(c, MSK_ERR_INVALID, why);
+  hipLaunchKernelGGL(k_episode_book, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, *book);
+  HIP_TRY(hipGetLastError());
+  return MSK_OK;
+}
+
 MSK_API int msk_update_kinematics(msk_ctx* c, void* stream) {
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "update_kinematics before finalize");
   const int N = c->model.N;

@@ -533,6 +533,46 @@ ORC_EXPORT int orc_reset_masked(orc_ctx* c, const uint8_t* mask, const float* im
   return MSK_OK;
 }
 
+/* msk_episode_book_step (include/msk_physx.h): ManiSkillVectorEnv.step's episode book-keeping (vector/wrappers/gymnasium.py:127-176) -- returns += rew,
+ * success_once |= success, the report (clones of the book before it is cleared), terminations cleared when they are ignored, dones = terminated | truncated,
+ * dones.any(), and the book of the envs about to be reset cleared (:104-125) -- env by env */
+ORC_EXPORT int orc_episode_book_step(orc_ctx* c, int n, const msk_episode_book* b, void* stream) {
+  (void)stream;
+  if (n < 1 || !b || !b->terminated || !b->truncated || !b->out_terminated || !b->out_done || !b->any_done) return fail(c, MSK_ERR_INVALID, "episode_book_step: missing argument");
+  if (b->record_metrics && (!b->reward || !b->elapsed || !b->returns || !b->out_return || !b->out_episode_len || !b->out_reward))
+    return fail(c, MSK_ERR_INVALID, "episode_book_step: record_metrics needs reward, elapsed, returns and their outputs");
+  int any = 0;
+  for (int e = 0; e < n; ++e) {
+    const int term = !b->ignore_terminations && b->terminated[(size_t)e * b->terminated_stride] != 0;
+    const int done = term || b->truncated[(size_t)e * b->truncated_stride] != 0;
+    if (b->record_metrics) {
+      const float ret = b->returns[e] + b->reward[e];
+      const int len = b->elapsed[e];
+      b->out_return[e] = ret;
+      b->out_episode_len[e] = len;
+      b->out_reward[e] = ret / (float)len;
+      b->returns[e] = (done && b->clear_done) ? 0.0f : ret;
+      if (b->success) {
+        const int now = b->success[(size_t)e * b->success_stride] != 0, once = b->success_once[e] != 0 || now;
+        b->out_success_once[e] = (uint8_t)once;
+        if (b->ignore_terminations) b->out_success_at_end[e] = (uint8_t)now;
+        b->success_once[e] = (uint8_t)(once && !(done && b->clear_done));
+      }
+      if (b->fail) {
+        const int now = b->fail[(size_t)e * b->fail_stride] != 0, once = b->fail_once[e] != 0 || now;
+        b->out_fail_once[e] = (uint8_t)once;
+        if (b->ignore_terminations) b->out_fail_at_end[e] = (uint8_t)now;
+        b->fail_once[e] = (uint8_t)(once && !(done && b->clear_done));
+      }
+    }
+    b->out_terminated[e] = (uint8_t)term;
+    b->out_done[e] = (uint8_t)done;
+    any |= done;
+  }
+  b->any_done[0] = any;
+  return MSK_OK;
+}
+
 ORC_EXPORT int orc_step(orc_ctx* c, void* stream) {
   (void)stream;
   if (!c->finalized) return fail(c, MSK_ERR_INVALID, "step before finalize");
