@@ -39,9 +39,10 @@ struct DynLds {
     pose = o; o += nb * 8;
     S = o; o += nb * 6;
     V = o; o += nb * 6;
-    acc = o; o += nb * 6;            /* acc on the way down, f on the way back */
+    acc = o; o += nb * 6;            /* acc on the way down (16-byte aligned: nb * 20 floats precede it) ... */
+    Ic = o; o += nb * 10;            /* ... the cross terms of the forward pass; on the way back the two regions together are ONE array of 16 floats per body, */
+                                     /* [f (6) | composite inertia (10)]: a link's record is four ds_read_b128 for whoever sums it up (phase 3) */
     meta = o; o += nb * 2;           /* per body: its joint's dof, its root_dof (int bits): what the CRBA rows ask of their ancestors */
-    Ic = o; o += nb * 10;
     M = o; o += md * (md + 1);
     L = o; o += md * (md + 1);
 #ifdef MSK_VP_GUARD
@@ -50,7 +51,7 @@ struct DynLds {
 #else
     vec = o; o += 8 * md;            /* qd | bias | Kd | Dd | fconst | err | rhs | vfree */
 #endif
-    total = o;
+    total = (o + 3) & ~3;            /* (every env's carve starts 16-byte aligned) */
   }
 #ifdef MSK_VP_GUARD
   int fvp;
@@ -314,6 +315,12 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
 #else
 #define DPHASE()
 #endif
+  /* what phase 5 wants from the template and the env record, asked for now: two dependent loads (the joint's link, its force limit) that would otherwise be
+   * waited for behind the barriers of phases 1-4 (the compiler does not move loads across them) */
+  const bool rowlane = i < nd;   /* surplus half-waves compute along (LDS only) and store nothing */
+  const float fmax_i = rowlane ? m->bodies[m->dof_body[i]].fmax : 0.0f;
+  const float qdt_i = rowlane ? E[m->lay.qdt + i] : 0.0f;
+  const float qf_i = rowlane ? E[m->lay.qf + i] : 0.0f;
   DPHASE();
   /* ---- 1. frames, velocities, bias accelerations (down the tree) ------------------------------------ */
   sv6 S, V, acc;
@@ -380,52 +387,42 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
       }
     }
   }
-  dyn_sync(); /* everybody has read its parent's acc: the slot now carries f */
-  float* fi = lds + ly.acc + (has ? i : 0) * 6;
-  float* Ii = lds + ly.Ic + (has ? i : 0) * 10;
+  dyn_sync(); /* everybody has read its parent's acc: the two regions now carry [f | inertia] records of 16 floats */
+  float* rec = lds + ly.acc + (has ? i : 0) * 16;
   if (link) {
-    lds_put_sv6(fi, f);
+    *(float4*)(rec) = make_float4(f.a.x, f.a.y, f.a.z, f.l.x);
+    *(float4*)(rec + 4) = make_float4(f.l.y, f.l.z, Ic.m, Ic.h.x);
+    *(float4*)(rec + 8) = make_float4(Ic.h.y, Ic.h.z, Ic.I[0], Ic.I[1]);
+    *(float4*)(rec + 12) = make_float4(Ic.I[2], Ic.I[3], Ic.I[4], Ic.I[5]);
 #ifdef MSK_VP_GUARD
     lds_put_sv6(lds + ly.fvp + i * 6, fvp);
 #endif
-    Ii[0] = Ic.m; Ii[1] = Ic.h.x; Ii[2] = Ic.h.y; Ii[3] = Ic.h.z;
-    for (int k = 0; k < 6; ++k) Ii[4 + k] = Ic.I[k];
   }
+  const int mydepth = has ? m->depth[i] : -1;
+  const int maxdepth = m->maxdepth;
+  /* the link's descendants (descending body index, DModel::desc): the first sixteen in registers, fetched before the barrier */
+  const int ndesc = link ? (int)m->ndesc[i] : 0;
+  uint4 dk = ndesc > 0 ? *(const uint4*)(m->desc[i]) : make_uint4(0, 0, 0, 0);
   dyn_sync();
   DPHASE();
-  /* ---- 3. back up the tree: parents absorb their children (descending body index, as the oracle) --------- */
-  const int mydepth = has ? m->depth[i] : -1;
-  /* child lists fetched before the level loop (the first four children in registers) */
-  const int maxdepth = m->maxdepth;
-  const int c0 = link ? m->child_off[i] : 0, c1 = link ? m->child_off[i + 1] : 0;
-  int chs[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) if (c0 + k < c1) chs[k] = m->child_idx[c0 + k];
-  for (int d = maxdepth; d >= 1; --d) {
-    if (link && mydepth == d - 1) {
-      if (c1 > c0) {
-        for (int cc = c0; cc < c1; ++cc) {
-          const int kc = cc - c0;
-          const int ch = (kc == 0) ? chs[0] : ((kc == 1) ? chs[1] : ((kc == 2) ? chs[2] : ((kc == 3) ? chs[3] : m->child_idx[cc])));
-          f = sv6_add(f, lds_sv6(lds + ly.acc + ch * 6));
+  /* ---- 3. back up the tree: every link adds its descendants' OWN records to its own, one by one in descending body index (oracle: dynamics(), the
+   * backward pass) -- lane-parallel, no hand-off between levels: the loop is as long as the root's list, a step is four wide LDS reads and sixteen adds ---- */
+  for (int k = 0; k < ndesc; ++k) {
+    if (k >= 16 && (k & 15) == 0) dk = *(const uint4*)(m->desc[i] + k);
+    const unsigned w = (k & 8) ? ((k & 4) ? dk.w : dk.z) : ((k & 4) ? dk.y : dk.x);
+    const int d = (int)((w >> ((k & 3) * 8)) & 0xffu);
+    const float* rd = lds + ly.acc + d * 16;
+    const float4 r0 = *(const float4*)(rd), r1 = *(const float4*)(rd + 4), r2 = *(const float4*)(rd + 8), r3 = *(const float4*)(rd + 12);
+    f.a = v3_add(f.a, v3_make(r0.x, r0.y, r0.z));
+    f.l = v3_add(f.l, v3_make(r0.w, r1.x, r1.y));
+    Ic.m += r1.z;
+    Ic.h = v3_add(Ic.h, v3_make(r1.w, r2.x, r2.y));
+    Ic.I[0] += r2.z; Ic.I[1] += r2.w; Ic.I[2] += r3.x; Ic.I[3] += r3.y; Ic.I[4] += r3.z; Ic.I[5] += r3.w;
 #ifdef MSK_VP_GUARD
-          fvp = sv6_add(fvp, lds_sv6(lds + ly.fvp + ch * 6));
+    fvp = sv6_add(fvp, lds_sv6(lds + ly.fvp + d * 6));
 #endif
-          const float* Ic_c = lds + ly.Ic + ch * 10;
-          Ic.m += Ic_c[0];
-          Ic.h = v3_add(Ic.h, v3_make(Ic_c[1], Ic_c[2], Ic_c[3]));
-          for (int k = 0; k < 6; ++k) Ic.I[k] += Ic_c[4 + k];
-        }
-        lds_put_sv6(fi, f);
-#ifdef MSK_VP_GUARD
-        lds_put_sv6(lds + ly.fvp + i * 6, fvp);
-#endif
-        Ii[0] = Ic.m; Ii[1] = Ic.h.x; Ii[2] = Ic.h.y; Ii[3] = Ic.h.z;
-        for (int k = 0; k < 6; ++k) Ii[4 + k] = Ic.I[k];
-      }
-    }
-    dyn_sync();
   }
+  dyn_sync();
   DPHASE();
   /* ---- 4. bias torques and CRBA rows (lane = body with a dof) ------------------------------------------------ */
   if (link && b->dof >= 0) {
@@ -514,10 +511,6 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
   DPHASE();
   /* ---- 5. implicit PD: A = M + dt D + dt^2 K (+ tendons), Cholesky, solves; second pass without the drives whose predicted force
    * exceeds their limit: those become soft rows of the solver, clamped to +-fmax dt (st.drv_mask, st.drv; oracle: dynamics()) ---- */
-  const bool rowlane = i < nd;   /* surplus half-waves compute along (LDS only) and store nothing */
-  const float fmax_i = rowlane ? m->bodies[m->dof_body[i]].fmax : 0.0f;
-  const float qdt_i = rowlane ? E[m->lay.qdt + i] : 0.0f;
-  const float qf_i = rowlane ? E[m->lay.qf + i] : 0.0f;
   const float bias_i = rowlane ? vec[DV_BIAS * MD + i] : 0.0f;
   float Kd = rowlane ? vec[DV_KD * MD + i] : 0.0f, Dd = rowlane ? vec[DV_DD * MD + i] : 0.0f;
   float err = rowlane ? vec[DV_ERR * MD + i] : 0.0f;

@@ -68,6 +68,8 @@ struct DModel {
   /* tree tables for the wave-per-env dynamics (msk_dynamics.h) */
   int depth[MSK_MAX_BODIES];           /* links: distance to the root link; actors: 0            */
   int maxdepth;
+  alignas(16) unsigned char desc[MSK_MAX_BODIES][MSK_MAX_BODIES];   /* links: the link's descendants in DESCENDING body index (msk_dynamics.h phase 3) */
+  unsigned char ndesc[MSK_MAX_BODIES];
   alignas(16) unsigned char path[MSK_MAX_BODIES][MSK_MAX_BODIES];   /* links: [0] the root link, [d] the ancestor at depth d, [depth] the body itself (msk_dynamics.h forward_pass) */
   int child_off[MSK_MAX_BODIES + 1];   /* CSR of child links, each list in DESCENDING body index */
   int child_idx[MSK_MAX_BODIES];

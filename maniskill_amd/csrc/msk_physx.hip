@@ -599,6 +599,18 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
       m.path[i][m.depth[i]] = (unsigned char)i;
     }
   }
+  for (int i = 0; i < m.nb; ++i) { /* a link's descendants, in descending body index: what its lane sums up on the way back (the oracle's order) */
+    int k = 0;
+    memset(m.desc[i], 0, sizeof(m.desc[i]));
+    if (m.bodies[i].kind == MSK_BODY_LINK)
+      for (int d = m.nb - 1; d > i; --d) {
+        if (m.bodies[d].kind != MSK_BODY_LINK) continue;
+        int a = m.bodies[d].parent;
+        while (a > i) a = m.bodies[a].parent;
+        if (a == i) m.desc[i][k++] = (unsigned char)d;
+      }
+    m.ndesc[i] = (unsigned char)k;
+  }
   {
     int o = 0;
     for (int i = 0; i < m.nb; ++i) {

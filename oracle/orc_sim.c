@@ -250,19 +250,29 @@ static void dynamics(const orc_ctx* c, orc_env* e, orc_scratch* s) {
       }
     }
   }
-  /* backward pass: bias torques, composite inertias */
-  for (int i = c->nb - 1; i >= 0; --i) {
-    const orc_body* b = &c->bodies[i];
-    if (b->kind != MSK_BODY_LINK) continue;
-    if (b->dof >= 0) { bias[b->dof] = sv6_dot(s->S[i], f[i]); bias_vp[b->dof] = sv6_dot(s->S[i], fvp[i]); }
-    if (b->root_dof >= 0) { /* the accumulated wrench: force, moment about the root's centre of mass */
-      root_project(f[i], s->comw[i], bias + b->root_dof);
-      root_project(fvp[i], s->comw[i], bias_vp + b->root_dof);
-    }
-    if (b->parent >= 0) {
-      f[b->parent] = sv6_add(f[b->parent], f[i]);
-      fvp[b->parent] = sv6_add(fvp[b->parent], fvp[i]);
-      sinertia_acc(&Ic[b->parent], &Ic[i]);
+  /* backward pass: bias torques, composite inertias.  A link's accumulated wrench / composite inertia is its OWN term plus its descendants' own terms, added one by
+   * one in DESCENDING body index (a flat sum per link: every link can do its own, no hand-off from level to level -- the HIP kernel's lanes each walk their
+   * descendants' list; the nested form "parents absorb their children's sums" was a chain of tree-depth barriers there) */
+  {
+    sv6 fown[MSK_MAX_BODIES], fvpown[MSK_MAX_BODIES];
+    for (int i = 0; i < c->nb; ++i) { fown[i] = f[i]; fvpown[i] = fvp[i]; }   /* (Isp keeps the links' own inertias) */
+    for (int i = c->nb - 1; i >= 0; --i) {
+      const orc_body* b = &c->bodies[i];
+      if (b->kind != MSK_BODY_LINK) continue;
+      for (int d = c->nb - 1; d > i; --d) {
+        if (c->bodies[d].kind != MSK_BODY_LINK) continue;
+        int a = c->bodies[d].parent;
+        while (a > i) a = c->bodies[a].parent;      /* (a link's index is above its parent's) */
+        if (a != i) continue;
+        f[i] = sv6_add(f[i], fown[d]);
+        fvp[i] = sv6_add(fvp[i], fvpown[d]);
+        sinertia_acc(&Ic[i], &Isp[d]);
+      }
+      if (b->dof >= 0) { bias[b->dof] = sv6_dot(s->S[i], f[i]); bias_vp[b->dof] = sv6_dot(s->S[i], fvp[i]); }
+      if (b->root_dof >= 0) { /* the accumulated wrench: force, moment about the root's centre of mass */
+        root_project(f[i], s->comw[i], bias + b->root_dof);
+        root_project(fvp[i], s->comw[i], bias_vp + b->root_dof);
+      }
     }
   }
   /* CRBA */

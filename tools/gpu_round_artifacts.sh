@@ -1,9 +1,9 @@
 #!/bin/bash
-# Produces the round's measurement artefacts on the GPU box (gpurun_out/r04art/...): bench lines, rocprofv3 kernel stats, PMC passes.
+# Produces the round's measurement artefacts on the GPU box (gpurun_out/$ART_DIR, default r06art): bench lines, rocprofv3 kernel stats, PMC passes.
 #   bash tools/gpu_round_artifacts.sh [quick]        (quick: without the PMC passes and the secondary configs)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r04art
+O=$R/gpurun_out/${ART_DIR:-r06art}
 mkdir -p $O
 cd $R
 python bench.py > $O/bench_n1_default.json 2> $O/bench_n1_default.err
