@@ -876,8 +876,12 @@ def _selection_arithmetic(func, args, kwargs):
     srcs = []
     for a in args:
         if isinstance(a, _MaskedSelection):
-            if a._msk_mask is not mask or a._msk_src.shape != sels[0]._msk_src.shape:
+            if a._msk_mask is not mask:
                 return None
+            if a._msk_src.shape != sels[0]._msk_src.shape:      # x[m] / n[m].view(-1, 1) (sapien_utils.py:354): sources that broadcast behind the mask's dimensions
+                sa, sb = a._msk_src.shape, sels[0]._msk_src.shape
+                if len(sa) != len(sb) or sa[:mask.ndim] != sb[:mask.ndim] or any(p != q and 1 not in (p, q) for p, q in zip(sa[mask.ndim:], sb[mask.ndim:])):
+                    return None
             srcs.append(a._unchanged()._msk_src)
         elif isinstance(a, (int, float)) and not isinstance(a, bool):
             srcs.append(a)
@@ -914,6 +918,7 @@ class DeviceConstants(torch.overrides.TorchFunctionMode):
         self.masked = self.rewritten = self.syncs_skipped = 0      # y[mask] handed out unevaluated / masked assignments turned into selects / device waits skipped
         self._seen, self._nots = {}, {}
         self._depth, self._sync = 0, None
+        self._one_hot = {}      # id(tensor) -> (tensor, its version, idx, idx's version): results of F.one_hot(idx, C) and of `that > 0.5`
         # masks that are all True for the whole step, by construction: `scene._reset_mask` outside a reset (the reference indexes through it in every pose setter,
         # utils/structs/actor.py:389-391 `idx[reset_mask[scene_idxs]]`: a boolean index, i.e. nonzero() and a wait, for a selection that selects everything).
         # all_true(): the current mask object; a selection through it -- or through a gather of it -- is the whole source.  Checked once per mask object (a wait,
@@ -960,6 +965,16 @@ class DeviceConstants(torch.overrides.TorchFunctionMode):
             with torch._C.DisableTorchFunctionSubclass():
                 ok = self._true_ok[id(cur)] = (cur, cur._version, bool(cur.all()))
         return ok[2]
+
+    def _one_hot_index(self, x, index):
+        """idx when ``index`` is ``(F.one_hot(idx, C) > t, slice(None)...)`` over the two leading dimensions of x, else None"""
+        if not (isinstance(index, tuple) and len(index) >= 1 and isinstance(index[0], torch.Tensor) and index[0].dtype == torch.bool and index[0].ndim == 2
+                and all(isinstance(r, slice) and r == slice(None) for r in index[1:]) and x.ndim >= 2 and tuple(index[0].shape) == tuple(x.shape[:2])):
+            return None
+        rec = self._one_hot.get(id(index[0]))
+        if rec is None or rec[0] is not index[0] or rec[1] != index[0]._version or rec[2]._version != rec[3] or rec[2].shape[0] != x.shape[0]:
+            return None
+        return rec[2]
 
     @staticmethod
     def _site():
@@ -1014,6 +1029,33 @@ class DeviceConstants(torch.overrides.TorchFunctionMode):
         elif func in _SELECTION_UNARY and len(args) == 1 and not kwargs and isinstance(args[0], _MaskedSelection):
             with torch._C.DisableTorchFunctionSubclass():      # f(a[m]) == f(a)[m], element for element (what f makes of the unselected elements is never looked at)
                 return _MaskedSelection.make(_SELECTION_UNARY[func](args[0]._unchanged()._msk_src), args[0]._msk_mask)
+        elif func in (torch.Tensor.view, torch.Tensor.reshape, torch.Tensor.unsqueeze) and args and isinstance(args[0], _MaskedSelection) and not kwargs \
+                and args[0]._msk_src.ndim == args[0]._msk_mask.ndim and (tuple(args[1:]) in ((-1, 1), ((-1, 1),)) if func is not torch.Tensor.unsqueeze else tuple(args[1:]) == (-1,)):
+            with torch._C.DisableTorchFunctionSubclass():      # n[m].view(-1, 1) == n.unsqueeze(-1)[m]
+                return _MaskedSelection.make(args[0]._unchanged()._msk_src.unsqueeze(-1), args[0]._msk_mask)
+        elif func is torch.nn.functional.one_hot and args and isinstance(args[0], torch.Tensor) and args[0].ndim == 1:
+            ncls = kwargs.get("num_classes", args[1] if len(args) > 1 else -1)
+            if not isinstance(ncls, int) or ncls < 1:
+                return func(*args, **kwargs)                      # (the class count taken from the data: a read-back)
+            # F.one_hot(idx, C), without the range check that reads the data back on a host tensor (ATen skips it on a GPU): remembered, so that
+            # `x[one_hot > 0.5, :]` can be the gather it is
+            out = (args[0].unsqueeze(-1) == torch.arange(ncls, device=args[0].device)).to(torch.int64)
+            self._one_hot[id(out)] = (out, out._version, args[0], args[0]._version)
+            return out
+        elif func in (torch.Tensor.__gt__, torch.gt, torch.Tensor.gt) and len(args) == 2 and id(args[0]) in self._one_hot and isinstance(args[1], float) and 0.0 < args[1] < 1.0:
+            rec = self._one_hot[id(args[0])]
+            out = func(*args)
+            if rec[0] is args[0] and rec[1] == args[0]._version:
+                self._one_hot[id(out)] = (out, out._version, rec[2], rec[3])
+                if len(self._one_hot) > 64:
+                    self._one_hot = {id(out): self._one_hot[id(out)]}
+            return out
+        elif func is torch.Tensor.__getitem__ and len(args) == 2 and type(args[0]) is torch.Tensor and self._one_hot_index(args[0], args[1]) is not None:
+            # x[F.one_hot(idx, C) > 0.5, :] (rotation_conversions.py:161-163: the best-conditioned of four candidates per row): exactly one row of x[n] per n, in order
+            idx = self._one_hot_index(args[0], args[1])
+            self.masked += 1
+            x = args[0]
+            return torch.take_along_dim(x, idx.reshape((-1, 1) + (1,) * (x.ndim - 2)), dim=1).squeeze(1)
         elif func in _MASK_NOT and len(args) == 1 and not kwargs and type(args[0]) is torch.Tensor and args[0].dtype == torch.bool:
             # `x[~m] = f(y[~m])` evaluates ~m once per use (rotation_conversions.py:549-552): the uses have to be ONE mask to be recognised as one selection
             hit = self._nots.get(id(args[0]))
@@ -1070,6 +1112,10 @@ class DeviceConstants(torch.overrides.TorchFunctionMode):
                 return func(x, mask, v._real())
             if isinstance(v, torch.Tensor) and v.numel() == 1 and v.device == x.device and v.dtype == x.dtype:      # x[mask] = a one-element device tensor
                 x.copy_(torch.where(_broadcast_mask(mask, x), v.reshape(()), x))
+                self.rewritten += 1
+                return None
+            if isinstance(v, torch.Tensor) and mask.ndim < x.ndim and tuple(v.shape) == tuple(x.shape[mask.ndim:]) and v.device == x.device and v.dtype == x.dtype:
+                x.copy_(torch.where(_broadcast_mask(mask, x), v, x))      # x[mask] = one row for every selected row (sapien_utils.py:353)
                 self.rewritten += 1
                 return None
         elif func is torch.Tensor.__getitem__ and len(args) == 2 and isinstance(args[1], (list, tuple)):

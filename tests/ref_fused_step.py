@@ -63,7 +63,9 @@ def _compare(gym, eid, n, steps, kw, acc_kw, atol=0.0, history=0):
     # steps the physics once under them): the env that is compared against gets the same history
     for _ in range(getattr(acc, "throwaway_steps", 0) + history):
         a.unwrapped.step(torch.zeros(a.action_space.shape, device=dev))
+    torch.manual_seed(7)
     oa, _ = a.reset(seed=3)
+    torch.manual_seed(7)
     ob, _ = b.reset(seed=3)
     res = dict(level=acc.level, graph=acc.graph is not None, reset_equal=bool(torch.equal(_flat(oa), _flat(ob))), groups=len(getattr(a.unwrapped.scene.px, "_groups", [0])))
     g = torch.Generator().manual_seed(1)
@@ -75,13 +77,17 @@ def _compare(gym, eid, n, steps, kw, acc_kw, atol=0.0, history=0):
         if k % 7 == 3:
             act = act * 3                       # outside the box: clipped
         act = act.to(dev)
-        ra, rb = a.step(act), b.step(act)
+        torch.manual_seed(1000 + k)      # (tasks that draw from torch's global generator inside a step -- SO100GraspCube's camera mount -- draw the same in both envs)
+        ra = a.step(act)
+        torch.manual_seed(1000 + k)
+        rb = b.step(act)
         sa, sb = _state(a), _state(b)
         worst_state = max(worst_state, float((sa - sb).abs().max()))
         if len(trace) < 6 and float((sa - sb).abs().max()) > 0:      # where a mismatch starts: step, env, state column
             d = (sa - sb).abs()
             trace.append((k, int(d.max(dim=1).values.argmax()), int(d.max(dim=0).values.argmax()), float(d.max()), int((d.max(dim=1).values > 0).sum())))
-        worst_obs = max(worst_obs, float((_flat(ra[0]) - _flat(rb[0])).abs().max()))
+        if _flat(ra[0]).numel():      # (a camera task built with render_backend="none" has no observation to compare)
+            worst_obs = max(worst_obs, float((_flat(ra[0]) - _flat(rb[0])).abs().max()))
         assert ra[1].dtype == rb[1].dtype and type(ra[0]) is type(rb[0])
         worst_rew = max(worst_rew, float((ra[1].float() - rb[1].float()).abs().max()))
         flags = flags and bool(torch.equal(ra[2], rb[2])) and bool(torch.equal(ra[3], rb[3])) and bool(torch.equal(ra[4]["elapsed_steps"], rb[4]["elapsed_steps"]))
@@ -89,13 +95,18 @@ def _compare(gym, eid, n, steps, kw, acc_kw, atol=0.0, history=0):
             flags = flags and bool(torch.equal(ra[4]["success"], rb[4]["success"]))
     # a partial reset in the middle of the rollout, then on
     idx = torch.arange(0, n, 2, device=dev)
-    a.reset(seed=5, options=dict(env_idx=idx)); b.reset(seed=5, options=dict(env_idx=idx))
+    torch.manual_seed(8); a.reset(seed=5, options=dict(env_idx=idx))
+    torch.manual_seed(8); b.reset(seed=5, options=dict(env_idx=idx))
     for k in range(3):
         act = (2 * torch.rand(a.action_space.shape, generator=g) - 1).to(dev)
-        ra, rb = a.step(act), b.step(act)
-        worst_obs = max(worst_obs, float((_flat(ra[0]) - _flat(rb[0])).abs().max()))
+        torch.manual_seed(2000 + k)
+        ra = a.step(act)
+        torch.manual_seed(2000 + k)
+        rb = b.step(act)
+        if _flat(ra[0]).numel():
+            worst_obs = max(worst_obs, float((_flat(ra[0]) - _flat(rb[0])).abs().max()))
         worst_state = max(worst_state, float((_state(a) - _state(b)).abs().max()))
-    res.update(worst_obs=worst_obs, worst_rew=worst_rew, worst_state=worst_state, flags=flags, finite=bool(torch.isfinite(_flat(ra[0])).all()), mismatch_trace=trace)
+    res.update(worst_obs=worst_obs, worst_rew=worst_rew, worst_state=worst_state, flags=flags, finite=bool(torch.isfinite(_flat(ra[0])).all() and torch.isfinite(ra[1]).all()), mismatch_trace=trace)
     acc.restore()
     res["restored"] = "step" not in b.unwrapped.__dict__ and "_step_action" not in b.unwrapped.__dict__
     return res

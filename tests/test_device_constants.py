@@ -159,3 +159,40 @@ def test_a_mask_with_a_slice_behind_it_is_the_mask_over_the_view():
             return out
     v = graph_safety(step, torch.zeros(()))
     assert v["sync"] == [] and v["flow"] == [], v
+
+
+def test_a_row_picked_per_env_through_a_one_hot_mask_is_a_gather():
+    """rotation_conversions.py:161-163 (matrix_to_quaternion): ``cand[F.one_hot(q_abs.argmax(-1), 4) > 0.5, :]`` -- boolean indexing sized by data; here the gather"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    cand, q_abs = torch.rand(6, 4, 4, generator=g), torch.rand(6, 4, generator=g)
+    want = cand[F.one_hot(q_abs.argmax(dim=-1), num_classes=4) > 0.5, :].reshape(6, 4)
+    c = _mode()
+
+    def step(a):
+        with c:
+            return cand[F.one_hot(q_abs.argmax(dim=-1), num_classes=4) > 0.5, :].reshape(6, 4) + a
+    assert torch.equal(step(torch.zeros(())), want)
+    v = graph_safety(step, torch.zeros(()))
+    assert v["sync"] == [] and v["flow"] == [], v
+
+
+def test_normalising_the_rows_a_mask_names_needs_no_nonzero():
+    """sapien_utils.py:349-355 (look_at's normalize_tensor): ``x[zero] = torch.zeros(3); x[~zero] /= norm[~zero].view(-1, 1)``"""
+    x0 = torch.tensor([[3.0, 0.0, 4.0], [0.0, 0.0, 0.0], [0.0, 2.0, 0.0]])
+
+    def normalize(x):
+        norm = torch.linalg.norm(x, dim=-1)
+        zero = norm < 1e-6
+        x[zero] = torch.zeros(3)
+        x[~zero] /= norm[~zero].view(-1, 1)
+        return x
+    want = normalize(x0.clone())
+    c = _mode()
+
+    def step(a):
+        with c:
+            return normalize(x0.clone() + a)
+    assert torch.equal(step(torch.zeros(())), want)
+    v = graph_safety(step, torch.zeros(()))
+    assert v["sync"] == [] and v["flow"] == [], v

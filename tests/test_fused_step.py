@@ -170,6 +170,17 @@ def test_state_handed_over_through_fresh_tensors_moves_into_persistent_ones(buil
 
 
 @needs_ref
+def test_the_look_at_and_matrix_to_quaternion_idioms_become_selects_and_a_gather(built):
+    """SO100GraspCube-v1 re-aims its camera through sapien_utils.look_at (``x[zero] = torch.zeros(3); x[~zero] /= norm[~zero].view(-1, 1)``, :349-355) and
+    matrix_to_quaternion (``cand[F.one_hot(q_abs.argmax(-1), 4) > 0.5, :]``, rotation_conversions.py:161-163): boolean indexing sized by data in the reference,
+    selects and a gather under DeviceConstants -- the watch finds nothing, the eager run of the same path has the reference's bits (round 5 refused the task)"""
+    res = _run("oracle", "graph_safe:SO100GraspCube-v1", 3)
+    assert res["sync"] == [] and res["flow"] == [] and res["rewritten"] >= 8, res
+    res = _run("oracle", "dry:SO100GraspCube-v1", 2, 12)
+    assert res["worst_state"] == 0.0 and res["worst_rew"] == 0.0 and res["flags"] and res["finite"], res
+
+
+@needs_ref
 def test_host_data_that_changes_between_steps_cannot_be_baked_into_a_graph(built):
     res = _run("oracle", "changing_constant")
     assert res["raised"] and res["served"] == 4 and res["clones"] and res["equal"], res
@@ -189,7 +200,7 @@ def test_masked_assignments_of_the_reference_become_selects(built, env_id, idiom
 
 @needs_ref
 def test_the_watch_does_flag_a_step_that_cannot_be_captured(built):
-    res = _run("oracle", "graph_safe:SO100GraspCube-v1", 3)         # a row picked per env through a 2-D one-hot mask (rotation_conversions.py:161-163): nonzero()
+    res = _run("oracle", "graph_safe:DrawTriangle-v1", 3)           # `torch.all(self.dots_dist[mask], dim=-1)` (draw_triangle.py:382): a selection sized by the data
     assert res["sync"], res
     res = _run("oracle", "graph_safe:MS-HopperHop-v1", 3)           # `link.mass[0].item()` (control/hopper.py:196): host data the step has just made, read on the host
     assert res["sync"] == [] and res["flow"] == [], res
