@@ -486,6 +486,10 @@ def main():
             env._elapsed_steps.copy_(torch.randint(0, int(env.max_episode_steps), (n_local,), device=dev, dtype=torch.int32))
             for _ in range(max(args.warmup, 60)):       # (the first pass through every phase: the ring of prepared episodes has been refilled once)
                 venv.step(2 * torch.rand(n_local, env.action_dim, device=dev) - 1)
+            if getattr(env, "_dev_reset", None) is not None:      # a seeded reset voids the prepared episodes; a worker builds them again (0.4-3 s at 4096 envs) while
+                env._dev_reset.wait_ready()                       # resets are host-side: the steady state is the device path, so the leg waits for it
+                for _ in range(40):
+                    venv.step(2 * torch.rand(n_local, env.action_dim, device=dev) - 1)
             sync()
             t3 = time.perf_counter()
             n_vec, n_final = 400, 0

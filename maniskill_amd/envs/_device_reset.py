@@ -76,6 +76,8 @@ class DeviceReset:
         self._side = torch.cuda.Stream(dev) if dev.type == "cuda" else None
         self._uploaded = None             # event on the side stream: the last refill's uploads
         self._snap = None                 # pinned host copy of the counters + its event
+        self._rebuild_job = None          # a whole-ring build in flight: (thread, [exception], cancel flag, sub-scenes, their first episodes)
+        self.rebuilds = 0
         self.rebuild(np.arange(self.n))
 
     # ---------------------------------------------------------------------------------------------------------------- the shadow env
@@ -187,12 +189,12 @@ class DeviceReset:
             ev.record(torch.cuda.current_stream(self.dev))
             self.image[di[:, 0], di[:, 1]] = d
 
-    def _fill(self, idx: np.ndarray, first: np.ndarray, upto: np.ndarray):
+    def _fill(self, idx: np.ndarray, first: np.ndarray, upto: np.ndarray, cancel=None):
         """images of episodes first[i] .. upto[i] - 1 of sub-scene idx[i]"""
         j = 0
         while True:
             sel = first + j < upto
-            if not sel.any():
+            if not sel.any() or (cancel is not None and cancel.is_set()):
                 break
             ii, ep = idx[sel], (first + j)[sel]
             self._run(ii, ep)
@@ -201,19 +203,88 @@ class DeviceReset:
             j += 1
 
     def rebuild(self, idx: np.ndarray):
-        """sub-scenes whose seeds or episode counters the host set (a seeded reset, set_state ...): their ring starts over at the host's counter"""
+        """sub-scenes whose seeds or episode counters the host set (a seeded reset): their ring starts over at the host's counter.  A whole ring is ``slots`` runs of the
+        env's reset over these sub-scenes -- 0.4 to 3 s for 4096 x 64 on the GPU boxes' host cores (round 6's first default bench line: 2.9 s inside every seeded
+        reset).  Threaded: a worker builds it while the caller goes on; until it is done ``ready()`` is False and resets are the host's (the env's own ``reset``:
+        correct, slower), then the device's counters take the host's over and the device path resumes.  A new seeded reset cancels a build in flight."""
         self.join()
         idx = np.asarray(idx, dtype=np.int64)
+        pend = self._cancel_rebuild()
+        if pend is not None:
+            idx = np.union1d(idx, pend)
         if len(idx) == 0:
             return
         ep0 = self.env._episode_count[idx].astype(np.int64)
-        self.episode[torch.as_tensor(idx, dtype=torch.long, device=self.dev)] = torch.as_tensor(ep0, dtype=torch.int32, device=self.dev)
-        self._fill(idx, ep0, ep0 + self.slots)
+        if not self.threaded:
+            self.episode[torch.as_tensor(idx, dtype=torch.long, device=self.dev)] = torch.as_tensor(ep0, dtype=torch.int32, device=self.dev)
+            self._fill(idx, ep0, ep0 + self.slots)
+            self.filled[idx] = ep0 + self.slots
+            return
+        cancel, err = threading.Event(), []
+
+        def work():
+            try:
+                torch.set_num_threads(1)
+                self._fill(idx, ep0, ep0 + self.slots, cancel)
+                if self._side is not None:
+                    self._uploaded = self._side.record_event()
+            except BaseException as e:          # noqa: BLE001 -- re-raised on the caller's thread when the build is taken over
+                err.append(e)
+
+        t = threading.Thread(target=work, name="msk-device-reset-rebuild", daemon=True)
+        self._rebuild_job = (t, err, cancel, idx, ep0)
+        self.rebuilds += 1
+        t.start()
+
+    def _cancel_rebuild(self):
+        """stops a ring build in flight; -> the sub-scenes it was building (they are not built), or None"""
+        job = self._rebuild_job
+        if job is None:
+            return None
+        job[2].set()
+        job[0].join()
+        self._rebuild_job = None
+        return job[3]
+
+    def ready(self) -> bool:
+        """the device path may be used: no ring build is in flight (one that has just finished is taken over here)"""
+        job = self._rebuild_job
+        if job is None:
+            return True
+        if job[0].is_alive():
+            return False
+        self._finish_rebuild()
+        return True
+
+    def wait_ready(self):
+        job = self._rebuild_job
+        if job is not None:
+            job[0].join()
+            self._finish_rebuild()
+
+    def _finish_rebuild(self):
+        t, err, cancel, idx, ep0 = self._rebuild_job
+        t.join()
+        self._rebuild_job = None
+        if err:
+            raise err[0]
+        if self._uploaded is not None:
+            torch.cuda.current_stream(self.dev).wait_event(self._uploaded)
+            self._uploaded = None
         self.filled[idx] = ep0 + self.slots
+        cnt = self.env._episode_count.astype(np.int64)          # the host reset the envs meanwhile: its counters are the ones that count
+        self.episode.copy_(torch.as_tensor(cnt.astype(np.int32)).to(self.dev))
+        low = np.nonzero(self.filled - cnt < self.slots // 2 + 1)[0]
+        if len(low):                                             # (a long build, many host-side resets meanwhile: topped up before the device path goes on)
+            self._fill(low, self.filled[low], cnt[low] + self.slots)
+            self.filled[low] = cnt[low] + self.slots
+        self.since_refresh = 0
 
     def pull_counts(self) -> np.ndarray:
         """the device's episode counters (one read-back); the host's copy follows"""
         self.join()
+        if self._rebuild_job is not None and not self.ready():      # a ring build in flight: resets are the host's, so are the counters
+            return self.env._episode_count.astype(np.int64)
         ep = self.episode.cpu().numpy().astype(np.int64)
         self.env._episode_count[:] = ep.astype(np.uint64)
         return ep
@@ -262,7 +333,8 @@ class DeviceReset:
         t.start()
 
     def _job_thread(self) -> bool:
-        return self._job is not None and threading.current_thread() is self._job[0]
+        cur = threading.current_thread()
+        return (self._job is not None and cur is self._job[0]) or (self._rebuild_job is not None and cur is self._rebuild_job[0])
 
     def join(self):
         """the refill in flight has finished, and the caller's stream is behind its uploads"""
@@ -343,7 +415,7 @@ class DeviceResetMixin:
                 self._dev_reset = DeviceReset(self, slots=int(getattr(self, "device_reset_slots", 64)), threaded=getattr(self, "device_reset_threaded", None))
             except RuntimeError:
                 self.device_reset = want = False
-        return bool(want)
+        return bool(want) and self._dev_reset.ready()
 
     def _reset_on_device(self, seed, options):
         """-> (obs, info), or None when this reset is the host's (a seed, a state to restore, device resets switched off)"""
@@ -368,6 +440,14 @@ class DeviceResetMixin:
         if self._dev_reset is not None:
             self._dev_reset.pull_counts()
 
-    def _host_reset_ends(self, idx_np):
-        if self._dev_reset is not None:
-            self._dev_reset.rebuild(idx_np)
+    def _host_reset_ends(self, idx_np, reseeded: bool = True):
+        """reseeded: the reset set these sub-scenes' seeds / episode counters (``reset(seed=...)``): their prepared episodes are void.  A host-side reset without a
+        seed only consumed one episode each -- the ring stays, the device's counters follow when the device path resumes"""
+        dr = self._dev_reset
+        if dr is None:
+            return
+        if reseeded:
+            dr.rebuild(idx_np)
+        elif dr._rebuild_job is None:      # (device path in use and the host reset some envs itself: options other than env_idx)
+            idx = torch.as_tensor(np.asarray(idx_np), dtype=torch.long, device=dr.dev)
+            dr.episode[idx] = torch.as_tensor(self._episode_count[idx_np].astype(np.int32)).to(dr.dev)

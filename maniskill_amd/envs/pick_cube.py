@@ -328,7 +328,7 @@ class PickCubeEnv(DeviceResetMixin):
         self.px.gpu_apply_all()
         self.px.gpu_update_articulation_kinematics()
         self.px.gpu_fetch_all()
-        self._host_reset_ends(idx_np)
+        self._host_reset_ends(idx_np, reseeded=seed is not None)
         if "target_delta" in self.control_mode and self.control_mode.startswith("pd_ee"):   # controller.reset(): target = current ee pose
             cur = self.ee_pose_at_base()
             if getattr(self, "_target_pose", None) is None:

@@ -270,7 +270,7 @@ class PushTEnv(DeviceResetMixin):
         self.px.gpu_update_articulation_kinematics()
         self.px.gpu_fetch_all()
         self._buffers_stale = False
-        self._host_reset_ends(idx_np)
+        self._host_reset_ends(idx_np, reseeded=seed is not None)
         if self.fused:
             obs, _, _, _, info = self._fused_observe(False)
             return obs, info

@@ -40,6 +40,10 @@ def _rollout(host, dev, adim, steps, seed=0, every=3):
     oh, _ = host.reset(seed=2022)
     od, _ = dev.reset(seed=2022)
     _same(oh, od, "first obs")
+    if dev.device_reset:      # (where the ring is built by a worker -- on a GPU, or when asked for -- this rollout waits for it: it is about the device path)
+        dev._device_reset_wanted()
+        if dev._dev_reset is not None:
+            dev._dev_reset.wait_ready()
     for t in range(steps):
         a = 2 * torch.rand(n, adim, generator=g) - 1
         rh, rd = host.step(a), dev.step(a)
@@ -84,6 +88,49 @@ def test_refills_by_the_worker_thread_leave_the_same_rows(oracle_factory):
         dr.join()
 
 
+def test_resets_are_the_hosts_while_a_worker_builds_the_ring_and_the_devices_afterwards(oracle_factory):
+    """a seeded reset voids the prepared episodes; building 64 per sub-scene again takes seconds at 4096 envs.  Threaded, the caller goes on at once: resets are
+    host-side until the worker is done (same episodes, same bits), then the device's counters take the host's over and the mask path resumes"""
+    import threading
+    host, dev = _pair(PickCubeEnv, 6, oracle_factory, fused=False)
+    dev.device_reset_threaded = True
+    host.reset(seed=11); dev.reset(seed=11)
+    dev._device_reset_wanted()
+    dr = dev._dev_reset
+    dr.wait_ready()
+    gate = threading.Event()
+    fill = dr._fill
+    dr._fill = lambda *a, **k: (gate.wait(), fill(*a, **k))[1]      # the next ring build waits for the gate
+    host.reset(seed=12); dev.reset(seed=12)                          # ... this one's
+    assert not dr.ready() and not dev._device_reset_wanted()
+    g = torch.Generator().manual_seed(0)
+
+    def round_(k):
+        a = 2 * torch.rand(6, 8, generator=g) - 1
+        rh, rd = host.step(a), dev.step(a)
+        assert torch.equal(rh[0], rd[0])
+        done = torch.tensor([k % 2 == 0, True, False, k % 3 == 0, False, True])
+        oh, _ = host.reset(options=dict(env_idx=torch.nonzero(done).reshape(-1)))
+        od, _ = dev.reset_mask(done)
+        assert torch.equal(oh, od) and torch.equal(host.get_state(), dev.get_state())
+    before = dr.resets
+    for k in range(3):
+        round_(k)
+    assert dr.resets == before                                        # host-side so far
+    gate.set()
+    dr.wait_ready()
+    assert dev._device_reset_wanted()
+    for k in range(3, 9):
+        round_(k)
+    assert dr.resets == before + 6 and dr.rebuilds >= 2
+    assert np.array_equal(dr.pull_counts(), host._episode_count.astype(np.int64))
+    host.reset(seed=13); dev.reset(seed=13)                          # a build in flight is cancelled by the next seeded reset
+    host.reset(seed=14); dev.reset(seed=14)
+    dr.wait_ready()
+    for k in range(9, 12):
+        round_(k)
+
+
 def test_an_env_built_under_inference_mode_refills_from_the_worker_thread(oracle_factory):
     """bench.py steps under torch.inference_mode(); the refill thread is outside it (the mode is thread-local) and must still be allowed to write the shadow's
     buffers and the ring: round 6's first default bench run died on `Inplace update to inference tensor outside InferenceMode`"""
@@ -91,6 +138,8 @@ def test_an_env_built_under_inference_mode_refills_from_the_worker_thread(oracle
         env = PickCubeEnv(num_envs=6, px_factory=oracle_factory, fused=False, device_reset=True)
         env.device_reset_slots, env.device_reset_threaded = 4, True
         env.reset(seed=3)
+        env._device_reset_wanted()
+        env._dev_reset.wait_ready()
         for _ in range(10):
             env.step(torch.zeros(6, 8))
             env.reset_mask(torch.tensor([True, False, True, False, True, True]))

@@ -39,6 +39,10 @@ if os.environ.get("SOAK_HOST_RESETS"):
     venv.base_env.device_reset = False
 venv.base_env.enable_step_graph()
 venv.reset(seed=7)
+if not os.environ.get("SOAK_HOST_RESETS"):      # (a seeded reset voids the prepared episodes: a worker builds the ring again, resets are host-side meanwhile)
+    venv.base_env._device_reset_wanted()
+    if venv.base_env._dev_reset is not None:
+        venv.base_env._dev_reset.wait_ready()
 venv.base_env._elapsed_steps.copy_(torch.randint(0, 50, (n,), device="cuda:0", dtype=torch.int32))
 for w in range(W):
     torch.cuda.synchronize(); t0 = time.perf_counter()

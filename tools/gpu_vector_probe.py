@@ -15,6 +15,9 @@ def fresh(device_reset):
     env = PickCubeEnv(num_envs=n, device=D, device_reset=device_reset)
     env.enable_step_graph()
     env.reset(seed=3)
+    if device_reset:      # (the ring of prepared episodes is built by a worker after a seeded reset: the probe is about the device path)
+        env._device_reset_wanted()
+        env._dev_reset.wait_ready()
     env._elapsed_steps.copy_(torch.randint(0, 50, (n,), device=D, dtype=torch.int32))
     return env
 
