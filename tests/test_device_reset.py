@@ -208,6 +208,8 @@ def test_hip_reset_from_a_mask_equals_the_oracles_host_side_reset(oracle_factory
     gpu.device_reset_slots = 4
     g = torch.Generator().manual_seed(0)
     cpu.reset(seed=2022); gpu.reset(seed=2022)
+    gpu._device_reset_wanted()          # (on a GPU the ring is built by a worker after a seeded reset and resets are the host's meanwhile: this test is about the kernel)
+    gpu._dev_reset.wait_ready()
     for t in range(60):
         a = 2 * torch.rand(n, adim, generator=g) - 1
         cpu.step(a); gpu.step(a.to(DEV))
@@ -232,6 +234,8 @@ def test_hip_vector_env_with_step_graph_and_mask_resets_equals_the_host_side_pat
     b_env.enable_step_graph()
     va, vb = ManiSkillVectorEnv(a_env, record_metrics=True), ManiSkillVectorEnv(b_env, record_metrics=True)
     va.reset(seed=5); vb.reset(seed=5)
+    b_env._device_reset_wanted()
+    b_env._dev_reset.wait_ready()       # (the ring is rebuilt by a worker after the seeded reset: the comparison is about the device path)
     phase = torch.randint(0, 50, (n,), generator=torch.Generator().manual_seed(1), dtype=torch.int32).to(DEV)
     a_env._elapsed_steps.copy_(phase); b_env._elapsed_steps.copy_(phase)
     torch.manual_seed(0)
