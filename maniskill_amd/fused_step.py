@@ -1440,9 +1440,18 @@ class Accelerated:
                             culprit = f"(probe failed: {str(pe).splitlines()[0][:120]})"
                     raise Unsupported(f"the task's step cannot be captured as a HIP graph: {str(e).splitlines()[0][:300]}" + (f" -- first offender: {culprit}" if culprit else "")) from e
                 self.level = "graph"
+                # The tensors the env's attributes named when the step was captured are the ones a replay reads and writes.  A reset may bind an attribute to a new
+                # tensor (`self.cum_rotation_angle = torch.zeros((b,))` when every sub-scene is reset, rotate_single_object_in_hand.py:210, while a step updates it in
+                # place, :276): before a replay such an attribute's value is copied into the captured tensor and the attribute bound to it again.
+                held = self._held = {k: t for k, t in base.__dict__.items() if isinstance(t, torch.Tensor) and t.device == base.device}
+
                 def replayed(action):
-                    if persist:
-                        adopt()      # (a reset in between may have rebound a state attribute)
+                    d = base.__dict__
+                    for name, t0 in held.items():
+                        cur = d.get(name)
+                        if cur is not t0 and isinstance(cur, torch.Tensor) and cur.shape == t0.shape and cur.dtype == t0.dtype and cur.device == t0.device:
+                            t0.copy_(cur)
+                            d[name] = t0
                     return g(action) if action is not None else cls_step(base, None)
                 self._step_fn = replayed
             base.step = self._step

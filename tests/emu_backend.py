@@ -21,7 +21,10 @@ _lib = None
 def emu_lib() -> N.NativeLib:
     global _lib
     if _lib is None:
-        subprocess.check_call(["make", "-s", "-C", EMU_DIR, os.path.basename(EMU_LIB)])      # (make rebuilds it when a kernel source changed)
+        import fcntl
+        with open(os.path.join(EMU_DIR, ".build.lock"), "w") as lock:      # (pytest -n: one worker builds, the others find it done)
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-s", "-C", EMU_DIR, os.path.basename(EMU_LIB)])      # (make rebuilds it when a kernel source changed)
         _lib = N.NativeLib(EMU_LIB, "msk_")
     return _lib
 
