@@ -909,29 +909,8 @@ static void np_launch_shape(int N, int plane_pairs, int nverts, int* group_out, 
   *group_out = group;
 }
 
-/* The wide solver class's launch (envs of more than MSK_MAX_BLOCKS blocks; empty in most substeps of most tasks, and then still ~5 us of launch and drain) runs on a
- * stream of its own BESIDE k_csolve: both wait for the narrowphase, the next k_dynamics waits for both; they solve disjoint envs and share only read-only lists.  Inside a
- * captured step graph these are two parallel branches.  Per process and device, one side stream per env partition.  MSK_WIDE_CONCURRENT=0: behind k_csolve, as before. */
-static hipStream_t g_wide_stream[MSK_STEP_PARTS_MAX];
-static hipEvent_t g_wide_fork[MSK_STEP_PARTS_MAX], g_wide_join[MSK_STEP_PARTS_MAX];
-static int g_wide_dev = -1;
-static bool wide_streams(int device) {
-  static const int want = getenv("MSK_WIDE_CONCURRENT") ? atoi(getenv("MSK_WIDE_CONCURRENT")) : 1;
-  if (!want) return false;
-  if (g_wide_dev == device) return true;
-  if (g_wide_dev != -1) return false;      /* (a second device in one process: its contexts keep the serial order) */
-  if (hipSetDevice(device) != hipSuccess) return false;
-  for (int k = 0; k < MSK_STEP_PARTS_MAX; ++k) {
-    if (hipStreamCreateWithFlags(&g_wide_stream[k], hipStreamNonBlocking) != hipSuccess) return false;
-    if (hipEventCreateWithFlags(&g_wide_fork[k], hipEventDisableTiming) != hipSuccess) return false;
-    if (hipEventCreateWithFlags(&g_wide_join[k], hipEventDisableTiming) != hipSuccess) return false;
-  }
-  g_wide_dev = device;
-  return true;
-}
-
-/* one substep of one env partition (msk_ctx::StepPart, number `part`) on stream s; ev: the partition's [kernel][begin, end] events of an armed step, or null */
-static void step_part(msk_ctx* c, const msk_ctx::StepPart& p, hipStream_t s, hipEvent_t* ev, int part = 0) {
+/* one substep of one env partition (msk_ctx::StepPart) on stream s; ev: the partition's [kernel][begin, end] events of an armed step, or null */
+static void step_part(msk_ctx* c, const msk_ctx::StepPart& p, hipStream_t s, hipEvent_t* ev) {
   const int N = p.n;
   const int nblk = (N + 63) / 64;
   hipEvent_t* const ev_dyn = ev ? ev + 2 * MSK_K_DYNAMICS : nullptr;
@@ -954,13 +933,6 @@ static void step_part(msk_ctx* c, const msk_ctx::StepPart& p, hipStream_t s, hip
     LAUNCH_TIMED(ev_np, k_classify, dim3(nblk), dim3(64), 0, s, p.d_model, p.st);
   }
   const int gm = p.solve_workers;
-  const bool beside = p.st.wide_workers > 0 && wide_streams(c->device);
-  hipStream_t sw = s;
-  if (beside) { /* fork behind the narrowphase */
-    sw = g_wide_stream[part];
-    hipEventRecord(g_wide_fork[part], s);
-    hipStreamWaitEvent(sw, g_wide_fork[part], 0);
-  }
   if (c->model.G == 16) {
     auto k0 = k_csolve<16, 16>;
     LAUNCH_TIMED(ev_cs, k0, dim3(gm + (N + 3) / 4), dim3(64), c->lds_solve, s, p.d_model, p.st, gm);
@@ -973,13 +945,9 @@ static void step_part(msk_ctx* c, const msk_ctx::StepPart& p, hipStream_t s, hip
   }
   if (p.st.wide_workers > 0) { /* msk_config.contact_capacity = 1: the envs of more than MSK_MAX_BLOCKS blocks (msk_solve_wide.h) */
     const int G = c->model.G;
-    if (G == 16) hipLaunchKernelGGL(k_csolve_wide<16>, dim3(p.st.wide_workers), dim3(64), CsWide<16>::TOTAL * sizeof(float), sw, p.d_model, p.st);
-    else if (G == 32) hipLaunchKernelGGL(k_csolve_wide<32>, dim3(p.st.wide_workers), dim3(64), CsWide<32>::TOTAL * sizeof(float), sw, p.d_model, p.st);
-    else hipLaunchKernelGGL(k_csolve_wide<64>, dim3(p.st.wide_workers), dim3(64), CsWide<64>::TOTAL * sizeof(float), sw, p.d_model, p.st);
-    if (beside) { /* join: whatever follows on s waits for both solver launches */
-      hipEventRecord(g_wide_join[part], sw);
-      hipStreamWaitEvent(s, g_wide_join[part], 0);
-    }
+    if (G == 16) hipLaunchKernelGGL(k_csolve_wide<16>, dim3(p.st.wide_workers), dim3(64), CsWide<16>::TOTAL * sizeof(float), s, p.d_model, p.st);
+    else if (G == 32) hipLaunchKernelGGL(k_csolve_wide<32>, dim3(p.st.wide_workers), dim3(64), CsWide<32>::TOTAL * sizeof(float), s, p.d_model, p.st);
+    else hipLaunchKernelGGL(k_csolve_wide<64>, dim3(p.st.wide_workers), dim3(64), CsWide<64>::TOTAL * sizeof(float), s, p.d_model, p.st);
   }
 }
 
@@ -1014,7 +982,7 @@ MSK_API int msk_step_n(msk_ctx* c, int count, void* stream) {
     hipStream_t sk = k == 0 ? s : g_part_stream[k];
     for (int i = 0; i < count; ++i) {
       const bool timed = t0 + i < c->t_cap;
-      step_part(c, c->parts[k], sk, timed ? &c->tev[(size_t)(t0 + i) * per_step + (size_t)k * 2 * MSK_K_KERNELS] : nullptr, k);
+      step_part(c, c->parts[k], sk, timed ? &c->tev[(size_t)(t0 + i) * per_step + (size_t)k * 2 * MSK_K_KERNELS] : nullptr);
     }
   }
   for (int i = 0; i < count; ++i) if (c->t_n < c->t_cap) c->t_n++;
