@@ -1664,13 +1664,20 @@ MSK_API int msk_task_peg_observe(msk_ctx* c, float* obs, float* reward, uint8_t*
                                  int advance, void* stream) {
   if (!c->has_peg) return fail(c, MSK_ERR_INVALID, "peg task not initialised");
   const int N = c->model.N;
-  if (c->kin_dirty) {
-    launch_kinematics(c->model, c->d_model, c->st, (hipStream_t)stream);
-    c->kin_dirty = false;
-  }
   const float cos_max = cosf(c->pickcube.max_angle_deg * 3.14159265358979323846f / 180.0f);
-  hipLaunchKernelGGL(k_peg_observe, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->d_model, c->st, c->pickcube, c->peg_tb,
-                     obs, reward, flags, elapsed, head_at_hole, advance, cos_max);
+  if (c->kin_dirty) { /* the usual case behind msk_control_step: frames and observation in one launch */
+    const int lpe = lanes_per_env(c->model), epb = 64 / lpe;
+    const size_t lds = (size_t)DynLds(c->model.nb, 0).total * sizeof(float) * epb;
+    if (lpe == 32)
+      hipLaunchKernelGGL(k_peg_observe_kin<32>, dim3((N + 1) / 2), dim3(64), lds, (hipStream_t)stream, c->d_model, c->st, c->pickcube, c->pick_lsel, c->pick_rsel,
+                         c->peg_tb, obs, reward, flags, elapsed, head_at_hole, advance, cos_max);
+    else
+      hipLaunchKernelGGL(k_peg_observe_kin<64>, dim3(N), dim3(64), lds, (hipStream_t)stream, c->d_model, c->st, c->pickcube, c->pick_lsel, c->pick_rsel,
+                         c->peg_tb, obs, reward, flags, elapsed, head_at_hole, advance, cos_max);
+    c->kin_dirty = false;
+  } else
+    hipLaunchKernelGGL(k_peg_observe, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, c->d_model, c->st, c->pickcube, c->pick_lsel, c->pick_rsel, c->peg_tb,
+                       obs, reward, flags, elapsed, head_at_hole, advance, cos_max);
   HIP_TRY(hipGetLastError());
   return MSK_OK;
 }

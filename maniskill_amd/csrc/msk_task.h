@@ -358,12 +358,9 @@ MSK_DEV pose pose_from_p(float x, float y, float z) {
   return r;
 }
 
-__global__ void __launch_bounds__(256) k_peg_observe(const DModel* __restrict__ m, DState st, msk_pickcube_desc d, PegTables tb,
-                                                     float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags,
-                                                     int* __restrict__ elapsed, float* __restrict__ head_at_hole, int advance,
-                                                     float cos_max_angle) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= m->N) return;
+MSK_DEV void peg_observe_env(const DModel* __restrict__ m, const DState& st, const msk_pickcube_desc& d, const PairSel& lsel, const PairSel& rsel, const PegTables& tb,
+                             float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags, int* __restrict__ elapsed,
+                             float* __restrict__ head_at_hole, const int advance, const float cos_max_angle, const int e) {
   const float* E = EREC(st, m, e);
   const int nq = d.arm_dofs + 2;
   float* o = obs + (size_t)e * 43;
@@ -380,8 +377,8 @@ __global__ void __launch_bounds__(256) k_peg_observe(const DModel* __restrict__ 
   const bool success = -0.015f <= inside.x && -rr <= inside.y && inside.y <= rr && -rr <= inside.z && inside.z <= rr;
   /* is_grasping(max_angle=20): contact forces = impulses of the last substep / dt */
   const float inv_dt = 1.0f / m->cfg.timestep;
-  const v3 lforce = v3_scale(pair_impulse(m, st, e, d.left_finger, d.cube), inv_dt);
-  const v3 rforce = v3_scale(pair_impulse(m, st, e, d.right_finger, d.cube), inv_dt);
+  const v3 lforce = v3_scale(pair_impulse_sel(m, st, e, lsel), inv_dt);      /* (the finger-peg candidate pairs, prepared on the host: the same sum in the same order as a scan of the pair table) */
+  const v3 rforce = v3_scale(pair_impulse_sel(m, st, e, rsel), inv_dt);
   const m33 Rl = quat_to_m33(lf.q), Rr = quat_to_m33(rf.q);
   const v3 ldir = m33_col(&Rl, 1), rdir = v3_neg(m33_col(&Rr, 1));
   const bool grasped = finger_grasps(lforce, ldir, d.min_force, cos_max_angle) && finger_grasps(rforce, rdir, d.min_force, cos_max_angle);
@@ -412,6 +409,31 @@ __global__ void __launch_bounds__(256) k_peg_observe(const DModel* __restrict__ 
   f[4] = success;                       /* terminated */
   f[5] = el >= d.max_episode_steps;     /* truncated (TimeLimitWrapper) */
   f[6] = 0; f[7] = 0;
+}
+
+/* lane = env: the link frames are current (a reset's observation behind msk_update_kinematics) */
+__global__ void __launch_bounds__(64) k_peg_observe(const DModel* __restrict__ m, DState st, msk_pickcube_desc d, PairSel lsel, PairSel rsel, PegTables tb,
+                                                    float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags,
+                                                    int* __restrict__ elapsed, float* __restrict__ head_at_hole, int advance,
+                                                    float cos_max_angle) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e < m->N) peg_observe_env(m, st, d, lsel, rsel, tb, obs, reward, flags, elapsed, head_at_hole, advance, cos_max_angle, e);
+}
+
+/* behind a control step: the link frames of the post-step (q, qd) and the observation in one launch, as k_pickcube_observe_kin (round 6: the observation was a launch
+ * of its own behind k_kinematics, one lane per env over 16 workgroups, scanning the whole pair table twice for the finger impulses: 13 + 46 us) */
+template <int LPE>
+__global__ void __launch_bounds__(64) k_peg_observe_kin(const DModel* __restrict__ m, DState st, msk_pickcube_desc d, PairSel lsel, PairSel rsel, PegTables tb,
+                                                        float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ flags,
+                                                        int* __restrict__ elapsed, float* __restrict__ head_at_hole, int advance,
+                                                        float cos_max_angle) {
+  extern __shared__ __attribute__((aligned(16))) float lds_ok[];      /* (the name k_pickcube_observe_kin gives its carve: one symbol for the emulation to back) */
+  kinematics_block<LPE>(m, st, lds_ok, blockIdx.x);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   /* the frames just stored are read back by the env's first lane */
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const int e = blockIdx.x * (64 / LPE) + threadIdx.x / LPE;
+  if (threadIdx.x % LPE == 0 && e < m->N) peg_observe_env(m, st, d, lsel, rsel, tb, obs, reward, flags, elapsed, head_at_hole, advance, cos_max_angle, e);
 }
 
 /* ---- PushT-v1 ------------------------------------------------------------------------------------------------------ */

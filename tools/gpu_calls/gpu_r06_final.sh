@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6, the round's evidence on ONE commit: the driver's own commands (pytest -m gpu -x -q, smoke, bench.py --gpus 1 --steps 20 --warmup 5), the default bench line,
-# the bench forms, a same-box A/B against the library of the round's first commit (libmsk_r06c3.so = 18e0277's csrc), the phase probes, the vector-env probe and soak,
+# the bench forms, a same-box A/B against the library of the first evidence run (libmsk_r06ev.so = a0cba64's csrc: the same kernels but PegInsertionSide's observation), the phase probes, the vector-env probe and soak,
 # rocprofv3 kernel statistics and the PMC passes (summarised here: only the summaries travel back), the MFMA question's microbenchmark
 #   gpurun --timeout 3000 -- 'bash tools/gpu_calls/gpu_r06_final.sh'
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -23,9 +23,9 @@ except Exception as e: print("$n failed", e); print(open("$O/ab_$n.err").read()[
 PY
 }
 ( run new_1 MSK_LIB=maniskill_amd/csrc/libmsk_physx.so
-  run old_1 MSK_LIB=maniskill_amd/csrc/libmsk_r06c3.so
+  run old_1 MSK_LIB=maniskill_amd/csrc/libmsk_r06ev.so
   run new_2 MSK_LIB=maniskill_amd/csrc/libmsk_physx.so
-  run old_2 MSK_LIB=maniskill_amd/csrc/libmsk_r06c3.so ) | tee $O/ab_head_vs_18e0277.log
+  run old_2 MSK_LIB=maniskill_amd/csrc/libmsk_r06ev.so ) | tee $O/ab_head_vs_first_evidence_run.log
 PROBE_STEPS=100 timeout 300 python tools/gpu_phase_probe.py > $O/phase_probe_pickcube.log 2>&1; tail -3 $O/phase_probe_pickcube.log | cut -c1-300
 timeout 600 python tools/gpu_vector_probe.py 4096 300 > $O/vector_probe.log 2>&1; grep -v Warning $O/vector_probe.log | cut -c1-160 | sed -n 3,14p
 timeout 600 python tools/gpu_soak_rate.py 20 4096 > $O/soak_20000.log 2>&1; grep "vector env\|bare" $O/soak_20000.log | cut -c1-80 | tail -22
