@@ -90,17 +90,13 @@ MSK_DEV int select_feature(const CShape* sh, const pose* T, v3 n, v3 t1, v3 t2, 
   return cnt;
 }
 
-/* height (n coordinate) of a feature's surface above the in-plane point (u, v) */
-MSK_DEV float feature_height(const LArr f, int n, float u, float v) {
-  if (n == 1) return f(2);
-  if (n == 2) {
-    float du = f(3) - f(0), dv = f(4) - f(1);
-    float l2 = fmaf(du, du, dv * dv);
-    float t = (l2 > 1e-12f) ? fmaf(u - f(0), du, (v - f(1)) * dv) / l2 : 0.0f;
-    t = fminf(fmaxf(t, 0.0f), 1.0f);
-    return fmaf(t, f(5) - f(2), f(2));
-  }
-  /* Newell normal and centroid */
+/* A polygonal feature's plane: Newell normal (mx, my, mz) and centroid (gu, gv, gh).  It belongs to the feature, not to the point whose height is asked for: computed
+ * ONCE per feature (build_manifold) -- the height of every clipped point evaluated it again before (up to 8 points x 2 features x a loop over the feature's vertices in LDS:
+ * a quarter of the manifold's instructions on a face-face pair).  Same operations in the same order as the oracle's feature_height, hence the same bits. */
+struct FeatPlane { float mx, my, mz, gu, gv, gh; };
+MSK_DEV FeatPlane feature_plane(const LArr f, int n) {
+  FeatPlane pl = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  if (n < 3) return pl;
   float mx = 0, my = 0, mz = 0, gu = 0, gv = 0, gh = 0;
   for (int i = 0; i < n; ++i) {
     const int j = (i + 1 == n) ? 0 : i + 1;
@@ -113,8 +109,22 @@ MSK_DEV float feature_height(const LArr f, int n, float u, float v) {
   }
   float inv = 1.0f / (float)n;
   gu *= inv; gv *= inv; gh *= inv;
-  if (fabsf(mz) < 1e-12f) return gh;
-  return gh - (mx * (u - gu) + my * (v - gv)) / mz;
+  pl.mx = mx; pl.my = my; pl.mz = mz; pl.gu = gu; pl.gv = gv; pl.gh = gh;
+  return pl;
+}
+
+/* height (n coordinate) of a feature's surface above the in-plane point (u, v) */
+MSK_DEV float feature_height(const LArr f, int n, const FeatPlane& pl, float u, float v) {
+  if (n == 1) return f(2);
+  if (n == 2) {
+    float du = f(3) - f(0), dv = f(4) - f(1);
+    float l2 = fmaf(du, du, dv * dv);
+    float t = (l2 > 1e-12f) ? fmaf(u - f(0), du, (v - f(1)) * dv) / l2 : 0.0f;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    return fmaf(t, f(5) - f(2), f(2));
+  }
+  if (fabsf(pl.mz) < 1e-12f) return pl.gh;
+  return pl.gh - (pl.mx * (u - pl.gu) + pl.my * (v - pl.gv)) / pl.mz;
 }
 
 /* clip the segment p0-p1 against the convex CCW polygon poly; returns number of points (0..2) */
@@ -253,10 +263,11 @@ MSK_DEV int build_manifold(float* lb, const CShape* A, const pose* TA, const CSh
   else if (kb == 2 && ka >= 3) np = clip_segment_poly(fb, fa, ka, pts);
   else np = seg_seg(fa, fb, pts);
   int nc = 0;
+  const FeatPlane pla = feature_plane(fa, ka), plb = feature_plane(fb, kb);
   for (int i = 0; i < np; ++i) {
     const float pu = pts(i * 2), pv = pts(i * 2 + 1);
-    float ha = feature_height(fa, ka, pu, pv);
-    float hb = feature_height(fb, kb, pu, pv);
+    float ha = feature_height(fa, ka, pla, pu, pv);
+    float hb = feature_height(fb, kb, plb, pu, pv);
     float sep = ha - hb;
     if (sep > margin) continue;
     cs(nc * 4) = pu; cs(nc * 4 + 1) = pv; cs(nc * 4 + 2) = 0.5f * (ha + hb); cs(nc * 4 + 3) = sep;

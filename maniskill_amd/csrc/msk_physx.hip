@@ -1636,12 +1636,13 @@ MSK_API int msk_task_pusht_observe(msk_ctx* c, float* obs, int obs_dim, float* r
                                    void* stream) {
   if (!c->has_pusht) return fail(c, MSK_ERR_INVALID, "pusht task not initialised");
   if (obs_dim != 2 * c->pusht.arm_dofs + 7 && obs_dim != 2 * c->pusht.arm_dofs + 17) return fail(c, MSK_ERR_INVALID, "pusht: obs_dim is 21 or 31");
-  if (c->kin_dirty) {
-    launch_kinematics(c->model, c->d_model, c->st, (hipStream_t)stream);
+  if (c->kin_dirty) { /* the usual case behind msk_control_step: frames and observation in one launch */
+    hipLaunchKernelGGL(k_pusht_observe<true>, dim3(c->model.N), dim3(64), (size_t)DynLds(c->model.nb, 0).total * sizeof(float), (hipStream_t)stream, c->d_model, c->st,
+                       c->pusht, c->pusht_tb, obs, obs_dim, reward, flags, elapsed, advance);
     c->kin_dirty = false;
-  }
-  hipLaunchKernelGGL(k_pusht_observe, dim3(c->model.N), dim3(64), 0, (hipStream_t)stream, c->d_model, c->st, c->pusht, c->pusht_tb, obs,
-                     obs_dim, reward, flags, elapsed, advance);
+  } else
+    hipLaunchKernelGGL(k_pusht_observe<false>, dim3(c->model.N), dim3(64), 0, (hipStream_t)stream, c->d_model, c->st, c->pusht, c->pusht_tb, obs,
+                       obs_dim, reward, flags, elapsed, advance);
   HIP_TRY(hipGetLastError());
   return MSK_OK;
 }

@@ -727,8 +727,10 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
    *   contact block: flim = mu, hi_c = 0 -> +-mu*lam_n ; joint block (limit rows): flim = 0, hi_c = cap -> [0, cap] */
   const float flim = is_contact ? mu : 0.0f;
   const float hi_c = is_contact ? 0.0f : MSK_MAX_ROW_IMPULSE;
-  auto sweep = [&](auto posit_tag) {
+  auto sweep = [&](auto posit_tag, auto tors_tag) {
     constexpr bool POSIT = decltype(posit_tag)::value;
+    constexpr bool TORS = decltype(tors_tag)::value;      /* some env of the wavefront has a torsional block; without one (most templates) the per-block test of `tblocks` -- a
+                                                           * scalar branch and two moves in every block of the unrolled stream -- is not compiled into the sweep */
     /* sweep-invariant bias terms of my rows.  slot 0: a contact's normal row (position bias / restitution), or the constant velocity bias
      * of a drive row (0 for joint-friction and torsional rows); slots 1, 2: limit rows of a joint block, friction rows of a contact block */
     const float t0n = bias_over_arr<POSIT, false>(bv[0], c0[0], rinv[0], inv_h, inv_dt, pen_rate, rest0, vclose0);
@@ -761,7 +763,7 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
       float l0 = lam[0];
       if (rowbits & 1u) {
         float lo = lo0, hi = hi0;
-        if (!decltype(all_rows_tag)::value && ((tblocks >> blk) & 1ull)) { /* a torsional block: its cone is sized by its point's normal impulse */
+        if (TORS && !decltype(all_rows_tag)::value && ((tblocks >> blk) & 1ull)) { /* a torsional block: its cone is sized by its point's normal impulse */
           const float lref = __shfl(lam[0], tref, GL);
           if (is_tors) { hi = mu_r * lref; lo = -hi; }
         }
@@ -893,11 +895,19 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
       }
     }
   };
-  for (int sb = 0; sb < nsub; ++sb) {
-    sweep(std::true_type{});
-    sweep(std::false_type{});
+  if (tblocks != 0ull) {      /* (wave-uniform: a ballot) */
+    for (int sb = 0; sb < nsub; ++sb) {
+      sweep(std::true_type{}, std::true_type{});
+      sweep(std::false_type{}, std::true_type{});
+    }
+    for (int it = 0; it < nfinal; ++it) sweep(std::false_type{}, std::true_type{});
+  } else {
+    for (int sb = 0; sb < nsub; ++sb) {
+      sweep(std::true_type{}, std::false_type{});
+      sweep(std::false_type{}, std::false_type{});
+    }
+    for (int it = 0; it < nfinal; ++it) sweep(std::false_type{}, std::false_type{});
   }
-  for (int it = 0; it < nfinal; ++it) sweep(std::false_type{});
 
   PHASE();
   /* ---- back to generalized coordinates ----------------------------------------------------------------------------------- */

@@ -463,10 +463,20 @@ MSK_DEV float pusht_z_euler(quat q) {
 
 /* one wavefront per env: the T's mask pixels are pushed through goal-from-world x world-from-T and marked in a 64 x 64 bit
  * image in LDS; the marks that fall on the goal mask are counted */
+/* KIN: behind a control step -- the env's link frames first (the wavefront is the env's: the 64-lane form of the forward pass), then the observation: one launch
+ * instead of k_kinematics + this one */
+template <bool KIN>
 __global__ void __launch_bounds__(64) k_pusht_observe(const DModel* __restrict__ m, DState st, msk_pusht_desc d, PushTTables tb,
                                                       float* __restrict__ obs, int obs_dim, float* __restrict__ reward,
                                                       uint8_t* __restrict__ flags, int* __restrict__ elapsed, int advance) {
   __shared__ unsigned img[128];
+  if (KIN) {
+    extern __shared__ __attribute__((aligned(16))) float lds_ok[];
+    kinematics_block<64>(m, st, lds_ok, blockIdx.x);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   /* the frames just stored are read back below */
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
   const int e = blockIdx.x, lane = threadIdx.x;
   const float* E = EREC(st, m, e);
   img[lane] = 0u; img[lane + 64] = 0u;
