@@ -276,14 +276,14 @@ __global__ void __launch_bounds__(64) k_kinematics(const DModel* __restrict__ m,
  * link frames (the forward pass), and runs beside the rest of the dynamics on another SIMD of the CU (it used to be the kernel's tail:
  * ~25 k cycles of the ~105 k of a block). */
 template <int LPE>
-MSK_DEV void broadphase_block(const DModel* __restrict__ m, const DState& st, const int blk) {
+MSK_DEV void broadphase_block(const DModel* __restrict__ m, const DState& st, const int blk, const BpConst& bk) {
   __shared__ float bp_aabb[MSK_MAX_SHAPES][6];
   __shared__ float bp_obb[MSK_MAX_SHAPES][13];   /* rotation columns (9), local half extents (3); odd stride: no bank conflicts */
   if (blk == 0 && (threadIdx.x & 63) < MSK_SOLVE_CLASSES) st.cls_count[threadIdx.x & 63] = 0;   /* this substep's solver lists (filled by the narrowphase) */
 #pragma unroll 1
   for (int k = 0; k < 64 / LPE; ++k) {
     const int eb = blk * (64 / LPE) + k;
-    if (eb < m->N) broadphase_env(m, st, eb, bp_aabb, bp_obb);
+    if (eb < m->N) broadphase_env(m, st, eb, bp_aabb, bp_obb, bk);
   }
 }
 
@@ -312,6 +312,7 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
   long long* dstamp = st.dbg + (size_t)m->N * 8 + 64 + (size_t)e * 8;
   int dsi = 0;
 #define DPHASE() do { if (live && i == 0) dstamp[dsi] = (long long)__builtin_readcyclecounter(); dsi++; } while (0)
+  const unsigned long long drt0 = __builtin_amdgcn_s_memrealtime();   /* the 100 MHz clock: where in the launch this wave ran (tools/gpu_phase_probe.py) */
 #else
 #define DPHASE()
 #endif
@@ -859,6 +860,9 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
     store_v3(E, m->lay.comw, i, comw);
   }
   DPHASE();
+#ifdef MSK_PROFILE_PHASES
+  if (live && i == 0) dstamp[7] = (long long)(((__builtin_amdgcn_s_memrealtime() & 0xffffffffull) << 32) | (drt0 & 0xffffffffull));
+#endif
 #undef DPHASE
 }
 /* 64 (DW + 1) threads, DW = 1 or 2: wavefronts 0 .. DW-1 = the dynamics of DW consecutive env blocks (a block = the 64 / LPE envs of one
@@ -866,9 +870,14 @@ MSK_DEV void dynamics_block(const DModel* __restrict__ m, const DState& st, floa
  * link frames; it runs beside the rest of the dynamics on another SIMD.  The host picks the widest form whose wavefronts are all resident at
  * once (3 per SIMD at this kernel's register count = 3072 on the chip): 4096 envs of two per wavefront are 1024 workgroups of 192 threads --
  * with 128-thread workgroups they were 4096 wavefronts that queued, so the broadphase stayed the ~25 k-cycle tail of the one wavefront.
- * 64 threads: that form (broadphase as the tail), for launches larger still. */
+ * 64 threads: that form (broadphase as the tail), for launches larger still.
+ * Round 6 (profiles/r06_launch_position_probe.log): at 154 VGPRs three wavefronts fit a SIMD, so the 1024 x 3 wavefronts of 4096 envs fill the chip EXACTLY -- the 100 MHz
+ * stamps of the profiling build showed workgroups starting 21-23 us after the first (one that finds no CU with three free slots on the right SIMDs waits for a dynamics
+ * wavefront to end: a 25-30 us kernel became 38-47 us, and which CUs overflowed depended on what the launch before had left behind).  Holding the kernel to 128 VGPRs (four per
+ * SIMD) starts every wavefront at once but spills and makes each 11 % longer (profiles/r06_ab_dynamics_four_waves_per_simd.log: + 1 % at 4096 envs, - 2 % at 8192 and more).
+ * 256 threads = three dynamics wavefronts + the broadphase wavefront of their three blocks: one wavefront per SIMD per workgroup, 683 workgroups for 4096 envs = 89 % of the slots. */
 template <int LPE, int MD>
-__global__ void __launch_bounds__(192) k_dynamics(const DModel* __restrict__ m, DState st) {
+__global__ void __launch_bounds__(256) k_dynamics(const DModel* __restrict__ m, DState st) {
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int DW = nwaves > 1 ? nwaves - 1 : 1;
@@ -881,13 +890,15 @@ __global__ void __launch_bounds__(192) k_dynamics(const DModel* __restrict__ m, 
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   /* the other half-wave's stores to its env record */
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      broadphase_block<LPE>(m, st, blk);
+      const BpConst bk = bp_const(m);
+      broadphase_block<LPE>(m, st, blk, bk);
     }
   } else {
+    const BpConst bk = bp_const(m);      /* what the broadphase asks of the template, fetched while the dynamics wavefronts compute the link frames */
     __syncthreads();
     if (m->np > 0)
       for (int w = 0; w < DW; ++w)
-        if (blockIdx.x * DW + w < nblk) broadphase_block<LPE>(m, st, blockIdx.x * DW + w);
+        if (blockIdx.x * DW + w < nblk) broadphase_block<LPE>(m, st, blockIdx.x * DW + w, bk);
   }
 }
 

@@ -777,11 +777,13 @@ __global__ void __launch_bounds__(128) k_multi_dynamics(const GroupRef* __restri
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      broadphase_block<LPE>(r.m, r.st, blk);
+      const BpConst bk = bp_const(r.m);
+      broadphase_block<LPE>(r.m, r.st, blk, bk);
     }
   } else {
+    const BpConst bk = bp_const(r.m);
     __syncthreads();
-    if (r.m->np > 0) broadphase_block<LPE>(r.m, r.st, blk);
+    if (r.m->np > 0) broadphase_block<LPE>(r.m, r.st, blk, bk);
   }
 }
 template <int LPE>

@@ -43,21 +43,28 @@ static void launch_kinematics(const DModel& m, const DModel* d_model, const DSta
   else hipLaunchKernelGGL(k_kinematics<64>, dim3(m.N), dim3(64), lds, s, d_model, st);
 }
 /* threads per workgroup of the dynamics launch: 64 (DW + 1) -- DW wavefronts run the dynamics of DW env blocks, one more their broadphase
- * beside it (msk_dynamics.h) -- in the widest form whose wavefronts are all resident at once (3 per SIMD at the kernel's register count:
- * 3072 on the 256 CUs): 128 threads up to 1536 env blocks, 192 up to 2048 (4096 envs at two per wavefront: 1024 workgroups x 3), else 64
- * (broadphase as the tail of the one wavefront).  MI355X, round 2: 512 envs 44 -> 38 us per launch with 128 threads. */
-static int dyn_threads(int env_blocks) {
+ * beside it (msk_dynamics.h) -- in the widest form whose wavefronts are all resident at once WITH ROOM TO SPARE (3 per SIMD at the kernel's
+ * register count: 3072 on the 256 CUs): 128 threads up to 1280 env blocks, 256 (three dynamics wavefronts + one: a wavefront per SIMD per
+ * workgroup) up to 2304 -- 4096 envs at two per wavefront are 683 workgroups x 4 = 89 % of the slots --, else 64 (broadphase as the tail of the
+ * one wavefront).  Round 6 (profiles/r06_launch_position_probe.log): 1024 workgroups x 3 filled the slots exactly and workgroups that found their
+ * CU full started 21-23 us late.  MI355X, round 2: 512 envs 44 -> 38 us per launch with 128 threads. */
+static int dyn_threads(int env_blocks, int lpe = 32) {
   static const int e = getenv("MSK_DYN_THREADS") ? atoi(getenv("MSK_DYN_THREADS")) : 0;   /* tuning aid */
-  if (e == 64 || e == 128 || e == 192) return e;
-  if (2 * env_blocks <= 3072) return 128;
-  if (3 * ((env_blocks + 1) / 2) <= 3072) return 192;
+  if (e == 64 || e == 128 || e == 192 || (e == 256 && lpe == 32)) return e;
+  if (lpe != 32) { /* a wavefront per env (more registers, up to 36 KB of LDS per env): the forms of round 2 */
+    if (2 * env_blocks <= 3072) return 128;
+    if (3 * ((env_blocks + 1) / 2) <= 3072) return 192;
+    return 64;
+  }
+  if (2 * env_blocks <= 2560) return 128;
+  if (4 * ((env_blocks + 2) / 3) <= 3072) return 256;
   return 64;
 }
 static void launch_dynamics(const DModel& m, int N, const DModel* d_model, const DState& st, hipStream_t s, hipEvent_t* ev = nullptr) {
   const int lpe = lanes_per_env(m), epb = 64 / lpe;
   const int md = dyn_md(m);
   const int blocks = lpe == 32 ? (N + 1) / 2 : N;      /* env blocks: the envs of one dynamics wavefront */
-  const int th = dyn_threads(blocks);
+  const int th = dyn_threads(blocks, lpe);
   const int dw = th > 64 ? th / 64 - 1 : 1;            /* dynamics wavefronts per workgroup */
   const size_t lds = (size_t)DynLds(m.nb, md).total * sizeof(float) * epb * dw;
   const int wgs = (blocks + dw - 1) / dw;
@@ -1113,10 +1120,10 @@ static int batch_merged(msk_ctx* const* ctxs, int n, int op, uint32_t mask, hipS
   };
   switch (op) {
     case MSK_BATCH_STEP: {
-      if (lpe == 32) hipLaunchKernelGGL((k_multi_dynamics<32, 16>), dim3(mc.t_dyn), dim3(dyn_threads(mc.t_dyn) == 128 ? 128 : 64), mc.lds_dyn, s, mc.d_refs, n);
-      else if (md == 16) hipLaunchKernelGGL((k_multi_dynamics<64, 16>), dim3(mc.t_dyn), dim3(dyn_threads(mc.t_dyn) == 128 ? 128 : 64), mc.lds_dyn, s, mc.d_refs, n);
-      else if (md == 32) hipLaunchKernelGGL((k_multi_dynamics<64, 32>), dim3(mc.t_dyn), dim3(dyn_threads(mc.t_dyn) == 128 ? 128 : 64), mc.lds_dyn, s, mc.d_refs, n);
-      else hipLaunchKernelGGL((k_multi_dynamics<64, 64>), dim3(mc.t_dyn), dim3(dyn_threads(mc.t_dyn) == 128 ? 128 : 64), mc.lds_dyn, s, mc.d_refs, n);
+      if (lpe == 32) hipLaunchKernelGGL((k_multi_dynamics<32, 16>), dim3(mc.t_dyn), dim3(dyn_threads(mc.t_dyn, 64) == 128 ? 128 : 64), mc.lds_dyn, s, mc.d_refs, n);
+      else if (md == 16) hipLaunchKernelGGL((k_multi_dynamics<64, 16>), dim3(mc.t_dyn), dim3(dyn_threads(mc.t_dyn, 64) == 128 ? 128 : 64), mc.lds_dyn, s, mc.d_refs, n);
+      else if (md == 32) hipLaunchKernelGGL((k_multi_dynamics<64, 32>), dim3(mc.t_dyn), dim3(dyn_threads(mc.t_dyn, 64) == 128 ? 128 : 64), mc.lds_dyn, s, mc.d_refs, n);
+      else hipLaunchKernelGGL((k_multi_dynamics<64, 64>), dim3(mc.t_dyn), dim3(dyn_threads(mc.t_dyn, 64) == 128 ? 128 : 64), mc.lds_dyn, s, mc.d_refs, n);
       hipLaunchKernelGGL(k_multi_narrowphase, dim3(mc.t_np), dim3(64), mc.lds_np, s, mc.d_refs, n);
       if (G == 16) { auto k0 = k_multi_csolve<16, 16>; hipLaunchKernelGGL(k0, dim3(mc.t_cs), dim3(64), c->lds_solve, s, mc.d_refs, n); }
       else if (G == 32) { auto k0 = k_multi_csolve<32, 32>; hipLaunchKernelGGL(k0, dim3(mc.t_cs), dim3(64), c->lds_solve, s, mc.d_refs, n); }

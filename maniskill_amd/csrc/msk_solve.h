@@ -262,6 +262,7 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
 #define GBALLOT(pred) ((__ballot(pred) >> gshift) & gmask)
 #ifdef MSK_PROFILE_PHASES
   long long tph[8]; int nph = 0;
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();   /* the 100 MHz clock: where in the launch this wave ran (tools/gpu_phase_probe.py) */
 #define PHASE() tph[nph++] = (long long)__builtin_readcyclecounter()
 #else
 #define PHASE()
@@ -995,7 +996,10 @@ MSK_DEV void solve_env(const DModel* __restrict__ m, const DState& st, const int
   }
   PHASE();
 #ifdef MSK_PROFILE_PHASES
-  if (active && lane == 0) for (int i = 0; i < 7; ++i) st.dbg[(size_t)e * 8 + i] = tph[i];
+  if (active && lane == 0) {
+    for (int i = 0; i < 7; ++i) st.dbg[(size_t)e * 8 + i] = tph[i];
+    st.dbg[(size_t)e * 8 + 7] = (long long)(((__builtin_amdgcn_s_memrealtime() & 0xffffffffull) << 32) | (rt0 & 0xffffffffull));
+  }
 #endif
 #undef PHASE
 #undef GBALLOT

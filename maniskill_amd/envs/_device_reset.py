@@ -16,13 +16,32 @@ ops over a few thousand rows cost 4 ms that way and 200 ms through an OpenMP tea
 slots nothing reads (the slots of episodes already consumed) -- so the step path only launches; the next refill first joins the one before it."""
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import threading
+import weakref
 
 import numpy as np
 import torch
 
 RIGID, QPOS, QVEL, TQPOS, TQVEL = 0, 1, 2, 3, 4      # include/msk_physx.h: MSK_RESET_*
+
+
+_LIVE = weakref.WeakSet()      # the DeviceReset objects of this process (their workers are stopped before the interpreter goes)
+
+
+def _stop_workers():
+    """at exit: a daemon worker still inside torch when the interpreter finalises is unwound by ``pthread_exit`` through C++ frames -- ``terminate called without an
+    active exception`` and a core instead of exit code 0 (seen once in four default bench runs: gpurun_out/r06_final3/bench_n1_default.err).  Builds in flight are
+    cancelled, refills joined; errors at this point have nobody to go to."""
+    for dr in list(_LIVE):
+        try:
+            dr.close()
+        except BaseException:          # noqa: BLE001
+            pass
+
+
+atexit.register(_stop_workers)
 
 
 class _NullPx:
@@ -78,6 +97,8 @@ class DeviceReset:
         self._snap = None                 # pinned host copy of the counters + its event
         self._rebuild_job = None          # a whole-ring build in flight: (thread, [exception], cancel flag, sub-scenes, their first episodes)
         self.rebuilds = 0
+        self._unbuilt = None              # sub-scenes whose ring build close() cancelled
+        _LIVE.add(self)
         self.rebuild(np.arange(self.n))
 
     # ---------------------------------------------------------------------------------------------------------------- the shadow env
@@ -212,6 +233,8 @@ class DeviceReset:
         pend = self._cancel_rebuild()
         if pend is not None:
             idx = np.union1d(idx, pend)
+        if self._unbuilt is not None:
+            idx, self._unbuilt = np.union1d(idx, self._unbuilt), None
         if len(idx) == 0:
             return
         ep0 = self.env._episode_count[idx].astype(np.int64)
@@ -250,11 +273,11 @@ class DeviceReset:
         """the device path may be used: no ring build is in flight (one that has just finished is taken over here)"""
         job = self._rebuild_job
         if job is None:
-            return True
+            return self._unbuilt is None
         if job[0].is_alive():
             return False
         self._finish_rebuild()
-        return True
+        return self._unbuilt is None
 
     def wait_ready(self):
         job = self._rebuild_job
@@ -331,6 +354,16 @@ class DeviceReset:
         t = threading.Thread(target=work, name="msk-device-reset-refill", daemon=True)
         self._job = (t, err)
         t.start()
+
+    def close(self):
+        """no worker of this object runs after this: a refill in flight is joined, a ring build in flight cancelled -- its sub-scenes stay the host's (``ready()`` is
+        False) until the next seeded reset builds their ring again"""
+        job = self._job
+        if job is not None and threading.current_thread() is not job[0]:
+            job[0].join()
+        pend = self._cancel_rebuild()
+        if pend is not None and len(pend):
+            self._unbuilt = pend if self._unbuilt is None else np.union1d(self._unbuilt, pend)
 
     def _job_thread(self) -> bool:
         cur = threading.current_thread()

@@ -131,6 +131,43 @@ def test_resets_are_the_hosts_while_a_worker_builds_the_ring_and_the_devices_aft
         round_(k)
 
 
+def test_close_stops_the_workers_and_leaves_the_host_path_until_the_next_seeded_reset(oracle_factory):
+    """what the exit hook does (a daemon worker inside torch at interpreter shutdown = `terminate called without an active exception`): a build in flight is
+    cancelled, resets stay correct on the host path, the next seeded reset builds the ring again"""
+    import threading
+    from maniskill_amd.envs import _device_reset as mod
+    host, dev = _pair(PickCubeEnv, 5, oracle_factory, fused=False)
+    dev.device_reset_threaded = True
+    host.reset(seed=21); dev.reset(seed=21)
+    dev._device_reset_wanted()
+    dr = dev._dev_reset
+    assert dr in mod._LIVE
+    dr.wait_ready()
+    gate = threading.Event()
+    fill = dr._fill
+    dr._fill = lambda *a, **k: (gate.wait(), fill(*a, **k))[1]
+    host.reset(seed=22); dev.reset(seed=22)
+    t = dr._rebuild_job[0]
+    gate.set()
+    mod._stop_workers()
+    assert not t.is_alive() and dr._rebuild_job is None and dr._job is None
+    assert not dr.ready() and not dev._device_reset_wanted()
+    done = torch.tensor([True, False, True, False, True])
+    a = torch.zeros(5, 8)
+    assert torch.equal(host.step(a)[0], dev.step(a)[0])
+    oh, _ = host.reset(options=dict(env_idx=torch.nonzero(done).reshape(-1)))
+    od, _ = dev.reset_mask(done)
+    assert torch.equal(oh, od)
+    dr._fill = fill
+    host.reset(seed=23); dev.reset(seed=23)
+    dr.wait_ready()
+    assert dr.ready() and dev._device_reset_wanted()
+    before = dr.resets
+    oh, _ = host.reset(options=dict(env_idx=torch.nonzero(done).reshape(-1)))
+    od, _ = dev.reset_mask(done)
+    assert torch.equal(oh, od) and dr.resets == before + 1
+
+
 def test_an_env_built_under_inference_mode_refills_from_the_worker_thread(oracle_factory):
     """bench.py steps under torch.inference_mode(); the refill thread is outside it (the mode is thread-local) and must still be allowed to write the shadow's
     buffers and the ring: round 6's first default bench run died on `Inplace update to inference tensor outside InferenceMode`"""

@@ -41,9 +41,39 @@ def np_report(tag, launches):
     items = max(d[2, 0], 1)
     print(tag, f"hull items: through EPA {x[0]/launches:.1f}/launch, EPA cycles mean {x[1]/max(x[0],1):.0f} max {x[2]}; GJK iterations mean {x[3]/items:.2f} max {x[4]}; "
           f"cull stage mean {x[5]/items:.0f} cycles, items into GJK {x[6]/launches:.1f}/launch; primary histogram (<25k <50k <100k <150k <200k <300k <400k more) per launch {[round(float(v)/launches, 1) for v in x[8:16]]}")
+def where_in_the_launch(name, rows, cyc):
+    """slot 7 of a row: the 100 MHz clock at the wave's first and last stamp (low / high word) -- of the LAST launch: how long the launch is from its first wave's
+    start to its last wave's end, how late waves start, what a wave's cycle count is in time (= the clock the chip ran at)"""
+    w = rows[:, 7].astype(np.uint64)
+    ok = w != 0
+    t0 = (w[ok] & np.uint64(0xffffffff)).astype(np.int64)
+    t1 = (w[ok] >> np.uint64(32)).astype(np.int64)
+    t1 = np.where(t1 < t0, t1 + (1 << 32), t1)
+    first = t0.min()
+    start, dur = (t0 - first) / 100.0, (t1 - t0) / 100.0
+    span = (t1.max() - first) / 100.0
+    ghz = cyc[ok] / np.maximum(dur, 1e-3) / 1e3
+    q = lambda a, p: float(np.percentile(a, p))      # noqa: E731
+    print(f"{name}: first wave start -> last wave end {span:.1f} us; a wave starts {q(start, 50):.1f} us (median) / {q(start, 90):.1f} (90 %) / {q(start, 99):.1f} (99 %) / {start.max():.1f} (last) after the first, {100.0 * float((start > 5.0).mean()):.1f} % later than 5 us; "
+          f"a wave lasts {dur.mean():.1f} us mean / {dur.max():.1f} max = {q(ghz, 50):.2f} GHz (median of cycles / time); the last wave to end started at {float(start[np.argmax(t1)]):.1f} us and lasted {float(dur[np.argmax(t1)]):.1f}")
+
+
+
+def where_all(tag):
+    o = np.zeros(n * 16 + 64, dtype=np.int64)
+    dll.msk_debug_phases(env.px.ctx, o.ctypes.data_as(C.POINTER(C.c_longlong)))
+    r = o[:n * 8].reshape(n, 8)
+    where_in_the_launch(tag + " k_csolve  ", r, (r[:, 6] - r[:, 0]).astype(np.float64))
+    r = o[n * 8 + 64:n * 16 + 64].reshape(n, 8)
+    where_in_the_launch(tag + " k_dynamics", r, (r[:, 6] - r[:, 0]).astype(np.float64))
+
+
 for _ in range(3): env.step(torch.zeros(n, 8, device="cuda:0"))
 report("zero  ")
-for _ in range(60): env.step(2 * torch.rand(n, 8, device="cuda:0") - 1)
+where_all("zero actions, step 3:")
+for _ in range(17): env.step(2 * torch.rand(n, 8, device="cuda:0") - 1)
+where_all("random actions, step 20:")
+for _ in range(43): env.step(2 * torch.rand(n, 8, device="cuda:0") - 1)
 report("random")
 np_report("random(all steps)", 63 * 5 + 5)
 env.px.lib.dll.msk_debug_reset.argtypes = [C.c_void_p]
@@ -59,3 +89,4 @@ dll.msk_debug_phases(env.px.ctx, out.ctypes.data_as(C.POINTER(C.c_longlong)))
 dd = np.diff(out[n * 8 + 64:n * 16 + 64].reshape(n, 8)[:, :7], axis=1)
 print("k_dynamics phases (mean cycles): forward", int(dd[:, 0].mean()), "rnea", int(dd[:, 1].mean()), "backward", int(dd[:, 2].mean()),
       "crba", int(dd[:, 3].mean()), "solve", int(dd[:, 4].mean()), "free", int(dd[:, 5].mean()), "total", int(dd.sum(1).mean()))
+where_all("random actions, last step:")
