@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6, the round's evidence on ONE commit: the driver's own commands (pytest -m gpu -x -q, smoke, bench.py --gpus 1 --steps 20 --warmup 5), the default bench line,
-# the bench forms, a same-box A/B against the library of the first evidence run (libmsk_r06ev.so = a0cba64's csrc: the same kernels but PegInsertionSide's observation), the phase probes, the vector-env probe and soak,
+# the bench forms, a same-box A/B against the library of the evidence run before this one (libmsk_base.so = 72d5aae's csrc: before the 256-thread k_dynamics and the broadphase's constants once per wavefront), the phase probes, the vector-env probe and soak,
 # rocprofv3 kernel statistics and the PMC passes (summarised here: only the summaries travel back), the MFMA question's microbenchmark
 #   gpurun --timeout 3000 -- 'bash tools/gpu_calls/gpu_r06_final.sh'
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -8,6 +8,13 @@ O=$R/gpurun_out/${FINAL_DIR:-r06_final}; mkdir -p $O
 cd $R
 ( time timeout 1800 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider ) > $O/gpu_tests_driver_form.log 2>&1; tail -6 $O/gpu_tests_driver_form.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+# the PMC passes first: the bench lines below quote their bytes (roofline.traffic) only when the committed summary is of THESE kernel sources, so the summary goes into profiles/ of this copy before they run
+rm -rf $R/gpurun_out/pmc; timeout 500 bash tools/pmc_collect.sh > /dev/null 2>&1
+python tools/pmc_summarise.py $R/gpurun_out/pmc $O/pmc_counters_4096.json "python bench.py --steps 20 --warmup 40 --no-cpu-baseline --no-extras" r06-final > $O/pmc_summary.log 2>&1; tail -12 $O/pmc_summary.log
+rm -rf $R/gpurun_out/pmc; timeout 500 bash tools/pmc_collect.sh --env PushT-v1 --obs-mode depth+segmentation > /dev/null 2>&1
+python tools/pmc_summarise.py $R/gpurun_out/pmc $O/pmc_counters_camera_4096.json "python bench.py --steps 20 --warmup 40 --no-cpu-baseline --no-extras --env PushT-v1 --obs-mode depth+segmentation" r06-final > $O/pmc_camera_summary.log 2>&1; tail -6 $O/pmc_camera_summary.log
+rm -rf $R/gpurun_out/pmc
+cp $O/pmc_counters_4096.json $O/pmc_counters_camera_4096.json $R/profiles/ 2>/dev/null; for f in pmc_counters_4096 pmc_counters_camera_4096; do mv $R/profiles/$f.json $R/profiles/r06_$f.json; done
 MSK_BENCH_EXTRA_S=500 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1_driver_form.json 2> $O/bench_n1_driver_form.err; tail -c 300 $O/bench_n1_driver_form.json; echo
 timeout 300 python bench.py --no-cpu-baseline > $O/bench_n1_default_1000.json 2> $O/bench_n1_default.err; tail -c 200 $O/bench_n1_default_1000.json; echo
 timeout 200 python bench.py --envs 512 --no-cpu-baseline --no-extras > $O/bench_n1_512envs.json 2>/dev/null
@@ -23,9 +30,9 @@ except Exception as e: print("$n failed", e); print(open("$O/ab_$n.err").read()[
 PY
 }
 ( run new_1 MSK_LIB=maniskill_amd/csrc/libmsk_physx.so
-  run old_1 MSK_LIB=maniskill_amd/csrc/libmsk_r06ev.so
+  run old_1 MSK_LIB=maniskill_amd/csrc/libmsk_base.so
   run new_2 MSK_LIB=maniskill_amd/csrc/libmsk_physx.so
-  run old_2 MSK_LIB=maniskill_amd/csrc/libmsk_r06ev.so ) | tee $O/ab_head_vs_first_evidence_run.log
+  run old_2 MSK_LIB=maniskill_amd/csrc/libmsk_base.so ) | tee $O/ab_head_vs_previous_evidence_run.log
 PROBE_STEPS=100 timeout 300 python tools/gpu_phase_probe.py > $O/phase_probe_pickcube.log 2>&1; tail -3 $O/phase_probe_pickcube.log | cut -c1-300
 timeout 600 python tools/gpu_vector_probe.py 4096 300 > $O/vector_probe.log 2>&1; grep -v Warning $O/vector_probe.log | cut -c1-160 | sed -n 3,14p
 timeout 600 python tools/gpu_soak_rate.py 20 4096 > $O/soak_20000.log 2>&1; grep "vector env\|bare" $O/soak_20000.log | cut -c1-80 | tail -22
@@ -39,9 +46,4 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_vect
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_pusht_dropin -- python $R/tools/bench_reference_host.py --env PushT-v1 --obs-mode depth+segmentation --envs 4096 --steps 50 --accelerate graph > $O/prof_pusht_dropin.log 2>&1
 find $O -name '*kernel_trace.csv' -delete
 cd $R
-rm -rf $R/gpurun_out/pmc; timeout 500 bash tools/pmc_collect.sh > /dev/null 2>&1
-python tools/pmc_summarise.py $R/gpurun_out/pmc $O/pmc_counters_4096.json "python bench.py --steps 20 --warmup 40 --no-cpu-baseline --no-extras" r06-final > $O/pmc_summary.log 2>&1; tail -12 $O/pmc_summary.log
-rm -rf $R/gpurun_out/pmc; timeout 500 bash tools/pmc_collect.sh --env PushT-v1 --obs-mode depth+segmentation > /dev/null 2>&1
-python tools/pmc_summarise.py $R/gpurun_out/pmc $O/pmc_counters_camera_4096.json "python bench.py --steps 20 --warmup 40 --no-cpu-baseline --no-extras --env PushT-v1 --obs-mode depth+segmentation" r06-final > $O/pmc_camera_summary.log 2>&1; tail -6 $O/pmc_camera_summary.log
-rm -rf $R/gpurun_out/pmc
 find $O -name "*kernel_stats.csv"
