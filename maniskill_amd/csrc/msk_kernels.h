@@ -403,8 +403,28 @@ MSK_DEV void narrowphase_block(const DModel* __restrict__ m, const DState& st, c
   }
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_narrowphase(const DModel* __restrict__ m, DState st, const int group, const NpCfg cfg) {
+#define MSK_DBG_NP_BLOCKS 8192   /* DState::dbg, profiling builds: one word per narrowphase workgroup behind the per-env stamps */
+MSK_DEV void narrowphase_launch_body(const DModel* __restrict__ m, const DState& st, const int group, const NpCfg& cfg) {
+#ifdef MSK_PROFILE_PHASES
+  const unsigned long long nrt0 = __builtin_amdgcn_s_memrealtime();   /* the 100 MHz clock: where in the launch this workgroup ran (tools/gpu_phase_probe.py) */
+#endif
   narrowphase_block(m, st, group, cfg, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+#ifdef MSK_PROFILE_PHASES
+  const int nb_ = blockIdx.y * gridDim.x + blockIdx.x;
+  if (threadIdx.x == 0 && nb_ < MSK_DBG_NP_BLOCKS)
+    st.dbg[(size_t)m->N * 16 + 64 + nb_] = (long long)(((__builtin_amdgcn_s_memrealtime() & 0xffffffffull) << 32) | (nrt0 & 0xffffffffull));
+#endif
+}
+/* Two register budgets of the same code (round 6, profiles/r06_launch_position_probe.log, r06_ab_narrowphase_two_waves_per_simd.log).  k_narrowphase: 256 VGPRs + 45 AGPRs = ONE wavefront
+ * per SIMD, 1024 slots for the 1792 workgroups of 4096 envs -- workgroups queue, but each runs as fast as it can, and at 4096 PickCube envs the launch is as long as its longest workgroup
+ * (a box-box block, 32-40 us; a hull item through EPA).  k_narrowphase_w2: 256 VGPRs, no AGPRs = two per SIMD, 183 scratch instructions instead of 42: every workgroup ~5 % slower
+ * (4096 PickCube envs: 45.2 -> 47.5 us), but launches whose workgroups are mostly busy, or many times the slots, stop queueing: 16384 PegInsertionSide envs 191 -> 154 us, 65536 PickCube
+ * envs 213 -> 166 us.  The host picks by env count (step_part). */
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) k_narrowphase(const DModel* __restrict__ m, DState st, const int group, const NpCfg cfg) {
+  narrowphase_launch_body(m, st, group, cfg);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_narrowphase_w2(const DModel* __restrict__ m, DState st, const int group, const NpCfg cfg) {
+  narrowphase_launch_body(m, st, group, cfg);
 }
 
 /* ---- AoS <-> SoA converters ------------------------------------------------------------------ */

@@ -522,7 +522,7 @@ static int build_step_parts(msk_ctx* c, int want = 0) {
       ALLOC(v.wide_scratch, (size_t)v.wide_workers * wide_scratch_words(m.G));
     }
     ALLOC(v.hq_items, (size_t)n * np1); ALLOC(v.hq_count, 1);
-    ALLOC(v.dbg, (size_t)n * 16 + 64);
+    ALLOC(v.dbg, (size_t)n * 16 + 64 + MSK_DBG_NP_BLOCKS);
     p.st = v;
     c->parts.push_back(p);
   }
@@ -702,7 +702,7 @@ MSK_API int msk_finalize(msk_ctx* c, int num_envs) {
   ALLOC(st.Scol, N * G * 8); ALLOC(st.W, N * G * G); ALLOC(st.vfree, N * G);
   ALLOC(st.ct_cnt, N * m.npp); ALLOC(st.ct_rec, N * m.npp * MSK_CT_REC);
   ALLOC(st.cls_list, MSK_SOLVE_CLASSES * N); ALLOC(st.cls_count, MSK_SOLVE_CLASSES); ALLOC(st.np_done, N);
-  ALLOC(st.dbg, N * 16 + 64);
+  ALLOC(st.dbg, N * 16 + 64 + MSK_DBG_NP_BLOCKS);
   /* the solver launch (msk_solve.h): one LDS size for every kind of workgroup; one-env-per-wave workers */
   c->solve_workers = num_envs < 768 ? num_envs : 768;
   ALLOC(st.a_scratch, (size_t)c->solve_workers * 9 * MSK_CLASS3_BLOCKS * (MSK_CLASS3_BLOCKS + 4));   /* + prefetch slack */
@@ -933,8 +933,12 @@ static void step_part(msk_ctx* c, const msk_ctx::StepPart& p, hipStream_t s, hip
     int group;
     NpCfg cfg;
     np_launch_shape(N, c->plane_pairs, c->nverts_total, &group, &cfg);
-    LAUNCH_TIMED(ev_np, k_narrowphase, dim3((N + group - 1) / group, cfg.nplane + cfg.nbox + cfg.nhull), dim3(64),
-                 (size_t)cfg.lds_words * sizeof(float), s, p.d_model, p.st, group, cfg);
+    static const int e_w2 = getenv("MSK_NP_W2") ? atoi(getenv("MSK_NP_W2")) : -1;   /* measurement knob: 0 / 1 = never / always the two-per-SIMD form */
+    const dim3 npgrid((N + group - 1) / group, cfg.nplane + cfg.nbox + cfg.nhull);
+    if (e_w2 >= 0 ? e_w2 != 0 : N >= 8192)   /* several times more workgroups than one-per-SIMD slots: msk_kernels.h, k_narrowphase_w2 */
+      LAUNCH_TIMED(ev_np, k_narrowphase_w2, npgrid, dim3(64), (size_t)cfg.lds_words * sizeof(float), s, p.d_model, p.st, group, cfg);
+    else
+      LAUNCH_TIMED(ev_np, k_narrowphase, npgrid, dim3(64), (size_t)cfg.lds_words * sizeof(float), s, p.d_model, p.st, group, cfg);
   } else {
     hipMemsetAsync(p.st.cls_count, 0, sizeof(int) * MSK_SOLVE_CLASSES, s);
     LAUNCH_TIMED(ev_np, k_classify, dim3(nblk), dim3(64), 0, s, p.d_model, p.st);
@@ -1760,14 +1764,15 @@ MSK_API int msk_task_pickcube_observe(msk_ctx* c, float* obs, float* reward, uin
 MSK_API int msk_debug_reset(msk_ctx* c) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemset(c->st.dbg, 0, sizeof(long long) * (16 * (size_t)c->model.N + 64)));
+  HIP_TRY(hipMemset(c->st.dbg, 0, sizeof(long long) * (16 * (size_t)c->model.N + 64 + MSK_DBG_NP_BLOCKS)));
   return MSK_OK;
 }
-/* development aid (MSK_PROFILE_PHASES builds): per-env cycle stamps of the solver phases, out[num_envs*8] */
+/* development aid (MSK_PROFILE_PHASES builds): per-env cycle stamps of the solver and dynamics phases, the narrowphase's counters, the 100 MHz stamps of the narrowphase's
+ * workgroups: out[num_envs * 16 + 64 + MSK_DBG_NP_BLOCKS] */
 MSK_API int msk_debug_phases(msk_ctx* c, long long* out) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out, c->st.dbg, sizeof(long long) * (16 * (size_t)c->model.N + 64), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, c->st.dbg, sizeof(long long) * (16 * (size_t)c->model.N + 64 + MSK_DBG_NP_BLOCKS), hipMemcpyDeviceToHost));
   return MSK_OK;
 }
 #endif

@@ -19,7 +19,7 @@ dll = env.px.lib.dll
 dll.msk_debug_phases.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 names = ["count", "stage", "rowsJ", "Y", "A", "sweeps", "finish"]
 def report(tag):
-    out = np.zeros(n * 16 + 64, dtype=np.int64)
+    out = np.zeros(n * 16 + 64 + 8192, dtype=np.int64)
     dll.msk_debug_phases(env.px.ctx, out.ctypes.data_as(C.POINTER(C.c_longlong)))
     t = out[:n * 8].reshape(n, 8)
     d = np.diff(t[:, :7], axis=1)
@@ -31,7 +31,7 @@ def report(tag):
             print(tag, f"contacts {lo}-{hi} n={sel.sum()}", {k: int(v) for k, v in zip(names[1:], d[sel].mean(0))}, "total mean", int(tot.mean()), "max", int(tot.max()),
                   "of the slowest env:", {k: int(v) for k, v in zip(names[1:], d[sel][tot.argmax()])}, "its contacts", int(c[sel][tot.argmax()]))
 def np_report(tag, launches):
-    out = np.zeros(n * 16 + 64, dtype=np.int64)
+    out = np.zeros(n * 16 + 64 + 8192, dtype=np.int64)
     dll.msk_debug_phases(env.px.ctx, out.ctypes.data_as(C.POINTER(C.c_longlong)))
     d = out[n * 8:n * 8 + 24].reshape(3, 8)
     for t, name in enumerate(("plane", "boxbox", "gjk")):
@@ -60,12 +60,28 @@ def where_in_the_launch(name, rows, cyc):
 
 
 def where_all(tag):
-    o = np.zeros(n * 16 + 64, dtype=np.int64)
+    o = np.zeros(n * 16 + 64 + 8192, dtype=np.int64)
     dll.msk_debug_phases(env.px.ctx, o.ctypes.data_as(C.POINTER(C.c_longlong)))
     r = o[:n * 8].reshape(n, 8)
     where_in_the_launch(tag + " k_csolve  ", r, (r[:, 6] - r[:, 0]).astype(np.float64))
     r = o[n * 8 + 64:n * 16 + 64].reshape(n, 8)
     where_in_the_launch(tag + " k_dynamics", r, (r[:, 6] - r[:, 0]).astype(np.float64))
+    # the narrowphase's workgroups (grid: env groups x [plane | box-box | hull] kinds, x fastest): one word each
+    w = o[n * 16 + 64:].astype(np.uint64)
+    ok = np.nonzero(w)[0]
+    if len(ok):
+        t0 = (w[ok] & np.uint64(0xffffffff)).astype(np.int64); t1 = (w[ok] >> np.uint64(32)).astype(np.int64)
+        t1 = np.where(t1 < t0, t1 + (1 << 32), t1)
+        first = t0.min(); start = (t0 - first) / 100.0; dur = (t1 - t0) / 100.0; end = (t1 - first) / 100.0
+        gx = (n + 15) // 16
+        kinds = ok // gx
+        q = lambda a, p: float(np.percentile(a, p))      # noqa: E731
+        print(f"{tag} k_narrowphase: {len(ok)} workgroups, first start -> last end {end.max():.1f} us; starts: median {q(start, 50):.1f} / 90 % {q(start, 90):.1f} / last {start.max():.1f} us, {100.0 * float((start > 5.0).mean()):.1f} % later than 5 us; "
+              f"a workgroup lasts {dur.mean():.1f} us mean / {q(dur, 99):.1f} (99 %) / {dur.max():.1f} max; the last to end: kind row {int(kinds[np.argmax(end)])}, started at {float(start[np.argmax(end)]):.1f} us, lasted {float(dur[np.argmax(end)]):.1f}")
+        for k in np.unique(kinds):
+            sel = kinds == k
+            print(f"      kind row {int(k)}: {int(sel.sum())} workgroups, start median {q(start[sel], 50):.1f} / last {start[sel].max():.1f} us, lasts mean {dur[sel].mean():.1f} / 99 % {q(dur[sel], 99):.1f} / max {dur[sel].max():.1f} us, last end {end[sel].max():.1f} us, over 10 us: {int((dur[sel] > 10).sum())}")
+
 
 
 for _ in range(3): env.step(torch.zeros(n, 8, device="cuda:0"))
@@ -84,7 +100,7 @@ for _ in range(40): env.step(2 * torch.rand(n, 8, device="cuda:0") - 1)
 report("random, steps 160-200")
 np_report("random(steps 160-200)", 40 * 5)
 print("solver classes", env.px.get_solver_class_counts())
-out = np.zeros(n * 16 + 64, dtype=np.int64)
+out = np.zeros(n * 16 + 64 + 8192, dtype=np.int64)
 dll.msk_debug_phases(env.px.ctx, out.ctypes.data_as(C.POINTER(C.c_longlong)))
 dd = np.diff(out[n * 8 + 64:n * 16 + 64].reshape(n, 8)[:, :7], axis=1)
 print("k_dynamics phases (mean cycles): forward", int(dd[:, 0].mean()), "rnea", int(dd[:, 1].mean()), "backward", int(dd[:, 2].mean()),
