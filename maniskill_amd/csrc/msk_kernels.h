@@ -70,6 +70,7 @@ __global__ void __launch_bounds__(64) k_classify(const DModel* __restrict__ m, D
 }
 
 #define NP_GROUP_MAX 16
+#define MSK_DBG_NP_BLOCKS 8192   /* DState::dbg, profiling builds: behind the per-env stamps, a word per narrowphase workgroup (launch position) and, for the first 4096, a word of its phases */
 /* One wavefront per (env group, narrowphase list).
  *   plane and box-box lists (blockIdx.y = 0, 1): one lane per surviving pair of `group` envs (msk_collide_lane.h) — the
  *     lists are long, a wave holds up to 64 pairs and fetches the per-pair code once for all of them;
@@ -89,6 +90,11 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
   constexpr bool GLOBALQ = TYPE == NP_GJK;   /* hull items: one queue for the whole launch (part / nparts count over all hull blocks) */
   const int lane = threadIdx.x;
   const float margin = 2.0f * m->cfg.contact_offset;
+#ifdef MSK_PROFILE_PHASES   /* where a workgroup's time goes, 100 MHz clock: first pass only: [0] entry, [2] operands fetched, [3] contacts computed, [1] speculative points filtered, [5] old record read / count and total updated, [4] slots written (tools/gpu_phase_probe.py) */
+  unsigned long long brt[6];
+  brt[0] = brt[1] = brt[2] = brt[3] = brt[4] = brt[5] = __builtin_amdgcn_s_memrealtime();
+  bool brt_first = true;
+#endif
   int count;
   if constexpr (GLOBALQ) {
     count = *st.hq_count;
@@ -137,6 +143,7 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
   const CShape* B = &cB;
 #ifdef MSK_PROFILE_PHASES
   long long tq[6]; tq[0] = (long long)__builtin_readcyclecounter(); tq[1] = tq[2] = tq[5] = tq[0]; tq[3] = tq[4] = 0;
+  if (brt_first) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); brt[2] = __builtin_amdgcn_s_memrealtime(); }
 #endif
   v3 opos[4], onrm = v3_make(0, 0, 1);
   float osep[4];
@@ -210,6 +217,8 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
   }
 #ifdef MSK_PROFILE_PHASES
   tq[2] = (long long)__builtin_readcyclecounter();
+  if (brt_first) brt[3] = __builtin_amdgcn_s_memrealtime();
+#ifndef MSK_PROFILE_NO_NPSTATS   /* (the counters below are same-address atomics from every workgroup: ~14 us of a box-box block; -DMSK_PROFILE_NO_NPSTATS leaves the stamps alone) */
   if (writer) { /* per type: [0] items, [1] sum primary, [2] max primary, [3] sum manifold, [4] max manifold, [5] hits */
     unsigned long long* d = (unsigned long long*)st.dbg + (size_t)m->N * 8 + type * 8;
     atomicAdd(&d[0], 1ull);
@@ -226,6 +235,7 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
       atomicAdd(&x[8 + bk], 1ull);
     }
   }
+#endif
 #endif
   if (!writer) break;
   /* Speculative points that cannot touch within this step are no contacts (oracle: orc_collide_pair): a point further apart than
@@ -260,6 +270,9 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
     }
     n = kept;
   }
+#ifdef MSK_PROFILE_PHASES
+  if (brt_first) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); brt[1] = __builtin_amdgcn_s_memrealtime(); }   /* (the speculative-point filter done) */
+#endif
   /* warm start from the previous contents of this pair's slot, then overwrite it */
   int* cntp = st.ct_cnt + (size_t)e * m->npp + pi;
   float* rec = st.ct_rec + ((size_t)e * m->npp + pi) * MSK_CT_REC;
@@ -292,6 +305,9 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
     *slip = (nprev > 0 && Nn > 0.0f && fmaf(T1, T1, T2 * T2) >= lim * lim) ? 1 : 0;
   }
   const float prev_lam_t = rec[3];
+#ifdef MSK_PROFILE_PHASES
+  if (brt_first) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); brt[5] = __builtin_amdgcn_s_memrealtime(); }   /* (the old record read, count and total updated, slip flag written) */
+#endif
   if (n > 0) { rec[0] = onrm.x; rec[1] = onrm.y; rec[2] = onrm.z; rec[3] = 0.0f; }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -317,6 +333,9 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
     for (int a = 0; a < 3; ++a) rec[20 + k * 3 + a] = lam[a];
   }
   } while (0);
+#ifdef MSK_PROFILE_PHASES
+  if (brt_first) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); brt[4] = __builtin_amdgcn_s_memrealtime(); brt_first = false; }
+#endif
   if constexpr (GLOBALQ) { /* sign the pass's items off with their chunks (see k_narrowphase); a wave may finish several chunks */
     /* the writer's atomic on the contact total must have been performed before the sign-off is: a workgroup-scope release emits no
      * wait on this target (two global atomics back to back), so the memory counter is drained explicitly -- still no L2 write-back */
@@ -336,6 +355,16 @@ MSK_DEV void narrowphase_body(const DModel* __restrict__ m, const DState& st, co
     }
   }
   }
+#ifdef MSK_PROFILE_PHASES
+  {
+    const int nb_ = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0 && nb_ < MSK_DBG_NP_BLOCKS / 2) {
+      unsigned long long w = 0ull;
+      for (int k = 1; k < 6; ++k) { unsigned long long d = brt[k] - brt[0]; if (d > 4095ull) d = 4095ull; w |= d << (12 * (k - 1)); }
+      st.dbg[(size_t)m->N * 16 + 64 + MSK_DBG_NP_BLOCKS / 2 + nb_] = (long long)w;
+    }
+  }
+#endif
 }
 
 /* blockIdx.y walks [plane | box-box | hull] blocks of env group blockIdx.x: cfg.nplane / nbox / nhull of them, the
@@ -364,8 +393,11 @@ MSK_DEV void narrowphase_block(const DModel* __restrict__ m, const DState& st, c
   float* s_ws = s_lds;
   float* s_we = s_lds + (64 / NPG) * WS_TOTAL;
   const int e0 = bx * group;
-  int y = by;
   const int fixed_per_group = cfg.nplane + cfg.nbox;
+  /* y: [plane | box-box | hull] as everything below counts; by: the row of the grid, which is also the ORDER OF DISPATCH -- hull rows first, then box-box, plane last.  With one
+   * wavefront per SIMD the 1792 workgroups of 4096 envs queue for 1024 slots, and the longest ones are hull items (GJK / EPA: 40-60 us): behind the plane and box-box rows the last
+   * hull rows of PegInsertionSide started 21-24 us late and ended the launch at 72-75 us, its workgroups lasting 51 at most (round 6, call 23: profiles/r06_launch_position_probe.log) */
+  const int y = (by < cfg.nhull) ? fixed_per_group + by : ((by - cfg.nhull < cfg.nbox) ? cfg.nplane + (by - cfg.nhull) : by - cfg.nhull - cfg.nbox);
   const bool lane_kind = (y >= cfg.nplane) && (y - cfg.nplane < cfg.nbox);   /* box-box, one lane per pair: boxes only */
   /* plane and hull blocks scan hull vertices over and over (support points, features): the template's vertex pool (<= 12 KB) is
    * staged in the part of the LDS image that only the lane-per-pair kind uses, so every scan is an LDS read instead of an L2 hit */
@@ -403,7 +435,6 @@ MSK_DEV void narrowphase_block(const DModel* __restrict__ m, const DState& st, c
   }
 }
 
-#define MSK_DBG_NP_BLOCKS 8192   /* DState::dbg, profiling builds: one word per narrowphase workgroup behind the per-env stamps */
 MSK_DEV void narrowphase_launch_body(const DModel* __restrict__ m, const DState& st, const int group, const NpCfg& cfg) {
 #ifdef MSK_PROFILE_PHASES
   const unsigned long long nrt0 = __builtin_amdgcn_s_memrealtime();   /* the 100 MHz clock: where in the launch this workgroup ran (tools/gpu_phase_probe.py) */
@@ -411,7 +442,7 @@ MSK_DEV void narrowphase_launch_body(const DModel* __restrict__ m, const DState&
   narrowphase_block(m, st, group, cfg, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 #ifdef MSK_PROFILE_PHASES
   const int nb_ = blockIdx.y * gridDim.x + blockIdx.x;
-  if (threadIdx.x == 0 && nb_ < MSK_DBG_NP_BLOCKS)
+  if (threadIdx.x == 0 && nb_ < MSK_DBG_NP_BLOCKS / 2)
     st.dbg[(size_t)m->N * 16 + 64 + nb_] = (long long)(((__builtin_amdgcn_s_memrealtime() & 0xffffffffull) << 32) | (nrt0 & 0xffffffffull));
 #endif
 }

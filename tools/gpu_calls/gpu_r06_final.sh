@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6, the round's evidence on ONE commit: the driver's own commands (pytest -m gpu -x -q, smoke, bench.py --gpus 1 --steps 20 --warmup 5), the default bench line,
-# the bench forms, a same-box A/B against the library of the evidence run before this one (libmsk_base.so = 72d5aae's csrc: before the 256-thread k_dynamics and the broadphase's constants once per wavefront), the phase probes, the vector-env probe and soak,
+# the bench forms, a same-box A/B against the library of the evidence run before this one (libmsk_base.so = 72d5aae's csrc: before this round's launch-position work: the 256-thread k_dynamics, the broadphase's constants once per wavefront, the narrowphase's hull rows dispatched first), the phase probes, the vector-env probe and soak,
 # rocprofv3 kernel statistics and the PMC passes (summarised here: only the summaries travel back), the MFMA question's microbenchmark
 #   gpurun --timeout 3000 -- 'bash tools/gpu_calls/gpu_r06_final.sh'
 R=${GRAFT_REPO_ROOT:-/root/repo}

@@ -5,8 +5,8 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 src = os.path.join(ROOT, "maniskill_amd", "csrc")
-lib = os.path.join(src, "libmsk_prof.so")      # build it where hipcc is (the build container: `make -C maniskill_amd/csrc libmsk_prof.so`); it travels with the snapshot
-if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src) if f.endswith((".h", ".hip"))):
+lib = os.path.join(src, os.environ.get("PROBE_LIB", "libmsk_prof.so"))      # libmsk_prof_nostats.so: the same without the narrowphase's atomic counters (they cost a box-box block ~14 us)      # build it where hipcc is (the build container: `make -C maniskill_amd/csrc libmsk_prof.so`); it travels with the snapshot
+if "PROBE_LIB" not in os.environ and (not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src) if f.endswith((".h", ".hip")))):
     subprocess.check_call(f"make -C {src} libmsk_prof.so", shell=True)
 from maniskill_amd import _native as N
 N.DEFAULT_LIB = lib
@@ -66,8 +66,9 @@ def where_all(tag):
     where_in_the_launch(tag + " k_csolve  ", r, (r[:, 6] - r[:, 0]).astype(np.float64))
     r = o[n * 8 + 64:n * 16 + 64].reshape(n, 8)
     where_in_the_launch(tag + " k_dynamics", r, (r[:, 6] - r[:, 0]).astype(np.float64))
-    # the narrowphase's workgroups (grid: env groups x [plane | box-box | hull] kinds, x fastest): one word each
-    w = o[n * 16 + 64:].astype(np.uint64)
+    # the narrowphase's workgroups (grid: env groups x rows, x fastest; rows in dispatch order: the hull rows (4), the box-box rows (2), the plane row): one word each
+    w = o[n * 16 + 64:n * 16 + 64 + 4096].astype(np.uint64)
+    w2 = o[n * 16 + 64 + 4096:n * 16 + 64 + 8192].astype(np.uint64)      # the workgroup's phases: five 12-bit offsets from its entry, 10 ns units
     ok = np.nonzero(w)[0]
     if len(ok):
         t0 = (w[ok] & np.uint64(0xffffffff)).astype(np.int64); t1 = (w[ok] >> np.uint64(32)).astype(np.int64)
@@ -80,6 +81,11 @@ def where_all(tag):
               f"a workgroup lasts {dur.mean():.1f} us mean / {q(dur, 99):.1f} (99 %) / {dur.max():.1f} max; the last to end: kind row {int(kinds[np.argmax(end)])}, started at {float(start[np.argmax(end)]):.1f} us, lasted {float(dur[np.argmax(end)]):.1f}")
         for k in np.unique(kinds):
             sel = kinds == k
+            ph = np.stack([((w2[ok][sel] >> np.uint64(12 * j)) & np.uint64(4095)).astype(np.float64) / 100.0 for j in range(5)], axis=1)
+            big = dur[sel] > 10
+            if big.any():
+                pm = ph[big].mean(0)
+                print(f"      kind row {int(k)}, the {int(big.sum())} workgroups over 10 us, first pass, mean us from entry: operands fetched {pm[1]:.1f}, contacts computed {pm[2]:.1f}, speculative points filtered {pm[0]:.1f}, old record read + count / total updated {pm[4]:.1f}, slots written {pm[3]:.1f}; whole workgroup {dur[sel][big].mean():.1f}")
             print(f"      kind row {int(k)}: {int(sel.sum())} workgroups, start median {q(start[sel], 50):.1f} / last {start[sel].max():.1f} us, lasts mean {dur[sel].mean():.1f} / 99 % {q(dur[sel], 99):.1f} / max {dur[sel].max():.1f} us, last end {end[sel].max():.1f} us, over 10 us: {int((dur[sel] > 10).sum())}")
 
 
