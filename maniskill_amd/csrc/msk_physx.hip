@@ -944,20 +944,22 @@ static void step_part(msk_ctx* c, const msk_ctx::StepPart& p, hipStream_t s, hip
     LAUNCH_TIMED(ev_np, k_classify, dim3(nblk), dim3(64), 0, s, p.d_model, p.st);
   }
   const int gm = p.solve_workers;
-  if (c->model.G == 16) {
+  if (c->model.G == 16) { /* (the wide class's workers, msk_config.contact_capacity = 1, are the first workgroups of this launch: msk_solve.h) */
     auto k0 = k_csolve<16, 16>;
-    LAUNCH_TIMED(ev_cs, k0, dim3(gm + (N + 3) / 4), dim3(64), c->lds_solve, s, p.d_model, p.st, gm);
+    static const int e_merge = getenv("MSK_WIDE_IN_CSOLVE") ? atoi(getenv("MSK_WIDE_IN_CSOLVE")) : 1;   /* measurement knob: 0 = the launch of its own */
+    const int ww = e_merge ? p.st.wide_workers : 0;
+    LAUNCH_TIMED(ev_cs, k0, dim3(ww + gm + (N + 3) / 4), dim3(64), c->lds_solve, s, p.d_model, p.st, gm, ww);
+    if (!e_merge && p.st.wide_workers > 0) hipLaunchKernelGGL(k_csolve_wide<16>, dim3(p.st.wide_workers), dim3(64), CsWide<16>::TOTAL * sizeof(float), s, p.d_model, p.st);
+    return;
   } else if (c->model.G == 32) {
     auto k0 = k_csolve<32, 32>;
-    LAUNCH_TIMED(ev_cs, k0, dim3(gm + (N + 1) / 2), dim3(64), c->lds_solve, s, p.d_model, p.st, gm);
+    LAUNCH_TIMED(ev_cs, k0, dim3(gm + (N + 1) / 2), dim3(64), c->lds_solve, s, p.d_model, p.st, gm, 0);
   } else {
     auto k0 = k_csolve<64, 64>;
-    LAUNCH_TIMED(ev_cs, k0, dim3(gm + N), dim3(64), c->lds_solve, s, p.d_model, p.st, gm);
+    LAUNCH_TIMED(ev_cs, k0, dim3(gm + N), dim3(64), c->lds_solve, s, p.d_model, p.st, gm, 0);
   }
   if (p.st.wide_workers > 0) { /* msk_config.contact_capacity = 1: the envs of more than MSK_MAX_BLOCKS blocks (msk_solve_wide.h) */
-    const int G = c->model.G;
-    if (G == 16) hipLaunchKernelGGL(k_csolve_wide<16>, dim3(p.st.wide_workers), dim3(64), CsWide<16>::TOTAL * sizeof(float), s, p.d_model, p.st);
-    else if (G == 32) hipLaunchKernelGGL(k_csolve_wide<32>, dim3(p.st.wide_workers), dim3(64), CsWide<32>::TOTAL * sizeof(float), s, p.d_model, p.st);
+    if (c->model.G == 32) hipLaunchKernelGGL(k_csolve_wide<32>, dim3(p.st.wide_workers), dim3(64), CsWide<32>::TOTAL * sizeof(float), s, p.d_model, p.st);
     else hipLaunchKernelGGL(k_csolve_wide<64>, dim3(p.st.wide_workers), dim3(64), CsWide<64>::TOTAL * sizeof(float), s, p.d_model, p.st);
   }
 }

@@ -1036,15 +1036,12 @@ MSK_DEV void csolve_block(const DModel* __restrict__ m, const DState& st, const 
     solve_env<NVP, GL, GL, false>(m, st, st.cls_list, first, count, lds, blk);
   }
 }
-template <int NVP, int GL>
-__global__ void __launch_bounds__(64) k_csolve(const DModel* __restrict__ m, DState st, const int gm) {
-  extern __shared__ __attribute__((aligned(16))) float lds_cs[];
-  csolve_block<NVP, GL>(m, st, gm, blockIdx.x, lds_cs);
-}
-
-/* The wide class (msk_solve_wide.h) is a launch of its own behind k_csolve, issued only for contexts created with
- * msk_config.contact_capacity = 1: two blocks per lane need twice the registers, and inside k_csolve that would halve the occupancy of
- * every other class.  worker w of `workers` takes entries w, w + workers, ... of the class list with its slice of DState::wide_scratch. */
+/* The wide class (msk_solve_wide.h), only for contexts created with msk_config.contact_capacity = 1: worker w of `workers` takes entries
+ * w, w + workers, ... of the class list with its slice of DState::wide_scratch.  Two blocks per lane need twice the registers of the packed
+ * class: with 32 and 64 coordinates that would halve the occupancy of every other class inside k_csolve (AGPRs, scratch), so there it is a
+ * launch of its own behind k_csolve (k_csolve_wide).  With 16 coordinates it fits k_csolve's own budget (242 against 251 VGPRs, 8 against
+ * 22 KB of LDS) and its workers are the FIRST `ww` workgroups of k_csolve's grid: an almost always empty launch per substep less, and when
+ * there are wide envs -- the longest solves of all -- they start first. */
 template <int NVP>
 MSK_DEV void csolve_wide_block(const DModel* __restrict__ m, const DState& st, const int w, float* lds) {
   static_assert(CsWide<NVP>::TOTAL * sizeof(float) <= 48 * 1024, "the wide class's LDS image needs no opt-in");
@@ -1052,6 +1049,15 @@ MSK_DEV void csolve_wide_block(const DModel* __restrict__ m, const DState& st, c
   const int n4 = st.cls_count[MSK_SOLVE_CLASSES - 1];
   for (int i = w; i < n4; i += st.wide_workers)
     solve_env_wide<NVP>(m, st, st.cls_list[(size_t)(MSK_SOLVE_CLASSES - 1) * m->N + i], lds, st.wide_scratch + (size_t)w * CsWide<NVP>::SCRATCH);
+}
+template <int NVP, int GL>
+__global__ void __launch_bounds__(64) k_csolve(const DModel* __restrict__ m, DState st, const int gm, const int ww) {
+  extern __shared__ __attribute__((aligned(16))) float lds_cs[];
+  if constexpr (NVP == 16) {
+    static_assert(CsWide<16>::TOTAL <= CsLds<16, GL, GL>::TOTAL, "the wide class's LDS image fits the launch's");
+    if ((int)blockIdx.x < ww) { csolve_wide_block<NVP>(m, st, blockIdx.x, lds_cs); return; }
+  }
+  csolve_block<NVP, GL>(m, st, gm, (int)blockIdx.x - ww, lds_cs);
 }
 template <int NVP>
 __global__ void __launch_bounds__(64) k_csolve_wide(const DModel* __restrict__ m, DState st) {
