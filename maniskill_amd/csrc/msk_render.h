@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(MSK_RENDER_THREADS) k_render_splat(const DMode
   int* Lcnt = (int*)(Llight + MSK_LIGHT_WORDS);                     /* [ntiles + 1] */
   int* Lfill = Lcnt + ntiles + 1;                                   /* [ntiles] */
   int* Lbig = Lfill + ntiles;                                       /* [MSK_MAX_BIG] */
-  int* Lmisc = Lbig + MSK_MAX_BIG;                                  /* [16]: 0 records, 1 large ones, 2..5 wave sums of a scan */
+  int* Lmisc = Lbig + MSK_MAX_BIG;                                  /* [16]: 0 records, 1 large ones, 2..5 wave sums of a scan, 6 textured records, 7 packed work items, 8 the next segment to draw */
   unsigned short* Lmask = (unsigned short*)(Lmisc + 16);
   unsigned short* Lcover = Lmask + ((ntiles + 1) & ~1);
   unsigned short* Lidx = Lcover + ((ntiles + 1) & ~1);              /* [icap] the tiles' lists: medium records only */
@@ -949,7 +949,14 @@ __global__ void __launch_bounds__(MSK_RENDER_THREADS) k_render_splat(const DMode
 #else
 #define MSK_CUT_IS(k) false
 #endif
-    for (int sg = wave; sg < nseg; sg += MSK_RENDER_THREADS / 64) {
+    /* segments are TAKEN, not dealt: wavefront w used to own segments w, w + 4, ... = every other tile row of one half of the picture, so a robot in the left half made
+     * two wavefronts do the work while two waited at the end of the workgroup; a counter in LDS hands the next segment to whoever is free (which wavefront draws a segment
+     * does not reach the picture: its key buffer is its own and empty again after every segment) */
+    for (;;) {
+      int sg = 0;
+      if (lane == 0) sg = atomicAdd(&Lmisc[8], 1);
+      sg = __builtin_amdgcn_readfirstlane(sg);
+      if (sg >= nseg) break;
       const int ty = sg / segs_x, sx = sg - ty * segs_x;
       if (!MSK_CUT_IS(6) && !MSK_CUT_IS(8)) splat_segment(sg, ty, sx);
       /* my wavefront's atomics above, my wavefront's reads below: LDS operations of one wavefront complete in order */
